@@ -1,0 +1,120 @@
+/*
+ * lws_hip.h -- C ABI of the MI355X-native LWS engine (liblws_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of Jonathan-LeRoux/lws: everything the
+ * reference's Python binding (python/lws.pyx) or its mex gateways (matlab/{batch,online,
+ * nofuture}_lws.cpp) do between "I have a complex T x F spectrogram, weights and a threshold
+ * schedule" and "here is the updated spectrogram".  Plain pointers and sizes only; no C++,
+ * torch or HIP types appear in a signature (a stream is passed as void*).
+ *
+ * Each entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - spectrograms: B independent T x F complex matrices, row-major, bin fastest, frame next
+ *     (numpy C order of a (B,T,F) array; identical memory to MATLAB's F x T column-major).
+ *     F must be odd (non-negative frequencies of an even FFT) -- lws.pyx:223-224.
+ *   - host entry points take/return complex128 (interleaved re,im doubles), exactly the dtype
+ *     the reference returns (lws.pyx:212-213,256); device entry points work in place on
+ *     complex64 (fp32 plans) or complex128 (fp64 plans) device memory.
+ *   - weights: complex128 interleaved, C order [Qp][Q][L+1] as produced by create_weights
+ *     (lws.pyx:160-181): Qp == Q ("summarised") or Qp == 2(F-1) ("general", the reference's
+ *     fractionalQ kernels).  A weight participates iff |w| > 1e-12 (lws.pyx:231-232).
+ *   - thresholds: `iters` doubles, NOT yet scaled; every spectrogram scales them by its own
+ *     mean(|S|) as lws.pyx:240,245 / batch_lws.cpp:119-129 do.
+ *   - every function returns LWS_OK (0) or an error code; lws_last_error() gives the text of the
+ *     calling thread's most recent failure.  Nothing aborts, nothing throws.
+ *   - a plan may be used from one thread at a time; distinct plans are independent.
+ */
+#ifndef LWS_HIP_H_
+#define LWS_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lws_plan lws_plan; /* opaque */
+
+enum {
+    LWS_OK = 0,
+    LWS_ERR_INVALID = 1,     /* bad shape / argument (the ValueErrors of lws.pyx) */
+    LWS_ERR_HIP = 2,         /* a HIP runtime call failed */
+    LWS_ERR_NOMEM = 3,
+    LWS_ERR_UNSUPPORTED = 4  /* valid request this build cannot serve */
+};
+
+/* plan flags */
+enum {
+    LWS_PRECISION_FP32 = 0,        /* default: fp32 state, weights and accumulation */
+    LWS_PRECISION_FP64 = 1,        /* fp64 everywhere (reference arithmetic; slow path only) */
+    LWS_NOFUTURE_Q4_COMPAT = 2,    /* reproduce NoFuture_LWSQ4's addressing (lwslib.cpp:559-594) when Q == Qp == 4 */
+    LWS_FORCE_GENERIC = 4          /* never use the specialised systolic batch kernel */
+};
+
+/* which of the plan's weight tensors a call uses (class lws passes W_ai to nofuture_lws, lws.pyx:475) */
+enum { LWS_W = 0, LWS_W_AI = 1, LWS_W_AF = 2 };
+
+int lws_hip_version(void);                 /* 10000*major + 100*minor + patch */
+const char *lws_last_error(void);
+int lws_device_count(void);                /* GPUs visible to this process, 0 if none */
+
+/* Replaces the per-call weight preparation of lws.pyx:227-232, 280-285, 341-352 and
+ * batch_lws.cpp:78-105: uploads the three weight tensors once.  W_ai / W_af may be NULL if the
+ * online path is not used.  `device` is a HIP device ordinal. */
+int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp,
+                    const double *W, const double *W_ai, const double *W_af, unsigned flags);
+void lws_plan_destroy(lws_plan *plan);
+
+/* lws.batch_lws(S, W, thresholds)            (lws.pyx:209-258; mex batch_lws.cpp:20-154)
+ * S_out may alias S_in.  iters == 0 copies the input (lws.pyx:219-220). */
+int lws_batch_lws(lws_plan *plan, int wsel, const double *S_in, double *S_out, int B, int T,
+                  const double *thresholds, int iters);
+
+/* lws.nofuture_lws(S, W, thresholds)         (lws.pyx:261-311; mex nofuture_lws.cpp:20-157) */
+int lws_nofuture_lws(lws_plan *plan, int wsel, const double *S_in, double *S_out, int B, int T,
+                     const double *thresholds, int iters);
+
+/* lws.online_lws(S, W, W_ai, W_af, thresholds, LA, fshift)
+ *                                            (lws.pyx:314-375; mex online_lws.cpp:21-181;
+ *                                             driver TF_RTISI_LA lwslib.cpp:1424-1492)
+ * qdiv is the reference's Qfloat = N / fshift (only read when update == 1, which no shipped caller
+ * uses; kept for interface fidelity). */
+int lws_online_lws(lws_plan *plan, const double *S_in, double *S_out, int B, int T,
+                   const double *thresholds, int iters, int LA, double qdiv);
+
+/* lws.lws.run_lws(S) = nofuture -> online -> batch (lws.pyx:495-499) without leaving the device.
+ * Between stages the edge-pad frames are refreshed from the current first/last frame exactly as
+ * three separate calls would (each call re-runs extspec, lws.pyx:155-156,235). A stage with
+ * zero iterations is skipped.  Thresholds are per stage. */
+int lws_run_lws(lws_plan *plan, const double *S_in, double *S_out, int B, int T,
+                const double *thr_nofuture, int it_nofuture,
+                const double *thr_online, int it_online, int LA, double qdiv,
+                const double *thr_batch, int it_batch);
+
+/* Device-resident variants: `S_dev` is a device pointer to B*T*F complex64 (fp32 plan) or
+ * complex128 (fp64 plan) values, updated in place; `stream` is a hipStream_t (or NULL).
+ * Work is enqueued on `stream`; the call returns without synchronising unless noted. */
+int lws_batch_lws_dev(lws_plan *plan, int wsel, void *S_dev, int B, int T,
+                      const double *thresholds, int iters, void *stream);
+int lws_nofuture_lws_dev(lws_plan *plan, int wsel, void *S_dev, int B, int T,
+                         const double *thresholds, int iters, void *stream);
+int lws_online_lws_dev(lws_plan *plan, void *S_dev, int B, int T,
+                       const double *thresholds, int iters, int LA, double qdiv, void *stream);
+
+/* Consistency-residual proxy: for each spectrogram b
+ *   out[2b]   = sum over bins of |acc + w00*S|^2   (acc = the LWS weighted sum, w00 = W[0][0][0])
+ *   out[2b+1] = sum over bins of |S|^2
+ * in fp64, on the device buffer `S_dev`.  out is a HOST array of 2*B doubles (synchronises). */
+int lws_residual_dev(lws_plan *plan, const void *S_dev, int B, int T, double *out, void *stream);
+
+/* Timing of the most recent *_dev / host call on this plan, measured with HIP events on the
+ * stream the kernels ran on: total milliseconds spent in the update kernels and the number of
+ * update-kernel launches (prep / extract kernels are not counted). */
+int lws_last_kernel_time(lws_plan *plan, float *ms, int *launches);
+
+/* Name of the update kernel the last call dispatched ("generic_fp32", "systolic_q4", ...). */
+const char *lws_last_kernel_name(lws_plan *plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,209 @@
+"""ctypes binding of liblws_hip.so (include/lws_hip.h).
+
+This is the binding a maintainer of the reference would add next to ``lwslib.pxd``: the Cython
+``cdef extern`` block of python/lwslib.pxd:1-13 is replaced by the ``extern "C"`` prototypes
+below (see INTEGRATION.md for the equivalent .pxd).  The library is mandatory: if it cannot be
+loaded the LWS entry points raise -- there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblws_hip.so")
+
+# lws_hip.h enums
+LWS_OK, LWS_ERR_INVALID, LWS_ERR_HIP, LWS_ERR_NOMEM, LWS_ERR_UNSUPPORTED = range(5)
+LWS_PRECISION_FP32, LWS_PRECISION_FP64, LWS_NOFUTURE_Q4_COMPAT, LWS_FORCE_GENERIC = 0, 1, 2, 4
+LWS_W, LWS_W_AI, LWS_W_AF = 0, 1, 2
+
+EXPORTS = (
+    "lws_hip_version", "lws_last_error", "lws_device_count", "lws_plan_create", "lws_plan_destroy",
+    "lws_batch_lws", "lws_nofuture_lws", "lws_online_lws", "lws_run_lws", "lws_batch_lws_dev",
+    "lws_nofuture_lws_dev", "lws_online_lws_dev", "lws_residual_dev", "lws_last_kernel_time",
+    "lws_last_kernel_name",
+)
+
+_lib = None
+
+
+class LwsHipError(RuntimeError):
+    """A non-OK status from liblws_hip.so that is not an argument error."""
+
+
+def load():
+    """Load liblws_hip.so once and declare its prototypes.  Raises OSError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C lws_amd/csrc` (hipcc, gfx950).  lws_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, ip = C.c_void_p, C.c_int
+    lib.lws_hip_version.restype = C.c_int
+    lib.lws_last_error.restype = C.c_char_p
+    lib.lws_device_count.restype = C.c_int
+    lib.lws_plan_create.argtypes = [C.POINTER(vp), ip, ip, ip, ip, ip, vp, vp, vp, C.c_uint]
+    lib.lws_plan_destroy.argtypes = [vp]
+    lib.lws_plan_destroy.restype = None
+    lib.lws_batch_lws.argtypes = [vp, ip, vp, vp, ip, ip, vp, ip]
+    lib.lws_nofuture_lws.argtypes = [vp, ip, vp, vp, ip, ip, vp, ip]
+    lib.lws_online_lws.argtypes = [vp, vp, vp, ip, ip, vp, ip, ip, C.c_double]
+    lib.lws_run_lws.argtypes = [vp, vp, vp, ip, ip, vp, ip, vp, ip, ip, C.c_double, vp, ip]
+    lib.lws_batch_lws_dev.argtypes = [vp, ip, vp, ip, ip, vp, ip, vp]
+    lib.lws_nofuture_lws_dev.argtypes = [vp, ip, vp, ip, ip, vp, ip, vp]
+    lib.lws_online_lws_dev.argtypes = [vp, vp, ip, ip, vp, ip, ip, C.c_double, vp]
+    lib.lws_residual_dev.argtypes = [vp, vp, ip, ip, vp, vp]
+    lib.lws_last_kernel_time.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.lws_last_kernel_name.argtypes = [vp]
+    lib.lws_last_kernel_name.restype = C.c_char_p
+    for name in EXPORTS:  # fail at load time, not at first use, if a symbol is missing
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map a status code to the exception the reference's Python layer would raise."""
+    if rc == LWS_OK:
+        return
+    msg = load().lws_last_error().decode("utf-8", "replace")
+    if rc == LWS_ERR_INVALID:
+        raise ValueError(msg)  # lws.pyx:224,277,337 raise ValueError for bad shapes
+    if rc == LWS_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise LwsHipError(f"liblws_hip status {rc}: {msg}")
+
+
+def _c128(a):
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    return a
+
+
+class Plan:
+    """Owns an ``lws_plan`` (device copies of W / W_ai / W_af for one (F, L, Q) shape)."""
+
+    def __init__(self, F, W, W_ai=None, W_af=None, device=0, precision="fp32",
+                 nofuture_q4_compat=True, force_generic=False):
+        lib = load()
+        W = _c128(W)
+        if W.ndim != 3:
+            raise ValueError("weights must have shape (Qprime, Q, L+1)")
+        self.Qp, self.Q, self.L = W.shape[0], W.shape[1], W.shape[2] - 1
+        self.F = int(F)
+        self._keep = [W]
+        ptrs = [W.ctypes.data]
+        for other in (W_ai, W_af):
+            if other is None:
+                ptrs.append(None)
+                continue
+            other = _c128(other)
+            if other.shape != W.shape:
+                raise ValueError("W, W_ai and W_af must have the same shape")
+            self._keep.append(other)
+            ptrs.append(other.ctypes.data)
+        flags = 0
+        if precision == "fp64":
+            flags |= LWS_PRECISION_FP64
+        elif precision != "fp32":
+            raise ValueError("precision must be 'fp32' or 'fp64'")
+        if nofuture_q4_compat:
+            flags |= LWS_NOFUTURE_Q4_COMPAT
+        if force_generic:
+            flags |= LWS_FORCE_GENERIC
+        self.precision = precision
+        self.device = int(device)
+        h = C.c_void_p()
+        check(lib.lws_plan_create(C.byref(h), self.device, self.F, self.L, self.Q, self.Qp,
+                                  ptrs[0], ptrs[1], ptrs[2], flags))
+        self._h = h
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lws_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host (numpy complex128) entry points ----
+    def _io(self, S):
+        S = _c128(S)
+        if S.ndim == 2:
+            S3 = S[None]
+        elif S.ndim == 3:
+            S3 = S
+        else:
+            raise ValueError("expected a (T, F) spectrogram or a (B, T, F) stack")
+        if S3.shape[2] != self.F:
+            raise ValueError(f"plan was built for F={self.F} bins, got {S3.shape[2]}")
+        out = np.empty_like(S3)
+        return S, S3, out
+
+    @staticmethod
+    def _thr(thresholds):
+        t = np.ascontiguousarray(thresholds, dtype=np.float64).ravel()
+        return t, (t.ctypes.data if t.size else None)
+
+    def batch(self, S, thresholds, wsel=LWS_W):
+        S, S3, out = self._io(S)
+        t, tp = self._thr(thresholds)
+        check(self._lib.lws_batch_lws(self._h, wsel, S3.ctypes.data, out.ctypes.data, S3.shape[0],
+                                      S3.shape[1], tp, t.size))
+        return out.reshape(S.shape)
+
+    def nofuture(self, S, thresholds, wsel=LWS_W):
+        S, S3, out = self._io(S)
+        t, tp = self._thr(thresholds)
+        check(self._lib.lws_nofuture_lws(self._h, wsel, S3.ctypes.data, out.ctypes.data,
+                                         S3.shape[0], S3.shape[1], tp, t.size))
+        return out.reshape(S.shape)
+
+    def online(self, S, thresholds, LA, qdiv):
+        S, S3, out = self._io(S)
+        t, tp = self._thr(thresholds)
+        check(self._lib.lws_online_lws(self._h, S3.ctypes.data, out.ctypes.data, S3.shape[0],
+                                       S3.shape[1], tp, t.size, int(LA), float(qdiv)))
+        return out.reshape(S.shape)
+
+    def run(self, S, thr_nofuture, thr_online, LA, qdiv, thr_batch):
+        S, S3, out = self._io(S)
+        t0, p0 = self._thr(thr_nofuture)
+        t1, p1 = self._thr(thr_online)
+        t2, p2 = self._thr(thr_batch)
+        check(self._lib.lws_run_lws(self._h, S3.ctypes.data, out.ctypes.data, S3.shape[0], S3.shape[1],
+                                    p0, t0.size, p1, t1.size, int(LA), float(qdiv), p2, t2.size))
+        return out.reshape(S.shape)
+
+    # ---- device-resident entry points (raw pointers: torch tensors pass .data_ptr()) ----
+    def batch_dev(self, ptr, B, T, thresholds, wsel=LWS_W, stream=None):
+        t, tp = self._thr(thresholds)
+        check(self._lib.lws_batch_lws_dev(self._h, wsel, ptr, B, T, tp, t.size, stream))
+
+    def nofuture_dev(self, ptr, B, T, thresholds, wsel=LWS_W, stream=None):
+        t, tp = self._thr(thresholds)
+        check(self._lib.lws_nofuture_lws_dev(self._h, wsel, ptr, B, T, tp, t.size, stream))
+
+    def online_dev(self, ptr, B, T, thresholds, LA, qdiv, stream=None):
+        t, tp = self._thr(thresholds)
+        check(self._lib.lws_online_lws_dev(self._h, ptr, B, T, tp, t.size, int(LA), float(qdiv), stream))
+
+    def residual_dev(self, ptr, B, T, stream=None):
+        out = np.empty((B, 2), dtype=np.float64)
+        check(self._lib.lws_residual_dev(self._h, ptr, B, T, out.ctypes.data, stream))
+        return out
+
+    def last_kernel(self):
+        ms, n = C.c_float(), C.c_int()
+        check(self._lib.lws_last_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return {"ms": ms.value, "launches": n.value,
+                "name": self._lib.lws_last_kernel_name(self._h).decode()}

@@ -1,0 +1,491 @@
+// lws_capi.hip -- the extern "C" boundary declared in include/lws_hip.h: plan management, buffer
+// ownership, dispatch between the generic order-exact kernel and the systolic batch kernel, and
+// HIP-event timing of the update kernels.
+#include "../../include/lws_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lws_common.h"
+#include "lws_systolic.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(LWS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return LWS_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(LWS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return LWS_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct lws_plan {
+    int device = 0;
+    int F = 0, L = 0, Q = 0, Qp = 0;
+    unsigned flags = 0;
+    bool fp64 = false;
+    bool have[3] = {false, false, false};
+    std::vector<double> hostW[3];  // complex128 interleaved copies (eligibility analysis, systolic tables)
+    DevBuf w[3], wflag[3];
+    DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out;
+    lws::SystolicPlan sys;         // device tables of the systolic kernel (empty if not eligible)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_pending = false;
+    float last_ms = 0.f;
+    int last_launches = 0;
+    const char *last_name = "none";
+};
+
+namespace {
+
+template <typename real>
+int upload_weights(lws_plan *p, int which, const double *W) {
+    using C = typename lws::cx<real>::type;
+    const size_t n = (size_t)p->Qp * p->Q * (p->L + 1);
+    std::vector<C> w(n);
+    std::vector<uint8_t> f(n);
+    for (size_t i = 0; i < n; ++i) {
+        const double re = W[2 * i], im = W[2 * i + 1];
+        const bool on = std::hypot(re, im) > 1.0e-12;  // lws.pyx:231-232
+        f[i] = on ? 1 : 0;
+        w[i].x = on ? (real)re : (real)0;
+        w[i].y = on ? (real)im : (real)0;
+    }
+    int rc = p->w[which].ensure(n * sizeof(C));
+    if (rc) return rc;
+    rc = p->wflag[which].ensure(n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(p->w[which].p, w.data(), n * sizeof(C), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->wflag[which].p, f.data(), n, hipMemcpyHostToDevice));
+    p->hostW[which].assign(W, W + 2 * n);
+    p->have[which] = true;
+    return LWS_OK;
+}
+
+template <typename real>
+lws::WeightSet<real> wset(const lws_plan *p, int which) {
+    lws::WeightSet<real> s;
+    s.w = static_cast<const typename lws::cx<real>::type *>(p->w[which].p);
+    s.flag = static_cast<const uint8_t *>(p->wflag[which].p);
+    return s;
+}
+
+int check_common(const lws_plan *p, int B, int T, const double *thr, int iters) {
+    if (!p) return fail(LWS_ERR_INVALID, "null plan");
+    if (B < 0 || T < 1) return fail(LWS_ERR_INVALID, "need B >= 0 and T >= 1 (got B=%d T=%d)", B, T);
+    if (iters < 0) return fail(LWS_ERR_INVALID, "negative iteration count");
+    if (iters > 0 && !thr) return fail(LWS_ERR_INVALID, "null threshold array");
+    return LWS_OK;
+}
+
+// ---- scratch management -------------------------------------------------------------------
+template <typename real>
+int ensure_scratch(lws_plan *p, int B, int T, int n_thr) {
+    using C = typename lws::cx<real>::type;
+    const size_t Np = p->F + 2 * p->L, Tp = T + 2 * (p->Q - 1);
+    int rc;
+    if ((rc = p->state.ensure((size_t)B * Tp * Np * sizeof(C)))) return rc;
+    if ((rc = p->amp.ensure((size_t)B * Tp * Np * sizeof(real)))) return rc;
+    if ((rc = p->row_sums.ensure((size_t)B * T * sizeof(double)))) return rc;
+    if ((rc = p->mean_amp.ensure((size_t)B * sizeof(double)))) return rc;
+    if ((rc = p->thr_host_copy.ensure((size_t)(n_thr > 0 ? n_thr : 1) * sizeof(double)))) return rc;
+    if ((rc = p->thr_scaled.ensure((size_t)B * (n_thr > 0 ? n_thr : 1) * sizeof(real)))) return rc;
+    return LWS_OK;
+}
+
+void begin_timing(lws_plan *p, hipStream_t s) {
+    (void)hipEventRecord(p->ev0, s);
+    p->last_launches = 0;
+}
+void end_timing(lws_plan *p, hipStream_t s) {
+    (void)hipEventRecord(p->ev1, s);
+    p->timing_pending = true;
+}
+
+// One stage on the extended device buffers: thresholds -> scaled table -> update kernel.
+//   mode: lws::Mode.  Assumes state/amp/mean_amp are current.
+template <typename real>
+int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, int iters, int LA,
+              double qdiv, hipStream_t s) {
+    using C = typename lws::cx<real>::type;
+    if (iters <= 0) return LWS_OK;
+    HIP_TRY(hipMemcpyAsync(p->thr_host_copy.p, thr, sizeof(double) * iters, hipMemcpyHostToDevice, s));
+    HIP_TRY(lws::launch_scale_thresholds<real>(static_cast<const double *>(p->thr_host_copy.p),
+                                              static_cast<const double *>(p->mean_amp.p),
+                                              static_cast<real *>(p->thr_scaled.p), B, iters, s));
+    if (mode == lws::MODE_NOFUTURE && (p->flags & LWS_NOFUTURE_Q4_COMPAT) && p->Q == 4 && p->Qp == 4)
+        mode = lws::MODE_NOFUTURE_Q4_COMPAT;
+
+    // the systolic kernel serves batch sweeps of plans it was built for (fp32, summarised weights
+    // with the twiddle structure of create_weights, supported shape); everything else is generic.
+    if (!p->fp64 && mode == lws::MODE_BATCH && !(p->flags & LWS_FORCE_GENERIC) &&
+        lws::systolic_supports(p->sys, wsel, T)) {
+        int launches = 0;
+        hipError_t e = lws::launch_systolic(p->sys, wsel, static_cast<float2 *>(p->state.p),
+                                            static_cast<const float *>(p->amp.p),
+                                            static_cast<const float *>(p->thr_scaled.p), B, T, iters,
+                                            s, &launches, p->ev0, p->ev1);
+        p->timing_pending = true;
+        if (e != hipSuccess) return fail(LWS_ERR_HIP, "systolic launch failed: %s", hipGetErrorString(e));
+        p->last_launches = launches;
+        p->last_name = lws::systolic_name(p->sys);
+        return LWS_OK;
+    }
+
+    lws::GenericArgs<real> a;
+    a.state = static_cast<C *>(p->state.p);
+    a.amp = static_cast<const real *>(p->amp.p);
+    a.thr = static_cast<const real *>(p->thr_scaled.p);
+    for (int i = 0; i < 3; ++i) a.w[i] = wset<real>(p, p->have[i] ? i : 0);
+    a.wsel = wsel;
+    a.F = p->F; a.T = T; a.L = p->L; a.Q = p->Q; a.Qp = p->Qp;
+    a.n_thr = iters;
+    a.LA = LA;
+    a.update = 2;  // both shipped callers pass 2 (lws.pyx:363, online_lws.cpp:160)
+    a.qdiv = (real)qdiv;
+    a.mode = mode;
+    a.group = 1;
+    begin_timing(p, s);
+    hipError_t e = lws::launch_generic<real>(a, B, s);
+    end_timing(p, s);
+    if (e != hipSuccess) return fail(LWS_ERR_HIP, "generic launch failed: %s", hipGetErrorString(e));
+    p->last_launches = 1;
+    p->last_name = p->fp64 ? "generic_fp64" : "generic_fp32";
+    return LWS_OK;
+}
+
+struct StageSpec {
+    int mode, wsel;
+    const double *thr;
+    int iters;
+    int LA;
+    double qdiv;
+};
+
+// prep -> stages (with pad refresh in between) -> extract, for either host (double2) or device
+// (float2 / double2, in place) spectrogram buffers.
+template <typename real, typename io_cx>
+int run_pipeline(lws_plan *p, const io_cx *in_dev, io_cx *out_dev, const io_cx *orig_dev, int B,
+                 int T, const StageSpec *stages, int nstages, hipStream_t s) {
+    using C = typename lws::cx<real>::type;
+    int max_it = 1;
+    for (int i = 0; i < nstages; ++i)
+        if (stages[i].iters > max_it) max_it = stages[i].iters;
+    int rc = ensure_scratch<real>(p, B, T, max_it);
+    if (rc) return rc;
+    HIP_TRY((lws::launch_prep<real, io_cx>(in_dev, static_cast<C *>(p->state.p),
+                                           static_cast<real *>(p->amp.p),
+                                           static_cast<double *>(p->row_sums.p),
+                                           static_cast<double *>(p->mean_amp.p), B, T, p->F, p->L,
+                                           p->Q, s)));
+    bool dirty = false;
+    for (int i = 0; i < nstages; ++i) {
+        if (stages[i].iters <= 0) continue;  // "return S" of lws.pyx:219-220 / 272-273 / 332-333
+        if (dirty)
+            HIP_TRY(lws::launch_refresh<real>(static_cast<C *>(p->state.p),
+                                              static_cast<real *>(p->amp.p),
+                                              static_cast<double *>(p->row_sums.p),
+                                              static_cast<double *>(p->mean_amp.p), B, T, p->F,
+                                              p->L, p->Q, s));
+        rc = run_stage<real>(p, stages[i].mode, stages[i].wsel, B, T, stages[i].thr, stages[i].iters,
+                             stages[i].LA, stages[i].qdiv, s);
+        if (rc) return rc;
+        dirty = true;
+    }
+    HIP_TRY((lws::launch_extract<real, io_cx>(static_cast<const C *>(p->state.p), out_dev, orig_dev, B,
+                                              T, p->F, p->L, p->Q, s)));
+    return LWS_OK;
+}
+
+int need_weights(const lws_plan *p, const StageSpec *st, int n) {
+    for (int i = 0; i < n; ++i) {
+        if (st[i].iters <= 0) continue;
+        if (st[i].mode == lws::MODE_ONLINE) {
+            if (!(p->have[0] && p->have[1] && p->have[2]))
+                return fail(LWS_ERR_INVALID, "online LWS needs W, W_ai and W_af in the plan");
+        } else {
+            if (st[i].wsel < 0 || st[i].wsel > 2 || !p->have[st[i].wsel])
+                return fail(LWS_ERR_INVALID, "weight tensor %d is not part of this plan", st[i].wsel);
+        }
+    }
+    return LWS_OK;
+}
+
+// host complex128 in/out
+int run_host(lws_plan *p, const double *S_in, double *S_out, int B, int T, const StageSpec *st, int n) {
+    if (!S_in || !S_out) return fail(LWS_ERR_INVALID, "null spectrogram pointer");
+    int rc = need_weights(p, st, n);
+    if (rc) return rc;
+    const size_t count = (size_t)B * T * p->F;
+    bool any = false;
+    for (int i = 0; i < n; ++i) any |= st[i].iters > 0;
+    if (!any || B == 0) {
+        if (S_out != S_in) memcpy(S_out, S_in, count * 2 * sizeof(double));
+        return LWS_OK;
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    if ((rc = p->stage.ensure(count * sizeof(double2)))) return rc;
+    hipStream_t s = nullptr;
+    HIP_TRY(hipMemcpyAsync(p->stage.p, S_in, count * sizeof(double2), hipMemcpyHostToDevice, s));
+    double2 *io = static_cast<double2 *>(p->stage.p);
+    if (p->fp64) rc = run_pipeline<double, double2>(p, io, io, io, B, T, st, n, s);
+    else rc = run_pipeline<float, double2>(p, io, io, io, B, T, st, n, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(S_out, p->stage.p, count * sizeof(double2), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LWS_OK;
+}
+
+// device in place: complex64 for fp32 plans, complex128 for fp64 plans
+int run_dev(lws_plan *p, void *S_dev, int B, int T, const StageSpec *st, int n, void *stream) {
+    if (!S_dev) return fail(LWS_ERR_INVALID, "null device pointer");
+    int rc = need_weights(p, st, n);
+    if (rc) return rc;
+    bool any = false;
+    for (int i = 0; i < n; ++i) any |= st[i].iters > 0;
+    if (!any || B == 0) return LWS_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p->fp64) {
+        double2 *io = static_cast<double2 *>(S_dev);
+        return run_pipeline<double, double2>(p, io, io, io, B, T, st, n, s);
+    }
+    float2 *io = static_cast<float2 *>(S_dev);
+    return run_pipeline<float, float2>(p, io, io, io, B, T, st, n, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lws_hip_version(void) { return 100; }  // 0.1.0
+
+const char *lws_last_error(void) { return g_err.c_str(); }
+
+int lws_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, const double *W,
+                    const double *W_ai, const double *W_af, unsigned flags) {
+    if (!plan) return fail(LWS_ERR_INVALID, "null plan pointer");
+    *plan = nullptr;
+    if (F < 3 || (F % 2) == 0)
+        return fail(LWS_ERR_INVALID,
+                    "Please only include non-negative frequencies in the input spectrogram. (F=%d must be odd)", F);
+    if (L < 1 || Q < 1) return fail(LWS_ERR_INVALID, "need L >= 1 and Q >= 1 (got L=%d Q=%d)", L, Q);
+    if (L > F - 2) return fail(LWS_ERR_INVALID, "L=%d is too large for F=%d bins", L, F);
+    if (Qp != Q && Qp != 2 * (F - 1))
+        return fail(LWS_ERR_INVALID,
+                    "weight tensor has %d rows; expected Q=%d (summarised) or N=2(F-1)=%d (general)", Qp, Q,
+                    2 * (F - 1));
+    if (!W) return fail(LWS_ERR_INVALID, "null weight tensor");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(LWS_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    lws_plan *p = new (std::nothrow) lws_plan();
+    if (!p) return fail(LWS_ERR_NOMEM, "out of host memory");
+    p->device = device;
+    p->F = F; p->L = L; p->Q = Q; p->Qp = Qp;
+    p->flags = flags;
+    p->fp64 = (flags & LWS_PRECISION_FP64) != 0;
+    int rc = LWS_OK;
+    const double *src[3] = {W, W_ai, W_af};
+    for (int i = 0; i < 3 && rc == LWS_OK; ++i) {
+        if (!src[i]) continue;
+        rc = p->fp64 ? upload_weights<double>(p, i, src[i]) : upload_weights<float>(p, i, src[i]);
+    }
+    if (rc == LWS_OK) {
+        if (hipEventCreate(&p->ev0) != hipSuccess || hipEventCreate(&p->ev1) != hipSuccess)
+            rc = fail(LWS_ERR_HIP, "hipEventCreate failed");
+    }
+    if (rc == LWS_OK && !p->fp64 && !(flags & LWS_FORCE_GENERIC)) {
+        const double *hw[3] = {p->have[0] ? p->hostW[0].data() : nullptr,
+                               p->have[1] ? p->hostW[1].data() : nullptr,
+                               p->have[2] ? p->hostW[2].data() : nullptr};
+        hipError_t e = lws::systolic_build(p->sys, F, L, Q, Qp, hw);
+        if (e != hipSuccess) rc = fail(LWS_ERR_HIP, "systolic table upload failed: %s", hipGetErrorString(e));
+    }
+    if (rc != LWS_OK) {
+        lws_plan_destroy(p);
+        return rc;
+    }
+    *plan = p;
+    return LWS_OK;
+}
+
+void lws_plan_destroy(lws_plan *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (int i = 0; i < 3; ++i) { p->w[i].release(); p->wflag[i].release(); }
+    p->state.release(); p->amp.release(); p->row_sums.release(); p->mean_amp.release();
+    p->thr_host_copy.release(); p->thr_scaled.release(); p->stage.release();
+    p->resid_rows.release(); p->resid_out.release();
+    lws::systolic_release(p->sys);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    delete p;
+}
+
+int lws_batch_lws(lws_plan *p, int wsel, const double *S_in, double *S_out, int B, int T,
+                  const double *thresholds, int iters) {
+    int rc = check_common(p, B, T, thresholds, iters);
+    if (rc) return rc;
+    StageSpec st{lws::MODE_BATCH, wsel, thresholds, iters, 0, (double)p->Q};
+    return run_host(p, S_in, S_out, B, T, &st, 1);
+}
+
+int lws_nofuture_lws(lws_plan *p, int wsel, const double *S_in, double *S_out, int B, int T,
+                     const double *thresholds, int iters) {
+    int rc = check_common(p, B, T, thresholds, iters);
+    if (rc) return rc;
+    StageSpec st{lws::MODE_NOFUTURE, wsel, thresholds, iters, 0, (double)p->Q};
+    return run_host(p, S_in, S_out, B, T, &st, 1);
+}
+
+int lws_online_lws(lws_plan *p, const double *S_in, double *S_out, int B, int T,
+                   const double *thresholds, int iters, int LA, double qdiv) {
+    int rc = check_common(p, B, T, thresholds, iters);
+    if (rc) return rc;
+    if (LA < 0) return fail(LWS_ERR_INVALID, "negative look-ahead");
+    StageSpec st{lws::MODE_ONLINE, 0, thresholds, iters, LA, qdiv};
+    return run_host(p, S_in, S_out, B, T, &st, 1);
+}
+
+int lws_run_lws(lws_plan *p, const double *S_in, double *S_out, int B, int T,
+                const double *thr_nofuture, int it_nofuture, const double *thr_online, int it_online,
+                int LA, double qdiv, const double *thr_batch, int it_batch) {
+    int rc = check_common(p, B, T, thr_nofuture, it_nofuture);
+    if (!rc) rc = check_common(p, B, T, thr_online, it_online);
+    if (!rc) rc = check_common(p, B, T, thr_batch, it_batch);
+    if (rc) return rc;
+    if (LA < 0) return fail(LWS_ERR_INVALID, "negative look-ahead");
+    StageSpec st[3] = {{lws::MODE_NOFUTURE, LWS_W_AI, thr_nofuture, it_nofuture, 0, (double)p->Q},
+                       {lws::MODE_ONLINE, 0, thr_online, it_online, LA, qdiv},
+                       {lws::MODE_BATCH, LWS_W, thr_batch, it_batch, 0, (double)p->Q}};
+    return run_host(p, S_in, S_out, B, T, st, 3);
+}
+
+int lws_batch_lws_dev(lws_plan *p, int wsel, void *S_dev, int B, int T, const double *thresholds,
+                      int iters, void *stream) {
+    int rc = check_common(p, B, T, thresholds, iters);
+    if (rc) return rc;
+    StageSpec st{lws::MODE_BATCH, wsel, thresholds, iters, 0, (double)p->Q};
+    return run_dev(p, S_dev, B, T, &st, 1, stream);
+}
+
+int lws_nofuture_lws_dev(lws_plan *p, int wsel, void *S_dev, int B, int T, const double *thresholds,
+                         int iters, void *stream) {
+    int rc = check_common(p, B, T, thresholds, iters);
+    if (rc) return rc;
+    StageSpec st{lws::MODE_NOFUTURE, wsel, thresholds, iters, 0, (double)p->Q};
+    return run_dev(p, S_dev, B, T, &st, 1, stream);
+}
+
+int lws_online_lws_dev(lws_plan *p, void *S_dev, int B, int T, const double *thresholds, int iters,
+                       int LA, double qdiv, void *stream) {
+    int rc = check_common(p, B, T, thresholds, iters);
+    if (rc) return rc;
+    if (LA < 0) return fail(LWS_ERR_INVALID, "negative look-ahead");
+    StageSpec st{lws::MODE_ONLINE, 0, thresholds, iters, LA, qdiv};
+    return run_dev(p, S_dev, B, T, &st, 1, stream);
+}
+
+int lws_residual_dev(lws_plan *p, const void *S_dev, int B, int T, double *out, void *stream) {
+    if (!p || !S_dev || !out) return fail(LWS_ERR_INVALID, "null argument");
+    if (B <= 0 || T < 1) return fail(LWS_ERR_INVALID, "need B >= 1 and T >= 1");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
+    if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
+    if (p->fp64) {
+        if ((rc = ensure_scratch<double>(p, B, T, 1))) return rc;
+        const double2 *in = static_cast<const double2 *>(S_dev);
+        HIP_TRY((lws::launch_prep<double, double2>(in, static_cast<double2 *>(p->state.p),
+                                                   static_cast<double *>(p->amp.p),
+                                                   static_cast<double *>(p->row_sums.p),
+                                                   static_cast<double *>(p->mean_amp.p), B, T, p->F,
+                                                   p->L, p->Q, s)));
+        HIP_TRY(lws::launch_residual<double>(static_cast<const double2 *>(p->state.p), wset<double>(p, 0),
+                                             static_cast<double *>(p->resid_rows.p),
+                                             static_cast<double *>(p->resid_out.p), B, T, p->F, p->L,
+                                             p->Q, p->Qp, s));
+    } else {
+        if ((rc = ensure_scratch<float>(p, B, T, 1))) return rc;
+        const float2 *in = static_cast<const float2 *>(S_dev);
+        HIP_TRY((lws::launch_prep<float, float2>(in, static_cast<float2 *>(p->state.p),
+                                                 static_cast<float *>(p->amp.p),
+                                                 static_cast<double *>(p->row_sums.p),
+                                                 static_cast<double *>(p->mean_amp.p), B, T, p->F, p->L,
+                                                 p->Q, s)));
+        HIP_TRY(lws::launch_residual<float>(static_cast<const float2 *>(p->state.p), wset<float>(p, 0),
+                                            static_cast<double *>(p->resid_rows.p),
+                                            static_cast<double *>(p->resid_out.p), B, T, p->F, p->L,
+                                            p->Q, p->Qp, s));
+    }
+    HIP_TRY(hipMemcpyAsync(out, p->resid_out.p, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LWS_OK;
+}
+
+int lws_last_kernel_time(lws_plan *p, float *ms, int *launches) {
+    if (!p) return fail(LWS_ERR_INVALID, "null plan");
+    if (p->timing_pending) {
+        HIP_TRY(hipEventSynchronize(p->ev1));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, p->ev0, p->ev1));
+        p->last_ms = t;
+        p->timing_pending = false;
+    }
+    if (ms) *ms = p->last_ms;
+    if (launches) *launches = p->last_launches;
+    return LWS_OK;
+}
+
+const char *lws_last_kernel_name(lws_plan *p) { return p ? p->last_name : "none"; }
+
+}  // extern "C"

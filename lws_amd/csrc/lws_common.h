@@ -1,0 +1,73 @@
+// lws_common.h -- internal declarations shared by the HIP translation units of liblws_hip.so.
+// Not part of the public ABI (that is include/lws_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lws {
+
+template <typename real> struct cx;
+template <> struct cx<float>  { using type = float2; };
+template <> struct cx<double> { using type = double2; };
+
+// What a sweep does, in the reference's terms.
+//   BATCH    : LWSQ2/LWSQ4/LWSanyQ/LWSfractionalQ            (lwslib.cpp:72-467)
+//   NOFUTURE : NoFuture_LWS{Q2,anyQ,fractionalQ}              (lwslib.cpp:473-535,620-764)
+//   NOFUTURE_Q4_COMPAT : NoFuture_LWSQ4 with its flat-offset addressing (lwslib.cpp:538-617)
+//   ONLINE   : TF_RTISI_LA and the Asym_UpdatePhase* calls it makes (lwslib.cpp:776-1492)
+enum Mode { MODE_BATCH = 0, MODE_NOFUTURE = 1, MODE_NOFUTURE_Q4_COMPAT = 2, MODE_ONLINE = 3 };
+
+// Device weights of one weight tensor: [Qp][Q][L+1], entries with |w| <= 1e-12 have flag 0.
+template <typename real> struct WeightSet {
+    const typename cx<real>::type *w;
+    const uint8_t *flag;
+};
+
+// Arguments of the order-exact generic wavefront kernel (lws_generic.hip).
+template <typename real> struct GenericArgs {
+    typename cx<real>::type *state;  // [B][Tp][Np] extended spectrograms (the reference's ExtSr/ExtSi)
+    const real *amp;                 // [B][Tp][Np] target magnitudes (AmpSpec)
+    const real *thr;                 // [B][n_thr]  thresholds already scaled by mean|S| of each spectrogram
+    WeightSet<real> w[3];            // LWS_W, LWS_W_AI, LWS_W_AF
+    int wsel;                        // weight tensor used by batch / no-future sweeps
+    int F, T, L, Q, Qp;
+    int n_thr;                       // sweeps (batch / no-future) or iterations per frame (online)
+    int LA;                          // look-ahead (online)
+    int update;                      // 1: add S/qdiv to the centre sum (dead in shipped callers), 2: do not
+    real qdiv;
+    int mode;
+    int group;                       // max sweeps in flight (batch / no-future)
+};
+
+template <typename real>
+hipError_t launch_generic(const GenericArgs<real> &a, int B, hipStream_t stream);
+
+// ---- prep / extract (lws_generic.hip) ----
+// in: [B][T][F] complex (double2 or float2).  Builds the extended buffer, |.|, per-spectrogram
+// mean|S| and the scaled threshold table.  row_sums: scratch [B][T] doubles.
+template <typename real, typename in_cx>
+hipError_t launch_prep(const in_cx *in, typename cx<real>::type *state, real *amp,
+                       double *row_sums, double *mean_amp, int B, int T, int F, int L, int Q,
+                       hipStream_t stream);
+template <typename real>
+hipError_t launch_scale_thresholds(const double *thr, const double *mean_amp, real *out, int B,
+                                   int n, hipStream_t stream);
+// Re-creates the edge-pad frames from the current first / last frame (what a fresh extspec()
+// call would do, lws.pyx:155-156) and recomputes |.| and mean|S| from the current state.
+template <typename real>
+hipError_t launch_refresh(typename cx<real>::type *state, real *amp, double *row_sums,
+                          double *mean_amp, int B, int T, int F, int L, int Q, hipStream_t stream);
+// out: [B][T][F]; if `orig` is non-null, bins whose state still equals the rounded original are
+// returned as the original value (never-updated bins stay bit-identical).
+template <typename real, typename out_cx>
+hipError_t launch_extract(const typename cx<real>::type *state, out_cx *out, const out_cx *orig,
+                          int B, int T, int F, int L, int Q, hipStream_t stream);
+
+// rows: scratch [B][T][2] doubles; out: device [B][2] doubles.
+template <typename real>
+hipError_t launch_residual(const typename cx<real>::type *state, WeightSet<real> ws, double *rows,
+                           double *out, int B, int T, int F, int L, int Q, int Qp,
+                           hipStream_t stream);
+
+}  // namespace lws

@@ -1,0 +1,28 @@
+// lws_systolic.h -- interface of the systolic batch-LWS kernel (lws_systolic.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lws {
+
+struct SystolicPlan {
+    bool ok[3] = {false, false, false};  // per weight tensor: kernel applicable
+    int F = 0, L = 0, Q = 0;
+    void *tables[3] = {nullptr, nullptr, nullptr};  // device weight tables
+    void *sk_state = nullptr, *sk_amp = nullptr;    // skewed-layout scratch
+    size_t sk_state_cap = 0, sk_amp_cap = 0;
+    const char *name = "systolic";
+};
+
+// Analyse the (host, complex128 interleaved) weight tensors and upload tables for the ones the
+// kernel can serve.  Never fails for "not applicable"; only for HIP errors.
+hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3]);
+void systolic_release(SystolicPlan &sp);
+bool systolic_supports(const SystolicPlan &sp, int wsel, int T);
+const char *systolic_name(const SystolicPlan &sp);
+// Runs `iters` batch sweeps on the extended buffers (reference layout), in place.
+// ev0/ev1 (may be null) are recorded around the update kernel(s) only.
+hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp,
+                           const float *thr, int B, int T, int iters, hipStream_t stream,
+                           int *launches, hipEvent_t ev0, hipEvent_t ev1);
+
+}  // namespace lws

@@ -1,0 +1,403 @@
+"""Python surface of the reference's ``lws`` module (python/lws.pyx, v1.2.8) on the MI355X engine.
+
+Same names, arguments, defaults, return dtypes and error behaviour as the reference; the three LWS
+entry points ``batch_lws`` / ``nofuture_lws`` / ``online_lws`` (lws.pyx:209-375) and the methods of
+``class lws`` call the HIP engine through the C ABI (include/lws_hip.h) instead of the CPU kernels of
+lwslib.cpp.  Everything else in this file is host-side setup (windows, weights, STFT for evaluation):
+one-off numpy work that feeds the kernels, restated here so the package is self-contained.
+
+Extensions that do not change 2-D behaviour: the LWS entry points also accept a ``(B, T, F)`` stack of
+independent spectrograms, and ``class lws`` takes ``device=`` / ``precision=`` / ``nofuture_q4_compat=``.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _capi
+
+__version__ = "1.2.8"  # version of the interface mirrored
+
+
+# --------------------------------------------------------------------------------------------
+# windows (lws.pyx:10-40)
+# --------------------------------------------------------------------------------------------
+def hann(n, symmetric=True, use_offset=False):
+    """Hann window of length n (lws.pyx:10-19)."""
+    if symmetric:
+        phase = (2.0 * np.arange(n) + 1.0) / (2.0 * n)  # sample points at the half-integers
+    else:
+        phase = (np.arange(n) + (1 if use_offset else 0)) / float(n)
+    return 0.5 * (1.0 - np.cos(2.0 * np.pi * phase))
+
+
+def synthwin(awin, fshift, swin=None):
+    """Synthesis window normalised for perfect reconstruction (lws.pyx:22-40)."""
+    fsize = len(awin)
+    Q = int(math.ceil(float(fsize) / float(fshift)))
+    if swin is None:
+        swin = awin
+    prod = np.zeros(Q * fshift)
+    prod[:fsize] = np.asarray(awin) * np.asarray(swin)
+    overlap = prod.reshape(Q, fshift).sum(axis=0)  # sum of the shifted window products
+    norm = np.tile(overlap, Q)[:fsize]
+    if norm.min() <= 0:
+        raise ValueError('The normalizer is not strictly positive')
+    return swin / norm
+
+
+# --------------------------------------------------------------------------------------------
+# STFT / iSTFT / consistency (lws.pyx:43-144) -- evaluation helpers, host numpy
+# --------------------------------------------------------------------------------------------
+def _perfectrec_prepad(fsize, fshift):
+    rem = fsize % fshift
+    return fsize - fshift if rem == 0 else fsize - rem
+
+
+def stft(x, fsize, fshift, awin, fftsize=None, perfectrec=False):
+    """STFT with a fixed frame shift; returns (frames, fftsize//2+1) complex128 (lws.pyx:43-90)."""
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError('We only deal with single channel signals here')
+    if fftsize is None:
+        fftsize = fsize
+    if fftsize % 2 == 1:
+        raise ValueError('Odd ffts not supported.')
+    x = x.astype(np.float64, copy=False) if not np.iscomplexobj(x) else x
+    if perfectrec is True:
+        pre = _perfectrec_prepad(fsize, fshift)
+        post = (-len(x)) % fshift
+        x = np.concatenate([np.zeros(pre), x, np.zeros(post)])
+        M = len(x) // fshift
+    else:
+        post = (-(len(x) - fsize)) % fshift
+        x = np.concatenate([x, np.zeros(post)])
+        M = (len(x) - fsize) // fshift + 1
+    need = (M - 1) * fshift + fsize
+    if need > len(x):
+        x = np.concatenate([x, np.zeros(need - len(x))])
+    idx = fshift * np.arange(M)[:, None] + np.arange(fsize)[None, :]
+    frames = x[idx] * np.asarray(awin)[None, :]
+    spec = np.fft.fft(frames, n=fftsize, axis=1)[:, : fftsize // 2 + 1]
+    return spec.astype(np.complex128)
+
+
+def istft(spec, fshift, swin, awin=None, fftsize=None, perfectrec=False):
+    """Inverse STFT by weighted overlap-add (lws.pyx:93-137)."""
+    spec = np.asarray(spec)
+    if spec.ndim != 2:
+        raise ValueError('We only deal with single channel signals here')
+    M, N = spec.shape
+    if N % 2 != 1:
+        raise ValueError('We expect the spectrogram to only have non-negative frequencies')
+    fsize = 2 * (N - 1)
+    if awin is not None:
+        swin = synthwin(awin, fshift, swin=swin)
+    if fftsize is None:
+        fftsize = fsize
+    swin = np.asarray(swin, dtype=np.float64)
+    if fftsize > len(swin):
+        swin = np.concatenate([swin, np.zeros(fftsize - len(swin))])
+    full = np.concatenate([spec, np.conjugate(spec[:, -2:0:-1])], axis=1)  # Hermitian completion
+    frames = np.real(np.fft.ifft(full, n=fftsize, axis=1))[:, :fsize] * np.squeeze(swin)[None, :fsize]
+    signal = np.zeros(fshift * (M - 1) + fsize)
+    for s in range(M):
+        signal[fshift * s: fshift * s + fsize] += frames[s]
+    if perfectrec is True:
+        signal = signal[_perfectrec_prepad(fsize, fshift):(fshift - fsize)]
+    return signal
+
+
+def get_consistency(S, fsize, fshift, awin, swin, perfectrec=False):
+    """20 log10(|S| / |stft(istft(S)) - S|) in dB (lws.pyx:140-144)."""
+    back = stft(istft(S, fshift, swin, perfectrec=perfectrec), fsize, fshift, awin, perfectrec=perfectrec)
+    return 20 * np.log10(np.linalg.norm(S) / np.linalg.norm(back - S))
+
+
+def extspec(S, L, Q):
+    """Extended spectrogram: L Hermitian columns each side, Q-1 repeated frames each end (lws.pyx:146-157)."""
+    S = np.asarray(S)
+    T, F = S.shape
+    E = np.zeros((T + 2 * (Q - 1), F + 2 * L), dtype=S.dtype)
+    E[Q - 1:Q - 1 + T, L:L + F] = S
+    for j in range(1, L + 1):
+        E[:, L - j] = np.conjugate(E[:, L + j])
+        E[:, F + L - 1 + j] = np.conjugate(E[:, F + L - 1 - j])
+    E[:Q - 1] = E[Q - 1]
+    E[Q - 1 + T:] = E[Q - 2 + T]
+    return E
+
+
+# --------------------------------------------------------------------------------------------
+# weights (lws.pyx:160-206)
+# --------------------------------------------------------------------------------------------
+def create_weights(awin, swin, fshift, L, use_summarized_weights=True):
+    """Complex LWS weights, shape (Qprime, Q, L+1) (lws.pyx:160-181).
+
+    W[p, q, l] = exp(2j*pi*p*q/Qf) * exp(-2j*pi*l*q/Qf) * sum_t awin[t]*swin[t+q*fshift]/T * exp(-2j*pi*l*t/T)
+    with 1 subtracted from the (q=0, l=0) term; Qf = T/fshift; Qprime = Q when the shift divides the
+    window and summarised weights are requested, else T.
+    """
+    awin = np.asarray(awin, dtype=np.float64)
+    swin = np.asarray(swin, dtype=np.float64)
+    T = len(awin)
+    Q = int(math.ceil(float(T) / float(fshift)))
+    Qf = float(T) / float(fshift)
+    Qprime = Q if (T % fshift == 0 and use_summarized_weights) else T
+    lag = np.arange(L + 1)[:, None]
+    prod = np.zeros((T, Q))
+    for q in range(Q):
+        n = T - q * fshift
+        prod[:n, q] = awin[:n] * swin[q * fshift:q * fshift + n] / T
+    base = np.exp(-2j * np.pi * lag * np.arange(T)[None, :] / T).dot(prod)      # (L+1, Q)
+    base = base * np.exp(-2j * np.pi * lag * np.arange(Q)[None, :] / Qf)
+    base[0, 0] -= 1
+    twiddle = np.exp(2j * np.pi * np.arange(Qprime)[:, None] * np.arange(Q)[None, :] / Qf)  # (Qprime, Q)
+    W = base[:, None, :] * twiddle[None, :, :]                                  # (L+1, Qprime, Q)
+    return np.ascontiguousarray(W.transpose(1, 2, 0))
+
+
+def build_asymmetric_windows(awin_swin, fshift):
+    """Mirrored envelopes of RTISI-LA from the analysis*synthesis product (lws.pyx:184-200)."""
+    awin_swin = np.asarray(awin_swin, dtype=np.float64)
+    T = len(awin_swin)
+    Q = int(math.ceil(float(T) / float(fshift)))
+    shifted = np.zeros((T, Q))
+    for q in range(Q):
+        n = T - q * fshift
+        shifted[:n, q] = awin_swin[q * fshift:q * fshift + n]
+    win_ai = shifted[:, 1:].sum(axis=1)[::-1]
+    win_af = shifted.sum(axis=1)[::-1]
+    if T % fshift == 2:  # kept verbatim from lws.pyx:198 (the MATLAB binding tests Q == 2 instead)
+        win_ai = awin_swin
+    return win_ai, win_af
+
+
+def get_thresholds(iterations, alpha, beta, gamma):
+    """alpha * exp(-beta * i**gamma), i = 0..iterations-1 (lws.pyx:203-206)."""
+    return alpha * np.exp(-beta * np.arange(iterations) ** gamma)
+
+
+# --------------------------------------------------------------------------------------------
+# the hot path (lws.pyx:209-375) -> HIP engine
+# --------------------------------------------------------------------------------------------
+_PLAN_DEFAULTS = {"device": 0, "precision": "fp32", "nofuture_q4_compat": True, "force_generic": False}
+
+
+def _prepare(S, W, use_simplifications, n_extra_w=()):
+    """Argument handling shared by the three wrappers (lws.pyx:212-224)."""
+    S = np.asarray(S)
+    if S.dtype != np.complex128:
+        S = S.astype(np.complex128)
+    W = np.asarray(W)
+    Qp, Q = W.shape[0], W.shape[1]
+    F = S.shape[-1]
+    return S, W, Qp, Q, F
+
+
+def _check(S, W, Qp, Q, F, use_simplifications):
+    if F % 2 == 0:
+        raise ValueError('Please only include non-negative frequencies in the input spectrogram.')
+    if Qp != Q and Qp != 2 * (F - 1):
+        raise ValueError('Weights have %d rows: expected Q=%d (summarized) or N=%d (general).' % (Qp, Q, 2 * (F - 1)))
+    if Qp == Q and not use_simplifications:
+        # the reference would index a Q-row tensor with the bin number here (undefined behaviour)
+        raise ValueError('use_simplifications=False needs general weights '
+                         '(create_weights(..., use_summarized_weights=False)).')
+
+
+def batch_lws(S, W, thresholds, use_simplifications=True, **plan_kw):
+    """Batch LWS (lws.pyx:209-258): ``len(thresholds)`` in-place Gauss-Seidel sweeps."""
+    S, W, Qp, Q, F = _prepare(S, W, use_simplifications)
+    if len(thresholds) == 0:
+        return S
+    _check(S, W, Qp, Q, F, use_simplifications)
+    plan = _capi.Plan(F, W, **{**_PLAN_DEFAULTS, **plan_kw})
+    try:
+        return plan.batch(S, thresholds)
+    finally:
+        plan.close()
+
+
+def nofuture_lws(S, W, thresholds, use_simplifications=True, **plan_kw):
+    """LWS using past frames only (lws.pyx:261-311); for Q == 4 the default reproduces the
+    reference's NoFuture_LWSQ4 addressing (pass ``nofuture_q4_compat=False`` for the anyQ semantics)."""
+    S, W, Qp, Q, F = _prepare(S, W, use_simplifications)
+    if len(thresholds) == 0:
+        return S
+    _check(S, W, Qp, Q, F, use_simplifications)
+    plan = _capi.Plan(F, W, **{**_PLAN_DEFAULTS, **plan_kw})
+    try:
+        return plan.nofuture(S, thresholds)
+    finally:
+        plan.close()
+
+
+def online_lws(S, W, W_ai, W_af, thresholds, LA, fshift, use_simplifications=True, **plan_kw):
+    """Online LWS / TF-RTISI-LA (lws.pyx:314-375)."""
+    thresholds = np.asarray(thresholds, dtype=np.float64)
+    if thresholds.ndim != 1:
+        raise ValueError('Buffer has wrong number of dimensions (expected 1, got %d)' % thresholds.ndim)
+    S, W, Qp, Q, F = _prepare(S, W, use_simplifications)
+    if len(thresholds) == 0:
+        return S
+    _check(S, W, Qp, Q, F, use_simplifications)
+    qdiv = float(2 * (F - 1) / int(fshift))  # lws.pyx:339
+    plan = _capi.Plan(F, W, W_ai, W_af, **{**_PLAN_DEFAULTS, **plan_kw})
+    try:
+        return plan.online(S, thresholds, int(LA), qdiv)
+    finally:
+        plan.close()
+
+
+class lws(object):
+    """Configuration object of the reference (lws.pyx:378-499), same keyword arguments."""
+
+    def __init__(self, awin_or_fsize, fshift, L=5, swin=None, look_ahead=3,
+                 nofuture_iterations=0, nofuture_alpha=1, nofuture_beta=0.1, nofuture_gamma=1,
+                 online_iterations=0, online_alpha=1, online_beta=0.1, online_gamma=1,
+                 batch_iterations=100, batch_alpha=100, batch_beta=0.1, batch_gamma=1,
+                 symmetric_win=True, mode=None, fftsize=None, perfectrec=True, use_simplifications=True,
+                 device=0, precision="fp32", nofuture_q4_compat=True, force_generic=False):
+        if isinstance(awin_or_fsize, (int, np.integer)):
+            awin = np.sqrt(hann(int(awin_or_fsize), symmetric=symmetric_win, use_offset=False))
+            awin = np.sqrt(awin * synthwin(awin, fshift))
+        else:
+            awin = np.asarray(awin_or_fsize)
+        if awin.ndim > 1:
+            # lws.pyx:391 compares a shape tuple with an int (TypeError on Python 3); the intent is clear
+            if awin.ndim > 2 or min(awin.shape) > 1:
+                raise ValueError('The analysis window should be flat')
+            awin = awin.flatten()
+        if fftsize is None:
+            fftsize = len(awin)
+        if fftsize > len(awin):
+            if (fftsize - len(awin)) % 2 != 0:
+                raise ValueError('The zero-padding should add even length to the original window.')
+            pad_length = (fftsize - len(awin)) // 2
+            print('Zero-padding symmetrically around the original windows.\n'
+                  'WARNING: for code simplicity, a consequence is that the first/last '
+                  '{} samples of the signal will not be '.format(pad_length) +
+                  'in the perfect reconstruction region.')
+            pad = np.zeros(pad_length)
+            awin = np.hstack((pad, awin, pad))
+            if swin is not None:
+                swin = np.hstack((pad, swin, pad))
+        self.awin = awin
+        if swin is not None:
+            print('Provided synthesis window is renormalized for perfect reconstruction.')
+        self.swin = synthwin(awin, fshift, swin=swin)
+        self.fshift = fshift
+        self.fsize = len(awin)
+        self.perfectrec = perfectrec
+        self.L = L
+        self.Q = int(self.fsize / self.fshift) if self.fsize % self.fshift == 0 else self.fsize / self.fshift
+        self.use_simplifications = use_simplifications
+        self.W = create_weights(self.awin, self.swin, self.fshift, self.L,
+                                use_summarized_weights=self.use_simplifications)
+        self.win_ai, self.win_af = build_asymmetric_windows(self.awin * self.swin, self.fshift)
+        self.W_ai = create_weights(self.win_ai, self.swin, self.fshift, self.L,
+                                   use_summarized_weights=self.use_simplifications)
+        self.W_af = create_weights(self.win_af, self.swin, self.fshift, self.L,
+                                   use_summarized_weights=self.use_simplifications)
+        self.look_ahead = look_ahead
+        if mode == 'speech':
+            nofuture_iterations = 0
+            online_iterations = 0
+        elif mode == 'music':
+            nofuture_iterations = 1
+            online_iterations = 10
+        self.batch_iterations = batch_iterations
+        self.batch_alpha = batch_alpha
+        self.batch_beta = batch_beta
+        self.batch_gamma = batch_gamma
+        self.online_iterations = online_iterations
+        self.online_alpha = online_alpha
+        self.online_beta = online_beta
+        self.online_gamma = online_gamma
+        self.nofuture_iterations = nofuture_iterations
+        self.nofuture_alpha = nofuture_alpha
+        self.nofuture_beta = nofuture_beta
+        self.nofuture_gamma = nofuture_gamma
+        if not np.allclose(awin, awin[::-1]):
+            print('WARNING: It appears you are using an analysis window that is not symmetric.\n'
+                  'The current code uses simplifications that rely on such symmetry, so the code may not behave properly.')
+        self._plan_kw = dict(device=device, precision=precision, nofuture_q4_compat=nofuture_q4_compat,
+                             force_generic=force_generic)
+        self._plan = None
+
+    # -- engine plumbing (not part of the reference surface) --
+    def plan(self):
+        """The cached device plan holding W, W_ai, W_af for this configuration."""
+        if self._plan is None:
+            self._plan = _capi.Plan(self.fsize // 2 + 1, self.W, self.W_ai, self.W_af, **self._plan_kw)
+        return self._plan
+
+    def _qdiv(self):
+        return float(self.fsize / self.fshift)
+
+    def _as_c128(self, S):
+        S = np.asarray(S)
+        return S if S.dtype == np.complex128 else S.astype(np.complex128)
+
+    def _check(self, S):
+        F = S.shape[-1]
+        if F % 2 == 0:
+            raise ValueError('Please only include non-negative frequencies in the input spectrogram.')
+        if F != self.fsize // 2 + 1:
+            raise ValueError('This lws object works on %d-bin spectrograms, got %d.' % (self.fsize // 2 + 1, F))
+
+    # -- reference surface --
+    def get_consistency(self, S):
+        return get_consistency(S, self.fsize, self.fshift, self.awin, self.swin, perfectrec=self.perfectrec)
+
+    def stft(self, S):
+        return stft(S, self.fsize, self.fshift, self.awin, perfectrec=self.perfectrec)
+
+    def istft(self, S):
+        return istft(S, self.fshift, self.swin, perfectrec=self.perfectrec)
+
+    def nofuture_lws(self, S, iterations=None, thresholds=None):
+        if iterations is None:
+            iterations = self.nofuture_iterations
+        if thresholds is None:
+            thresholds = get_thresholds(iterations, self.nofuture_alpha, self.nofuture_beta, self.nofuture_gamma)
+        S = self._as_c128(S)
+        if len(thresholds) == 0:
+            return S
+        self._check(S)
+        return self.plan().nofuture(S, thresholds, wsel=_capi.LWS_W_AI)  # W_ai on purpose: lws.pyx:475
+
+    def online_lws(self, S, iterations=None, thresholds=None):
+        if iterations is None:
+            iterations = self.online_iterations
+        if thresholds is None:
+            thresholds = get_thresholds(iterations, self.online_alpha, self.online_beta, self.online_gamma)
+        S = self._as_c128(S)
+        if len(thresholds) == 0:
+            return S
+        self._check(S)
+        return self.plan().online(S, thresholds, self.look_ahead, self._qdiv())
+
+    def batch_lws(self, S, iterations=None, thresholds=None):
+        if iterations is None:
+            iterations = self.batch_iterations
+        if thresholds is None:
+            thresholds = get_thresholds(iterations, self.batch_alpha, self.batch_beta, self.batch_gamma)
+        S = self._as_c128(S)
+        if len(thresholds) == 0:
+            return S
+        self._check(S)
+        return self.plan().batch(S, thresholds)
+
+    def run_lws(self, S):
+        """nofuture -> online -> batch (lws.pyx:495-499) as one device-resident pipeline."""
+        S = self._as_c128(S)
+        t0 = get_thresholds(self.nofuture_iterations, self.nofuture_alpha, self.nofuture_beta, self.nofuture_gamma)
+        t1 = get_thresholds(self.online_iterations, self.online_alpha, self.online_beta, self.online_gamma)
+        t2 = get_thresholds(self.batch_iterations, self.batch_alpha, self.batch_beta, self.batch_gamma)
+        if len(t0) + len(t1) + len(t2) == 0:
+            return S
+        self._check(S)
+        return self.plan().run(S, t0, t1, self.look_ahead, self._qdiv(), t2)

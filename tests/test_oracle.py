@@ -1,0 +1,163 @@
+"""CPU: pins the fp64 C restatement (oracle/lws_oracle.c) against the reference.
+
+Sources of truth: (a) golden vectors generated from the reference (tests/golden/make_golden.py),
+(b) oracle/_ref/liblws_ref.so = the reference's lwslib.cpp compiled in place (skipped if absent).
+Tolerance: the restatement re-associates fp64 sums (one canonical kernel instead of the reference's
+Q2/Q4 specialisations), and a bin whose weighted sum nearly cancels amplifies that by 1/|acc|; the
+reference's own Q2/Q4 kernels differ from its anyQ kernels by up to 1e-9 in the same way
+(SURVEY.md fact 2), so multi-sweep comparisons use 1e-9 absolute, single sweeps 1e-11.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle.oracle import M0_ALL, FLAVOUR_NOFUTURE_Q4_COMPAT
+
+ATOL_SWEEP = 1e-11
+ATOL_MULTI = 1e-9
+
+
+def _cases(g):
+    for ci in range(int(g["ncases"])):
+        tag = f"c{ci}"
+        fsize, fshift, Q, T, F, L = [int(v) for v in g[f"{tag}_meta"]]
+        yield tag, Q, T, F, L
+
+
+def _fresh(oracle, S, L, Q):
+    er, ei = oracle.extend(S, L, Q)
+    return er, ei, np.abs(er + 1j * ei)
+
+
+def test_extend_matches_reference_extspec(oracle):
+    g = load_golden("helpers.npz")
+    er, ei = oracle.extend(g["ext_in"], 2, 3)
+    assert np.array_equal(er + 1j * ei, g["ext_L2_Q3"])
+
+
+def test_single_sweeps_all_families(oracle):
+    g = load_golden("sweeps.npz")
+    n = 0
+    for tag, Q, T, F, L in _cases(g):
+        S, W, W_ai, W_af = g[f"{tag}_S"], g[f"{tag}_W"], g[f"{tag}_W_ai"], g[f"{tag}_W_af"]
+        sets = {"W": W, "W_ai": W_ai, "W_af": W_af}
+        for ti, thr in enumerate(g[f"{tag}_thr"]):
+            er, ei, amp = _fresh(oracle, S, L, Q)
+            oracle.sweep(er, ei, W, amp, F, T, L, Q, thr)
+            assert np.abs(er + 1j * ei - g[f"{tag}_t{ti}_batch_any"]).max() < ATOL_SWEEP
+            if f"{tag}_t{ti}_batch_q" in g:  # LWSQ2 / LWSQ4 are the same kernel re-associated
+                assert np.abs(er + 1j * ei - g[f"{tag}_t{ti}_batch_q"]).max() < 1e-9
+            for wname in ("W", "W_ai"):
+                er, ei, amp = _fresh(oracle, S, L, Q)
+                oracle.sweep(er, ei, sets[wname], amp, F, T, L, Q, thr, M0=0)
+                assert np.abs(er + 1j * ei - g[f"{tag}_t{ti}_nofut_any_{wname}"]).max() < ATOL_SWEEP
+                key = f"{tag}_t{ti}_nofut_q_{wname}"
+                if key in g and Q == 2:  # NoFuture_LWSQ2 == anyQ
+                    assert np.abs(er + 1j * ei - g[key]).max() < 1e-9
+                if key in g and Q == 4:  # NoFuture_LWSQ4: the shipped addressing defect, reproduced
+                    er, ei, amp = _fresh(oracle, S, L, Q)
+                    oracle.sweep(er, ei, sets[wname], amp, F, T, L, Q, thr, flavour=FLAVOUR_NOFUTURE_Q4_COMPAT)
+                    assert np.abs(er + 1j * ei - g[key]).max() < 1e-9
+            for ai, (row0, M, M0, wi) in enumerate(g[f"{tag}_asym_shapes"]):
+                for upd in (2, 1):
+                    key = f"{tag}_t{ti}_asym{ai}_u{upd}"
+                    if key not in g:
+                        continue
+                    er, ei, amp = _fresh(oracle, S, L, Q)
+                    oracle.sweep(er, ei, [W, W_ai, W_af][wi], amp, F, int(M), L, Q, thr, M0=int(M0),
+                                 update=upd, row0=int(row0))
+                    assert np.abs(er + 1j * ei - g[key]).max() < ATOL_SWEEP, key
+                    n += 1
+    assert n > 20
+
+
+def test_infinite_threshold_is_identity(oracle):
+    g = load_golden("sweeps.npz")
+    for tag, Q, T, F, L in _cases(g):
+        er, ei, amp = _fresh(oracle, g[f"{tag}_S"], L, Q)
+        e0 = er + 1j * ei
+        oracle.sweep(er, ei, g[f"{tag}_W"], amp, F, T, L, Q, 1e30)
+        assert np.array_equal(er + 1j * ei, e0)
+
+
+@pytest.mark.parametrize("tag", ["64_16", "64_32", "64_8", "48_16"])
+def test_wrappers(oracle, tag):
+    g = load_golden("wrappers.npz")
+    h = load_golden("helpers.npz")
+    S, thr = g[f"S_{tag}"], g[f"thr_{tag}"]
+    W, W_ai, W_af = h[f"W_{tag}"], h[f"W_ai_{tag}"], h[f"W_af_{tag}"]
+    fshift = int(tag.split("_")[1])
+    assert np.abs(oracle.batch_lws(S, W, thr) - g[f"batch_{tag}"]).max() < ATOL_MULTI
+    assert np.abs(oracle.batch_lws(np.abs(S), W, thr) - g[f"batch_mag_{tag}"]).max() < ATOL_MULTI
+    assert np.abs(oracle.nofuture_lws(S, W_ai, thr[:2]) - g[f"nofuture_{tag}"]).max() < ATOL_MULTI
+    assert np.abs(oracle.online_lws(S, W, W_ai, W_af, thr[:3], 3, fshift) - g[f"online_{tag}"]).max() < ATOL_MULTI
+    assert np.abs(oracle.online_lws(S, W, W_ai, W_af, thr[:3], 0, fshift) - g[f"online_la0_{tag}"]).max() < ATOL_MULTI
+    assert np.abs(oracle.online_lws(S, W, W_ai, W_af, thr[:2], 5, fshift) - g[f"online_la5_{tag}"]).max() < ATOL_MULTI
+    # class lws(mode='music', batch_iterations=12, batch_alpha=3).run_lws(|S|): 1 no-future, 10 online, 12 batch
+    M = np.abs(S)
+    t_nf = 1.0 * np.exp(-0.1 * np.arange(1))
+    t_on = 1.0 * np.exp(-0.1 * np.arange(10))
+    t_b = 3.0 * np.exp(-0.1 * np.arange(12))
+    s0 = oracle.nofuture_lws(M, W_ai, t_nf)
+    assert np.abs(s0 - g[f"run_nofuture_{tag}"]).max() < ATOL_MULTI
+    s1 = oracle.online_lws(s0, W, W_ai, W_af, t_on, 3, fshift)
+    assert np.abs(s1 - g[f"run_online_{tag}"]).max() < 1e-8
+    s2 = oracle.batch_lws(s1, W, t_b)
+    assert np.abs(s2 - g[f"run_{tag}"]).max() < 1e-8
+    # default thresholds 100*exp(-0.1 i), 10 iterations: nothing is above threshold
+    t_noop = 100.0 * np.exp(-0.1 * np.arange(10))
+    assert np.array_equal(oracle.batch_lws(M, W, t_noop), M.astype(np.complex128))
+    assert np.array_equal(g[f"default_noop_{tag}"], M.astype(np.complex128))
+
+
+def test_even_bin_count_is_rejected(oracle):
+    h = load_golden("helpers.npz")
+    with pytest.raises(ValueError):
+        oracle.batch_lws(np.ones((8, 32), complex), h["W_64_16"], [0.0])
+
+
+def test_zero_iterations_returns_input(oracle):
+    h = load_golden("helpers.npz")
+    S = np.arange(33 * 5, dtype=float).reshape(5, 33) + 0j
+    assert np.array_equal(oracle.batch_lws(S, h["W_64_16"], []), S)
+
+
+@pytest.mark.parametrize("tag", ["32_8", "32_12"])
+def test_general_weights_periodic_row(oracle, tag):
+    """fractionalQ kernels: reference pinned with a periodically extended weight tensor."""
+    g = load_golden("general_weights.npz")
+    fsize, fshift, T, F, Q, L, LA = [int(v) for v in g[f"meta_{tag}"]]
+    S, thr = g[f"S_{tag}"], float(g[f"thr_{tag}"][0])
+    W, W_ai, W_af = g[f"W_{tag}"], g[f"W_ai_{tag}"], g[f"W_af_{tag}"]
+    er, ei, amp = _fresh(oracle, S, L, Q)
+    oracle.sweep(er, ei, W, amp, F, T, L, Q, thr)
+    oracle.sweep(er, ei, W, amp, F, T, L, Q, 0.0)
+    assert np.abs(er + 1j * ei - g[f"batch_{tag}"]).max() < ATOL_MULTI
+    er, ei, _ = _fresh(oracle, S, L, Q)
+    oracle.sweep(er, ei, W_ai, amp, F, T, L, Q, thr, M0=0)
+    assert np.abs(er + 1j * ei - g[f"nofuture_{tag}"]).max() < ATOL_MULTI
+    # online through the wrapper: thresholds are scaled by mean|S| inside, so undo that
+    mean = np.mean(np.abs(S))
+    out = oracle.online_lws(S, W, W_ai, W_af, np.array([thr, 0.5 * thr]) / mean, LA, fshift)
+    ref = g[f"online_{tag}"][Q - 1:Q - 1 + T, L:L + F]
+    assert np.abs(out - ref).max() < ATOL_MULTI
+
+
+def test_against_compiled_reference_live(oracle, reflib):
+    """Random shapes straight against the reference's kernels (only where /root/reference was built)."""
+    h = load_golden("helpers.npz")
+    rng = np.random.default_rng(7)
+    for tag, Q in (("64_16", 4), ("64_32", 2), ("64_8", 8), ("48_16", 3)):
+        F = int(tag.split("_")[0]) // 2 + 1
+        W = h[f"W_{tag}"]
+        L = W.shape[2] - 1
+        for T in (5, 11):
+            S = rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))
+            thr = 0.5
+            er, ei = reflib.extend(S, L, Q)
+            amp = np.ascontiguousarray(np.abs(er + 1j * ei))
+            oer, oei = er.copy(), ei.copy()
+            for _ in range(3):
+                reflib.call("LWSanyQ", er, ei, W, amp, F, T, L, Q, thr)
+                oracle.sweep(oer, oei, W, amp, F, T, L, Q, thr, M0=M0_ALL)
+            assert np.abs(er - oer).max() < ATOL_MULTI and np.abs(ei - oei).max() < ATOL_MULTI
