@@ -157,7 +157,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     // the systolic kernel serves batch sweeps of plans it was built for (fp32, summarised weights
     // with the twiddle structure of create_weights, supported shape); everything else is generic.
     if (!p->fp64 && mode == lws::MODE_BATCH && !(p->flags & LWS_FORCE_GENERIC) &&
-        lws::systolic_supports(p->sys, wsel, T)) {
+        iters <= lws::SYSTOLIC_MAX_ITERS && lws::systolic_supports(p->sys, wsel, T)) {
         int launches = 0;
         hipError_t e = lws::launch_systolic(p->sys, wsel, static_cast<float2 *>(p->state.p),
                                             static_cast<const float *>(p->amp.p),

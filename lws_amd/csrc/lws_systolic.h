@@ -4,6 +4,8 @@
 
 namespace lws {
 
+constexpr int SYSTOLIC_MAX_ITERS = 440;  // thresholds of one call live in LDS
+
 struct SystolicPlan {
     bool ok[3] = {false, false, false};  // per weight tensor: kernel applicable
     int F = 0, L = 0, Q = 0;

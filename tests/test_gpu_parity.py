@@ -125,6 +125,9 @@ def test_fp32_wrappers_vs_oracle(tag, force_generic, oracle):
     mean = np.mean(np.abs(S))
     plan = _capi.Plan(F, W, W_ai, W_af, force_generic=force_generic)
     check_fp32(plan.batch(S, thr), g[f"batch_{tag}"], mean)
+    name = plan.last_kernel()["name"]
+    # Q in {2,4} with create_weights' structure and F-1 a multiple of 8 -> systolic kernel unless forced
+    assert name.startswith("systolic") == ((not force_generic) and tag in ("64_16", "64_32")), name
     check_fp32(plan.nofuture(S, thr[:2], wsel=_capi.LWS_W_AI), g[f"nofuture_{tag}"], mean)
     check_fp32(plan.online(S, thr[:3], 3, 2 * (F - 1) / fshift), g[f"online_{tag}"], mean)
     plan.close()
@@ -238,11 +241,26 @@ def test_config_scale_against_oracle_and_fingerprint(oracle):
     assert np.abs(np.abs(out) - M).max() < 1e-6 * M.max()
     c_out, c_ref = p.get_consistency(out), float(fp["consistency_out"])
     assert abs(c_out - c_ref) < 0.05, (c_out, c_ref)
-    # dense variant (all bins active every sweep): 20 sweeps
-    out_d = p.batch_lws(M, thresholds=np.zeros(20))
-    d = np.abs(out_d.ravel()[::97] - fp["sample_dense20"])
-    assert np.linalg.norm(d) / np.linalg.norm(fp["sample_dense20"]) < 1e-3
-    assert abs(p.get_consistency(out_d) - float(fp["consistency_dense20"])) < 0.05
+    assert p.plan().last_kernel()["name"].startswith("systolic_q4")
+    # the same through the generic engine
+    pg = lws_amd.lws(1024, 256, force_generic=True)
+    outg = pg.run_lws(M)
+    assert pg.plan().last_kernel()["name"] == "generic_fp32"
+    assert rel_l2(outg, ref) < 1e-3 and np.median(np.abs(outg - ref)) < 1e-6 * mean
+    # dense variant (all 20 thresholds 0, every bin updated from a zero-phase start).  This start is
+    # ill-conditioned: with all phases equal the weighted sums nearly cancel, so rounding differences are
+    # amplified by 1/|acc| and trajectories of individual bins diverge (fp64 GPU vs fp64 CPU already differ
+    # by 7e-8 here, fp32 by O(0.1) on a minority of bins) while the solution quality is identical.  The
+    # schedule is therefore pinned in fp64, and fp32 by the consistency it reaches and magnitude preservation.
+    p64 = lws_amd.lws(1024, 256, precision="fp64")
+    out64 = p64.batch_lws(M, thresholds=np.zeros(20))
+    d = np.abs(out64.ravel()[::97] - fp["sample_dense20"])
+    assert np.linalg.norm(d) / np.linalg.norm(fp["sample_dense20"]) < 1e-5
+    for eng in (p, pg):
+        out_d = eng.batch_lws(M, thresholds=np.zeros(20))
+        assert abs(eng.get_consistency(out_d) - float(fp["consistency_dense20"])) < 0.05
+        assert np.abs(np.abs(out_d) - M).max() < 1e-6 * M.max()
+        assert np.median(np.abs(out_d.ravel()[::97] - fp["sample_dense20"])) < 1e-3 * mean
 
 
 def test_config1_shape_noop_and_ten_iterations(oracle):
