@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblws_hip.so")
+LIB_PATH = os.environ.get("LWS_HIP_LIB", os.path.join(_HERE, "liblws_hip.so"))  # override: kernel-variant experiments
 
 # lws_hip.h enums
 LWS_OK, LWS_ERR_INVALID, LWS_ERR_HIP, LWS_ERR_NOMEM, LWS_ERR_UNSUPPORTED = range(5)

@@ -1,8 +1,8 @@
 // lws_systolic.hip -- the fast path for batch LWS (LWSQ2 / LWSQ4 / LWSanyQ, lwslib.cpp:72-373) on
 // gfx950: an order-exact *systolic* re-statement of the in-place Gauss-Seidel sweep.
 //
-// One workgroup (8 compute waves + 1 service wave) owns one spectrogram and keeps I = 8 consecutive
-// sweeps in flight.  A lane is a (sweep, frame) processor that marches along the bins of its frame,
+// One workgroup (7 compute waves + 1 service wave = 2 waves per SIMD) owns one spectrogram and keeps
+// I = 7 consecutive sweeps in flight.  A lane is a (sweep, frame) processor that marches along the bins of its frame,
 // one bin per step; the 64 lanes of compute wave i work on 64 consecutive frames of sweep
 // "iteration g*I + i", frame m trailing frame m-1 by SKEW = 8 bins, and sweep j+1 trailing sweep j
 // by LAG = 32 steps:
@@ -21,8 +21,8 @@
 // i.e. a value is addressed by WHEN it was produced, not by where it lives in the spectrogram, and a
 // reader's address is  lane_base + ((t + const) mod 32)*512  with a compile-time `const` per stencil
 // tap (the step loop is unrolled by 8 so that the bin phase -- and with it bin % Q, the twiddle of
-// the weights and the ring slot -- is static).  HBM is touched once per 8 sweeps: the service wave
-// streams the spectrogram in (set 0) ahead of wave 0, wave 7 streams it out, both through a
+// the weights and the ring slot -- is static).  HBM is touched once per I sweeps: the service wave
+// streams the spectrogram in (set 0) ahead of wave 0, the last wave streams it out, both through a
 // time-skewed global layout  state_w[(8m + c) mod G][m mod 64]  in which every access of a wave is
 // 64 consecutive elements.
 //
@@ -48,16 +48,28 @@ namespace {
 
 constexpr int LANES = 64;
 constexpr int RING = 32;
-constexpr int SLOT_BYTES = LANES * 8;                    // one ring slot: 64 float2
+// ring entry of production time nu, lane l:  set + ((nu >> 1) & 15) * PAIR_BYTES + l * 16 + (nu & 1) * 8
+// -- two consecutive times of one lane share a 16-byte cell, so a reader fetches two adjacent taps with one
+// ds_read_b128 (which, unlike ds_read_b64, reaches the LDS peak rate at 1-2 waves per SIMD)
+constexpr int SLOT_BYTES = LANES * 8;                    // bytes per production time (64 float2)
+constexpr int PAIR_BYTES = 2 * SLOT_BYTES;               // two consecutive times x 64 lanes
+constexpr int BLK_BYTES = 8 * SLOT_BYTES;                // one block of 8 steps
+constexpr int LANE_B = 16;
 constexpr int SET_BYTES = RING * SLOT_BYTES;             // 16 KiB
-constexpr int NSLOTS = 8;                                // sweeps in flight (compute waves)
+#ifndef LWS_NSLOTS
+#define LWS_NSLOTS 7
+#endif
+#ifndef LWS_PF
+#define LWS_PF 8
+#endif
+constexpr int NSLOTS = LWS_NSLOTS;                       // sweeps in flight (compute waves)
 constexpr int NSETS = NSLOTS + 1;
 constexpr int NYQ_OFF = NSETS * SET_BYTES;               // Nyquist values: [set][lane] float2
 constexpr int THR_OFF = NYQ_OFF + NSETS * SLOT_BYTES;    // effective thresholds: floats
 constexpr int MAX_ITERS = 440;
 constexpr int META_OFF = THR_OFF + MAX_ITERS * 4;        // n_eff
 constexpr int LDS_BYTES = META_OFF + 16;
-constexpr int SKEW = 8, ROWP = SKEW * LANES, LAG = 32, PF = 8;
+constexpr int SKEW = 8, ROWP = SKEW * LANES, LAG = 32, PF = LWS_PF;  // PF: global prefetch distance (4 or 8 steps)
 constexpr int NTHREADS = LANES * (NSLOTS + 1);
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
@@ -72,10 +84,11 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
 // Where a stencil tap is found.  off: production time relative to the reader's clock (already
 // includes -LAG for "old" values); set_new: ring set of the reader's own sweep (1) or of the
 // previous sweep (0).
-enum { K_RING = 0, K_NYQ = 1, K_SELF = 2 };
+enum { K_RING = 0, K_NYQ = 1, K_SELF = 2, K_NEXT = 3 };  // K_SELF / K_NEXT: previous-sweep value of the own bin c / c+1 (prefetched registers)
 struct Src { int kind, set_new, off, conj; };
 
 __host__ __device__ constexpr Src src_normal(int dr, int dk) {
+    if (dr == 0 && dk == 1) return Src{K_NEXT, 0, 0, 0};
     const bool is_new = dr < 0 || (dr == 0 && dk < 0);
     return Src{K_RING, is_new ? 1 : 0, SKEW * dr + dk - (is_new ? 0 : LAG), 0};
 }
@@ -84,6 +97,7 @@ __host__ __device__ constexpr Src src_start(int P, int dr, int dk) {
     const int cm = -(P + dk);            // mirrored bin, 1..L
     const int off0 = SKEW * dr + cm - P;
     if (dr == 0 && cm == P) return Src{K_SELF, 0, 0, 1};
+    if (dr == 0 && cm == P + 1) return Src{K_NEXT, 0, 0, 1};
     const bool is_new = dr < 0 || (dr == 0 && cm < P);
     return Src{K_RING, is_new ? 1 : 0, off0 - (is_new ? 0 : LAG), 1};
 }
@@ -94,6 +108,7 @@ __host__ __device__ constexpr Src src_end(int P, int dr, int dk) {
     if (dk == e) return Src{K_NYQ, dr < 0 ? 1 : 0, 0, 0};
     const int d = 2 * e - dk;            // mirrored bin minus reader bin
     if (dr == 0 && d == 0) return Src{K_SELF, 0, 0, 1};
+    if (dr == 0 && d == 1) return Src{K_NEXT, 0, 0, 1};
     const bool is_new = dr < 0 || (dr == 0 && d < 0);
     return Src{K_RING, is_new ? 1 : 0, SKEW * dr + d - (is_new ? 0 : LAG), 1};
 }
@@ -109,13 +124,23 @@ struct SysArgs {
     float w[2 * 4 * 8];      // W[0][r][k] as (re, im), r < Q, k <= L (at most 4 x 8)
 };
 
+// volatile: keeps every tap a separate ds_read_b64 (the backend otherwise fuses pairs into
+// ds_read2st64_b64, which moves half the bytes per LDS cycle -- MI355X_MICROARCH.md, LDS table)
 __device__ __forceinline__ float2 lds_read(int addr) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    return *reinterpret_cast<const float2 *>(smem + addr);
+    // `addr` is a byte offset into the dynamic LDS segment, which starts at LDS address 0 (the kernel
+    // has no static __shared__ objects); address space 3 keeps it a ds_ instruction
+    using lds_u64 = const volatile __attribute__((address_space(3))) unsigned long long;
+    const unsigned long long u = *(lds_u64 *)(unsigned)addr;
+    return make_float2(__uint_as_float((unsigned)(u & 0xffffffffull)), __uint_as_float((unsigned)(u >> 32)));
 }
 __device__ __forceinline__ void lds_write(int addr, float2 v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     *reinterpret_cast<float2 *>(smem + addr) = v;
+}
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f lds_read128(int addr) {
+    using lds_v4 = const volatile __attribute__((address_space(3))) v4f;
+    return *(lds_v4 *)(unsigned)addr;
 }
 __device__ __forceinline__ float2 cj(float2 v) { return make_float2(v.x, -v.y); }
 
@@ -129,11 +154,23 @@ __device__ __forceinline__ float2 load_l2(const float2 *p) {
     return v;
 }
 
+// Workgroup barrier between steps.  Every cross-wave read is at least 3 steps younger than its write except the
+// Nyquist lane's taps of bins C-1, C-2 (written in phases 7 and 6, read in phase 0), and no entry is read later
+// than 30 steps after it was produced while its slot is rewritten after 32: a barrier after every odd phase
+// therefore separates every cross-wave write->read and read->overwrite pair (LWS_BARRIER_EVERY=1: every step).
+#ifndef LWS_BARRIER_EVERY
+#define LWS_BARRIER_EVERY 2
+#endif
+template <int P> __device__ __forceinline__ void step_barrier() {
+    if constexpr (LWS_BARRIER_EVERY == 1 || (P & 1)) __syncthreads();
+}
+
 // Per-lane registers of a compute lane that stay valid for one block of 8 steps.
 struct LaneCtx {
     int nb[4][4];     // [d][m]: LDS address of lane (rho - d) in the own (new) set, block (a - m) & 3
     int ob[4][4];     // [d][m]: lane (rho + d) in the previous sweep's (old) set
-    int nyq_n[4], nyq_o[4];
+    int nyq_base;     // NYQ_OFF + own set row + lane*8 (taps derive the neighbour lane / set from it)
+    int lane8;
     bool is_start, is_end, live, store;
     float thr;
 };
@@ -145,36 +182,111 @@ template <int P, int OFF> __device__ __forceinline__ int ring_addr(const int (&b
     constexpr int fl = (q >= 0) ? 0 : -((-q + 7) / 8);   // floor(q / 8)
     constexpr int m = (-fl) & 3;
     constexpr int within = q - 8 * fl;
-    return base[m] + within * SLOT_BYTES;
+    return base[m] + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
 }
 
 template <int P, int DR, int DK, int EDGE>  // EDGE: 0 normal, 1 frame start, 2 frame end
-__device__ __forceinline__ float2 tap(const LaneCtx &cx, float2 self_old) {
+__device__ __forceinline__ float2 tap(const LaneCtx &cx, float2 self_old, float2 next_old) {
     constexpr Src s = (EDGE == 0) ? src_normal(DR, DK) : (EDGE == 1 ? src_start(P, DR, DK) : src_end(P, DR, DK));
     constexpr int d = DR < 0 ? -DR : DR;
     float2 v;
     if constexpr (s.kind == K_SELF) v = self_old;
-    else if constexpr (s.kind == K_NYQ) v = lds_read(s.set_new ? cx.nyq_n[d] : cx.nyq_o[d]);
+    else if constexpr (s.kind == K_NEXT) v = next_old;
+    else if constexpr (s.kind == K_NYQ) {
+        // rare (one lane, last bins of a frame): Nyquist value of frame m+DR in the own / previous set
+        const int ln = (cx.lane8 + 8 * DR) & (SLOT_BYTES - 1);
+        v = lds_read(cx.nyq_base - cx.lane8 + ln - (s.set_new ? 0 : SLOT_BYTES));
+    }
     else {
-        static_assert(s.off <= -1 && s.off >= -31, "tap outside ring retention");
+        static_assert(s.off <= -1 && s.off >= -30, "tap outside ring retention (ages 1..30)");
         v = lds_read(s.set_new ? ring_addr<P, s.off>(cx.nb[d]) : ring_addr<P, s.off>(cx.ob[d]));
     }
     if constexpr (s.conj) v = cj(v);
     return v;
 }
 
+// Normal-source taps of frame m+DR (DR != 0), bins c-L .. c+L: they are consecutive in production time, so
+// two of them come with each ds_read_b128.  KMASK bit |dk| says whether the tap is used.
+template <int P, int DR, int L, uint32_t KMASK>
+__device__ __forceinline__ void load_row(const LaneCtx &cx, float2 (&t)[2 * L + 1]) {
+    constexpr int d = DR < 0 ? -DR : DR;
+    constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
+    constexpr int q_lo = P + base_off - L;                       // first tap, relative production time
+    constexpr int q_first = (q_lo >= 0) ? (q_lo & ~1) : -(((-q_lo) + 1) & ~1);   // round down to even
+    static_for<L + 2>([&](auto ip) {
+        constexpr int q = q_first + 2 * decltype(ip)::value;     // even
+        constexpr int dka = q - P - base_off, dkb = dka + 1;
+        constexpr bool in_a = dka >= -L && dka <= L, in_b = dkb >= -L && dkb <= L;
+        constexpr bool need_a = in_a && ((KMASK >> (dka < 0 ? -dka : dka)) & 1u);
+        constexpr bool need_b = in_b && ((KMASK >> (dkb < 0 ? -dkb : dkb)) & 1u);
+        if constexpr (need_a || need_b) {
+            static_assert(q >= -32 && q + 1 <= 7, "ring retention exceeded");
+            constexpr int fl = (q >= 0) ? 0 : -((-q + 7) / 8);
+            constexpr int m = (-fl) & 3;
+            constexpr int within = q - 8 * fl;                   // even, 0..6
+            const int addr = (DR < 0 ? cx.nb[d][m] : cx.ob[d][m]) + (within >> 1) * PAIR_BYTES;
+            if constexpr (need_a && need_b) {
+                const v4f v = lds_read128(addr);
+                t[dka + L] = make_float2(v.x, v.y);
+                t[dkb + L] = make_float2(v.z, v.w);
+            } else if constexpr (need_a) {
+                t[dka + L] = lds_read(addr);
+            } else {
+                t[dkb + L] = lds_read(addr + 8);
+            }
+        }
+    });
+}
+
 // acc += w*b + conj(w)*c with w = (wr, wi) * j^ROT   (grouped form of lwslib.cpp:310-311)
+#ifndef LWS_PKMATH
+#define LWS_PKMATH 0
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int ROT> __device__ __forceinline__ void pair_rot(float2 &a, float wr, float wi, float2 b, float2 c) {
+#if LWS_PKMATH
+    // packed fp32: (sx, sy) = b + c, (dx, dy) = b - c, then two v_pk_fma_f32
+    const v2f vb = {b.x, b.y}, vc = {c.x, c.y};
+    const v2f sm = vb + vc, df = vb - vc;
+    const v2f dsw = {df.y, df.x};
+    v2f acc = {a.x, a.y};
+    v2f w1, w2;
+    if constexpr (ROT == 0) { w1 = (v2f){wr, wr}; w2 = (v2f){-wi, wi}; }
+    else if constexpr (ROT == 1) { w1 = (v2f){-wi, -wi}; w2 = (v2f){-wr, wr}; }
+    else if constexpr (ROT == 2) { w1 = (v2f){-wr, -wr}; w2 = (v2f){wi, -wi}; }
+    else { w1 = (v2f){wi, wi}; w2 = (v2f){wr, -wr}; }
+    acc = __builtin_elementwise_fma(w1, sm, acc);
+    acc = __builtin_elementwise_fma(w2, dsw, acc);
+    a.x = acc.x; a.y = acc.y;
+#else
     const float sx = b.x + c.x, dy = b.y - c.y, sy = b.y + c.y, dx = b.x - c.x;
-    if constexpr (ROT == 0) { a.x += wr * sx - wi * dy; a.y += wr * sy + wi * dx; }
-    else if constexpr (ROT == 1) { a.x += -wi * sx - wr * dy; a.y += -wi * sy + wr * dx; }
-    else if constexpr (ROT == 2) { a.x += -wr * sx + wi * dy; a.y += -wr * sy - wi * dx; }
-    else { a.x += wi * sx + wr * dy; a.y += wi * sy - wr * dx; }
+    // two fused multiply-adds per component (weights are wave-uniform scalars)
+    if constexpr (ROT == 0) { a.x = fmaf(-wi, dy, fmaf(wr, sx, a.x)); a.y = fmaf(wi, dx, fmaf(wr, sy, a.y)); }
+    else if constexpr (ROT == 1) { a.x = fmaf(-wr, dy, fmaf(-wi, sx, a.x)); a.y = fmaf(wr, dx, fmaf(-wi, sy, a.y)); }
+    else if constexpr (ROT == 2) { a.x = fmaf(wi, dy, fmaf(-wr, sx, a.x)); a.y = fmaf(-wi, dx, fmaf(-wr, sy, a.y)); }
+    else { a.x = fmaf(wr, dy, fmaf(wi, sx, a.x)); a.y = fmaf(-wr, dx, fmaf(wi, sy, a.y)); }
+#endif
+}
+__device__ __forceinline__ float2 cadd(float2 p, float2 q) {
+#if LWS_PKMATH
+    const v2f r = (v2f){p.x, p.y} + (v2f){q.x, q.y};
+    return make_float2(r.x, r.y);
+#else
+    return make_float2(p.x + q.x, p.y + q.y);
+#endif
+}
+__device__ __forceinline__ float2 csub(float2 p, float2 q) {
+#if LWS_PKMATH
+    const v2f r = (v2f){p.x, p.y} - (v2f){q.x, q.y};
+    return make_float2(r.x, r.y);
+#else
+    return make_float2(p.x - q.x, p.y - q.y);
+#endif
 }
 
 // The weighted sum of one bin at phase P (bin % 8 == P), all taps with compile-time ring offsets.
 template <int Q, int L, uint32_t MASK, int P>
-__device__ __forceinline__ float2 weighted_sum(const SysArgs &a, const LaneCtx &cx, float2 self_old) {
+__device__ __forceinline__ float2 weighted_sum(const SysArgs &a, const LaneCtx &cx, float2 self_old, float2 next_old) {
     constexpr int K1 = L + 1;
     float2 acc = make_float2(0.f, 0.f);
     // centre frame: W[.,0,k] does not depend on bin % Q
@@ -183,22 +295,22 @@ __device__ __forceinline__ float2 weighted_sum(const SysArgs &a, const LaneCtx &
         static_for<L>([&](auto ik) {
             constexpr int k = decltype(ik)::value + 1;
             if constexpr ((MASK >> k) & 1u) {
-                lo[k - 1] = tap<P, 0, -k, 0>(cx, self_old);
-                hi[k - 1] = tap<P, 0, k, 0>(cx, self_old);
+                lo[k - 1] = tap<P, 0, -k, 0>(cx, self_old, next_old);
+                hi[k - 1] = tap<P, 0, k, 0>(cx, self_old, next_old);
             }
         });
         if constexpr (P < L) {
             if (cx.is_start)
                 static_for<L>([&](auto ik) {
                     constexpr int k = decltype(ik)::value + 1;
-                    if constexpr (((MASK >> k) & 1u) && (P - k < 0)) lo[k - 1] = tap<P, 0, -k, 1>(cx, self_old);
+                    if constexpr (((MASK >> k) & 1u) && (P - k < 0)) lo[k - 1] = tap<P, 0, -k, 1>(cx, self_old, next_old);
                 });
         }
         if constexpr (P + L >= 8) {
             if (cx.is_end)
                 static_for<L>([&](auto ik) {
                     constexpr int k = decltype(ik)::value + 1;
-                    if constexpr (((MASK >> k) & 1u) && (P + k >= 8)) hi[k - 1] = tap<P, 0, k, 2>(cx, self_old);
+                    if constexpr (((MASK >> k) & 1u) && (P + k >= 8)) hi[k - 1] = tap<P, 0, k, 2>(cx, self_old, next_old);
                 });
         }
         static_for<L>([&](auto ik) {
@@ -212,21 +324,16 @@ __device__ __forceinline__ float2 weighted_sum(const SysArgs &a, const LaneCtx &
         constexpr int rot = ((mod * r) % Q) * (4 / Q);  // quarter turns of exp(2j*pi*mod*r/Q)
         // taps of frames m-r (up) and m+r (dn), bins c-L .. c+L
         float2 up[2 * L + 1], dn[2 * L + 1];
-        static_for<2 * L + 1>([&](auto id) {
-            constexpr int dk = decltype(id)::value - L;
-            constexpr int k = dk < 0 ? -dk : dk;
-            if constexpr ((MASK >> (r * K1 + k)) & 1u) {
-                up[dk + L] = tap<P, -r, dk, 0>(cx, self_old);
-                dn[dk + L] = tap<P, r, dk, 0>(cx, self_old);
-            }
-        });
+        constexpr uint32_t kmask = (MASK >> (r * K1)) & ((1u << K1) - 1u);
+        load_row<P, -r, L, kmask>(cx, up);
+        load_row<P, r, L, kmask>(cx, dn);
         if constexpr (P < L) {
             if (cx.is_start)
                 static_for<L>([&](auto ik) {
                     constexpr int k = decltype(ik)::value + 1;
                     if constexpr (((MASK >> (r * K1 + k)) & 1u) && (P - k < 0)) {
-                        up[L - k] = tap<P, -r, -k, 1>(cx, self_old);
-                        dn[L - k] = tap<P, r, -k, 1>(cx, self_old);
+                        up[L - k] = tap<P, -r, -k, 1>(cx, self_old, next_old);
+                        dn[L - k] = tap<P, r, -k, 1>(cx, self_old, next_old);
                     }
                 });
         }
@@ -235,13 +342,14 @@ __device__ __forceinline__ float2 weighted_sum(const SysArgs &a, const LaneCtx &
                 static_for<L>([&](auto ik) {
                     constexpr int k = decltype(ik)::value + 1;
                     if constexpr (((MASK >> (r * K1 + k)) & 1u) && (P + k >= 8)) {
-                        up[L + k] = tap<P, -r, k, 2>(cx, self_old);
-                        dn[L + k] = tap<P, r, k, 2>(cx, self_old);
+                        up[L + k] = tap<P, -r, k, 2>(cx, self_old, next_old);
+                        dn[L + k] = tap<P, r, k, 2>(cx, self_old, next_old);
                     }
                 });
         }
+        float2 accr = make_float2(0.f, 0.f);  // one accumulator per frame pair: independent dependency chains
         if constexpr ((MASK >> (r * K1)) & 1u)
-            pair_rot<rot>(acc, a.w[2 * (r * K1)], a.w[2 * (r * K1) + 1], up[L], dn[L]);
+            pair_rot<rot>(accr, a.w[2 * (r * K1)], a.w[2 * (r * K1) + 1], up[L], dn[L]);
         static_for<L>([&](auto ik) {
             constexpr int k = decltype(ik)::value + 1;
             if constexpr ((MASK >> (r * K1 + k)) & 1u) {
@@ -249,26 +357,30 @@ __device__ __forceinline__ float2 weighted_sum(const SysArgs &a, const LaneCtx &
                 // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
                 const float wr = a.w[2 * (r * K1 + k)], wi = a.w[2 * (r * K1 + k) + 1];
                 float2 b, c;
-                if constexpr ((rot & 1) == 0) {
-                    b = make_float2(up[L - k].x + dn[L + k].x, up[L - k].y + dn[L + k].y);
-                    c = make_float2(dn[L - k].x + up[L + k].x, dn[L - k].y + up[L + k].y);
-                } else {
-                    b = make_float2(up[L - k].x - dn[L + k].x, up[L - k].y - dn[L + k].y);
-                    c = make_float2(dn[L - k].x - up[L + k].x, dn[L - k].y - up[L + k].y);
-                }
-                pair_rot<rot>(acc, wr, wi, b, c);
+                if constexpr ((rot & 1) == 0) { b = cadd(up[L - k], dn[L + k]); c = cadd(dn[L - k], up[L + k]); }
+                else { b = csub(up[L - k], dn[L + k]); c = csub(dn[L - k], up[L + k]); }
+                pair_rot<rot>(accr, wr, wi, b, c);
             }
         });
+        acc = cadd(acc, accr);
     });
     return acc;
 }
 
-// Magnitude re-projection (lwslib.cpp:356-360): keep the old value unless the bin is active and the sum is non-zero.
+// Magnitude re-projection (lwslib.cpp:356-360): keep the old value unless the bin is active and the sum is
+// non-zero.  target/|acc| is evaluated as target * rsqrt(|acc|^2) with one Newton step on the hardware
+// reciprocal square root (relative error < 2^-22, the size of the two roundings of sqrt-then-divide);
+// sums too small to square in fp32 are rescaled first, so "|acc| > 0" keeps the reference's meaning.
 __device__ __forceinline__ float2 project(float2 acc, float target, bool active, float2 old) {
-    const float mag = sqrtf(acc.x * acc.x + acc.y * acc.y);
-    const bool ok = active && (mag > 0.f);
-    const float s = target / mag;
-    return ok ? make_float2(acc.x * s, acc.y * s) : old;
+    float m2 = acc.x * acc.x + acc.y * acc.y;
+    const bool tiny = m2 < 1e-30f;
+    const float ax = tiny ? acc.x * 0x1p60f : acc.x, ay = tiny ? acc.y * 0x1p60f : acc.y;
+    m2 = tiny ? ax * ax + ay * ay : m2;
+    const bool ok = active && (m2 > 0.f);
+    float r = __frsqrt_rn(m2);
+    r = r * fmaf(-0.5f * m2 * r, r, 1.5f);
+    const float sc = target * r;
+    return ok ? make_float2(ax * sc, ay * sc) : old;
 }
 
 // Per-lane bookkeeping of a sweep processor at clock v: which (sweep, frame) it is working on.
@@ -287,23 +399,29 @@ __device__ __forceinline__ RowInfo row_info(int vv /* v - 8*rho, start of frame 
 }
 
 template <int Q, int L, uint32_t MASK, int P>
-__device__ __forceinline__ void compute_step(const SysArgs &a, const LaneCtx &cx, int lane, int v, float2 &self_old,
-                                             float (&ampq)[PF], float2 *state_w_b, const float *amp_w_b, int G) {
+__device__ __forceinline__ void compute_step(const SysArgs &a, const LaneCtx &cx, int lane, int vmod /* clock mod G at phase 0 */,
+                                             float2 &self_old, float2 &next_old, float (&ampq)[PF], float2 *state_w_b,
+                                             const float *amp_w_b, int G) {
     // taps, weighted sum, projection
-    const float2 acc = weighted_sum<Q, L, MASK, P>(a, cx, self_old);
-    const float target = ampq[P];
+    const float2 acc = weighted_sum<Q, L, MASK, P>(a, cx, self_old, next_old);
+    const float target = ampq[P % PF];
     const bool active = cx.live && (target > cx.thr);
     const float2 out = project(acc, target, active, self_old);
     // publish: own set, slot (v mod 32) = block m = 0, within = P
-    lds_write(cx.nb[0][0] + P * SLOT_BYTES, out);
-    if (cx.store) state_w_b[(size_t)(v % G) * LANES + lane] = out;
-    // prefetch for later steps: own old value of the next step (age 31 now), target magnitude 8 steps ahead
-    self_old = lds_read(ring_addr<P, -31>(cx.ob[0]));
-    ampq[P] = amp_w_b[(size_t)((v + PF + G) % G) * LANES + lane];  // + G: clocks start negative
+    lds_write(cx.nb[0][0] + (P >> 1) * PAIR_BYTES + (P & 1) * 8, out);
+    if (cx.store) state_w_b[(size_t)(vmod + P) * LANES + lane] = out;   // G is a multiple of 8: no wrap inside a block
+    // prefetch for later steps: previous-sweep value of the own bin two steps ahead (age 30 now: no ring read is
+    // ever older, which leaves two steps between the last read of an entry and its overwrite), and the target
+    // magnitude PF steps ahead
+    self_old = next_old;
+    next_old = lds_read(ring_addr<P, -30>(cx.ob[0]));
+    int ipf = vmod + P + PF;
+    ipf -= (ipf >= G) ? G : 0;
+    ampq[P % PF] = amp_w_b[(size_t)ipf * LANES + lane];
 }
 
 template <int Q, int L, uint32_t MASK>
-__global__ void __launch_bounds__(NTHREADS, 3) k_systolic(SysArgs a) {
+__global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -338,7 +456,7 @@ __global__ void __launch_bounds__(NTHREADS, 3) k_systolic(SysArgs a) {
         // ------------------------------------------------------------------ compute wave = sweep slot
         const int slot = wave;
         LaneCtx cx;
-        float2 self_old = make_float2(0.f, 0.f);
+        float2 self_old = make_float2(0.f, 0.f), next_old = make_float2(0.f, 0.f);
         float ampq[PF];
 #pragma unroll
         for (int i = 0; i < PF; ++i) ampq[i] = 0.f;
@@ -360,26 +478,27 @@ __global__ void __launch_bounds__(NTHREADS, 3) k_systolic(SysArgs a) {
             cx.is_end = (cbase == C - 8);
             cx.thr = thr_eff[(valid ? j : 0)];
             const int ablk = (v0 >> 3);
+            cx.lane8 = lane * 8;
+            cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + lane * 8;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const int ln = ((lane - d) & 63) * 8, lo = ((lane + d) & 63) * 8;
-                cx.nyq_n[d] = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln;
-                cx.nyq_o[d] = NYQ_OFF + slot * SLOT_BYTES + lo;
+                const int ln = ((lane - d) & 63) * LANE_B, lo = ((lane + d) & 63) * LANE_B;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const int blk = ((ablk - m) & 3) * (8 * SLOT_BYTES);
+                    const int blk = ((ablk - m) & 3) * BLK_BYTES;
                     cx.nb[d][m] = set_new + blk + ln;
                     cx.ob[d][m] = set_old + blk + lo;
                 }
             }
             // one block early, so that the prefetched own-old value and magnitudes are warm at the first bin
             const bool any_valid = __any((vv >= -8) && (j < n_eff || vv < 0));
+            const int vmod = __builtin_amdgcn_readfirstlane(((v0 % G) + G) % G);  // wave-uniform, once per 8 steps
             // ---- 8 steps, phase static
             static_for<8>([&](auto ip) {
                 constexpr int P = decltype(ip)::value;
                 if (any_valid)
-                    compute_step<Q, L, MASK, P>(a, cx, lane, v0 + P, self_old, ampq, state_w_b, amp_w_b, G);
-                __syncthreads();
+                    compute_step<Q, L, MASK, P>(a, cx, lane, vmod, self_old, next_old, ampq, state_w_b, amp_w_b, G);
+                step_barrier<P>();
             });
         }
     } else {
@@ -422,14 +541,14 @@ __global__ void __launch_bounds__(NTHREADS, 3) k_systolic(SysArgs a) {
                     int nb[4][4], ob[4][4], nn[4], no[4];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        const int ln = ((rho - d) & 63) * 8, lo = ((rho + d) & 63) * 8;
-                        nn[d] = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln;
-                        no[d] = NYQ_OFF + slot * SLOT_BYTES + lo;
+                        const int ln = ((rho - d) & 63), lo = ((rho + d) & 63);
+                        nn[d] = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln * 8;
+                        no[d] = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
-                            const int blk = ((ablk - m) & 3) * (8 * SLOT_BYTES);
-                            nb[d][m] = set_new + blk + ln;
-                            ob[d][m] = set_old + blk + lo;
+                            const int blk = ((ablk - m) & 3) * BLK_BYTES;
+                            nb[d][m] = set_new + blk + ln * LANE_B;
+                            ob[d][m] = set_old + blk + lo * LANE_B;
                         }
                     }
                     const float2 old = lds_read(no[0]);
@@ -468,12 +587,14 @@ __global__ void __launch_bounds__(NTHREADS, 3) k_systolic(SysArgs a) {
                 }
             }
             // ---- loader: feed set 0 with the values the virtual previous sweep would produce, 8 steps ahead
+            const int tmod = __builtin_amdgcn_readfirstlane(t0 % G);
             static_for<8>([&](auto ip) {
                 constexpr int P = decltype(ip)::value;
-                const int v = t0 + P;
-                lds_write(((ablk & 3) * 8 + P) * SLOT_BYTES + lane * 8, pend[P]);
-                pend[P] = load_l2(state_w_b + (size_t)((v + PF) % G) * LANES + lane);
-                __syncthreads();
+                lds_write((ablk & 3) * BLK_BYTES + (P >> 1) * PAIR_BYTES + (P & 1) * 8 + lane * LANE_B, pend[P % PF]);
+                int ild = tmod + P + PF;
+                ild -= (ild >= G) ? G : 0;
+                pend[P % PF] = load_l2(state_w_b + (size_t)ild * LANES + lane);
+                step_barrier<P>();
             });
         }
     }
