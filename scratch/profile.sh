@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 kernel-trace + stats of the default bench command, and PMC passes for HBM traffic
+set -x
+cd /root/repo
+export TMPDIR=/tmp
+mkdir -p gpurun_out/prof
+python bench.py --steps 3 --warmup 1 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+tail -1 gpurun_out/bench_default.json
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof/trace -o r01 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-default-schedule > gpurun_out/prof/bench_traced.json 2> gpurun_out/prof/trace.err
+ls -R gpurun_out/prof/trace | head -20
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof/pmc_fetch -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-default-schedule > /dev/null 2> gpurun_out/prof/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof/pmc_write -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-default-schedule > /dev/null 2> gpurun_out/prof/pmc_write.err
+ls -R gpurun_out/prof | head -40
