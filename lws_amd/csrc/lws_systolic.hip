@@ -1,8 +1,8 @@
 // lws_systolic.hip -- the fast path for batch LWS (LWSQ2 / LWSQ4 / LWSanyQ, lwslib.cpp:72-373) on
 // gfx950: an order-exact *systolic* re-statement of the in-place Gauss-Seidel sweep.
 //
-// One workgroup (7 compute waves + 1 service wave = 2 waves per SIMD) owns one spectrogram and keeps
-// I = 7 consecutive sweeps in flight.  A lane is a (sweep, frame) processor that marches along the bins of its frame,
+// One workgroup (8 waves = 2 per SIMD; the last one also carries the service duties: HBM loader and the Nyquist
+// bins) owns one spectrogram and keeps I = 8 consecutive sweeps in flight.  A lane is a (sweep, frame) processor that marches along the bins of its frame,
 // one bin per step; the 64 lanes of compute wave i work on 64 consecutive frames of sweep
 // "iteration g*I + i", frame m trailing frame m-1 by SKEW = 8 bins, and sweep j+1 trailing sweep j
 // by LAG = 32 steps:
@@ -68,9 +68,13 @@ constexpr int NYQ_OFF = NSETS * SET_BYTES;               // Nyquist values: [set
 constexpr int THR_OFF = NYQ_OFF + NSETS * SLOT_BYTES;    // effective thresholds: floats
 constexpr int MAX_ITERS = 440;
 constexpr int META_OFF = THR_OFF + MAX_ITERS * 4;        // n_eff
-constexpr int LDS_BYTES = META_OFF + 16;
+constexpr int DONE_OFF = META_OFF + 16;               // per-wave count of completed steps (flow control)
+constexpr int LDS_BYTES = DONE_OFF + 64;
 constexpr int SKEW = 8, ROWP = SKEW * LANES, LAG = 32, PF = LWS_PF;  // PF: global prefetch distance (4 or 8 steps)
-constexpr int NTHREADS = LANES * (NSLOTS + 1);
+#ifndef LWS_SERVICE_WAVE
+#define LWS_SERVICE_WAVE 1   // 1: loader + Nyquist bins on a wave of their own; 0: carried by the last compute wave
+#endif
+constexpr int NTHREADS = LANES * (NSLOTS + LWS_SERVICE_WAVE);
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 template <int... Is, typename F>
@@ -126,7 +130,16 @@ struct SysArgs {
 
 // volatile: keeps every tap a separate ds_read_b64 (the backend otherwise fuses pairs into
 // ds_read2st64_b64, which moves half the bytes per LDS cycle -- MI355X_MICROARCH.md, LDS table)
+#ifndef LWS_DBG_NOLDS
+#define LWS_DBG_NOLDS 0     // timing experiment: taps come from registers instead of LDS (results invalid)
+#endif
+#ifndef LWS_DBG_NOMATH
+#define LWS_DBG_NOMATH 0    // timing experiment: one add per tap pair instead of the weighted sum (results invalid)
+#endif
 __device__ __forceinline__ float2 lds_read(int addr) {
+#if LWS_DBG_NOLDS
+    return make_float2(__int_as_float(addr), 1.0f);
+#endif
     // `addr` is a byte offset into the dynamic LDS segment, which starts at LDS address 0 (the kernel
     // has no static __shared__ objects); address space 3 keeps it a ds_ instruction
     using lds_u64 = const volatile __attribute__((address_space(3))) unsigned long long;
@@ -134,11 +147,23 @@ __device__ __forceinline__ float2 lds_read(int addr) {
     return make_float2(__uint_as_float((unsigned)(u & 0xffffffffull)), __uint_as_float((unsigned)(u >> 32)));
 }
 __device__ __forceinline__ void lds_write(int addr, float2 v) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    *reinterpret_cast<float2 *>(smem + addr) = v;
+    // volatile, like the reads: program order of all ring traffic is what the flow control below relies on
+    using lds_u64w = volatile __attribute__((address_space(3))) unsigned long long;
+    *(lds_u64w *)(unsigned)addr = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+}
+__device__ __forceinline__ int lds_read_i32(int addr) {
+    using lds_i32 = const volatile __attribute__((address_space(3))) int;
+    return *(lds_i32 *)(unsigned)addr;
+}
+__device__ __forceinline__ void lds_write_i32(int addr, int v) {
+    using lds_i32w = volatile __attribute__((address_space(3))) int;
+    *(lds_i32w *)(unsigned)addr = v;
 }
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4f lds_read128(int addr) {
+#if LWS_DBG_NOLDS
+    return (v4f){__int_as_float(addr), 1.0f, 2.0f, __int_as_float(addr + 1)};
+#endif
     using lds_v4 = const volatile __attribute__((address_space(3))) v4f;
     return *(lds_v4 *)(unsigned)addr;
 }
@@ -163,6 +188,29 @@ __device__ __forceinline__ float2 load_l2(const float2 *p) {
 #endif
 template <int P> __device__ __forceinline__ void step_barrier() {
     if constexpr (LWS_BARRIER_EVERY == 1 || (P & 1)) __syncthreads();
+}
+
+// Barrier-free alternative (LWS_FLOW=1, default): every wave publishes how many steps it has completed; before a
+// step a wave only waits for the waves it actually exchanges data with --
+//   data:       its producer (previous slot, or the service wave's loader / Nyquist lanes) must have completed step s-3
+//   overwrite:  its consumer (next slot) must have completed step s-2 (ring entries are read for at most 30 steps)
+// so waves drift by a step or two against each other and the two waves of a SIMD stop bursting LDS reads and
+// arithmetic at the same moments.  LDS executes the operations of a wave in program order, all ring accesses are
+// volatile (compiler order), so "write data, then the counter" / "read the counter, then the data" is sufficient.
+#ifndef LWS_FLOW
+#define LWS_FLOW 1
+#endif
+__device__ __forceinline__ void flow_wait(int lane, int s, int req_off) {
+    // lane l < NWAVES watches wave l; req_off: how many steps behind s that wave may be (large = don't care)
+    const int addr = DONE_OFF + (lane & 15) * 4;
+    while (true) {
+        const int v = lds_read_i32(addr);
+        if (__all(v >= s - req_off)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void flow_publish(int lane, int wave, int s_done) {
+    if (lane == 0) lds_write_i32(DONE_OFF + wave * 4, s_done);
 }
 
 // Per-lane registers of a compute lane that stay valid for one block of 8 steps.
@@ -244,6 +292,9 @@ __device__ __forceinline__ void load_row(const LaneCtx &cx, float2 (&t)[2 * L + 
 #endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 template <int ROT> __device__ __forceinline__ void pair_rot(float2 &a, float wr, float wi, float2 b, float2 c) {
+#if LWS_DBG_NOMATH
+    a.x += b.x; a.y += c.y; return;
+#endif
 #if LWS_PKMATH
     // packed fp32: (sx, sy) = b + c, (dx, dy) = b - c, then two v_pk_fma_f32
     const v2f vb = {b.x, b.y}, vc = {c.x, c.y};
@@ -400,24 +451,105 @@ __device__ __forceinline__ RowInfo row_info(int vv /* v - 8*rho, start of frame 
 
 template <int Q, int L, uint32_t MASK, int P>
 __device__ __forceinline__ void compute_step(const SysArgs &a, const LaneCtx &cx, int lane, int vmod /* clock mod G at phase 0 */,
-                                             float2 &self_old, float2 &next_old, float (&ampq)[PF], float2 *state_w_b,
-                                             const float *amp_w_b, int G) {
+                                             float2 &self_old, float2 &next_old, const float (&amp_cur)[8], float2 *state_w_b) {
     // taps, weighted sum, projection
     const float2 acc = weighted_sum<Q, L, MASK, P>(a, cx, self_old, next_old);
-    const float target = ampq[P % PF];
+    const float target = amp_cur[P];
     const bool active = cx.live && (target > cx.thr);
     const float2 out = project(acc, target, active, self_old);
     // publish: own set, slot (v mod 32) = block m = 0, within = P
     lds_write(cx.nb[0][0] + (P >> 1) * PAIR_BYTES + (P & 1) * 8, out);
     if (cx.store) state_w_b[(size_t)(vmod + P) * LANES + lane] = out;   // G is a multiple of 8: no wrap inside a block
-    // prefetch for later steps: previous-sweep value of the own bin two steps ahead (age 30 now: no ring read is
-    // ever older, which leaves two steps between the last read of an entry and its overwrite), and the target
-    // magnitude PF steps ahead
+    // prefetch: previous-sweep value of the own bin two steps ahead (age 30 now: no ring read is ever older,
+    // which leaves two steps between the last read of an entry and its overwrite)
     self_old = next_old;
     next_old = lds_read(ring_addr<P, -30>(cx.ob[0]));
-    int ipf = vmod + P + PF;
-    ipf -= (ipf >= G) ? G : 0;
-    ampq[P % PF] = amp_w_b[(size_t)ipf * LANES + lane];
+}
+
+// State of the service duties (HBM loader for set 0 and the Nyquist bins of every sweep slot).
+struct ServiceState {
+    float2 pend[PF];        // loader: values in flight from HBM
+    float nyq_amp_next;     // Nyquist lanes: target magnitude of the next block's Nyquist bin
+    float2 nyq_in_next;     // Nyquist loader lane: previous-sweep Nyquist value of the next block's frame
+};
+
+// Phase 0 of a block: lane l < NSLOTS computes the Nyquist bin (bin C = F-1) of the frame of sweep slot l whose
+// 512-step period has just ended; lane NSLOTS feeds set 0 with the stored Nyquist value of that frame.
+template <int Q, int L, uint32_t MASK>
+__device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &sv, int lane, int t0, int n_eff,
+                                                int n_groups, const float *thr_eff, float2 *state_nyq_b,
+                                                const float *amp_nyq_b) {
+    constexpr int K1 = L + 1;
+    const int C = a.C, Kr = a.Kr;
+    const int ablk = (t0 >> 3);
+    const int slot = lane;                       // lanes 0..NSLOTS-1
+    const bool is_nyq_lane = lane < NSLOTS;
+    const bool is_nyq_loader = lane == NSLOTS;
+    const int v0 = t0 - (is_nyq_lane ? (slot + 1) * LAG : 0);
+    const int vrow = (v0 - C) >> 3;              // virtual frame whose Nyquist bin is due now
+    const int rho = vrow & 63, kap = vrow >> 6;
+    const int g = kap / Kr, k = kap - g * Kr;
+    const int me = k * LANES + rho;
+    const int j = g * NSLOTS + (is_nyq_lane ? slot : -1);
+    const bool valid = (v0 - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
+    if (is_nyq_loader) {
+        lds_write(NYQ_OFF + rho * 8, sv.nyq_in_next);  // loaded one block ago for this frame
+        const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
+        const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
+        if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2(state_nyq_b + me1);
+    }
+    if (is_nyq_lane) {
+        const float target = sv.nyq_amp_next;
+        const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
+        const float thr = thr_eff[valid ? j : 0];
+        const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
+        int nb[4][4], ob[4][4], nn[4], no[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int ln = ((rho - d) & 63), lo = ((rho + d) & 63);
+            nn[d] = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln * 8;
+            no[d] = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int blk = ((ablk - m) & 3) * BLK_BYTES;
+                nb[d][m] = set_new + blk + ln * LANE_B;
+                ob[d][m] = set_old + blk + lo * LANE_B;
+            }
+        }
+        const float2 old = lds_read(no[0]);
+        float2 acc = make_float2(0.f, 0.f);
+        // bin C: bin % Q == 0, every twiddle is 1; taps above Nyquist are conjugated images
+        static_for<L>([&](auto ik) {
+            constexpr int k = decltype(ik)::value + 1;
+            if constexpr ((MASK >> k) & 1u) {
+                const float2 lo = lds_read(ring_addr<0, -k>(nb[0]));
+                pair_rot<0>(acc, a.w[2 * k], a.w[2 * k + 1], lo, cj(lo));
+            }
+        });
+        static_for<Q - 1>([&](auto ir) {
+            constexpr int r = decltype(ir)::value + 1;
+            if constexpr ((MASK >> (r * K1)) & 1u)
+                pair_rot<0>(acc, a.w[2 * r * K1], a.w[2 * r * K1 + 1], lds_read(nn[r]), lds_read(no[r]));
+            static_for<L>([&](auto ik) {
+                constexpr int k = decltype(ik)::value + 1;
+                if constexpr ((MASK >> (r * K1 + k)) & 1u) {
+                    const float2 up = lds_read(ring_addr<0, -SKEW * r - k>(nb[r]));
+                    const float2 dn = lds_read(ring_addr<0, SKEW * r - k - LAG>(ob[r]));
+                    const float2 bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
+                    const float2 csum = make_float2(dn.x + up.x, dn.y - up.y);   // dn + conj(up)
+                    pair_rot<0>(acc, a.w[2 * (r * K1 + k)], a.w[2 * (r * K1 + k) + 1], bsum, csum);
+                }
+            });
+        });
+        const bool active = real_row && (target > thr);
+        const float2 out = project(acc, target, active, old);
+        lds_write(nn[0], out);
+        if (valid && (slot == NSLOTS - 1 || j == n_eff - 1)) state_nyq_b[me] = out;
+        // target magnitude of the next block's Nyquist bin
+        const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
+        const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
+        sv.nyq_amp_next = (vr1 >= 0 && me1 < a.Tp) ? amp_nyq_b[me1] : 0.f;
+    }
 }
 
 template <int Q, int L, uint32_t MASK>
@@ -445,6 +577,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     }
     // poison-free start: rings may hold anything, but zero keeps the arithmetic of idle lanes finite
     for (int i = threadIdx.x; i < THR_OFF / 8; i += NTHREADS) reinterpret_cast<float2 *>(smem)[i] = make_float2(0.f, 0.f);
+    if (threadIdx.x < 16) reinterpret_cast<int *>(smem + DONE_OFF)[threadIdx.x] = 0;
     __syncthreads();
     const int n_eff = meta[0];
     if (n_eff == 0) return;
@@ -452,151 +585,114 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     // slot i runs on clock v_i = t - (i+1)*LAG; the loader (virtual slot -1) on clock t
     const int t_end = (n_groups - 1) * G + (NSLOTS + 1) * LAG + SKEW * a.Tp + ROWP + 8;
 
-    if (wave < NSLOTS) {
-        // ------------------------------------------------------------------ compute wave = sweep slot
-        const int slot = wave;
-        LaneCtx cx;
-        float2 self_old = make_float2(0.f, 0.f), next_old = make_float2(0.f, 0.f);
-        float ampq[PF];
+    const bool is_compute = wave < NSLOTS;
+    const bool is_service = LWS_SERVICE_WAVE ? (wave == NSLOTS) : (wave == NSLOTS - 1);
+    const int slot = wave;
+    LaneCtx cx;
+    float2 self_old = make_float2(0.f, 0.f), next_old = make_float2(0.f, 0.f);
+    // target magnitudes of the current block's 8 bins and (in flight) of the next block's: all 8 global loads of a
+    // block are issued together one block ahead, so no step ever waits on HBM latency
+    float amp_cur[8], amp_nxt[8];
 #pragma unroll
-        for (int i = 0; i < PF; ++i) ampq[i] = 0.f;
-        const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
-        for (int t0 = 0; t0 < t_end; t0 += 8) {
-            const int v0 = t0 - (slot + 1) * LAG;  // clock at phase 0 of this block (multiple of 8)
-            // ---- block prologue: where is this lane?
-            const int vv = v0 - SKEW * lane;        // clock relative to the start of lane's first frame
-            const int cbase = vv & (ROWP - 1);
-            const int kap = vv >> 9;
-            const int g = kap / Kr, k = kap - g * Kr;
-            const int me = k * LANES + lane;
-            const int j = g * NSLOTS + slot;
-            const bool valid = (vv >= 0) && (j < n_eff) && (me < a.Tp);
-            const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
-            cx.live = real_row && (cbase < C);
-            cx.store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
-            cx.is_start = (cbase == 0);
-            cx.is_end = (cbase == C - 8);
-            cx.thr = thr_eff[(valid ? j : 0)];
-            const int ablk = (v0 >> 3);
-            cx.lane8 = lane * 8;
-            cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + lane * 8;
+    for (int i = 0; i < 8; ++i) amp_cur[i] = amp_nxt[i] = 0.f;
+    ServiceState sv;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int ln = ((lane - d) & 63) * LANE_B, lo = ((lane + d) & 63) * LANE_B;
+    for (int i = 0; i < PF; ++i) sv.pend[i] = make_float2(0.f, 0.f);
+    sv.nyq_amp_next = 0.f;
+    sv.nyq_in_next = make_float2(0.f, 0.f);
+    if (is_service) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int blk = ((ablk - m) & 3) * BLK_BYTES;
-                    cx.nb[d][m] = set_new + blk + ln;
-                    cx.ob[d][m] = set_old + blk + lo;
-                }
-            }
-            // one block early, so that the prefetched own-old value and magnitudes are warm at the first bin
-            const bool any_valid = __any((vv >= -8) && (j < n_eff || vv < 0));
-            const int vmod = __builtin_amdgcn_readfirstlane(((v0 % G) + G) % G);  // wave-uniform, once per 8 steps
-            // ---- 8 steps, phase static
-            static_for<8>([&](auto ip) {
-                constexpr int P = decltype(ip)::value;
-                if (any_valid)
-                    compute_step<Q, L, MASK, P>(a, cx, lane, vmod, self_old, next_old, ampq, state_w_b, amp_w_b, G);
-                step_barrier<P>();
-            });
+        for (int i = 0; i < PF; ++i) sv.pend[i] = load_l2(state_w_b + (size_t)(i % G) * LANES + lane);  // clocks 0..7
+    }
+    const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
+    // flow control: which waves this wave waits for (lane l watches wave l), and how far behind they may be
+    constexpr int NWAVES = NSLOTS + LWS_SERVICE_WAVE, SVC = LWS_SERVICE_WAVE ? NSLOTS : NSLOTS - 1, FAR = 1 << 29;
+    int req_off = FAR, req_off_p0 = FAR;
+    if (lane < NWAVES) {
+        if (LWS_SERVICE_WAVE && wave == SVC) {
+            // loader overwrites what slot 0 still reads; Nyquist lanes read last step's bins of every slot at phase 0
+            req_off = (lane == 0) ? 1 : FAR;
+            req_off_p0 = (lane < NSLOTS) ? 0 : FAR;
+        } else {
+            const int producer = (wave == 0) ? SVC : wave - 1;
+            if (lane == producer || lane == SVC) req_off = 2;
+            if (lane == wave + 1 && lane < NSLOTS) req_off = 1;
+            if (lane == wave) req_off = FAR;
+            req_off_p0 = req_off;
         }
-    } else {
-        // ------------------------------------------------------------------ service wave: loader + Nyquist bins
-        float2 pend[PF];
+    }
+    for (int t0 = 0; t0 < t_end; t0 += 8) {
+        const int v0 = t0 - (slot + 1) * LAG;  // clock of this sweep slot at phase 0 of the block (multiple of 8)
+        // ---- block prologue: where is this lane?
+        const int vv = v0 - SKEW * lane;        // clock relative to the start of lane's first frame
+        const int cbase = vv & (ROWP - 1);
+        const int kap = vv >> 9;
+        const int g = kap / Kr, k = kap - g * Kr;
+        const int me = k * LANES + lane;
+        const int j = g * NSLOTS + slot;
+        const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
+        const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
+        cx.live = real_row && (cbase < C);
+        cx.store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
+        cx.is_start = (cbase == 0);
+        cx.is_end = (cbase == C - 8);
+        cx.thr = thr_eff[(valid ? j : 0)];
+        const int ablk = (v0 >> 3);
+        cx.lane8 = lane * 8;
+        cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + lane * 8;
 #pragma unroll
-        for (int i = 0; i < PF; ++i) pend[i] = load_l2(state_w_b + (size_t)(i % G) * LANES + lane);  // clocks 0..7
-        // Nyquist lanes: lane l < NSLOTS serves slot l; lane NSLOTS loads Nyquist values for set 0
-        float nyq_amp_next = 0.f;
-        float2 nyq_in_next = make_float2(0.f, 0.f);
-        constexpr int K1 = L + 1;
-        for (int t0 = 0; t0 < t_end; t0 += 8) {
-            const int ablk = (t0 >> 3);
-            // ---- Nyquist bins fall on phase 0 (C is a multiple of 8)
-            {
-                const int slot = lane;                       // lanes 0..7
-                const bool is_nyq_lane = lane < NSLOTS;
-                const bool is_nyq_loader = lane == NSLOTS;
-                const int v0 = t0 - (is_nyq_lane ? (slot + 1) * LAG : 0);
-                const int vrow = (v0 - C) >> 3;              // virtual frame whose Nyquist bin is due now
-                const int rho = vrow & 63, kap = vrow >> 6;
-                const int g = kap / Kr, k = kap - g * Kr;
-                const int me = k * LANES + rho;
-                const int j = g * NSLOTS + (is_nyq_lane ? slot : -1);
-                const bool valid = (v0 - C >= 0) && (me < a.Tp) &&
-                                   (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
-                if (is_nyq_loader) {
-                    // value loaded one block ago belongs to this frame
-                    lds_write(NYQ_OFF + rho * 8, nyq_in_next);
-                    // next block's frame
-                    const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
-                    const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
-                    if (vr1 >= 0 && me1 < a.Tp) nyq_in_next = load_l2(state_nyq_b + me1);
-                }
-                if (is_nyq_lane) {
-                    const float target = nyq_amp_next;
-                    const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
-                    const float thr = thr_eff[valid ? j : 0];
-                    const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
-                    int nb[4][4], ob[4][4], nn[4], no[4];
+        for (int d = 0; d < 4; ++d) {
+            const int ln = ((lane - d) & 63) * LANE_B, lo = ((lane + d) & 63) * LANE_B;
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const int ln = ((rho - d) & 63), lo = ((rho + d) & 63);
-                        nn[d] = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln * 8;
-                        no[d] = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const int blk = ((ablk - m) & 3) * BLK_BYTES;
-                            nb[d][m] = set_new + blk + ln * LANE_B;
-                            ob[d][m] = set_old + blk + lo * LANE_B;
-                        }
-                    }
-                    const float2 old = lds_read(no[0]);
-                    float2 acc = make_float2(0.f, 0.f);
-                    // bin C: bin % Q == 0, every twiddle is 1; taps above Nyquist are conjugated images
-                    static_for<L>([&](auto ik) {
-                        constexpr int k = decltype(ik)::value + 1;
-                        if constexpr ((MASK >> k) & 1u) {
-                            const float2 lo = lds_read(ring_addr<0, -k>(nb[0]));
-                            pair_rot<0>(acc, a.w[2 * k], a.w[2 * k + 1], lo, cj(lo));
-                        }
-                    });
-                    static_for<Q - 1>([&](auto ir) {
-                        constexpr int r = decltype(ir)::value + 1;
-                        if constexpr ((MASK >> (r * K1)) & 1u)
-                            pair_rot<0>(acc, a.w[2 * r * K1], a.w[2 * r * K1 + 1], lds_read(nn[r]), lds_read(no[r]));
-                        static_for<L>([&](auto ik) {
-                            constexpr int k = decltype(ik)::value + 1;
-                            if constexpr ((MASK >> (r * K1 + k)) & 1u) {
-                                const float2 up = lds_read(ring_addr<0, -SKEW * r - k>(nb[r]));
-                                const float2 dn = lds_read(ring_addr<0, SKEW * r - k - LAG>(ob[r]));
-                                const float2 bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
-                                const float2 csum = make_float2(dn.x + up.x, dn.y - up.y);   // dn + conj(up)
-                                pair_rot<0>(acc, a.w[2 * (r * K1 + k)], a.w[2 * (r * K1 + k) + 1], bsum, csum);
-                            }
-                        });
-                    });
-                    const bool active = real_row && (target > thr);
-                    const float2 out = project(acc, target, active, old);
-                    lds_write(nn[0], out);
-                    if (valid && (slot == NSLOTS - 1 || j == n_eff - 1)) state_nyq_b[me] = out;
-                    // target magnitude of the next block's Nyquist bin
-                    const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
-                    const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
-                    nyq_amp_next = (vr1 >= 0 && me1 < a.Tp) ? amp_nyq_b[me1] : 0.f;
-                }
+            for (int m = 0; m < 4; ++m) {
+                const int blk = ((ablk - m) & 3) * BLK_BYTES;
+                cx.nb[d][m] = set_new + blk + ln;
+                cx.ob[d][m] = set_old + blk + lo;
             }
-            // ---- loader: feed set 0 with the values the virtual previous sweep would produce, 8 steps ahead
-            const int tmod = __builtin_amdgcn_readfirstlane(t0 % G);
-            static_for<8>([&](auto ip) {
-                constexpr int P = decltype(ip)::value;
-                lds_write((ablk & 3) * BLK_BYTES + (P >> 1) * PAIR_BYTES + (P & 1) * 8 + lane * LANE_B, pend[P % PF]);
+        }
+        // one block early, so that the prefetched own-old value and magnitudes are warm at the first bin
+        const bool any_valid = is_compute && __any((vv >= -8) && (j < n_eff || vv < 0));
+        const int vmod = __builtin_amdgcn_readfirstlane(((v0 % G) + G) % G);  // wave-uniform, once per 8 steps
+        const int tmod = __builtin_amdgcn_readfirstlane(t0 % G);
+        {
+            int vnext = vmod + 8;
+            vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                amp_cur[i] = amp_nxt[i];
+                amp_nxt[i] = amp_w_b[(size_t)(vnext + i) * LANES + lane];
+            }
+        }
+#if LWS_FLOW
+        flow_wait(lane, t0, req_off_p0);
+#endif
+        // ---- Nyquist bins of all slots fall on phase 0 (C is a multiple of 8)
+        if (is_service) service_nyquist<Q, L, MASK>(a, sv, lane, t0, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+        // ---- 8 steps, phase static
+        static_for<8>([&](auto ip) {
+            constexpr int P = decltype(ip)::value;
+#if LWS_FLOW
+            if constexpr (P > 0) flow_wait(lane, t0 + P, req_off);
+#endif
+            if (any_valid)
+                compute_step<Q, L, MASK, P>(a, cx, lane, vmod, self_old, next_old, amp_cur, state_w_b);
+            if (is_service) {
+                // loader: feed set 0 with the values the virtual previous sweep would produce, PF steps ahead
+                lds_write(((t0 >> 3) & 3) * BLK_BYTES + (P >> 1) * PAIR_BYTES + (P & 1) * 8 + lane * LANE_B, sv.pend[P % PF]);
                 int ild = tmod + P + PF;
                 ild -= (ild >= G) ? G : 0;
-                pend[P % PF] = load_l2(state_w_b + (size_t)ild * LANES + lane);
-                step_barrier<P>();
-            });
-        }
+#if LWS_DBG_NOLDS && LWS_DBG_NOMATH
+                sv.pend[P % PF] = make_float2((float)ild, 0.f);   // skeleton timing: no HBM latency floor either
+#else
+                sv.pend[P % PF] = load_l2(state_w_b + (size_t)ild * LANES + lane);
+#endif
+            }
+#if LWS_FLOW
+            flow_publish(lane, wave, t0 + P + 1);
+#else
+            step_barrier<P>();
+#endif
+        });
     }
 }
 
