@@ -48,14 +48,17 @@ namespace {
 
 constexpr int LANES = 64;
 constexpr int RING = 32;
-// ring entry of production time nu, lane l:  set + ((nu >> 1) & 15) * PAIR_BYTES + l * 16 + (nu & 1) * 8
+// ring entry of production time nu, lane l:  set + ((nu >> 1) & 15) * PAIR_BYTES + (l + HALO) * 16 + (nu & 1) * 8
 // -- two consecutive times of one lane share a 16-byte cell, so a reader fetches two adjacent taps with one
-// ds_read_b128 (which, unlike ds_read_b64, reaches the LDS peak rate at 1-2 waves per SIMD)
-constexpr int SLOT_BYTES = LANES * 8;                    // bytes per production time (64 float2)
-constexpr int PAIR_BYTES = 2 * SLOT_BYTES;               // two consecutive times x 64 lanes
-constexpr int BLK_BYTES = 8 * SLOT_BYTES;                // one block of 8 steps
+// ds_read_b128; every row of 64 lanes carries HALO copies of the opposite end on each side (lanes -3..-1 mirror
+// 61..63, lanes 64..66 mirror 0..2), so "the lane d frames above / below" is a compile-time address offset and a
+// lane needs one base register per ring block instead of one per (neighbour, block).
+constexpr int SLOT_BYTES = LANES * 8;                    // Nyquist buffer: bytes per set (64 float2)
+constexpr int HALO = 3;                                  // >= Q - 1
 constexpr int LANE_B = 16;
-constexpr int SET_BYTES = RING * SLOT_BYTES;             // 16 KiB
+constexpr int PAIR_BYTES = (LANES + 2 * HALO) * LANE_B;  // two consecutive times x 70 lanes
+constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
+constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 17.5 KiB
 #ifndef LWS_NSLOTS
 #define LWS_NSLOTS 7
 #endif
@@ -70,9 +73,9 @@ constexpr int MAX_ITERS = 440;
 constexpr int META_OFF = THR_OFF + MAX_ITERS * 4;        // n_eff
 constexpr int DONE_OFF = META_OFF + 16;               // per-wave count of completed steps (flow control)
 constexpr int LDS_BYTES = DONE_OFF + 64;
-constexpr int SKEW = 8, ROWP = SKEW * LANES, LAG = 32, PF = LWS_PF;  // PF: global prefetch distance (4 or 8 steps)
+constexpr int SKEW = 8, ROWP = SKEW * LANES, LAG = 32;
 #ifndef LWS_SERVICE_WAVE
-#define LWS_SERVICE_WAVE 1   // 1: loader + Nyquist bins on a wave of their own; 0: carried by the last compute wave
+#define LWS_SERVICE_WAVE 1   // loader + Nyquist bins run on a wave of their own
 #endif
 constexpr int NTHREADS = LANES * (NSLOTS + LWS_SERVICE_WAVE);
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -88,11 +91,14 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
 // Where a stencil tap is found.  off: production time relative to the reader's clock (already
 // includes -LAG for "old" values); set_new: ring set of the reader's own sweep (1) or of the
 // previous sweep (0).
-enum { K_RING = 0, K_NYQ = 1, K_SELF = 2, K_NEXT = 3 };  // K_SELF / K_NEXT: previous-sweep value of the own bin c / c+1 (prefetched registers)
+enum { K_RING = 0, K_NYQ = 1, K_SELF = 2, K_NEXT = 3, K_PREV = 4 };
+// register sources: K_SELF / K_NEXT = previous-sweep value of the own bin c / c+1 (prefetched), K_PREV = this sweep's
+// value of bin c-1 (the lane's own previous output; for the second bin of a pair it is not in LDS yet)
 struct Src { int kind, set_new, off, conj; };
 
 __host__ __device__ constexpr Src src_normal(int dr, int dk) {
     if (dr == 0 && dk == 1) return Src{K_NEXT, 0, 0, 0};
+    if (dr == 0 && dk == -1) return Src{K_PREV, 0, 0, 0};
     const bool is_new = dr < 0 || (dr == 0 && dk < 0);
     return Src{K_RING, is_new ? 1 : 0, SKEW * dr + dk - (is_new ? 0 : LAG), 0};
 }
@@ -102,6 +108,7 @@ __host__ __device__ constexpr Src src_start(int P, int dr, int dk) {
     const int off0 = SKEW * dr + cm - P;
     if (dr == 0 && cm == P) return Src{K_SELF, 0, 0, 1};
     if (dr == 0 && cm == P + 1) return Src{K_NEXT, 0, 0, 1};
+    if (dr == 0 && cm == P - 1) return Src{K_PREV, 0, 0, 1};
     const bool is_new = dr < 0 || (dr == 0 && cm < P);
     return Src{K_RING, is_new ? 1 : 0, off0 - (is_new ? 0 : LAG), 1};
 }
@@ -113,6 +120,7 @@ __host__ __device__ constexpr Src src_end(int P, int dr, int dk) {
     const int d = 2 * e - dk;            // mirrored bin minus reader bin
     if (dr == 0 && d == 0) return Src{K_SELF, 0, 0, 1};
     if (dr == 0 && d == 1) return Src{K_NEXT, 0, 0, 1};
+    if (dr == 0 && d == -1) return Src{K_PREV, 0, 0, 1};
     const bool is_new = dr < 0 || (dr == 0 && d < 0);
     return Src{K_RING, is_new ? 1 : 0, SKEW * dr + d - (is_new ? 0 : LAG), 1};
 }
@@ -179,243 +187,224 @@ __device__ __forceinline__ float2 load_l2(const float2 *p) {
     return v;
 }
 
-// Workgroup barrier between steps.  Every cross-wave read is at least 3 steps younger than its write except the
-// Nyquist lane's taps of bins C-1, C-2 (written in phases 7 and 6, read in phase 0), and no entry is read later
-// than 30 steps after it was produced while its slot is rewritten after 32: a barrier after every odd phase
-// therefore separates every cross-wave write->read and read->overwrite pair (LWS_BARRIER_EVERY=1: every step).
-#ifndef LWS_BARRIER_EVERY
-#define LWS_BARRIER_EVERY 2
-#endif
-template <int P> __device__ __forceinline__ void step_barrier() {
-    if constexpr (LWS_BARRIER_EVERY == 1 || (P & 1)) __syncthreads();
-}
-
-// Barrier-free alternative (LWS_FLOW=1, default): every wave publishes how many steps it has completed; before a
-// step a wave only waits for the waves it actually exchanges data with --
-//   data:       its producer (previous slot, or the service wave's loader / Nyquist lanes) must have completed step s-3
-//   overwrite:  its consumer (next slot) must have completed step s-2 (ring entries are read for at most 30 steps)
-// so waves drift by a step or two against each other and the two waves of a SIMD stop bursting LDS reads and
-// arithmetic at the same moments.  LDS executes the operations of a wave in program order, all ring accesses are
-// volatile (compiler order), so "write data, then the counter" / "read the counter, then the data" is sufficient.
-#ifndef LWS_FLOW
-#define LWS_FLOW 1
-#endif
-__device__ __forceinline__ void flow_wait(int lane, int s, int req_off) {
-    // lane l < NWAVES watches wave l; req_off: how many steps behind s that wave may be (large = don't care)
-    const int addr = DONE_OFF + (lane & 15) * 4;
+// ---- synchronisation between the waves of a workgroup -----------------------------------------------------
+// The step loop works on PAIRS of consecutive bins (phases 1+2, 3+4, 5+6, 7+0'): every tap of both bins, except the
+// lane's own previous output, is at least 2 steps old when the pair starts, and nothing older than 30 steps is
+// ever read while a ring slot is rewritten after 32.  A wave may therefore start a pair as soon as the waves it
+// exchanges data with -- its producer (previous slot, or the service wave), its consumer (next slot) and the
+// service wave -- have completed the previous pair.  Each wave publishes the first step it has not completed yet
+// in LDS; LDS executes the operations of one wave in program order and all ring accesses are volatile (compiler
+// order), so "write data, then the counter" / "read the counter, then the data" is sufficient.  No barriers.
+__device__ __forceinline__ void flow_wait(int lane, int s, bool watched) {
+    const int addr = DONE_OFF + (lane & 15) * 4;   // lane l < number of waves watches wave l
     while (true) {
         const int v = lds_read_i32(addr);
-        if (__all(v >= s - req_off)) break;
+        if (__all(!watched || v >= s)) break;
         __builtin_amdgcn_s_sleep(1);
     }
 }
-__device__ __forceinline__ void flow_publish(int lane, int wave, int s_done) {
-    if (lane == 0) lds_write_i32(DONE_OFF + wave * 4, s_done);
+__device__ __forceinline__ void flow_publish(int lane, int wave, int s_next) {
+    if (lane == 0) lds_write_i32(DONE_OFF + wave * 4, s_next);
 }
 
 // Per-lane registers of a compute lane that stay valid for one block of 8 steps.
 struct LaneCtx {
-    int nb[4][4];     // [d][m]: LDS address of lane (rho - d) in the own (new) set, block (a - m) & 3
-    int ob[4][4];     // [d][m]: lane (rho + d) in the previous sweep's (old) set
+    int nb[4];        // [m]: LDS address of this lane's halo-shifted origin in the own (new) set, block (a - m) & 3
+    int ob[4];        // [m]: the same in the previous sweep's (old) set
     int nyq_base;     // NYQ_OFF + own set row + lane*8 (taps derive the neighbour lane / set from it)
+    int halo_shift;   // +-64 lanes in bytes for the 6 lanes that also write a halo copy, else 0
     int lane8;
-    bool is_start, is_end, live, store;
-    float thr;
+    bool is_start, is_end, live, store;          // this block (8 bins of one frame)
+    bool nxt_start, nxt_end, nxt_live, nxt_store; // the following block (possibly the next frame of the lane)
+    float thr, nxt_thr;
 };
 
-// address of the ring entry produced OFF steps relative to the current clock (phase P of block a)
-template <int P, int OFF> __device__ __forceinline__ int ring_addr(const int (&base)[4]) {
-    constexpr int q = P + OFF;
-    static_assert(q >= -32 && q <= 7, "ring retention exceeded");
-    constexpr int fl = (q >= 0) ? 0 : -((-q + 7) / 8);   // floor(q / 8)
-    constexpr int m = (-fl) & 3;
-    constexpr int within = q - 8 * fl;
-    return base[m] + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
+__host__ __device__ constexpr int floor_div8(int q) { return (q >= 0) ? q / 8 : -((-q + 7) / 8); }
+
+// write a lane's value and, for the first / last HALO lanes, its halo copy at the other end of the row
+__device__ __forceinline__ void ring_publish(int addr, int halo_shift, float2 v) {
+    lds_write(addr, v);
+    if (halo_shift != 0) lds_write(addr + halo_shift, v);
 }
 
-template <int P, int DR, int DK, int EDGE>  // EDGE: 0 normal, 1 frame start, 2 frame end
-__device__ __forceinline__ float2 tap(const LaneCtx &cx, float2 self_old, float2 next_old) {
-    constexpr Src s = (EDGE == 0) ? src_normal(DR, DK) : (EDGE == 1 ? src_start(P, DR, DK) : src_end(P, DR, DK));
-    constexpr int d = DR < 0 ? -DR : DR;
+// address of the ring entry of the lane DR frames away, produced at clock (block start + P + OFF); P may be 8
+// (phase 0 of the next block).  base[m] addresses lane - HALO of block (a - m) & 3.
+template <int P, int OFF, int DR = 0> __device__ __forceinline__ int ring_addr(const int (&base)[4]) {
+    constexpr int q = P + OFF;
+    static_assert(q >= -32 && q <= 15, "ring retention exceeded");
+    static_assert(DR >= -HALO && DR <= HALO, "halo too small");
+    constexpr int fl = floor_div8(q);
+    constexpr int m = (-fl) & 3;                 // block a+1 shares the physical block of a-3
+    constexpr int within = q - 8 * fl;
+    return base[m] + (HALO + DR) * LANE_B + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
+}
+
+template <int PH, int DR, int DK, int EDGE> __host__ __device__ constexpr Src tap_src() {
+    return (EDGE == 0) ? src_normal(DR, DK) : (EDGE == 1 ? src_start(PH, DR, DK) : src_end(PH, DR, DK));
+}
+template <int PH, int DR, int DK, int EDGE> __host__ __device__ constexpr bool tap_in_lds() {
+    constexpr Src s = tap_src<PH, DR, DK, EDGE>();
+    return s.kind == K_RING || s.kind == K_NYQ;
+}
+// One tap fetched from LDS.  PH: bin phase the tap belongs to (decides which taps are images / the Nyquist bin);
+// PB: clock of that bin relative to the start of the current block (PH, or 8 for phase 0 of the next block).
+template <int PH, int PB, int DR, int DK, int EDGE>  // EDGE: 0 normal, 1 frame start, 2 frame end
+__device__ __forceinline__ float2 tap_lds(const LaneCtx &cx) {
+    constexpr Src s = tap_src<PH, DR, DK, EDGE>();
+    static_assert(s.kind == K_RING || s.kind == K_NYQ, "register-sourced tap");
     float2 v;
-    if constexpr (s.kind == K_SELF) v = self_old;
-    else if constexpr (s.kind == K_NEXT) v = next_old;
-    else if constexpr (s.kind == K_NYQ) {
+    if constexpr (s.kind == K_NYQ) {
         // rare (one lane, last bins of a frame): Nyquist value of frame m+DR in the own / previous set
         const int ln = (cx.lane8 + 8 * DR) & (SLOT_BYTES - 1);
         v = lds_read(cx.nyq_base - cx.lane8 + ln - (s.set_new ? 0 : SLOT_BYTES));
-    }
-    else {
-        static_assert(s.off <= -1 && s.off >= -30, "tap outside ring retention (ages 1..30)");
-        v = lds_read(s.set_new ? ring_addr<P, s.off>(cx.nb[d]) : ring_addr<P, s.off>(cx.ob[d]));
+    } else {
+        static_assert(s.off <= -2 && s.off >= -30, "tap outside ring retention (ages 2..30)");
+        v = lds_read(s.set_new ? ring_addr<PB, s.off, DR>(cx.nb) : ring_addr<PB, s.off, DR>(cx.ob));
     }
     if constexpr (s.conj) v = cj(v);
     return v;
 }
+// register-sourced value of a tap (K_SELF / K_NEXT / K_PREV), conjugated if it is an image
+template <int PH, int DR, int DK, int EDGE>
+__device__ __forceinline__ float2 tap_reg(float2 self_old, float2 next_old, float2 prev_out) {
+    constexpr Src s = tap_src<PH, DR, DK, EDGE>();
+    float2 v = (s.kind == K_SELF) ? self_old : (s.kind == K_NEXT ? next_old : prev_out);
+    if constexpr (s.conj) v = cj(v);
+    return v;
+}
+template <int PH, int PB, int DR, int DK, int EDGE>
+__device__ __forceinline__ float2 tap_any(const LaneCtx &cx, float2 self_old, float2 next_old, float2 prev_out) {
+    if constexpr (tap_in_lds<PH, DR, DK, EDGE>()) return tap_lds<PH, PB, DR, DK, EDGE>(cx);
+    else return tap_reg<PH, DR, DK, EDGE>(self_old, next_old, prev_out);
+}
 
-// Normal-source taps of frame m+DR (DR != 0), bins c-L .. c+L: they are consecutive in production time, so
-// two of them come with each ds_read_b128.  KMASK bit |dk| says whether the tap is used.
-template <int P, int DR, int L, uint32_t KMASK>
-__device__ __forceinline__ void load_row(const LaneCtx &cx, float2 (&t)[2 * L + 1]) {
-    constexpr int d = DR < 0 ? -DR : DR;
+// Normal-source taps of frame m+DR (DR != 0) for the TWO bins of a pair: bins cA-L .. cA+L+1 are 2L+2 consecutive
+// production times starting on an even one (PA and L are odd), i.e. exactly L+1 aligned 16-byte cells -- one
+// ds_read_b128 each.  t[j] is the tap at bin cA - L + j: tap dk of bin A is t[dk+L], of bin B t[dk+L+1].
+// KMASK bit |dk| says whether tap dk is used (by either bin).
+template <int PA, int DR, int L, uint32_t KMASK>
+__device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L + 2]) {
+    static_assert((PA & 1) == 1 && (L & 1) == 1, "pairs start on odd phases; L odd");
     constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
-    constexpr int q_lo = P + base_off - L;                       // first tap, relative production time
-    constexpr int q_first = (q_lo >= 0) ? (q_lo & ~1) : -(((-q_lo) + 1) & ~1);   // round down to even
-    static_for<L + 2>([&](auto ip) {
-        constexpr int q = q_first + 2 * decltype(ip)::value;     // even
-        constexpr int dka = q - P - base_off, dkb = dka + 1;
-        constexpr bool in_a = dka >= -L && dka <= L, in_b = dkb >= -L && dkb <= L;
-        constexpr bool need_a = in_a && ((KMASK >> (dka < 0 ? -dka : dka)) & 1u);
-        constexpr bool need_b = in_b && ((KMASK >> (dkb < 0 ? -dkb : dkb)) & 1u);
-        if constexpr (need_a || need_b) {
-            static_assert(q >= -32 && q + 1 <= 7, "ring retention exceeded");
-            constexpr int fl = (q >= 0) ? 0 : -((-q + 7) / 8);
+    constexpr int q_first = PA + base_off - L;                   // even
+    static_for<L + 1>([&](auto ip) {
+        constexpr int j = 2 * decltype(ip)::value;
+        constexpr int q = q_first + j;
+        constexpr auto used = [](int jj) {                        // is t[jj] needed by bin A (dk = jj-L) or bin B (dk = jj-L-1)?
+            const int da = jj - L, db = jj - L - 1;
+            const bool na = da >= -L && da <= L && ((KMASK >> (da < 0 ? -da : da)) & 1u);
+            const bool nb = db >= -L && db <= L && ((KMASK >> (db < 0 ? -db : db)) & 1u);
+            return na || nb;
+        };
+        constexpr bool need0 = used(j), need1 = used(j + 1);
+        if constexpr (need0 || need1) {
+            static_assert(q >= -32 && q + 1 <= 15, "ring retention exceeded");
+            constexpr int fl = floor_div8(q);
             constexpr int m = (-fl) & 3;
-            constexpr int within = q - 8 * fl;                   // even, 0..6
-            const int addr = (DR < 0 ? cx.nb[d][m] : cx.ob[d][m]) + (within >> 1) * PAIR_BYTES;
-            if constexpr (need_a && need_b) {
+            constexpr int within = q - 8 * fl;                   // even
+            const int addr = (DR < 0 ? cx.nb[m] : cx.ob[m]) + (HALO + DR) * LANE_B + (within >> 1) * PAIR_BYTES;
+            if constexpr (need0 && need1) {
                 const v4f v = lds_read128(addr);
-                t[dka + L] = make_float2(v.x, v.y);
-                t[dkb + L] = make_float2(v.z, v.w);
-            } else if constexpr (need_a) {
-                t[dka + L] = lds_read(addr);
+                t[j] = make_float2(v.x, v.y);
+                t[j + 1] = make_float2(v.z, v.w);
+            } else if constexpr (need0) {
+                t[j] = lds_read(addr);
             } else {
-                t[dkb + L] = lds_read(addr + 8);
+                t[j + 1] = lds_read(addr + 8);
             }
         }
     });
 }
 
 // acc += w*b + conj(w)*c with w = (wr, wi) * j^ROT   (grouped form of lwslib.cpp:310-311)
-#ifndef LWS_PKMATH
-#define LWS_PKMATH 0
-#endif
-typedef float v2f __attribute__((ext_vector_type(2)));
 template <int ROT> __device__ __forceinline__ void pair_rot(float2 &a, float wr, float wi, float2 b, float2 c) {
 #if LWS_DBG_NOMATH
     a.x += b.x; a.y += c.y; return;
 #endif
-#if LWS_PKMATH
-    // packed fp32: (sx, sy) = b + c, (dx, dy) = b - c, then two v_pk_fma_f32
-    const v2f vb = {b.x, b.y}, vc = {c.x, c.y};
-    const v2f sm = vb + vc, df = vb - vc;
-    const v2f dsw = {df.y, df.x};
-    v2f acc = {a.x, a.y};
-    v2f w1, w2;
-    if constexpr (ROT == 0) { w1 = (v2f){wr, wr}; w2 = (v2f){-wi, wi}; }
-    else if constexpr (ROT == 1) { w1 = (v2f){-wi, -wi}; w2 = (v2f){-wr, wr}; }
-    else if constexpr (ROT == 2) { w1 = (v2f){-wr, -wr}; w2 = (v2f){wi, -wi}; }
-    else { w1 = (v2f){wi, wi}; w2 = (v2f){wr, -wr}; }
-    acc = __builtin_elementwise_fma(w1, sm, acc);
-    acc = __builtin_elementwise_fma(w2, dsw, acc);
-    a.x = acc.x; a.y = acc.y;
-#else
     const float sx = b.x + c.x, dy = b.y - c.y, sy = b.y + c.y, dx = b.x - c.x;
-    // two fused multiply-adds per component (weights are wave-uniform scalars)
+    // two fused multiply-adds per component (weights are wave-uniform scalars; the packed v_pk_* forms measured
+    // slower on gfx950)
     if constexpr (ROT == 0) { a.x = fmaf(-wi, dy, fmaf(wr, sx, a.x)); a.y = fmaf(wi, dx, fmaf(wr, sy, a.y)); }
     else if constexpr (ROT == 1) { a.x = fmaf(-wr, dy, fmaf(-wi, sx, a.x)); a.y = fmaf(wr, dx, fmaf(-wi, sy, a.y)); }
     else if constexpr (ROT == 2) { a.x = fmaf(wi, dy, fmaf(-wr, sx, a.x)); a.y = fmaf(-wi, dx, fmaf(-wr, sy, a.y)); }
     else { a.x = fmaf(wr, dy, fmaf(wi, sx, a.x)); a.y = fmaf(-wr, dx, fmaf(wi, sy, a.y)); }
-#endif
 }
-__device__ __forceinline__ float2 cadd(float2 p, float2 q) {
-#if LWS_PKMATH
-    const v2f r = (v2f){p.x, p.y} + (v2f){q.x, q.y};
-    return make_float2(r.x, r.y);
-#else
-    return make_float2(p.x + q.x, p.y + q.y);
-#endif
-}
-__device__ __forceinline__ float2 csub(float2 p, float2 q) {
-#if LWS_PKMATH
-    const v2f r = (v2f){p.x, p.y} - (v2f){q.x, q.y};
-    return make_float2(r.x, r.y);
-#else
-    return make_float2(p.x - q.x, p.y - q.y);
-#endif
-}
+__device__ __forceinline__ float2 cadd(float2 p, float2 q) { return make_float2(p.x + q.x, p.y + q.y); }
+__device__ __forceinline__ float2 csub(float2 p, float2 q) { return make_float2(p.x - q.x, p.y - q.y); }
 
-// The weighted sum of one bin at phase P (bin % 8 == P), all taps with compile-time ring offsets.
-template <int Q, int L, uint32_t MASK, int P>
-__device__ __forceinline__ float2 weighted_sum(const SysArgs &a, const LaneCtx &cx, float2 self_old, float2 next_old) {
-    constexpr int K1 = L + 1;
+// Contribution of the centre frame (W[.,0,k] does not depend on bin % Q) to the bin at phase PH / clock PB.
+template <int L, uint32_t MASK, int PH, int PB>
+__device__ __forceinline__ float2 centre_sum(const SysArgs &a, const LaneCtx &cx, bool st, bool en, float2 self_old,
+                                             float2 next_old, float2 prev_out) {
     float2 acc = make_float2(0.f, 0.f);
-    // centre frame: W[.,0,k] does not depend on bin % Q
-    {
-        float2 lo[L], hi[L];
-        static_for<L>([&](auto ik) {
-            constexpr int k = decltype(ik)::value + 1;
-            if constexpr ((MASK >> k) & 1u) {
-                lo[k - 1] = tap<P, 0, -k, 0>(cx, self_old, next_old);
-                hi[k - 1] = tap<P, 0, k, 0>(cx, self_old, next_old);
+    static_for<L>([&](auto ik) {
+        constexpr int k = decltype(ik)::value + 1;
+        if constexpr ((MASK >> k) & 1u) {
+            float2 lo = tap_any<PH, PB, 0, -k, 0>(cx, self_old, next_old, prev_out);
+            float2 hi = tap_any<PH, PB, 0, k, 0>(cx, self_old, next_old, prev_out);
+            if constexpr (PH - k < 0) {        // first bins of a frame: (m, c-k) is the image of bin k-c
+                if constexpr (tap_in_lds<PH, 0, -k, 1>()) { if (st) lo = tap_lds<PH, PB, 0, -k, 1>(cx); }
+                else { const float2 im = tap_reg<PH, 0, -k, 1>(self_old, next_old, prev_out); lo = st ? im : lo; }
             }
-        });
-        if constexpr (P < L) {
-            if (cx.is_start)
-                static_for<L>([&](auto ik) {
-                    constexpr int k = decltype(ik)::value + 1;
-                    if constexpr (((MASK >> k) & 1u) && (P - k < 0)) lo[k - 1] = tap<P, 0, -k, 1>(cx, self_old, next_old);
-                });
-        }
-        if constexpr (P + L >= 8) {
-            if (cx.is_end)
-                static_for<L>([&](auto ik) {
-                    constexpr int k = decltype(ik)::value + 1;
-                    if constexpr (((MASK >> k) & 1u) && (P + k >= 8)) hi[k - 1] = tap<P, 0, k, 2>(cx, self_old, next_old);
-                });
-        }
-        static_for<L>([&](auto ik) {
-            constexpr int k = decltype(ik)::value + 1;
-            if constexpr ((MASK >> k) & 1u) pair_rot<0>(acc, a.w[2 * k], a.w[2 * k + 1], lo[k - 1], hi[k - 1]);
-        });
-    }
-    static_for<Q - 1>([&](auto ir) {
-        constexpr int r = decltype(ir)::value + 1;
-        constexpr int mod = P % Q;
-        constexpr int rot = ((mod * r) % Q) * (4 / Q);  // quarter turns of exp(2j*pi*mod*r/Q)
-        // taps of frames m-r (up) and m+r (dn), bins c-L .. c+L
-        float2 up[2 * L + 1], dn[2 * L + 1];
-        constexpr uint32_t kmask = (MASK >> (r * K1)) & ((1u << K1) - 1u);
-        load_row<P, -r, L, kmask>(cx, up);
-        load_row<P, r, L, kmask>(cx, dn);
-        if constexpr (P < L) {
-            if (cx.is_start)
-                static_for<L>([&](auto ik) {
-                    constexpr int k = decltype(ik)::value + 1;
-                    if constexpr (((MASK >> (r * K1 + k)) & 1u) && (P - k < 0)) {
-                        up[L - k] = tap<P, -r, -k, 1>(cx, self_old, next_old);
-                        dn[L - k] = tap<P, r, -k, 1>(cx, self_old, next_old);
-                    }
-                });
-        }
-        if constexpr (P + L >= 8) {
-            if (cx.is_end)
-                static_for<L>([&](auto ik) {
-                    constexpr int k = decltype(ik)::value + 1;
-                    if constexpr (((MASK >> (r * K1 + k)) & 1u) && (P + k >= 8)) {
-                        up[L + k] = tap<P, -r, k, 2>(cx, self_old, next_old);
-                        dn[L + k] = tap<P, r, k, 2>(cx, self_old, next_old);
-                    }
-                });
-        }
-        float2 accr = make_float2(0.f, 0.f);  // one accumulator per frame pair: independent dependency chains
-        if constexpr ((MASK >> (r * K1)) & 1u)
-            pair_rot<rot>(accr, a.w[2 * (r * K1)], a.w[2 * (r * K1) + 1], up[L], dn[L]);
-        static_for<L>([&](auto ik) {
-            constexpr int k = decltype(ik)::value + 1;
-            if constexpr ((MASK >> (r * K1 + k)) & 1u) {
-                // W[mod]*S[m-r,c-k] + conj(W[mod])*S[m+r,c-k] + W[-mod]*S[m+r,c+k] + conj(W[-mod])*S[m-r,c+k]
-                // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
-                const float wr = a.w[2 * (r * K1 + k)], wi = a.w[2 * (r * K1 + k) + 1];
-                float2 b, c;
-                if constexpr ((rot & 1) == 0) { b = cadd(up[L - k], dn[L + k]); c = cadd(dn[L - k], up[L + k]); }
-                else { b = csub(up[L - k], dn[L + k]); c = csub(dn[L - k], up[L + k]); }
-                pair_rot<rot>(accr, wr, wi, b, c);
+            if constexpr (PH + k >= 8) {       // last bins of a frame: Nyquist bin or an image
+                if constexpr (tap_in_lds<PH, 0, k, 2>()) { if (en) hi = tap_lds<PH, PB, 0, k, 2>(cx); }
+                else { const float2 im = tap_reg<PH, 0, k, 2>(self_old, next_old, prev_out); hi = en ? im : hi; }
             }
-        });
-        acc = cadd(acc, accr);
+            pair_rot<0>(acc, a.w[2 * k], a.w[2 * k + 1], lo, hi);
+        }
     });
     return acc;
+}
+
+// Contribution of frames m-R and m+R to the bin at phase PH / clock PB; OFFS = 0 / 1: first / second bin of the pair
+template <int Q, int L, uint32_t MASK, int PH, int PB, int R, int OFFS>
+__device__ __forceinline__ float2 rows_sum(const SysArgs &a, const LaneCtx &cx, bool st, bool en,
+                                           const float2 (&tu)[2 * L + 2], const float2 (&td)[2 * L + 2]) {
+    constexpr int K1 = L + 1;
+    constexpr int mod = PH % Q;
+    constexpr int rot = ((mod * R) % Q) * (4 / Q);  // quarter turns of exp(2j*pi*mod*R/Q)
+    float2 up[2 * L + 1], dn[2 * L + 1];
+    static_for<2 * L + 1>([&](auto id) {
+        constexpr int i = decltype(id)::value;
+        constexpr int k = i < L ? L - i : i - L;
+        if constexpr ((MASK >> (R * K1 + k)) & 1u) { up[i] = tu[i + OFFS]; dn[i] = td[i + OFFS]; }
+    });
+    if constexpr (PH < L) {
+        if (st)
+            static_for<L>([&](auto ik) {
+                constexpr int k = decltype(ik)::value + 1;
+                if constexpr (((MASK >> (R * K1 + k)) & 1u) && (PH - k < 0)) {
+                    up[L - k] = tap_lds<PH, PB, -R, -k, 1>(cx);
+                    dn[L - k] = tap_lds<PH, PB, R, -k, 1>(cx);
+                }
+            });
+    }
+    if constexpr (PH + L >= 8) {
+        if (en)
+            static_for<L>([&](auto ik) {
+                constexpr int k = decltype(ik)::value + 1;
+                if constexpr (((MASK >> (R * K1 + k)) & 1u) && (PH + k >= 8)) {
+                    up[L + k] = tap_lds<PH, PB, -R, k, 2>(cx);
+                    dn[L + k] = tap_lds<PH, PB, R, k, 2>(cx);
+                }
+            });
+    }
+    float2 accr = make_float2(0.f, 0.f);
+    if constexpr ((MASK >> (R * K1)) & 1u)
+        pair_rot<rot>(accr, a.w[2 * (R * K1)], a.w[2 * (R * K1) + 1], up[L], dn[L]);
+    static_for<L>([&](auto ik) {
+        constexpr int k = decltype(ik)::value + 1;
+        if constexpr ((MASK >> (R * K1 + k)) & 1u) {
+            // W[mod]*S[m-r,c-k] + conj(W[mod])*S[m+r,c-k] + W[-mod]*S[m+r,c+k] + conj(W[-mod])*S[m-r,c+k]
+            // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
+            const float wr = a.w[2 * (R * K1 + k)], wi = a.w[2 * (R * K1 + k) + 1];
+            float2 b, c;
+            if constexpr ((rot & 1) == 0) { b = cadd(up[L - k], dn[L + k]); c = cadd(dn[L - k], up[L + k]); }
+            else { b = csub(up[L - k], dn[L + k]); c = csub(dn[L - k], up[L + k]); }
+            pair_rot<rot>(accr, wr, wi, b, c);
+        }
+    });
+    return accr;
 }
 
 // Magnitude re-projection (lwslib.cpp:356-360): keep the old value unless the bin is active and the sum is
@@ -434,47 +423,66 @@ __device__ __forceinline__ float2 project(float2 acc, float target, bool active,
     return ok ? make_float2(ax * sc, ay * sc) : old;
 }
 
-// Per-lane bookkeeping of a sweep processor at clock v: which (sweep, frame) it is working on.
-struct RowInfo { bool valid, real; int j, me; };
-__device__ __forceinline__ RowInfo row_info(int vv /* v - 8*rho, start of frame relative clock */, int slot,
-                                            const SysArgs &a, int n_eff, int Q) {
-    RowInfo r;
-    const int kap = vv >> 9;  // ROWP == 512
-    const int g = kap / a.Kr, k = kap - g * a.Kr;
-    r.me = k * LANES;  // caller adds rho
-    r.j = g * NSLOTS + slot;
-    r.valid = (vv >= 0) && (r.j < n_eff);
-    r.real = false;
-    (void)Q;
-    return r;
-}
+// Registers a compute lane carries from pair to pair: the previous sweep's values of its next bins and its last output.
+struct Carry { float2 o0, o1, o2, prev_out; };
 
-template <int Q, int L, uint32_t MASK, int P>
-__device__ __forceinline__ void compute_step(const SysArgs &a, const LaneCtx &cx, int lane, int vmod /* clock mod G at phase 0 */,
-                                             float2 &self_old, float2 &next_old, const float (&amp_cur)[8], float2 *state_w_b) {
-    // taps, weighted sum, projection
-    const float2 acc = weighted_sum<Q, L, MASK, P>(a, cx, self_old, next_old);
-    const float target = amp_cur[P];
-    const bool active = cx.live && (target > cx.thr);
-    const float2 out = project(acc, target, active, self_old);
-    // publish: own set, slot (v mod 32) = block m = 0, within = P
-    lds_write(cx.nb[0][0] + (P >> 1) * PAIR_BYTES + (P & 1) * 8, out);
-    if (cx.store) state_w_b[(size_t)(vmod + P) * LANES + lane] = out;   // G is a multiple of 8: no wrap inside a block
-    // prefetch: previous-sweep value of the own bin two steps ahead (age 30 now: no ring read is ever older,
-    // which leaves two steps between the last read of an entry and its overwrite)
-    self_old = next_old;
-    next_old = lds_read(ring_addr<P, -30>(cx.ob[0]));
+// One pair of bins (phases PA odd, PA+1) of one lane.
+template <int Q, int L, uint32_t MASK, int PA>
+__device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx, int lane, int vmod, int G, Carry &cr,
+                                             const float (&amp_cur)[8], const float (&amp_nxt)[8], float2 *state_w_b) {
+    constexpr int K1 = L + 1;
+    constexpr int PHB = (PA + 1) & 7, PBB = PA + 1;          // second bin: phase and clock relative to this block
+    constexpr bool wrap = (PA == 7);                         // the second bin belongs to the next block
+    const bool stA = cx.is_start, enA = cx.is_end;
+    const bool stB = wrap ? cx.nxt_start : cx.is_start, enB = wrap ? cx.nxt_end : cx.is_end;
+    // previous-sweep values of the own bins of the NEXT pair (ages 29 and 28 now, 31 and 30 by then)
+    const float2 o3 = lds_read(ring_addr<PA, 3 - LAG>(cx.ob));
+    const float2 o4 = lds_read(ring_addr<PA, 4 - LAG>(cx.ob));
+    float2 accA = centre_sum<L, MASK, PA, PA>(a, cx, stA, enA, cr.o0, cr.o1, cr.prev_out);
+    float2 accB = make_float2(0.f, 0.f);
+    // frame pairs m-+R, one after the other (scheduling fences keep the compiler from hoisting every fetch to the top,
+    // which would not fit the register file; the other wave of the SIMD covers the LDS latency)
+    static_for<Q - 1>([&](auto ir) {
+        constexpr int R = decltype(ir)::value + 1;
+        constexpr uint32_t kmask = (MASK >> (R * K1)) & ((1u << K1) - 1u);
+        float2 tu[2 * L + 2], td[2 * L + 2];
+        load_row2<PA, -R, L, kmask>(cx, tu);
+        load_row2<PA, R, L, kmask>(cx, td);
+        accA = cadd(accA, rows_sum<Q, L, MASK, PA, PA, R, 0>(a, cx, stA, enA, tu, td));
+        accB = cadd(accB, rows_sum<Q, L, MASK, PHB, PBB, R, 1>(a, cx, stB, enB, tu, td));
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    // ---- first bin
+    const float tA = amp_cur[PA];
+    const float2 outA = project(accA, tA, cx.live && (tA > cx.thr), cr.o0);
+    ring_publish(ring_addr<PA, 0>(cx.nb), cx.halo_shift, outA);
+    if (cx.store) state_w_b[(size_t)(vmod + PA) * LANES + lane] = outA;   // G is a multiple of 8: no wrap inside a block
+    // ---- second bin (its centre taps include the first bin's result)
+    accB = cadd(accB, centre_sum<L, MASK, PHB, PBB>(a, cx, stB, enB, cr.o1, cr.o2, outA));
+    const float tB = wrap ? amp_nxt[0] : amp_cur[PBB & 7];
+    const bool liveB = wrap ? cx.nxt_live : cx.live;
+    const float2 outB = project(accB, tB, liveB && (tB > (wrap ? cx.nxt_thr : cx.thr)), cr.o1);
+    ring_publish(ring_addr<PBB, 0>(cx.nb), cx.halo_shift, outB);
+    if (wrap ? cx.nxt_store : cx.store) {
+        int ib = vmod + PBB;
+        ib -= (ib >= G) ? G : 0;
+        state_w_b[(size_t)ib * LANES + lane] = outB;
+    }
+    cr.prev_out = outB;
+    cr.o0 = cr.o2;
+    cr.o1 = o3;
+    cr.o2 = o4;
 }
 
 // State of the service duties (HBM loader for set 0 and the Nyquist bins of every sweep slot).
 struct ServiceState {
-    float2 pend[PF];        // loader: values in flight from HBM
     float nyq_amp_next;     // Nyquist lanes: target magnitude of the next block's Nyquist bin
     float2 nyq_in_next;     // Nyquist loader lane: previous-sweep Nyquist value of the next block's frame
 };
 
-// Phase 0 of a block: lane l < NSLOTS computes the Nyquist bin (bin C = F-1) of the frame of sweep slot l whose
-// 512-step period has just ended; lane NSLOTS feeds set 0 with the stored Nyquist value of that frame.
+// Lane l < NSLOTS computes the Nyquist bin (bin C = F-1) of the frame of sweep slot l whose 512-step period ended at
+// clock t0 (phase 0 of the current block); lane NSLOTS feeds set 0 with the stored Nyquist value of that frame.
+// Called at the start of the first pair of the block, when every slot has published bins C-1, C-2, ...
 template <int Q, int L, uint32_t MASK>
 __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &sv, int lane, int t0, int n_eff,
                                                 int n_groups, const float *thr_eff, float2 *state_nyq_b,
@@ -512,7 +520,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int blk = ((ablk - m) & 3) * BLK_BYTES;
-                nb[d][m] = set_new + blk + ln * LANE_B;
+                nb[d][m] = set_new + blk + ln * LANE_B;   // ring_addr adds the HALO offset
                 ob[d][m] = set_old + blk + lo * LANE_B;
             }
         }
@@ -564,6 +572,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const float *amp_w_b = a.amp_w + (size_t)b * G * LANES;
     float2 *state_nyq_b = a.state_nyq + (size_t)b * a.TpPad;
     const float *amp_nyq_b = a.amp_nyq + (size_t)b * a.TpPad;
+    constexpr int T_START = -8;   // one block of warm-up: the pair (7, 0') of block -1 produces clock 0
 
     // sweeps whose threshold is not below the largest magnitude cannot change anything: drop them
     if (threadIdx.x == 0) {
@@ -577,7 +586,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     }
     // poison-free start: rings may hold anything, but zero keeps the arithmetic of idle lanes finite
     for (int i = threadIdx.x; i < THR_OFF / 8; i += NTHREADS) reinterpret_cast<float2 *>(smem)[i] = make_float2(0.f, 0.f);
-    if (threadIdx.x < 16) reinterpret_cast<int *>(smem + DONE_OFF)[threadIdx.x] = 0;
+    if (threadIdx.x < 16) reinterpret_cast<int *>(smem + DONE_OFF)[threadIdx.x] = T_START + 1;
     __syncthreads();
     const int n_eff = meta[0];
     if (n_eff == 0) return;
@@ -586,75 +595,81 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const int t_end = (n_groups - 1) * G + (NSLOTS + 1) * LAG + SKEW * a.Tp + ROWP + 8;
 
     const bool is_compute = wave < NSLOTS;
-    const bool is_service = LWS_SERVICE_WAVE ? (wave == NSLOTS) : (wave == NSLOTS - 1);
+    const bool is_service = (wave == NSLOTS);
     const int slot = wave;
     LaneCtx cx;
-    float2 self_old = make_float2(0.f, 0.f), next_old = make_float2(0.f, 0.f);
+    Carry cr;
+    cr.o0 = cr.o1 = cr.o2 = cr.prev_out = make_float2(0.f, 0.f);
     // target magnitudes of the current block's 8 bins and (in flight) of the next block's: all 8 global loads of a
     // block are issued together one block ahead, so no step ever waits on HBM latency
+    // (a wave is either a sweep slot or the service wave: the 16 registers below hold amp_cur[8] | amp_nxt[8] for the
+    //  former and the loader's 8 complex values in flight for the latter)
     float amp_cur[8], amp_nxt[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) amp_cur[i] = amp_nxt[i] = 0.f;
     ServiceState sv;
-#pragma unroll
-    for (int i = 0; i < PF; ++i) sv.pend[i] = make_float2(0.f, 0.f);
     sv.nyq_amp_next = 0.f;
     sv.nyq_in_next = make_float2(0.f, 0.f);
     if (is_service) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) sv.pend[i] = load_l2(state_w_b + (size_t)(i % G) * LANES + lane);  // clocks 0..7
+        for (int i = 0; i < 8; ++i) {   // clocks 0..7
+            const float2 v = load_l2(state_w_b + (size_t)i * LANES + lane);
+            amp_cur[i] = v.x;
+            amp_nxt[i] = v.y;
+        }
     }
     const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
-    // flow control: which waves this wave waits for (lane l watches wave l), and how far behind they may be
-    constexpr int NWAVES = NSLOTS + LWS_SERVICE_WAVE, SVC = LWS_SERVICE_WAVE ? NSLOTS : NSLOTS - 1, FAR = 1 << 29;
-    int req_off = FAR, req_off_p0 = FAR;
-    if (lane < NWAVES) {
-        if (LWS_SERVICE_WAVE && wave == SVC) {
-            // loader overwrites what slot 0 still reads; Nyquist lanes read last step's bins of every slot at phase 0
-            req_off = (lane == 0) ? 1 : FAR;
-            req_off_p0 = (lane < NSLOTS) ? 0 : FAR;
-        } else {
-            const int producer = (wave == 0) ? SVC : wave - 1;
-            if (lane == producer || lane == SVC) req_off = 2;
-            if (lane == wave + 1 && lane < NSLOTS) req_off = 1;
-            if (lane == wave) req_off = FAR;
-            req_off_p0 = req_off;
-        }
+    // flow control: lane l watches wave l.  A compute wave waits for its producer, its consumer and the service wave;
+    // the service wave for every compute wave (loader overwrites what slot 0 reads; the Nyquist lanes read every slot).
+    bool watched = false;
+    if (lane <= NSLOTS) {
+        if (is_service) watched = lane < NSLOTS;
+        else watched = (lane == wave - 1) || (lane == wave + 1) || (lane == NSLOTS);
     }
-    for (int t0 = 0; t0 < t_end; t0 += 8) {
+    for (int t0 = T_START; t0 < t_end; t0 += 8) {
         const int v0 = t0 - (slot + 1) * LAG;  // clock of this sweep slot at phase 0 of the block (multiple of 8)
-        // ---- block prologue: where is this lane?
-        const int vv = v0 - SKEW * lane;        // clock relative to the start of lane's first frame
-        const int cbase = vv & (ROWP - 1);
-        const int kap = vv >> 9;
-        const int g = kap / Kr, k = kap - g * Kr;
-        const int me = k * LANES + lane;
-        const int j = g * NSLOTS + slot;
-        const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
-        const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
-        cx.live = real_row && (cbase < C);
-        cx.store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
-        cx.is_start = (cbase == 0);
-        cx.is_end = (cbase == C - 8);
-        cx.thr = thr_eff[(valid ? j : 0)];
+        // ---- block prologue: where is this lane in this block and in the next one?
         const int ablk = (v0 >> 3);
+        {
+            const int vv = v0 - SKEW * lane;        // clock relative to the start of the lane's first frame
+            const int cbase = vv & (ROWP - 1);
+            const int kap = vv >> 9;
+            const int g = kap / Kr, k = kap - g * Kr;
+            const int me = k * LANES + lane;
+            const int j = g * NSLOTS + slot;
+            const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
+            cx.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
+            cx.store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
+            cx.is_start = (cbase == 0);
+            cx.is_end = (cbase == C - 8);
+            cx.thr = thr_eff[(valid ? j : 0)];
+        }
+        {
+            const int vv = v0 + 8 - SKEW * lane;
+            const int cbase = vv & (ROWP - 1);
+            const int kap = vv >> 9;
+            const int g = kap / Kr, k = kap - g * Kr;
+            const int me = k * LANES + lane;
+            const int j = g * NSLOTS + slot;
+            const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
+            cx.nxt_live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
+            cx.nxt_store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
+            cx.nxt_start = (cbase == 0);
+            cx.nxt_end = (cbase == C - 8);
+            cx.nxt_thr = thr_eff[(valid ? j : 0)];
+        }
         cx.lane8 = lane * 8;
         cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + lane * 8;
+        cx.halo_shift = (lane < HALO) ? LANES * LANE_B : (lane >= LANES - HALO ? -LANES * LANE_B : 0);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int ln = ((lane - d) & 63) * LANE_B, lo = ((lane + d) & 63) * LANE_B;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int blk = ((ablk - m) & 3) * BLK_BYTES;
-                cx.nb[d][m] = set_new + blk + ln;
-                cx.ob[d][m] = set_old + blk + lo;
-            }
+        for (int m = 0; m < 4; ++m) {
+            const int blk = ((ablk - m) & 3) * BLK_BYTES;
+            cx.nb[m] = set_new + blk + lane * LANE_B;
+            cx.ob[m] = set_old + blk + lane * LANE_B;
         }
-        // one block early, so that the prefetched own-old value and magnitudes are warm at the first bin
-        const bool any_valid = is_compute && __any((vv >= -8) && (j < n_eff || vv < 0));
         const int vmod = __builtin_amdgcn_readfirstlane(((v0 % G) + G) % G);  // wave-uniform, once per 8 steps
-        const int tmod = __builtin_amdgcn_readfirstlane(t0 % G);
-        {
+        const int tmod = __builtin_amdgcn_readfirstlane(((t0 % G) + G) % G);
+        if (is_compute) {
             int vnext = vmod + 8;
             vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
 #pragma unroll
@@ -663,35 +678,30 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 amp_nxt[i] = amp_w_b[(size_t)(vnext + i) * LANES + lane];
             }
         }
-#if LWS_FLOW
-        flow_wait(lane, t0, req_off_p0);
-#endif
-        // ---- Nyquist bins of all slots fall on phase 0 (C is a multiple of 8)
-        if (is_service) service_nyquist<Q, L, MASK>(a, sv, lane, t0, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
-        // ---- 8 steps, phase static
-        static_for<8>([&](auto ip) {
-            constexpr int P = decltype(ip)::value;
-#if LWS_FLOW
-            if constexpr (P > 0) flow_wait(lane, t0 + P, req_off);
-#endif
-            if (any_valid)
-                compute_step<Q, L, MASK, P>(a, cx, lane, vmod, self_old, next_old, amp_cur, state_w_b);
+        // ---- 4 pairs of bins, phases static
+        static_for<4>([&](auto ip) {
+            constexpr int PA = 2 * decltype(ip)::value + 1;
+            flow_wait(lane, t0 + PA, watched);
+            if (is_compute) compute_pair<Q, L, MASK, PA>(a, cx, lane, vmod, G, cr, amp_cur, amp_nxt, state_w_b);
             if (is_service) {
-                // loader: feed set 0 with the values the virtual previous sweep would produce, PF steps ahead
-                lds_write(((t0 >> 3) & 3) * BLK_BYTES + (P >> 1) * PAIR_BYTES + (P & 1) * 8 + lane * LANE_B, sv.pend[P % PF]);
-                int ild = tmod + P + PF;
-                ild -= (ild >= G) ? G : 0;
-#if LWS_DBG_NOLDS && LWS_DBG_NOMATH
-                sv.pend[P % PF] = make_float2((float)ild, 0.f);   // skeleton timing: no HBM latency floor either
-#else
-                sv.pend[P % PF] = load_l2(state_w_b + (size_t)ild * LANES + lane);
-#endif
+                // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
+                if constexpr (PA == 1)
+                    service_nyquist<Q, L, MASK>(a, sv, lane, t0, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+                // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
+                int ldb[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) ldb[m] = (((t0 >> 3) - m) & 3) * BLK_BYTES + lane * LANE_B;
+                ring_publish(ring_addr<PA, 0>(ldb), cx.halo_shift, make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]));
+                ring_publish(ring_addr<PA + 1, 0>(ldb), cx.halo_shift, make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]));
+                int i0 = tmod + PA + 8, i1 = tmod + PA + 9;
+                i0 -= (i0 >= G) ? G : 0;
+                i1 -= (i1 >= G) ? G : 0;
+                const float2 p0 = load_l2(state_w_b + (size_t)i0 * LANES + lane);
+                const float2 p1 = load_l2(state_w_b + (size_t)i1 * LANES + lane);
+                amp_cur[PA & 7] = p0.x; amp_nxt[PA & 7] = p0.y;
+                amp_cur[(PA + 1) & 7] = p1.x; amp_nxt[(PA + 1) & 7] = p1.y;
             }
-#if LWS_FLOW
-            flow_publish(lane, wave, t0 + P + 1);
-#else
-            step_barrier<P>();
-#endif
+            flow_publish(lane, wave, t0 + PA + 2);
         });
     }
 }
