@@ -52,13 +52,18 @@ constexpr int RING = 32;
 // -- two consecutive times of one lane share a 16-byte cell, so a reader fetches two adjacent taps with one
 // ds_read_b128; every row of 64 lanes carries HALO copies of the opposite end on each side (lanes -3..-1 mirror
 // 61..63, lanes 64..66 mirror 0..2), so "the lane d frames above / below" is a compile-time address offset and a
-// lane needs one base register per ring block instead of one per (neighbour, block).
+// lane needs one base register per ring block instead of one per (neighbour, block).  Two more pseudo-lanes per row
+// hold the Hermitian images: lane PLL the bins -1..-L of the frames (at the production times those bins would have,
+// 8m - j), lane PLR the Nyquist bin and the bins above it (times 8m + C + j), written conjugated by the lane that
+// produces the mirrored bin -- the reference's pad columns (lwslib.cpp:362-367), kept in time coordinates.  A lane
+// near a frame edge reads those cells instead of its neighbour lane's: same compile-time offsets, other base.
 constexpr int SLOT_BYTES = LANES * 8;                    // Nyquist buffer: bytes per set (64 float2)
 constexpr int HALO = 3;                                  // >= Q - 1
 constexpr int LANE_B = 16;
-constexpr int PAIR_BYTES = (LANES + 2 * HALO) * LANE_B;  // two consecutive times x 70 lanes
+constexpr int PLL = LANES + 2 * HALO, PLR = PLL + 1;      // absolute row indices of the two image pseudo-lanes
+constexpr int PAIR_BYTES = (LANES + 2 * HALO + 2) * LANE_B;  // two consecutive times x 72 row entries
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
-constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 17.5 KiB
+constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB
 #ifndef LWS_NSLOTS
 #define LWS_NSLOTS 7
 #endif
@@ -72,7 +77,8 @@ constexpr int THR_OFF = NYQ_OFF + NSETS * SLOT_BYTES;    // effective thresholds
 constexpr int MAX_ITERS = 440;
 constexpr int META_OFF = THR_OFF + MAX_ITERS * 4;        // n_eff
 constexpr int DONE_OFF = META_OFF + 16;               // per-wave count of completed steps (flow control)
-constexpr int LDS_BYTES = DONE_OFF + 64;
+constexpr int DUMMY_OFF = DONE_OFF + 64;               // 64 x 8 B: where predicated-off lanes park their conditional writes
+constexpr int LDS_BYTES = DUMMY_OFF + LANES * 8;
 constexpr int SKEW = 8, ROWP = SKEW * LANES, LAG = 32;
 #ifndef LWS_SERVICE_WAVE
 #define LWS_SERVICE_WAVE 1   // loader + Nyquist bins run on a wave of their own
@@ -209,10 +215,12 @@ __device__ __forceinline__ void flow_publish(int lane, int wave, int s_next) {
 
 // Per-lane registers of a compute lane that stay valid for one block of 8 steps.
 struct LaneCtx {
-    int nb[4];        // [m]: LDS address of this lane's halo-shifted origin in the own (new) set, block (a - m) & 3
-    int ob[4];        // [m]: the same in the previous sweep's (old) set
+    int ob[4];        // [m]: LDS address of this lane's halo-shifted origin in the previous sweep's (old) set, block (a - m) & 3;
+                      //      the own (new) set is the next one: + SET_BYTES, a compile-time offset
+    int uo[4];        // [m]: wave-uniform row origin (set + block) of the old set, for the image pseudo-lanes
     int nyq_base;     // NYQ_OFF + own set row + lane*8 (taps derive the neighbour lane / set from it)
     int halo_shift;   // +-64 lanes in bytes for the 6 lanes that also write a halo copy, else 0
+    int dummy;        // private LDS slot for predicated-off conditional writes
     int lane8;
     bool is_start, is_end, live, store;          // this block (8 bins of one frame)
     bool nxt_start, nxt_end, nxt_live, nxt_store; // the following block (possibly the next frame of the lane)
@@ -222,21 +230,61 @@ struct LaneCtx {
 __host__ __device__ constexpr int floor_div8(int q) { return (q >= 0) ? q / 8 : -((-q + 7) / 8); }
 
 // write a lane's value and, for the first / last HALO lanes, its halo copy at the other end of the row
-__device__ __forceinline__ void ring_publish(int addr, int halo_shift, float2 v) {
+// (branch-free: the 58 lanes without a halo copy write to a private dummy slot instead -- an exec-masked branch per
+//  conditional write costs more than the write)
+#ifndef LWS_DBG_NOIMG
+#define LWS_DBG_NOIMG 0     // timing experiment: no halo / image writes (results invalid)
+#endif
+#ifndef LWS_DBG_NOWRAP2
+#define LWS_DBG_NOWRAP2 0   // timing experiment: the straddling pair shares one set of fetches (results invalid)
+#endif
+__device__ __forceinline__ void ring_publish(int addr, int halo_shift, int dummy, float2 v) {
     lds_write(addr, v);
-    if (halo_shift != 0) lds_write(addr + halo_shift, v);
+#if !LWS_DBG_NOIMG
+    lds_write(halo_shift != 0 ? addr + halo_shift : dummy, v);
+#endif
 }
 
 // address of the ring entry of the lane DR frames away, produced at clock (block start + P + OFF); P may be 8
 // (phase 0 of the next block).  base[m] addresses lane - HALO of block (a - m) & 3.
-template <int P, int OFF, int DR = 0> __device__ __forceinline__ int ring_addr(const int (&base)[4]) {
+// NEWSET: 1 = the lane's own output set (base + SET_BYTES), 0 = the set base[] points to.
+template <int P, int OFF, int DR = 0, int NEWSET = 0> __device__ __forceinline__ int ring_addr(const int (&base)[4]) {
     constexpr int q = P + OFF;
     static_assert(q >= -32 && q <= 15, "ring retention exceeded");
     static_assert(DR >= -HALO && DR <= HALO, "halo too small");
     constexpr int fl = floor_div8(q);
     constexpr int m = (-fl) & 3;                 // block a+1 shares the physical block of a-3
     constexpr int within = q - 8 * fl;
-    return base[m] + (HALO + DR) * LANE_B + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
+    return base[m] + NEWSET * SET_BYTES + (HALO + DR) * LANE_B + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
+}
+
+// the same for an absolute row index (halo copies, image pseudo-lanes); base[m] is the row origin (set + block)
+template <int P, int OFF, int LIDX, int NEWSET = 0> __device__ __forceinline__ int ring_addr_abs(const int (&base)[4]) {
+    constexpr int q = P + OFF;
+    static_assert(q >= -32 && q <= 15, "ring retention exceeded");
+    constexpr int fl = floor_div8(q);
+    constexpr int m = (-fl) & 3;
+    constexpr int within = q - 8 * fl;
+    return base[m] + NEWSET * SET_BYTES + LIDX * LANE_B + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
+}
+
+// Hermitian image upkeep (lwslib.cpp:362-367 in time coordinates): the lane that has just produced bin j in 1..L of
+// its frame (phase PH = j, flag st) or bin C-j (phase PH = 8-j, flag en) stores the conjugate where bin -j / C+j
+// would have been produced: 2j steps earlier / later.  `u` = wave-uniform row origins of the lane's output set.
+template <int L, int PH, int PB, int NEWSET>
+__device__ __forceinline__ void image_publish(const int (&u)[4], bool st, bool en, int dummy, float2 out) {
+#if LWS_DBG_NOIMG
+    return;
+#endif
+    constexpr bool lo = (PH >= 1 && PH <= L), hi = (PH >= 8 - L && PH <= 7);
+    if constexpr (lo && hi) {   // a lane is at the start or at the end of a frame, never both
+        const int a_lo = ring_addr_abs<PB, -2 * PH, PLL, NEWSET>(u), a_hi = ring_addr_abs<PB, 2 * (8 - PH), PLR, NEWSET>(u);
+        lds_write(st ? a_lo : (en ? a_hi : dummy), cj(out));
+    } else if constexpr (lo) {
+        lds_write(st ? ring_addr_abs<PB, -2 * PH, PLL, NEWSET>(u) : dummy, cj(out));
+    } else if constexpr (hi) {
+        lds_write(en ? ring_addr_abs<PB, 2 * (8 - PH), PLR, NEWSET>(u) : dummy, cj(out));
+    }
 }
 
 template <int PH, int DR, int DK, int EDGE> __host__ __device__ constexpr Src tap_src() {
@@ -259,7 +307,7 @@ __device__ __forceinline__ float2 tap_lds(const LaneCtx &cx) {
         v = lds_read(cx.nyq_base - cx.lane8 + ln - (s.set_new ? 0 : SLOT_BYTES));
     } else {
         static_assert(s.off <= -2 && s.off >= -30, "tap outside ring retention (ages 2..30)");
-        v = lds_read(s.set_new ? ring_addr<PB, s.off, DR>(cx.nb) : ring_addr<PB, s.off, DR>(cx.ob));
+        v = lds_read(ring_addr<PB, s.off, DR, s.set_new>(cx.ob));
     }
     if constexpr (s.conj) v = cj(v);
     return v;
@@ -278,31 +326,47 @@ __device__ __forceinline__ float2 tap_any(const LaneCtx &cx, float2 self_old, fl
     else return tap_reg<PH, DR, DK, EDGE>(self_old, next_old, prev_out);
 }
 
-// Normal-source taps of frame m+DR (DR != 0) for the TWO bins of a pair: bins cA-L .. cA+L+1 are 2L+2 consecutive
-// production times starting on an even one (PA and L are odd), i.e. exactly L+1 aligned 16-byte cells -- one
-// ds_read_b128 each.  t[j] is the tap at bin cA - L + j: tap dk of bin A is t[dk+L], of bin B t[dk+L+1].
-// KMASK bit |dk| says whether tap dk is used (by either bin).
-template <int PA, int DR, int L, uint32_t KMASK>
-__device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L + 2]) {
+// Taps of frame m+DR (DR != 0) for the TWO bins of a pair: bins cA-L .. cA+L+1 are 2L+2 consecutive production times
+// starting on an even one (PA and L are odd), i.e. exactly L+1 aligned 16-byte cells -- one ds_read_b128 each.
+// t[j] is the tap at bin cA - L + j: tap dk of bin A is t[dk+L], of bin B t[dk+L+1].  KMASK bit |dk|: tap used.
+// Cells are (even bin, odd bin) pairs, so a cell lies entirely inside the frame or entirely among its images; for
+// the one lane of a wave at the start (st) / end (en) of its frame the image cells come from the pseudo-lanes.
+// MODE 0: both bins in one frame.  The pair (7, 0') straddles two frames of the lane, and the same production times
+// hold the images above Nyquist of the old frame (pseudo-lane PLR) and the first bins of the new one (real lane):
+// MODE 1 fetches bin A's view (en = last bin of a frame), MODE 2 bin B's (st = first bin of a frame).
+template <int PA, int DR, int L, uint32_t KMASK, int MODE>
+__device__ __forceinline__ void load_row2(const LaneCtx &cx, bool st, bool en, float2 (&t)[2 * L + 2]) {
     static_assert((PA & 1) == 1 && (L & 1) == 1, "pairs start on odd phases; L odd");
+    static_assert(MODE == 0 || PA == 7, "split views only for the pair that straddles two frames");
+    static_assert(LWS_DBG_NOWRAP2 || MODE != 0 || PA != 7, "the straddling pair needs split views");
     constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
     constexpr int q_first = PA + base_off - L;                   // even
     static_for<L + 1>([&](auto ip) {
         constexpr int j = 2 * decltype(ip)::value;
         constexpr int q = q_first + j;
-        constexpr auto used = [](int jj) {                        // is t[jj] needed by bin A (dk = jj-L) or bin B (dk = jj-L-1)?
+        constexpr auto used = [](int jj) {                        // is t[jj] needed by bin A (dk = jj-L) / bin B (dk = jj-L-1)?
             const int da = jj - L, db = jj - L - 1;
-            const bool na = da >= -L && da <= L && ((KMASK >> (da < 0 ? -da : da)) & 1u);
-            const bool nb = db >= -L && db <= L && ((KMASK >> (db < 0 ? -db : db)) & 1u);
+            const bool na = MODE != 2 && da >= -L && da <= L && ((KMASK >> (da < 0 ? -da : da)) & 1u);
+            const bool nb = MODE != 1 && db >= -L && db <= L && ((KMASK >> (db < 0 ? -db : db)) & 1u);
             return na || nb;
         };
         constexpr bool need0 = used(j), need1 = used(j + 1);
+        // image cells of the edge lanes: below DC (frame start) / Nyquist and above (frame end)
+        constexpr bool img_lo = (MODE == 0) ? (j <= L - PA - 2) : (MODE == 2 ? (j <= L - 1) : false);
+        constexpr bool img_hi = (MODE == 0 || MODE == 1) ? (j >= 8 + L - PA) : false;
         if constexpr (need0 || need1) {
             static_assert(q >= -32 && q + 1 <= 15, "ring retention exceeded");
             constexpr int fl = floor_div8(q);
             constexpr int m = (-fl) & 3;
             constexpr int within = q - 8 * fl;                   // even
-            const int addr = (DR < 0 ? cx.nb[m] : cx.ob[m]) + (HALO + DR) * LANE_B + (within >> 1) * PAIR_BYTES;
+            constexpr int setoff = (DR < 0) ? SET_BYTES : 0;     // frames above: own sweep's set; below: previous sweep's
+            const int real_base = cx.ob[m] + (HALO + DR) * LANE_B;
+            int base = real_base;
+#if !LWS_DBG_NOSEL
+            if constexpr (img_lo) base = st ? cx.uo[m] + PLL * LANE_B : real_base;
+            if constexpr (img_hi) base = en ? cx.uo[m] + PLR * LANE_B : real_base;
+#endif
+            const int addr = base + setoff + (within >> 1) * PAIR_BYTES;
             if constexpr (need0 && need1) {
                 const v4f v = lds_read128(addr);
                 t[j] = make_float2(v.x, v.y);
@@ -342,13 +406,15 @@ __device__ __forceinline__ float2 centre_sum(const SysArgs &a, const LaneCtx &cx
         if constexpr ((MASK >> k) & 1u) {
             float2 lo = tap_any<PH, PB, 0, -k, 0>(cx, self_old, next_old, prev_out);
             float2 hi = tap_any<PH, PB, 0, k, 0>(cx, self_old, next_old, prev_out);
+            // images, branch-free: the alternative source is fetched by every lane (the address is valid for all of
+            // them) and selected for the one lane at the frame edge
             if constexpr (PH - k < 0) {        // first bins of a frame: (m, c-k) is the image of bin k-c
-                if constexpr (tap_in_lds<PH, 0, -k, 1>()) { if (st) lo = tap_lds<PH, PB, 0, -k, 1>(cx); }
-                else { const float2 im = tap_reg<PH, 0, -k, 1>(self_old, next_old, prev_out); lo = st ? im : lo; }
+                const float2 im = tap_any<PH, PB, 0, -k, 1>(cx, self_old, next_old, prev_out);
+                lo.x = st ? im.x : lo.x; lo.y = st ? im.y : lo.y;
             }
             if constexpr (PH + k >= 8) {       // last bins of a frame: Nyquist bin or an image
-                if constexpr (tap_in_lds<PH, 0, k, 2>()) { if (en) hi = tap_lds<PH, PB, 0, k, 2>(cx); }
-                else { const float2 im = tap_reg<PH, 0, k, 2>(self_old, next_old, prev_out); hi = en ? im : hi; }
+                const float2 im = tap_any<PH, PB, 0, k, 2>(cx, self_old, next_old, prev_out);
+                hi.x = en ? im.x : hi.x; hi.y = en ? im.y : hi.y;
             }
             pair_rot<0>(acc, a.w[2 * k], a.w[2 * k + 1], lo, hi);
         }
@@ -356,51 +422,25 @@ __device__ __forceinline__ float2 centre_sum(const SysArgs &a, const LaneCtx &cx
     return acc;
 }
 
-// Contribution of frames m-R and m+R to the bin at phase PH / clock PB; OFFS = 0 / 1: first / second bin of the pair
-template <int Q, int L, uint32_t MASK, int PH, int PB, int R, int OFFS>
-__device__ __forceinline__ float2 rows_sum(const SysArgs &a, const LaneCtx &cx, bool st, bool en,
-                                           const float2 (&tu)[2 * L + 2], const float2 (&td)[2 * L + 2]) {
+// Contribution of frames m-R and m+R to the bin at phase PH; OFFS = 0 / 1: first / second bin of the pair
+template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS>
+__device__ __forceinline__ float2 rows_sum(const SysArgs &a, const float2 (&tu)[2 * L + 2], const float2 (&td)[2 * L + 2]) {
     constexpr int K1 = L + 1;
     constexpr int mod = PH % Q;
     constexpr int rot = ((mod * R) % Q) * (4 / Q);  // quarter turns of exp(2j*pi*mod*R/Q)
-    float2 up[2 * L + 1], dn[2 * L + 1];
-    static_for<2 * L + 1>([&](auto id) {
-        constexpr int i = decltype(id)::value;
-        constexpr int k = i < L ? L - i : i - L;
-        if constexpr ((MASK >> (R * K1 + k)) & 1u) { up[i] = tu[i + OFFS]; dn[i] = td[i + OFFS]; }
-    });
-    if constexpr (PH < L) {
-        if (st)
-            static_for<L>([&](auto ik) {
-                constexpr int k = decltype(ik)::value + 1;
-                if constexpr (((MASK >> (R * K1 + k)) & 1u) && (PH - k < 0)) {
-                    up[L - k] = tap_lds<PH, PB, -R, -k, 1>(cx);
-                    dn[L - k] = tap_lds<PH, PB, R, -k, 1>(cx);
-                }
-            });
-    }
-    if constexpr (PH + L >= 8) {
-        if (en)
-            static_for<L>([&](auto ik) {
-                constexpr int k = decltype(ik)::value + 1;
-                if constexpr (((MASK >> (R * K1 + k)) & 1u) && (PH + k >= 8)) {
-                    up[L + k] = tap_lds<PH, PB, -R, k, 2>(cx);
-                    dn[L + k] = tap_lds<PH, PB, R, k, 2>(cx);
-                }
-            });
-    }
     float2 accr = make_float2(0.f, 0.f);
     if constexpr ((MASK >> (R * K1)) & 1u)
-        pair_rot<rot>(accr, a.w[2 * (R * K1)], a.w[2 * (R * K1) + 1], up[L], dn[L]);
+        pair_rot<rot>(accr, a.w[2 * (R * K1)], a.w[2 * (R * K1) + 1], tu[L + OFFS], td[L + OFFS]);
     static_for<L>([&](auto ik) {
         constexpr int k = decltype(ik)::value + 1;
         if constexpr ((MASK >> (R * K1 + k)) & 1u) {
             // W[mod]*S[m-r,c-k] + conj(W[mod])*S[m+r,c-k] + W[-mod]*S[m+r,c+k] + conj(W[-mod])*S[m-r,c+k]
             // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
             const float wr = a.w[2 * (R * K1 + k)], wi = a.w[2 * (R * K1 + k) + 1];
+            const float2 um = tu[L - k + OFFS], up = tu[L + k + OFFS], dm = td[L - k + OFFS], dp = td[L + k + OFFS];
             float2 b, c;
-            if constexpr ((rot & 1) == 0) { b = cadd(up[L - k], dn[L + k]); c = cadd(dn[L - k], up[L + k]); }
-            else { b = csub(up[L - k], dn[L + k]); c = csub(dn[L - k], up[L + k]); }
+            if constexpr ((rot & 1) == 0) { b = cadd(um, dp); c = cadd(dm, up); }
+            else { b = csub(um, dp); c = csub(dm, up); }
             pair_rot<rot>(accr, wr, wi, b, c);
         }
     });
@@ -438,31 +478,53 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     // previous-sweep values of the own bins of the NEXT pair (ages 29 and 28 now, 31 and 30 by then)
     const float2 o3 = lds_read(ring_addr<PA, 3 - LAG>(cx.ob));
     const float2 o4 = lds_read(ring_addr<PA, 4 - LAG>(cx.ob));
-    float2 accA = centre_sum<L, MASK, PA, PA>(a, cx, stA, enA, cr.o0, cr.o1, cr.prev_out);
+#ifndef LWS_DBG_NOCPATCH
+#define LWS_DBG_NOCPATCH 0   // timing experiment: centre-frame taps never use images (results invalid)
+#endif
+#ifndef LWS_DBG_NOSEL
+#define LWS_DBG_NOSEL 0      // timing experiment: row taps never use the image lanes (results invalid)
+#endif
+    constexpr bool CP = !LWS_DBG_NOCPATCH;
+    float2 accA = centre_sum<L, MASK, PA, PA>(a, cx, CP && stA, CP && enA, cr.o0, cr.o1, cr.prev_out);
     float2 accB = make_float2(0.f, 0.f);
-    // frame pairs m-+R, one after the other (scheduling fences keep the compiler from hoisting every fetch to the top,
-    // which would not fit the register file; the other wave of the SIMD covers the LDS latency)
+    // frame pairs m-+R
     static_for<Q - 1>([&](auto ir) {
         constexpr int R = decltype(ir)::value + 1;
         constexpr uint32_t kmask = (MASK >> (R * K1)) & ((1u << K1) - 1u);
-        float2 tu[2 * L + 2], td[2 * L + 2];
-        load_row2<PA, -R, L, kmask>(cx, tu);
-        load_row2<PA, R, L, kmask>(cx, td);
-        accA = cadd(accA, rows_sum<Q, L, MASK, PA, PA, R, 0>(a, cx, stA, enA, tu, td));
-        accB = cadd(accB, rows_sum<Q, L, MASK, PHB, PBB, R, 1>(a, cx, stB, enB, tu, td));
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!wrap || LWS_DBG_NOWRAP2) {
+            float2 tu[2 * L + 2], td[2 * L + 2];
+            load_row2<PA, -R, L, kmask, 0>(cx, stA, enA, tu);
+            load_row2<PA, R, L, kmask, 0>(cx, stA, enA, td);
+            accA = cadd(accA, rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td));
+            accB = cadd(accB, rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td));
+        } else {
+            {
+                float2 tu[2 * L + 2], td[2 * L + 2];
+                load_row2<PA, -R, L, kmask, 1>(cx, false, enA, tu);
+                load_row2<PA, R, L, kmask, 1>(cx, false, enA, td);
+                accA = cadd(accA, rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td));
+            }
+            {
+                float2 tu[2 * L + 2], td[2 * L + 2];
+                load_row2<PA, -R, L, kmask, 2>(cx, stB, false, tu);
+                load_row2<PA, R, L, kmask, 2>(cx, stB, false, td);
+                accB = cadd(accB, rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td));
+            }
+        }
     });
     // ---- first bin
     const float tA = amp_cur[PA];
     const float2 outA = project(accA, tA, cx.live && (tA > cx.thr), cr.o0);
-    ring_publish(ring_addr<PA, 0>(cx.nb), cx.halo_shift, outA);
+    ring_publish(ring_addr<PA, 0, 0, 1>(cx.ob), cx.halo_shift, cx.dummy, outA);
+    image_publish<L, PA, PA, 1>(cx.uo, stA, enA, cx.dummy, outA);
     if (cx.store) state_w_b[(size_t)(vmod + PA) * LANES + lane] = outA;   // G is a multiple of 8: no wrap inside a block
     // ---- second bin (its centre taps include the first bin's result)
-    accB = cadd(accB, centre_sum<L, MASK, PHB, PBB>(a, cx, stB, enB, cr.o1, cr.o2, outA));
+    accB = cadd(accB, centre_sum<L, MASK, PHB, PBB>(a, cx, CP && stB, CP && enB, cr.o1, cr.o2, outA));
     const float tB = wrap ? amp_nxt[0] : amp_cur[PBB & 7];
     const bool liveB = wrap ? cx.nxt_live : cx.live;
     const float2 outB = project(accB, tB, liveB && (tB > (wrap ? cx.nxt_thr : cx.thr)), cr.o1);
-    ring_publish(ring_addr<PBB, 0>(cx.nb), cx.halo_shift, outB);
+    ring_publish(ring_addr<PBB, 0, 0, 1>(cx.ob), cx.halo_shift, cx.dummy, outB);
+    image_publish<L, PHB, PBB, 1>(cx.uo, stB, enB, cx.dummy, outB);
     if (wrap ? cx.nxt_store : cx.store) {
         int ib = vmod + PBB;
         ib -= (ib >= G) ? G : 0;
@@ -502,6 +564,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     const bool valid = (v0 - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
     if (is_nyq_loader) {
         lds_write(NYQ_OFF + rho * 8, sv.nyq_in_next);  // loaded one block ago for this frame
+        lds_write((ablk & 3) * BLK_BYTES + PLR * LANE_B, sv.nyq_in_next);   // and as entry "bin C" of set 0's image lane
         const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
         if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2(state_nyq_b + me1);
@@ -552,6 +615,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         const bool active = real_row && (target > thr);
         const float2 out = project(acc, target, active, old);
         lds_write(nn[0], out);
+        lds_write(set_new + (ablk & 3) * BLK_BYTES + PLR * LANE_B, out);   // bin C of the image lane: production time = this clock
         if (valid && (slot == NSLOTS - 1 || j == n_eff - 1)) state_nyq_b[me] = out;
         // target magnitude of the next block's Nyquist bin
         const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
@@ -564,7 +628,7 @@ template <int Q, int L, uint32_t MASK>
 __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave: provably uniform
     float *thr_eff = reinterpret_cast<float *>(smem + THR_OFF);
     int *meta = reinterpret_cast<int *>(smem + META_OFF);
     const int G = a.G, C = a.C, Kr = a.Kr;
@@ -618,7 +682,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             amp_nxt[i] = v.y;
         }
     }
-    const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
+    const int set_old = slot * SET_BYTES;   // ring set this slot reads "old" values from; it writes the next one
     // flow control: lane l watches wave l.  A compute wave waits for its producer, its consumer and the service wave;
     // the service wave for every compute wave (loader overwrites what slot 0 reads; the Nyquist lanes read every slot).
     bool watched = false;
@@ -660,11 +724,12 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         }
         cx.lane8 = lane * 8;
         cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + lane * 8;
+        cx.dummy = DUMMY_OFF + lane * 8;
         cx.halo_shift = (lane < HALO) ? LANES * LANE_B : (lane >= LANES - HALO ? -LANES * LANE_B : 0);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int blk = ((ablk - m) & 3) * BLK_BYTES;
-            cx.nb[m] = set_new + blk + lane * LANE_B;
+            cx.uo[m] = set_old + blk;
             cx.ob[m] = set_old + blk + lane * LANE_B;
         }
         const int vmod = __builtin_amdgcn_readfirstlane(((v0 % G) + G) % G);  // wave-uniform, once per 8 steps
@@ -688,11 +753,21 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 if constexpr (PA == 1)
                     service_nyquist<Q, L, MASK>(a, sv, lane, t0, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
                 // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
-                int ldb[4];
+                // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
+                int ldb[4], ldu[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) ldb[m] = (((t0 >> 3) - m) & 3) * BLK_BYTES + lane * LANE_B;
-                ring_publish(ring_addr<PA, 0>(ldb), cx.halo_shift, make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]));
-                ring_publish(ring_addr<PA + 1, 0>(ldb), cx.halo_shift, make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]));
+                for (int m = 0; m < 4; ++m) {
+                    ldu[m] = (((t0 >> 3) - m) & 3) * BLK_BYTES;
+                    ldb[m] = ldu[m] + lane * LANE_B;
+                }
+                const int cb0 = (t0 - SKEW * lane) & (ROWP - 1), cb1 = (t0 + 8 - SKEW * lane) & (ROWP - 1);
+                const bool l_st = cb0 == 0, l_en = cb0 == C - 8, l_stn = cb1 == 0, l_enn = cb1 == C - 8;
+                const float2 vA = make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]);
+                const float2 vB = make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]);
+                ring_publish(ring_addr<PA, 0>(ldb), cx.halo_shift, cx.dummy, vA);
+                image_publish<L, PA, PA, 0>(ldu, l_st, l_en, cx.dummy, vA);
+                ring_publish(ring_addr<PA + 1, 0>(ldb), cx.halo_shift, cx.dummy, vB);
+                image_publish<L, (PA + 1) & 7, PA + 1, 0>(ldu, PA == 7 ? l_stn : l_st, PA == 7 ? l_enn : l_en, cx.dummy, vB);
                 int i0 = tmod + PA + 8, i1 = tmod + PA + 9;
                 i0 -= (i0 >= G) ? G : 0;
                 i1 -= (i1 >= G) ? G : 0;
