@@ -1,0 +1,107 @@
+"""GPU (-m gpu): the systolic batch kernel against the oracle across the shapes that stress its schedule --
+frame counts around the 64-lane rounds, bin counts below the 512-step frame period, sweep counts around the
+7-slot groups, dropped (no-op) sweeps, per-spectrogram thresholds in one launch, Q = 2 and Q = 4.
+Every case is also run through the generic engine in fp64 (<= 1e-8 vs the oracle: schedule) so that a failure
+here isolates the systolic kernel."""
+import numpy as np
+import pytest
+
+import lws_amd
+from lws_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def run_case(oracle, fsize, fshift, T, thr, seed, B=1, scale=None):
+    p = lws_amd.lws(fsize, fshift)
+    F = fsize // 2 + 1
+    rng = np.random.default_rng(seed)
+    S = rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))
+    if scale is not None:
+        S *= np.asarray(scale)[:, None, None]
+    out = p.plan().batch(S, thr)
+    assert p.plan().last_kernel()["name"].startswith("systolic"), p.plan().last_kernel()
+    p64 = _capi.Plan(F, p.W, precision="fp64")
+    for b in range(B):
+        ref = oracle.batch_lws(S[b], p.W, thr)
+        assert np.abs(p64.batch(S[b], thr) - ref).max() < 1e-8
+        mean = np.mean(np.abs(S[b]))
+        d = np.abs(out[b] - ref)
+        assert rel_l2(out[b], ref) < 3e-3, (fsize, fshift, T, b, rel_l2(out[b], ref))
+        assert np.median(d) < 2e-6 * mean
+        assert np.abs(np.abs(out[b]) - np.abs(S[b])).max() < 2e-6 * np.abs(S[b]).max()
+    p64.close()
+    return out
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 57, 58, 59, 63, 64, 65, 122, 131])
+def test_frame_counts_around_lane_rounds(oracle, T):
+    """T + 2(Q-1) extended frames are dealt to 64 lanes round-robin: exercise 1, 2 and 3 rounds and their edges."""
+    run_case(oracle, 64, 16, T, [0.6, 0.3, 0.0], seed=T)
+
+
+@pytest.mark.parametrize("n_it", [1, 6, 7, 8, 13, 14, 15, 22])
+def test_sweep_counts_around_slot_groups(oracle, n_it):
+    """7 sweeps are in flight; 8, 15, 22 sweeps need 2, 3, 4 passes over HBM with a partial last group."""
+    thr = np.linspace(0.8, 0.0, n_it)
+    run_case(oracle, 64, 16, 21, thr, seed=100 + n_it)
+
+
+@pytest.mark.parametrize("fsize,fshift", [(64, 16), (64, 32), (128, 32), (128, 64), (512, 128), (1024, 256), (1024, 512)])
+def test_bin_counts_and_q(oracle, fsize, fshift):
+    """F - 1 = 32 ... 512 (frames shorter than the 512-step period leave lanes idle part of the time), Q = 4 and 2."""
+    T = 70 if fsize <= 128 else 37
+    run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0], seed=fsize + fshift)
+
+
+def test_dropped_sweeps_and_mixed_schedules(oracle):
+    """Thresholds above the largest magnitude are dropped per spectrogram; spectrograms of one launch have different
+    scales, hence different sets of dropped sweeps and different scaled thresholds."""
+    thr = np.array([50.0, 3.5, 2.5, 30.0, 1.5, 0.7, 0.0, 9.0, 0.2])
+    out = run_case(oracle, 64, 16, 40, thr, seed=7, B=4, scale=[1.0, 0.01, 25.0, 3.0])
+    assert out.shape == (4, 40, 33)
+    # non-monotone schedule with every sweep a no-op: bit-identical output
+    p = lws_amd.lws(64, 16)
+    S = np.random.default_rng(1).standard_normal((33, 33)) + 0j
+    assert np.array_equal(p.plan().batch(S, [40.0, 90.0, 41.0]), S)
+
+
+def test_real_magnitude_input_and_many_sweeps(oracle):
+    """Zero-phase magnitudes (the actual use: run_lws(abs(X))) with the default schedule shortened to 60 sweeps."""
+    p = lws_amd.lws(128, 32)
+    rng = np.random.default_rng(5)
+    M = np.abs(rng.standard_normal((90, 65)) + 1j * rng.standard_normal((90, 65)))
+    thr = lws_amd.get_thresholds(60, 20, 0.1, 1)
+    out = p.batch_lws(M, thresholds=thr)
+    assert p.plan().last_kernel()["name"].startswith("systolic")
+    ref = oracle.batch_lws(M, p.W, thr)
+    assert rel_l2(out, ref) < 3e-3
+    assert abs(p.get_consistency(out) - p.get_consistency(ref)) < 0.05
+
+
+def test_weights_without_zero_pattern_use_the_allmask_kernel(oracle):
+    """A weight tensor with create_weights' twiddle structure but no vanishing entries."""
+    p = lws_amd.lws(64, 16)
+    W = np.array(p.W)
+    rng = np.random.default_rng(2)
+    base = W[0] + 1e-3 * (rng.standard_normal(W[0].shape) + 1j * rng.standard_normal(W[0].shape))
+    Q = 4
+    tw = np.exp(2j * np.pi * np.arange(Q)[:, None] * np.arange(Q)[None, :] / Q)
+    W2 = base[None, :, :] * tw[:, :, None]
+    S = rng.standard_normal((30, 33)) + 1j * rng.standard_normal((30, 33))
+    thr = [0.4, 0.0, 0.0]
+    plan = _capi.Plan(33, W2)
+    out = plan.batch(S, thr)
+    assert plan.last_kernel()["name"] == "systolic_q4_l5_allmask"
+    ref = oracle.batch_lws(S, W2, thr)
+    assert rel_l2(out, ref) < 3e-3
+    # weights that break the structure fall back to the generic engine
+    W3 = W2.copy(); W3[1, 2, 3] *= 1.01
+    plan3 = _capi.Plan(33, W3)
+    out3 = plan3.batch(S, thr)
+    assert plan3.last_kernel()["name"] == "generic_fp32"
+    assert rel_l2(out3, oracle.batch_lws(S, W3, thr)) < 3e-3
