@@ -179,6 +179,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     a.F = p->F; a.T = T; a.L = p->L; a.Q = p->Q; a.Qp = p->Qp;
     a.n_thr = iters;
     a.LA = LA;
+    a.M0 = 0;
     a.update = 2;  // both shipped callers pass 2 (lws.pyx:363, online_lws.cpp:160)
     a.qdiv = (real)qdiv;
     a.mode = mode;

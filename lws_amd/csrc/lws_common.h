@@ -16,7 +16,8 @@ template <> struct cx<double> { using type = double2; };
 //   NOFUTURE : NoFuture_LWS{Q2,anyQ,fractionalQ}              (lwslib.cpp:473-535,620-764)
 //   NOFUTURE_Q4_COMPAT : NoFuture_LWSQ4 with its flat-offset addressing (lwslib.cpp:538-617)
 //   ONLINE   : TF_RTISI_LA and the Asym_UpdatePhase* calls it makes (lwslib.cpp:776-1492)
-enum Mode { MODE_BATCH = 0, MODE_NOFUTURE = 1, MODE_NOFUTURE_Q4_COMPAT = 2, MODE_ONLINE = 3 };
+enum Mode { MODE_BATCH = 0, MODE_NOFUTURE = 1, MODE_NOFUTURE_Q4_COMPAT = 2, MODE_ONLINE = 3,
+            MODE_ASYM = 4 /* one Asym_UpdatePhase* call: T frames that may read M0 frames to their right */ };
 
 // Device weights of one weight tensor: [Qp][Q][L+1], entries with |w| <= 1e-12 have flag 0.
 template <typename real> struct WeightSet {
@@ -34,6 +35,7 @@ template <typename real> struct GenericArgs {
     int F, T, L, Q, Qp;
     int n_thr;                       // sweeps (batch / no-future) or iterations per frame (online)
     int LA;                          // look-ahead (online)
+    int M0;                          // frames usable to the right of the first one (MODE_ASYM)
     int update;                      // 1: add S/qdiv to the centre sum (dead in shipped callers), 2: do not
     real qdiv;
     int mode;

@@ -162,10 +162,11 @@ __global__ void __launch_bounds__(1024) k_generic(GenericArgs<real> a) {
     const int sk = L + 1, D = Q * sk;
     const bool add_self = (a.update == 1);
 
-    if (a.mode == MODE_BATCH || a.mode == MODE_NOFUTURE) {
+    if (a.mode == MODE_BATCH || a.mode == MODE_NOFUTURE || a.mode == MODE_ASYM) {
         const WeightSet<real> ws = a.w[a.wsel];
-        const bool centre = (a.mode == MODE_BATCH);
-        const int two_sided = (a.mode == MODE_BATCH) ? Q : 1;
+        const bool asym = (a.mode == MODE_ASYM);
+        bool centre = (a.mode == MODE_BATCH);
+        int two_sided = (a.mode == MODE_BATCH) ? Q : 1;
         const int nsweeps = a.n_thr;
         int lpi = (F - 1) / sk + 1;  // frames that can sit on one hyperplane
         if (lpi > T) lpi = T;
@@ -184,6 +185,12 @@ __global__ void __launch_bounds__(1024) k_generic(GenericArgs<real> a) {
                     if (mm < 0) continue;
                     const int c = u - sk * mm;
                     if (c >= F) continue;
+                    if (asym) {  // cframe / rframe of lwslib.cpp:1143-1151 for local frame mm
+                        two_sided = a.M0 - mm;
+                        if (two_sided > Q) two_sided = Q;
+                        centre = two_sided >= 1;
+                        if (two_sided < 1) two_sided = 1;
+                    }
                     update_bin<real>(S, amp, mm + Q - 1, c, centre, two_sided, ws, thr[g0 + k], F, L,
                                      Q, Qp, add_self, a.qdiv);
                 }
@@ -258,7 +265,7 @@ hipError_t launch_generic(const GenericArgs<real> &a, int B, hipStream_t stream)
     int threads;
     GenericArgs<real> args = a;
     const int sk = a.L + 1;
-    if (a.mode == MODE_BATCH || a.mode == MODE_NOFUTURE) {
+    if (a.mode == MODE_BATCH || a.mode == MODE_NOFUTURE || a.mode == MODE_ASYM) {
         int lpi = (a.F - 1) / sk + 1;
         if (lpi > a.T) lpi = a.T;
         threads = 1024;

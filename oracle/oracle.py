@@ -153,8 +153,9 @@ class RefLib:
     def available():
         return os.path.exists(REF_SO)
 
-    def __init__(self):
-        self.lib = C.CDLL(REF_SO)
+    def __init__(self, path=None):
+        # `path`: any library exporting the lwslib.h symbols (tests point it at liblws_hip.so's compat shims)
+        self.lib = C.CDLL(path or REF_SO)
         vp, ci, cd = C.c_void_p, C.c_int, C.c_double
         six = [vp] * 6
         sig = {

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 (rocpd sqlite) outputs of scratch/profile.sh into the summaries kept under profiles/.
+usage: collect_profiles.py <prof_dir> <out_dir> <tag>     (run on the GPU box or on merged gpurun_out/)"""
+import csv, glob, json, os, sqlite3, sys
+
+prof, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(out, exist_ok=True)
+
+def db(sub):
+    f = glob.glob(os.path.join(prof, sub, "*.db"))
+    return sqlite3.connect(f[0]) if f else None
+
+con = db("trace")
+if con:
+    rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+        fh.write('"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-default-schedule  (MI355X; durations in microseconds)"\n')
+        w = csv.writer(fh)
+        w.writerow(["kernel", "calls", "total_us", "average_us", "min_us", "max_us", "percent"])
+        for n, c, s, a, mn, mx in rows:
+            w.writerow([n[:160], c, round(s / 1e3, 3), round(a / 1e3, 3), round(mn / 1e3, 3), round(mx / 1e3, 3), round(100 * s / tot, 3)])
+
+res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) -- python bench.py --steps 2 "
+               "--warmup 1 --no-cpu-baseline --no-default-schedule; counters are KiB per dispatch. MI355X_MICROARCH.md (HBM section): on "
+               "gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e. reports 1/2 of the bytes -> doubled here; WRITE_SIZE is exact.",
+       "all_kernels": {}}
+for sub, cn in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    con = db(sub)
+    if not con:
+        continue
+    for n, c, a in con.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name", (cn,)):
+        res["all_kernels"].setdefault(n[:120], {})[cn] = {"launches": c, "avg_per_launch": a}
+for n, d in res["all_kernels"].items():
+    if "k_systolic" in n and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        f, w = d["FETCH_SIZE"]["avg_per_launch"], d["WRITE_SIZE"]["avg_per_launch"]
+        res["systolic_q4_l5_hannmask"] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
+                                          "algorithmic_bytes_per_launch": 256 * 500 * 513 * 100 * 20.0,
+                                          "note": "one launch = 256 spectrograms x 100 dense sweeps; 7 sweeps share one pass over HBM"}
+json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(out, f"{tag}_kernel_stats.csv")).read()[:1500])
+print(json.dumps(res.get("systolic_q4_l5_hannmask"), indent=1))
