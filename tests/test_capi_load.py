@@ -64,3 +64,17 @@ def test_product_code_never_touches_the_checker():
                 if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
                     src = open(os.path.join(dirpath, f)).read().lower()
                     assert "oracle" not in src and "lwso_" not in src, f"{f} references the checker"
+
+
+def test_library_exports_the_lwslib_h_interface():
+    """include/lwslib_compat.h: the reference's 16 native entry points, under the reference's own mangled names
+    (the table oracle.RefLib binds the compiled reference with)."""
+    from oracle.oracle import RefLib
+    text = open(os.path.join(ROOT, "include", "lwslib_compat.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"^(?:void|const char \*)\s*([A-Za-z_0-9]+)\s*\(", text, flags=re.M))
+    assert declared - {"lwslib_compat_last_error"} == set(RefLib.SYMS)
+    lib = _capi.load()
+    for name, sym in RefLib.SYMS.items():
+        assert hasattr(lib, sym), f"{name} ({sym}) not exported"
+    assert hasattr(lib, "_Z24lwslib_compat_last_errorv")
