@@ -393,6 +393,20 @@ template <int ROT> __device__ __forceinline__ void pair_rot(float2 &a, float wr,
     else if constexpr (ROT == 2) { a.x = fmaf(wi, dy, fmaf(-wr, sx, a.x)); a.y = fmaf(-wi, dx, fmaf(-wr, sy, a.y)); }
     else { a.x = fmaf(wr, dy, fmaf(wi, sx, a.x)); a.y = fmaf(-wr, dx, fmaf(wi, sy, a.y)); }
 }
+// the same for a weight whose imaginary part is exactly zero (W[0][r][0] of symmetric windows): half the work
+template <int ROT> __device__ __forceinline__ void pair_rot_real(float2 &a, float wr, float2 b, float2 c) {
+    if constexpr (ROT == 0) { a.x = fmaf(wr, b.x + c.x, a.x); a.y = fmaf(wr, b.y + c.y, a.y); }
+    else if constexpr (ROT == 1) { a.x = fmaf(-wr, b.y - c.y, a.x); a.y = fmaf(wr, b.x - c.x, a.y); }
+    else if constexpr (ROT == 2) { a.x = fmaf(-wr, b.x + c.x, a.x); a.y = fmaf(-wr, b.y + c.y, a.y); }
+    else { a.x = fmaf(wr, b.y - c.y, a.x); a.y = fmaf(-wr, b.x - c.x, a.y); }
+}
+// v * j^ROT
+template <int ROT> __device__ __forceinline__ float2 crot(float2 v) {
+    if constexpr ((ROT & 3) == 0) return v;
+    else if constexpr ((ROT & 3) == 1) return make_float2(-v.y, v.x);
+    else if constexpr ((ROT & 3) == 2) return make_float2(-v.x, -v.y);
+    else return make_float2(v.y, -v.x);
+}
 __device__ __forceinline__ float2 cadd(float2 p, float2 q) { return make_float2(p.x + q.x, p.y + q.y); }
 __device__ __forceinline__ float2 csub(float2 p, float2 q) { return make_float2(p.x - q.x, p.y - q.y); }
 
@@ -422,15 +436,28 @@ __device__ __forceinline__ float2 centre_sum(const SysArgs &a, const LaneCtx &cx
     return acc;
 }
 
+// Structure flags carried in the top bits of the MASK template word (the tap mask itself needs Q*(L+1) <= 24 bits)
+constexpr uint32_t FLAG_K0REAL = 1u << 30;  // Im W[0][r][0] == 0 for r >= 1
+constexpr uint32_t FLAG_R13 = 1u << 31;     // Q = 4 and W[0][3][k] == j^k W[0][1][k] for 2 <= k <= L (sqrt-Hann, 75% overlap)
+
+// With FLAG_R13 the taps k >= 2 of frames m-+3 share the weight of frames m-+1 up to a quarter turn:
+//   W1 (j^mod B1 + j^(k-mod) B3) + conj(W1) (j^-mod C1 + j^(mod-k) C3),   B = um +- dp, C = dm +- up,
+// so rows 3 only contribute rotated partial sums (kept in P3) and rows 1 do the complex multiply for both.
+template <int L> struct R13Partials { float2 b[L + 1], c[L + 1]; };
+
 // Contribution of frames m-R and m+R to the bin at phase PH; OFFS = 0 / 1: first / second bin of the pair
 template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS>
-__device__ __forceinline__ float2 rows_sum(const SysArgs &a, const float2 (&tu)[2 * L + 2], const float2 (&td)[2 * L + 2]) {
+__device__ __forceinline__ float2 rows_sum(const SysArgs &a, const float2 (&tu)[2 * L + 2], const float2 (&td)[2 * L + 2],
+                                           R13Partials<L> &p3) {
     constexpr int K1 = L + 1;
     constexpr int mod = PH % Q;
     constexpr int rot = ((mod * R) % Q) * (4 / Q);  // quarter turns of exp(2j*pi*mod*R/Q)
+    constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
     float2 accr = make_float2(0.f, 0.f);
-    if constexpr ((MASK >> (R * K1)) & 1u)
-        pair_rot<rot>(accr, a.w[2 * (R * K1)], a.w[2 * (R * K1) + 1], tu[L + OFFS], td[L + OFFS]);
+    if constexpr ((MASK >> (R * K1)) & 1u) {
+        if constexpr ((MASK & FLAG_K0REAL) != 0) pair_rot_real<rot>(accr, a.w[2 * (R * K1)], tu[L + OFFS], td[L + OFFS]);
+        else pair_rot<rot>(accr, a.w[2 * (R * K1)], a.w[2 * (R * K1) + 1], tu[L + OFFS], td[L + OFFS]);
+    }
     static_for<L>([&](auto ik) {
         constexpr int k = decltype(ik)::value + 1;
         if constexpr ((MASK >> (R * K1 + k)) & 1u) {
@@ -441,7 +468,15 @@ __device__ __forceinline__ float2 rows_sum(const SysArgs &a, const float2 (&tu)[
             float2 b, c;
             if constexpr ((rot & 1) == 0) { b = cadd(um, dp); c = cadd(dm, up); }
             else { b = csub(um, dp); c = csub(dm, up); }
-            pair_rot<rot>(accr, wr, wi, b, c);
+            if constexpr (r13 && R == 3 && k >= 2) {
+                // j^(k+rot3) B3 and its mirror, rot3 = 3 mod = -mod (mod 4)
+                p3.b[k] = crot<k + rot>(b);
+                p3.c[k] = crot<8 - k - rot>(c);
+            } else if constexpr (r13 && R == 1 && k >= 2) {
+                pair_rot<0>(accr, wr, wi, cadd(crot<rot>(b), p3.b[k]), cadd(crot<4 - rot>(c), p3.c[k]));
+            } else {
+                pair_rot<rot>(accr, wr, wi, b, c);
+            }
         }
     });
     return accr;
@@ -487,28 +522,31 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     constexpr bool CP = !LWS_DBG_NOCPATCH;
     float2 accA = centre_sum<L, MASK, PA, PA>(a, cx, CP && stA, CP && enA, cr.o0, cr.o1, cr.prev_out);
     float2 accB = make_float2(0.f, 0.f);
-    // frame pairs m-+R
+    // frame pairs m-+R.  With FLAG_R13 rows 3 leave partial sums for rows 1: order 2, 3, 1 keeps them short-lived.
+    constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
+    R13Partials<L> p3A, p3B;
     static_for<Q - 1>([&](auto ir) {
-        constexpr int R = decltype(ir)::value + 1;
+        constexpr int i = decltype(ir)::value;
+        constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
         constexpr uint32_t kmask = (MASK >> (R * K1)) & ((1u << K1) - 1u);
         if constexpr (!wrap || LWS_DBG_NOWRAP2) {
             float2 tu[2 * L + 2], td[2 * L + 2];
             load_row2<PA, -R, L, kmask, 0>(cx, stA, enA, tu);
             load_row2<PA, R, L, kmask, 0>(cx, stA, enA, td);
-            accA = cadd(accA, rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td));
-            accB = cadd(accB, rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td));
+            accA = cadd(accA, rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A));
+            accB = cadd(accB, rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B));
         } else {
             {
                 float2 tu[2 * L + 2], td[2 * L + 2];
                 load_row2<PA, -R, L, kmask, 1>(cx, false, enA, tu);
                 load_row2<PA, R, L, kmask, 1>(cx, false, enA, td);
-                accA = cadd(accA, rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td));
+                accA = cadd(accA, rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A));
             }
             {
                 float2 tu[2 * L + 2], td[2 * L + 2];
                 load_row2<PA, -R, L, kmask, 2>(cx, stB, false, tu);
                 load_row2<PA, R, L, kmask, 2>(cx, stB, false, td);
-                accB = cadd(accB, rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td));
+                accB = cadd(accB, rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B));
             }
         }
     });
@@ -856,6 +894,7 @@ constexpr uint32_t MASK_Q2_L5_DEFAULT = 0b010111'000011u;                       
 struct Tables {
     int Q, L;
     uint32_t mask;
+    bool k0real, r13;  // structure the kernels can exploit (FLAG_K0REAL / FLAG_R13)
     float w[64];
 };
 
@@ -899,6 +938,25 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
                 tb->w[2 * (r * K1 + k)] = on ? (float)wr : 0.f;
                 tb->w[2 * (r * K1 + k) + 1] = on ? (float)wi : 0.f;
             }
+        // structure of symmetric windows, checked on the fp64 weights well below fp32 resolution
+        tb->k0real = true;
+        for (int r = 1; r < Q; ++r)
+            if (((tb->mask >> (r * K1)) & 1u) && std::fabs(W[i][2 * (r * K1) + 1]) > 1e-13 * scale) tb->k0real = false;
+        tb->r13 = (Q == 4);
+        for (int k = 2; k <= L && tb->r13; ++k) {
+            const bool on1 = (tb->mask >> (1 * K1 + k)) & 1u, on3 = (tb->mask >> (3 * K1 + k)) & 1u;
+            if (on1 != on3) { tb->r13 = false; break; }
+            if (!on1) continue;
+            double xr = W[i][2 * (1 * K1 + k)], xi = W[i][2 * (1 * K1 + k) + 1];   // W1 * j^k
+            for (int q = 0; q < (k & 3); ++q) { const double t = xr; xr = -xi; xi = t; }
+            if (std::hypot(W[i][2 * (3 * K1 + k)] - xr, W[i][2 * (3 * K1 + k) + 1] - xi) > 1e-13 * scale) tb->r13 = false;
+        }
+#ifdef LWS_NO_R13
+        tb->r13 = false;
+#endif
+#ifdef LWS_NO_K0REAL
+        tb->k0real = false;
+#endif
         sp.tables[i] = tb;
         sp.ok[i] = true;
     }
@@ -969,10 +1027,12 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
         a.T = T; a.Tp = Tp; a.TpPad = TpPad; a.Kr = Kr; a.G = G; a.C = F - 1;
         for (int x = 0; x < 64; ++x) a.w[x] = x < 2 * Q * (L + 1) ? tb->w[x] : 0.f;
         if (Q == 4) {
-            if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B, stream); sp.name = "systolic_q4_l5_hannmask"; }
+            if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, B, stream); sp.name = "systolic_q4_l5_hann"; }
+            else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B, stream); sp.name = "systolic_q4_l5_hannmask"; }
             else { e = launch_k<4, 5, mask_all(4, 5)>(a, B, stream); sp.name = "systolic_q4_l5_allmask"; }
         } else {
-            if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B, stream); sp.name = "systolic_q2_l5_hannmask"; }
+            if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, B, stream); sp.name = "systolic_q2_l5_hann"; }
+            else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B, stream); sp.name = "systolic_q2_l5_hannmask"; }
             else { e = launch_k<2, 5, mask_all(2, 5)>(a, B, stream); sp.name = "systolic_q2_l5_allmask"; }
         }
         if (e != hipSuccess) return e;

@@ -34,9 +34,9 @@ for sub, cn in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 for n, d in res["all_kernels"].items():
     if "k_systolic" in n and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = d["FETCH_SIZE"]["avg_per_launch"], d["WRITE_SIZE"]["avg_per_launch"]
-        res["systolic_q4_l5_hannmask"] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
+        res["systolic_q4_l5_hann"] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
                                           "algorithmic_bytes_per_launch": 256 * 500 * 513 * 100 * 20.0,
                                           "note": "one launch = 256 spectrograms x 100 dense sweeps; 7 sweeps share one pass over HBM"}
 json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(out, f"{tag}_kernel_stats.csv")).read()[:1500])
-print(json.dumps(res.get("systolic_q4_l5_hannmask"), indent=1))
+print(json.dumps(res.get("systolic_q4_l5_hann"), indent=1))
