@@ -209,10 +209,17 @@ __global__ void __launch_bounds__(1024) k_generic(GenericArgs<real> a) {
                 for (int n = L + tid; n < n_split; n += nthr)
                     update_bin_nfq4<real>(S, amp, m + Q - 1, n - L, ws, th, F, L);
                 __syncthreads();
-                if (tid == 0)
-                    for (int n = n_split; n < F + L; ++n)
+                // upper bins: the flat offset of frame m-1 runs into frame m itself, columns 2n - Np +- k <= 2n - Np + L,
+                // all below n.  Bins [n0, n1) are independent of each other (and so reproduce the sequential order) as
+                // long as every such column lies below n0: n < (n0 + Np - L) / 2.  The remaining range halves each round.
+                for (int n0 = n_split; n0 < F + L;) {
+                    int n1 = (n0 + Np - L + 1) / 2;
+                    if (n1 > F + L) n1 = F + L;
+                    for (int n = n0 + tid; n < n1; n += nthr)
                         update_bin_nfq4<real>(S, amp, m + Q - 1, n - L, ws, th, F, L);
-                __syncthreads();
+                    __syncthreads();
+                    n0 = n1;
+                }
             }
         }
     } else {  // MODE_ONLINE: TF_RTISI_LA (lwslib.cpp:1432-1491)
