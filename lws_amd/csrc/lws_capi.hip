@@ -11,7 +11,9 @@
 #include <vector>
 
 #include "lws_common.h"
+#include <type_traits>
 #include "lws_systolic.h"
+#include "lws_online.h"
 
 namespace {
 
@@ -184,6 +186,19 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     a.qdiv = (real)qdiv;
     a.mode = mode;
     a.group = 1;
+    if constexpr (std::is_same<real, float>::value) {
+        // online driver: frames of the moving window live in LDS when the shape allows it
+        if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) &&
+            lws::online_lds_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update)) {
+            begin_timing(p, s);
+            hipError_t e = lws::launch_online_lds(a, B, s);
+            end_timing(p, s);
+            if (e != hipSuccess) return fail(LWS_ERR_HIP, "online launch failed: %s", hipGetErrorString(e));
+            p->last_launches = 1;
+            p->last_name = "online_lds_fp32";
+            return LWS_OK;
+        }
+    }
     begin_timing(p, s);
     hipError_t e = lws::launch_generic<real>(a, B, s);
     end_timing(p, s);

@@ -1,0 +1,14 @@
+// lws_online.h -- LDS-resident fp32 engine for the online driver (lws_online.hip).  Internal, not part of the ABI.
+#pragma once
+#include "lws_common.h"
+
+namespace lws {
+
+// true if launch_online_lds can run this shape (summarised weights, L = 5, Q in {2,4,8}, the window of frames the
+// sweeps in flight need fits the LDS ring); otherwise the caller uses the generic engine.
+bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update);
+
+// Same contract as launch_generic<float> with mode == MODE_ONLINE.
+hipError_t launch_online_lds(const GenericArgs<float> &a, int B, hipStream_t stream);
+
+}  // namespace lws

@@ -1,0 +1,96 @@
+"""The LDS-resident online engine (lws_amd/csrc/lws_online.hip) behind lws_online_lws / online_lws().
+
+Two anchors.  (1) At small sizes, where fp32 rounding stays rounding, it is checked against the fp64 oracle like every
+other fp32 path.  (2) At realistic sizes the online algorithm amplifies rounding differences (two correct fp32
+engines end up as far from each other as from fp64), so there the engine's schedule, frame window and slot logic are
+pinned bit for bit: its verification variant (LWS_ONLINE_SERIAL_TAPS=1: same kernel, taps summed by one lane in the
+generic engine's order) must reproduce the order-exact generic engine's fp32 result exactly.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import lws_amd
+from lws_amd import _capi
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _online(F, W, S, thr, LA, qdiv, **kw):
+    plan = _capi.Plan(F, W[0], W[1], W[2], **kw)
+    out = plan.online(S, thr, LA, qdiv)
+    name = plan.last_kernel()["name"]
+    plan.close()
+    return out, name
+
+
+@pytest.mark.parametrize("fsize,fshift,T,LA,iters,B", [
+    (512, 128, 100, 3, 10, 2),     # Q = 4, config-1 frame size
+    (1024, 256, 150, 3, 10, 3),    # Q = 4, the headline frame size, music-mode schedule
+    (1024, 256, 40, 5, 3, 1),      # longer look-ahead
+    (1024, 256, 60, 5, 2, 1),      # ... with few iterations: the 16-frame ring is exactly full
+    (1024, 256, 33, 0, 4, 1),      # no look-ahead
+    (1024, 512, 90, 3, 6, 2),      # Q = 2
+    (512, 64, 60, 2, 5, 2),        # Q = 8
+    (256, 64, 5, 3, 4, 1),         # fewer frames than the window
+    (256, 64, 1, 3, 2, 1),         # a single frame
+])
+def test_serial_variant_is_bit_identical_to_generic(fsize, fshift, T, LA, iters, B, monkeypatch):
+    rng = np.random.default_rng(fsize + T)
+    p = lws_amd.lws(fsize, fshift, mode="music")
+    F = fsize // 2 + 1
+    S = rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))
+    if B > 1:
+        S[1] = np.abs(S[1])                       # magnitudes with zero phase, as run_lws feeds them
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.1, 1)
+    W = (p.W, p.W_ai, p.W_af)
+    ref, name = _online(F, W, S, thr, LA, fsize / fshift, force_generic=True)
+    assert name == "generic_fp32"
+    monkeypatch.setenv("LWS_ONLINE_SERIAL_TAPS", "1")
+    out, name = _online(F, W, S, thr, LA, fsize / fshift)
+    assert name == "online_lds_fp32"
+    assert np.array_equal(out, ref)
+    # the production variant only re-associates the sum over frames: same magnitudes
+    monkeypatch.delenv("LWS_ONLINE_SERIAL_TAPS")
+    prod, name = _online(F, W, S, thr, LA, fsize / fshift)
+    assert name == "online_lds_fp32"
+    assert np.abs(np.abs(prod) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
+
+
+@pytest.mark.parametrize("tag", ["64_16", "64_32", "64_8"])
+@pytest.mark.parametrize("T", [1, 2, 3, 7, 24])
+@pytest.mark.parametrize("LA", [0, 1, 3, 5])
+def test_small_shapes_vs_oracle(tag, T, LA, oracle):
+    h, g = load_golden("helpers.npz"), load_golden("wrappers.npz")
+    W = (h[f"W_{tag}"], h[f"W_ai_{tag}"], h[f"W_af_{tag}"])
+    fsize, fshift = [int(v) for v in tag.split("_")]
+    S = g[f"S_{tag}"][:T]
+    F = S.shape[1]
+    thr = [0.6, 0.2, 0.0]
+    ref = oracle.online_lws(S, *W, thr, LA, fshift)
+    out, name = _online(F, W, S, thr, LA, fsize / fshift)
+    assert name == "online_lds_fp32"
+    err = np.abs(out - ref)
+    scale = np.mean(np.abs(S))
+    assert np.median(err) < 2e-6 * scale and np.linalg.norm(err) < 5e-3 * np.linalg.norm(ref)
+    assert np.abs(np.abs(out) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
+
+
+def test_fallbacks_to_generic():
+    """Shapes the LDS ring cannot hold, and fp64 plans, stay on the generic engine."""
+    rng = np.random.default_rng(0)
+    p = lws_amd.lws(48, 16, mode="music")            # Q = 3
+    S = rng.standard_normal((9, 25)) + 1j * rng.standard_normal((9, 25))
+    out, name = _online(25, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 3.0)
+    assert name == "generic_fp32"
+    p = lws_amd.lws(64, 16, mode="music")
+    S = rng.standard_normal((9, 33)) + 1j * rng.standard_normal((9, 33))
+    out, name = _online(33, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 4.0, precision="fp64")
+    assert name == "generic_fp64"
+    # one iteration per frame on a wide frame: too many frames in flight for the 16-frame ring
+    p = lws_amd.lws(2048, 512, mode="music")
+    S = rng.standard_normal((30, 1025)) + 1j * rng.standard_normal((30, 1025))
+    out, name = _online(1025, (p.W, p.W_ai, p.W_af), S, [0.5], 3, 4.0)
+    assert name == "generic_fp32"
