@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-default-schedule", action="store_true")
+    ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     args = ap.parse_args()
 
@@ -185,6 +186,35 @@ def main():
             "effective_sweeps": active / (B * T * F),
             "ms_per_step": 1e3 * dt2 / max(1, args.steps),
             "algorithmic_GBs": (16.0 * active + 4.0 * B * T * F * iters) / (kms2 / max(1, args.steps) * 1e-3) / 1e9}
+
+    # BASELINE config 3: the run_lws pipeline of lws(1024, 256, mode='music') -- 1 no-future sweep (W_ai, alpha 1),
+    # 10 online iterations with look-ahead 3, 100 batch sweeps of the default schedule -- stage by stage on the device
+    if not args.no_config3:
+        pm = lws_amd.lws(1024, 256, mode="music", device=local_rank, force_generic=args.force_generic)
+        planm = pm.plan()
+        stages = [
+            ("nofuture", lambda: planm.nofuture_dev(state.data_ptr(), B, T, lws_amd.get_thresholds(
+                pm.nofuture_iterations, pm.nofuture_alpha, pm.nofuture_beta, pm.nofuture_gamma), wsel=1, stream=stream)),
+            ("online", lambda: planm.online_dev(state.data_ptr(), B, T, lws_amd.get_thresholds(
+                pm.online_iterations, pm.online_alpha, pm.online_beta, pm.online_gamma), pm.look_ahead, 4.0, stream=stream)),
+            ("batch", lambda: planm.batch_dev(state.data_ptr(), B, T, lws_amd.get_thresholds(
+                pm.batch_iterations, pm.batch_alpha, pm.batch_beta, pm.batch_gamma), stream=stream)),
+        ]
+        c3 = {}
+        for rep in range(2):   # second repetition is the one reported
+            state.copy_(mags)
+            sync_all()
+            t_all = time.perf_counter()
+            for name, fn in stages:
+                t0 = time.perf_counter()
+                fn()
+                info = planm.last_kernel()
+                torch.cuda.synchronize()
+                c3[name] = {"wall_ms": 1e3 * (time.perf_counter() - t0), "kernel_ms": info["ms"], "kernel": info["name"]}
+            c3["total_wall_ms"] = 1e3 * (time.perf_counter() - t_all)
+        c3["iterations"] = {"nofuture": pm.nofuture_iterations, "online": pm.online_iterations, "batch": pm.batch_iterations,
+                            "look_ahead": pm.look_ahead}
+        extra["config3_run_lws_music"] = c3
 
     # optional final consistency-residual reduction (the only collective): sum over all spectrograms
     step(thr_dense)
