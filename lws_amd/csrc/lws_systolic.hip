@@ -822,54 +822,95 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 // ---------------------------------------------------------------------------------------------
 // layout conversion: reference extended layout <-> time-skewed layout
 // ---------------------------------------------------------------------------------------------
+// Both directions move 64 x 64 tiles (64 frames of one lane round x 64 production times) through LDS: in the reference
+// layout a frame's bins are contiguous, in the skewed layout the 64 lanes of a time step are, so the tile is read along
+// one and written along the other and both sides of the copy are full 512-byte segments.
+// grid: (Kr * NT, B) with NT = ceil((SKEW*63 + C) / 64) time tiles per round of 64 frames; 256 threads.
+constexpr int TILE = 64, TPAD = TILE + 1;
+
 __global__ void __launch_bounds__(256) k_to_skew(const float2 *state, const float *amp, float2 *state_w, float *amp_w,
                                                   float2 *state_nyq, float *amp_nyq, unsigned *amax_bits, int T, int F,
-                                                  int L, int Q, int G, int TpPad) {
-    const int me = blockIdx.x, b = blockIdx.y;
+                                                  int L, int Q, int G, int TpPad, int NT) {
+    __shared__ float2 ts[TILE][TPAD];
+    __shared__ float ta[TILE][TPAD];
+    __shared__ float red[256];
+    const int kk = blockIdx.x / NT, tt = blockIdx.x - kk * NT, b = blockIdx.y;
     const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), C = F - 1;
-    const float2 *srow = state + ((size_t)b * Tp + me) * Np + L;
-    const float *arow = amp + ((size_t)b * Tp + me) * Np + L;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tau0 = SKEW * LANES * kk + TILE * tt;          // first production time of the tile (before the mod G)
     float2 *sw = state_w + (size_t)b * G * LANES;
     float *aw = amp_w + (size_t)b * G * LANES;
-    const bool real_row = me >= Q - 1 && me < T + Q - 1;
     float mx = 0.f;
-    for (int c = threadIdx.x; c < F; c += blockDim.x) {
-        const float av = arow[c];
-        if (real_row) mx = fmaxf(mx, av);
-        if (c < C) {
-            const size_t idx = (size_t)((SKEW * me + c) % G) * LANES + (me & 63);
-            sw[idx] = srow[c];
-            aw[idx] = av;
-        } else {
-            state_nyq[(size_t)b * TpPad + me] = srow[c];
+    for (int ml = wave; ml < TILE; ml += 4) {                // one frame per wave: 64 consecutive bins
+        const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;   // tile column = production time - tau0
+        float2 v = make_float2(0.f, 0.f);
+        float av = 0.f;
+        if (me < Tp && c >= 0 && c < C) {
+            const size_t i = ((size_t)b * Tp + me) * Np + L + c;
+            v = state[i];
+            av = amp[i];
+            if (me >= Q - 1 && me < T + Q - 1) mx = fmaxf(mx, av);
+        }
+        ts[ml][lane] = v;
+        ta[ml][lane] = av;
+    }
+    if (tt == 0 && wave == 0) {                              // Nyquist bins of the round's frames
+        const int me = LANES * kk + lane;
+        if (me < Tp) {
+            const size_t i = ((size_t)b * Tp + me) * Np + L + C;
+            const float av = amp[i];
+            state_nyq[(size_t)b * TpPad + me] = state[i];
             amp_nyq[(size_t)b * TpPad + me] = av;
+            if (me >= Q - 1 && me < T + Q - 1) mx = fmaxf(mx, av);
+        }
+    }
+    __syncthreads();
+    for (int tl = wave; tl < TILE; tl += 4) {                // one production time per wave: 64 consecutive lanes
+        const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
+        if (me < Tp && c >= 0 && c < C) {
+            const size_t idx = (size_t)((tau0 + tl) % G) * LANES + lane;
+            sw[idx] = ts[lane][tl];
+            aw[idx] = ta[lane][tl];
         }
     }
     // block max -> atomic max on the bit pattern (non-negative floats order like unsigned ints)
-    __shared__ float red[256];
     red[threadIdx.x] = mx;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
         __syncthreads();
     }
-    if (threadIdx.x == 0 && real_row) atomicMax(amax_bits + b, __float_as_uint(red[0]));
+    if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(amax_bits + b, __float_as_uint(red[0]));
 }
 
+// Also restores the Hermitian pad columns and the Nyquist column of the extended layout.
 __global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float2 *state_w, const float2 *state_nyq, int T,
-                                                    int F, int L, int Q, int G, int TpPad) {
-    const int me = blockIdx.x, b = blockIdx.y;
+                                                    int F, int L, int Q, int G, int TpPad, int NT) {
+    __shared__ float2 ts[TILE][TPAD];
+    const int kk = blockIdx.x / NT, tt = blockIdx.x - kk * NT, b = blockIdx.y;
     const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), C = F - 1;
-    float2 *orow = state + ((size_t)b * Tp + me) * Np;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tau0 = SKEW * LANES * kk + TILE * tt;
     const float2 *sw = state_w + (size_t)b * G * LANES;
-    for (int n = threadIdx.x; n < Np; n += blockDim.x) {
-        int c = n - L;
-        bool conj = false;
-        if (c < 0) { c = -c; conj = true; }
-        else if (c > C) { c = 2 * C - c; conj = true; }
-        float2 v = (c < C) ? sw[(size_t)((SKEW * me + c) % G) * LANES + (me & 63)] : state_nyq[(size_t)b * TpPad + me];
-        if (conj) v.y = -v.y;
-        orow[n] = v;
+    for (int tl = wave; tl < TILE; tl += 4) {
+        const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
+        if (me < Tp && c >= 0 && c < C) ts[lane][tl] = sw[(size_t)((tau0 + tl) % G) * LANES + lane];
+    }
+    __syncthreads();
+    for (int ml = wave; ml < TILE; ml += 4) {
+        const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
+        if (me < Tp && c >= 0 && c < C) {
+            float2 *orow = state + ((size_t)b * Tp + me) * Np;
+            const float2 v = ts[ml][lane];
+            orow[L + c] = v;
+            const float2 vc = make_float2(v.x, -v.y);
+            if (c >= 1 && c <= L) orow[L - c] = vc;                 // image below DC
+            if (c >= C - L) orow[L + 2 * C - c] = vc;               // image above Nyquist
+        }
+    }
+    if (tt == 0 && wave == 0) {
+        const int me = LANES * kk + lane;
+        if (me < Tp) state[((size_t)b * Tp + me) * Np + L + C] = state_nyq[(size_t)b * TpPad + me];
     }
 }
 
@@ -1012,8 +1053,9 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
     float *amp_nyq = amp_w + n_w;
     unsigned *amax_bits = reinterpret_cast<unsigned *>(amp_nyq + n_n);
     if ((e = hipMemsetAsync(amax_bits, 0, (size_t)B * sizeof(unsigned), stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_to_skew, dim3(Tp, B), dim3(256), 0, stream, state, amp, state_w, amp_w, state_nyq, amp_nyq,
-                       amax_bits, T, F, L, Q, G, TpPad);
+    const int NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;   // time tiles per round of 64 frames
+    hipLaunchKernelGGL(k_to_skew, dim3(Kr * NT, B), dim3(256), 0, stream, state, amp, state_w, amp_w, state_nyq, amp_nyq,
+                       amax_bits, T, F, L, Q, G, TpPad, NT);
     if ((e = hipGetLastError()) != hipSuccess) return e;
 
     int nl = 0;
@@ -1039,7 +1081,7 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
         ++nl;
     }
     if (ev1) (void)hipEventRecord(ev1, stream);
-    hipLaunchKernelGGL(k_from_skew, dim3(Tp, B), dim3(256), 0, stream, state, state_w, state_nyq, T, F, L, Q, G, TpPad);
+    hipLaunchKernelGGL(k_from_skew, dim3(Kr * NT, B), dim3(256), 0, stream, state, state_w, state_nyq, T, F, L, Q, G, TpPad, NT);
     if (launches) *launches = nl;
     return hipGetLastError();
 }
