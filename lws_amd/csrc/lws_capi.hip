@@ -69,6 +69,7 @@ struct lws_plan {
     DevBuf w[3], wflag[3];
     DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out;
     lws::SystolicPlan sys;         // device tables of the systolic kernel (empty if not eligible)
+    lws::SystolicPlan sysw;        // ... of its wide build (frames of 521..1025 bins)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_pending = false;
     float last_ms = 0.f;
@@ -158,18 +159,21 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
 
     // the systolic kernel serves batch sweeps of plans it was built for (fp32, summarised weights
     // with the twiddle structure of create_weights, supported shape); everything else is generic.
-    if (!p->fp64 && mode == lws::MODE_BATCH && !(p->flags & LWS_FORCE_GENERIC) &&
-        iters <= lws::SYSTOLIC_MAX_ITERS && lws::systolic_supports(p->sys, wsel, T)) {
-        int launches = 0;
-        hipError_t e = lws::launch_systolic(p->sys, wsel, static_cast<float2 *>(p->state.p),
-                                            static_cast<const float *>(p->amp.p),
-                                            static_cast<const float *>(p->thr_scaled.p), B, T, iters,
-                                            s, &launches, p->ev0, p->ev1);
-        p->timing_pending = true;
-        if (e != hipSuccess) return fail(LWS_ERR_HIP, "systolic launch failed: %s", hipGetErrorString(e));
-        p->last_launches = launches;
-        p->last_name = lws::systolic_name(p->sys);
-        return LWS_OK;
+    if (!p->fp64 && mode == lws::MODE_BATCH && !(p->flags & LWS_FORCE_GENERIC) && iters <= lws::SYSTOLIC_MAX_ITERS) {
+        const bool narrow = lws::systolic_supports(p->sys, wsel, T);
+        const bool wide = !narrow && lws::wide::systolic_supports(p->sysw, wsel, T);
+        if (narrow || wide) {
+            int launches = 0;
+            float2 *st = static_cast<float2 *>(p->state.p);
+            const float *am = static_cast<const float *>(p->amp.p), *th = static_cast<const float *>(p->thr_scaled.p);
+            hipError_t e = narrow ? lws::launch_systolic(p->sys, wsel, st, am, th, B, T, iters, s, &launches, p->ev0, p->ev1)
+                                  : lws::wide::launch_systolic(p->sysw, wsel, st, am, th, B, T, iters, s, &launches, p->ev0, p->ev1);
+            p->timing_pending = true;
+            if (e != hipSuccess) return fail(LWS_ERR_HIP, "systolic launch failed: %s", hipGetErrorString(e));
+            p->last_launches = launches;
+            p->last_name = narrow ? lws::systolic_name(p->sys) : lws::wide::systolic_name(p->sysw);
+            return LWS_OK;
+        }
     }
 
     lws::GenericArgs<real> a;
@@ -363,6 +367,7 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
                                p->have[1] ? p->hostW[1].data() : nullptr,
                                p->have[2] ? p->hostW[2].data() : nullptr};
         hipError_t e = lws::systolic_build(p->sys, F, L, Q, Qp, hw);
+        if (e == hipSuccess && !(p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2])) e = lws::wide::systolic_build(p->sysw, F, L, Q, Qp, hw);
         if (e != hipSuccess) rc = fail(LWS_ERR_HIP, "systolic table upload failed: %s", hipGetErrorString(e));
     }
     if (rc != LWS_OK) {
@@ -381,6 +386,7 @@ void lws_plan_destroy(lws_plan *p) {
     p->thr_host_copy.release(); p->thr_scaled.release(); p->stage.release();
     p->resid_rows.release(); p->resid_out.release();
     lws::systolic_release(p->sys);
+    lws::wide::systolic_release(p->sysw);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;

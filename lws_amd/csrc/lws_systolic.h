@@ -27,4 +27,16 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
                            const float *thr, int B, int T, int iters, hipStream_t stream,
                            int *launches, hipEvent_t ev0, hipEvent_t ev1);
 
+// The same kernel compiled for frames of up to 1025 bins (lws_systolic.hip with -DLWS_WIDE=1): 16-step lane skew,
+// 64-step ring, 3 sweep slots.  Same contract.
+namespace wide {
+hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3]);
+void systolic_release(SystolicPlan &sp);
+bool systolic_supports(const SystolicPlan &sp, int wsel, int T);
+const char *systolic_name(const SystolicPlan &sp);
+hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp,
+                           const float *thr, int B, int T, int iters, hipStream_t stream,
+                           int *launches, hipEvent_t ev0, hipEvent_t ev1);
+}  // namespace wide
+
 }  // namespace lws

@@ -43,11 +43,27 @@
 #include <utility>
 #include <vector>
 
-namespace lws {
+// The file is compiled twice: as is (frames of up to 513 bins: 8-step skew between lanes, 32-step ring, 7 sweep slots)
+// and with -DLWS_WIDE=1 into namespace lws::wide (frames of up to 1025 bins: a lane needs 1024 steps per frame, so the
+// 64 lanes of a round are skewed by 16 steps, the lag between sweeps and the ring are 64 steps deep and 3 sweep slots
+// fit the LDS).
+#ifndef LWS_WIDE
+#define LWS_WIDE 0
+#endif
+#if LWS_WIDE
+#define LWS_NS_OPEN namespace lws { namespace wide {
+#define LWS_NS_CLOSE } }
+#else
+#define LWS_NS_OPEN namespace lws {
+#define LWS_NS_CLOSE }
+#endif
+
+LWS_NS_OPEN
 namespace {
 
 constexpr int LANES = 64;
-constexpr int RING = 32;
+constexpr int RING = LWS_WIDE ? 64 : 32;
+constexpr int NBLK = RING / 8;                           // ring blocks of 8 steps
 // ring entry of production time nu, lane l:  set + ((nu >> 1) & 15) * PAIR_BYTES + (l + HALO) * 16 + (nu & 1) * 8
 // -- two consecutive times of one lane share a 16-byte cell, so a reader fetches two adjacent taps with one
 // ds_read_b128; every row of 64 lanes carries HALO copies of the opposite end on each side (lanes -3..-1 mirror
@@ -65,7 +81,7 @@ constexpr int PAIR_BYTES = (LANES + 2 * HALO + 2) * LANE_B;  // two consecutive 
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
 constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB
 #ifndef LWS_NSLOTS
-#define LWS_NSLOTS 7
+#define LWS_NSLOTS (LWS_WIDE ? 3 : 7)
 #endif
 #ifndef LWS_PF
 #define LWS_PF 8
@@ -79,7 +95,9 @@ constexpr int META_OFF = THR_OFF + MAX_ITERS * 4;        // n_eff
 constexpr int DONE_OFF = META_OFF + 16;               // per-wave count of completed steps (flow control)
 constexpr int DUMMY_OFF = DONE_OFF + 64;               // 64 x 8 B: where predicated-off lanes park their conditional writes
 constexpr int LDS_BYTES = DUMMY_OFF + LANES * 8;
-constexpr int SKEW = 8, ROWP = SKEW * LANES, LAG = 32;
+constexpr int SKEW = LWS_WIDE ? 16 : 8, ROWP = SKEW * LANES, LAG = RING;
+constexpr int ROWP_SHIFT = LWS_WIDE ? 10 : 9;
+static_assert((1 << ROWP_SHIFT) == ROWP, "frame period");
 #ifndef LWS_SERVICE_WAVE
 #define LWS_SERVICE_WAVE 1   // loader + Nyquist bins run on a wave of their own
 #endif
@@ -215,9 +233,9 @@ __device__ __forceinline__ void flow_publish(int lane, int wave, int s_next) {
 
 // Per-lane registers of a compute lane that stay valid for one block of 8 steps.
 struct LaneCtx {
-    int ob[4];        // [m]: LDS address of this lane's halo-shifted origin in the previous sweep's (old) set, block (a - m) & 3;
+    int ob[NBLK];     // [m]: LDS address of this lane's halo-shifted origin in the previous sweep's (old) set, block (a - m) & 3;
                       //      the own (new) set is the next one: + SET_BYTES, a compile-time offset
-    int uo[4];        // [m]: wave-uniform row origin (set + block) of the old set, for the image pseudo-lanes
+    int uo[NBLK];     // [m]: wave-uniform row origin (set + block) of the old set, for the image pseudo-lanes
     int nyq_base;     // NYQ_OFF + own set row + lane*8 (taps derive the neighbour lane / set from it)
     int halo_shift;   // +-64 lanes in bytes for the 6 lanes that also write a halo copy, else 0
     int dummy;        // private LDS slot for predicated-off conditional writes
@@ -248,22 +266,22 @@ __device__ __forceinline__ void ring_publish(int addr, int halo_shift, int dummy
 // address of the ring entry of the lane DR frames away, produced at clock (block start + P + OFF); P may be 8
 // (phase 0 of the next block).  base[m] addresses lane - HALO of block (a - m) & 3.
 // NEWSET: 1 = the lane's own output set (base + SET_BYTES), 0 = the set base[] points to.
-template <int P, int OFF, int DR = 0, int NEWSET = 0> __device__ __forceinline__ int ring_addr(const int (&base)[4]) {
+template <int P, int OFF, int DR = 0, int NEWSET = 0> __device__ __forceinline__ int ring_addr(const int (&base)[NBLK]) {
     constexpr int q = P + OFF;
-    static_assert(q >= -32 && q <= 15, "ring retention exceeded");
+    static_assert(q >= -RING && q <= 15, "ring retention exceeded");
     static_assert(DR >= -HALO && DR <= HALO, "halo too small");
     constexpr int fl = floor_div8(q);
-    constexpr int m = (-fl) & 3;                 // block a+1 shares the physical block of a-3
+    constexpr int m = (-fl) & (NBLK - 1);        // block a+1 shares the physical block of a-(NBLK-1)
     constexpr int within = q - 8 * fl;
     return base[m] + NEWSET * SET_BYTES + (HALO + DR) * LANE_B + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
 }
 
 // the same for an absolute row index (halo copies, image pseudo-lanes); base[m] is the row origin (set + block)
-template <int P, int OFF, int LIDX, int NEWSET = 0> __device__ __forceinline__ int ring_addr_abs(const int (&base)[4]) {
+template <int P, int OFF, int LIDX, int NEWSET = 0> __device__ __forceinline__ int ring_addr_abs(const int (&base)[NBLK]) {
     constexpr int q = P + OFF;
-    static_assert(q >= -32 && q <= 15, "ring retention exceeded");
+    static_assert(q >= -RING && q <= 15, "ring retention exceeded");
     constexpr int fl = floor_div8(q);
-    constexpr int m = (-fl) & 3;
+    constexpr int m = (-fl) & (NBLK - 1);
     constexpr int within = q - 8 * fl;
     return base[m] + NEWSET * SET_BYTES + LIDX * LANE_B + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
 }
@@ -272,7 +290,7 @@ template <int P, int OFF, int LIDX, int NEWSET = 0> __device__ __forceinline__ i
 // its frame (phase PH = j, flag st) or bin C-j (phase PH = 8-j, flag en) stores the conjugate where bin -j / C+j
 // would have been produced: 2j steps earlier / later.  `u` = wave-uniform row origins of the lane's output set.
 template <int L, int PH, int PB, int NEWSET>
-__device__ __forceinline__ void image_publish(const int (&u)[4], bool st, bool en, int dummy, float2 out) {
+__device__ __forceinline__ void image_publish(const int (&u)[NBLK], bool st, bool en, int dummy, float2 out) {
 #if LWS_DBG_NOIMG
     return;
 #endif
@@ -306,7 +324,7 @@ __device__ __forceinline__ float2 tap_lds(const LaneCtx &cx) {
         const int ln = (cx.lane8 + 8 * DR) & (SLOT_BYTES - 1);
         v = lds_read(cx.nyq_base - cx.lane8 + ln - (s.set_new ? 0 : SLOT_BYTES));
     } else {
-        static_assert(s.off <= -2 && s.off >= -30, "tap outside ring retention (ages 2..30)");
+        static_assert(s.off <= -2 && s.off >= -(RING - 2), "tap outside ring retention (ages 2..RING-2)");
         v = lds_read(ring_addr<PB, s.off, DR, s.set_new>(cx.ob));
     }
     if constexpr (s.conj) v = cj(v);
@@ -355,9 +373,9 @@ __device__ __forceinline__ void load_row2(const LaneCtx &cx, bool st, bool en, f
         constexpr bool img_lo = (MODE == 0) ? (j <= L - PA - 2) : (MODE == 2 ? (j <= L - 1) : false);
         constexpr bool img_hi = (MODE == 0 || MODE == 1) ? (j >= 8 + L - PA) : false;
         if constexpr (need0 || need1) {
-            static_assert(q >= -32 && q + 1 <= 15, "ring retention exceeded");
+            static_assert(q >= -RING && q + 1 <= 15, "ring retention exceeded");
             constexpr int fl = floor_div8(q);
-            constexpr int m = (-fl) & 3;
+            constexpr int m = (-fl) & (NBLK - 1);
             constexpr int within = q - 8 * fl;                   // even
             constexpr int setoff = (DR < 0) ? SET_BYTES : 0;     // frames above: own sweep's set; below: previous sweep's
             const int real_base = cx.ob[m] + (HALO + DR) * LANE_B;
@@ -594,7 +612,10 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     const bool is_nyq_lane = lane < NSLOTS;
     const bool is_nyq_loader = lane == NSLOTS;
     const int v0 = t0 - (is_nyq_lane ? (slot + 1) * LAG : 0);
-    const int vrow = (v0 - C) >> 3;              // virtual frame whose Nyquist bin is due now
+    // a frame ends every SKEW clocks; with a skew of two blocks only every other block has one (the same blocks for
+    // every slot and for the loader: LAG and C are multiples of SKEW)
+    if (((v0 - C) & (SKEW - 1)) != 0) return;
+    const int vrow = (v0 - C) / SKEW;            // virtual frame whose Nyquist bin is due now (floor: SKEW | v0 - C)
     const int rho = vrow & 63, kap = vrow >> 6;
     const int g = kap / Kr, k = kap - g * Kr;
     const int me = k * LANES + rho;
@@ -602,7 +623,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     const bool valid = (v0 - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
     if (is_nyq_loader) {
         lds_write(NYQ_OFF + rho * 8, sv.nyq_in_next);  // loaded one block ago for this frame
-        lds_write((ablk & 3) * BLK_BYTES + PLR * LANE_B, sv.nyq_in_next);   // and as entry "bin C" of set 0's image lane
+        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, sv.nyq_in_next);   // and as entry "bin C" of set 0's image lane
         const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
         if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2(state_nyq_b + me1);
@@ -612,15 +633,15 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
         const float thr = thr_eff[valid ? j : 0];
         const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
-        int nb[4][4], ob[4][4], nn[4], no[4];
+        int nb[4][NBLK], ob[4][NBLK], nn[4], no[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int ln = ((rho - d) & 63), lo = ((rho + d) & 63);
             nn[d] = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln * 8;
             no[d] = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int blk = ((ablk - m) & 3) * BLK_BYTES;
+            for (int m = 0; m < NBLK; ++m) {
+                const int blk = ((ablk - m) & (NBLK - 1)) * BLK_BYTES;
                 nb[d][m] = set_new + blk + ln * LANE_B;   // ring_addr adds the HALO offset
                 ob[d][m] = set_old + blk + lo * LANE_B;
             }
@@ -653,7 +674,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         const bool active = real_row && (target > thr);
         const float2 out = project(acc, target, active, old);
         lds_write(nn[0], out);
-        lds_write(set_new + (ablk & 3) * BLK_BYTES + PLR * LANE_B, out);   // bin C of the image lane: production time = this clock
+        lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, out);   // bin C of the image lane: production time = this clock
         if (valid && (slot == NSLOTS - 1 || j == n_eff - 1)) state_nyq_b[me] = out;
         // target magnitude of the next block's Nyquist bin
         const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
@@ -735,7 +756,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         {
             const int vv = v0 - SKEW * lane;        // clock relative to the start of the lane's first frame
             const int cbase = vv & (ROWP - 1);
-            const int kap = vv >> 9;
+            const int kap = vv >> ROWP_SHIFT;
             const int g = kap / Kr, k = kap - g * Kr;
             const int me = k * LANES + lane;
             const int j = g * NSLOTS + slot;
@@ -749,7 +770,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         {
             const int vv = v0 + 8 - SKEW * lane;
             const int cbase = vv & (ROWP - 1);
-            const int kap = vv >> 9;
+            const int kap = vv >> ROWP_SHIFT;
             const int g = kap / Kr, k = kap - g * Kr;
             const int me = k * LANES + lane;
             const int j = g * NSLOTS + slot;
@@ -765,8 +786,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         cx.dummy = DUMMY_OFF + lane * 8;
         cx.halo_shift = (lane < HALO) ? LANES * LANE_B : (lane >= LANES - HALO ? -LANES * LANE_B : 0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int blk = ((ablk - m) & 3) * BLK_BYTES;
+        for (int m = 0; m < NBLK; ++m) {
+            const int blk = ((ablk - m) & (NBLK - 1)) * BLK_BYTES;
             cx.uo[m] = set_old + blk;
             cx.ob[m] = set_old + blk + lane * LANE_B;
         }
@@ -792,10 +813,10 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                     service_nyquist<Q, L, MASK>(a, sv, lane, t0, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
                 // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
                 // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
-                int ldb[4], ldu[4];
+                int ldb[NBLK], ldu[NBLK];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    ldu[m] = (((t0 >> 3) - m) & 3) * BLK_BYTES;
+                for (int m = 0; m < NBLK; ++m) {
+                    ldu[m] = (((t0 >> 3) - m) & (NBLK - 1)) * BLK_BYTES;
                     ldb[m] = ldu[m] + lane * LANE_B;
                 }
                 const int cb0 = (t0 - SKEW * lane) & (ROWP - 1), cb1 = (t0 + 8 - SKEW * lane) & (ROWP - 1);
@@ -949,7 +970,7 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
     for (int i = 0; i < 3; ++i) sp.ok[i] = false;
     const int C = F - 1;
     if (Qp != Q || !(Q == 2 || Q == 4) || L != 5) return hipSuccess;
-    if (C % 8 != 0 || C > ROWP || C < 16) return hipSuccess;
+    if (C % SKEW != 0 || C > ROWP || C < 16) return hipSuccess;
     if ((Q - 1) * SKEW + L + 1 > LAG) return hipSuccess;
     const int K1 = L + 1;
     for (int i = 0; i < 3; ++i) {
@@ -1069,13 +1090,13 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
         a.T = T; a.Tp = Tp; a.TpPad = TpPad; a.Kr = Kr; a.G = G; a.C = F - 1;
         for (int x = 0; x < 64; ++x) a.w[x] = x < 2 * Q * (L + 1) ? tb->w[x] : 0.f;
         if (Q == 4) {
-            if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, B, stream); sp.name = "systolic_q4_l5_hann"; }
-            else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B, stream); sp.name = "systolic_q4_l5_hannmask"; }
-            else { e = launch_k<4, 5, mask_all(4, 5)>(a, B, stream); sp.name = "systolic_q4_l5_allmask"; }
+            if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hann" : "systolic_q4_l5_hann"; }
+            else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hannmask" : "systolic_q4_l5_hannmask"; }
+            else { e = launch_k<4, 5, mask_all(4, 5)>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_allmask" : "systolic_q4_l5_allmask"; }
         } else {
-            if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, B, stream); sp.name = "systolic_q2_l5_hann"; }
-            else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B, stream); sp.name = "systolic_q2_l5_hannmask"; }
-            else { e = launch_k<2, 5, mask_all(2, 5)>(a, B, stream); sp.name = "systolic_q2_l5_allmask"; }
+            if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hann" : "systolic_q2_l5_hann"; }
+            else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hannmask" : "systolic_q2_l5_hannmask"; }
+            else { e = launch_k<2, 5, mask_all(2, 5)>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_allmask" : "systolic_q2_l5_allmask"; }
         }
         if (e != hipSuccess) return e;
         ++nl;
@@ -1086,4 +1107,4 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
     return hipGetLastError();
 }
 
-}  // namespace lws
+LWS_NS_CLOSE

@@ -105,3 +105,32 @@ def test_weights_without_zero_pattern_use_the_allmask_kernel(oracle):
     out3 = plan3.batch(S, thr)
     assert plan3.last_kernel()["name"] == "generic_fp32"
     assert rel_l2(out3, oracle.batch_lws(S, W3, thr)) < 3e-3
+
+
+# ----------------------------------------------------------------------------- wide build: frames of 521..1025 bins
+def _wide_name(p):
+    return p.plan().last_kernel()["name"]
+
+
+@pytest.mark.parametrize("fsize,fshift,T", [(2048, 512, 9), (2048, 512, 70), (2048, 1024, 40), (1536, 384, 33),
+                                            (1280, 320, 66), (1056, 264, 21)])
+def test_wide_frames(oracle, fsize, fshift, T):
+    """F - 1 in (512, 1024], a multiple of 16: the 16-step-skew / 64-step-ring build (3 sweep slots), BASELINE
+    config 5's frame size included; T around one and two rounds of 64 lanes."""
+    out = run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0, 0.0], seed=fsize + T)
+    p = lws_amd.lws(fsize, fshift)
+    p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
+    assert _wide_name(p).startswith("systolic_wide_q"), _wide_name(p)
+    assert out.shape == (1, T, fsize // 2 + 1)
+
+
+@pytest.mark.parametrize("n_it", [1, 3, 4, 7, 10])
+def test_wide_sweep_counts_around_slot_groups(oracle, n_it):
+    run_case(oracle, 2048, 512, 12, np.linspace(0.8, 0.0, n_it), seed=300 + n_it, B=2, scale=[1.0, 7.0])
+
+
+def test_wide_needs_a_multiple_of_16():
+    """F - 1 = 520 is a multiple of 8 but not of 16: generic engine."""
+    p = lws_amd.lws(1040, 260)
+    p.batch_lws(np.ones((4, 521)), thresholds=[0.0])
+    assert p.plan().last_kernel()["name"] == "generic_fp32"
