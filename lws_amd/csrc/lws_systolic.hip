@@ -39,6 +39,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -157,7 +158,7 @@ struct SysArgs {
     const float *thr;        // [B][n_iters] thresholds scaled by mean|S|
     const float *amax;       // [B] max target magnitude
     int n_iters, T, Tp, TpPad, Kr, G, C;
-    float w[2 * 4 * 8];      // W[0][r][k] as (re, im), r < Q, k <= L (at most 4 x 8)
+    unsigned long long w[4 * 8];   // W[0][r][k], r < Q, k <= L (at most 4 x 8): bit patterns of (re, im) as one 64-bit scalar
 };
 
 // volatile: keeps every tap a separate ds_read_b64 (the backend otherwise fuses pairs into
@@ -398,35 +399,79 @@ __device__ __forceinline__ void load_row2(const LaneCtx &cx, bool st, bool en, f
     });
 }
 
+// Complex values travel as (re, im) register pairs (that is how ds_read_b128 delivers them), so sums and differences
+// of two of them and "real scalar times complex" are single packed v_pk_add_f32 / v_pk_fma_f32 instructions (1.7x the
+// float2 throughput of two scalar ones on gfx950, scratch/pk_ubench.hip).  Quarter turns, conjugation-like sign flips
+// and "broadcast one half of the (re, im) weight pair" are the instructions' own operand modifiers (op_sel / neg), which
+// the compiler does not derive from C++ (it builds the operands with v_mov / v_xor instead): hence the inline assembly.
+// A weight is wave-uniform and stays in an aligned SGPR pair.
+typedef float v2f __attribute__((ext_vector_type(2)));
+using wp_t = unsigned long long;   // bit pattern of (re, im) as one 64-bit scalar
+__device__ __forceinline__ v2f vv(float2 a) { return (v2f){a.x, a.y}; }
+__device__ __forceinline__ float2 ff(v2f a) { return make_float2(a.x, a.y); }
+
+// acc + (sl * w.HALF) * v'  with v' = v (SWZ 0) or (v.y, v.x) (SWZ 1) and the sign of the product chosen per lane
+#define LWS_PKFMA(H, S, NL, NH)                                                                                     \
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[" #H "," #S ",0] op_sel_hi:[" #H "," LWS_NOT_##S ",1] neg_lo:[" #NL    \
+        ",0,0] neg_hi:[" #NH ",0,0]"                                                                                \
+        : "+v"(acc)                                                                                                 \
+        : "s"(w), "v"(v))
+#define LWS_NOT_0 "1"
+#define LWS_NOT_1 "0"
+template <int HALF, int SWZ, int NEGLO, int NEGHI> __device__ __forceinline__ v2f pk_fma_w(v2f acc, wp_t w, v2f v) {
+    if constexpr (HALF == 0 && SWZ == 0 && NEGLO == 0 && NEGHI == 0) LWS_PKFMA(0, 0, 0, 0);
+    else if constexpr (HALF == 0 && SWZ == 0 && NEGLO == 1 && NEGHI == 1) LWS_PKFMA(0, 0, 1, 1);
+    else if constexpr (HALF == 1 && SWZ == 0 && NEGLO == 0 && NEGHI == 0) LWS_PKFMA(1, 0, 0, 0);
+    else if constexpr (HALF == 1 && SWZ == 0 && NEGLO == 1 && NEGHI == 1) LWS_PKFMA(1, 0, 1, 1);
+    else if constexpr (HALF == 0 && SWZ == 1 && NEGLO == 1 && NEGHI == 0) LWS_PKFMA(0, 1, 1, 0);
+    else if constexpr (HALF == 0 && SWZ == 1 && NEGLO == 0 && NEGHI == 1) LWS_PKFMA(0, 1, 0, 1);
+    else if constexpr (HALF == 1 && SWZ == 1 && NEGLO == 1 && NEGHI == 0) LWS_PKFMA(1, 1, 1, 0);
+    else if constexpr (HALF == 1 && SWZ == 1 && NEGLO == 0 && NEGHI == 1) LWS_PKFMA(1, 1, 0, 1);
+    else static_assert(HALF < 0, "modifier combination not instantiated");
+    return acc;
+}
+// x - y in one instruction (the compiler splits a vector subtraction into two scalar ones)
+__device__ __forceinline__ v2f pk_sub(v2f x, v2f y) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+// x * j^ROT + y
+template <int ROT> __device__ __forceinline__ v2f pk_add_rot(v2f x, v2f y) {
+    v2f d;
+    if constexpr ((ROT & 3) == 0) d = x + y;
+    else if constexpr ((ROT & 3) == 1) asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(d) : "v"(x), "v"(y));
+    else if constexpr ((ROT & 3) == 2) d = pk_sub(y, x);
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+
 // acc += w*b + conj(w)*c with w = (wr, wi) * j^ROT   (grouped form of lwslib.cpp:310-311)
-template <int ROT> __device__ __forceinline__ void pair_rot(float2 &a, float wr, float wi, float2 b, float2 c) {
+//   = p (b + c) + q j (b - c)   with (p, q) = (wr, wi), (-wi, wr), (-wr, -wi), (wi, -wr) for ROT = 0..3,
+//   j (dx, dy) = (-dy, dx)
+template <int ROT> __device__ __forceinline__ void pair_rot(float2 &a, wp_t w, float2 b, float2 c) {
 #if LWS_DBG_NOMATH
     a.x += b.x; a.y += c.y; return;
 #endif
-    const float sx = b.x + c.x, dy = b.y - c.y, sy = b.y + c.y, dx = b.x - c.x;
-    // two fused multiply-adds per component (weights are wave-uniform scalars; the packed v_pk_* forms measured
-    // slower on gfx950)
-    if constexpr (ROT == 0) { a.x = fmaf(-wi, dy, fmaf(wr, sx, a.x)); a.y = fmaf(wi, dx, fmaf(wr, sy, a.y)); }
-    else if constexpr (ROT == 1) { a.x = fmaf(-wr, dy, fmaf(-wi, sx, a.x)); a.y = fmaf(wr, dx, fmaf(-wi, sy, a.y)); }
-    else if constexpr (ROT == 2) { a.x = fmaf(wi, dy, fmaf(-wr, sx, a.x)); a.y = fmaf(-wi, dx, fmaf(-wr, sy, a.y)); }
-    else { a.x = fmaf(wr, dy, fmaf(wi, sx, a.x)); a.y = fmaf(-wr, dx, fmaf(wi, sy, a.y)); }
+    const v2f S = vv(b) + vv(c), Dm = pk_sub(vv(b), vv(c));
+    v2f acc = vv(a);
+    constexpr int R = ROT & 3;
+    acc = pk_fma_w<(R & 1), 0, (R == 1 || R == 2), (R == 1 || R == 2)>(acc, w, S);        // p * S
+    acc = pk_fma_w<1 - (R & 1), 1, (R < 2), (R >= 2)>(acc, w, Dm);                          // q * (-dy, dx)
+    a = ff(acc);
 }
 // the same for a weight whose imaginary part is exactly zero (W[0][r][0] of symmetric windows): half the work
-template <int ROT> __device__ __forceinline__ void pair_rot_real(float2 &a, float wr, float2 b, float2 c) {
-    if constexpr (ROT == 0) { a.x = fmaf(wr, b.x + c.x, a.x); a.y = fmaf(wr, b.y + c.y, a.y); }
-    else if constexpr (ROT == 1) { a.x = fmaf(-wr, b.y - c.y, a.x); a.y = fmaf(wr, b.x - c.x, a.y); }
-    else if constexpr (ROT == 2) { a.x = fmaf(-wr, b.x + c.x, a.x); a.y = fmaf(-wr, b.y + c.y, a.y); }
-    else { a.x = fmaf(wr, b.y - c.y, a.x); a.y = fmaf(-wr, b.x - c.x, a.y); }
+template <int ROT> __device__ __forceinline__ void pair_rot_real(float2 &a, wp_t w, float2 b, float2 c) {
+    constexpr int R = ROT & 3;
+    v2f acc = vv(a);
+    if constexpr (R == 0) acc = pk_fma_w<0, 0, 0, 0>(acc, w, vv(b) + vv(c));
+    else if constexpr (R == 1) acc = pk_fma_w<0, 1, 1, 0>(acc, w, pk_sub(vv(b), vv(c)));
+    else if constexpr (R == 2) acc = pk_fma_w<0, 0, 1, 1>(acc, w, vv(b) + vv(c));
+    else acc = pk_fma_w<0, 1, 0, 1>(acc, w, pk_sub(vv(b), vv(c)));
+    a = ff(acc);
 }
-// v * j^ROT
-template <int ROT> __device__ __forceinline__ float2 crot(float2 v) {
-    if constexpr ((ROT & 3) == 0) return v;
-    else if constexpr ((ROT & 3) == 1) return make_float2(-v.y, v.x);
-    else if constexpr ((ROT & 3) == 2) return make_float2(-v.x, -v.y);
-    else return make_float2(v.y, -v.x);
-}
-__device__ __forceinline__ float2 cadd(float2 p, float2 q) { return make_float2(p.x + q.x, p.y + q.y); }
-__device__ __forceinline__ float2 csub(float2 p, float2 q) { return make_float2(p.x - q.x, p.y - q.y); }
+__device__ __forceinline__ float2 cadd(float2 p, float2 q) { return ff(vv(p) + vv(q)); }
+__device__ __forceinline__ float2 csub(float2 p, float2 q) { return ff(pk_sub(vv(p), vv(q))); }
 
 // Contribution of the centre frame (W[.,0,k] does not depend on bin % Q) to the bin at phase PH / clock PB.
 template <int L, uint32_t MASK, int PH, int PB>
@@ -448,7 +493,7 @@ __device__ __forceinline__ float2 centre_sum(const SysArgs &a, const LaneCtx &cx
                 const float2 im = tap_any<PH, PB, 0, k, 2>(cx, self_old, next_old, prev_out);
                 hi.x = en ? im.x : hi.x; hi.y = en ? im.y : hi.y;
             }
-            pair_rot<0>(acc, a.w[2 * k], a.w[2 * k + 1], lo, hi);
+            pair_rot<0>(acc, a.w[k], lo, hi);
         }
     });
     return acc;
@@ -473,27 +518,30 @@ __device__ __forceinline__ float2 rows_sum(const SysArgs &a, const float2 (&tu)[
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
     float2 accr = make_float2(0.f, 0.f);
     if constexpr ((MASK >> (R * K1)) & 1u) {
-        if constexpr ((MASK & FLAG_K0REAL) != 0) pair_rot_real<rot>(accr, a.w[2 * (R * K1)], tu[L + OFFS], td[L + OFFS]);
-        else pair_rot<rot>(accr, a.w[2 * (R * K1)], a.w[2 * (R * K1) + 1], tu[L + OFFS], td[L + OFFS]);
+        if constexpr ((MASK & FLAG_K0REAL) != 0) pair_rot_real<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
+        else pair_rot<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
     }
     static_for<L>([&](auto ik) {
         constexpr int k = decltype(ik)::value + 1;
         if constexpr ((MASK >> (R * K1 + k)) & 1u) {
             // W[mod]*S[m-r,c-k] + conj(W[mod])*S[m+r,c-k] + W[-mod]*S[m+r,c+k] + conj(W[-mod])*S[m-r,c+k]
             // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
-            const float wr = a.w[2 * (R * K1 + k)], wi = a.w[2 * (R * K1 + k) + 1];
+            const wp_t w = a.w[R * K1 + k];
             const float2 um = tu[L - k + OFFS], up = tu[L + k + OFFS], dm = td[L - k + OFFS], dp = td[L + k + OFFS];
             float2 b, c;
             if constexpr ((rot & 1) == 0) { b = cadd(um, dp); c = cadd(dm, up); }
             else { b = csub(um, dp); c = csub(dm, up); }
             if constexpr (r13 && R == 3 && k >= 2) {
-                // j^(k+rot3) B3 and its mirror, rot3 = 3 mod = -mod (mod 4)
-                p3.b[k] = crot<k + rot>(b);
-                p3.c[k] = crot<8 - k - rot>(c);
+                p3.b[k] = b;      // rotated when rows 1 pick them up
+                p3.c[k] = c;
             } else if constexpr (r13 && R == 1 && k >= 2) {
-                pair_rot<0>(accr, wr, wi, cadd(crot<rot>(b), p3.b[k]), cadd(crot<4 - rot>(c), p3.c[k]));
+                // j^rot1 (B1 + j^(k+rot3-rot1) B3) and j^-rot1 (C1 + j^(rot1-k-rot3) C3): one multiply for both rows
+                constexpr int rot3 = ((mod * 3) % Q) * (4 / Q);
+                const v2f bb = pk_add_rot<(k + rot3 - rot + 8) & 3>(vv(p3.b[k]), vv(b));
+                const v2f cc = pk_add_rot<(rot - k - rot3 + 16) & 3>(vv(p3.c[k]), vv(c));
+                pair_rot<rot>(accr, w, ff(bb), ff(cc));
             } else {
-                pair_rot<rot>(accr, wr, wi, b, c);
+                pair_rot<rot>(accr, w, b, c);
             }
         }
     });
@@ -653,13 +701,13 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
             constexpr int k = decltype(ik)::value + 1;
             if constexpr ((MASK >> k) & 1u) {
                 const float2 lo = lds_read(ring_addr<0, -k>(nb[0]));
-                pair_rot<0>(acc, a.w[2 * k], a.w[2 * k + 1], lo, cj(lo));
+                pair_rot<0>(acc, a.w[k], lo, cj(lo));
             }
         });
         static_for<Q - 1>([&](auto ir) {
             constexpr int r = decltype(ir)::value + 1;
             if constexpr ((MASK >> (r * K1)) & 1u)
-                pair_rot<0>(acc, a.w[2 * r * K1], a.w[2 * r * K1 + 1], lds_read(nn[r]), lds_read(no[r]));
+                pair_rot<0>(acc, a.w[r * K1], lds_read(nn[r]), lds_read(no[r]));
             static_for<L>([&](auto ik) {
                 constexpr int k = decltype(ik)::value + 1;
                 if constexpr ((MASK >> (r * K1 + k)) & 1u) {
@@ -667,7 +715,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
                     const float2 dn = lds_read(ring_addr<0, SKEW * r - k - LAG>(ob[r]));
                     const float2 bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
                     const float2 csum = make_float2(dn.x + up.x, dn.y - up.y);   // dn + conj(up)
-                    pair_rot<0>(acc, a.w[2 * (r * K1 + k)], a.w[2 * (r * K1 + k) + 1], bsum, csum);
+                    pair_rot<0>(acc, a.w[r * K1 + k], bsum, csum);
                 }
             });
         });
@@ -1088,7 +1136,12 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
         a.thr = thr + i0; a.amax = reinterpret_cast<const float *>(amax_bits);
         a.n_iters = (iters - i0 < MAX_ITERS) ? iters - i0 : MAX_ITERS;
         a.T = T; a.Tp = Tp; a.TpPad = TpPad; a.Kr = Kr; a.G = G; a.C = F - 1;
-        for (int x = 0; x < 64; ++x) a.w[x] = x < 2 * Q * (L + 1) ? tb->w[x] : 0.f;
+        for (int x = 0; x < 32; ++x) {
+            const float re = x < Q * (L + 1) ? tb->w[2 * x] : 0.f, im = x < Q * (L + 1) ? tb->w[2 * x + 1] : 0.f;
+            unsigned ur, ui;
+            memcpy(&ur, &re, 4); memcpy(&ui, &im, 4);
+            a.w[x] = ((unsigned long long)ui << 32) | ur;
+        }
         if (Q == 4) {
             if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hann" : "systolic_q4_l5_hann"; }
             else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hannmask" : "systolic_q4_l5_hannmask"; }
