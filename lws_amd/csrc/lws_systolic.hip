@@ -225,7 +225,9 @@ __device__ __forceinline__ void flow_wait(int lane, int s, bool watched) {
     while (true) {
         const int v = lds_read_i32(addr);
         if (__all(!watched || v >= s)) break;
-        __builtin_amdgcn_s_sleep(1);
+#ifdef LWS_SLEEP
+        __builtin_amdgcn_s_sleep(1);   // measured: polling without a sleep is 1 % faster
+#endif
     }
 }
 __device__ __forceinline__ void flow_publish(int lane, int wave, int s_next) {
