@@ -223,6 +223,16 @@ def main():
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     extra["residual_db_after"] = float(10 * np.log10(tot[1].item() / tot[0].item()))
+    # the true consistency 20 log10(|S| / |STFT(iSTFT(S)) - S|) (lws.pyx:140-144) of the same result, on the device
+    # (lws_stft.hip), summed over all spectrograms of all ranks with the same all-reduce
+    t0 = time.perf_counter()
+    sums = lws_amd._capi.consistency_dev(state.data_ptr(), B, T, 1024, 256, p.awin, p.swin, p.perfectrec,
+                                          device=local_rank, stream=stream)
+    extra["consistency_ms"] = 1e3 * (time.perf_counter() - t0)
+    tot2 = torch.tensor(sums.sum(axis=0), dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot2, op=dist.ReduceOp.SUM)
+    extra["consistency_db_after"] = float(10 * np.log10(tot2[0].item() / tot2[1].item()))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

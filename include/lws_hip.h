@@ -114,6 +114,26 @@ int lws_last_kernel_time(lws_plan *plan, float *ms, int *launches);
 /* Name of the update kernel the last call dispatched ("generic_fp32", "systolic_q4", ...). */
 const char *lws_last_kernel_name(lws_plan *plan);
 
+/* ---- the steps either side of the path, on the device (lws.pyx:43-144; float32, frame size N a power of two in
+ *      [32, 2048], fftsize == fsize).  Windows are host arrays of N doubles, already normalised the way the caller
+ *      wants them (class lws: awin and synthwin(awin, fshift)).  perfectrec as in lws.pyx:55-67,130-137. ---- */
+
+/* Frames stft() produces for a signal of `len` samples (lws.pyx:55-76); < 1 if the signal is too short. */
+int lws_stft_frames(int len, int N, int fshift, int perfectrec);
+/* Samples istft() returns for M frames (lws.pyx:121,130-137). */
+int lws_istft_length(int M, int N, int fshift, int perfectrec);
+/* stft (lws.pyx:43-90) of B signals x_dev[B][len] (float32) into S_dev[B][M][N/2+1] (complex64), M = lws_stft_frames(). */
+int lws_stft_dev(int device, const float *x_dev, int B, int len, int N, int fshift, const double *awin,
+                 int perfectrec, void *S_dev, void *stream);
+/* istft (lws.pyx:93-137) of S_dev[B][M][N/2+1] (complex64) into x_dev[B][lws_istft_length()] (float32). */
+int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *swin,
+                  int perfectrec, float *x_dev, void *stream);
+/* get_consistency (lws.pyx:140-144) per spectrogram: out[2b] = sum |S|^2, out[2b+1] = sum |stft(istft(S)) - S|^2
+ * (fp64 sums of the fp32 transform); consistency in dB = 10 log10(out[2b] / out[2b+1]).  out: HOST, 2*B doubles
+ * (synchronises).  Sums of several spectrograms / ranks add up to the batch consistency. */
+int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *awin,
+                        const double *swin, int perfectrec, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,8 @@ EXPORTS = (
     "lws_hip_version", "lws_last_error", "lws_device_count", "lws_plan_create", "lws_plan_destroy",
     "lws_batch_lws", "lws_nofuture_lws", "lws_online_lws", "lws_run_lws", "lws_batch_lws_dev",
     "lws_nofuture_lws_dev", "lws_online_lws_dev", "lws_residual_dev", "lws_last_kernel_time",
-    "lws_last_kernel_name",
+    "lws_last_kernel_name", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev",
+    "lws_consistency_dev",
 )
 
 _lib = None
@@ -62,6 +63,11 @@ def load():
     lib.lws_last_kernel_time.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.lws_last_kernel_name.argtypes = [vp]
     lib.lws_last_kernel_name.restype = C.c_char_p
+    lib.lws_stft_frames.argtypes = [ip, ip, ip, ip]
+    lib.lws_istft_length.argtypes = [ip, ip, ip, ip]
+    lib.lws_stft_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp]
+    lib.lws_istft_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp]
+    lib.lws_consistency_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp]
     for name in EXPORTS:  # fail at load time, not at first use, if a symbol is missing
         getattr(lib, name)
     _lib = lib
@@ -207,3 +213,39 @@ class Plan:
         check(self._lib.lws_last_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return {"ms": ms.value, "launches": n.value,
                 "name": self._lib.lws_last_kernel_name(self._h).decode()}
+
+
+# ---- the steps either side of the path, on the device (include/lws_hip.h; lws.pyx:43-144) --------------------------
+def _win(w):
+    return np.ascontiguousarray(w, dtype=np.float64)
+
+
+def stft_frames(length, fsize, fshift, perfectrec):
+    return load().lws_stft_frames(int(length), int(fsize), int(fshift), int(bool(perfectrec)))
+
+
+def istft_length(frames, fsize, fshift, perfectrec):
+    return load().lws_istft_length(int(frames), int(fsize), int(fshift), int(bool(perfectrec)))
+
+
+def stft_dev(x_ptr, B, length, fsize, fshift, awin, perfectrec, S_ptr, device=0, stream=None):
+    """x_ptr: device float32 [B][length]; S_ptr: device complex64 [B][stft_frames(...)][fsize//2+1]."""
+    a = _win(awin)
+    check(load().lws_stft_dev(int(device), x_ptr, int(B), int(length), int(fsize), int(fshift), a.ctypes.data,
+                              int(bool(perfectrec)), S_ptr, stream))
+
+
+def istft_dev(S_ptr, B, frames, fsize, fshift, swin, perfectrec, x_ptr, device=0, stream=None):
+    """S_ptr: device complex64 [B][frames][fsize//2+1]; x_ptr: device float32 [B][istft_length(...)]."""
+    w = _win(swin)
+    check(load().lws_istft_dev(int(device), S_ptr, int(B), int(frames), int(fsize), int(fshift), w.ctypes.data,
+                               int(bool(perfectrec)), x_ptr, stream))
+
+
+def consistency_dev(S_ptr, B, frames, fsize, fshift, awin, swin, perfectrec, device=0, stream=None):
+    """Per spectrogram [sum |S|^2, sum |stft(istft(S)) - S|^2] (fp64, host array (B, 2)); dB = 10 log10(ratio)."""
+    a, w = _win(awin), _win(swin)
+    out = np.empty((int(B), 2), dtype=np.float64)
+    check(load().lws_consistency_dev(int(device), S_ptr, int(B), int(frames), int(fsize), int(fshift), a.ctypes.data,
+                                     w.ctypes.data, int(bool(perfectrec)), out.ctypes.data, stream))
+    return out

@@ -37,6 +37,23 @@ int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                               \
     } while (0)
 
+}  // namespace
+
+namespace lws {
+// error text for lws_last_error(), shared with the other translation units of the library
+int set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace lws
+
+namespace {
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;

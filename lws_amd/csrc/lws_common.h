@@ -7,6 +7,9 @@
 
 namespace lws {
 
+// records the text lws_last_error() returns and passes `code` through (lws_capi.hip)
+int set_error(int code, const char *fmt, ...);
+
 template <typename real> struct cx;
 template <> struct cx<float>  { using type = float2; };
 template <> struct cx<double> { using type = double2; };

@@ -323,6 +323,7 @@ class lws(object):
         if not np.allclose(awin, awin[::-1]):
             print('WARNING: It appears you are using an analysis window that is not symmetric.\n'
                   'The current code uses simplifications that rely on such symmetry, so the code may not behave properly.')
+        self.device = int(device)
         self._plan_kw = dict(device=device, precision=precision, nofuture_q4_compat=nofuture_q4_compat,
                              force_generic=force_generic)
         self._plan = None
@@ -354,6 +355,57 @@ class lws(object):
 
     def stft(self, S):
         return stft(S, self.fsize, self.fshift, self.awin, perfectrec=self.perfectrec)
+
+    # ---- device versions of the three helpers above (float32 transforms; frame size a power of two, 32..2048).
+    # Arguments are torch CUDA tensors (complex64 spectrograms (B, T, F) / float32 signals (B, len)) or numpy arrays,
+    # which are moved to the plan's device through torch -- PyTorch is only the owner of the device memory here.
+    def _to_dev(self, a, dtype):
+        import torch
+        dev = torch.device("cuda", self.device)
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(device=dev, dtype=dtype).contiguous()
+
+    def get_consistency_dev(self, S):
+        """Consistency in dB of each spectrogram of the stack S (B, T, F) or of the single spectrogram (T, F), computed
+        on the device (lws.pyx:140-144)."""
+        import torch
+        t = self._to_dev(S, torch.complex64)
+        single = t.dim() == 2
+        if single:
+            t = t[None]
+        sums = _capi.consistency_dev(t.data_ptr(), t.shape[0], t.shape[1], self.fsize, self.fshift, self.awin, self.swin,
+                                     self.perfectrec, device=self.device,
+                                     stream=torch.cuda.current_stream(t.device).cuda_stream)
+        db = 10 * np.log10(sums[:, 0] / sums[:, 1])
+        return float(db[0]) if single else db
+
+    def stft_dev(self, x):
+        """STFT of the signals x (B, len) (or one signal (len,)) on the device: complex64 torch tensor (B, T, F)."""
+        import torch
+        t = self._to_dev(x, torch.float32)
+        single = t.dim() == 1
+        if single:
+            t = t[None]
+        B, n = t.shape
+        T = _capi.stft_frames(n, self.fsize, self.fshift, self.perfectrec)
+        out = torch.empty((B, T, self.fsize // 2 + 1), dtype=torch.complex64, device=t.device)
+        _capi.stft_dev(t.data_ptr(), B, n, self.fsize, self.fshift, self.awin, self.perfectrec, out.data_ptr(),
+                       device=self.device, stream=torch.cuda.current_stream(t.device).cuda_stream)
+        return out[0] if single else out
+
+    def istft_dev(self, S):
+        """Inverse STFT of the spectrograms S (B, T, F) (or one (T, F)) on the device: float32 torch tensor (B, len)."""
+        import torch
+        t = self._to_dev(S, torch.complex64)
+        single = t.dim() == 2
+        if single:
+            t = t[None]
+        B, T, _ = t.shape
+        n = _capi.istft_length(T, self.fsize, self.fshift, self.perfectrec)
+        out = torch.empty((B, n), dtype=torch.float32, device=t.device)
+        _capi.istft_dev(t.data_ptr(), B, T, self.fsize, self.fshift, self.swin, self.perfectrec, out.data_ptr(),
+                        device=self.device, stream=torch.cuda.current_stream(t.device).cuda_stream)
+        return out[0] if single else out
 
     def istft(self, S):
         return istft(S, self.fshift, self.swin, perfectrec=self.perfectrec)
