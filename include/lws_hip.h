@@ -134,6 +134,28 @@ int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift
 int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *awin,
                         const double *swin, int perfectrec, double *out, void *stream);
 
+/* ---- host-side construction of windows, weights and schedules (lws.pyx:10-40,160-206), fp64, no device work: what a
+ *      caller without numpy needs to build a plan.  Complex outputs are interleaved (re, im) doubles. ---- */
+
+/* hann (lws.pyx:10-19): out[n]. */
+int lws_hann(int n, int symmetric, int use_offset, double *out);
+/* synthwin (lws.pyx:22-40): synthesis window normalised for perfect reconstruction; swin may be NULL (= awin). */
+int lws_synthwin(const double *awin, int fsize, int fshift, const double *swin, double *out);
+/* shape of create_weights' result: Q = ceil(fsize/fshift), Qprime = Q (summarised, shift divides the window) or fsize. */
+int lws_weights_shape(int fsize, int fshift, int use_summarized_weights, int *Qprime, int *Q);
+/* create_weights (lws.pyx:160-181): W[Qprime][Q][L+1] complex128. */
+int lws_create_weights(const double *awin, const double *swin, int fsize, int fshift, int L, int use_summarized_weights,
+                       double *W);
+/* build_asymmetric_windows (lws.pyx:184-200) from the product awin*swin: win_ai[fsize], win_af[fsize]. */
+int lws_build_asymmetric_windows(const double *awin_swin, int fsize, int fshift, double *win_ai, double *win_af);
+/* get_thresholds (lws.pyx:203-206): out[i] = alpha * exp(-beta * i^gamma). */
+int lws_get_thresholds(int iterations, double alpha, double beta, double gamma, double *out);
+/* What `lws.lws(awin_or_fsize, fshift, L=..., swin=...)` sets up (lws.pyx:384-431): awin == NULL means the default
+ * sqrt-Hann window of `fsize` samples; swin may be NULL; the three weight tensors W, W_ai, W_af are built and the plan
+ * created.  awin_out / swin_out (may be NULL) receive the windows actually used, fsize doubles each. */
+int lws_plan_create_from_windows(lws_plan **plan, int device, const double *awin, const double *swin, int fsize,
+                                 int fshift, int L, int symmetric_win, unsigned flags, double *awin_out, double *swin_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,8 @@ EXPORTS = (
     "lws_batch_lws", "lws_nofuture_lws", "lws_online_lws", "lws_run_lws", "lws_batch_lws_dev",
     "lws_nofuture_lws_dev", "lws_online_lws_dev", "lws_residual_dev", "lws_last_kernel_time",
     "lws_last_kernel_name", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev",
-    "lws_consistency_dev",
+    "lws_consistency_dev", "lws_hann", "lws_synthwin", "lws_weights_shape", "lws_create_weights",
+    "lws_build_asymmetric_windows", "lws_get_thresholds", "lws_plan_create_from_windows",
 )
 
 _lib = None
@@ -44,6 +45,15 @@ def load():
         raise OSError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C lws_amd/csrc` (hipcc, gfx950).  lws_amd has no CPU fallback.")
+    # PyTorch's ROCm wheels bundle their own HIP/HSA runtime next to the system one this library links.  Both can
+    # live in one process only if PyTorch's is initialised first (the other order leaves torch with "No HIP GPUs are
+    # available"), so do that here when PyTorch is installed -- the *_dev entry points are meant to be fed from it.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # no torch, or no usable device: nothing to order
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, ip = C.c_void_p, C.c_int
     lib.lws_hip_version.restype = C.c_int
@@ -68,6 +78,14 @@ def load():
     lib.lws_stft_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp]
     lib.lws_istft_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp]
     lib.lws_consistency_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp]
+    dp = C.c_double
+    lib.lws_hann.argtypes = [ip, ip, ip, vp]
+    lib.lws_synthwin.argtypes = [vp, ip, ip, vp, vp]
+    lib.lws_weights_shape.argtypes = [ip, ip, ip, C.POINTER(ip), C.POINTER(ip)]
+    lib.lws_create_weights.argtypes = [vp, vp, ip, ip, ip, ip, vp]
+    lib.lws_build_asymmetric_windows.argtypes = [vp, ip, ip, vp, vp]
+    lib.lws_get_thresholds.argtypes = [ip, dp, dp, dp, vp]
+    lib.lws_plan_create_from_windows.argtypes = [C.POINTER(vp), ip, vp, vp, ip, ip, ip, ip, C.c_uint, vp, vp]
     for name in EXPORTS:  # fail at load time, not at first use, if a symbol is missing
         getattr(lib, name)
     _lib = lib
