@@ -286,6 +286,21 @@ int need_weights(const lws_plan *p, const StageSpec *st, int n) {
     return LWS_OK;
 }
 
+// After a synchronisation point: did a multi-workgroup systolic launch give up waiting (workgroups of one spectrogram
+// not co-scheduled, e.g. the device was shared)?  The results of that call are then invalid.
+int check_systolic_flag(lws_plan *p) {
+    for (lws::SystolicPlan *sp : {&p->sys, &p->sysw}) {
+        if (sp->last_nwg > 1 && sp->err_dev) {
+            int flag = 0;
+            HIP_TRY(hipMemcpy(&flag, sp->err_dev, sizeof(int), hipMemcpyDeviceToHost));
+            sp->last_nwg = 1;
+            if (flag) return fail(LWS_ERR_HIP, "systolic kernel: the workgroups sharing a spectrogram were not running "
+                                               "concurrently (device shared with other work?); set LWS_SYSTOLIC_NWG=1");
+        }
+    }
+    return LWS_OK;
+}
+
 // host complex128 in/out
 int run_host(lws_plan *p, const double *S_in, double *S_out, int B, int T, const StageSpec *st, int n) {
     if (!S_in || !S_out) return fail(LWS_ERR_INVALID, "null spectrogram pointer");
@@ -308,7 +323,7 @@ int run_host(lws_plan *p, const double *S_in, double *S_out, int B, int T, const
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(S_out, p->stage.p, count * sizeof(double2), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    return LWS_OK;
+    return check_systolic_flag(p);
 }
 
 // device in place: complex64 for fp32 plans, complex128 for fp64 plans
@@ -519,6 +534,8 @@ int lws_last_kernel_time(lws_plan *p, float *ms, int *launches) {
         HIP_TRY(hipEventElapsedTime(&t, p->ev0, p->ev1));
         p->last_ms = t;
         p->timing_pending = false;
+        int rc = check_systolic_flag(p);
+        if (rc) return rc;
     }
     if (ms) *ms = p->last_ms;
     if (launches) *launches = p->last_launches;

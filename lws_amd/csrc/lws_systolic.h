@@ -13,6 +13,8 @@ struct SystolicPlan {
     void *sk_state = nullptr, *sk_amp = nullptr;    // skewed-layout scratch
     size_t sk_state_cap = 0, sk_amp_cap = 0;
     const char *name = "systolic";
+    int *err_dev = nullptr;   // device flag of the last launch: a workgroup gave up waiting for its producer
+    int last_nwg = 1;         // workgroups per spectrogram of the last launch
 };
 
 // Analyse the (host, complex128 interleaved) weight tensors and upload tables for the ones the

@@ -39,6 +39,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <utility>
@@ -158,6 +159,9 @@ struct SysArgs {
     const float *thr;        // [B][n_iters] thresholds scaled by mean|S|
     const float *amax;       // [B] max target magnitude
     int n_iters, T, Tp, TpPad, Kr, G, C;
+    int nwg;                 // workgroups per spectrogram (passes over HBM are dealt round-robin to them)
+    unsigned *progress;      // [B][nwg] rows of the skewed state each workgroup has completed (nwg > 1)
+    int *err;                // set if a workgroup gave up waiting for its producer
     unsigned long long w[4 * 8];   // W[0][r][k], r < Q, k <= L (at most 4 x 8): bit patterns of (re, im) as one 64-bit scalar
 };
 
@@ -210,6 +214,17 @@ __device__ __forceinline__ float2 load_l2(const float2 *p) {
     v.x = __uint_as_float((unsigned)(u & 0xffffffffull));
     v.y = __uint_as_float((unsigned)(u >> 32));
     return v;
+}
+
+// Stores another workgroup (possibly on another XCD, behind another L2) will read during this launch: write through.
+// (With one workgroup per spectrogram producer and consumer share the CU's XCD and a plain store is enough.)
+__device__ __forceinline__ void store_l2(float2 *p, float2 v, bool shared) {
+    if (shared) {
+        const unsigned long long u = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = v;
+    }
 }
 
 // ---- synchronisation between the waves of a workgroup -----------------------------------------------------
@@ -570,7 +585,7 @@ __device__ __forceinline__ float2 project(float2 acc, float target, bool active,
 struct Carry { float2 o0, o1, o2, prev_out; };
 
 // One pair of bins (phases PA odd, PA+1) of one lane.
-template <int Q, int L, uint32_t MASK, int PA>
+template <int Q, int L, uint32_t MASK, int PA, bool MULTI>
 __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx, int lane, int vmod, int G, Carry &cr,
                                              const float (&amp_cur)[8], const float (&amp_nxt)[8], float2 *state_w_b) {
     constexpr int K1 = L + 1;
@@ -623,7 +638,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     const float2 outA = project(accA, tA, cx.live && (tA > cx.thr), cr.o0);
     ring_publish(ring_addr<PA, 0, 0, 1>(cx.ob), cx.halo_shift, cx.dummy, outA);
     image_publish<L, PA, PA, 1>(cx.uo, stA, enA, cx.dummy, outA);
-    if (cx.store) state_w_b[(size_t)(vmod + PA) * LANES + lane] = outA;   // G is a multiple of 8: no wrap inside a block
+    if (cx.store) store_l2(state_w_b + (size_t)(vmod + PA) * LANES + lane, outA, MULTI);   // G is a multiple of 8: no wrap inside a block
     // ---- second bin (its centre taps include the first bin's result)
     accB = cadd(accB, centre_sum<L, MASK, PHB, PBB>(a, cx, CP && stB, CP && enB, cr.o1, cr.o2, outA));
     const float tB = wrap ? amp_nxt[0] : amp_cur[PBB & 7];
@@ -634,7 +649,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     if (wrap ? cx.nxt_store : cx.store) {
         int ib = vmod + PBB;
         ib -= (ib >= G) ? G : 0;
-        state_w_b[(size_t)ib * LANES + lane] = outB;
+        store_l2(state_w_b + (size_t)ib * LANES + lane, outB, MULTI);
     }
     cr.prev_out = outB;
     cr.o0 = cr.o2;
@@ -651,8 +666,8 @@ struct ServiceState {
 // Lane l < NSLOTS computes the Nyquist bin (bin C = F-1) of the frame of sweep slot l whose 512-step period ended at
 // clock t0 (phase 0 of the current block); lane NSLOTS feeds set 0 with the stored Nyquist value of that frame.
 // Called at the start of the first pair of the block, when every slot has published bins C-1, C-2, ...
-template <int Q, int L, uint32_t MASK>
-__device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &sv, int lane, int t0, int n_eff,
+template <int Q, int L, uint32_t MASK, bool MULTI>
+__device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &sv, int lane, int t0, int wg, int n_eff,
                                                 int n_groups, const float *thr_eff, float2 *state_nyq_b,
                                                 const float *amp_nyq_b) {
     constexpr int K1 = L + 1;
@@ -667,7 +682,8 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     if (((v0 - C) & (SKEW - 1)) != 0) return;
     const int vrow = (v0 - C) / SKEW;            // virtual frame whose Nyquist bin is due now (floor: SKEW | v0 - C)
     const int rho = vrow & 63, kap = vrow >> 6;
-    const int g = kap / Kr, k = kap - g * Kr;
+    const int gl = kap / Kr, k = kap - gl * Kr;
+    const int g = MULTI ? gl * a.nwg + wg : gl;   // global pass (this workgroup runs passes wg, wg + nwg, ...)
     const int me = k * LANES + rho;
     const int j = g * NSLOTS + (is_nyq_lane ? slot : -1);
     const bool valid = (v0 - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
@@ -725,7 +741,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         const float2 out = project(acc, target, active, old);
         lds_write(nn[0], out);
         lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, out);   // bin C of the image lane: production time = this clock
-        if (valid && (slot == NSLOTS - 1 || j == n_eff - 1)) state_nyq_b[me] = out;
+        if (valid && (slot == NSLOTS - 1 || j == n_eff - 1)) store_l2(state_nyq_b + me, out, MULTI);
         // target magnitude of the next block's Nyquist bin
         const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
@@ -733,10 +749,12 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     }
 }
 
-template <int Q, int L, uint32_t MASK>
+// MULTI: several workgroups share a spectrogram (a.nwg > 1); the single-workgroup instantiation carries none of it
+template <int Q, int L, uint32_t MASK, bool MULTI>
 __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
+    const int nwg = MULTI ? a.nwg : 1;
+    const int b = MULTI ? blockIdx.x / nwg : blockIdx.x, wg = MULTI ? blockIdx.x - b * nwg : 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave: provably uniform
     float *thr_eff = reinterpret_cast<float *>(smem + THR_OFF);
     int *meta = reinterpret_cast<int *>(smem + META_OFF);
@@ -764,8 +782,35 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const int n_eff = meta[0];
     if (n_eff == 0) return;
     const int n_groups = (n_eff + NSLOTS - 1) / NSLOTS;
+    // Passes (groups of NSLOTS sweeps) are dealt round-robin to the nwg workgroups of the spectrogram: this one runs the
+    // global passes wg, wg + nwg, ... back to back on its own clock ("local pass" gl = clock / G), each one trailing the
+    // pass before it -- run by the previous workgroup of the ring -- by a few hundred steps through HBM (see below).
+    const int n_local = (wg < n_groups) ? (n_groups - wg + nwg - 1) / nwg : 0;
+    if (n_local == 0) return;
     // slot i runs on clock v_i = t - (i+1)*LAG; the loader (virtual slot -1) on clock t
-    const int t_end = (n_groups - 1) * G + (NSLOTS + 1) * LAG + SKEW * a.Tp + ROWP + 8;
+    const int t_end = (n_local - 1) * G + (NSLOTS + 1) * LAG + SKEW * a.Tp + ROWP + 8;
+    // ---- hand-over between the workgroups of a spectrogram (nwg > 1).  Row r of the skewed state written by pass g is
+    // read by pass g + 1.  A workgroup publishes (release, agent scope) the number of rows -- in its own clock -- its
+    // last slot and its Nyquist lanes have completed; the loader of the next workgroup in the ring waits (acquire)
+    // until the rows it is about to fetch are there.  The producer of local pass gl is the previous workgroup's local
+    // pass gl, or for workgroup 0 the last workgroup's local pass gl - 1 (one pass = G rows earlier on its clock).
+    const unsigned *prod_progress = a.progress + (size_t)b * nwg + (wg ? wg - 1 : nwg - 1);
+    unsigned *my_progress = a.progress + (size_t)b * nwg + wg;
+    const int prod_shift = wg ? 0 : G;
+    const int need_max = n_local * G;           // rows beyond my last pass are fetched but never used
+    auto wait_rows = [&](int need) {            // service wave: rows < need of my clock must be complete
+        if (need > need_max) need = need_max;
+        need -= prod_shift;
+        if (need <= 0) return;
+        int spins = 0;
+        // data rows are written through (store_l2) and read past the L1 and the XCD's L2 (load_l2), so no cache-wide
+        // write-back / invalidate is needed: a counter that is only raised after the producer's stores have completed
+        while ((int)__hip_atomic_load(prod_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 21)) { if (lane == 0) *a.err = 1; break; }   // seconds: a co-scheduling failure, not a hang
+        }
+        asm volatile("" ::: "memory");
+    };
 
     const bool is_compute = wave < NSLOTS;
     const bool is_service = (wave == NSLOTS);
@@ -784,6 +829,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     sv.nyq_amp_next = 0.f;
     sv.nyq_in_next = make_float2(0.f, 0.f);
     if (is_service) {
+        if constexpr (MULTI) wait_rows(8 + 40);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {   // clocks 0..7
             const float2 v = load_l2(state_w_b + (size_t)i * LANES + lane);
@@ -807,9 +853,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             const int vv = v0 - SKEW * lane;        // clock relative to the start of the lane's first frame
             const int cbase = vv & (ROWP - 1);
             const int kap = vv >> ROWP_SHIFT;
-            const int g = kap / Kr, k = kap - g * Kr;
+            const int gl = kap / Kr, k = kap - gl * Kr;
             const int me = k * LANES + lane;
-            const int j = g * NSLOTS + slot;
+            const int j = (gl * nwg + wg) * NSLOTS + slot;
             const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
             cx.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
             cx.store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
@@ -821,9 +867,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             const int vv = v0 + 8 - SKEW * lane;
             const int cbase = vv & (ROWP - 1);
             const int kap = vv >> ROWP_SHIFT;
-            const int g = kap / Kr, k = kap - g * Kr;
+            const int gl = kap / Kr, k = kap - gl * Kr;
             const int me = k * LANES + lane;
-            const int j = g * NSLOTS + slot;
+            const int j = (gl * nwg + wg) * NSLOTS + slot;
             const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
             cx.nxt_live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
             cx.nxt_store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
@@ -856,11 +902,26 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         static_for<4>([&](auto ip) {
             constexpr int PA = 2 * decltype(ip)::value + 1;
             flow_wait(lane, t0 + PA, watched);
-            if (is_compute) compute_pair<Q, L, MASK, PA>(a, cx, lane, vmod, G, cr, amp_cur, amp_nxt, state_w_b);
+            if (is_compute) compute_pair<Q, L, MASK, PA, MULTI>(a, cx, lane, vmod, G, cr, amp_cur, amp_nxt, state_w_b);
+            if constexpr (PA == 7) {
+                // the block's stores must be visible to the other workgroups before this wave reports the block done
+                if constexpr (MULTI) { if (is_compute) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            }
+            if constexpr (PA == 1 && MULTI) {
+                if (is_service) {
+                    // every slot has finished the previous block (flow_wait above) and fenced its stores; so have the
+                    // Nyquist lanes of this wave (program order + the release below): rows below the last slot's clock
+                    const int done_rows = t0 - NSLOTS * LAG;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Nyquist stores of the previous block
+                    if (done_rows > 0 && lane == 0)
+                        __hip_atomic_store(my_progress, (unsigned)done_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    wait_rows(t0 + 16 + 40);   // the loader fetches up to row t0 + 16 in this block, the Nyquist loader a frame ahead
+                }
+            }
             if (is_service) {
                 // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
                 if constexpr (PA == 1)
-                    service_nyquist<Q, L, MASK>(a, sv, lane, t0, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+                    service_nyquist<Q, L, MASK, MULTI>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
                 // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
                 // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
                 int ldb[NBLK], ldu[NBLK];
@@ -987,16 +1048,19 @@ __global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float2 *
 
 constexpr uint32_t mask_all(int Q, int L) { return (Q * (L + 1) >= 32) ? 0xffffffffu : ((1u << (Q * (L + 1))) - 1u); }
 
-template <int Q, int L, uint32_t MASK> hipError_t launch_k(const SysArgs &a, int B, hipStream_t s) {
+template <int Q, int L, uint32_t MASK, bool MULTI> hipError_t launch_km(const SysArgs &a, int grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_systolic<Q, L, MASK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_systolic<Q, L, MASK, MULTI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_systolic<Q, L, MASK>), dim3(B), dim3(NTHREADS), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
     return hipGetLastError();
+}
+template <int Q, int L, uint32_t MASK> hipError_t launch_k(const SysArgs &a, int grid, hipStream_t s) {
+    return a.nwg > 1 ? launch_km<Q, L, MASK, true>(a, grid, s) : launch_km<Q, L, MASK, false>(a, grid, s);
 }
 
 // mask bit r*(L+1)+k set <=> |W[0][r][k]| > 1e-12.  Default sqrt-Hann windows give these patterns (L = 5):
@@ -1104,7 +1168,24 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
     // scratch: state_w, state_nyq | amp_w, amp_nyq, amax
     const size_t n_w = (size_t)B * G * LANES, n_n = (size_t)B * TpPad;
     const size_t need_s = (n_w + n_n) * sizeof(float2);
-    const size_t need_a = (n_w + n_n) * sizeof(float) + (size_t)B * sizeof(unsigned);
+    hipError_t e0;
+    // workgroups per spectrogram: as many as there are CUs to keep busy and passes to share out; every workgroup must
+    // be resident (they wait for each other), which one workgroup per CU (the rings fill the LDS) and a grid no larger
+    // than the CU count guarantee
+    int n_cu = 0, dev = 0;
+    if ((e0 = hipGetDevice(&dev)) != hipSuccess) return e0;
+    if ((e0 = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e0;
+    int nwg = B > 0 ? n_cu / B : 1;
+    const int n_pass_max = ((iters < MAX_ITERS ? iters : MAX_ITERS) + NSLOTS - 1) / NSLOTS;
+    if (nwg > n_pass_max) nwg = n_pass_max;
+    if (const char *ev = getenv("LWS_SYSTOLIC_NWG")) { const int v = atoi(ev); if (v >= 1 && (long)v * B <= n_cu) nwg = v; }
+    // each workgroup trails its producer by NSLOTS*LAG + 56 rows, and the first one starts its next pass G rows after
+    // its previous one: the lags around the ring must fit into one pass
+    const int ring_max = G / (NSLOTS * LAG + 96);
+    if (nwg > ring_max) nwg = ring_max;
+    if (nwg < 1) nwg = 1;
+    const size_t n_prog = (size_t)B * nwg + 1;   // progress counters + the error flag
+    const size_t need_a = (n_w + n_n) * sizeof(float) + (size_t)B * sizeof(unsigned) + n_prog * sizeof(unsigned);
     hipError_t e;
     if (need_s > sp.sk_state_cap) {
         if (sp.sk_state) (void)hipFree(sp.sk_state);
@@ -1123,7 +1204,8 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
     float *amp_w = static_cast<float *>(sp.sk_amp);
     float *amp_nyq = amp_w + n_w;
     unsigned *amax_bits = reinterpret_cast<unsigned *>(amp_nyq + n_n);
-    if ((e = hipMemsetAsync(amax_bits, 0, (size_t)B * sizeof(unsigned), stream)) != hipSuccess) return e;
+    unsigned *progress = amax_bits + B;
+    if ((e = hipMemsetAsync(amax_bits, 0, ((size_t)B + n_prog) * sizeof(unsigned), stream)) != hipSuccess) return e;
     const int NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;   // time tiles per round of 64 frames
     hipLaunchKernelGGL(k_to_skew, dim3(Kr * NT, B), dim3(256), 0, stream, state, amp, state_w, amp_w, state_nyq, amp_nyq,
                        amax_bits, T, F, L, Q, G, TpPad, NT);
@@ -1138,6 +1220,8 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
         a.thr = thr + i0; a.amax = reinterpret_cast<const float *>(amax_bits);
         a.n_iters = (iters - i0 < MAX_ITERS) ? iters - i0 : MAX_ITERS;
         a.T = T; a.Tp = Tp; a.TpPad = TpPad; a.Kr = Kr; a.G = G; a.C = F - 1;
+        a.nwg = nwg; a.progress = progress; a.err = reinterpret_cast<int *>(progress + (size_t)B * nwg);
+        sp.err_dev = a.err; sp.last_nwg = nwg;
         for (int x = 0; x < 32; ++x) {
             const float re = x < Q * (L + 1) ? tb->w[2 * x] : 0.f, im = x < Q * (L + 1) ? tb->w[2 * x + 1] : 0.f;
             unsigned ur, ui;
@@ -1145,13 +1229,13 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
             a.w[x] = ((unsigned long long)ui << 32) | ur;
         }
         if (Q == 4) {
-            if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hann" : "systolic_q4_l5_hann"; }
-            else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hannmask" : "systolic_q4_l5_hannmask"; }
-            else { e = launch_k<4, 5, mask_all(4, 5)>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_allmask" : "systolic_q4_l5_allmask"; }
+            if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hann" : "systolic_q4_l5_hann"; }
+            else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hannmask" : "systolic_q4_l5_hannmask"; }
+            else { e = launch_k<4, 5, mask_all(4, 5)>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_allmask" : "systolic_q4_l5_allmask"; }
         } else {
-            if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hann" : "systolic_q2_l5_hann"; }
-            else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hannmask" : "systolic_q2_l5_hannmask"; }
-            else { e = launch_k<2, 5, mask_all(2, 5)>(a, B, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_allmask" : "systolic_q2_l5_allmask"; }
+            if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hann" : "systolic_q2_l5_hann"; }
+            else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hannmask" : "systolic_q2_l5_hannmask"; }
+            else { e = launch_k<2, 5, mask_all(2, 5)>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_allmask" : "systolic_q2_l5_allmask"; }
         }
         if (e != hipSuccess) return e;
         ++nl;

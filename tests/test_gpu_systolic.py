@@ -134,3 +134,27 @@ def test_wide_needs_a_multiple_of_16():
     p = lws_amd.lws(1040, 260)
     p.batch_lws(np.ones((4, 521)), thresholds=[0.0])
     assert p.plan().last_kernel()["name"] == "generic_fp32"
+
+
+# ----------------------------------------------------------------------------- several workgroups per spectrogram
+@pytest.mark.parametrize("fsize,fshift,B,T,iters", [(64, 16, 1, 200, 30), (64, 16, 3, 300, 50), (1024, 256, 2, 200, 30),
+                                                    (1024, 256, 9, 300, 45), (1024, 512, 5, 260, 16),
+                                                    (2048, 512, 3, 150, 20)])
+def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, iters, monkeypatch):
+    """When there are fewer spectrograms than CUs the passes over HBM are dealt to several workgroups per spectrogram
+    that hand the skewed state to each other through HBM; the result must be bit-identical to one workgroup doing all
+    passes (LWS_SYSTOLIC_NWG=1), including the partial last group of sweeps and dropped sweeps."""
+    rng = np.random.default_rng(B * T)
+    F = fsize // 2 + 1
+    S = np.abs(rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))).astype(np.complex128)
+    S[0] *= 30.0                                   # other scale: other set of dropped sweeps
+    thr = lws_amd.get_thresholds(iters, 3.0, 0.15, 1)
+    p = lws_amd.lws(fsize, fshift)
+    monkeypatch.setenv("LWS_SYSTOLIC_NWG", "1")
+    ref = p.plan().batch(S, thr)
+    assert p.plan().last_kernel()["name"].startswith("systolic")
+    for nwg in ("2", "3", "4"):
+        monkeypatch.setenv("LWS_SYSTOLIC_NWG", nwg)
+        assert np.array_equal(p.plan().batch(S, thr), ref), nwg
+    monkeypatch.delenv("LWS_SYSTOLIC_NWG")
+    assert np.array_equal(p.plan().batch(S, thr), ref)
