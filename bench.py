@@ -187,6 +187,20 @@ def main():
             "ms_per_step": 1e3 * dt2 / max(1, args.steps),
             "algorithmic_GBs": (16.0 * active + 4.0 * B * T * F * iters) / (kms2 / max(1, args.steps) * 1e-3) / 1e9}
 
+    # latency of ONE spectrogram of the same shape and schedule: its passes over HBM are pipelined over several
+    # workgroups ("fewer spectrograms than CUs")
+    if not args.no_config3:
+        one = state[:1].clone()
+        for rep in range(2):
+            one.copy_(mags[:1])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            plan.batch_dev(one.data_ptr(), 1, T, thr_dense, stream=stream)
+            info = plan.last_kernel()
+            torch.cuda.synchronize()
+            extra["single_spectrogram"] = {"wall_ms": 1e3 * (time.perf_counter() - t0), "kernel_ms": info["ms"],
+                                           "kernel": info["name"]}
+
     # BASELINE config 3: the run_lws pipeline of lws(1024, 256, mode='music') -- 1 no-future sweep (W_ai, alpha 1),
     # 10 online iterations with look-ahead 3, 100 batch sweeps of the default schedule -- stage by stage on the device
     if not args.no_config3:

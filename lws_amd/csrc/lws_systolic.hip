@@ -797,10 +797,15 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const unsigned *prod_progress = a.progress + (size_t)b * nwg + (wg ? wg - 1 : nwg - 1);
     unsigned *my_progress = a.progress + (size_t)b * nwg + wg;
     const int prod_shift = wg ? 0 : G;
-    const int need_max = n_local * G;           // rows beyond my last pass are fetched but never used
+    // Last row, on the producer's clock, that any valid frame of my last pass reads (frame me starts SKEW*me rows into
+    // a pass, so lanes are up to SKEW*63 rows apart and a pass ends later for the later frames): rows beyond it are
+    // fetched but never used, and the producer's counter stops short of them.  For workgroup 0 the producer's pass is
+    // one local pass behind; its first pass reads the caller's data and waits for nobody.
+    const int prod_passes = n_local - (wg ? 0 : 1);   // passes of the producer this workgroup consumes
+    const int need_max = prod_passes > 0 ? (prod_passes - 1) * G + SKEW * a.Tp + C + 16 : 0;
     auto wait_rows = [&](int need) {            // service wave: rows < need of my clock must be complete
-        if (need > need_max) need = need_max;
         need -= prod_shift;
+        if (need > need_max) need = need_max;
         if (need <= 0) return;
         int spins = 0;
         // data rows are written through (store_l2) and read past the L1 and the XCD's L2 (load_l2), so no cache-wide

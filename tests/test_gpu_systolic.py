@@ -158,3 +158,28 @@ def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, it
         assert np.array_equal(p.plan().batch(S, thr), ref), nwg
     monkeypatch.delenv("LWS_SYSTOLIC_NWG")
     assert np.array_equal(p.plan().batch(S, thr), ref)
+
+
+def test_workgroup_sharing_randomised(monkeypatch):
+    """Forty random shapes / schedules (frame counts from 1 to several lane rounds, 1..45 sweeps some of which are
+    dropped, 1..6 spectrograms, both builds): whatever number of workgroups the launcher picks, and 2 and 5 forced,
+    must reproduce the single-workgroup result bit for bit, and never time out."""
+    rng = np.random.default_rng(20260928)
+    plans = {(fs, sh): lws_amd.lws(fs, sh) for fs, sh in ((64, 16), (64, 32), (128, 32), (1056, 264))}
+    keys = list(plans)
+    for trial in range(40):
+        fs, sh = keys[int(rng.integers(0, 4 if trial % 8 == 0 else 3))]
+        p = plans[(fs, sh)]
+        F = fs // 2 + 1
+        B, T, iters = int(rng.integers(1, 7)), int(rng.integers(1, 700 if fs < 1000 else 150)), int(rng.integers(1, 46))
+        S = np.abs(rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))).astype(np.complex128)
+        S *= 10.0 ** rng.uniform(-1, 1, size=(B, 1, 1))
+        thr = rng.uniform(0.0, 6.0, size=iters) * (rng.random(iters) < 0.8)
+        monkeypatch.setenv("LWS_SYSTOLIC_NWG", "1")
+        ref = p.plan().batch(S, thr)
+        for nwg in (None, "2", "5"):
+            if nwg is None:
+                monkeypatch.delenv("LWS_SYSTOLIC_NWG")
+            else:
+                monkeypatch.setenv("LWS_SYSTOLIC_NWG", nwg)
+            assert np.array_equal(p.plan().batch(S, thr), ref), (trial, fs, sh, B, T, iters, nwg)
