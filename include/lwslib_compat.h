@@ -22,48 +22,51 @@
 
 #include <math.h>
 
-/* helpers -- lwslib.h:6-8, lwslib.cpp:15-65 */
-void ExtendSpec(double *ExtSr, double *ExtSi, double *InSr, double *InSi, int Nreal, int M, int L, int Q);
-void CopySpec(double *ExtSr, double *ExtSi, double *InSr, double *InSi, int Nreal, int M, int L, int Q);
-void ComputeAmpSpec(double *Sr, double *Si, double *AmpSpec, int size);
+/* Argument groups shared by the entry points (types and order are the reference's; the names are ours):
+ *   planes   real and imaginary plane of the extended spectrogram, row pitch bins + 2*half_width, updated in place
+ *   weights  real plane, imaginary plane and participation flags of one weight tensor [Qp][Q][half_width + 1]
+ *   target   magnitudes the updated bins are projected to (same layout as the planes) */
+#define LWSLIB_PLANES double *re, double *im
+#define LWSLIB_WEIGHTS double *w_re, double *w_im, int *w_on
+#define LWSLIB_SWEEP LWSLIB_PLANES, LWSLIB_WEIGHTS, double *target
 
-/* batch sweeps -- lwslib.h:10-13, lwslib.cpp:72-467 */
-void LWSQ2(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-           int Nreal, int M, int L, double threshold);
-void LWSQ4(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-           int Nreal, int M, int L, double threshold);
-void LWSanyQ(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-             int Nreal, int M, int L, int Q, double threshold);
-void LWSfractionalQ(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-                    int Nreal, int M, int L, int Q, double threshold);
+/* helpers -- lwslib.h:6-8, lwslib.cpp:15-65: pad to / cut from the extended layout, magnitudes */
+void ExtendSpec(double *ext_re, double *ext_im, double *in_re, double *in_im, int bins, int frames, int half_width, int overlap);
+void CopySpec(double *ext_re, double *ext_im, double *out_re, double *out_im, int bins, int frames, int half_width, int overlap);
+void ComputeAmpSpec(LWSLIB_PLANES, double *magnitude, int count);
+
+/* batch sweeps -- lwslib.h:10-13, lwslib.cpp:72-467 (level: bins with target <= level are left alone) */
+void LWSQ2(LWSLIB_SWEEP, int bins, int frames, int half_width, double level);
+void LWSQ4(LWSLIB_SWEEP, int bins, int frames, int half_width, double level);
+void LWSanyQ(LWSLIB_SWEEP, int bins, int frames, int half_width, int overlap, double level);
+void LWSfractionalQ(LWSLIB_SWEEP, int bins, int frames, int half_width, int overlap, double level);
 
 /* sweeps that use past frames only -- lwslib.h:15-18, lwslib.cpp:473-764.
  * NoFuture_LWSQ4 reproduces the reference's addressing (flat offset (m-r)*Np + 2n +- k, lwslib.cpp:559-594). */
-void NoFuture_LWSQ2(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-                    int Nreal, int M, int L, double threshold);
-void NoFuture_LWSQ4(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-                    int Nreal, int M, int L, double threshold);
-void NoFuture_LWSanyQ(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-                      int Nreal, int M, int L, int Q, double threshold);
-void NoFuture_LWSfractionalQ(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-                             int Nreal, int M, int L, int Q, double threshold);
+void NoFuture_LWSQ2(LWSLIB_SWEEP, int bins, int frames, int half_width, double level);
+void NoFuture_LWSQ4(LWSLIB_SWEEP, int bins, int frames, int half_width, double level);
+void NoFuture_LWSanyQ(LWSLIB_SWEEP, int bins, int frames, int half_width, int overlap, double level);
+void NoFuture_LWSfractionalQ(LWSLIB_SWEEP, int bins, int frames, int half_width, int overlap, double level);
 
-/* sweeps over M frames that may read M0 frames to their right -- lwslib.h:20-23, lwslib.cpp:776-1421 */
-void Asym_UpdatePhaseQ2(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-                        int Nreal, int M, int M0, int L, double threshold, int update);
-void Asym_UpdatePhaseQ4(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-                        int Nreal, int M, int M0, int L, double threshold, int update);
-void Asym_UpdatePhaseanyQ(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-                          int Nreal, int M, int M0, int L, int Q, double threshold, int update);
-void Asym_UpdatePhasefractionalQ(double *Sr, double *Si, double *wr, double *wi, int *w_flag, double *AmpSpec,
-                                 int Nreal, int M, int M0, int L, int Q, double Qfloat, double threshold, int update);
+/* sweeps over `frames` frames that may read `usable_right` frames to their right -- lwslib.h:20-23,
+ * lwslib.cpp:776-1421 (self_term 1: add S/Q to the centre sum; the shipped callers pass 2) */
+void Asym_UpdatePhaseQ2(LWSLIB_SWEEP, int bins, int frames, int usable_right, int half_width, double level, int self_term);
+void Asym_UpdatePhaseQ4(LWSLIB_SWEEP, int bins, int frames, int usable_right, int half_width, double level, int self_term);
+void Asym_UpdatePhaseanyQ(LWSLIB_SWEEP, int bins, int frames, int usable_right, int half_width, int overlap, double level,
+                          int self_term);
+void Asym_UpdatePhasefractionalQ(LWSLIB_SWEEP, int bins, int frames, int usable_right, int half_width, int overlap,
+                                 double overlap_exact, double level, int self_term);
 
-/* online driver -- lwslib.h:24-26, lwslib.cpp:1424-1492 */
-void TF_RTISI_LA(double *Sr, double *Si, double *wr, double *wi,
-                 double *wr_asym_init, double *wi_asym_init, double *wr_asym_full, double *wi_asym_full,
-                 int *w_flag, int *w_flag_ai, int *w_flag_af, double *AmpSpec,
-                 int iter, int LA, int Nreal, int M, int L, int Q, double Qfloat,
-                 int use_summarized_weights, double *ThresholdArray, int update);
+/* online driver -- lwslib.h:24-26, lwslib.cpp:1424-1492: the weights of the symmetric window, of the envelope used for a
+ * frame's first estimate and of the envelope of the newest frame; one level per iteration */
+void TF_RTISI_LA(LWSLIB_PLANES, double *w_re, double *w_im, double *first_re, double *first_im, double *newest_re,
+                 double *newest_im, int *w_on, int *first_on, int *newest_on, double *target, int iterations,
+                 int look_ahead, int bins, int frames, int half_width, int overlap, double overlap_exact,
+                 int summarised_weights, double *levels, int self_term);
+
+#undef LWSLIB_SWEEP
+#undef LWSLIB_WEIGHTS
+#undef LWSLIB_PLANES
 
 /* not in the reference: text of the most recent HIP failure inside one of the calls above ("" if none) */
 const char *lwslib_compat_last_error(void);
