@@ -72,13 +72,16 @@ template <int Q> __device__ __forceinline__ float quad_sum(float v) {
     v += dpp(v, std::integral_constant<int, 0xB1>());                    // quad_perm [1,0,3,2]
     if constexpr (Q >= 4) v += dpp(v, std::integral_constant<int, 0x4E>());   // quad_perm [2,3,0,1]
     if constexpr (Q >= 8) v += dpp(v, std::integral_constant<int, 0x141>());  // row_half_mirror: the other quad of the 8
+    if constexpr (Q >= 16) v += dpp(v, std::integral_constant<int, 0x140>()); // row_mirror: the other half of the 16
     return v;
 }
 
 // SERIAL: verification variant -- lane 0 of a bin sums every tap itself in the generic engine's order, which makes the
 // result bit-identical to lws_generic.hip's fp32 online mode (same schedule, same arithmetic); tests use it to pin the
 // window / slot logic at sizes where fp32-vs-fp64 comparisons are dominated by the algorithm's own sensitivity.
-template <int Q, int L, bool SERIAL>
+// H: lanes per frame pair.  1: one lane sums the taps of frames rho-r and rho+r.  2: one lane each -- half the
+// instructions per wave and twice the waves, which is what a step (one dependent chain per wave, then a barrier) wants.
+template <int Q, int L, bool SERIAL, int H>
 __global__ void __launch_bounds__(1024) k_online(OnlineArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int K1 = L + 1, SK = L + 1, D = Q * SK;
@@ -109,7 +112,7 @@ __global__ void __launch_bounds__(1024) k_online(OnlineArgs a) {
     for (int i = tid; i < loaded * Np; i += nthr) { S[i] = gS[i]; A[i] = gA[i]; }
 
     // this lane: tap group r of frame position j of sweep slot sigma
-    const int r = tid % Q, j = (tid / Q) % rps, sigma = tid / (Q * rps);
+    const int h = tid % H, r = (tid / H) % Q, j = (tid / (Q * H)) % rps, sigma = tid / (Q * H * rps);
     const bool lane_used = sigma < NSW;
     int s = sigma;
     // per-sweep constants of the lane
@@ -118,6 +121,13 @@ __global__ void __launch_bounds__(1024) k_online(OnlineArgs a) {
     bool valid = false, centre = false, both = false;
     float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
     const int xsgn = (r == 0) ? 1 : -1;
+    // H == 2: lane h = 0 takes the terms of the left frame (W lf[-k], conj(W') lf[+k]), lane h = 1 those of the right
+    // frame (conj(W) rt[-k], W' rt[+k]); for the centre frame (r = 0) both read it, h = 1 at +k.
+    const int side_a = (h == 0) ? -1 : xsgn;            // sign of k for the first sum
+    const float sgn_a = (h == 0) ? 1.f : -1.f;          // conj(W) for the right frame
+    const float sgn_b = (h == 0) ? -1.f : 1.f;          // conj(W') for the left frame
+    float ga = 0.f, gb = 0.f;
+    int my_base = 0;
     float thr = 0.f;
     auto setup = [&]() {
         const int m = s / per, q = s - m * per;
@@ -142,6 +152,9 @@ __global__ void __launch_bounds__(1024) k_online(OnlineArgs a) {
         g2 = both ? 1.f : 0.f;
         g3 = (r != 0 && both) ? 1.f : 0.f;
         g4 = (r != 0) ? 1.f : 0.f;
+        ga = (h == 0) ? g1 : g2;
+        gb = (h == 0) ? g4 : g3;
+        my_base = (h == 0) ? lf_base : rt_base;
     };
     __syncthreads();
     setup();
@@ -184,6 +197,23 @@ __global__ void __launch_bounds__(1024) k_online(OnlineArgs a) {
                         }
                     }
                 }
+            } else if constexpr (H == 2) {
+                const int fb = (my_base + c) * 8;                                                // S starts at LDS byte 0
+                const int w_off = (int)((NW * Np) * 12) + w_base * 8;                           // W follows S and A
+                const int wa_r = w_off + row * (Q * K1 * 8), wb_r = w_off + rowneg * (Q * K1 * 8);
+                float2 va[K1], vb[K1], wA[K1], wB[K1];
+#pragma unroll
+                for (int k = 0; k <= L; ++k) { va[k] = lds_read64(fb + side_a * 8 * k); wA[k] = lds_read64(wa_r + 8 * k); }
+#pragma unroll
+                for (int k = 1; k <= L; ++k) { vb[k] = lds_read64(fb + 8 * k); wB[k] = lds_read64(wb_r + 8 * k); }
+                __builtin_amdgcn_sched_barrier(0);
+                float2 pa = zero, pb = zero;
+#pragma unroll
+                for (int k = 0; k <= L; ++k) cmac(pa, make_float2(wA[k].x, sgn_a * wA[k].y), va[k]);
+#pragma unroll
+                for (int k = 1; k <= L; ++k) cmac(pb, make_float2(wB[k].x, sgn_b * wB[k].y), vb[k]);
+                acc.x = quad_sum<Q * H>(fmaf(gb, pb.x, ga * pa.x));
+                acc.y = quad_sum<Q * H>(fmaf(gb, pb.y, ga * pa.y));
             } else {
                 // One instruction stream for all Q lanes of the bin.  Lanes r >= 1: frames rho-r (lf) and rho+r (rt),
                 // weights W[row][r][k] for the taps at -k and W[-row][r][k] for the taps at +k.  Lane 0: lf == rt == the
@@ -226,7 +256,7 @@ __global__ void __launch_bounds__(1024) k_online(OnlineArgs a) {
                 acc.x = quad_sum<Q>(acc.x);
                 acc.y = quad_sum<Q>(acc.y);
             }
-            if (r == 0) {
+            if (r == 0 && h == 0) {
                 const int li = (e & (NW - 1)) * Np + n;
                 const float target = A[li];
                 if (target > thr) {
@@ -288,26 +318,27 @@ __global__ void __launch_bounds__(1024) k_online(OnlineArgs a) {
     }
 }
 
-template <int Q, int L, bool SERIAL> hipError_t launch_q(const OnlineArgs &a, int B, int threads, size_t lds, hipStream_t s) {
+template <int Q, int L, bool SERIAL, int H> hipError_t launch_q(const OnlineArgs &a, int B, int threads, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online<Q, L, SERIAL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online<Q, L, SERIAL, H>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_online<Q, L, SERIAL>), dim3(B), dim3(threads), lds, s, a);
+    hipLaunchKernelGGL((k_online<Q, L, SERIAL, H>), dim3(B), dim3(threads), lds, s, a);
     return hipGetLastError();
 }
 
-struct Shape { int NSW, threads; size_t lds; bool ok; };
+struct Shape { int NSW, threads, threads2; size_t lds; bool ok; };
 
 Shape shape_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
-    Shape sh{0, 0, 0, false};
+    Shape sh{0, 0, 0, 0, false};
     if (Qp != Q || L != 5 || !(Q == 2 || Q == 4 || Q == 8) || LA < 0 || n_thr < 1 || T < 1) return sh;
     const int SK = L + 1, D = Q * SK, Np = F + 2 * L, per = n_thr + 1;
     sh.NSW = (F - 1 + SK * LA) / D + 2;                       // > sweeps in flight
     sh.threads = ((sh.NSW * (LA + 1) * Q + 63) / 64) * 64;
+    sh.threads2 = ((sh.NSW * (LA + 1) * Q * 2 + 63) / 64) * 64;   // two lanes per frame pair
     if (sh.threads > 1024) return sh;
     // Frames alive at once.  The frame loaded at the end of step t (newest frame m_new, (D*per + SK) m_new <= t + 1)
     // replaces the one NW rows below it, and the oldest sweep still running (of frame m_lo, t <= D (per m_lo + per - 1)
@@ -337,13 +368,21 @@ hipError_t launch_online_lds(const GenericArgs<float> &g, int B, hipStream_t str
     a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = sh.NSW;
     const char *ev = getenv("LWS_ONLINE_SERIAL_TAPS");   // verification only, see k_online
     if (ev && ev[0] == '1') {
-        if (g.Q == 4) return launch_q<4, 5, true>(a, B, sh.threads, sh.lds, stream);
-        if (g.Q == 2) return launch_q<2, 5, true>(a, B, sh.threads, sh.lds, stream);
-        return launch_q<8, 5, true>(a, B, sh.threads, sh.lds, stream);
+        if (g.Q == 4) return launch_q<4, 5, true, 1>(a, B, sh.threads, sh.lds, stream);
+        if (g.Q == 2) return launch_q<2, 5, true, 1>(a, B, sh.threads, sh.lds, stream);
+        return launch_q<8, 5, true, 1>(a, B, sh.threads, sh.lds, stream);
     }
-    if (g.Q == 4) return launch_q<4, 5, false>(a, B, sh.threads, sh.lds, stream);
-    if (g.Q == 2) return launch_q<2, 5, false>(a, B, sh.threads, sh.lds, stream);
-    return launch_q<8, 5, false>(a, B, sh.threads, sh.lds, stream);
+    // two lanes per frame pair (half the instructions per wave, twice the waves) measured 9 % slower than one
+    // (129 vs 118.6 ms on config 3): kept selectable for re-measurement
+    const char *e1 = getenv("LWS_ONLINE_LANES");
+    if (sh.threads2 <= 1024 && e1 && e1[0] == '2') {
+        if (g.Q == 4) return launch_q<4, 5, false, 2>(a, B, sh.threads2, sh.lds, stream);
+        if (g.Q == 2) return launch_q<2, 5, false, 2>(a, B, sh.threads2, sh.lds, stream);
+        return launch_q<8, 5, false, 2>(a, B, sh.threads2, sh.lds, stream);
+    }
+    if (g.Q == 4) return launch_q<4, 5, false, 1>(a, B, sh.threads, sh.lds, stream);
+    if (g.Q == 2) return launch_q<2, 5, false, 1>(a, B, sh.threads, sh.lds, stream);
+    return launch_q<8, 5, false, 1>(a, B, sh.threads, sh.lds, stream);
 }
 
 }  // namespace lws
