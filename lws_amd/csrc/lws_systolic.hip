@@ -466,15 +466,64 @@ template <int ROT> __device__ __forceinline__ v2f pk_add_rot(v2f x, v2f y) {
 // acc += w*b + conj(w)*c with w = (wr, wi) * j^ROT   (grouped form of lwslib.cpp:310-311)
 //   = p (b + c) + q j (b - c)   with (p, q) = (wr, wi), (-wi, wr), (-wr, -wi), (wi, -wr) for ROT = 0..3,
 //   j (dx, dy) = (-dy, dx)
+// One asm statement per group of instructions: the compiler cannot see inside a statement and puts a wait state
+// (s_nop) after each one whose result the next instruction reads -- a quarter of the kernel's s_nops before the
+// statements were merged.  (The packed fp32 operations have no such forwarding hazard; the rule is for 16-bit
+// destination selects.)  Operand modifiers of the two multiply-adds for ROT = 0..3, see pk_fma_w:
+#define LWS_M1_0 "op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+#define LWS_M2_0 "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+#define LWS_M1_1 "op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+#define LWS_M2_1 "op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]"
+#define LWS_M1_2 "op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+#define LWS_M2_2 "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
+#define LWS_M1_3 "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+#define LWS_M2_3 "op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"
+#define LWS_NEG2 " neg_lo:[0,1] neg_hi:[0,1]"
+// acc += p (b + c) + q j (b - c)
+#define LWS_PAIR_ASM(M1, M2)                                                                             \
+    asm("v_pk_add_f32 %[s], %[b], %[c]\n\t"                                                               \
+        "v_pk_add_f32 %[d], %[b], %[c]" LWS_NEG2 "\n\t"                                                   \
+        "v_pk_fma_f32 %[a], %[w], %[s], %[a] " M1 "\n\t"                                                  \
+        "v_pk_fma_f32 %[a], %[w], %[d], %[a] " M2                                                          \
+        : [a] "+v"(acc), [s] "=&v"(t0), [d] "=&v"(t1)                                                      \
+        : [w] "s"(w), [b] "v"(vb), [c] "v"(vc))
+// b = um +- dp, c = dm +- up, then the same
+#define LWS_QUAD_ASM(SG, M1, M2)                                                                         \
+    asm("v_pk_add_f32 %[b], %[um], %[dp]" SG "\n\t"                                                       \
+        "v_pk_add_f32 %[c], %[dm], %[up]" SG "\n\t"                                                       \
+        "v_pk_add_f32 %[s], %[b], %[c]\n\t"                                                               \
+        "v_pk_add_f32 %[b], %[b], %[c]" LWS_NEG2 "\n\t"                                                   \
+        "v_pk_fma_f32 %[a], %[w], %[s], %[a] " M1 "\n\t"                                                  \
+        "v_pk_fma_f32 %[a], %[w], %[b], %[a] " M2                                                          \
+        : [a] "+v"(acc), [b] "=&v"(t0), [c] "=&v"(t1), [s] "=&v"(t2)                                       \
+        : [w] "s"(w), [um] "v"(vum), [up] "v"(vup), [dm] "v"(vdm), [dp] "v"(vdp))
+
+// acc += w*b + conj(w)*c with w = (wr, wi) * j^ROT   (grouped form of lwslib.cpp:310-311)
+//   = p (b + c) + q j (b - c)   with (p, q) = (wr, wi), (-wi, wr), (-wr, -wi), (wi, -wr) for ROT = 0..3,
+//   j (dx, dy) = (-dy, dx)
 template <int ROT> __device__ __forceinline__ void pair_rot(float2 &a, wp_t w, float2 b, float2 c) {
 #if LWS_DBG_NOMATH
     a.x += b.x; a.y += c.y; return;
 #endif
-    const v2f S = vv(b) + vv(c), Dm = pk_sub(vv(b), vv(c));
-    v2f acc = vv(a);
+    v2f acc = vv(a), t0, t1;
+    const v2f vb = vv(b), vc = vv(c);
     constexpr int R = ROT & 3;
-    acc = pk_fma_w<(R & 1), 0, (R == 1 || R == 2), (R == 1 || R == 2)>(acc, w, S);        // p * S
-    acc = pk_fma_w<1 - (R & 1), 1, (R < 2), (R >= 2)>(acc, w, Dm);                          // q * (-dy, dx)
+    if constexpr (R == 0) LWS_PAIR_ASM(LWS_M1_0, LWS_M2_0);
+    else if constexpr (R == 1) LWS_PAIR_ASM(LWS_M1_1, LWS_M2_1);
+    else if constexpr (R == 2) LWS_PAIR_ASM(LWS_M1_2, LWS_M2_2);
+    else LWS_PAIR_ASM(LWS_M1_3, LWS_M2_3);
+    a = ff(acc);
+}
+// the four taps (m-R, c-k), (m-R, c+k), (m+R, c-k), (m+R, c+k) of one weight:  b = um +- dp, c = dm +- up (minus for an
+// odd quarter turn: W[-mod] = -W[mod]), then acc += w j^ROT b + conj(w j^ROT) c
+template <int ROT> __device__ __forceinline__ void quad_rot(float2 &a, wp_t w, float2 um, float2 up, float2 dm, float2 dp) {
+    v2f acc = vv(a), t0, t1, t2;
+    const v2f vum = vv(um), vup = vv(up), vdm = vv(dm), vdp = vv(dp);
+    constexpr int R = ROT & 3;
+    if constexpr (R == 0) LWS_QUAD_ASM("", LWS_M1_0, LWS_M2_0);
+    else if constexpr (R == 1) LWS_QUAD_ASM(LWS_NEG2, LWS_M1_1, LWS_M2_1);
+    else if constexpr (R == 2) LWS_QUAD_ASM("", LWS_M1_2, LWS_M2_2);
+    else LWS_QUAD_ASM(LWS_NEG2, LWS_M1_3, LWS_M2_3);
     a = ff(acc);
 }
 // the same for a weight whose imaginary part is exactly zero (W[0][r][0] of symmetric windows): half the work
@@ -545,6 +594,10 @@ __device__ __forceinline__ float2 rows_sum(const SysArgs &a, const float2 (&tu)[
             // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
             const wp_t w = a.w[R * K1 + k];
             const float2 um = tu[L - k + OFFS], up = tu[L + k + OFFS], dm = td[L - k + OFFS], dp = td[L + k + OFFS];
+            if constexpr (!(r13 && (R == 1 || R == 3) && k >= 2)) {
+                quad_rot<rot>(accr, w, um, up, dm, dp);
+                return;
+            }
             float2 b, c;
             if constexpr ((rot & 1) == 0) { b = cadd(um, dp); c = cadd(dm, up); }
             else { b = csub(um, dp); c = csub(dm, up); }
