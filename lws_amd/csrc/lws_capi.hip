@@ -239,10 +239,47 @@ struct StageSpec {
 
 // prep -> stages (with pad refresh in between) -> extract, for either host (double2) or device
 // (float2 / double2, in place) spectrogram buffers.
+// A call that is exactly one batch stage the systolic kernel can serve, on device complex64 spectrograms: the
+// spectrograms go straight into the kernel's layout and straight back (no extended buffers, no prep / extract passes).
+int run_direct_batch(lws_plan *p, const float2 *in_dev, float2 *out_dev, int B, int T, const StageSpec &st, hipStream_t s) {
+    const bool narrow = lws::systolic_supports(p->sys, st.wsel, T);
+    int rc;
+    if ((rc = p->mean_amp.ensure((size_t)B * sizeof(double)))) return rc;
+    if ((rc = p->thr_host_copy.ensure((size_t)st.iters * sizeof(double)))) return rc;
+    if ((rc = p->thr_scaled.ensure((size_t)B * st.iters * sizeof(float)))) return rc;
+    const size_t n_part = narrow ? lws::systolic_io_partials(p->sys, T) : lws::wide::systolic_io_partials(p->sysw, T);
+    if ((rc = p->row_sums.ensure((size_t)B * n_part * sizeof(double)))) return rc;
+    double *partial = static_cast<double *>(p->row_sums.p), *mean = static_cast<double *>(p->mean_amp.p);
+    hipError_t e = narrow ? lws::systolic_io_load(p->sys, in_dev, B, T, st.iters, partial, mean, s)
+                          : lws::wide::systolic_io_load(p->sysw, in_dev, B, T, st.iters, partial, mean, s);
+    if (e != hipSuccess) return fail(LWS_ERR_HIP, "systolic load failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(p->thr_host_copy.p, st.thr, sizeof(double) * st.iters, hipMemcpyHostToDevice, s));
+    HIP_TRY(lws::launch_scale_thresholds<float>(static_cast<const double *>(p->thr_host_copy.p), mean,
+                                                static_cast<float *>(p->thr_scaled.p), B, st.iters, s));
+    int launches = 0;
+    const float *th = static_cast<const float *>(p->thr_scaled.p);
+    e = narrow ? lws::systolic_io_run(p->sys, st.wsel, th, out_dev, B, T, st.iters, s, &launches, p->ev0, p->ev1)
+               : lws::wide::systolic_io_run(p->sysw, st.wsel, th, out_dev, B, T, st.iters, s, &launches, p->ev0, p->ev1);
+    p->timing_pending = true;
+    if (e != hipSuccess) return fail(LWS_ERR_HIP, "systolic launch failed: %s", hipGetErrorString(e));
+    p->last_launches = launches;
+    p->last_name = narrow ? lws::systolic_name(p->sys) : lws::wide::systolic_name(p->sysw);
+    return LWS_OK;
+}
+
 template <typename real, typename io_cx>
 int run_pipeline(lws_plan *p, const io_cx *in_dev, io_cx *out_dev, const io_cx *orig_dev, int B,
                  int T, const StageSpec *stages, int nstages, hipStream_t s) {
     using C = typename lws::cx<real>::type;
+    if constexpr (std::is_same<real, float>::value && std::is_same<io_cx, float2>::value) {
+        int active = 0, which = -1;
+        for (int i = 0; i < nstages; ++i)
+            if (stages[i].iters > 0) { ++active; which = i; }
+        if (active == 1 && stages[which].mode == lws::MODE_BATCH && !(p->flags & (LWS_FORCE_GENERIC | LWS_NO_DIRECT_IO)) &&
+            stages[which].iters <= lws::SYSTOLIC_MAX_ITERS &&
+            (lws::systolic_supports(p->sys, stages[which].wsel, T) || lws::wide::systolic_supports(p->sysw, stages[which].wsel, T)))
+            return run_direct_batch(p, in_dev, out_dev, B, T, stages[which], s);
+    }
     int max_it = 1;
     for (int i = 0; i < nstages; ++i)
         if (stages[i].iters > max_it) max_it = stages[i].iters;

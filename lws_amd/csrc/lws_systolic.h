@@ -28,6 +28,14 @@ const char *systolic_name(const SystolicPlan &sp);
 hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp,
                            const float *thr, int B, int T, int iters, hipStream_t stream,
                            int *launches, hipEvent_t ev0, hipEvent_t ev1);
+// A call that consists of one batch stage on device complex64 spectrograms [B][T][F] skips the extended buffers:
+// systolic_io_load converts `in` straight to the kernel's layout and computes mean|S| (partial: scratch of
+// B * systolic_io_partials() doubles), the caller scales the thresholds, systolic_io_run runs the sweeps and writes `out`.
+size_t systolic_io_partials(const SystolicPlan &sp, int T);
+hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, int iters, double *partial, double *mean_amp,
+                            hipStream_t stream);
+hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, float2 *out, int B, int T, int iters,
+                           hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1);
 
 // The same kernel compiled for frames of up to 1025 bins (lws_systolic.hip with -DLWS_WIDE=1): 16-step lane skew,
 // 64-step ring, 3 sweep slots.  Same contract.
@@ -39,6 +47,14 @@ const char *systolic_name(const SystolicPlan &sp);
 hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp,
                            const float *thr, int B, int T, int iters, hipStream_t stream,
                            int *launches, hipEvent_t ev0, hipEvent_t ev1);
+// A call that consists of one batch stage on device complex64 spectrograms [B][T][F] skips the extended buffers:
+// systolic_io_load converts `in` straight to the kernel's layout and computes mean|S| (partial: scratch of
+// B * systolic_io_partials() doubles), the caller scales the thresholds, systolic_io_run runs the sweeps and writes `out`.
+size_t systolic_io_partials(const SystolicPlan &sp, int T);
+hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, int iters, double *partial, double *mean_amp,
+                            hipStream_t stream);
+hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, float2 *out, int B, int T, int iters,
+                           hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1);
 }  // namespace wide
 
 }  // namespace lws

@@ -1104,6 +1104,116 @@ __global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float2 *
     }
 }
 
+// The same two conversions straight from / to the caller's unpadded [B][T][F] complex64 spectrograms, for calls that
+// are one batch stage: what k_prep + k_to_skew and k_from_skew + k_extract do in two passes each.
+// partial: [B][T][NT + 1] sums of |S| in fp64 (one per time tile a frame appears in, the last one its Nyquist bin) for
+// mean|S|; every slot is written on every call.
+__global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *state_w, float *amp_w, float2 *state_nyq,
+                                                     float *amp_nyq, unsigned *amax_bits, double *partial, int T, int F,
+                                                     int Q, int G, int TpPad, int NT) {
+    __shared__ float2 ts[TILE][TPAD];
+    __shared__ float ta[TILE][TPAD];
+    __shared__ float red[256];
+    const int kk = blockIdx.x / NT, tt = blockIdx.x - kk * NT, b = blockIdx.y;
+    const int Tp = T + 2 * (Q - 1), C = F - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tau0 = SKEW * LANES * kk + TILE * tt;
+    float2 *sw = state_w + (size_t)b * G * LANES;
+    float *aw = amp_w + (size_t)b * G * LANES;
+    float mx = 0.f;
+    for (int ml = wave; ml < TILE; ml += 4) {
+        const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
+        const bool real_frame = me >= Q - 1 && me < T + Q - 1;
+        int src = me - (Q - 1);                                  // edge-pad frames repeat the first / last frame
+        src = src < 0 ? 0 : (src > T - 1 ? T - 1 : src);
+        float2 v = make_float2(0.f, 0.f);
+        float av = 0.f;
+        double mag = 0.0;
+        if (me < Tp && c >= 0 && c < C) {
+            v = in[((size_t)b * T + src) * F + c];
+            mag = hypot((double)v.x, (double)v.y);               // as k_prep: magnitude in fp64, then rounded
+            av = (float)mag;
+            if (real_frame) mx = fmaxf(mx, av); else mag = 0.0;
+        }
+        ts[ml][lane] = v;
+        ta[ml][lane] = av;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mag += __shfl_xor(mag, off);   // fixed order: deterministic
+        if (lane == 0 && me < Tp && real_frame) partial[((size_t)b * T + src) * (NT + 1) + tt] = mag;
+    }
+    if (tt == 0 && wave == 0) {                                  // Nyquist bins of the round's frames
+        const int me = LANES * kk + lane;
+        if (me < Tp) {
+            int src = me - (Q - 1);
+            src = src < 0 ? 0 : (src > T - 1 ? T - 1 : src);
+            const float2 v = in[((size_t)b * T + src) * F + C];
+            const double mag = hypot((double)v.x, (double)v.y);
+            state_nyq[(size_t)b * TpPad + me] = v;
+            amp_nyq[(size_t)b * TpPad + me] = (float)mag;
+            if (me >= Q - 1 && me < T + Q - 1) {
+                mx = fmaxf(mx, (float)mag);
+                partial[((size_t)b * T + src) * (NT + 1) + NT] = mag;
+            }
+        }
+    }
+    __syncthreads();
+    for (int tl = wave; tl < TILE; tl += 4) {
+        const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
+        if (me < Tp && c >= 0 && c < C) {
+            const size_t idx = (size_t)((tau0 + tl) % G) * LANES + lane;
+            sw[idx] = ts[lane][tl];
+            aw[idx] = ta[lane][tl];
+        }
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(amax_bits + b, __float_as_uint(red[0]));
+}
+
+// mean|S| of each spectrogram from the partial sums, fixed order
+__global__ void __launch_bounds__(256) k_mean_partials(const double *partial, double *mean_amp, int n, double denom) {
+    __shared__ double red[256];
+    const int b = blockIdx.x;
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[(size_t)b * n + i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mean_amp[b] = red[0] / denom;
+}
+
+// skewed layout -> unpadded [B][T][F] output (real frames only, no pad columns)
+__global__ void __launch_bounds__(256) k_skew_to_out(float2 *out, const float2 *state_w, const float2 *state_nyq, int T,
+                                                      int F, int Q, int G, int TpPad, int NT) {
+    __shared__ float2 ts[TILE][TPAD];
+    const int kk = blockIdx.x / NT, tt = blockIdx.x - kk * NT, b = blockIdx.y;
+    const int Tp = T + 2 * (Q - 1), C = F - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tau0 = SKEW * LANES * kk + TILE * tt;
+    const float2 *sw = state_w + (size_t)b * G * LANES;
+    for (int tl = wave; tl < TILE; tl += 4) {
+        const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
+        if (me < Tp && c >= 0 && c < C) ts[lane][tl] = sw[(size_t)((tau0 + tl) % G) * LANES + lane];
+    }
+    __syncthreads();
+    for (int ml = wave; ml < TILE; ml += 4) {
+        const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
+        if (me >= Q - 1 && me < T + Q - 1 && c >= 0 && c < C)
+            out[((size_t)b * T + (me - (Q - 1))) * F + c] = ts[ml][lane];
+    }
+    if (tt == 0 && wave == 0) {
+        const int me = LANES * kk + lane;
+        if (me >= Q - 1 && me < T + Q - 1) out[((size_t)b * T + (me - (Q - 1))) * F + C] = state_nyq[(size_t)b * TpPad + me];
+    }
+}
+
 constexpr uint32_t mask_all(int Q, int L) { return (Q * (L + 1) >= 32) ? 0xffffffffu : ((1u << (Q * (L + 1))) - 1u); }
 
 template <int Q, int L, uint32_t MASK, bool MULTI> hipError_t launch_km(const SysArgs &a, int grid, hipStream_t s) {
@@ -1215,36 +1325,45 @@ bool systolic_supports(const SystolicPlan &sp, int wsel, int T) {
 
 const char *systolic_name(const SystolicPlan &sp) { return sp.name; }
 
-hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp, const float *thr, int B,
-                           int T, int iters, hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1) {
-    const Tables *tb = static_cast<const Tables *>(sp.tables[wsel]);
-    const int Q = sp.Q, L = sp.L, F = sp.F;
-    const int Tp = T + 2 * (Q - 1);
-    const int Kr = (Tp + LANES - 1) / LANES;
-    const int G = ROWP * Kr;
-    const int TpPad = (Tp + 63) & ~63;
-    // scratch: state_w, state_nyq | amp_w, amp_nyq, amax
-    const size_t n_w = (size_t)B * G * LANES, n_n = (size_t)B * TpPad;
+namespace {
+
+// Shapes and scratch pointers of one call.
+struct Geom {
+    int Tp, Kr, G, TpPad, NT, nwg;
+    float2 *state_w, *state_nyq;
+    float *amp_w, *amp_nyq;
+    unsigned *amax_bits, *progress;
+};
+
+hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
+    const int Q = sp.Q, F = sp.F;
+    g.Tp = T + 2 * (Q - 1);
+    g.Kr = (g.Tp + LANES - 1) / LANES;
+    g.G = ROWP * g.Kr;
+    g.TpPad = (g.Tp + 63) & ~63;
+    g.NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;   // time tiles per round of 64 frames
+    // scratch: state_w, state_nyq | amp_w, amp_nyq, amax, progress counters, error flag
+    const size_t n_w = (size_t)B * g.G * LANES, n_n = (size_t)B * g.TpPad;
     const size_t need_s = (n_w + n_n) * sizeof(float2);
-    hipError_t e0;
+    hipError_t e;
     // workgroups per spectrogram: as many as there are CUs to keep busy and passes to share out; every workgroup must
     // be resident (they wait for each other), which one workgroup per CU (the rings fill the LDS) and a grid no larger
     // than the CU count guarantee
     int n_cu = 0, dev = 0;
-    if ((e0 = hipGetDevice(&dev)) != hipSuccess) return e0;
-    if ((e0 = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
     int nwg = B > 0 ? n_cu / B : 1;
     const int n_pass_max = ((iters < MAX_ITERS ? iters : MAX_ITERS) + NSLOTS - 1) / NSLOTS;
     if (nwg > n_pass_max) nwg = n_pass_max;
     if (const char *ev = getenv("LWS_SYSTOLIC_NWG")) { const int v = atoi(ev); if (v >= 1 && (long)v * B <= n_cu) nwg = v; }
     // each workgroup trails its producer by NSLOTS*LAG + 56 rows, and the first one starts its next pass G rows after
     // its previous one: the lags around the ring must fit into one pass
-    const int ring_max = G / (NSLOTS * LAG + 96);
+    const int ring_max = g.G / (NSLOTS * LAG + 96);
     if (nwg > ring_max) nwg = ring_max;
     if (nwg < 1) nwg = 1;
+    g.nwg = nwg;
     const size_t n_prog = (size_t)B * nwg + 1;   // progress counters + the error flag
     const size_t need_a = (n_w + n_n) * sizeof(float) + (size_t)B * sizeof(unsigned) + n_prog * sizeof(unsigned);
-    hipError_t e;
     if (need_s > sp.sk_state_cap) {
         if (sp.sk_state) (void)hipFree(sp.sk_state);
         sp.sk_state = nullptr; sp.sk_state_cap = 0;
@@ -1257,50 +1376,105 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
         if ((e = hipMalloc(&sp.sk_amp, need_a)) != hipSuccess) return e;
         sp.sk_amp_cap = need_a;
     }
-    float2 *state_w = static_cast<float2 *>(sp.sk_state);
-    float2 *state_nyq = state_w + n_w;
-    float *amp_w = static_cast<float *>(sp.sk_amp);
-    float *amp_nyq = amp_w + n_w;
-    unsigned *amax_bits = reinterpret_cast<unsigned *>(amp_nyq + n_n);
-    unsigned *progress = amax_bits + B;
-    if ((e = hipMemsetAsync(amax_bits, 0, ((size_t)B + n_prog) * sizeof(unsigned), stream)) != hipSuccess) return e;
-    const int NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;   // time tiles per round of 64 frames
-    hipLaunchKernelGGL(k_to_skew, dim3(Kr * NT, B), dim3(256), 0, stream, state, amp, state_w, amp_w, state_nyq, amp_nyq,
-                       amax_bits, T, F, L, Q, G, TpPad, NT);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    g.state_w = static_cast<float2 *>(sp.sk_state);
+    g.state_nyq = g.state_w + n_w;
+    g.amp_w = static_cast<float *>(sp.sk_amp);
+    g.amp_nyq = g.amp_w + n_w;
+    g.amax_bits = reinterpret_cast<unsigned *>(g.amp_nyq + n_n);
+    g.progress = g.amax_bits + B;
+    return hipSuccess;
+}
 
-    int nl = 0;
-    if (ev0) (void)hipEventRecord(ev0, stream);
+hipError_t clear_flags(const Geom &g, int B, hipStream_t stream) {
+    return hipMemsetAsync(g.amax_bits, 0, ((size_t)B + (size_t)B * g.nwg + 1) * sizeof(unsigned), stream);
+}
+
+hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *thr, int B, int T, int iters,
+                      hipStream_t stream) {
+    const Tables *tb = static_cast<const Tables *>(sp.tables[wsel]);
+    const int Q = sp.Q, L = sp.L, F = sp.F, nwg = g.nwg;
     if (iters > MAX_ITERS) return hipErrorInvalidValue;  // caller checks SYSTOLIC_MAX_ITERS
-    for (int i0 = 0; i0 < iters; i0 += MAX_ITERS) {
-        SysArgs a;
-        a.state_w = state_w; a.amp_w = amp_w; a.state_nyq = state_nyq; a.amp_nyq = amp_nyq;
-        a.thr = thr + i0; a.amax = reinterpret_cast<const float *>(amax_bits);
-        a.n_iters = (iters - i0 < MAX_ITERS) ? iters - i0 : MAX_ITERS;
-        a.T = T; a.Tp = Tp; a.TpPad = TpPad; a.Kr = Kr; a.G = G; a.C = F - 1;
-        a.nwg = nwg; a.progress = progress; a.err = reinterpret_cast<int *>(progress + (size_t)B * nwg);
-        sp.err_dev = a.err; sp.last_nwg = nwg;
-        for (int x = 0; x < 32; ++x) {
-            const float re = x < Q * (L + 1) ? tb->w[2 * x] : 0.f, im = x < Q * (L + 1) ? tb->w[2 * x + 1] : 0.f;
-            unsigned ur, ui;
-            memcpy(&ur, &re, 4); memcpy(&ui, &im, 4);
-            a.w[x] = ((unsigned long long)ui << 32) | ur;
-        }
-        if (Q == 4) {
-            if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hann" : "systolic_q4_l5_hann"; }
-            else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hannmask" : "systolic_q4_l5_hannmask"; }
-            else { e = launch_k<4, 5, mask_all(4, 5)>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_allmask" : "systolic_q4_l5_allmask"; }
-        } else {
-            if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hann" : "systolic_q2_l5_hann"; }
-            else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hannmask" : "systolic_q2_l5_hannmask"; }
-            else { e = launch_k<2, 5, mask_all(2, 5)>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_allmask" : "systolic_q2_l5_allmask"; }
-        }
-        if (e != hipSuccess) return e;
-        ++nl;
+    hipError_t e;
+    SysArgs a;
+    a.state_w = g.state_w; a.amp_w = g.amp_w; a.state_nyq = g.state_nyq; a.amp_nyq = g.amp_nyq;
+    a.thr = thr; a.amax = reinterpret_cast<const float *>(g.amax_bits);
+    a.n_iters = iters;
+    a.T = T; a.Tp = g.Tp; a.TpPad = g.TpPad; a.Kr = g.Kr; a.G = g.G; a.C = F - 1;
+    a.nwg = nwg; a.progress = g.progress; a.err = reinterpret_cast<int *>(g.progress + (size_t)B * nwg);
+    sp.err_dev = a.err; sp.last_nwg = nwg;
+    for (int x = 0; x < 32; ++x) {
+        const float re = x < Q * (L + 1) ? tb->w[2 * x] : 0.f, im = x < Q * (L + 1) ? tb->w[2 * x + 1] : 0.f;
+        unsigned ur, ui;
+        memcpy(&ur, &re, 4); memcpy(&ui, &im, 4);
+        a.w[x] = ((unsigned long long)ui << 32) | ur;
     }
+    if (Q == 4) {
+        if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hann" : "systolic_q4_l5_hann"; }
+        else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hannmask" : "systolic_q4_l5_hannmask"; }
+        else { e = launch_k<4, 5, mask_all(4, 5)>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_allmask" : "systolic_q4_l5_allmask"; }
+    } else {
+        if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hann" : "systolic_q2_l5_hann"; }
+        else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hannmask" : "systolic_q2_l5_hannmask"; }
+        else { e = launch_k<2, 5, mask_all(2, 5)>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_allmask" : "systolic_q2_l5_allmask"; }
+    }
+    return e;
+}
+
+}  // namespace
+
+hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp, const float *thr, int B,
+                           int T, int iters, hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1) {
+    Geom g;
+    hipError_t e;
+    if ((e = prepare(sp, B, T, iters, g)) != hipSuccess) return e;
+    if ((e = clear_flags(g, B, stream)) != hipSuccess) return e;
+    const int Q = sp.Q, L = sp.L, F = sp.F;
+    hipLaunchKernelGGL(k_to_skew, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, g.state_w, g.amp_w, g.state_nyq,
+                       g.amp_nyq, g.amax_bits, T, F, L, Q, g.G, g.TpPad, g.NT);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    if ((e = run_kernel(sp, g, wsel, thr, B, T, iters, stream)) != hipSuccess) return e;
     if (ev1) (void)hipEventRecord(ev1, stream);
-    hipLaunchKernelGGL(k_from_skew, dim3(Kr * NT, B), dim3(256), 0, stream, state, state_w, state_nyq, T, F, L, Q, G, TpPad, NT);
-    if (launches) *launches = nl;
+    hipLaunchKernelGGL(k_from_skew, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, g.state_w, g.state_nyq, T, F, L, Q,
+                       g.G, g.TpPad, g.NT);
+    if (launches) *launches = 1;
+    return hipGetLastError();
+}
+
+// ---- a call that is one batch stage on the caller's unpadded complex64 spectrograms: no extended buffers at all
+namespace {
+size_t io_partials_n(int F, int T) {
+    const int NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;
+    return (size_t)T * (NT + 1);
+}
+}  // namespace
+size_t systolic_io_partials(const SystolicPlan &sp, int T) { return io_partials_n(sp.F, T); }
+
+hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, int iters, double *partial, double *mean_amp,
+                            hipStream_t stream) {
+    Geom g;
+    hipError_t e;
+    if ((e = prepare(sp, B, T, iters, g)) != hipSuccess) return e;
+    if ((e = clear_flags(g, B, stream)) != hipSuccess) return e;
+    const size_t n = io_partials_n(sp.F, T);
+    if ((e = hipMemsetAsync(partial, 0, (size_t)B * n * sizeof(double), stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_in_to_skew, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, in, g.state_w, g.amp_w, g.state_nyq,
+                       g.amp_nyq, g.amax_bits, partial, T, sp.F, sp.Q, g.G, g.TpPad, g.NT);
+    hipLaunchKernelGGL(k_mean_partials, dim3(B), dim3(256), 0, stream, partial, mean_amp, (int)n, (double)T * (double)sp.F);
+    return hipGetLastError();
+}
+
+hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, float2 *out, int B, int T, int iters,
+                           hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1) {
+    Geom g;
+    hipError_t e;
+    if ((e = prepare(sp, B, T, iters, g)) != hipSuccess) return e;   // same shapes: no reallocation, same pointers
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    if ((e = run_kernel(sp, g, wsel, thr, B, T, iters, stream)) != hipSuccess) return e;
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    hipLaunchKernelGGL(k_skew_to_out, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, out, g.state_w, g.state_nyq, T, sp.F, sp.Q,
+                       g.G, g.TpPad, g.NT);
+    if (launches) *launches = 1;
     return hipGetLastError();
 }
 

@@ -183,3 +183,32 @@ def test_workgroup_sharing_randomised(monkeypatch):
             else:
                 monkeypatch.setenv("LWS_SYSTOLIC_NWG", nwg)
             assert np.array_equal(p.plan().batch(S, thr), ref), (trial, fs, sh, B, T, iters, nwg)
+
+
+# ----------------------------------------------------------------------------- direct device I/O
+@pytest.mark.parametrize("fsize,fshift,B,T", [(64, 16, 3, 77), (1024, 256, 2, 130), (1024, 512, 2, 65), (2048, 512, 2, 40)])
+def test_direct_device_io_equals_the_padded_path(fsize, fshift, B, T):
+    """A *_dev call that is one batch stage converts the caller's complex64 spectrograms straight to the kernel's
+    layout and back.  Same sweeps on the same values: the result equals the path through the extended buffers bit for
+    bit whenever both compute the same scaled thresholds (mean|S| is summed in another order, so allow the last bit of a
+    threshold to differ: compare with zero thresholds for identity, and the default schedule within tolerance)."""
+    import torch
+    rng = np.random.default_rng(fsize + T)
+    F = fsize // 2 + 1
+    p = lws_amd.lws(fsize, fshift)
+    S = (rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))).astype(np.complex64)
+    direct = _capi.Plan(F, p.W)
+    padded = _capi.Plan(F, p.W, direct_io=False)
+    stream = torch.cuda.current_stream().cuda_stream
+    for thr in (np.zeros(9), lws_amd.get_thresholds(12, 2.0, 0.3, 1)):
+        a = torch.from_numpy(S.copy()).cuda()
+        b = torch.from_numpy(S.copy()).cuda()
+        direct.batch_dev(a.data_ptr(), B, T, thr, stream=stream)
+        assert direct.last_kernel()["name"].startswith("systolic")
+        padded.batch_dev(b.data_ptr(), B, T, thr, stream=stream)
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        if not thr.any():
+            assert np.array_equal(a, b)
+        else:
+            assert np.abs(a - b).max() < 1e-4 * np.abs(S).max() and np.mean(a != b) < 1e-2
+    direct.close(); padded.close()
