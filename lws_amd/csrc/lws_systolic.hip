@@ -219,6 +219,9 @@ __device__ __forceinline__ float2 load_l2(const float2 *p) {
 // Stores another workgroup (possibly on another XCD, behind another L2) will read during this launch: write through.
 // (With one workgroup per spectrogram producer and consumer share the CU's XCD and a plain store is enough.)
 __device__ __forceinline__ void store_l2(float2 *p, float2 v, bool shared) {
+#ifdef LWS_DBG_NOSTORE   // timing experiment: nothing is written back (results invalid)
+    return;
+#endif
     if (shared) {
         const unsigned long long u = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -236,6 +239,9 @@ __device__ __forceinline__ void store_l2(float2 *p, float2 v, bool shared) {
 // in LDS; LDS executes the operations of one wave in program order and all ring accesses are volatile (compiler
 // order), so "write data, then the counter" / "read the counter, then the data" is sufficient.  No barriers.
 __device__ __forceinline__ void flow_wait(int lane, int s, bool watched) {
+#ifdef LWS_DBG_NOFLOW   // timing experiment: waves do not wait for each other (results invalid)
+    return;
+#endif
     const int addr = DONE_OFF + (lane & 15) * 4;   // lane l < number of waves watches wave l
     while (true) {
         const int v = lds_read_i32(addr);
@@ -275,6 +281,9 @@ __host__ __device__ constexpr int floor_div8(int q) { return (q >= 0) ? q / 8 : 
 #define LWS_DBG_NOWRAP2 0   // timing experiment: the straddling pair shares one set of fetches (results invalid)
 #endif
 __device__ __forceinline__ void ring_publish(int addr, int halo_shift, int dummy, float2 v) {
+#ifdef LWS_DBG_NOPUBLISH   // timing experiment: results are not written to the rings (results invalid)
+    return;
+#endif
     lds_write(addr, v);
 #if !LWS_DBG_NOIMG
     lds_write(halo_shift != 0 ? addr + halo_shift : dummy, v);
@@ -623,6 +632,9 @@ __device__ __forceinline__ float2 rows_sum(const SysArgs &a, const float2 (&tu)[
 // reciprocal square root (relative error < 2^-22, the size of the two roundings of sqrt-then-divide);
 // sums too small to square in fp32 are rescaled first, so "|acc| > 0" keeps the reference's meaning.
 __device__ __forceinline__ float2 project(float2 acc, float target, bool active, float2 old) {
+#ifdef LWS_DBG_NOPROJECT   // timing experiment: no re-projection (results invalid)
+    return active ? make_float2(acc.x * target, acc.y * target) : old;
+#endif
     float m2 = acc.x * acc.x + acc.y * acc.y;
     const bool tiny = m2 < 1e-30f;
     const float ax = tiny ? acc.x * 0x1p60f : acc.x, ay = tiny ? acc.y * 0x1p60f : acc.y;
@@ -665,6 +677,9 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
         constexpr int i = decltype(ir)::value;
         constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
         constexpr uint32_t kmask = (MASK >> (R * K1)) & ((1u << K1) - 1u);
+#ifdef LWS_DBG_ONLYROW   // timing experiment: only this row pair (0: none) is fetched and summed (results invalid)
+        if constexpr (R != LWS_DBG_ONLYROW) return;
+#endif
         if constexpr (!wrap || LWS_DBG_NOWRAP2) {
             float2 tu[2 * L + 2], td[2 * L + 2];
             load_row2<PA, -R, L, kmask, 0>(cx, stA, enA, tu);
@@ -953,7 +968,11 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 amp_cur[i] = amp_nxt[i];
+#ifdef LWS_DBG_NOAMP   // timing experiment: no target-magnitude loads (results invalid)
+                amp_nxt[i] = (float)(vnext + i);
+#else
                 amp_nxt[i] = amp_w_b[(size_t)(vnext + i) * LANES + lane];
+#endif
             }
         }
         // ---- 4 pairs of bins, phases static
@@ -978,7 +997,11 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             }
             if (is_service) {
                 // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
+#ifndef LWS_DBG_NONYQ   // timing experiment: no Nyquist bins (results invalid)
                 if constexpr (PA == 1)
+#else
+                if constexpr (false)
+#endif
                     service_nyquist<Q, L, MASK, MULTI>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
                 // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
                 // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
@@ -999,8 +1022,12 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 int i0 = tmod + PA + 8, i1 = tmod + PA + 9;
                 i0 -= (i0 >= G) ? G : 0;
                 i1 -= (i1 >= G) ? G : 0;
+#ifdef LWS_DBG_NOLOADER   // timing experiment: the loader fetches nothing (results invalid)
+                const float2 p0 = make_float2((float)i0, 1.f), p1 = make_float2((float)i1, 2.f);
+#else
                 const float2 p0 = load_l2(state_w_b + (size_t)i0 * LANES + lane);
                 const float2 p1 = load_l2(state_w_b + (size_t)i1 * LANES + lane);
+#endif
                 amp_cur[PA & 7] = p0.x; amp_nxt[PA & 7] = p0.y;
                 amp_cur[(PA + 1) & 7] = p1.x; amp_nxt[(PA + 1) & 7] = p1.y;
             }
