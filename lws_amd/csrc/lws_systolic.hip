@@ -659,8 +659,12 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     const bool stA = cx.is_start, enA = cx.is_end;
     const bool stB = wrap ? cx.nxt_start : cx.is_start, enB = wrap ? cx.nxt_end : cx.is_end;
     // previous-sweep values of the own bins of the NEXT pair (ages 29 and 28 now, 31 and 30 by then)
+#ifdef LWS_DBG_NOCARRY   // timing experiment: the own previous-sweep values are not fetched (results invalid)
+    const float2 o3 = cr.o1, o4 = cr.o2;
+#else
     const float2 o3 = lds_read(ring_addr<PA, 3 - LAG>(cx.ob));
     const float2 o4 = lds_read(ring_addr<PA, 4 - LAG>(cx.ob));
+#endif
 #ifndef LWS_DBG_NOCPATCH
 #define LWS_DBG_NOCPATCH 0   // timing experiment: centre-frame taps never use images (results invalid)
 #endif
@@ -918,37 +922,48 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         if (is_service) watched = lane < NSLOTS;
         else watched = (lane == wave - 1) || (lane == wave + 1) || (lane == NSLOTS);
     }
+    // Where a lane is in a block of 8 steps (which frame of which sweep, first / last bins of the frame, active at
+    // all): evaluated once per block for the FOLLOWING block and shifted; the division by the number of lane rounds is
+    // done in floating point (exact for these magnitudes) and the threshold of the lane's sweep is re-read from LDS
+    // only when the sweep changes.
+    const float inv_kr = 1.0f / (float)Kr;
+    struct BlockInfo { bool live, store, start, end; float thr; int j; };
+    auto block_info = [&](int vblock, const BlockInfo &prev) {      // vblock: the slot's clock at phase 0 of the block
+        BlockInfo bi;
+        const int vv = vblock - SKEW * lane;        // clock relative to the start of the lane's first frame
+        const int cbase = vv & (ROWP - 1);
+        const int kap = vv >> ROWP_SHIFT;
+        const int gl = (int)(((float)kap + 0.5f) * inv_kr), k = kap - gl * Kr;
+        const int me = k * LANES + lane;
+        const int j = (gl * nwg + wg) * NSLOTS + slot;
+        const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
+        bi.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
+        bi.store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
+        bi.start = (cbase == 0);
+        bi.end = (cbase == C - 8);
+        bi.j = valid ? j : 0;
+        bi.thr = prev.thr;
+        if (__any(bi.j != prev.j)) bi.thr = thr_eff[bi.j];
+        return bi;
+    };
+    BlockInfo nxt_bi;
+    nxt_bi.j = -1; nxt_bi.thr = 0.f; nxt_bi.live = nxt_bi.store = nxt_bi.start = nxt_bi.end = false;
+    nxt_bi = block_info(T_START - (slot + 1) * LAG, nxt_bi);
+    int vmod = __builtin_amdgcn_readfirstlane((((T_START - (slot + 1) * LAG) % G) + G) % G - 8);   // advanced at the loop head
+    int tmod = __builtin_amdgcn_readfirstlane(((T_START % G) + G) % G - 8);
     for (int t0 = T_START; t0 < t_end; t0 += 8) {
         const int v0 = t0 - (slot + 1) * LAG;  // clock of this sweep slot at phase 0 of the block (multiple of 8)
         // ---- block prologue: where is this lane in this block and in the next one?
         const int ablk = (v0 >> 3);
+#ifdef LWS_DBG_NOPROLOG   // timing experiment: the per-block bookkeeping is done once (results invalid)
+        if (t0 == T_START)
+#endif
         {
-            const int vv = v0 - SKEW * lane;        // clock relative to the start of the lane's first frame
-            const int cbase = vv & (ROWP - 1);
-            const int kap = vv >> ROWP_SHIFT;
-            const int gl = kap / Kr, k = kap - gl * Kr;
-            const int me = k * LANES + lane;
-            const int j = (gl * nwg + wg) * NSLOTS + slot;
-            const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
-            cx.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
-            cx.store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
-            cx.is_start = (cbase == 0);
-            cx.is_end = (cbase == C - 8);
-            cx.thr = thr_eff[(valid ? j : 0)];
-        }
-        {
-            const int vv = v0 + 8 - SKEW * lane;
-            const int cbase = vv & (ROWP - 1);
-            const int kap = vv >> ROWP_SHIFT;
-            const int gl = kap / Kr, k = kap - gl * Kr;
-            const int me = k * LANES + lane;
-            const int j = (gl * nwg + wg) * NSLOTS + slot;
-            const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
-            cx.nxt_live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
-            cx.nxt_store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
-            cx.nxt_start = (cbase == 0);
-            cx.nxt_end = (cbase == C - 8);
-            cx.nxt_thr = thr_eff[(valid ? j : 0)];
+            const BlockInfo cur = nxt_bi;
+            nxt_bi = block_info(v0 + 8, cur);
+            cx.live = cur.live; cx.store = cur.store; cx.is_start = cur.start; cx.is_end = cur.end; cx.thr = cur.thr;
+            cx.nxt_live = nxt_bi.live; cx.nxt_store = nxt_bi.store; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end;
+            cx.nxt_thr = nxt_bi.thr;
         }
         cx.lane8 = lane * 8;
         cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + lane * 8;
@@ -960,8 +975,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             cx.uo[m] = set_old + blk;
             cx.ob[m] = set_old + blk + lane * LANE_B;
         }
-        const int vmod = __builtin_amdgcn_readfirstlane(((v0 % G) + G) % G);  // wave-uniform, once per 8 steps
-        const int tmod = __builtin_amdgcn_readfirstlane(((t0 % G) + G) % G);
+        vmod += 8; vmod -= (vmod >= G) ? G : 0;   // v0 mod G and t0 mod G (G is a multiple of 8), wave-uniform
+        tmod += 8; tmod -= (tmod >= G) ? G : 0;
         if (is_compute) {
             int vnext = vmod + 8;
             vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
