@@ -1372,6 +1372,8 @@ namespace {
 // Shapes and scratch pointers of one call.
 struct Geom {
     int Tp, Kr, G, TpPad, NT, nwg;
+    int n_full, nwg_rest;   // batches larger than the chip: n_full spectrograms with one workgroup each, then the rest
+                            // (B - n_full, fewer than there are CUs) with nwg_rest workgroups each
     float2 *state_w, *state_nyq;
     float *amp_w, *amp_nyq;
     unsigned *amax_bits, *progress;
@@ -1394,17 +1396,24 @@ hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
     int n_cu = 0, dev = 0;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-    int nwg = B > 0 ? n_cu / B : 1;
     const int n_pass_max = ((iters < MAX_ITERS ? iters : MAX_ITERS) + NSLOTS - 1) / NSLOTS;
-    if (nwg > n_pass_max) nwg = n_pass_max;
-    if (const char *ev = getenv("LWS_SYSTOLIC_NWG")) { const int v = atoi(ev); if (v >= 1 && (long)v * B <= n_cu) nwg = v; }
     // each workgroup trails its producer by NSLOTS*LAG + 56 rows, and the first one starts its next pass G rows after
     // its previous one: the lags around the ring must fit into one pass
     const int ring_max = g.G / (NSLOTS * LAG + 96);
-    if (nwg > ring_max) nwg = ring_max;
-    if (nwg < 1) nwg = 1;
+    const char *ev = getenv("LWS_SYSTOLIC_NWG");
+    auto pick = [&](int nb) {
+        int n = nb > 0 ? n_cu / nb : 1;
+        if (n > n_pass_max) n = n_pass_max;
+        if (ev) { const int v = atoi(ev); if (v >= 1 && (long)v * nb <= n_cu) n = v; }
+        if (n > ring_max) n = ring_max;
+        return n < 1 ? 1 : n;
+    };
+    const int nwg = pick(B);
     g.nwg = nwg;
-    const size_t n_prog = (size_t)B * nwg + 1;   // progress counters + the error flag
+    // a batch that does not fill the last round of workgroups: the spectrograms of that round share the idle CUs
+    g.n_full = B; g.nwg_rest = 1;
+    if (nwg == 1 && B > n_cu && B % n_cu != 0 && pick(B % n_cu) > 1) { g.n_full = B - B % n_cu; g.nwg_rest = pick(B % n_cu); }
+    const size_t n_prog = (size_t)B * nwg + (size_t)(B - g.n_full) * g.nwg_rest + 1;   // progress counters + the error flag
     const size_t need_a = (n_w + n_n) * sizeof(float) + (size_t)B * sizeof(unsigned) + n_prog * sizeof(unsigned);
     if (need_s > sp.sk_state_cap) {
         if (sp.sk_state) (void)hipFree(sp.sk_state);
@@ -1428,22 +1437,34 @@ hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
 }
 
 hipError_t clear_flags(const Geom &g, int B, hipStream_t stream) {
-    return hipMemsetAsync(g.amax_bits, 0, ((size_t)B + (size_t)B * g.nwg + 1) * sizeof(unsigned), stream);
+    const size_t n_prog = (size_t)B * g.nwg + (size_t)(B - g.n_full) * g.nwg_rest + 1;
+    return hipMemsetAsync(g.amax_bits, 0, ((size_t)B + n_prog) * sizeof(unsigned), stream);
 }
 
 hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *thr, int B, int T, int iters,
                       hipStream_t stream) {
     const Tables *tb = static_cast<const Tables *>(sp.tables[wsel]);
-    const int Q = sp.Q, L = sp.L, F = sp.F, nwg = g.nwg;
+    const int Q = sp.Q, L = sp.L, F = sp.F;
     if (iters > MAX_ITERS) return hipErrorInvalidValue;  // caller checks SYSTOLIC_MAX_ITERS
-    hipError_t e;
+    const int nwg = g.nwg;
+    hipError_t e = hipSuccess;
+    const size_t n_prog = (size_t)B * nwg + (size_t)(B - g.n_full) * g.nwg_rest;
+    int *err = reinterpret_cast<int *>(g.progress + n_prog);
+    sp.err_dev = err; sp.last_nwg = nwg > g.nwg_rest ? nwg : g.nwg_rest;
+  for (int chunk = 0; chunk < 2; ++chunk) {
+    // chunk 0: the first n_full spectrograms (all of them unless the batch leaves a partial last round on the chip);
+    // chunk 1: the rest, with several workgroups per spectrogram
+    const int b0 = chunk == 0 ? 0 : g.n_full, nb = chunk == 0 ? g.n_full : B - g.n_full;
+    const int nwg = chunk == 0 ? g.nwg : g.nwg_rest;
+    if (nb <= 0) continue;
     SysArgs a;
-    a.state_w = g.state_w; a.amp_w = g.amp_w; a.state_nyq = g.state_nyq; a.amp_nyq = g.amp_nyq;
-    a.thr = thr; a.amax = reinterpret_cast<const float *>(g.amax_bits);
+    a.state_w = g.state_w + (size_t)b0 * g.G * LANES; a.amp_w = g.amp_w + (size_t)b0 * g.G * LANES;
+    a.state_nyq = g.state_nyq + (size_t)b0 * g.TpPad; a.amp_nyq = g.amp_nyq + (size_t)b0 * g.TpPad;
+    a.thr = thr + (size_t)b0 * iters; a.amax = reinterpret_cast<const float *>(g.amax_bits) + b0;
     a.n_iters = iters;
     a.T = T; a.Tp = g.Tp; a.TpPad = g.TpPad; a.Kr = g.Kr; a.G = g.G; a.C = F - 1;
-    a.nwg = nwg; a.progress = g.progress; a.err = reinterpret_cast<int *>(g.progress + (size_t)B * nwg);
-    sp.err_dev = a.err; sp.last_nwg = nwg;
+    a.nwg = nwg; a.progress = g.progress + (chunk == 0 ? 0 : (size_t)B * g.nwg); a.err = err;
+    const int B = nb;   // the launch below is for this chunk
     for (int x = 0; x < 32; ++x) {
         const float re = x < Q * (L + 1) ? tb->w[2 * x] : 0.f, im = x < Q * (L + 1) ? tb->w[2 * x + 1] : 0.f;
         unsigned ur, ui;
@@ -1459,6 +1480,8 @@ hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *th
         else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hannmask" : "systolic_q2_l5_hannmask"; }
         else { e = launch_k<2, 5, mask_all(2, 5)>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_allmask" : "systolic_q2_l5_allmask"; }
     }
+    if (e != hipSuccess) return e;
+  }
     return e;
 }
 

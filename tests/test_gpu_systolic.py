@@ -212,3 +212,17 @@ def test_direct_device_io_equals_the_padded_path(fsize, fshift, B, T):
         else:
             assert np.abs(a - b).max() < 1e-4 * np.abs(S).max() and np.mean(a != b) < 1e-2
     direct.close(); padded.close()
+
+
+def test_partial_last_round_shares_the_chip(monkeypatch):
+    """More spectrograms than CUs with a remainder: the spectrograms of the partial last round get several workgroups
+    each (a second launch); same results as one workgroup each."""
+    rng = np.random.default_rng(77)
+    p = lws_amd.lws(64, 16)
+    B, T = 300, 90
+    S = np.abs(rng.standard_normal((B, T, 33)) + 1j * rng.standard_normal((B, T, 33))).astype(np.complex128)
+    thr = lws_amd.get_thresholds(20, 2.0, 0.2, 1)
+    monkeypatch.setenv("LWS_SYSTOLIC_NWG", "1")
+    ref = p.plan().batch(S, thr)
+    monkeypatch.delenv("LWS_SYSTOLIC_NWG")
+    assert np.array_equal(p.plan().batch(S, thr), ref)
