@@ -238,5 +238,41 @@ def main():
             print(f, os.path.getsize(os.path.join(HERE, f)))
 
 
+def extra():
+    """Fingerprints of BASELINE configs 3 and 5 (added later; `python make_golden.py extra` writes only these)."""
+    ref = build_reference_module()
+    # config 3: run_lws of mode='music' (1 no-future sweep, 10 online iterations with look-ahead 3, 100 batch sweeps) on
+    # one 500 x 513 magnitude spectrogram; the stages are kept separately
+    p = ref.lws(1024, 256, mode='music')
+    g = np.random.default_rng(20260928 + 3)
+    M = np.abs(g.standard_normal((500, 513)) + 1j * g.standard_normal((500, 513))).astype(np.float32).astype(np.float64)
+    s0 = p.nofuture_lws(M)
+    s1 = p.online_lws(s0)
+    s2 = p.batch_lws(s1)
+    np.savez_compressed(os.path.join(HERE, "config3_fingerprint.npz"),
+                        seed=np.array(20260928 + 3), shape=np.array([500, 513]),
+                        consistency_nofuture=np.array(p.get_consistency(s0)),
+                        consistency_online=np.array(p.get_consistency(s1)),
+                        consistency_out=np.array(p.get_consistency(s2)),
+                        sample_idx=np.arange(0, s0.size, 97), sample_nofuture=s0.ravel()[::97],
+                        norm_online=np.array(np.linalg.norm(s1)), norm_out=np.array(np.linalg.norm(s2)))
+    # config 5: 2048-point frames (1025 bins), hop 512; 150 frames, 30 sweeps of a schedule that keeps every sweep active
+    p = ref.lws(2048, 512)
+    g = np.random.default_rng(20260928 + 5)
+    M = np.abs(g.standard_normal((150, 1025)) + 1j * g.standard_normal((150, 1025))).astype(np.float32).astype(np.float64)
+    thr = ref.get_thresholds(30, 2.0, 0.1, 1)
+    Y = ref.batch_lws(M, p.W, thr)
+    np.savez_compressed(os.path.join(HERE, "config5_fingerprint.npz"),
+                        seed=np.array(20260928 + 5), shape=np.array([150, 1025]), thr=thr,
+                        consistency_in=np.array(p.get_consistency(M.astype(complex))),
+                        consistency_out=np.array(p.get_consistency(Y)),
+                        sample_idx=np.arange(0, Y.size, 97), sample_out=Y.ravel()[::97])
+    for f in ("config3_fingerprint.npz", "config5_fingerprint.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        extra()
+    else:
+        main()

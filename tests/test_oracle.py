@@ -161,3 +161,28 @@ def test_against_compiled_reference_live(oracle, reflib):
                 reflib.call("LWSanyQ", er, ei, W, amp, F, T, L, Q, thr)
                 oracle.sweep(oer, oei, W, amp, F, T, L, Q, thr, M0=M0_ALL)
             assert np.abs(er - oer).max() < ATOL_MULTI and np.abs(ei - oei).max() < ATOL_MULTI
+
+
+def test_config3_and_config5_fingerprints(oracle):
+    """BASELINE config 3 (run_lws of mode='music', stage by stage) and config 5 (1025-bin frames) at scale, against
+    fingerprints the reference produced (tests/golden/make_golden.py extra)."""
+    import lws_amd
+    fp = load_golden("config3_fingerprint.npz")
+    rng = np.random.default_rng(int(fp["seed"]))
+    M = np.abs(rng.standard_normal((500, 513)) + 1j * rng.standard_normal((500, 513))).astype(np.float32).astype(np.float64)
+    p = lws_amd.lws(1024, 256, mode="music")          # host-side construction only: no device work here
+    s0 = oracle.nofuture_lws(M, p.W_ai, lws_amd.get_thresholds(1, 1, 0.1, 1))
+    assert np.abs(s0.ravel()[::97] - fp["sample_nofuture"]).max() < 1e-9
+    s1 = oracle.online_lws(s0, p.W, p.W_ai, p.W_af, lws_amd.get_thresholds(10, 1, 0.1, 1), 3, 256)
+    assert abs(np.linalg.norm(s1) - float(fp["norm_online"])) < 1e-6 * float(fp["norm_online"])
+    # the online stage amplifies even the fp64 re-association differences between the reference's specialised kernels
+    # and the canonical form (individual phases drift, the quality reached does not)
+    assert abs(p.get_consistency(s1) - float(fp["consistency_online"])) < 0.05
+    s2 = oracle.batch_lws(s1, p.W, lws_amd.get_thresholds(100, 100, 0.1, 1))
+    assert abs(p.get_consistency(s2) - float(fp["consistency_out"])) < 0.05
+    fp = load_golden("config5_fingerprint.npz")
+    rng = np.random.default_rng(int(fp["seed"]))
+    M = np.abs(rng.standard_normal((150, 1025)) + 1j * rng.standard_normal((150, 1025))).astype(np.float32).astype(np.float64)
+    p5 = lws_amd.lws(2048, 512)
+    Y = oracle.batch_lws(M, p5.W, fp["thr"])
+    assert np.abs(Y.ravel()[::97] - fp["sample_out"]).max() < 1e-8
