@@ -18,6 +18,8 @@
 // the headline batch workload is the systolic kernel in lws_systolic.hip.
 #include "lws_common.h"
 
+#include <type_traits>
+
 namespace lws {
 
 // a += w*b + conj(w)*c in the grouped form of lwslib.cpp:310-311: cancels exactly when c == conj(b)
@@ -352,7 +354,10 @@ __global__ void __launch_bounds__(256) k_prep(const in_cx *in, typename cx<real>
         o.x = (real)re;
         o.y = (real)(sgn * im);
         orow[n] = o;
-        const double mag = hypot(re, im);
+        // |S| in fp64.  From float inputs the squares are exact and cannot overflow in fp64: one rounding in the sum, one
+        // in the square root (the systolic path's own loader, k_in_to_skew, uses the same form so that both agree bit
+        // for bit); complex128 inputs keep hypot's range.
+        const double mag = std::is_same<typename scalar_of<in_cx>::type, float>::value ? sqrt(re * re + im * im) : hypot(re, im);
         arow[n] = (real)mag;
         if (real_frame && n >= L && n < F + L) acc += mag;
     }

@@ -1148,14 +1148,14 @@ __global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float2 *
 
 // The same two conversions straight from / to the caller's unpadded [B][T][F] complex64 spectrograms, for calls that
 // are one batch stage: what k_prep + k_to_skew and k_from_skew + k_extract do in two passes each.
-// partial: [B][T][NT + 1] sums of |S| in fp64 (one per time tile a frame appears in, the last one its Nyquist bin) for
-// mean|S|; every slot is written on every call.
+// partial: [B][tiles] sums of |S| over the real frames in fp64, one per tile (block), for mean|S|.
 __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *state_w, float *amp_w, float2 *state_nyq,
                                                      float *amp_nyq, unsigned *amax_bits, double *partial, int T, int F,
                                                      int Q, int G, int TpPad, int NT) {
     __shared__ float2 ts[TILE][TPAD];
     __shared__ float ta[TILE][TPAD];
     __shared__ float red[256];
+    __shared__ double dred[256];
     const int kk = blockIdx.x / NT, tt = blockIdx.x - kk * NT, b = blockIdx.y;
     const int Tp = T + 2 * (Q - 1), C = F - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1163,6 +1163,7 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *st
     float2 *sw = state_w + (size_t)b * G * LANES;
     float *aw = amp_w + (size_t)b * G * LANES;
     float mx = 0.f;
+    double msum = 0.0;                                       // this thread's share of sum |S| over the real frames
     for (int ml = wave; ml < TILE; ml += 4) {
         const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
         const bool real_frame = me >= Q - 1 && me < T + Q - 1;
@@ -1173,15 +1174,12 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *st
         double mag = 0.0;
         if (me < Tp && c >= 0 && c < C) {
             v = in[((size_t)b * T + src) * F + c];
-            mag = hypot((double)v.x, (double)v.y);               // as k_prep: magnitude in fp64, then rounded
+            mag = sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);   // as k_prep: |S| in fp64, then rounded
             av = (float)mag;
-            if (real_frame) mx = fmaxf(mx, av); else mag = 0.0;
+            if (real_frame) { mx = fmaxf(mx, av); msum += mag; }
         }
         ts[ml][lane] = v;
         ta[ml][lane] = av;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mag += __shfl_xor(mag, off);   // fixed order: deterministic
-        if (lane == 0 && me < Tp && real_frame) partial[((size_t)b * T + src) * (NT + 1) + tt] = mag;
     }
     if (tt == 0 && wave == 0) {                                  // Nyquist bins of the round's frames
         const int me = LANES * kk + lane;
@@ -1189,12 +1187,12 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *st
             int src = me - (Q - 1);
             src = src < 0 ? 0 : (src > T - 1 ? T - 1 : src);
             const float2 v = in[((size_t)b * T + src) * F + C];
-            const double mag = hypot((double)v.x, (double)v.y);
+            const double mag = sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);
             state_nyq[(size_t)b * TpPad + me] = v;
             amp_nyq[(size_t)b * TpPad + me] = (float)mag;
             if (me >= Q - 1 && me < T + Q - 1) {
                 mx = fmaxf(mx, (float)mag);
-                partial[((size_t)b * T + src) * (NT + 1) + NT] = mag;
+                msum += mag;
             }
         }
     }
@@ -1208,12 +1206,19 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *st
         }
     }
     red[threadIdx.x] = mx;
+    dred[threadIdx.x] = msum;
     __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {               // fixed tree: deterministic
+        if (threadIdx.x < s2) {
+            red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+            dred[threadIdx.x] += dred[threadIdx.x + s2];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(amax_bits + b, __float_as_uint(red[0]));
+    if (threadIdx.x == 0) {
+        if (red[0] > 0.f) atomicMax(amax_bits + b, __float_as_uint(red[0]));
+        partial[(size_t)b * gridDim.x + blockIdx.x] = dred[0];   // one partial sum per tile
+    }
 }
 
 // mean|S| of each spectrogram from the partial sums, fixed order
@@ -1508,12 +1513,13 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
 
 // ---- a call that is one batch stage on the caller's unpadded complex64 spectrograms: no extended buffers at all
 namespace {
-size_t io_partials_n(int F, int T) {
+size_t io_partials_n(int F, int T, int Q) {            // one partial sum per tile of k_in_to_skew
     const int NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;
-    return (size_t)T * (NT + 1);
+    const int Tp = T + 2 * (Q - 1), Kr = (Tp + LANES - 1) / LANES;
+    return (size_t)Kr * NT;
 }
 }  // namespace
-size_t systolic_io_partials(const SystolicPlan &sp, int T) { return io_partials_n(sp.F, T); }
+size_t systolic_io_partials(const SystolicPlan &sp, int T) { return io_partials_n(sp.F, T, sp.Q); }
 
 hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, int iters, double *partial, double *mean_amp,
                             hipStream_t stream) {
@@ -1521,8 +1527,7 @@ hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, in
     hipError_t e;
     if ((e = prepare(sp, B, T, iters, g)) != hipSuccess) return e;
     if ((e = clear_flags(g, B, stream)) != hipSuccess) return e;
-    const size_t n = io_partials_n(sp.F, T);
-    if ((e = hipMemsetAsync(partial, 0, (size_t)B * n * sizeof(double), stream)) != hipSuccess) return e;
+    const size_t n = io_partials_n(sp.F, T, sp.Q);
     hipLaunchKernelGGL(k_in_to_skew, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, in, g.state_w, g.amp_w, g.state_nyq,
                        g.amp_nyq, g.amax_bits, partial, T, sp.F, sp.Q, g.G, g.TpPad, g.NT);
     hipLaunchKernelGGL(k_mean_partials, dim3(B), dim3(256), 0, stream, partial, mean_amp, (int)n, (double)T * (double)sp.F);
