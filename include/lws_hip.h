@@ -28,6 +28,8 @@
 #ifndef LWS_HIP_H_
 #define LWS_HIP_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -112,6 +114,10 @@ int lws_residual_dev(lws_plan *plan, const void *S_dev, int B, int T, double *ou
  * stream the kernels ran on: total milliseconds spent in the update kernels and the number of
  * update-kernel launches (prep / extract kernels are not counted). */
 int lws_last_kernel_time(lws_plan *plan, float *ms, int *launches);
+
+/* Device-to-device stream copy of `bytes` (a multiple of 16) with the library's own kernel: the measured HBM copy
+ * rate the roofline fraction is quoted beside (spec peak and measured copy peak). */
+int lws_stream_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 
 /* Name of the update kernel the last call dispatched ("generic_fp32", "systolic_q4", ...). */
 const char *lws_last_kernel_name(lws_plan *plan);

@@ -26,7 +26,7 @@ EXPORTS = (
     "lws_nofuture_lws_dev", "lws_online_lws_dev", "lws_residual_dev", "lws_last_kernel_time",
     "lws_last_kernel_name", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev",
     "lws_consistency_dev", "lws_hann", "lws_synthwin", "lws_weights_shape", "lws_create_weights",
-    "lws_build_asymmetric_windows", "lws_get_thresholds", "lws_plan_create_from_windows",
+    "lws_build_asymmetric_windows", "lws_get_thresholds", "lws_plan_create_from_windows", "lws_stream_copy",
 )
 
 _lib = None
@@ -72,6 +72,7 @@ def load():
     lib.lws_residual_dev.argtypes = [vp, vp, ip, ip, vp, vp]
     lib.lws_last_kernel_time.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.lws_last_kernel_name.argtypes = [vp]
+    lib.lws_stream_copy.argtypes = [vp, vp, C.c_size_t, vp]
     lib.lws_last_kernel_name.restype = C.c_char_p
     lib.lws_stft_frames.argtypes = [ip, ip, ip, ip]
     lib.lws_istft_length.argtypes = [ip, ip, ip, ip]

@@ -389,6 +389,34 @@ int lws_hip_version(void) { return 100; }  // 0.1.0
 
 const char *lws_last_error(void) { return g_err.c_str(); }
 
+typedef float vec4f __attribute__((ext_vector_type(4)));
+// one workgroup moves 4 x 256 x 16 B with non-temporal accesses; no grid-stride loop -- measured 6.0-6.5 TB/s on MI355X
+// against 4.4-4.9 TB/s for a grid-stride loop and 5.0 TB/s for hipMemcpyDtoD (scratch/copy_ubench.hip)
+__global__ void k_stream_copy(vec4f *__restrict__ dst, const vec4f *__restrict__ src, size_t n) {
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    vec4f v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < n) v[u] = __builtin_nontemporal_load(src + base + u * 256);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < n) __builtin_nontemporal_store(v[u], dst + base + u * 256);
+}
+
+int lws_stream_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stream) {
+    if (!dst_dev || !src_dev || (bytes & 15)) {
+        return lws::set_error(LWS_ERR_INVALID, "lws_stream_copy: null pointer or size not a multiple of 16");
+    }
+    if (bytes == 0) return LWS_OK;
+    const size_t n = bytes / 16;
+    const size_t blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (vec4f *)dst_dev, (const vec4f *)src_dev, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lws::set_error(LWS_ERR_HIP, "lws_stream_copy: %s", hipGetErrorString(e));
+    return LWS_OK;
+}
+
 int lws_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -61,3 +61,17 @@ def test_unsupported_frame_sizes_raise():
     p = lws_amd.lws(48, 16)                      # not a power of two
     with pytest.raises(lws_amd.LwsHipError):
         p.get_consistency_dev(np.ones((5, 25), complex))
+
+
+@pytest.mark.gpu
+def test_stream_copy_probe():
+    """lws_stream_copy (the bench's measured-copy-peak kernel) copies exactly and rejects ragged sizes."""
+    import torch
+    from lws_amd import _capi
+    lib = _capi.load()
+    src = torch.randint(0, 255, (1 << 20,), dtype=torch.uint8, device="cuda")
+    dst = torch.zeros_like(src)
+    assert lib.lws_stream_copy(dst.data_ptr(), src.data_ptr(), src.numel(), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    assert lib.lws_stream_copy(dst.data_ptr(), src.data_ptr(), 24, None) == _capi.LWS_ERR_INVALID
