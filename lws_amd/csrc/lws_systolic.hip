@@ -550,9 +550,8 @@ __device__ __forceinline__ float2 csub(float2 p, float2 q) { return ff(pk_sub(vv
 
 // Contribution of the centre frame (W[.,0,k] does not depend on bin % Q) to the bin at phase PH / clock PB.
 template <int L, uint32_t MASK, int PH, int PB>
-__device__ __forceinline__ float2 centre_sum(const SysArgs &a, const LaneCtx &cx, bool st, bool en, float2 self_old,
-                                             float2 next_old, float2 prev_out) {
-    float2 acc = make_float2(0.f, 0.f);
+__device__ __forceinline__ void centre_sum(const SysArgs &a, const LaneCtx &cx, bool st, bool en, float2 self_old,
+                                           float2 next_old, float2 prev_out, float2 &acc) {
     static_for<L>([&](auto ik) {
         constexpr int k = decltype(ik)::value + 1;
         if constexpr ((MASK >> k) & 1u) {
@@ -571,7 +570,6 @@ __device__ __forceinline__ float2 centre_sum(const SysArgs &a, const LaneCtx &cx
             pair_rot<0>(acc, a.w[k], lo, hi);
         }
     });
-    return acc;
 }
 
 // Structure flags carried in the top bits of the MASK template word (the tap mask itself needs Q*(L+1) <= 24 bits)
@@ -585,13 +583,13 @@ template <int L> struct R13Partials { float2 b[L + 1], c[L + 1]; };
 
 // Contribution of frames m-R and m+R to the bin at phase PH; OFFS = 0 / 1: first / second bin of the pair
 template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS>
-__device__ __forceinline__ float2 rows_sum(const SysArgs &a, const float2 (&tu)[2 * L + 2], const float2 (&td)[2 * L + 2],
-                                           R13Partials<L> &p3) {
+__device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[2 * L + 2], const float2 (&td)[2 * L + 2],
+                                         R13Partials<L> &p3, float2 &accr) {
     constexpr int K1 = L + 1;
     constexpr int mod = PH % Q;
     constexpr int rot = ((mod * R) % Q) * (4 / Q);  // quarter turns of exp(2j*pi*mod*R/Q)
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
-    float2 accr = make_float2(0.f, 0.f);
+    // accr: the bin's running sum (every group of taps is added to it directly: no partial sums to zero and combine)
     if constexpr ((MASK >> (R * K1)) & 1u) {
         if constexpr ((MASK & FLAG_K0REAL) != 0) pair_rot_real<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
         else pair_rot<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
@@ -624,7 +622,6 @@ __device__ __forceinline__ float2 rows_sum(const SysArgs &a, const float2 (&tu)[
             }
         }
     });
-    return accr;
 }
 
 // Magnitude re-projection (lwslib.cpp:356-360): keep the old value unless the bin is active and the sum is
@@ -672,7 +669,8 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
 #define LWS_DBG_NOSEL 0      // timing experiment: row taps never use the image lanes (results invalid)
 #endif
     constexpr bool CP = !LWS_DBG_NOCPATCH;
-    float2 accA = centre_sum<L, MASK, PA, PA>(a, cx, CP && stA, CP && enA, cr.o0, cr.o1, cr.prev_out);
+    float2 accA = make_float2(0.f, 0.f);
+    centre_sum<L, MASK, PA, PA>(a, cx, CP && stA, CP && enA, cr.o0, cr.o1, cr.prev_out, accA);
     float2 accB = make_float2(0.f, 0.f);
     // frame pairs m-+R.  With FLAG_R13 rows 3 leave partial sums for rows 1: order 2, 3, 1 keeps them short-lived.
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
@@ -688,20 +686,20 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             float2 tu[2 * L + 2], td[2 * L + 2];
             load_row2<PA, -R, L, kmask, 0>(cx, stA, enA, tu);
             load_row2<PA, R, L, kmask, 0>(cx, stA, enA, td);
-            accA = cadd(accA, rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A));
-            accB = cadd(accB, rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B));
+            rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
+            rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
         } else {
             {
                 float2 tu[2 * L + 2], td[2 * L + 2];
                 load_row2<PA, -R, L, kmask, 1>(cx, false, enA, tu);
                 load_row2<PA, R, L, kmask, 1>(cx, false, enA, td);
-                accA = cadd(accA, rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A));
+                rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
             }
             {
                 float2 tu[2 * L + 2], td[2 * L + 2];
                 load_row2<PA, -R, L, kmask, 2>(cx, stB, false, tu);
                 load_row2<PA, R, L, kmask, 2>(cx, stB, false, td);
-                accB = cadd(accB, rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B));
+                rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
             }
         }
     });
@@ -712,7 +710,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     image_publish<L, PA, PA, 1>(cx.uo, stA, enA, cx.dummy, outA);
     if (cx.store) store_l2(state_w_b + (size_t)(vmod + PA) * LANES + lane, outA, MULTI);   // G is a multiple of 8: no wrap inside a block
     // ---- second bin (its centre taps include the first bin's result)
-    accB = cadd(accB, centre_sum<L, MASK, PHB, PBB>(a, cx, CP && stB, CP && enB, cr.o1, cr.o2, outA));
+    centre_sum<L, MASK, PHB, PBB>(a, cx, CP && stB, CP && enB, cr.o1, cr.o2, outA, accB);
     const float tB = wrap ? amp_nxt[0] : amp_cur[PBB & 7];
     const bool liveB = wrap ? cx.nxt_live : cx.live;
     const float2 outB = project(accB, tB, liveB && (tB > (wrap ? cx.nxt_thr : cx.thr)), cr.o1);
@@ -821,13 +819,23 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     }
 }
 
+#ifdef LWS_DBG_TIMING   // timing experiment: clocks each wave of workgroup 0 spends waiting / working (scratch/exp_timing.py)
+__device__ unsigned long long g_dbg_timing[16 * 4];
+#endif
 // MULTI: several workgroups share a spectrogram (a.nwg > 1); the single-workgroup instantiation carries none of it
 template <int Q, int L, uint32_t MASK, bool MULTI>
 __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nwg = MULTI ? a.nwg : 1;
     const int b = MULTI ? blockIdx.x / nwg : blockIdx.x, wg = MULTI ? blockIdx.x - b * nwg : 0;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave: provably uniform
+    // `wave` is the ROLE of a wave (sweep slot 0..NSLOTS-1, or NSLOTS = service), not its hardware index: hardware
+    // waves w and w + 4 share a SIMD and the older one is served first, so the last slot -- the one that also writes
+    // the results back -- takes hardware wave 3 and shares its SIMD with the light service wave (hardware wave 7).
+#ifndef LWS_ROLE_SWAP
+#define LWS_ROLE_SWAP (!LWS_WIDE)
+#endif
+    const int hw_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // provably uniform
+    const int wave = (LWS_ROLE_SWAP && NSLOTS == 7) ? (hw_wave == 3 ? 6 : (hw_wave == 6 ? 3 : hw_wave)) : hw_wave;
     float *thr_eff = reinterpret_cast<float *>(smem + THR_OFF);
     int *meta = reinterpret_cast<int *>(smem + META_OFF);
     const int G = a.G, C = a.C, Kr = a.Kr;
@@ -951,6 +959,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     nxt_bi = block_info(T_START - (slot + 1) * LAG, nxt_bi);
     int vmod = __builtin_amdgcn_readfirstlane((((T_START - (slot + 1) * LAG) % G) + G) % G - 8);   // advanced at the loop head
     int tmod = __builtin_amdgcn_readfirstlane(((T_START % G) + G) % G - 8);
+#ifdef LWS_DBG_TIMING
+    unsigned long long tm_wait = 0, tm_work = 0, tm_pub = 0, tm_pro = 0, tm_mark = __builtin_amdgcn_s_memtime();
+#endif
     for (int t0 = T_START; t0 < t_end; t0 += 8) {
         const int v0 = t0 - (slot + 1) * LAG;  // clock of this sweep slot at phase 0 of the block (multiple of 8)
         // ---- block prologue: where is this lane in this block and in the next one?
@@ -993,7 +1004,13 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         // ---- 4 pairs of bins, phases static
         static_for<4>([&](auto ip) {
             constexpr int PA = 2 * decltype(ip)::value + 1;
+#ifdef LWS_DBG_TIMING
+            { const unsigned long long n = __builtin_amdgcn_s_memtime(); if (PA == 1) tm_pro += n - tm_mark; else tm_pub += n - tm_mark; tm_mark = n; }
+#endif
             flow_wait(lane, t0 + PA, watched);
+#ifdef LWS_DBG_TIMING
+            { const unsigned long long n = __builtin_amdgcn_s_memtime(); tm_wait += n - tm_mark; tm_mark = n; }
+#endif
             if (is_compute) compute_pair<Q, L, MASK, PA, MULTI>(a, cx, lane, vmod, G, cr, amp_cur, amp_nxt, state_w_b);
             if constexpr (PA == 7) {
                 // the block's stores must be visible to the other workgroups before this wave reports the block done
@@ -1046,9 +1063,18 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 amp_cur[PA & 7] = p0.x; amp_nxt[PA & 7] = p0.y;
                 amp_cur[(PA + 1) & 7] = p1.x; amp_nxt[(PA + 1) & 7] = p1.y;
             }
+#ifdef LWS_DBG_TIMING
+            { const unsigned long long n = __builtin_amdgcn_s_memtime(); tm_work += n - tm_mark; tm_mark = n; }
+#endif
             flow_publish(lane, wave, t0 + PA + 2);
         });
     }
+#ifdef LWS_DBG_TIMING
+    if (blockIdx.x == 0 && lane == 0) {
+        g_dbg_timing[wave * 4 + 0] = tm_wait; g_dbg_timing[wave * 4 + 1] = tm_work;
+        g_dbg_timing[wave * 4 + 2] = tm_pub; g_dbg_timing[wave * 4 + 3] = tm_pro;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1272,6 +1298,15 @@ template <int Q, int L, uint32_t MASK, bool MULTI> hipError_t launch_km(const Sy
         attr_set = true;
     }
     hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+#ifdef LWS_DBG_TIMING
+    {
+        unsigned long long h[16 * 4];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_timing), sizeof h);
+        for (int w = 0; w <= NSLOTS; ++w)
+            fprintf(stderr, "wave %d: wait %llu work %llu publish+loop %llu prologue %llu\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+    }
+#endif
     return hipGetLastError();
 }
 template <int Q, int L, uint32_t MASK> hipError_t launch_k(const SysArgs &a, int grid, hipStream_t s) {
