@@ -405,13 +405,14 @@ __device__ __forceinline__ void load_row2(const LaneCtx &cx, bool st, bool en, f
             constexpr int m = (-fl) & (NBLK - 1);
             constexpr int within = q - 8 * fl;                   // even
             constexpr int setoff = (DR < 0) ? SET_BYTES : 0;     // frames above: own sweep's set; below: previous sweep's
-            const int real_base = cx.ob[m] + (HALO + DR) * LANE_B;
-            int base = real_base;
+            // one select per (frame, ring block): the pseudo-lane's origin is wave-uniform (a scalar operand of the select)
+            // and everything else is the instruction's immediate offset
+            int base = cx.ob[m];
 #if !LWS_DBG_NOSEL
-            if constexpr (img_lo) base = st ? cx.uo[m] + PLL * LANE_B : real_base;
-            if constexpr (img_hi) base = en ? cx.uo[m] + PLR * LANE_B : real_base;
+            if constexpr (img_lo) base = st ? cx.uo[m] + (PLL - HALO - DR) * LANE_B : cx.ob[m];
+            if constexpr (img_hi) base = en ? cx.uo[m] + (PLR - HALO - DR) * LANE_B : cx.ob[m];
 #endif
-            const int addr = base + setoff + (within >> 1) * PAIR_BYTES;
+            const int addr = base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES;
             if constexpr (need0 && need1) {
                 const v4f v = lds_read128(addr);
                 t[j] = make_float2(v.x, v.y);
