@@ -626,8 +626,8 @@ __device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[2 
 }
 
 // Magnitude re-projection (lwslib.cpp:356-360): keep the old value unless the bin is active and the sum is
-// non-zero.  target/|acc| is evaluated as target * rsqrt(|acc|^2) with one Newton step on the hardware
-// reciprocal square root (relative error < 2^-22, the size of the two roundings of sqrt-then-divide);
+// non-zero.  target/|acc| is evaluated as target * rsqrt(|acc|^2) with the hardware reciprocal square root (1 ulp:
+// the new magnitude is within 3e-7 relative of the target, tests/test_gpu_parity.py checks 1e-6);
 // sums too small to square in fp32 are rescaled first, so "|acc| > 0" keeps the reference's meaning.
 __device__ __forceinline__ float2 project(float2 acc, float target, bool active, float2 old) {
 #ifdef LWS_DBG_NOPROJECT   // timing experiment: no re-projection (results invalid)
@@ -639,7 +639,9 @@ __device__ __forceinline__ float2 project(float2 acc, float target, bool active,
     m2 = tiny ? ax * ax + ay * ay : m2;
     const bool ok = active && (m2 > 0.f);
     float r = __frsqrt_rn(m2);
+#ifdef LWS_PROJECT_NEWTON   // one Newton step on the reciprocal square root: 3 more dependent operations per bin (1.2 ms per pass)
     r = r * fmaf(-0.5f * m2 * r, r, 1.5f);
+#endif
     const float sc = target * r;
     return ok ? make_float2(ax * sc, ay * sc) : old;
 }
