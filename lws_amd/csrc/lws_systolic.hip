@@ -627,16 +627,16 @@ __device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[2 
 
 // Magnitude re-projection (lwslib.cpp:356-360): keep the old value unless the bin is active and the sum is
 // non-zero.  target/|acc| is evaluated as target * rsqrt(|acc|^2) with the hardware reciprocal square root (1 ulp:
-// the new magnitude is within 3e-7 relative of the target, tests/test_gpu_parity.py checks 1e-6);
-// sums too small to square in fp32 are rescaled first, so "|acc| > 0" keeps the reference's meaning.
+// the new magnitude is within 3e-7 relative of the target, tests/test_gpu_parity.py checks 1e-6).
 __device__ __forceinline__ float2 project(float2 acc, float target, bool active, float2 old) {
 #ifdef LWS_DBG_NOPROJECT   // timing experiment: no re-projection (results invalid)
     return active ? make_float2(acc.x * target, acc.y * target) : old;
 #endif
-    float m2 = acc.x * acc.x + acc.y * acc.y;
-    const bool tiny = m2 < 1e-30f;
-    const float ax = tiny ? acc.x * 0x1p60f : acc.x, ay = tiny ? acc.y * 0x1p60f : acc.y;
-    m2 = tiny ? ax * ax + ay * ay : m2;
+    // sums too small to square in fp32 are scaled up first (by a power of two: exact), so "|acc| > 0" keeps the
+    // reference's meaning; the scale is chosen on |x| + |y|, before anything is squared
+    const float sel = (fabsf(acc.x) + fabsf(acc.y) < 1e-15f) ? 0x1p60f : 1.0f;
+    const float ax = acc.x * sel, ay = acc.y * sel;
+    const float m2 = ax * ax + ay * ay;
     const bool ok = active && (m2 > 0.f);
     float r = __frsqrt_rn(m2);
 #ifdef LWS_PROJECT_NEWTON   // one Newton step on the reciprocal square root: 3 more dependent operations per bin (1.2 ms per pass)
