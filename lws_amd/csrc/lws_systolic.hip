@@ -536,14 +536,69 @@ template <int ROT> __device__ __forceinline__ void quad_rot(float2 &a, wp_t w, f
     else LWS_QUAD_ASM(LWS_NEG2, LWS_M1_3, LWS_M2_3);
     a = ff(acc);
 }
+// Frames m-+1 and m-+3 sharing one weight (FLAG_R13): b = um +- dp, c = dm +- up, then B = p3b j^RB + b,
+// C = p3c j^-RB + c, then acc += w j^ROT B + conj(w j^ROT) C -- eight instructions in ONE statement: the compiler puts a
+// wait state in front of every asm statement that reads the register the previous instruction wrote, and every
+// instruction of a wave costs an issue slot whatever it does.
+#define LWS_ROTX_0 ""
+#define LWS_ROTX_1 " op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]"
+#define LWS_ROTX_2 " neg_lo:[1,0] neg_hi:[1,0]"
+#define LWS_ROTX_3 " op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]"
+#define LWS_R13_ASM(SG, RB, RC, M1, M2)                                                                  \
+    asm("v_pk_add_f32 %[b], %[um], %[dp]" SG "\n\t"                                                       \
+        "v_pk_add_f32 %[c], %[dm], %[up]" SG "\n\t"                                                       \
+        "v_pk_add_f32 %[b], %[pb], %[b]" RB "\n\t"                                                        \
+        "v_pk_add_f32 %[c], %[pc], %[c]" RC "\n\t"                                                        \
+        "v_pk_add_f32 %[s], %[b], %[c]\n\t"                                                               \
+        "v_pk_add_f32 %[b], %[b], %[c]" LWS_NEG2 "\n\t"                                                   \
+        "v_pk_fma_f32 %[a], %[w], %[s], %[a] " M1 "\n\t"                                                  \
+        "v_pk_fma_f32 %[a], %[w], %[b], %[a] " M2                                                          \
+        : [a] "+v"(acc), [b] "=&v"(t0), [c] "=&v"(t1), [s] "=&v"(t2)                                       \
+        : [w] "s"(w), [um] "v"(vum), [up] "v"(vup), [dm] "v"(vdm), [dp] "v"(vdp), [pb] "v"(vpb), [pc] "v"(vpc))
+#define LWS_R13_ROT(SG, M1, M2)                                                                          \
+    do {                                                                                                 \
+        if constexpr (RB == 0) LWS_R13_ASM(SG, LWS_ROTX_0, LWS_ROTX_0, M1, M2);                          \
+        else if constexpr (RB == 1) LWS_R13_ASM(SG, LWS_ROTX_1, LWS_ROTX_3, M1, M2);                     \
+        else if constexpr (RB == 2) LWS_R13_ASM(SG, LWS_ROTX_2, LWS_ROTX_2, M1, M2);                     \
+        else LWS_R13_ASM(SG, LWS_ROTX_3, LWS_ROTX_1, M1, M2);                                            \
+    } while (0)
+template <int ROT, int RB_>
+__device__ __forceinline__ void r13_rot(float2 &a, wp_t w, float2 um, float2 up, float2 dm, float2 dp, float2 pb, float2 pc) {
+    v2f acc = vv(a), t0, t1, t2;
+    const v2f vum = vv(um), vup = vv(up), vdm = vv(dm), vdp = vv(dp), vpb = vv(pb), vpc = vv(pc);
+    constexpr int R = ROT & 3, RB = RB_ & 3;
+    if constexpr (R == 0) LWS_R13_ROT("", LWS_M1_0, LWS_M2_0);
+    else if constexpr (R == 1) LWS_R13_ROT(LWS_NEG2, LWS_M1_1, LWS_M2_1);
+    else if constexpr (R == 2) LWS_R13_ROT("", LWS_M1_2, LWS_M2_2);
+    else LWS_R13_ROT(LWS_NEG2, LWS_M1_3, LWS_M2_3);
+    a = ff(acc);
+}
+// b = um +- dp, c = dm +- up (the partial sums rows 3 leave for rows 1) in one statement
+template <int ODD> __device__ __forceinline__ void bc_pair(float2 &b, float2 &c, float2 um, float2 up, float2 dm, float2 dp) {
+    v2f vb, vc;
+    const v2f vum = vv(um), vup = vv(up), vdm = vv(dm), vdp = vv(dp);
+    if constexpr (ODD)
+        asm("v_pk_add_f32 %0, %2, %3" LWS_NEG2 "\n\tv_pk_add_f32 %1, %4, %5" LWS_NEG2 : "=&v"(vb), "=&v"(vc) : "v"(vum), "v"(vdp), "v"(vdm), "v"(vup));
+    else
+        asm("v_pk_add_f32 %0, %2, %3\n\tv_pk_add_f32 %1, %4, %5" : "=&v"(vb), "=&v"(vc) : "v"(vum), "v"(vdp), "v"(vdm), "v"(vup));
+    b = ff(vb);
+    c = ff(vc);
+}
 // the same for a weight whose imaginary part is exactly zero (W[0][r][0] of symmetric windows): half the work
+#define LWS_REAL_ASM(SG, M)                                                                              \
+    asm("v_pk_add_f32 %[t], %[b], %[c]" SG "\n\t"                                                         \
+        "v_pk_fma_f32 %[a], %[w], %[t], %[a] " M                                                           \
+        : [a] "+v"(acc), [t] "=&v"(t0)                                                                     \
+        : [w] "s"(w), [b] "v"(vb), [c] "v"(vc))
 template <int ROT> __device__ __forceinline__ void pair_rot_real(float2 &a, wp_t w, float2 b, float2 c) {
     constexpr int R = ROT & 3;
-    v2f acc = vv(a);
-    if constexpr (R == 0) acc = pk_fma_w<0, 0, 0, 0>(acc, w, vv(b) + vv(c));
-    else if constexpr (R == 1) acc = pk_fma_w<0, 1, 1, 0>(acc, w, pk_sub(vv(b), vv(c)));
-    else if constexpr (R == 2) acc = pk_fma_w<0, 0, 1, 1>(acc, w, vv(b) + vv(c));
-    else acc = pk_fma_w<0, 1, 0, 1>(acc, w, pk_sub(vv(b), vv(c)));
+    v2f acc = vv(a), t0;
+    const v2f vb = vv(b), vc = vv(c);
+    // (wr, 0) j^ROT: p (b + c) for even ROT, q j (b - c) for odd ROT -- the first / second multiply-add of pair_rot
+    if constexpr (R == 0) LWS_REAL_ASM("", LWS_M1_0);
+    else if constexpr (R == 1) LWS_REAL_ASM(LWS_NEG2, LWS_M2_1);
+    else if constexpr (R == 2) LWS_REAL_ASM("", LWS_M1_2);
+    else LWS_REAL_ASM(LWS_NEG2, LWS_M2_3);
     a = ff(acc);
 }
 __device__ __forceinline__ float2 cadd(float2 p, float2 q) { return ff(vv(p) + vv(q)); }
@@ -606,19 +661,15 @@ __device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[2 
                 quad_rot<rot>(accr, w, um, up, dm, dp);
                 return;
             }
-            float2 b, c;
-            if constexpr ((rot & 1) == 0) { b = cadd(um, dp); c = cadd(dm, up); }
-            else { b = csub(um, dp); c = csub(dm, up); }
             if constexpr (r13 && R == 3 && k >= 2) {
-                p3.b[k] = b;      // rotated when rows 1 pick them up
-                p3.c[k] = c;
+                bc_pair<(rot & 1)>(p3.b[k], p3.c[k], um, up, dm, dp);      // rotated when rows 1 pick them up
             } else if constexpr (r13 && R == 1 && k >= 2) {
                 // j^rot1 (B1 + j^(k+rot3-rot1) B3) and j^-rot1 (C1 + j^(rot1-k-rot3) C3): one multiply for both rows
                 constexpr int rot3 = ((mod * 3) % Q) * (4 / Q);
-                const v2f bb = pk_add_rot<(k + rot3 - rot + 8) & 3>(vv(p3.b[k]), vv(b));
-                const v2f cc = pk_add_rot<(rot - k - rot3 + 16) & 3>(vv(p3.c[k]), vv(c));
-                pair_rot<rot>(accr, w, ff(bb), ff(cc));
+                r13_rot<rot, (k + rot3 - rot + 8) & 3>(accr, w, um, up, dm, dp, p3.b[k], p3.c[k]);
             } else {
+                float2 b, c;
+                bc_pair<(rot & 1)>(b, c, um, up, dm, dp);
                 pair_rot<rot>(accr, w, b, c);
             }
         }
