@@ -267,6 +267,10 @@ struct LaneCtx {
     bool is_start, is_end, live, store;          // this block (8 bins of one frame)
     bool nxt_start, nxt_end, nxt_live, nxt_store; // the following block (possibly the next frame of the lane)
     float thr, nxt_thr;
+    // image cells: byte offset from the lane's own origin ob[m] to the pseudo-lane's, minus what the compile-time offset
+    // of the neighbour frame DR adds -- for the lane at the start (lo: PLL) / end (hi: PLR) of its frame; zero for every
+    // other lane.  [DR + 3]; lo_nxt: for the first bin of the following block (second bin of the pair (7, 0'))
+    int wlo[7], whi[7], wlo_nxt[7];
 };
 
 __host__ __device__ constexpr int floor_div8(int q) { return (q >= 0) ? q / 8 : -((-q + 7) / 8); }
@@ -380,7 +384,7 @@ __device__ __forceinline__ float2 tap_any(const LaneCtx &cx, float2 self_old, fl
 // hold the images above Nyquist of the old frame (pseudo-lane PLR) and the first bins of the new one (real lane):
 // MODE 1 fetches bin A's view (en = last bin of a frame), MODE 2 bin B's (st = first bin of a frame).
 template <int PA, int DR, int L, uint32_t KMASK, int MODE>
-__device__ __forceinline__ void load_row2(const LaneCtx &cx, bool st, bool en, float2 (&t)[2 * L + 2]) {
+__device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L + 2]) {
     static_assert((PA & 1) == 1 && (L & 1) == 1, "pairs start on odd phases; L odd");
     static_assert(MODE == 0 || PA == 7, "split views only for the pair that straddles two frames");
     static_assert(LWS_DBG_NOWRAP2 || MODE != 0 || PA != 7, "the straddling pair needs split views");
@@ -405,12 +409,12 @@ __device__ __forceinline__ void load_row2(const LaneCtx &cx, bool st, bool en, f
             constexpr int m = (-fl) & (NBLK - 1);
             constexpr int within = q - 8 * fl;                   // even
             constexpr int setoff = (DR < 0) ? SET_BYTES : 0;     // frames above: own sweep's set; below: previous sweep's
-            // one select per (frame, ring block): the pseudo-lane's origin is wave-uniform (a scalar operand of the select)
-            // and everything else is the instruction's immediate offset
+            // one add per (frame, ring block) for the image cells: the lane's origin plus an offset that is zero except
+            // for the lane at the frame edge (LaneCtx::wlo / whi); everything else is the instruction's immediate offset
             int base = cx.ob[m];
 #if !LWS_DBG_NOSEL
-            if constexpr (img_lo) base = st ? cx.uo[m] + (PLL - HALO - DR) * LANE_B : cx.ob[m];
-            if constexpr (img_hi) base = en ? cx.uo[m] + (PLR - HALO - DR) * LANE_B : cx.ob[m];
+            if constexpr (img_lo) base = cx.ob[m] + (MODE == 2 ? cx.wlo_nxt[DR + 3] : cx.wlo[DR + 3]);
+            if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + 3];
 #endif
             const int addr = base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES;
             if constexpr (need0 && need1) {
@@ -738,21 +742,21 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
 #endif
         if constexpr (!wrap || LWS_DBG_NOWRAP2) {
             float2 tu[2 * L + 2], td[2 * L + 2];
-            load_row2<PA, -R, L, kmask, 0>(cx, stA, enA, tu);
-            load_row2<PA, R, L, kmask, 0>(cx, stA, enA, td);
+            load_row2<PA, -R, L, kmask, 0>(cx, tu);
+            load_row2<PA, R, L, kmask, 0>(cx, td);
             rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
             rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
         } else {
             {
                 float2 tu[2 * L + 2], td[2 * L + 2];
-                load_row2<PA, -R, L, kmask, 1>(cx, false, enA, tu);
-                load_row2<PA, R, L, kmask, 1>(cx, false, enA, td);
+                load_row2<PA, -R, L, kmask, 1>(cx, tu);
+                load_row2<PA, R, L, kmask, 1>(cx, td);
                 rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
             }
             {
                 float2 tu[2 * L + 2], td[2 * L + 2];
-                load_row2<PA, -R, L, kmask, 2>(cx, stB, false, tu);
-                load_row2<PA, R, L, kmask, 2>(cx, stB, false, td);
+                load_row2<PA, -R, L, kmask, 2>(cx, tu);
+                load_row2<PA, R, L, kmask, 2>(cx, td);
                 rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
             }
         }
@@ -1008,6 +1012,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         if (__any(bi.j != prev.j)) bi.thr = thr_eff[bi.j];
         return bi;
     };
+    int dlo[7];   // per-lane constants of the image-cell offsets: (PLL - HALO - DR - lane) * 16
+#pragma unroll
+    for (int d = 0; d < 7; ++d) dlo[d] = (PLL - HALO - (d - 3) - lane) * LANE_B;
     BlockInfo nxt_bi;
     nxt_bi.j = -1; nxt_bi.thr = 0.f; nxt_bi.live = nxt_bi.store = nxt_bi.start = nxt_bi.end = false;
     nxt_bi = block_info(T_START - (slot + 1) * LAG, nxt_bi);
@@ -1034,6 +1041,12 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + lane * 8;
         cx.dummy = DUMMY_OFF + lane * 8;
         cx.halo_shift = (lane < HALO) ? LANES * LANE_B : (lane >= LANES - HALO ? -LANES * LANE_B : 0);
+#pragma unroll
+        for (int d = 0; d < 7; ++d) {   // (only the entries of frames that exist, |DR| <= Q-1, are ever read)
+            cx.wlo[d] = cx.is_start ? dlo[d] : 0;
+            cx.whi[d] = cx.is_end ? dlo[d] + LANE_B : 0;   // PLR = PLL + 1
+            cx.wlo_nxt[d] = cx.nxt_start ? dlo[d] : 0;
+        }
 #pragma unroll
         for (int m = 0; m < NBLK; ++m) {
             const int blk = ((ablk - m) & (NBLK - 1)) * BLK_BYTES;
