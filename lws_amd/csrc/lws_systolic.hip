@@ -257,6 +257,7 @@ __device__ __forceinline__ void flow_publish(int lane, int wave, int s_next) {
 
 // Per-lane registers of a compute lane that stay valid for one block of 8 steps.
 struct LaneCtx {
+    int obh[NBLK];    // [m]: ob[m] + halo_shift: where the halo copy of this lane's output goes (the lane's own entry if it has none)
     int ob[NBLK];     // [m]: LDS address of this lane's halo-shifted origin in the previous sweep's (old) set, block (a - m) & 3;
                       //      the own (new) set is the next one: + SET_BYTES, a compile-time offset
     int uo[NBLK];     // [m]: wave-uniform row origin (set + block) of the old set, for the image pseudo-lanes
@@ -275,22 +276,22 @@ struct LaneCtx {
 
 __host__ __device__ constexpr int floor_div8(int q) { return (q >= 0) ? q / 8 : -((-q + 7) / 8); }
 
-// write a lane's value and, for the first / last HALO lanes, its halo copy at the other end of the row
-// (branch-free: the 58 lanes without a halo copy write to a private dummy slot instead -- an exec-masked branch per
-//  conditional write costs more than the write)
+// write a lane's value and, for the first / last HALO lanes, its halo copy at the other end of the row (branch-free and
+// without per-write address arithmetic: the halo origin obh[] is the lane's own origin shifted by +-64 lanes for those six
+// lanes and unshifted for the others, so both writes use the same immediate offset)
 #ifndef LWS_DBG_NOIMG
 #define LWS_DBG_NOIMG 0     // timing experiment: no halo / image writes (results invalid)
 #endif
 #ifndef LWS_DBG_NOWRAP2
 #define LWS_DBG_NOWRAP2 0   // timing experiment: the straddling pair shares one set of fetches (results invalid)
 #endif
-__device__ __forceinline__ void ring_publish(int addr, int halo_shift, int dummy, float2 v) {
+__device__ __forceinline__ void ring_publish(int addr, int addr_halo, float2 v) {
 #ifdef LWS_DBG_NOPUBLISH   // timing experiment: results are not written to the rings (results invalid)
     return;
 #endif
     lds_write(addr, v);
 #if !LWS_DBG_NOIMG
-    lds_write(halo_shift != 0 ? addr + halo_shift : dummy, v);
+    lds_write(addr_halo, v);   // the halo copy of the first / last HALO lanes; every other lane writes its own entry twice
 #endif
 }
 
@@ -764,7 +765,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     // ---- first bin
     const float tA = amp_cur[PA];
     const float2 outA = project(accA, tA, cx.live && (tA > cx.thr), cr.o0);
-    ring_publish(ring_addr<PA, 0, 0, 1>(cx.ob), cx.halo_shift, cx.dummy, outA);
+    ring_publish(ring_addr<PA, 0, 0, 1>(cx.ob), ring_addr<PA, 0, 0, 1>(cx.obh), outA);
     image_publish<L, PA, PA, 1>(cx.uo, stA, enA, cx.dummy, outA);
     if (cx.store) store_l2(state_w_b + (size_t)(vmod + PA) * LANES + lane, outA, MULTI);   // G is a multiple of 8: no wrap inside a block
     // ---- second bin (its centre taps include the first bin's result)
@@ -772,7 +773,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     const float tB = wrap ? amp_nxt[0] : amp_cur[PBB & 7];
     const bool liveB = wrap ? cx.nxt_live : cx.live;
     const float2 outB = project(accB, tB, liveB && (tB > (wrap ? cx.nxt_thr : cx.thr)), cr.o1);
-    ring_publish(ring_addr<PBB, 0, 0, 1>(cx.ob), cx.halo_shift, cx.dummy, outB);
+    ring_publish(ring_addr<PBB, 0, 0, 1>(cx.ob), ring_addr<PBB, 0, 0, 1>(cx.obh), outB);
     image_publish<L, PHB, PBB, 1>(cx.uo, stB, enB, cx.dummy, outB);
     if (wrap ? cx.nxt_store : cx.store) {
         int ib = vmod + PBB;
@@ -1052,6 +1053,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             const int blk = ((ablk - m) & (NBLK - 1)) * BLK_BYTES;
             cx.uo[m] = set_old + blk;
             cx.ob[m] = set_old + blk + lane * LANE_B;
+            cx.obh[m] = cx.ob[m] + cx.halo_shift;
         }
         vmod += 8; vmod -= (vmod >= G) ? G : 0;   // v0 mod G and t0 mod G (G is a multiple of 8), wave-uniform
         tmod += 8; tmod -= (tmod >= G) ? G : 0;
@@ -1104,19 +1106,20 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                     service_nyquist<Q, L, MASK, MULTI>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
                 // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
                 // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
-                int ldb[NBLK], ldu[NBLK];
+                int ldb[NBLK], ldu[NBLK], ldh[NBLK];
 #pragma unroll
                 for (int m = 0; m < NBLK; ++m) {
                     ldu[m] = (((t0 >> 3) - m) & (NBLK - 1)) * BLK_BYTES;
                     ldb[m] = ldu[m] + lane * LANE_B;
+                    ldh[m] = ldb[m] + cx.halo_shift;
                 }
                 const int cb0 = (t0 - SKEW * lane) & (ROWP - 1), cb1 = (t0 + 8 - SKEW * lane) & (ROWP - 1);
                 const bool l_st = cb0 == 0, l_en = cb0 == C - 8, l_stn = cb1 == 0, l_enn = cb1 == C - 8;
                 const float2 vA = make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]);
                 const float2 vB = make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]);
-                ring_publish(ring_addr<PA, 0>(ldb), cx.halo_shift, cx.dummy, vA);
+                ring_publish(ring_addr<PA, 0>(ldb), ring_addr<PA, 0>(ldh), vA);
                 image_publish<L, PA, PA, 0>(ldu, l_st, l_en, cx.dummy, vA);
-                ring_publish(ring_addr<PA + 1, 0>(ldb), cx.halo_shift, cx.dummy, vB);
+                ring_publish(ring_addr<PA + 1, 0>(ldb), ring_addr<PA + 1, 0>(ldh), vB);
                 image_publish<L, (PA + 1) & 7, PA + 1, 0>(ldu, PA == 7 ? l_stn : l_st, PA == 7 ? l_enn : l_en, cx.dummy, vB);
                 int i0 = tmod + PA + 8, i1 = tmod + PA + 9;
                 i0 -= (i0 >= G) ? G : 0;
