@@ -1260,17 +1260,25 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *st
     float *aw = amp_w + (size_t)b * G * LANES;
     float mx = 0.f;
     double msum = 0.0;                                       // this thread's share of sum |S| over the real frames
-    for (int ml = wave; ml < TILE; ml += 4) {
+    // all of a thread's loads are issued before the first one is used: 16 x 512 bytes in flight per wave
+    float2 vin[TILE / 4];
+#pragma unroll
+    for (int i = 0; i < TILE / 4; ++i) {
+        const int ml = wave + 4 * i;
         const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
-        const bool real_frame = me >= Q - 1 && me < T + Q - 1;
         int src = me - (Q - 1);                                  // edge-pad frames repeat the first / last frame
         src = src < 0 ? 0 : (src > T - 1 ? T - 1 : src);
-        float2 v = make_float2(0.f, 0.f);
+        vin[i] = (me < Tp && c >= 0 && c < C) ? in[((size_t)b * T + src) * F + c] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < TILE / 4; ++i) {
+        const int ml = wave + 4 * i;
+        const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
+        const bool real_frame = me >= Q - 1 && me < T + Q - 1;
+        const float2 v = vin[i];
         float av = 0.f;
-        double mag = 0.0;
         if (me < Tp && c >= 0 && c < C) {
-            v = in[((size_t)b * T + src) * F + c];
-            mag = sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);   // as k_prep: |S| in fp64, then rounded
+            const double mag = sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);   // as k_prep: |S| in fp64, then rounded
             av = (float)mag;
             if (real_frame) { mx = fmaxf(mx, av); msum += mag; }
         }
@@ -1341,10 +1349,15 @@ __global__ void __launch_bounds__(256) k_skew_to_out(float2 *out, const float2 *
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;
     const float2 *sw = state_w + (size_t)b * G * LANES;
-    for (int tl = wave; tl < TILE; tl += 4) {
+    float2 vin[TILE / 4];
+#pragma unroll
+    for (int i = 0; i < TILE / 4; ++i) {           // all loads first
+        const int tl = wave + 4 * i;
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
-        if (me < Tp && c >= 0 && c < C) ts[lane][tl] = sw[(size_t)((tau0 + tl) % G) * LANES + lane];
+        vin[i] = (me < Tp && c >= 0 && c < C) ? sw[(size_t)((tau0 + tl) % G) * LANES + lane] : make_float2(0.f, 0.f);
     }
+#pragma unroll
+    for (int i = 0; i < TILE / 4; ++i) ts[lane][wave + 4 * i] = vin[i];
     __syncthreads();
     for (int ml = wave; ml < TILE; ml += 4) {
         const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
