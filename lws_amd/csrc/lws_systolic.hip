@@ -1169,18 +1169,24 @@ __global__ void __launch_bounds__(256) k_to_skew(const float2 *state, const floa
     float2 *sw = state_w + (size_t)b * G * LANES;
     float *aw = amp_w + (size_t)b * G * LANES;
     float mx = 0.f;
-    for (int ml = wave; ml < TILE; ml += 4) {                // one frame per wave: 64 consecutive bins
+    float2 vin[TILE / 4];
+    float ain[TILE / 4];
+#pragma unroll
+    for (int i = 0; i < TILE / 4; ++i) {                     // one frame per wave: 64 consecutive bins; all loads first
+        const int ml = wave + 4 * i;
         const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;   // tile column = production time - tau0
-        float2 v = make_float2(0.f, 0.f);
-        float av = 0.f;
-        if (me < Tp && c >= 0 && c < C) {
-            const size_t i = ((size_t)b * Tp + me) * Np + L + c;
-            v = state[i];
-            av = amp[i];
-            if (me >= Q - 1 && me < T + Q - 1) mx = fmaxf(mx, av);
-        }
-        ts[ml][lane] = v;
-        ta[ml][lane] = av;
+        const bool in_range = me < Tp && c >= 0 && c < C;
+        const size_t idx = ((size_t)b * Tp + me) * Np + L + c;
+        vin[i] = in_range ? state[idx] : make_float2(0.f, 0.f);
+        ain[i] = in_range ? amp[idx] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TILE / 4; ++i) {
+        const int ml = wave + 4 * i;
+        const int me = LANES * kk + ml;
+        if (me >= Q - 1 && me < T + Q - 1) mx = fmaxf(mx, ain[i]);
+        ts[ml][lane] = vin[i];
+        ta[ml][lane] = ain[i];
     }
     if (tt == 0 && wave == 0) {                              // Nyquist bins of the round's frames
         const int me = LANES * kk + lane;
@@ -1220,10 +1226,15 @@ __global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float2 *
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;
     const float2 *sw = state_w + (size_t)b * G * LANES;
-    for (int tl = wave; tl < TILE; tl += 4) {
+    float2 vin[TILE / 4];
+#pragma unroll
+    for (int i = 0; i < TILE / 4; ++i) {           // all loads first
+        const int tl = wave + 4 * i;
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
-        if (me < Tp && c >= 0 && c < C) ts[lane][tl] = sw[(size_t)((tau0 + tl) % G) * LANES + lane];
+        vin[i] = (me < Tp && c >= 0 && c < C) ? sw[(size_t)((tau0 + tl) % G) * LANES + lane] : make_float2(0.f, 0.f);
     }
+#pragma unroll
+    for (int i = 0; i < TILE / 4; ++i) ts[lane][wave + 4 * i] = vin[i];
     __syncthreads();
     for (int ml = wave; ml < TILE; ml += 4) {
         const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
