@@ -767,7 +767,6 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     const float2 outA = project(accA, tA, cx.live && (tA > cx.thr), cr.o0);
     ring_publish(ring_addr<PA, 0, 0, 1>(cx.ob), ring_addr<PA, 0, 0, 1>(cx.obh), outA);
     image_publish<L, PA, PA, 1>(cx.uo, stA, enA, cx.dummy, outA);
-    if (cx.store) store_l2(state_w_b + (size_t)(vmod + PA) * LANES + lane, outA, MULTI);   // G is a multiple of 8: no wrap inside a block
     // ---- second bin (its centre taps include the first bin's result)
     centre_sum<L, MASK, PHB, PBB>(a, cx, CP && stB, CP && enB, cr.o1, cr.o2, outA, accB);
     const float tB = wrap ? amp_nxt[0] : amp_cur[PBB & 7];
@@ -775,11 +774,6 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     const float2 outB = project(accB, tB, liveB && (tB > (wrap ? cx.nxt_thr : cx.thr)), cr.o1);
     ring_publish(ring_addr<PBB, 0, 0, 1>(cx.ob), ring_addr<PBB, 0, 0, 1>(cx.obh), outB);
     image_publish<L, PHB, PBB, 1>(cx.uo, stB, enB, cx.dummy, outB);
-    if (wrap ? cx.nxt_store : cx.store) {
-        int ib = vmod + PBB;
-        ib -= (ib >= G) ? G : 0;
-        store_l2(state_w_b + (size_t)ib * LANES + lane, outB, MULTI);
-    }
     cr.prev_out = outB;
     cr.o0 = cr.o2;
     cr.o1 = o3;
@@ -870,7 +864,8 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         const float2 out = project(acc, target, active, old);
         lds_write(nn[0], out);
         lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, out);   // bin C of the image lane: production time = this clock
-        if (valid && (slot == NSLOTS - 1 || j == n_eff - 1)) store_l2(state_nyq_b + me, out, MULTI);
+        // (the last slot stores whatever reaches it: idle slots of the last group pass the final values on)
+        if ((slot == NSLOTS - 1) && (v0 - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2(state_nyq_b + me, out, MULTI);
         // target magnitude of the next block's Nyquist bin
         const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
@@ -888,13 +883,15 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const int nwg = MULTI ? a.nwg : 1;
     const int b = MULTI ? blockIdx.x / nwg : blockIdx.x, wg = MULTI ? blockIdx.x - b * nwg : 0;
     // `wave` is the ROLE of a wave (sweep slot 0..NSLOTS-1, or NSLOTS = service), not its hardware index: hardware
-    // waves w and w + 4 share a SIMD and the older one is served first, so the last slot -- the one that also writes
-    // the results back -- takes hardware wave 3 and shares its SIMD with the light service wave (hardware wave 7).
+    // waves w and w + 4 share a SIMD and the older one is served first.  Every sweep slot meets the service wave at every
+    // pair of bins (it feeds slot 0, computes the Nyquist bins and writes the results back), so the service wave takes
+    // hardware wave 3 and is never kept waiting for issue slots; the slot that gives up that place runs on hardware wave 7,
+    // beside it, where the service wave's light instruction stream leaves most of the SIMD free.
 #ifndef LWS_ROLE_SWAP
 #define LWS_ROLE_SWAP (!LWS_WIDE)
 #endif
     const int hw_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // provably uniform
-    const int wave = (LWS_ROLE_SWAP && NSLOTS == 7) ? (hw_wave == 3 ? 6 : (hw_wave == 6 ? 3 : hw_wave)) : hw_wave;
+    const int wave = (LWS_ROLE_SWAP && NSLOTS == 7) ? (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave)) : hw_wave;
     float *thr_eff = reinterpret_cast<float *>(smem + THR_OFF);
     int *meta = reinterpret_cast<int *>(smem + META_OFF);
     const int G = a.G, C = a.C, Kr = a.Kr;
@@ -969,6 +966,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     float amp_cur[8], amp_nxt[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) amp_cur[i] = amp_nxt[i] = 0.f;
+    bool wb_cur = false, wb_prev = false;   // service wave: does the last slot's lane have a bin to write back in this / the previous block
     ServiceState sv;
     sv.nyq_amp_next = 0.f;
     sv.nyq_in_next = make_float2(0.f, 0.f);
@@ -1005,7 +1003,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         const int j = (gl * nwg + wg) * NSLOTS + slot;
         const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
         bi.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
-        bi.store = valid && (cbase < C) && (slot == NSLOTS - 1 || j == n_eff - 1);
+        // the last slot writes back whatever reaches it: in the last, partial group of sweeps the idle slots pass the
+        // final values on unchanged (an idle lane re-publishes the previous sweep's value)
+        bi.store = is_compute && (slot == NSLOTS - 1) && (vv >= 0) && (me < a.Tp) && (cbase < C) && (gl * nwg + wg < n_groups);
         bi.start = (cbase == 0);
         bi.end = (cbase == C - 8);
         bi.j = valid ? j : 0;
@@ -1081,16 +1081,12 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             { const unsigned long long n = __builtin_amdgcn_s_memtime(); tm_wait += n - tm_mark; tm_mark = n; }
 #endif
             if (is_compute) compute_pair<Q, L, MASK, PA, MULTI>(a, cx, lane, vmod, G, cr, amp_cur, amp_nxt, state_w_b);
-            if constexpr (PA == 7) {
-                // the block's stores must be visible to the other workgroups before this wave reports the block done
-                if constexpr (MULTI) { if (is_compute) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            }
             if constexpr (PA == 1 && MULTI) {
                 if (is_service) {
-                    // every slot has finished the previous block (flow_wait above) and fenced its stores; so have the
-                    // Nyquist lanes of this wave (program order + the release below): rows below the last slot's clock
-                    const int done_rows = t0 - NSLOTS * LAG;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Nyquist stores of the previous block
+                    // every slot has finished the previous block (flow_wait above); this wave has written back what the last
+                    // slot produced up to 3 steps before that, and its Nyquist bins (program order + the wait below)
+                    const int done_rows = t0 - NSLOTS * LAG - 8;       // (the write-back below trails the last slot by 2..3 steps)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of the previous block
                     if (done_rows > 0 && lane == 0)
                         __hip_atomic_store(my_progress, (unsigned)done_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     wait_rows(t0 + 16 + 40);   // the loader fetches up to row t0 + 16 in this block, the Nyquist loader a frame ahead
@@ -1121,6 +1117,28 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 image_publish<L, PA, PA, 0>(ldu, l_st, l_en, cx.dummy, vA);
                 ring_publish(ring_addr<PA + 1, 0>(ldb), ring_addr<PA + 1, 0>(ldh), vB);
                 image_publish<L, (PA + 1) & 7, PA + 1, 0>(ldu, PA == 7 ? l_stn : l_st, PA == 7 ? l_enn : l_en, cx.dummy, vB);
+                // write-back: the two values the last sweep slot produced at steps t0+PA-3 and t0+PA-2 (one ring cell of its
+                // output set; complete, every slot has finished the previous pair) go to the rows of its clock.  Done
+                // here, by the wave with time to spare, so that the sweep slots carry no store and no branch around one.
+                {
+                    if constexpr (PA == 1) {   // where the last slot's lanes are in this block of its clock
+                        wb_prev = wb_cur;
+                        const int vv = t0 - NSLOTS * LAG - SKEW * lane;
+                        const int kap = vv >> ROWP_SHIFT;
+                        const int gl = (int)(((float)kap + 0.5f) * inv_kr), k = kap - gl * Kr;
+                        wb_cur = (vv >= 0) && ((vv & (ROWP - 1)) < C) && (k * LANES + lane < a.Tp) && (gl * nwg + wg < n_groups);
+                    }
+                    const v4f w = lds_read128(ring_addr<PA, -3>(ldb) + NSLOTS * SET_BYTES);
+                    int r0 = tmod + PA - 3 - NSLOTS * LAG;
+                    r0 += (r0 < 0) ? G : 0;
+                    r0 += (r0 < 0) ? G : 0;        // (G >= 512 > NSLOTS * LAG / 2)
+                    int r1 = r0 + 1;
+                    r1 -= (r1 >= G) ? G : 0;
+                    if (PA == 1 ? wb_prev : wb_cur) {
+                        store_l2(state_w_b + (size_t)r0 * LANES + lane, make_float2(w.x, w.y), MULTI);
+                        store_l2(state_w_b + (size_t)r1 * LANES + lane, make_float2(w.z, w.w), MULTI);
+                    }
+                }
                 int i0 = tmod + PA + 8, i1 = tmod + PA + 9;
                 i0 -= (i0 >= G) ? G : 0;
                 i1 -= (i1 >= G) ? G : 0;
