@@ -970,7 +970,6 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 
     const bool is_compute = wave < NSLOTS;
     const bool is_service = (wave == NSLOTS);
-    if (is_service) LWS_SETPRIO(3);
     const int slot = wave;
     LaneCtx cx;
     Carry cr;
@@ -1109,6 +1108,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 }
             }
             if (is_service) {
+                LWS_SETPRIO(3);   // (and back to 0 with everybody else after the publish below)
                 // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
 #ifndef LWS_DBG_NONYQ   // timing experiment: no Nyquist bins (results invalid)
                 if constexpr (PA == 1)
@@ -1171,7 +1171,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             { const unsigned long long n = __builtin_amdgcn_s_memtime(); tm_work += n - tm_mark; tm_mark = n; }
 #endif
             flow_publish(lane, wave, t0 + PA + 2);
-            if (is_compute) LWS_SETPRIO(0);   // polling for the next pair must not take issue slots from the wave still working
+            LWS_SETPRIO(0);   // polling for the next pair must not take issue slots from the wave still working
         });
     }
 #ifdef LWS_DBG_TIMING
