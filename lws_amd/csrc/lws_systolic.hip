@@ -1,8 +1,9 @@
 // lws_systolic.hip -- the fast path for batch LWS (LWSQ2 / LWSQ4 / LWSanyQ, lwslib.cpp:72-373) on
 // gfx950: an order-exact *systolic* re-statement of the in-place Gauss-Seidel sweep.
 //
-// One workgroup (8 waves = 2 per SIMD; the last one also carries the service duties: HBM loader and the Nyquist
-// bins) owns one spectrogram and keeps I = 8 consecutive sweeps in flight.  A lane is a (sweep, frame) processor that marches along the bins of its frame,
+// One workgroup (8 waves = 2 per SIMD: 7 sweep slots and a service wave that loads from HBM, computes the Nyquist
+// bins and writes the results back) owns one spectrogram and keeps I = 7 consecutive sweeps in flight.  A lane is a
+// (sweep, frame) processor that marches along the bins of its frame,
 // one bin per step; the 64 lanes of compute wave i work on 64 consecutive frames of sweep
 // "iteration g*I + i", frame m trailing frame m-1 by SKEW = 8 bins, and sweep j+1 trailing sweep j
 // by LAG = 32 steps:
@@ -26,9 +27,9 @@
 // time-skewed global layout  state_w[(8m + c) mod G][m mod 64]  in which every access of a wave is
 // 64 consecutive elements.
 //
-// Frequency edges: Hermitian images below DC / above Nyquist are never stored; the one lane of a wave
-// that is within L bins of a frame edge re-reads the image taps from the mirrored bin (conjugated)
-// under its own exec mask.  The Nyquist bin (bin F-1) does not fit the 512-step frame period and is
+// Frequency edges: the Hermitian images below DC / above Nyquist live in two pseudo-lanes of every ring row, written
+// (conjugated) by the lane that produces the mirrored bin; the one lane of a wave that is within L bins of a frame
+// edge reads its image taps there.  The Nyquist bin (bin F-1) does not fit the 512-step frame period and is
 // computed by the service wave (one lane per sweep in flight), which also runs the loader.
 //
 // Scope of this kernel: summarised weights with the twiddle structure create_weights produces
