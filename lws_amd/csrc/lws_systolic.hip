@@ -97,7 +97,9 @@ constexpr int MAX_ITERS = 440;
 constexpr int META_OFF = THR_OFF + MAX_ITERS * 4;        // n_eff
 constexpr int DONE_OFF = META_OFF + 16;               // per-wave count of completed steps (flow control)
 constexpr int DUMMY_OFF = DONE_OFF + 64;               // 64 x 8 B: where predicated-off lanes park their conditional writes
-constexpr int LDS_BYTES = DUMMY_OFF + LANES * 8;
+constexpr int SCRATCH_OFF = DUMMY_OFF + LANES * 8;     // where the compute lanes that have no image to publish store instead (see image_base)
+constexpr int SCRATCH_BYTES = 4 * PAIR_BYTES + LANES * 8;
+constexpr int LDS_BYTES = SCRATCH_OFF + SCRATCH_BYTES;
 constexpr int SKEW = LWS_WIDE ? 16 : 8, ROWP = SKEW * LANES, LAG = RING;
 constexpr int ROWP_SHIFT = LWS_WIDE ? 10 : 9;
 static_assert((1 << ROWP_SHIFT) == ROWP, "frame period");
@@ -273,6 +275,8 @@ struct LaneCtx {
     // of the neighbour frame DR adds -- for the lane at the start (lo: PLL) / end (hi: PLR) of its frame; zero for every
     // other lane.  [DR + 3]; lo_nxt: for the first bin of the following block (second bin of the pair (7, 0'))
     int wlo[7], whi[7], wlo_nxt[7];
+    int img_lo, img_hi, img_both;   // image_base(): row origin for the image stores of this block (phases with an image below DC / above
+                                    // Nyquist / both)
 };
 
 __host__ __device__ constexpr int floor_div8(int q) { return (q >= 0) ? q / 8 : -((-q + 7) / 8); }
@@ -336,6 +340,29 @@ __device__ __forceinline__ void image_publish(const int (&u)[NBLK], bool st, boo
     } else if constexpr (hi) {
         lds_write(en ? ring_addr_abs<PB, 2 * (8 - PH), PLR, NEWSET>(u) : dummy, cj(out));
     }
+}
+
+// The same store for the compute lanes without any per-store address arithmetic.  The image of the bin produced at phase PH
+// goes to production time PH - 2 PH (below DC, pseudo-lane PLL) or PH + 2 (8 - PH) (above Nyquist, pseudo-lane PLR):
+// 16 steps = two ring blocks apart, at the same position inside the block.  So both addresses are "row origin + the
+// same compile-time offset", and the row origin -- chosen once per block and lane -- says which one it is: the block of
+// the low image for a lane at the start of its frame, the block of the high image (+ one lane) for a lane at its end,
+// a scratch area for everybody else.
+template <int L> struct ImageBlocks {
+    static constexpr int m_lo = (-floor_div8(-1)) & (NBLK - 1), m_hi = (-floor_div8(15)) & (NBLK - 1);
+    static_assert(L <= 7, "images within one block of the frame edge");
+};
+template <int PH, int NEWSET> __host__ __device__ constexpr int image_off() {   // offset of phase PH's image from its row origin
+    constexpr int within = 8 - PH;
+    return NEWSET * SET_BYTES + PLL * LANE_B + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
+}
+template <int L, int PH, int NEWSET>
+__device__ __forceinline__ void image_store(int base_lo, int base_hi, int base_both, float2 out) {
+#if LWS_DBG_NOIMG
+    return;
+#endif
+    constexpr bool lo = (PH >= 1 && PH <= L), hi = (PH >= 8 - L && PH <= 7);
+    if constexpr (lo || hi) lds_write((lo && hi ? base_both : (lo ? base_lo : base_hi)) + image_off<PH, NEWSET>(), cj(out));
 }
 
 template <int PH, int DR, int DK, int EDGE> __host__ __device__ constexpr Src tap_src() {
@@ -782,14 +809,14 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     const float tA = amp_cur[PA];
     const float2 outA = project(accA, tA, cx.live && (tA > cx.thr), cr.o0);
     ring_publish(ring_addr<PA, 0, 0, 1>(cx.ob), ring_addr<PA, 0, 0, 1>(cx.obh), outA);
-    image_publish<L, PA, PA, 1>(cx.uo, stA, enA, cx.dummy, outA);
+    image_store<L, PA, 1>(cx.img_lo, cx.img_hi, cx.img_both, outA);
     // ---- second bin (its centre taps include the first bin's result)
     centre_sum<L, MASK, PHB, PBB>(a, cx, CP && stB, CP && enB, cr.o1, cr.o2, outA, accB);
     const float tB = wrap ? amp_nxt[0] : amp_cur[PBB & 7];
     const bool liveB = wrap ? cx.nxt_live : cx.live;
     const float2 outB = project(accB, tB, liveB && (tB > (wrap ? cx.nxt_thr : cx.thr)), cr.o1);
     ring_publish(ring_addr<PBB, 0, 0, 1>(cx.ob), ring_addr<PBB, 0, 0, 1>(cx.obh), outB);
-    image_publish<L, PHB, PBB, 1>(cx.uo, stB, enB, cx.dummy, outB);
+    image_store<L, PHB, 1>(cx.img_lo, cx.img_hi, cx.img_both, outB);   // (phase 0 has no image: the flags of this block apply to every store)
     cr.prev_out = outB;
     cr.o0 = cr.o2;
     cr.o1 = o3;
@@ -1070,6 +1097,13 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             cx.uo[m] = set_old + blk;
             cx.ob[m] = set_old + blk + lane * LANE_B;
             cx.obh[m] = cx.ob[m] + cx.halo_shift;
+        }
+        {
+            const int nowhere = SCRATCH_OFF + lane * 8 - (SET_BYTES + PLL * LANE_B);
+            const int lo_row = cx.uo[ImageBlocks<L>::m_lo], hi_row = cx.uo[ImageBlocks<L>::m_hi] + LANE_B;   // PLR = PLL + 1
+            cx.img_lo = cx.is_start ? lo_row : nowhere;
+            cx.img_hi = cx.is_end ? hi_row : nowhere;
+            cx.img_both = cx.is_start ? lo_row : cx.img_hi;
         }
         vmod += 8; vmod -= (vmod >= G) ? G : 0;   // v0 mod G and t0 mod G (G is a multiple of 8), wave-uniform
         tmod += 8; tmod -= (tmod >= G) ? G : 0;
