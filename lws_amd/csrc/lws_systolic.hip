@@ -716,18 +716,16 @@ __device__ __forceinline__ float2 project(float2 acc, float target, bool active,
 #ifdef LWS_DBG_NOPROJECT   // timing experiment: no re-projection (results invalid)
     return active ? make_float2(acc.x * target, acc.y * target) : old;
 #endif
-    // sums too small to square in fp32 are scaled up first (by a power of two: exact), so "|acc| > 0" keeps the
-    // reference's meaning; the scale is chosen on |x| + |y|, before anything is squared
-    const float sel = (fabsf(acc.x) + fabsf(acc.y) < 1e-15f) ? 0x1p60f : 1.0f;
-    const float ax = acc.x * sel, ay = acc.y * sel;
-    const float m2 = ax * ax + ay * ay;
+    // (the weights carry a per-spectrogram power-of-two scale that keeps |acc|^2 inside the fp32 range -- k_systolic;
+    // a sum more than 1e-19 below the spectrogram's largest magnitude counts as zero)
+    const float m2 = acc.x * acc.x + acc.y * acc.y;
     const bool ok = active && (m2 > 0.f);
     float r = __frsqrt_rn(m2);
 #ifdef LWS_PROJECT_NEWTON   // one Newton step on the reciprocal square root: 3 more dependent operations per bin (1.2 ms per pass)
     r = r * fmaf(-0.5f * m2 * r, r, 1.5f);
 #endif
     const float sc = target * r;
-    return ok ? make_float2(ax * sc, ay * sc) : old;
+    return ok ? make_float2(acc.x * sc, acc.y * sc) : old;
 }
 
 // Registers a compute lane carries from pair to pair: the previous sweep's values of its next bins and its last output.
@@ -921,10 +919,26 @@ __device__ unsigned long long g_dbg_timing[16 * 4];
 #endif
 // MULTI: several workgroups share a spectrogram (a.nwg > 1); the single-workgroup instantiation carries none of it
 template <int Q, int L, uint32_t MASK, bool MULTI>
-__global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a) {
+__global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nwg = MULTI ? a.nwg : 1;
+    const int nwg = MULTI ? a_in.nwg : 1;
     const int b = MULTI ? blockIdx.x / nwg : blockIdx.x, wg = MULTI ? blockIdx.x - b * nwg : 0;
+    // The weighted sums are only ever normalised (project()), so the weights of this spectrogram are scaled by the power
+    // of two that brings its largest magnitude to [1, 2): exact, and |acc|^2 can then be formed in fp32 without the
+    // rescue path for very small (or large) data that project() would otherwise need for every bin.
+    SysArgs a = a_in;
+    {
+        const unsigned ebits = (__float_as_uint(a_in.amax[b]) >> 23) & 0xffu;
+        const unsigned sbits = (ebits == 0u || ebits == 0xffu) ? 0x3f800000u : ((ebits >= 254u ? 1u : 254u - ebits) << 23);
+        const float sc = __uint_as_float(sbits);
+#pragma unroll
+        for (int x = 0; x < 32; ++x) {
+            const float re = __uint_as_float((unsigned)(a_in.w[x] & 0xffffffffull)) * sc;
+            const float im = __uint_as_float((unsigned)(a_in.w[x] >> 32)) * sc;
+            a.w[x] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(im)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(re));
+        }
+    }
     // `wave` is the ROLE of a wave (sweep slot 0..NSLOTS-1, or NSLOTS = service), not its hardware index: hardware
     // waves w and w + 4 share a SIMD and the older one is served first.  Every sweep slot meets the service wave at every
     // pair of bins (it feeds slot 0, computes the Nyquist bins and writes the results back), so the service wave takes
