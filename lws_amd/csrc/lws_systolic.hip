@@ -1125,14 +1125,21 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             int vnext = vmod + 8;
             vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                amp_cur[i] = amp_nxt[i];
+            for (int i = 0; i < 8; ++i) amp_cur[i] = amp_nxt[i];
 #ifdef LWS_DBG_NOAMP   // timing experiment: no target-magnitude loads (results invalid)
-                amp_nxt[i] = (float)(vnext + i);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) amp_nxt[i] = (float)(vnext + i);
 #else
-                amp_nxt[i] = amp_w_b[(size_t)(vnext + i) * LANES + lane];
+            // The loads are asm statements so that they land in amp_nxt's own registers and nobody waits for them here
+            // (written as plain loads the compiler fetches into temporaries and copies -- i.e. waits -- at once: a stall
+            // of one memory latency per block).  The waits are explicit: before amp_nxt[0] is first used (pair (7, 0'))
+            // and at the end of the block; these are the only vector-memory operations of a sweep slot.
+            const float *ap = amp_w_b + (size_t)vnext * LANES + lane;
+#define LWS_AMP_LOAD(i) asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * LANES * 4) : "memory")
+            LWS_AMP_LOAD(0); LWS_AMP_LOAD(1); LWS_AMP_LOAD(2); LWS_AMP_LOAD(3);
+            LWS_AMP_LOAD(4); LWS_AMP_LOAD(5); LWS_AMP_LOAD(6); LWS_AMP_LOAD(7);
+#undef LWS_AMP_LOAD
 #endif
-            }
         }
         // ---- 4 pairs of bins, phases static
         static_for<4>([&](auto ip) {
@@ -1143,6 +1150,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             flow_wait(lane, t0 + PA, watched);
 #ifdef LWS_DBG_TIMING
             { const unsigned long long n = __builtin_amdgcn_s_memtime(); tm_wait += n - tm_mark; tm_mark = n; }
+#endif
+#ifndef LWS_DBG_NOAMP
+            if constexpr (PA == 7) { if (is_compute) asm volatile("s_waitcnt vmcnt(7)" : "+v"(amp_nxt[0]) : : "memory"); }   // in-order: the first of the 8
 #endif
             if (is_compute) compute_pair<Q, L, MASK, PA, MULTI>(a, cx, lane, vmod, G, cr, amp_cur, amp_nxt, state_w_b);
             if constexpr (PA == 1 && MULTI) {
@@ -1222,6 +1232,11 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             flow_publish(lane, wave, t0 + PA + 2);
             LWS_SETPRIO(0);   // polling for the next pair must not take issue slots from the wave still working
         });
+#ifndef LWS_DBG_NOAMP
+        if (is_compute)   // the next block's magnitudes (issued 4 pairs ago) are in their registers before anything may move them
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(amp_nxt[0]), "+v"(amp_nxt[1]), "+v"(amp_nxt[2]), "+v"(amp_nxt[3]),
+                         "+v"(amp_nxt[4]), "+v"(amp_nxt[5]), "+v"(amp_nxt[6]), "+v"(amp_nxt[7]) : : "memory");
+#endif
     }
 #ifdef LWS_DBG_TIMING
     if (blockIdx.x == 0 && lane == 0) {
