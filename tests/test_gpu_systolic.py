@@ -226,3 +226,20 @@ def test_partial_last_round_shares_the_chip(monkeypatch):
     ref = p.plan().batch(S, thr)
     monkeypatch.delenv("LWS_SYSTOLIC_NWG")
     assert np.array_equal(p.plan().batch(S, thr), ref)
+
+
+def test_any_fp32_data_scale():
+    """LWS is scale-invariant; the systolic kernel scales its weights by a per-spectrogram power of two so that the
+    squared sums stay inside the fp32 range: data at 1e-20 and at 1e+20 give the scaled result (and each spectrogram
+    of a batch gets its own scale)."""
+    p = lws_amd.lws(1024, 256)
+    rng = np.random.default_rng(5)
+    S = rng.standard_normal((3, 70, 513)) + 1j * rng.standard_normal((3, 70, 513))
+    thr = lws_amd.get_thresholds(12, 1.0, 0.1, 1.0)
+    ref = p.plan().batch(S, thr)
+    assert p.plan().last_kernel()["name"].startswith("systolic")
+    scales = np.array([1e-20, 1.0, 1e20])[:, None, None]
+    out = p.plan().batch(S * scales, thr)
+    assert np.isfinite(out).all()
+    for b in range(3):
+        assert rel_l2(out[b] / scales[b], ref[b]) < 1e-4, (b, rel_l2(out[b] / scales[b], ref[b]))
