@@ -744,8 +744,10 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
 #ifdef LWS_DBG_NOCARRY   // timing experiment: the own previous-sweep values are not fetched (results invalid)
     const float2 o3 = cr.o1, o4 = cr.o2;
 #else
-    const float2 o3 = lds_read(ring_addr<PA, 3 - LAG>(cx.ob));
-    const float2 o4 = lds_read(ring_addr<PA, 4 - LAG>(cx.ob));
+    // (clocks PA+3 and PA+4 share a 16-byte cell: one conflict-free ds_read_b128 instead of two 8-byte reads)
+    static_assert(((PA + 3 - LAG) & 1) == 0, "cell alignment of the carried values");
+    const v4f o34 = lds_read128(ring_addr<PA, 3 - LAG>(cx.ob));
+    const float2 o3 = make_float2(o34.x, o34.y), o4 = make_float2(o34.z, o34.w);
 #endif
 #ifndef LWS_DBG_NOCPATCH
 #define LWS_DBG_NOCPATCH 0   // timing experiment: centre-frame taps never use images (results invalid)
