@@ -670,42 +670,123 @@ constexpr uint32_t FLAG_R13 = 1u << 31;     // Q = 4 and W[0][3][k] == j^k W[0][
 // so rows 3 only contribute rotated partial sums (kept in P3) and rows 1 do the complex multiply for both.
 template <int L> struct R13Partials { float2 b[L + 1], c[L + 1]; };
 
-// Contribution of frames m-R and m+R to the bin at phase PH; OFFS = 0 / 1: first / second bin of the pair
-template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS>
-__device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[2 * L + 2], const float2 (&td)[2 * L + 2],
-                                         R13Partials<L> &p3, float2 &accr) {
+// one group of taps (the four taps |dk| = K of frames m-R and m+R, or the two taps dk = 0) of the bin at phase PH;
+// the bin sits at index L + OFFS of the tap windows tu (frame m-R) / td (frame m+R)
+template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS, int K, int N>
+__device__ __forceinline__ void rows_group(const SysArgs &a, const float2 (&tu)[N], const float2 (&td)[N],
+                                           R13Partials<L> &p3, float2 &accr) {
     constexpr int K1 = L + 1;
     constexpr int mod = PH % Q;
     constexpr int rot = ((mod * R) % Q) * (4 / Q);  // quarter turns of exp(2j*pi*mod*R/Q)
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
+    static_assert(L + OFFS + K < N, "tap window too short");
     // accr: the bin's running sum (every group of taps is added to it directly: no partial sums to zero and combine)
-    if constexpr ((MASK >> (R * K1)) & 1u) {
+    if constexpr (((MASK >> (R * K1 + K)) & 1u) == 0) {
+        return;
+    } else if constexpr (K == 0) {
         if constexpr ((MASK & FLAG_K0REAL) != 0) pair_rot_real<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
         else pair_rot<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
+    } else {
+        constexpr int k = K;
+        // W[mod]*S[m-r,c-k] + conj(W[mod])*S[m+r,c-k] + W[-mod]*S[m+r,c+k] + conj(W[-mod])*S[m-r,c+k]
+        // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
+        const wp_t w = a.w[R * K1 + k];
+        const float2 um = tu[L - k + OFFS], up = tu[L + k + OFFS], dm = td[L - k + OFFS], dp = td[L + k + OFFS];
+        if constexpr (!(r13 && (R == 1 || R == 3) && k >= 2)) {
+            quad_rot<rot>(accr, w, um, up, dm, dp);
+        } else if constexpr (R == 3) {
+            bc_pair<(rot & 1)>(p3.b[k], p3.c[k], um, up, dm, dp);      // rotated when rows 1 pick them up
+        } else {
+            // j^rot1 (B1 + j^(k+rot3-rot1) B3) and j^-rot1 (C1 + j^(rot1-k-rot3) C3): one multiply for both rows
+            constexpr int rot3 = ((mod * 3) % Q) * (4 / Q);
+            r13_rot<rot, (k + rot3 - rot + 8) & 3>(accr, w, um, up, dm, dp, p3.b[k], p3.c[k]);
+        }
     }
-    static_for<L>([&](auto ik) {
-        constexpr int k = decltype(ik)::value + 1;
-        if constexpr ((MASK >> (R * K1 + k)) & 1u) {
-            // W[mod]*S[m-r,c-k] + conj(W[mod])*S[m+r,c-k] + W[-mod]*S[m+r,c+k] + conj(W[-mod])*S[m-r,c+k]
-            // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
-            const wp_t w = a.w[R * K1 + k];
-            const float2 um = tu[L - k + OFFS], up = tu[L + k + OFFS], dm = td[L - k + OFFS], dp = td[L + k + OFFS];
-            if constexpr (!(r13 && (R == 1 || R == 3) && k >= 2)) {
-                quad_rot<rot>(accr, w, um, up, dm, dp);
-                return;
-            }
-            if constexpr (r13 && R == 3 && k >= 2) {
-                bc_pair<(rot & 1)>(p3.b[k], p3.c[k], um, up, dm, dp);      // rotated when rows 1 pick them up
-            } else if constexpr (r13 && R == 1 && k >= 2) {
-                // j^rot1 (B1 + j^(k+rot3-rot1) B3) and j^-rot1 (C1 + j^(rot1-k-rot3) C3): one multiply for both rows
-                constexpr int rot3 = ((mod * 3) % Q) * (4 / Q);
-                r13_rot<rot, (k + rot3 - rot + 8) & 3>(accr, w, um, up, dm, dp, p3.b[k], p3.c[k]);
-            } else {
-                float2 b, c;
-                bc_pair<(rot & 1)>(b, c, um, up, dm, dp);
-                pair_rot<rot>(accr, w, b, c);
+}
+// Contribution of frames m-R and m+R to the bin at phase PH; OFFS = 0 / 1: first / second bin of the pair
+template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS, int N>
+__device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[N], const float2 (&td)[N],
+                                         R13Partials<L> &p3, float2 &accr) {
+    static_for<L + 1>([&](auto ik) { rows_group<Q, L, MASK, PH, R, OFFS, decltype(ik)::value>(a, tu, td, p3, accr); });
+}
+
+// ---- two pairs of bins from one set of tap windows (FLAG_R13 kernels, the pairs (1,2) and (3,4) of a block) -------------
+// The taps of the pair (3,4) are those of the pair (1,2) moved up by one 16-byte cell: 7 cells per neighbour frame cover
+// both pairs where two separate fetches take 12.  The first pair therefore also sums the neighbour-frame taps of the
+// second pair's bins (the sums do not depend on anything the first pair produces) and hands them over in registers.
+// Two frames cannot deliver their seventh cell yet when the first pair starts -- frame m-1 (its bins are 8 steps ahead
+// of this lane's: the cell holds what it produces during this very pair) and frame m+3 (previous sweep, 32 - 24 steps
+// ahead).  Exactly three tap groups of frames m-+1 / m-+3 touch those cells: (first bin, k = L), (second bin, k = L-1),
+// (second bin, k = L).  Their other operands are handed over as well and the second pair finishes them after fetching
+// the two cells.
+template <int L> struct QuadCarry {
+    float2 accA, accB;                               // neighbour-frame sums of the second pair's bins so far
+    float2 um1[3], dm1[3], dp1[3], um3[3], c3[3];    // the three unfinished groups: operands of r13_rot() that are known
+};
+template <int OFFS, int K, int L> __host__ __device__ constexpr bool quad_deferred() { return L + OFFS + K >= 2 * L + 2; }
+template <int OFFS, int K, int L> __host__ __device__ constexpr int quad_slot() { return OFFS == 2 ? 0 : (K == L - 1 ? 1 : 2); }
+
+// neighbour-frame taps of a bin of the SECOND pair (OFFS = 2, 3), summed during the first pair
+template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS, int N>
+__device__ __forceinline__ void rows_sum_ahead(const SysArgs &a, const float2 (&tu)[N], const float2 (&td)[N],
+                                               R13Partials<L> &p3, float2 &accr, QuadCarry<L> &qc) {
+    constexpr int K1 = L + 1;
+    constexpr int rot = (((PH % Q) * R) % Q) * (4 / Q);
+    static_for<L + 1>([&](auto ik) {
+        constexpr int k = decltype(ik)::value;
+        if constexpr (!(quad_deferred<OFFS, k, L>() && (R == 1 || R == 3))) {
+            rows_group<Q, L, MASK, PH, R, OFFS, k>(a, tu, td, p3, accr);
+        } else if constexpr ((MASK >> (R * K1 + k)) & 1u) {
+            static_assert(k >= 2, "only the shared-weight groups reach the late cells");
+            constexpr int i = quad_slot<OFFS, k, L>();
+            if constexpr (R == 3) {          // frame m+3's tap at +k is late: keep um3 and c3 = dm3 +- up3
+                qc.um3[i] = tu[L - k + OFFS];
+                if constexpr ((rot & 1) == 0) qc.c3[i] = cadd(td[L - k + OFFS], tu[L + k + OFFS]);
+                else qc.c3[i] = csub(td[L - k + OFFS], tu[L + k + OFFS]);
+            } else {                          // frame m-1's tap at +k is late: keep the other three
+                qc.um1[i] = tu[L - k + OFFS];
+                qc.dm1[i] = td[L - k + OFFS];
+                qc.dp1[i] = td[L + k + OFFS];
             }
         }
+    });
+}
+// the three unfinished groups, by the second pair: up1 = frame m-1's late tap, dp3 = frame m+3's
+template <int Q, int L, uint32_t MASK, int PH, int OFFS, int K>
+__device__ __forceinline__ void quad_finish(const SysArgs &a, const QuadCarry<L> &qc, float2 up1, float2 dp3, float2 &accr) {
+    constexpr int K1 = L + 1, mod = PH % Q;
+    constexpr int rot1 = ((mod * 1) % Q) * (4 / Q), rot3 = ((mod * 3) % Q) * (4 / Q);
+    constexpr int i = quad_slot<OFFS, K, L>();
+    if constexpr ((MASK >> (1 * K1 + K)) & 1u) {
+        float2 b3;
+        if constexpr ((rot3 & 1) == 0) b3 = cadd(qc.um3[i], dp3);
+        else b3 = csub(qc.um3[i], dp3);
+        r13_rot<rot1, (K + rot3 - rot1 + 8) & 3>(accr, a.w[1 * K1 + K], qc.um1[i], up1, qc.dm1[i], qc.dp1[i], b3, qc.c3[i]);
+    }
+}
+
+// NC consecutive cells of the taps of frame m+DR, starting at bin (PA - L): t[j] is the tap at block-relative bin PA - L + j.
+// Images of the edge lanes as in load_row2 (both bins of each cell lie in the same frame as the pair: no split views).
+template <int PA, int DR, int L, int C0, int NC, int N>
+__device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
+    static_assert((PA & 1) == 1 && (L & 1) == 1 && 2 * (C0 + NC) <= N, "cell window");
+    constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
+    constexpr int q_first = PA + base_off - L;                   // even
+    static_for<NC>([&](auto ip) {
+        constexpr int j = 2 * (C0 + decltype(ip)::value);
+        constexpr int q = q_first + j;
+        static_assert(q >= -RING && q + 1 <= 15, "ring retention exceeded");
+        constexpr bool img_lo = (PA - L + j + 1 < 0), img_hi = (PA - L + j >= 8);
+        constexpr int fl = floor_div8(q);
+        constexpr int m = (-fl) & (NBLK - 1);
+        constexpr int within = q - 8 * fl;                       // even
+        constexpr int setoff = (DR < 0) ? SET_BYTES : 0;
+        int base = cx.ob[m];
+        if constexpr (img_lo) base = cx.ob[m] + cx.wlo[DR + 3];
+        if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + 3];
+        const v4f v = lds_read128(base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES);
+        t[j] = make_float2(v.x, v.y);
+        t[j + 1] = make_float2(v.z, v.w);
     });
 }
 
@@ -734,7 +815,8 @@ struct Carry { float2 o0, o1, o2, prev_out; };
 // One pair of bins (phases PA odd, PA+1) of one lane.
 template <int Q, int L, uint32_t MASK, int PA, bool MULTI>
 __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx, int lane, int vmod, int G, Carry &cr,
-                                             const float (&amp_cur)[8], const float (&amp_nxt)[8], float2 *state_w_b) {
+                                             const float (&amp_cur)[8], const float (&amp_nxt)[8], float2 *state_w_b,
+                                             QuadCarry<L> &qc) {
     constexpr int K1 = L + 1;
     constexpr int PHB = (PA + 1) & 7, PBB = PA + 1;          // second bin: phase and clock relative to this block
     constexpr bool wrap = (PA == 7);                         // the second bin belongs to the next block
@@ -774,7 +856,41 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     float2 accB = make_float2(0.f, 0.f);
     // frame pairs m-+R.  With FLAG_R13 rows 3 leave partial sums for rows 1: order 2, 3, 1 keeps them short-lived.
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
+#ifndef LWS_QUAD
+#define LWS_QUAD (!LWS_WIDE)
+#endif
+    constexpr bool quad_first = LWS_QUAD && r13 && PA == 1, quad_second = LWS_QUAD && r13 && PA == 3;
     R13Partials<L> p3A, p3B;
+    if constexpr (quad_first) {
+        // this pair and the neighbour-frame sums of the next one, from 7-cell windows (rows_sum_ahead)
+        R13Partials<L> p3C, p3D;
+        qc.accA = make_float2(0.f, 0.f);
+        qc.accB = make_float2(0.f, 0.f);
+        static_for<Q - 1>([&](auto ir) {
+            constexpr int i = decltype(ir)::value;
+            constexpr int R = (i == 0 ? 2 : (i == 1 ? 3 : 1));
+            float2 tu[2 * L + 4], td[2 * L + 4];
+            load_cells<PA, -R, L, 0, (R == 1 ? L + 1 : L + 2)>(cx, tu);    // frame m-1 cannot deliver its seventh cell yet,
+            load_cells<PA, R, L, 0, (R == 3 ? L + 1 : L + 2)>(cx, td);     // nor can frame m+3
+            rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
+            rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
+            rows_sum_ahead<Q, L, MASK, PA + 2, R, 2>(a, tu, td, p3C, qc.accA, qc);
+            rows_sum_ahead<Q, L, MASK, PA + 3, R, 3>(a, tu, td, p3D, qc.accB, qc);
+            if constexpr (i == 0) LWS_SETPRIO(0);
+            if constexpr (i == Q - 2) LWS_SETPRIO(2);
+        });
+    } else if constexpr (quad_second) {
+        // the sums came with the previous pair; two cells were not there yet: finish the three groups that need them
+        float2 u1[2 * L + 4], d3[2 * L + 4];
+        load_cells<PA - 2, -1, L, L + 1, 1>(cx, u1);
+        load_cells<PA - 2, 3, L, L + 1, 1>(cx, d3);
+        accA = cadd(accA, qc.accA);
+        accB = qc.accB;
+        quad_finish<Q, L, MASK, PA, 2, L>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accA);
+        quad_finish<Q, L, MASK, PHB, 3, L - 1>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accB);
+        quad_finish<Q, L, MASK, PHB, 3, L>(a, qc, u1[2 * L + 3], d3[2 * L + 3], accB);
+        LWS_SETPRIO(2);
+    } else
     static_for<Q - 1>([&](auto ir) {
         constexpr int i = decltype(ir)::value;
         constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
@@ -1025,6 +1141,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     float amp_cur[8], amp_nxt[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) amp_cur[i] = amp_nxt[i] = 0.f;
+    QuadCarry<L> qc;   // sweep slots: what the pair (1,2) of a block hands to the pair (3,4)
     bool wb_cur = false, wb_prev = false;   // service wave: does the last slot's lane have a bin to write back in this / the previous block
     ServiceState sv;
     sv.nyq_amp_next = 0.f;
@@ -1156,7 +1273,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #ifndef LWS_DBG_NOAMP
             if constexpr (PA == 7) { if (is_compute) asm volatile("s_waitcnt vmcnt(7)" : "+v"(amp_nxt[0]) : : "memory"); }   // in-order: the first of the 8
 #endif
-            if (is_compute) compute_pair<Q, L, MASK, PA, MULTI>(a, cx, lane, vmod, G, cr, amp_cur, amp_nxt, state_w_b);
+            if (is_compute) compute_pair<Q, L, MASK, PA, MULTI>(a, cx, lane, vmod, G, cr, amp_cur, amp_nxt, state_w_b, qc);
             if constexpr (PA == 1 && MULTI) {
                 if (is_service) {
                     // every slot has finished the previous block (flow_wait above); this wave has written back what the last
