@@ -859,7 +859,8 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
 #ifndef LWS_QUAD
 #define LWS_QUAD (!LWS_WIDE)
 #endif
-    constexpr bool quad_first = LWS_QUAD && r13 && PA == 1, quad_second = LWS_QUAD && r13 && PA == 3;
+    // (1,2)+(3,4) in full; (5,6)+(7,0') for bin 7 only: bin 0' belongs to the lane's next frame and keeps its own fetches
+    constexpr bool quad_first = LWS_QUAD && r13 && (PA == 1 || PA == 5), quad_second = LWS_QUAD && r13 && (PA == 3 || PA == 7);
     R13Partials<L> p3A, p3B;
     if constexpr (quad_first) {
         // this pair and the neighbour-frame sums of the next one, from 7-cell windows (rows_sum_ahead)
@@ -875,7 +876,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
             rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
             rows_sum_ahead<Q, L, MASK, PA + 2, R, 2>(a, tu, td, p3C, qc.accA, qc);
-            rows_sum_ahead<Q, L, MASK, PA + 3, R, 3>(a, tu, td, p3D, qc.accB, qc);
+            if constexpr (PA == 1) rows_sum_ahead<Q, L, MASK, PA + 3, R, 3>(a, tu, td, p3D, qc.accB, qc);
             if constexpr (i == 0) LWS_SETPRIO(0);
             if constexpr (i == Q - 2) LWS_SETPRIO(2);
         });
@@ -885,10 +886,24 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
         load_cells<PA - 2, -1, L, L + 1, 1>(cx, u1);
         load_cells<PA - 2, 3, L, L + 1, 1>(cx, d3);
         accA = cadd(accA, qc.accA);
-        accB = qc.accB;
         quad_finish<Q, L, MASK, PA, 2, L>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accA);
-        quad_finish<Q, L, MASK, PHB, 3, L - 1>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accB);
-        quad_finish<Q, L, MASK, PHB, 3, L>(a, qc, u1[2 * L + 3], d3[2 * L + 3], accB);
+        if constexpr (PA == 3) {
+            accB = qc.accB;
+            quad_finish<Q, L, MASK, PHB, 3, L - 1>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accB);
+            quad_finish<Q, L, MASK, PHB, 3, L>(a, qc, u1[2 * L + 3], d3[2 * L + 3], accB);
+        } else {
+            // bin 0' of the lane's next frame: its own view of the taps (images below DC for the lane that starts a frame)
+            static_for<Q - 1>([&](auto ir) {
+                constexpr int i = decltype(ir)::value;
+                constexpr int R = (i == 0 ? 2 : (i == 1 ? 3 : 1));
+                constexpr uint32_t kmask = (MASK >> (R * K1)) & ((1u << K1) - 1u);
+                float2 tu[2 * L + 2], td[2 * L + 2];
+                load_row2<PA, -R, L, kmask, 2>(cx, tu);
+                load_row2<PA, R, L, kmask, 2>(cx, td);
+                rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
+                if constexpr (i == 0) LWS_SETPRIO(0);
+            });
+        }
         LWS_SETPRIO(2);
     } else
     static_for<Q - 1>([&](auto ir) {
