@@ -723,6 +723,8 @@ template <int L> struct QuadCarry {
     float2 accA, accB;                               // neighbour-frame sums of the second pair's bins so far
     float2 um1[3], dm1[3], dp1[3], um3[3], c3[3];    // the three unfinished groups: operands of r13_rot() that are known
 };
+// (with the 16-step skew of the wide build every frame is far enough ahead: nothing is late there)
+template <int DR> __host__ __device__ constexpr bool quad_late_frame() { return SKEW * DR - (DR > 0 ? LAG : 0) > -10; }
 template <int OFFS, int K, int L> __host__ __device__ constexpr bool quad_deferred() { return L + OFFS + K >= 2 * L + 2; }
 template <int OFFS, int K, int L> __host__ __device__ constexpr int quad_slot() { return OFFS == 2 ? 0 : (K == L - 1 ? 1 : 2); }
 
@@ -734,7 +736,7 @@ __device__ __forceinline__ void rows_sum_ahead(const SysArgs &a, const float2 (&
     constexpr int rot = (((PH % Q) * R) % Q) * (4 / Q);
     static_for<L + 1>([&](auto ik) {
         constexpr int k = decltype(ik)::value;
-        if constexpr (!(quad_deferred<OFFS, k, L>() && (R == 1 || R == 3))) {
+        if constexpr (!(quad_deferred<OFFS, k, L>() && (R == 1 || R == 3) && quad_late_frame<-1>())) {
             rows_group<Q, L, MASK, PH, R, OFFS, k>(a, tu, td, p3, accr);
         } else if constexpr ((MASK >> (R * K1 + k)) & 1u) {
             static_assert(k >= 2, "only the shared-weight groups reach the late cells");
@@ -857,7 +859,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     // frame pairs m-+R.  With FLAG_R13 rows 3 leave partial sums for rows 1: order 2, 3, 1 keeps them short-lived.
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
 #ifndef LWS_QUAD
-#define LWS_QUAD (!LWS_WIDE)
+#define LWS_QUAD 1
 #endif
     // (1,2)+(3,4) in full; (5,6)+(7,0') for bin 7 only: bin 0' belongs to the lane's next frame and keeps its own fetches
     constexpr bool quad_first = LWS_QUAD && r13 && (PA == 1 || PA == 5), quad_second = LWS_QUAD && r13 && (PA == 3 || PA == 7);
@@ -871,8 +873,10 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             constexpr int i = decltype(ir)::value;
             constexpr int R = (i == 0 ? 2 : (i == 1 ? 3 : 1));
             float2 tu[2 * L + 4], td[2 * L + 4];
-            load_cells<PA, -R, L, 0, (R == 1 ? L + 1 : L + 2)>(cx, tu);    // frame m-1 cannot deliver its seventh cell yet,
-            load_cells<PA, R, L, 0, (R == 3 ? L + 1 : L + 2)>(cx, td);     // nor can frame m+3
+            static_assert(quad_late_frame<-1>() == quad_late_frame<3>() && !quad_late_frame<-2>() && !quad_late_frame<2>() &&
+                          !quad_late_frame<1>() && !quad_late_frame<-3>(), "which frames are late");
+            load_cells<PA, -R, L, 0, (R == 1 && quad_late_frame<-1>() ? L + 1 : L + 2)>(cx, tu);    // frame m-1 cannot deliver its seventh cell yet,
+            load_cells<PA, R, L, 0, (R == 3 && quad_late_frame<3>() ? L + 1 : L + 2)>(cx, td);      // nor can frame m+3
             rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
             rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
             rows_sum_ahead<Q, L, MASK, PA + 2, R, 2>(a, tu, td, p3C, qc.accA, qc);
@@ -883,14 +887,18 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     } else if constexpr (quad_second) {
         // the sums came with the previous pair; two cells were not there yet: finish the three groups that need them
         float2 u1[2 * L + 4], d3[2 * L + 4];
-        load_cells<PA - 2, -1, L, L + 1, 1>(cx, u1);
-        load_cells<PA - 2, 3, L, L + 1, 1>(cx, d3);
         accA = cadd(accA, qc.accA);
-        quad_finish<Q, L, MASK, PA, 2, L>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accA);
+        if constexpr (quad_late_frame<-1>()) {
+            load_cells<PA - 2, -1, L, L + 1, 1>(cx, u1);
+            load_cells<PA - 2, 3, L, L + 1, 1>(cx, d3);
+            quad_finish<Q, L, MASK, PA, 2, L>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accA);
+        }
         if constexpr (PA == 3) {
             accB = qc.accB;
-            quad_finish<Q, L, MASK, PHB, 3, L - 1>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accB);
-            quad_finish<Q, L, MASK, PHB, 3, L>(a, qc, u1[2 * L + 3], d3[2 * L + 3], accB);
+            if constexpr (quad_late_frame<-1>()) {
+                quad_finish<Q, L, MASK, PHB, 3, L - 1>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accB);
+                quad_finish<Q, L, MASK, PHB, 3, L>(a, qc, u1[2 * L + 3], d3[2 * L + 3], accB);
+            }
         } else {
             // bin 0' of the lane's next frame: its own view of the taps (images below DC for the lane that starts a frame)
             static_for<Q - 1>([&](auto ir) {
