@@ -268,8 +268,8 @@ struct LaneCtx {
     int halo_shift;   // +-64 lanes in bytes for the 6 lanes that also write a halo copy, else 0
     int dummy;        // private LDS slot for predicated-off conditional writes
     int lane8;
-    bool is_start, is_end, live, store;          // this block (8 bins of one frame)
-    bool nxt_start, nxt_end, nxt_live, nxt_store; // the following block (possibly the next frame of the lane)
+    bool is_start, is_end, live;                 // this block (8 bins of one frame)
+    bool nxt_start, nxt_end, nxt_live;           // the following block (possibly the next frame of the lane)
     float thr, nxt_thr;
     // image cells: byte offset from the lane's own origin ob[m] to the pseudo-lane's, minus what the compile-time offset
     // of the neighbour frame DR adds -- for the lane at the start (lo: PLL) / end (hi: PLR) of its frame; zero for every
@@ -1187,37 +1187,45 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         else watched = (lane == wave - 1) || (lane == wave + 1) || (lane == NSLOTS);
     }
     // Where a lane is in a block of 8 steps (which frame of which sweep, first / last bins of the frame, active at
-    // all): evaluated once per block for the FOLLOWING block and shifted; the division by the number of lane rounds is
-    // done in floating point (exact for these magnitudes) and the threshold of the lane's sweep is re-read from LDS
-    // only when the sweep changes.
-    const float inv_kr = 1.0f / (float)Kr;
-    struct BlockInfo { bool live, store, start, end; float thr; int j; };
-    auto block_info = [&](int vblock, const BlockInfo &prev) {      // vblock: the slot's clock at phase 0 of the block
+    // all): evaluated once per block for the FOLLOWING block and shifted.  The lanes of a wave sit in at most two
+    // consecutive rounds of 64 frames ("kap" = clock / frame period, minus one for the lanes whose frame has not come
+    // round yet), so everything that depends on the round -- pass, frame index base, sweep number, threshold -- is
+    // kept as wave-uniform state for those two rounds and advanced (no division) when the clock enters a new round; a
+    // lane only selects between the two.
+    const float inv_kr = 1.0f / (float)Kr;   // (service wave: one division per block in floating point, exact for these magnitudes)
+    struct Round { int gl, k, meb; bool okj; float thr; };    // wave-uniform: local pass, round within it, first frame, sweep valid, its threshold
+    Round rcur, rprev;
+    rcur.gl = 0; rcur.k = 0; rcur.meb = 0; rcur.okj = false; rcur.thr = 0.f;
+    rprev = rcur;
+    int ks_state = (T_START - (slot + 1) * LAG) >> ROWP_SHIFT;     // round of lane 0 at the last evaluation (negative: not started)
+    struct BlockInfo { bool live, start, end; float thr; };
+    auto block_info = [&](int vblock) {      // vblock: the slot's clock at phase 0 of the block (wave-uniform)
+        const int rem = vblock & (ROWP - 1), ks = vblock >> ROWP_SHIFT;
+        if (ks != ks_state) {                 // once per 64 (128) blocks
+            ks_state = ks;
+            rprev = rcur;
+            if (ks <= 0) { rcur.gl = 0; rcur.k = 0; }
+            else if (++rcur.k == Kr) { rcur.k = 0; ++rcur.gl; }
+            const int j = (rcur.gl * nwg + wg) * NSLOTS + slot;
+            rcur.okj = is_compute && ks >= 0 && j < n_eff;
+            rcur.meb = rcur.k * LANES;
+            rcur.thr = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(thr_eff[rcur.okj ? j : 0])));
+        }
         BlockInfo bi;
-        const int vv = vblock - SKEW * lane;        // clock relative to the start of the lane's first frame
-        const int cbase = vv & (ROWP - 1);
-        const int kap = vv >> ROWP_SHIFT;
-        const int gl = (int)(((float)kap + 0.5f) * inv_kr), k = kap - gl * Kr;
-        const int me = k * LANES + lane;
-        const int j = (gl * nwg + wg) * NSLOTS + slot;
-        const bool valid = is_compute && (vv >= 0) && (j < n_eff) && (me < a.Tp);
+        const bool here = SKEW * lane <= rem;                    // this lane's frame of the current round has started
+        const int cbase = (rem - SKEW * lane) & (ROWP - 1);
+        const int me = (here ? rcur.meb : rprev.meb) + lane;
+        const bool valid = (here ? rcur.okj : rprev.okj) && (me < a.Tp);
         bi.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
-        // the last slot writes back whatever reaches it: in the last, partial group of sweeps the idle slots pass the
-        // final values on unchanged (an idle lane re-publishes the previous sweep's value)
-        bi.store = is_compute && (slot == NSLOTS - 1) && (vv >= 0) && (me < a.Tp) && (cbase < C) && (gl * nwg + wg < n_groups);
         bi.start = (cbase == 0);
         bi.end = (cbase == C - 8);
-        bi.j = valid ? j : 0;
-        bi.thr = prev.thr;
-        if (__any(bi.j != prev.j)) bi.thr = thr_eff[bi.j];
+        bi.thr = here ? rcur.thr : rprev.thr;
         return bi;
     };
     int dlo[7];   // per-lane constants of the image-cell offsets: (PLL - HALO - DR - lane) * 16
 #pragma unroll
     for (int d = 0; d < 7; ++d) dlo[d] = (PLL - HALO - (d - 3) - lane) * LANE_B;
-    BlockInfo nxt_bi;
-    nxt_bi.j = -1; nxt_bi.thr = 0.f; nxt_bi.live = nxt_bi.store = nxt_bi.start = nxt_bi.end = false;
-    nxt_bi = block_info(T_START - (slot + 1) * LAG, nxt_bi);
+    BlockInfo nxt_bi = block_info(T_START - (slot + 1) * LAG);
     int vmod = __builtin_amdgcn_readfirstlane((((T_START - (slot + 1) * LAG) % G) + G) % G - 8);   // advanced at the loop head
     int tmod = __builtin_amdgcn_readfirstlane(((T_START % G) + G) % G - 8);
 #ifdef LWS_DBG_TIMING
@@ -1232,9 +1240,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #endif
         {
             const BlockInfo cur = nxt_bi;
-            nxt_bi = block_info(v0 + 8, cur);
-            cx.live = cur.live; cx.store = cur.store; cx.is_start = cur.start; cx.is_end = cur.end; cx.thr = cur.thr;
-            cx.nxt_live = nxt_bi.live; cx.nxt_store = nxt_bi.store; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end;
+            nxt_bi = block_info(v0 + 8);
+            cx.live = cur.live; cx.is_start = cur.start; cx.is_end = cur.end; cx.thr = cur.thr;
+            cx.nxt_live = nxt_bi.live; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end;
             cx.nxt_thr = nxt_bi.thr;
         }
         cx.lane8 = lane * 8;
