@@ -722,6 +722,7 @@ __device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[N]
 template <int L> struct QuadCarry {
     float2 accA, accB;                               // neighbour-frame sums of the second pair's bins so far
     float2 um1[3], dm1[3], dp1[3], um3[3], c3[3];    // the three unfinished groups: operands of r13_rot() that are known
+    float2 g[4][3][4];                               // kernels without FLAG_R13: [R][group] the operands (um, up, dm, dp) of quad_rot()
 };
 // (with the 16-step skew of the wide build every frame is far enough ahead: nothing is late there)
 template <int DR> __host__ __device__ constexpr bool quad_late_frame() { return SKEW * DR - (DR > 0 ? LAG : 0) > -10; }
@@ -736,10 +737,19 @@ __device__ __forceinline__ void rows_sum_ahead(const SysArgs &a, const float2 (&
     constexpr int rot = (((PH % Q) * R) % Q) * (4 / Q);
     static_for<L + 1>([&](auto ik) {
         constexpr int k = decltype(ik)::value;
-        if constexpr (!(quad_deferred<OFFS, k, L>() && (R == 1 || R == 3) && quad_late_frame<-1>())) {
+        constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
+        constexpr bool late = quad_deferred<OFFS, k, L>() && (quad_late_frame<-R>() || quad_late_frame<R>());
+        if constexpr (!late) {
             rows_group<Q, L, MASK, PH, R, OFFS, k>(a, tu, td, p3, accr);
-        } else if constexpr ((MASK >> (R * K1 + k)) & 1u) {
-            static_assert(k >= 2, "only the shared-weight groups reach the late cells");
+        } else if constexpr (((MASK >> (R * K1 + k)) & 1u) == 0) {
+        } else if constexpr (!r13) {          // the late operand is filled in by the second pair (quad_finish_plain)
+            constexpr int i = quad_slot<OFFS, k, L>();
+            qc.g[R][i][0] = tu[L - k + OFFS];
+            if constexpr (!quad_late_frame<-R>()) qc.g[R][i][1] = tu[L + k + OFFS];
+            qc.g[R][i][2] = td[L - k + OFFS];
+            if constexpr (!quad_late_frame<R>()) qc.g[R][i][3] = td[L + k + OFFS];
+        } else {
+            static_assert(k >= 2 && (R == 1 || R == 3), "only the shared-weight groups reach the late cells");
             constexpr int i = quad_slot<OFFS, k, L>();
             if constexpr (R == 3) {          // frame m+3's tap at +k is late: keep um3 and c3 = dm3 +- up3
                 qc.um3[i] = tu[L - k + OFFS];
@@ -752,6 +762,16 @@ __device__ __forceinline__ void rows_sum_ahead(const SysArgs &a, const float2 (&
             }
         }
     });
+}
+// an unfinished group of a kernel without FLAG_R13: `late` is the tap that was not there yet (frame m-R's or m+R's, at +K)
+template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS, int K>
+__device__ __forceinline__ void quad_finish_plain(const SysArgs &a, const QuadCarry<L> &qc, float2 late, float2 &accr) {
+    constexpr int K1 = L + 1;
+    constexpr int rot = (((PH % Q) * R) % Q) * (4 / Q);
+    constexpr int i = quad_slot<OFFS, K, L>();
+    if constexpr ((MASK >> (R * K1 + K)) & 1u)
+        quad_rot<rot>(accr, a.w[R * K1 + K], qc.g[R][i][0], quad_late_frame<-R>() ? late : qc.g[R][i][1], qc.g[R][i][2],
+                      quad_late_frame<R>() ? late : qc.g[R][i][3]);
 }
 // the three unfinished groups, by the second pair: up1 = frame m-1's late tap, dp3 = frame m+3's
 template <int Q, int L, uint32_t MASK, int PH, int OFFS, int K>
@@ -862,7 +882,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
 #define LWS_QUAD 1
 #endif
     // (1,2)+(3,4) in full; (5,6)+(7,0') for bin 7 only: bin 0' belongs to the lane's next frame and keeps its own fetches
-    constexpr bool quad_first = LWS_QUAD && r13 && (PA == 1 || PA == 5), quad_second = LWS_QUAD && r13 && (PA == 3 || PA == 7);
+    constexpr bool quad_first = LWS_QUAD && (PA == 1 || PA == 5), quad_second = LWS_QUAD && (PA == 3 || PA == 7);
     R13Partials<L> p3A, p3B;
     if constexpr (quad_first) {
         // this pair and the neighbour-frame sums of the next one, from 7-cell windows (rows_sum_ahead)
@@ -871,12 +891,12 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
         qc.accB = make_float2(0.f, 0.f);
         static_for<Q - 1>([&](auto ir) {
             constexpr int i = decltype(ir)::value;
-            constexpr int R = (i == 0 ? 2 : (i == 1 ? 3 : 1));
+            constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
             float2 tu[2 * L + 4], td[2 * L + 4];
             static_assert(quad_late_frame<-1>() == quad_late_frame<3>() && !quad_late_frame<-2>() && !quad_late_frame<2>() &&
                           !quad_late_frame<1>() && !quad_late_frame<-3>(), "which frames are late");
-            load_cells<PA, -R, L, 0, (R == 1 && quad_late_frame<-1>() ? L + 1 : L + 2)>(cx, tu);    // frame m-1 cannot deliver its seventh cell yet,
-            load_cells<PA, R, L, 0, (R == 3 && quad_late_frame<3>() ? L + 1 : L + 2)>(cx, td);      // nor can frame m+3
+            load_cells<PA, -R, L, 0, (quad_late_frame<-R>() ? L + 1 : L + 2)>(cx, tu);    // frame m-1 cannot deliver its seventh cell yet,
+            load_cells<PA, R, L, 0, (quad_late_frame<R>() ? L + 1 : L + 2)>(cx, td);      // nor can frame m+3
             rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
             rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
             rows_sum_ahead<Q, L, MASK, PA + 2, R, 2>(a, tu, td, p3C, qc.accA, qc);
@@ -890,20 +910,34 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
         accA = cadd(accA, qc.accA);
         if constexpr (quad_late_frame<-1>()) {
             load_cells<PA - 2, -1, L, L + 1, 1>(cx, u1);
-            load_cells<PA - 2, 3, L, L + 1, 1>(cx, d3);
-            quad_finish<Q, L, MASK, PA, 2, L>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accA);
+            if constexpr (Q > 3) load_cells<PA - 2, 3, L, L + 1, 1>(cx, d3);
+            if constexpr (r13) {
+                quad_finish<Q, L, MASK, PA, 2, L>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accA);
+            } else {
+                quad_finish_plain<Q, L, MASK, PA, 1, 2, L>(a, qc, u1[2 * L + 2], accA);
+                if constexpr (Q > 3) quad_finish_plain<Q, L, MASK, PA, 3, 2, L>(a, qc, d3[2 * L + 2], accA);
+            }
         }
         if constexpr (PA == 3) {
             accB = qc.accB;
             if constexpr (quad_late_frame<-1>()) {
-                quad_finish<Q, L, MASK, PHB, 3, L - 1>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accB);
-                quad_finish<Q, L, MASK, PHB, 3, L>(a, qc, u1[2 * L + 3], d3[2 * L + 3], accB);
+                if constexpr (r13) {
+                    quad_finish<Q, L, MASK, PHB, 3, L - 1>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accB);
+                    quad_finish<Q, L, MASK, PHB, 3, L>(a, qc, u1[2 * L + 3], d3[2 * L + 3], accB);
+                } else {
+                    quad_finish_plain<Q, L, MASK, PHB, 1, 3, L - 1>(a, qc, u1[2 * L + 2], accB);
+                    quad_finish_plain<Q, L, MASK, PHB, 1, 3, L>(a, qc, u1[2 * L + 3], accB);
+                    if constexpr (Q > 3) {
+                        quad_finish_plain<Q, L, MASK, PHB, 3, 3, L - 1>(a, qc, d3[2 * L + 2], accB);
+                        quad_finish_plain<Q, L, MASK, PHB, 3, 3, L>(a, qc, d3[2 * L + 3], accB);
+                    }
+                }
             }
         } else {
             // bin 0' of the lane's next frame: its own view of the taps (images below DC for the lane that starts a frame)
             static_for<Q - 1>([&](auto ir) {
                 constexpr int i = decltype(ir)::value;
-                constexpr int R = (i == 0 ? 2 : (i == 1 ? 3 : 1));
+                constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
                 constexpr uint32_t kmask = (MASK >> (R * K1)) & ((1u << K1) - 1u);
                 float2 tu[2 * L + 2], td[2 * L + 2];
                 load_row2<PA, -R, L, kmask, 2>(cx, tu);
