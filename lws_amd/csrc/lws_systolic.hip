@@ -86,9 +86,6 @@ constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB
 #ifndef LWS_NSLOTS
 #define LWS_NSLOTS (LWS_WIDE ? 3 : 7)
 #endif
-#ifndef LWS_PF
-#define LWS_PF 8
-#endif
 constexpr int NSLOTS = LWS_NSLOTS;                       // sweeps in flight (compute waves)
 constexpr int NSETS = NSLOTS + 1;
 constexpr int NYQ_OFF = NSETS * SET_BYTES;               // Nyquist values: [set][lane] float2
