@@ -707,7 +707,7 @@ __device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[N]
     static_for<L + 1>([&](auto ik) { rows_group<Q, L, MASK, PH, R, OFFS, decltype(ik)::value>(a, tu, td, p3, accr); });
 }
 
-// ---- two pairs of bins from one set of tap windows (FLAG_R13 kernels, the pairs (1,2) and (3,4) of a block) -------------
+// ---- two pairs of bins from one set of tap windows: the pairs (1,2) + (3,4) of a block, and (5,6) + bin 7 ----------------
 // The taps of the pair (3,4) are those of the pair (1,2) moved up by one 16-byte cell: 7 cells per neighbour frame cover
 // both pairs where two separate fetches take 12.  The first pair therefore also sums the neighbour-frame taps of the
 // second pair's bins (the sums do not depend on anything the first pair produces) and hands them over in registers.
@@ -715,7 +715,8 @@ __device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[N]
 // of this lane's: the cell holds what it produces during this very pair) and frame m+3 (previous sweep, 32 - 24 steps
 // ahead).  Exactly three tap groups of frames m-+1 / m-+3 touch those cells: (first bin, k = L), (second bin, k = L-1),
 // (second bin, k = L).  Their other operands are handed over as well and the second pair finishes them after fetching
-// the two cells.
+// the two cells.  (Bin 0' after bin 7 belongs to the lane's next frame -- other images at the frame edge -- and keeps
+// its own fetches.)
 template <int L> struct QuadCarry {
     float2 accA, accB;                               // neighbour-frame sums of the second pair's bins so far
     float2 um1[3], dm1[3], dp1[3], um3[3], c3[3];    // the three unfinished groups: operands of r13_rot() that are known
