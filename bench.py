@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's headline metric on MI355X.
+"""bench.py -- BASELINE.json's headline metric on MI355X, plus one roofline block per BASELINE config.
 
-Workload (BASELINE config 2 / SURVEY.md 8d): B=256 synthetic magnitude spectrograms per GPU, 1024-point
-STFT (F=513 bins, hop 256 => Q=4, L=5), T=500 frames, 100 batch-LWS sweeps, fp32, zero initial phase.
-One "step" = one complete pass of the hot path over the batch: reset the state to the magnitudes,
-build the extended buffers, run the 100 in-place sweeps, extract the result -- everything resident in HBM.
+Headline (what `value` / `roofline` describe): BASELINE config 2 / SURVEY.md 8d -- B=256 synthetic magnitude
+spectrograms per GPU, 1024-point STFT (F=513 bins, hop 256 => Q=4, L=5), T=500 frames, 100 batch-LWS sweeps, fp32,
+zero initial phase.  One "step" = one complete pass of the hot path over the batch: reset the state to the magnitudes,
+convert to the kernel's layout, run the 100 in-place sweeps, convert back -- everything resident in HBM.  The timed
+workload is the DENSE variant (all thresholds 0, every bin updated in every sweep) so that no bin-iteration in the
+count is skipped work; the reference's default schedule 100*exp(-0.1 i) is measured beside it (extra.default_schedule).
 
-The timed workload is the DENSE variant (all 100 thresholds = 0, every bin updated in every sweep) so
-that no bin-iteration in the count is skipped work; the reference's default schedule 100*exp(-0.1 i)
-(51.8 effective sweeps, the first ~38 are no-ops) is measured next to it and reported in "extra".
+`extra.configs` carries one block per other BASELINE config, each with its own roofline (kernel, ms by HIP events on
+the launch stream, algorithmic bytes, fraction of 8 TB/s) and the property checks of the result:
+    2-T1024  the literal north-star shape 1024 x 513 (256 spectrograms of 1024 frames)
+    4shard   config 4's per-GPU shard: 1024 spectrograms of 500 x 513
+    3        run_lws(mode='music'): no-future -> online -> batch, stage by stage
+    5        64 clips of 56 250 frames x 1025 bins (2048-point STFT), 200 sweeps
+    5-f16    the same with fp16-complex storage (fp32 arithmetic)
 
-    python bench.py                       # 1 GPU, finishes in minutes
+    python bench.py                       # 1 GPU, headline + all config blocks, finishes in minutes
+    python bench.py --config 5 --no-extras --steps 1      # one config as the headline (profiling passes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: spectrograms are independent, so each rank owns its own B spectrograms (weak scaling, no
-data-path collective); RCCL is used only for the final consistency-residual all-reduce, outside the
-timed region.  Rank 0 prints ONE JSON line.
+Multi-GPU: spectrograms are independent, so each rank owns its own B spectrograms (weak scaling, no data-path
+collective); RCCL is used only for the final consistency-residual all-reduce, outside the timed region.  Rank 0
+prints ONE JSON line.
 """
 import argparse
 import json
@@ -30,7 +37,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a copy kernel reaches 6.0-6.5 TB/s (bench extra.hbm_copy_gbs_measured)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a copy kernel reaches 6.0-6.5 TB/s (extra.hbm_copy_gbs_measured)
+
+# name -> (B per GPU, T, fsize, fshift, sweeps, storage)
+BATCH_CONFIGS = {
+    "2":       dict(B=256, T=500, fsize=1024, fshift=256, iters=100, storage="fp32",
+                    what="BASELINE config 2: %(B)d spectrograms/GPU x %(T)d frames x %(F)d bins, lws(1024,256) Q=4 L=5"),
+    "2-T1024": dict(B=256, T=1024, fsize=1024, fshift=256, iters=100, storage="fp32",
+                    what="north-star shape: %(B)d spectrograms/GPU of 1024 x 513, lws(1024,256) Q=4 L=5"),
+    "4shard":  dict(B=1024, T=500, fsize=1024, fshift=256, iters=100, storage="fp32",
+                    what="BASELINE config 4, one GPU's shard: %(B)d spectrograms x %(T)d x %(F)d, lws(1024,256)"),
+    "5":       dict(B=64, T=56250, fsize=2048, fshift=512, iters=200, storage="fp32",
+                    what="BASELINE config 5: %(B)d clips x %(T)d frames x %(F)d bins (10 min @ 48 kHz), lws(2048,512) Q=4 L=5"),
+    "5-f16":   dict(B=64, T=56250, fsize=2048, fshift=512, iters=200, storage="fp16",
+                    what="BASELINE config 5 with fp16-complex storage (fp32 arithmetic): %(B)d clips x %(T)d x %(F)d, lws(2048,512)"),
+}
+BYTES_ACTIVE = {"fp32": 20.0, "fp16": 10.0}    # state read + magnitude + state written, per active bin-sweep
+BYTES_INACTIVE = {"fp32": 4.0, "fp16": 2.0}    # magnitude load for the threshold test
 
 
 def synth_magnitudes(B, T, F, first_seed):
@@ -39,6 +62,21 @@ def synth_magnitudes(B, T, F, first_seed):
         g = np.random.default_rng(first_seed + b)
         out[b] = np.abs(g.standard_normal((T, F)) + 1j * g.standard_normal((T, F))).astype(np.float32)
     return out
+
+
+def device_magnitudes(torch, dev, B, T, F, first_seed):
+    """Rayleigh magnitudes of the SURVEY 8(d) generator for shapes numpy handles in seconds; generated on the
+    device (torch Philox, same distribution) for config 5, whose 3.7e9 values would take numpy minutes."""
+    if B * T * F <= (1 << 29):
+        return torch.from_numpy(synth_magnitudes(B, T, F, first_seed)).to(dev), "numpy default_rng(20260928+b)"
+    g = torch.Generator(device=dev)
+    g.manual_seed(first_seed)
+    out = torch.empty((B, T, F), dtype=torch.float32, device=dev)
+    for b in range(B):   # one clip at a time: no 2x temporary of the whole batch
+        re = torch.randn((T, F), generator=g, device=dev)
+        im = torch.randn((T, F), generator=g, device=dev)
+        out[b] = torch.sqrt(re * re + im * im)
+    return out, "torch.randn on the device (Philox, seed 20260928)"
 
 
 def cpu_baseline(W, T, F, iters, budget_s=12.0):
@@ -87,17 +125,37 @@ def cpu_baseline(W, T, F, iters, budget_s=12.0):
             "all_cores_value": ncores * T * F * sweeps / wall, "all_cores": ncores}
 
 
+def load_traffic(kname, config):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*.json): NOT measured in
+    this run -- PMC collection needs the profiler around the process (tools/profile.sh regenerates the files)."""
+    for fn in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        ent = d.get("configs", {}).get(config) or (d.get(kname) if config == "2" else None)
+        if ent and ent.get("hbm_bytes_per_launch"):
+            return ent["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; not this run)" % fn
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="spectrograms per GPU")
-    ap.add_argument("--frames", type=int, default=500)
-    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--config", default="2", choices=sorted(BATCH_CONFIGS), help="headline workload (default: BASELINE config 2)")
+    ap.add_argument("--batch", type=int, default=None, help="spectrograms per GPU (default: the config's)")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--iters", type=int, default=None)
+    ap.add_argument("--schedule", default="dense", choices=["dense", "default"], help="thresholds of the headline workload")
+    ap.add_argument("--extras", default=None, help="comma list of config blocks for extra.configs (default: all at N=1, 4shard at N>1)")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-default-schedule", action="store_true")
-    ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     args = ap.parse_args()
 
@@ -116,19 +174,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-
-    B, T, F, iters = args.batch, args.frames, 513, args.iters
-    p = lws_amd.lws(1024, 256, device=local_rank, force_generic=args.force_generic)  # default sqrt-Hann pair, L=5, Q=4
-    plan = p.plan()
-    mags = torch.from_numpy(synth_magnitudes(B, T, F, 20260928 + rank * B)).to(dev)
-    state = torch.zeros((B, T, F), dtype=torch.complex64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    thr_dense = np.zeros(iters)
-    thr_default = lws_amd.get_thresholds(iters, 100, 0.1, 1)
-
-    def step(thr):
-        state.copy_(mags)  # zero phase: real, non-negative input exactly like run_lws(np.abs(X))
-        plan.batch_dev(state.data_ptr(), B, T, thr, stream=stream)
+    have_f16 = hasattr(lws_amd._capi, "LWS_STORAGE_FP16")
 
     def sync_all():
         torch.cuda.synchronize()
@@ -136,9 +183,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(thr, steps, warmup):
-        for _ in range(warmup):
-            step(thr)
+    plans = {}
+
+    def engine(fsize, fshift, storage="fp32", mode=None):
+        key = (fsize, fshift, storage, mode)
+        if key not in plans:
+            kw = dict(device=local_rank, force_generic=args.force_generic)
+            if storage == "fp16":
+                kw["storage"] = "fp16"
+            if mode:
+                kw["mode"] = mode
+            plans[key] = lws_amd.lws(fsize, fshift, **kw)
+        return plans[key]
+
+    def run_batch_config(name, steps, warmup, schedule="dense", B=None, T=None, iters=None, checks=True):
+        """Time `steps` passes of one batch-LWS configuration; returns the block with its roofline."""
+        cfg = dict(BATCH_CONFIGS[name])
+        B = B or cfg["B"]; T = T or cfg["T"]; iters = iters or cfg["iters"]
+        F = cfg["fsize"] // 2 + 1
+        storage = cfg["storage"]
+        p = engine(cfg["fsize"], cfg["fshift"], storage)
+        plan = p.plan()
+        mags, gen = device_magnitudes(torch, dev, B, T, F, 20260928 + rank * B)
+        state = torch.empty((B, T, F), dtype=torch.complex64, device=dev)
+        thr = np.zeros(iters) if schedule == "dense" else lws_amd.get_thresholds(iters, 100, 0.1, 1)
+
+        def step(th):
+            state.copy_(mags)  # zero phase: real, non-negative input exactly like run_lws(np.abs(X))
+            plan.batch_dev(state.data_ptr(), B, T, th, stream=stream)
+
+        for i in range(warmup):
+            step(thr if B * T * F <= (1 << 29) else thr[:min(3, iters)])   # big shapes: a short call allocates the same scratch
         sync_all()
         kms, launches = 0.0, 0
         t0 = time.perf_counter()
@@ -153,29 +228,51 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, kms, launches, info["name"]
+        units = float(B) * T * F * iters
+        if schedule == "dense":
+            active = units
+        else:
+            mean = mags.mean(dim=(1, 2), keepdim=True)
+            active = sum(float((mags > float(t) * mean).sum().item()) for t in thr)
+        alg = (BYTES_ACTIVE[storage] - BYTES_INACTIVE[storage]) * active + BYTES_INACTIVE[storage] * units   # per GPU
+        k_ms = kms / steps
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        traffic, tsrc = load_traffic(info["name"], name)
+        blk = {
+            "workload": (cfg["what"] % dict(B=B, T=T, F=F)) + ", %d %s batch-LWS sweeps" % (iters, "dense (all thresholds 0)" if schedule == "dense" else "default-schedule (100 exp(-0.1 i))"),
+            "batch_per_gpu": B, "frames": T, "bins": F, "iters": iters, "schedule": schedule, "storage": storage,
+            "data": "synthetic Rayleigh magnitudes, %s, zero phase" % gen,
+            "steps": steps, "ms_per_step": 1e3 * dt / steps, "value": units * world / (dt / steps),
+            "active_value": active * world / (dt / steps), "effective_sweeps": active / (float(B) * T * F),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": tsrc, "kernel": info["name"], "kernel_ms_per_step": k_ms,
+                         "launches_per_step": launches / steps,
+                         "algorithmic_bytes_per_launch": alg / max(1.0, launches / steps)},
+        }
+        if checks:
+            # size-independent properties of the result (the -m gpu tests assert the same ones at these sizes)
+            n_chk = min(B, 4)
+            out = state[:n_chk]
+            mg = mags[:n_chk]
+            tol = 1e-6 if storage == "fp32" else 2e-3
+            blk["checks"] = {"max_rel_magnitude_error": float(((out.abs() - mg).abs().max() / mg.max()).item()), "magnitude_tolerance": tol,
+                             "finite": bool(torch.isfinite(torch.view_as_real(state)).all().item())}
+            if cfg["fsize"] <= 2048:
+                c0 = lws_amd._capi.consistency_dev(mags[:1].to(torch.complex64).data_ptr(), 1, T, cfg["fsize"], cfg["fshift"], p.awin, p.swin,
+                                                   p.perfectrec, device=local_rank, stream=stream)
+                c1 = lws_amd._capi.consistency_dev(out.data_ptr(), 1, T, cfg["fsize"], cfg["fshift"], p.awin, p.swin, p.perfectrec,
+                                                   device=local_rank, stream=stream)
+                blk["checks"]["consistency_db_before"] = float(10 * np.log10(c0[0, 0] / c0[0, 1]))
+                blk["checks"]["consistency_db_after"] = float(10 * np.log10(c1[0, 0] / c1[0, 1]))
+        return blk, (p, plan, mags, state)
 
-    dt, kms, launches, kname = timed(thr_dense, args.steps, args.warmup)
-    ms_per_step = 1e3 * dt / args.steps
-    units_per_step = float(B) * T * F * iters * world
-    value = units_per_step / (dt / args.steps)
+    # ---- headline ---------------------------------------------------------------------------------------------------
+    head, (p, plan, mags, state) = run_batch_config(args.config, args.steps, args.warmup, schedule=args.schedule,
+                                                    B=args.batch, T=args.frames, iters=args.iters)
+    B, T, F, iters = head["batch_per_gpu"], head["frames"], head["bins"], head["iters"]
+    roof = dict(head["roofline"])
+    extra = {"headline_checks": head.get("checks")}
 
-    # roofline of the dominant (update) kernel: algorithmic bytes = 20 B per active bin-iteration
-    alg_bytes_per_step = 20.0 * B * T * F * iters  # per GPU
-    k_ms_per_step = kms / args.steps
-    achieved = alg_bytes_per_step / (k_ms_per_step * 1e-3) / 1e9
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
-            "kernel_ms_per_step": k_ms_per_step, "launches_per_step": launches / args.steps,
-            "algorithmic_bytes_per_launch": alg_bytes_per_step / max(1.0, launches / args.steps)}
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            roof["traffic"] = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-
-    extra = {}
     # measured HBM copy rate of this GPU with the library's own stream-copy kernel (quote the fraction
     # against the measured copy peak as well as the spec peak); read + write bytes both counted
     nbytes = 1 << 30
@@ -191,97 +288,153 @@ def main():
     copy_gbs = 2.0 * nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src, dst
     extra["hbm_copy_gbs_measured"] = copy_gbs
-    roof["frac_of_measured_copy"] = achieved / copy_gbs
-    if not args.no_default_schedule:
-        dt2, kms2, _, _ = timed(thr_default, max(1, args.steps), 1)
-        mean = mags.mean(dim=(1, 2), keepdim=True)
-        active = sum(float((mags > float(t) * mean).sum().item()) for t in thr_default)
-        extra["default_schedule"] = {
-            "nominal_value": units_per_step / (dt2 / max(1, args.steps)),
-            "active_value": active * world / (dt2 / max(1, args.steps)),
-            "effective_sweeps": active / (B * T * F),
-            "ms_per_step": 1e3 * dt2 / max(1, args.steps),
-            "algorithmic_GBs": (16.0 * active + 4.0 * B * T * F * iters) / (kms2 / max(1, args.steps) * 1e-3) / 1e9}
+    roof["frac_of_measured_copy"] = roof["achieved"] / copy_gbs
 
-    # latency of ONE spectrogram of the same shape and schedule: its passes over HBM are pipelined over several
-    # workgroups ("fewer spectrograms than CUs")
-    if not args.no_config3:
-        one = state[:1].clone()
-        for rep in range(2):
-            one.copy_(mags[:1])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            plan.batch_dev(one.data_ptr(), 1, T, thr_dense, stream=stream)
-            info = plan.last_kernel()
-            torch.cuda.synchronize()
-            extra["single_spectrogram"] = {"wall_ms": 1e3 * (time.perf_counter() - t0), "kernel_ms": info["ms"],
-                                           "kernel": info["name"]}
+    # optional final consistency-residual reduction (the only collective): sum over all spectrograms of all ranks
+    if B * T * F <= (1 << 29):
+        res = plan.residual_dev(state.data_ptr(), B, T, stream=stream)
+        tot = torch.tensor(res.sum(axis=0), dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        extra["residual_db_after"] = float(10 * np.log10(tot[1].item() / tot[0].item()))
+        # the true consistency 20 log10(|S| / |STFT(iSTFT(S)) - S|) (lws.pyx:140-144) of the same result, on the device
+        # (lws_stft.hip), summed over all spectrograms of all ranks with the same all-reduce
+        t0 = time.perf_counter()
+        sums = lws_amd._capi.consistency_dev(state.data_ptr(), B, T, p.fsize, p.fshift, p.awin, p.swin, p.perfectrec,
+                                              device=local_rank, stream=stream)
+        extra["consistency_ms"] = 1e3 * (time.perf_counter() - t0)
+        tot2 = torch.tensor(sums.sum(axis=0), dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tot2, op=dist.ReduceOp.SUM)
+        extra["consistency_db_after"] = float(10 * np.log10(tot2[0].item() / tot2[1].item()))
+    del mags, state
+    torch.cuda.empty_cache()
 
-    # BASELINE config 3: the run_lws pipeline of lws(1024, 256, mode='music') -- 1 no-future sweep (W_ai, alpha 1),
-    # 10 online iterations with look-ahead 3, 100 batch sweeps of the default schedule -- stage by stage on the device
-    if not args.no_config3:
-        pm = lws_amd.lws(1024, 256, mode="music", device=local_rank, force_generic=args.force_generic)
-        planm = pm.plan()
-        stages = [
-            ("nofuture", lambda: planm.nofuture_dev(state.data_ptr(), B, T, lws_amd.get_thresholds(
-                pm.nofuture_iterations, pm.nofuture_alpha, pm.nofuture_beta, pm.nofuture_gamma), wsel=1, stream=stream)),
-            ("online", lambda: planm.online_dev(state.data_ptr(), B, T, lws_amd.get_thresholds(
-                pm.online_iterations, pm.online_alpha, pm.online_beta, pm.online_gamma), pm.look_ahead, 4.0, stream=stream)),
-            ("batch", lambda: planm.batch_dev(state.data_ptr(), B, T, lws_amd.get_thresholds(
-                pm.batch_iterations, pm.batch_alpha, pm.batch_beta, pm.batch_gamma), stream=stream)),
-        ]
-        c3 = {}
-        for rep in range(2):   # second repetition is the one reported
-            state.copy_(mags)
-            sync_all()
-            t_all = time.perf_counter()
-            for name, fn in stages:
-                t0 = time.perf_counter()
-                fn()
-                info = planm.last_kernel()
-                torch.cuda.synchronize()
-                c3[name] = {"wall_ms": 1e3 * (time.perf_counter() - t0), "kernel_ms": info["ms"], "kernel": info["name"]}
-            c3["total_wall_ms"] = 1e3 * (time.perf_counter() - t_all)
-        c3["iterations"] = {"nofuture": pm.nofuture_iterations, "online": pm.online_iterations, "batch": pm.batch_iterations,
-                            "look_ahead": pm.look_ahead}
-        extra["config3_run_lws_music"] = c3
-
-    # optional final consistency-residual reduction (the only collective): sum over all spectrograms
-    step(thr_dense)
-    res = plan.residual_dev(state.data_ptr(), B, T, stream=stream)
-    tot = torch.tensor(res.sum(axis=0), dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    extra["residual_db_after"] = float(10 * np.log10(tot[1].item() / tot[0].item()))
-    # the true consistency 20 log10(|S| / |STFT(iSTFT(S)) - S|) (lws.pyx:140-144) of the same result, on the device
-    # (lws_stft.hip), summed over all spectrograms of all ranks with the same all-reduce
-    t0 = time.perf_counter()
-    sums = lws_amd._capi.consistency_dev(state.data_ptr(), B, T, 1024, 256, p.awin, p.swin, p.perfectrec,
-                                          device=local_rank, stream=stream)
-    extra["consistency_ms"] = 1e3 * (time.perf_counter() - t0)
-    tot2 = torch.tensor(sums.sum(axis=0), dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot2, op=dist.ReduceOp.SUM)
-    extra["consistency_db_after"] = float(10 * np.log10(tot2[0].item() / tot2[1].item()))
+    if args.no_extras:
+        wanted = []
+    elif args.extras is not None:
+        wanted = [x for x in args.extras.split(",") if x]
+    elif world == 1 and args.config == "2":
+        wanted = ["2-default", "2-single", "2-T1024", "4shard", "3", "5", "5-f16"]
+    else:
+        wanted = ["4shard"] if args.config == "2" else []
+    if args.no_default_schedule and "2-default" in wanted:
+        wanted.remove("2-default")
+    cfgs = {}
+    for name in wanted:
+        try:
+            if name == "2-default":
+                # the reference's default schedule on the headline shape (51.8 effective sweeps; the first ~38 are no-ops)
+                blk, keep = run_batch_config("2", max(1, args.steps), 1, schedule="default")
+                extra["default_schedule"] = blk
+                del keep
+            elif name == "2-single":
+                # latency of ONE spectrogram of the headline shape: its passes over HBM are pipelined over several workgroups
+                blk, keep = run_batch_config("2", 2, 1, B=1, checks=False)
+                extra["single_spectrogram"] = {"wall_ms": blk["ms_per_step"], "kernel_ms": blk["roofline"]["kernel_ms_per_step"],
+                                               "kernel": blk["roofline"]["kernel"]}
+                del keep
+            elif name == "3":
+                cfgs["3"] = run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, args.force_generic)
+            elif name in BATCH_CONFIGS:
+                if BATCH_CONFIGS[name]["storage"] == "fp16" and not have_f16:
+                    cfgs[name] = {"skipped": "this build has no fp16 storage mode"}
+                    continue
+                big = name.startswith("5")
+                blk, keep = run_batch_config(name, 1 if big else 2, 1)
+                del keep
+                cfgs[name] = blk
+                if big:   # the schedule BASELINE names for config 5 (get_thresholds(200, 100, 0.1, 1)), beside the dense roofline
+                    blk2, keep = run_batch_config(name, 1, 0, schedule="default", checks=False)
+                    del keep
+                    blk["default_schedule"] = {k: blk2[k] for k in ("ms_per_step", "value", "active_value", "effective_sweeps")}
+                    blk["default_schedule"]["algorithmic_GBs"] = blk2["roofline"]["achieved"]
+            else:
+                cfgs[name] = {"skipped": "unknown config"}
+        except Exception as e:   # a failing extra must not take the headline line with it
+            cfgs[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        torch.cuda.empty_cache()
+    if cfgs:
+        extra["configs"] = cfgs
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(p.W, T, F, iters)
+    if rank == 0 and not args.no_cpu_baseline:   # rank 0's host cores, outside every timed region
+        cpu = cpu_baseline(p.W, min(T, 500), F, iters)
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         line = {
-            "metric": "complex bins*iters/sec (batch LWS, 1024-pt STFT)", "value": value, "unit": "bin*iter/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic Rayleigh magnitudes, numpy default_rng(20260928+b), zero phase",
-            "config": {"workload": "BASELINE config 2: %d spectrograms/GPU x %d frames x %d bins, lws(1024,256) "
-                                   "Q=4 L=5, %d dense batch-LWS sweeps (all thresholds 0)" % (B, T, F, iters),
-                       "batch_per_gpu": B, "frames": T, "bins": F, "iters": iters, "parallelism": "shard%d" % world},
+            "metric": "complex bins*iters/sec (batch LWS, %d-pt STFT)" % p.fsize, "value": head["value"], "unit": "bin*iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if head["storage"] == "fp32" else "f32 math / f16 storage",
+            "data": head["data"],
+            "config": {"workload": head["workload"], "batch_per_gpu": B, "frames": T, "bins": F, "iters": iters,
+                       "parallelism": "shard%d" % world},
+            "parity_of_timed_workload": ("quality-level: the dense schedule from a zero-phase start is ill-conditioned (DESIGN 6); fp32 is "
+                                         "checked by magnitudes + consistency, the schedule by the fp64 plan; the default schedule "
+                                         "(extra.default_schedule) is checked value by value against the oracle (tests/test_gpu_parity.py)"),
             "roofline": roof, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, force_generic, B=256, T=500):
+    """BASELINE config 3: the run_lws pipeline of lws(1024, 256, mode='music') -- 1 no-future sweep (W_ai, alpha 1),
+    10 online iterations with look-ahead 3, 100 batch sweeps of the default schedule -- stage by stage on the device,
+    each stage with its own roofline block (algorithmic bytes of SURVEY 8(d): 20 B per active bin-sweep, 4 B per
+    inactive one; the online stage runs 1 + iters*(LA+1) frame sweeps per frame)."""
+    F = 513
+    pm = lws_amd.lws(1024, 256, mode="music", device=local_rank, force_generic=force_generic)
+    planm = pm.plan()
+    mags = torch.from_numpy(synth_magnitudes(B, T, F, 20260928 + rank * B)).to(dev)
+    state = torch.empty((B, T, F), dtype=torch.complex64, device=dev)
+    thr_nf = lws_amd.get_thresholds(pm.nofuture_iterations, pm.nofuture_alpha, pm.nofuture_beta, pm.nofuture_gamma)
+    thr_on = lws_amd.get_thresholds(pm.online_iterations, pm.online_alpha, pm.online_beta, pm.online_gamma)
+    thr_b = lws_amd.get_thresholds(pm.batch_iterations, pm.batch_alpha, pm.batch_beta, pm.batch_gamma)
+    stages = [
+        ("nofuture", thr_nf, 1, lambda: planm.nofuture_dev(state.data_ptr(), B, T, thr_nf, wsel=1, stream=stream)),
+        ("online", thr_on, pm.look_ahead + 1, lambda: planm.online_dev(state.data_ptr(), B, T, thr_on, pm.look_ahead, 4.0, stream=stream)),
+        ("batch", thr_b, 1, lambda: planm.batch_dev(state.data_ptr(), B, T, thr_b, stream=stream)),
+    ]
+    c3 = {"workload": "BASELINE config 3: run_lws(mode='music') on %d spectrograms of %d x %d, lws(1024,256): 1 no-future sweep, "
+                      "10 online iterations (look-ahead 3), 100 default-schedule batch sweeps" % (B, T, F)}
+    for rep in range(2):   # second repetition is the one reported
+        state.copy_(mags)
+        sync_all()
+        t_all = time.perf_counter()
+        for name, thr, sweeps_per_thr, fn in stages:
+            cur = state.abs()
+            mean = cur.mean(dim=(1, 2), keepdim=True)
+            t0 = time.perf_counter()
+            fn()
+            info = planm.last_kernel()
+            torch.cuda.synchronize()
+            wall = 1e3 * (time.perf_counter() - t0)
+            # bin-sweeps of the stage: the online driver also runs one initial sweep (threshold 0) per frame
+            act = sum(float((cur > float(t) * mean).sum().item()) for t in thr) * sweeps_per_thr
+            nominal = float(B) * T * F * len(thr) * sweeps_per_thr
+            if name == "online":
+                act += float(B) * T * F
+                nominal += float(B) * T * F
+            alg = 16.0 * act + 4.0 * nominal
+            ach = alg / (info["ms"] * 1e-3) / 1e9
+            c3[name] = {"wall_ms": wall, "kernel_ms": info["ms"], "kernel": info["name"], "bin_sweeps": nominal, "active_bin_sweeps": act,
+                        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                     "algorithmic_bytes_per_launch": alg, "kernel": info["name"], "kernel_ms_per_step": info["ms"]}}
+        c3["total_wall_ms"] = 1e3 * (time.perf_counter() - t_all)
+    c3["iterations"] = {"nofuture": pm.nofuture_iterations, "online": pm.online_iterations, "batch": pm.batch_iterations,
+                        "look_ahead": pm.look_ahead}
+    c0 = lws_amd._capi.consistency_dev(mags[:4].to(torch.complex64).data_ptr(), 4, T, 1024, 256, pm.awin, pm.swin, pm.perfectrec,
+                                       device=local_rank, stream=stream).sum(axis=0)
+    c1 = lws_amd._capi.consistency_dev(state[:4].data_ptr(), 4, T, 1024, 256, pm.awin, pm.swin, pm.perfectrec,
+                                       device=local_rank, stream=stream).sum(axis=0)
+    c3["checks"] = {"max_rel_magnitude_error": float(((state.abs() - mags).abs().max() / mags.max()).item()),
+                    "consistency_db_before": float(10 * np.log10(c0[0] / c0[1])), "consistency_db_after": float(10 * np.log10(c1[0] / c1[1]))}
+    return c3
 
 
 if __name__ == "__main__":

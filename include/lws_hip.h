@@ -50,8 +50,14 @@ enum {
     LWS_PRECISION_FP64 = 1,        /* fp64 everywhere (reference arithmetic; slow path only) */
     LWS_NOFUTURE_Q4_COMPAT = 2,    /* reproduce NoFuture_LWSQ4's addressing (lwslib.cpp:559-594) when Q == Qp == 4 */
     LWS_FORCE_GENERIC = 4,         /* never use the specialised systolic batch kernel */
-    LWS_NO_DIRECT_IO = 8           /* always go through the extended buffers (prep / extract passes), even for a call
+    LWS_NO_DIRECT_IO = 8,          /* always go through the extended buffers (prep / extract passes), even for a call
                                       that is one batch stage on device complex64 data -- for comparison */
+    LWS_STORAGE_FP16 = 16          /* fp16-complex storage (BASELINE config 5): between passes over HBM the batch kernel keeps
+                                      the spectrogram as half2 and the target magnitudes as half (10 B instead of 20 B per
+                                      active bin and sweep), scaled per spectrogram by the power of two that brings its
+                                      largest magnitude to [1, 2); arithmetic stays fp32.  The reference has no such mode
+                                      (every pointer of lwslib.h:6-26 is double*): tolerance in DESIGN.md section 6.
+                                      Applies to batch sweeps the systolic kernel serves; I/O stays complex64 / complex128 */
 };
 
 /* which of the plan's weight tensors a call uses (class lws passes W_ai to nofuture_lws, lws.pyx:475) */
@@ -104,11 +110,25 @@ int lws_nofuture_lws_dev(lws_plan *plan, int wsel, void *S_dev, int B, int T,
 int lws_online_lws_dev(lws_plan *plan, void *S_dev, int B, int T,
                        const double *thresholds, int iters, int LA, double qdiv, void *stream);
 
+/* lws.lws.run_lws on device-resident spectrograms (in place), the three stages enqueued back to back on `stream`. */
+int lws_run_lws_dev(lws_plan *plan, void *S_dev, int B, int T,
+                    const double *thr_nofuture, int it_nofuture,
+                    const double *thr_online, int it_online, int LA, double qdiv,
+                    const double *thr_batch, int it_batch, void *stream);
+
+/* Pre-size every scratch buffer of the plan for calls of up to B spectrograms of T frames and `max_iters` thresholds
+ * per stage.  The *_dev entry points only enqueue work and return -- unless a scratch buffer has to grow, which is a
+ * (synchronising) hipMalloc: reserve once and they never allocate.  The reference allocates per call (lws.pyx:227-240;
+ * the mex gateways malloc and never free, batch_lws.cpp:81-118). */
+int lws_plan_reserve(lws_plan *plan, int B, int T, int max_iters);
+
 /* Consistency-residual proxy: for each spectrogram b
  *   out[2b]   = sum over bins of |acc + w00*S|^2   (acc = the LWS weighted sum, w00 = W[0][0][0])
  *   out[2b+1] = sum over bins of |S|^2
  * in fp64, on the device buffer `S_dev`.  out is a HOST array of 2*B doubles (synchronises). */
 int lws_residual_dev(lws_plan *plan, const void *S_dev, int B, int T, double *out, void *stream);
+/* The same for HOST spectrograms S[B][T][F] complex128. */
+int lws_residual(lws_plan *plan, const double *S, int B, int T, double *out);
 
 /* Timing of the most recent *_dev / host call on this plan, measured with HIP events on the
  * stream the kernels ran on: total milliseconds spent in the update kernels and the number of
@@ -163,6 +183,27 @@ int lws_get_thresholds(int iterations, double alpha, double beta, double gamma, 
  * created.  awin_out / swin_out (may be NULL) receive the windows actually used, fsize doubles each. */
 int lws_plan_create_from_windows(lws_plan **plan, int device, const double *awin, const double *swin, int fsize,
                                  int fshift, int L, int symmetric_win, unsigned flags, double *awin_out, double *swin_out);
+
+/* ---- one node, several GPUs, no torch: independent spectrograms are dealt in contiguous blocks to one plan per device,
+ *      each driven by its own host thread and stream; no exchange between devices during the sweeps.
+ *      `devices`: ndev HIP ordinals, or NULL for devices 0..ndev-1; ndev <= 0 means every visible device.  A device may
+ *      be listed more than once (several shards on one GPU).  What a mex gateway or a C++ caller uses where the Python
+ *      layer uses one process per GPU (bench.py). ---- */
+typedef struct lws_multi_plan lws_multi_plan; /* opaque */
+int lws_multi_plan_create(lws_multi_plan **mp, int ndev, const int *devices, int F, int L, int Q, int Qp,
+                          const double *W, const double *W_ai, const double *W_af, unsigned flags);
+void lws_multi_plan_destroy(lws_multi_plan *mp);
+int lws_multi_plan_shards(const lws_multi_plan *mp);
+/* lws_batch_lws / lws_run_lws over all shards; S_out may alias S_in; same results as one plan on one device. */
+int lws_multi_batch_lws(lws_multi_plan *mp, int wsel, const double *S_in, double *S_out, int B, int T,
+                        const double *thresholds, int iters);
+int lws_multi_run_lws(lws_multi_plan *mp, const double *S_in, double *S_out, int B, int T,
+                      const double *thr_nofuture, int it_nofuture,
+                      const double *thr_online, int it_online, int LA, double qdiv,
+                      const double *thr_batch, int it_batch);
+/* The job's consistency-residual pair (see lws_residual_dev) of HOST spectrograms S[B][T][F] complex128, summed over all
+ * shards on the host: out[0] = sum |acc + w00 S|^2, out[1] = sum |S|^2. */
+int lws_multi_residual(lws_multi_plan *mp, const double *S, int B, int T, double *out);
 
 #ifdef __cplusplus
 }

@@ -9,4 +9,4 @@ from .lws import (  # noqa: F401
     build_asymmetric_windows, get_thresholds, batch_lws, nofuture_lws, online_lws, lws,
 )
 from . import _capi  # noqa: F401
-from ._capi import Plan, LwsHipError  # noqa: F401
+from ._capi import Plan, MultiPlan, LwsHipError  # noqa: F401

@@ -1,9 +1,12 @@
-"""ctypes binding of liblws_hip.so (include/lws_hip.h).
+"""Python binding of liblws_hip.so (include/lws_hip.h).
 
-This is the binding a maintainer of the reference would add next to ``lwslib.pxd``: the Cython
-``cdef extern`` block of python/lwslib.pxd:1-13 is replaced by the ``extern "C"`` prototypes
-below (see INTEGRATION.md for the equivalent .pxd).  The library is mandatory: if it cannot be
-loaded the LWS entry points raise -- there is no CPU fallback in the product path.
+Two interchangeable bindings of the same C ABI:
+  * ``lws_amd/_cylws`` -- the Cython shim (``_cylws.pyx`` over ``csrc/lws_hip.pxd``), the counterpart of the reference's
+    python/lws.pyx over python/lwslib.pxd:1-13; every call releases the GIL.  Built by ``make -C lws_amd/csrc``.
+  * ctypes -- the same prototypes declared below; used when the extension is absent (or ``LWS_BINDING=ctypes``).
+``load()`` returns whichever is in use; both expose the C functions under their C names with the C argument order.
+The library itself is mandatory: if it cannot be loaded the LWS entry points raise -- there is no CPU fallback in the
+product path.
 """
 from __future__ import annotations
 
@@ -18,6 +21,7 @@ LIB_PATH = os.environ.get("LWS_HIP_LIB", os.path.join(_HERE, "liblws_hip.so"))  
 # lws_hip.h enums
 LWS_OK, LWS_ERR_INVALID, LWS_ERR_HIP, LWS_ERR_NOMEM, LWS_ERR_UNSUPPORTED = range(5)
 LWS_PRECISION_FP32, LWS_PRECISION_FP64, LWS_NOFUTURE_Q4_COMPAT, LWS_FORCE_GENERIC, LWS_NO_DIRECT_IO = 0, 1, 2, 4, 8
+LWS_STORAGE_FP16 = 16
 LWS_W, LWS_W_AI, LWS_W_AF = 0, 1, 2
 
 EXPORTS = (
@@ -27,9 +31,12 @@ EXPORTS = (
     "lws_last_kernel_name", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev",
     "lws_consistency_dev", "lws_hann", "lws_synthwin", "lws_weights_shape", "lws_create_weights",
     "lws_build_asymmetric_windows", "lws_get_thresholds", "lws_plan_create_from_windows", "lws_stream_copy",
+    "lws_run_lws_dev", "lws_plan_reserve", "lws_residual", "lws_multi_plan_create", "lws_multi_plan_destroy",
+    "lws_multi_plan_shards", "lws_multi_batch_lws", "lws_multi_run_lws", "lws_multi_residual",
 )
 
 _lib = None
+BINDING = None   # "cython" or "ctypes", set by load()
 
 
 class LwsHipError(RuntimeError):
@@ -54,7 +61,18 @@ def load():
             torch.cuda.init()
     except Exception:  # no torch, or no usable device: nothing to order
         pass
+    global BINDING
+    if os.environ.get("LWS_BINDING", "cython") != "ctypes" and "LWS_HIP_LIB" not in os.environ:
+        try:
+            from . import _cylws   # links liblws_hip.so next to it (rpath $ORIGIN)
+            for name in EXPORTS:
+                getattr(_cylws, name)
+            _lib, BINDING = _cylws, "cython"
+            return _lib
+        except ImportError:
+            pass   # extension not built: the ctypes binding below serves the same ABI
     lib = C.CDLL(LIB_PATH)
+    BINDING = "ctypes"
     vp, ip = C.c_void_p, C.c_int
     lib.lws_hip_version.restype = C.c_int
     lib.lws_last_error.restype = C.c_char_p
@@ -87,10 +105,27 @@ def load():
     lib.lws_build_asymmetric_windows.argtypes = [vp, ip, ip, vp, vp]
     lib.lws_get_thresholds.argtypes = [ip, dp, dp, dp, vp]
     lib.lws_plan_create_from_windows.argtypes = [C.POINTER(vp), ip, vp, vp, ip, ip, ip, ip, C.c_uint, vp, vp]
+    lib.lws_run_lws_dev.argtypes = [vp, vp, ip, ip, vp, ip, vp, ip, ip, C.c_double, vp, ip, vp]
+    lib.lws_plan_reserve.argtypes = [vp, ip, ip, ip]
+    lib.lws_residual.argtypes = [vp, vp, ip, ip, vp]
+    lib.lws_multi_plan_create.argtypes = [C.POINTER(vp), ip, vp, ip, ip, ip, ip, vp, vp, vp, C.c_uint]
+    lib.lws_multi_plan_destroy.argtypes = [vp]
+    lib.lws_multi_plan_destroy.restype = None
+    lib.lws_multi_plan_shards.argtypes = [vp]
+    lib.lws_multi_batch_lws.argtypes = [vp, ip, vp, vp, ip, ip, vp, ip]
+    lib.lws_multi_run_lws.argtypes = [vp, vp, vp, ip, ip, vp, ip, vp, ip, ip, C.c_double, vp, ip]
+    lib.lws_multi_residual.argtypes = [vp, vp, ip, ip, vp]
     for name in EXPORTS:  # fail at load time, not at first use, if a symbol is missing
         getattr(lib, name)
     _lib = lib
     return lib
+
+
+def load_raw():
+    """The library as a plain ctypes handle (no prototypes declared): for symbols outside include/lws_hip.h, i.e. the
+    C++-mangled lwslib.h interface of include/lwslib_compat.h."""
+    load()   # (initialisation order with PyTorch's runtime, see load())
+    return C.CDLL(LIB_PATH)
 
 
 def check(rc):
@@ -114,7 +149,7 @@ class Plan:
     """Owns an ``lws_plan`` (device copies of W / W_ai / W_af for one (F, L, Q) shape)."""
 
     def __init__(self, F, W, W_ai=None, W_af=None, device=0, precision="fp32",
-                 nofuture_q4_compat=True, force_generic=False, direct_io=True):
+                 nofuture_q4_compat=True, force_generic=False, direct_io=True, storage="fp32"):
         lib = load()
         W = _c128(W)
         if W.ndim != 3:
@@ -143,6 +178,11 @@ class Plan:
             flags |= LWS_FORCE_GENERIC
         if not direct_io:
             flags |= LWS_NO_DIRECT_IO
+        if storage == "fp16":
+            flags |= LWS_STORAGE_FP16
+        elif storage != "fp32":
+            raise ValueError("storage must be 'fp32' or 'fp16'")
+        self.storage = storage
         self.precision = precision
         self.device = int(device)
         h = C.c_void_p()
@@ -224,6 +264,22 @@ class Plan:
         t, tp = self._thr(thresholds)
         check(self._lib.lws_online_lws_dev(self._h, ptr, B, T, tp, t.size, int(LA), float(qdiv), stream))
 
+    def run_dev(self, ptr, B, T, thr_nofuture, thr_online, LA, qdiv, thr_batch, stream=None):
+        t0, p0 = self._thr(thr_nofuture)
+        t1, p1 = self._thr(thr_online)
+        t2, p2 = self._thr(thr_batch)
+        check(self._lib.lws_run_lws_dev(self._h, ptr, B, T, p0, t0.size, p1, t1.size, int(LA), float(qdiv), p2, t2.size, stream))
+
+    def reserve(self, B, T, max_iters):
+        """Pre-size all scratch so that later *_dev calls of up to this shape only enqueue work (no hipMalloc)."""
+        check(self._lib.lws_plan_reserve(self._h, int(B), int(T), int(max_iters)))
+
+    def residual(self, S):
+        S, S3, _ = self._io(S)
+        out = np.empty((S3.shape[0], 2), dtype=np.float64)
+        check(self._lib.lws_residual(self._h, S3.ctypes.data, S3.shape[0], S3.shape[1], out.ctypes.data))
+        return out
+
     def residual_dev(self, ptr, B, T, stream=None):
         out = np.empty((B, 2), dtype=np.float64)
         check(self._lib.lws_residual_dev(self._h, ptr, B, T, out.ctypes.data, stream))
@@ -234,6 +290,74 @@ class Plan:
         check(self._lib.lws_last_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return {"ms": ms.value, "launches": n.value,
                 "name": self._lib.lws_last_kernel_name(self._h).decode()}
+
+
+class MultiPlan:
+    """One plan per device behind one handle (``lws_multi_*``): a batch is dealt in contiguous blocks to the devices,
+    one host thread per device inside the library.  ``devices``: list of HIP ordinals (a device may repeat), or None
+    for every visible device."""
+
+    def __init__(self, F, W, W_ai=None, W_af=None, devices=None, precision="fp32", nofuture_q4_compat=True,
+                 force_generic=False, storage="fp32"):
+        lib = load()
+        W = _c128(W)
+        self.Qp, self.Q, self.L = W.shape[0], W.shape[1], W.shape[2] - 1
+        self.F = int(F)
+        self._keep = [W]
+        ptrs = [W.ctypes.data]
+        for other in (W_ai, W_af):
+            if other is None:
+                ptrs.append(None)
+                continue
+            other = _c128(other)
+            self._keep.append(other)
+            ptrs.append(other.ctypes.data)
+        flags = (LWS_PRECISION_FP64 if precision == "fp64" else 0) | (LWS_NOFUTURE_Q4_COMPAT if nofuture_q4_compat else 0) \
+            | (LWS_FORCE_GENERIC if force_generic else 0) | (LWS_STORAGE_FP16 if storage == "fp16" else 0)
+        devs = None if devices is None else np.ascontiguousarray(devices, dtype=np.intc)
+        h = C.c_void_p()
+        check(lib.lws_multi_plan_create(C.byref(h), 0 if devs is None else int(devs.size), None if devs is None else devs.ctypes.data,
+                                        self.F, self.L, self.Q, self.Qp, ptrs[0], ptrs[1], ptrs[2], flags))
+        self._h, self._lib = h, lib
+        self.shards = lib.lws_multi_plan_shards(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lws_multi_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _io(self, S):
+        S = _c128(S)
+        if S.ndim != 3 or S.shape[2] != self.F:
+            raise ValueError(f"expected a (B, T, {self.F}) stack of spectrograms")
+        return S, np.empty_like(S)
+
+    def batch(self, S, thresholds, wsel=LWS_W):
+        S, out = self._io(S)
+        t, tp = Plan._thr(thresholds)
+        check(self._lib.lws_multi_batch_lws(self._h, wsel, S.ctypes.data, out.ctypes.data, S.shape[0], S.shape[1], tp, t.size))
+        return out
+
+    def run(self, S, thr_nofuture, thr_online, LA, qdiv, thr_batch):
+        S, out = self._io(S)
+        t0, p0 = Plan._thr(thr_nofuture)
+        t1, p1 = Plan._thr(thr_online)
+        t2, p2 = Plan._thr(thr_batch)
+        check(self._lib.lws_multi_run_lws(self._h, S.ctypes.data, out.ctypes.data, S.shape[0], S.shape[1], p0, t0.size, p1, t1.size,
+                                          int(LA), float(qdiv), p2, t2.size))
+        return out
+
+    def residual(self, S):
+        S, _ = self._io(S)
+        out = np.empty(2, dtype=np.float64)
+        check(self._lib.lws_multi_residual(self._h, S.ctypes.data, S.shape[0], S.shape[1], out.ctypes.data))
+        return out
 
 
 # ---- the steps either side of the path, on the device (include/lws_hip.h; lws.pyx:43-144) --------------------------

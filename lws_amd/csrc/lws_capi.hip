@@ -176,7 +176,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
 
     // the systolic kernel serves batch sweeps of plans it was built for (fp32, summarised weights
     // with the twiddle structure of create_weights, supported shape); everything else is generic.
-    if (!p->fp64 && mode == lws::MODE_BATCH && !(p->flags & LWS_FORCE_GENERIC) && iters <= lws::SYSTOLIC_MAX_ITERS) {
+    if (!p->fp64 && mode == lws::MODE_BATCH && !(p->flags & LWS_FORCE_GENERIC)) {
         const bool narrow = lws::systolic_supports(p->sys, wsel, T);
         const bool wide = !narrow && lws::wide::systolic_supports(p->sysw, wsel, T);
         if (narrow || wide) {
@@ -258,8 +258,8 @@ int run_direct_batch(lws_plan *p, const float2 *in_dev, float2 *out_dev, int B, 
                                                 static_cast<float *>(p->thr_scaled.p), B, st.iters, s));
     int launches = 0;
     const float *th = static_cast<const float *>(p->thr_scaled.p);
-    e = narrow ? lws::systolic_io_run(p->sys, st.wsel, th, out_dev, B, T, st.iters, s, &launches, p->ev0, p->ev1)
-               : lws::wide::systolic_io_run(p->sysw, st.wsel, th, out_dev, B, T, st.iters, s, &launches, p->ev0, p->ev1);
+    e = narrow ? lws::systolic_io_run(p->sys, st.wsel, th, in_dev, out_dev, partial, B, T, st.iters, s, &launches, p->ev0, p->ev1)
+               : lws::wide::systolic_io_run(p->sysw, st.wsel, th, in_dev, out_dev, partial, B, T, st.iters, s, &launches, p->ev0, p->ev1);
     p->timing_pending = true;
     if (e != hipSuccess) return fail(LWS_ERR_HIP, "systolic launch failed: %s", hipGetErrorString(e));
     p->last_launches = launches;
@@ -276,7 +276,6 @@ int run_pipeline(lws_plan *p, const io_cx *in_dev, io_cx *out_dev, const io_cx *
         for (int i = 0; i < nstages; ++i)
             if (stages[i].iters > 0) { ++active; which = i; }
         if (active == 1 && stages[which].mode == lws::MODE_BATCH && !(p->flags & (LWS_FORCE_GENERIC | LWS_NO_DIRECT_IO)) &&
-            stages[which].iters <= lws::SYSTOLIC_MAX_ITERS &&
             (lws::systolic_supports(p->sys, stages[which].wsel, T) || lws::wide::systolic_supports(p->sysw, stages[which].wsel, T)))
             return run_direct_batch(p, in_dev, out_dev, B, T, stages[which], s);
     }
@@ -324,15 +323,15 @@ int need_weights(const lws_plan *p, const StageSpec *st, int n) {
 }
 
 // After a synchronisation point: did a multi-workgroup systolic launch give up waiting (workgroups of one spectrogram
-// not co-scheduled, e.g. the device was shared)?  The results of that call are then invalid.
+// not co-scheduled, e.g. the device was shared)?  Not an error: the call was then re-run on the device with one
+// workgroup per spectrogram before it completed (lws_systolic.hip: run_kernel); the kernel name says so.
 int check_systolic_flag(lws_plan *p) {
     for (lws::SystolicPlan *sp : {&p->sys, &p->sysw}) {
         if (sp->last_nwg > 1 && sp->err_dev) {
             int flag = 0;
             HIP_TRY(hipMemcpy(&flag, sp->err_dev, sizeof(int), hipMemcpyDeviceToHost));
             sp->last_nwg = 1;
-            if (flag) return fail(LWS_ERR_HIP, "systolic kernel: the workgroups sharing a spectrogram were not running "
-                                               "concurrently (device shared with other work?); set LWS_SYSTOLIC_NWG=1");
+            if (flag) p->last_name = "systolic (multi-workgroup hand-over timed out: re-run with one workgroup per spectrogram)";
         }
     }
     return LWS_OK;
@@ -449,6 +448,10 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
     p->F = F; p->L = L; p->Q = Q; p->Qp = Qp;
     p->flags = flags;
     p->fp64 = (flags & LWS_PRECISION_FP64) != 0;
+    if (p->fp64 && (flags & LWS_STORAGE_FP16)) {
+        delete p;
+        return fail(LWS_ERR_INVALID, "LWS_STORAGE_FP16 is a storage mode of the fp32 engine; it cannot be combined with LWS_PRECISION_FP64");
+    }
     int rc = LWS_OK;
     const double *src[3] = {W, W_ai, W_af};
     for (int i = 0; i < 3 && rc == LWS_OK; ++i) {
@@ -463,8 +466,9 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
         const double *hw[3] = {p->have[0] ? p->hostW[0].data() : nullptr,
                                p->have[1] ? p->hostW[1].data() : nullptr,
                                p->have[2] ? p->hostW[2].data() : nullptr};
-        hipError_t e = lws::systolic_build(p->sys, F, L, Q, Qp, hw);
-        if (e == hipSuccess && !(p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2])) e = lws::wide::systolic_build(p->sysw, F, L, Q, Qp, hw);
+        const bool h16 = (flags & LWS_STORAGE_FP16) != 0;
+        hipError_t e = lws::systolic_build(p->sys, F, L, Q, Qp, hw, h16);
+        if (e == hipSuccess && !(p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2])) e = lws::wide::systolic_build(p->sysw, F, L, Q, Qp, hw, h16);
         if (e != hipSuccess) rc = fail(LWS_ERR_HIP, "systolic table upload failed: %s", hipGetErrorString(e));
     }
     if (rc != LWS_OK) {
@@ -553,6 +557,42 @@ int lws_online_lws_dev(lws_plan *p, void *S_dev, int B, int T, const double *thr
     return run_dev(p, S_dev, B, T, &st, 1, stream);
 }
 
+int lws_run_lws_dev(lws_plan *p, void *S_dev, int B, int T, const double *thr_nofuture, int it_nofuture,
+                    const double *thr_online, int it_online, int LA, double qdiv, const double *thr_batch, int it_batch,
+                    void *stream) {
+    int rc = check_common(p, B, T, thr_nofuture, it_nofuture);
+    if (!rc) rc = check_common(p, B, T, thr_online, it_online);
+    if (!rc) rc = check_common(p, B, T, thr_batch, it_batch);
+    if (rc) return rc;
+    if (LA < 0) return fail(LWS_ERR_INVALID, "negative look-ahead");
+    StageSpec st[3] = {{lws::MODE_NOFUTURE, LWS_W_AI, thr_nofuture, it_nofuture, 0, (double)p->Q},
+                       {lws::MODE_ONLINE, 0, thr_online, it_online, LA, qdiv},
+                       {lws::MODE_BATCH, LWS_W, thr_batch, it_batch, 0, (double)p->Q}};
+    return run_dev(p, S_dev, B, T, st, 3, stream);
+}
+
+int lws_plan_reserve(lws_plan *p, int B, int T, int max_iters) {
+    if (!p) return fail(LWS_ERR_INVALID, "null plan");
+    if (B < 1 || T < 1 || max_iters < 0) return fail(LWS_ERR_INVALID, "need B >= 1, T >= 1, max_iters >= 0");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = p->fp64 ? ensure_scratch<double>(p, B, T, max_iters) : ensure_scratch<float>(p, B, T, max_iters);
+    if (rc) return rc;
+    const size_t count = (size_t)B * T * p->F;
+    if ((rc = p->stage.ensure(count * sizeof(double2)))) return rc;          // host entry points stage complex128 here
+    if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
+    if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
+    if (!p->fp64) {
+        const bool narrow = p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2], wide = p->sysw.ok[0] || p->sysw.ok[1] || p->sysw.ok[2];
+        if (narrow || wide) {
+            const size_t n_part = narrow ? lws::systolic_io_partials(p->sys, T) : lws::wide::systolic_io_partials(p->sysw, T);
+            if ((rc = p->row_sums.ensure((size_t)B * (n_part > (size_t)T ? n_part : (size_t)T) * sizeof(double)))) return rc;
+            hipError_t e = narrow ? lws::systolic_reserve(p->sys, B, T, max_iters) : lws::wide::systolic_reserve(p->sysw, B, T, max_iters);
+            if (e != hipSuccess) return fail(LWS_ERR_NOMEM, "systolic scratch: %s", hipGetErrorString(e));
+        }
+    }
+    return LWS_OK;
+}
+
 int lws_residual_dev(lws_plan *p, const void *S_dev, int B, int T, double *out, void *stream) {
     if (!p || !S_dev || !out) return fail(LWS_ERR_INVALID, "null argument");
     if (B <= 0 || T < 1) return fail(LWS_ERR_INVALID, "need B >= 1 and T >= 1");
@@ -585,6 +625,40 @@ int lws_residual_dev(lws_plan *p, const void *S_dev, int B, int T, double *out, 
                                             static_cast<double *>(p->resid_rows.p),
                                             static_cast<double *>(p->resid_out.p), B, T, p->F, p->L,
                                             p->Q, p->Qp, s));
+    }
+    HIP_TRY(hipMemcpyAsync(out, p->resid_out.p, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LWS_OK;
+}
+
+int lws_residual(lws_plan *p, const double *S, int B, int T, double *out) {
+    if (!p || !S || !out) return fail(LWS_ERR_INVALID, "null argument");
+    if (B <= 0 || T < 1) return fail(LWS_ERR_INVALID, "need B >= 1 and T >= 1");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = nullptr;
+    const size_t count = (size_t)B * T * p->F;
+    int rc;
+    if ((rc = p->stage.ensure(count * sizeof(double2)))) return rc;
+    if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
+    if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->stage.p, S, count * sizeof(double2), hipMemcpyHostToDevice, s));
+    const double2 *in = static_cast<const double2 *>(p->stage.p);
+    if (p->fp64) {
+        if ((rc = ensure_scratch<double>(p, B, T, 1))) return rc;
+        HIP_TRY((lws::launch_prep<double, double2>(in, static_cast<double2 *>(p->state.p), static_cast<double *>(p->amp.p),
+                                                   static_cast<double *>(p->row_sums.p), static_cast<double *>(p->mean_amp.p),
+                                                   B, T, p->F, p->L, p->Q, s)));
+        HIP_TRY(lws::launch_residual<double>(static_cast<const double2 *>(p->state.p), wset<double>(p, 0),
+                                             static_cast<double *>(p->resid_rows.p), static_cast<double *>(p->resid_out.p), B, T,
+                                             p->F, p->L, p->Q, p->Qp, s));
+    } else {
+        if ((rc = ensure_scratch<float>(p, B, T, 1))) return rc;
+        HIP_TRY((lws::launch_prep<float, double2>(in, static_cast<float2 *>(p->state.p), static_cast<float *>(p->amp.p),
+                                                  static_cast<double *>(p->row_sums.p), static_cast<double *>(p->mean_amp.p),
+                                                  B, T, p->F, p->L, p->Q, s)));
+        HIP_TRY(lws::launch_residual<float>(static_cast<const float2 *>(p->state.p), wset<float>(p, 0),
+                                            static_cast<double *>(p->resid_rows.p), static_cast<double *>(p->resid_out.p), B, T,
+                                            p->F, p->L, p->Q, p->Qp, s));
     }
     HIP_TRY(hipMemcpyAsync(out, p->resid_out.p, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -4,7 +4,7 @@
 
 namespace lws {
 
-constexpr int SYSTOLIC_MAX_ITERS = 440;  // thresholds of one call live in LDS
+constexpr int SYSTOLIC_MAX_ITERS = 440;  // thresholds of one launch live in LDS; longer schedules run as several launches
 
 struct SystolicPlan {
     bool ok[3] = {false, false, false};  // per weight tensor: kernel applicable
@@ -13,15 +13,21 @@ struct SystolicPlan {
     void *sk_state = nullptr, *sk_amp = nullptr;    // skewed-layout scratch
     size_t sk_state_cap = 0, sk_amp_cap = 0;
     const char *name = "systolic";
-    int *err_dev = nullptr;   // device flag of the last launch: a workgroup gave up waiting for its producer
+    int *err_dev = nullptr;   // device flag of the last launch: a workgroup gave up waiting for its producer (the call was
+                              // then re-run with one workgroup per spectrogram, on the device, before it completed)
     int last_nwg = 1;         // workgroups per spectrogram of the last launch
+    bool h16 = false;         // fp16-complex storage of the skewed layout (LWS_STORAGE_FP16)
+    void *thr_chunk = nullptr;   // dense threshold table of one launch of a schedule longer than SYSTOLIC_MAX_ITERS
+    size_t thr_chunk_cap = 0;
 };
 
 // Analyse the (host, complex128 interleaved) weight tensors and upload tables for the ones the
 // kernel can serve.  Never fails for "not applicable"; only for HIP errors.
-hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3]);
+hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3], bool fp16_storage);
 void systolic_release(SystolicPlan &sp);
 bool systolic_supports(const SystolicPlan &sp, int wsel, int T);
+// Allocates the skewed-layout scratch for calls of up to B spectrograms x T frames (so that later calls do not).
+hipError_t systolic_reserve(SystolicPlan &sp, int B, int T, int iters);
 const char *systolic_name(const SystolicPlan &sp);
 // Runs `iters` batch sweeps on the extended buffers (reference layout), in place.
 // ev0/ev1 (may be null) are recorded around the update kernel(s) only.
@@ -34,15 +40,18 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
 size_t systolic_io_partials(const SystolicPlan &sp, int T);
 hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, int iters, double *partial, double *mean_amp,
                             hipStream_t stream);
-hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, float2 *out, int B, int T, int iters,
-                           hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1);
+// (`in` and `partial` as given to systolic_io_load: a failed multi-workgroup hand-over re-converts from them; `in` may be `out`)
+hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, const float2 *in, float2 *out, double *partial, int B,
+                           int T, int iters, hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1);
 
 // The same kernel compiled for frames of up to 1025 bins (lws_systolic.hip with -DLWS_WIDE=1): 16-step lane skew,
 // 64-step ring, 3 sweep slots.  Same contract.
 namespace wide {
-hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3]);
+hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3], bool fp16_storage);
 void systolic_release(SystolicPlan &sp);
 bool systolic_supports(const SystolicPlan &sp, int wsel, int T);
+// Allocates the skewed-layout scratch for calls of up to B spectrograms x T frames (so that later calls do not).
+hipError_t systolic_reserve(SystolicPlan &sp, int B, int T, int iters);
 const char *systolic_name(const SystolicPlan &sp);
 hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp,
                            const float *thr, int B, int T, int iters, hipStream_t stream,
@@ -53,8 +62,9 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
 size_t systolic_io_partials(const SystolicPlan &sp, int T);
 hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, int iters, double *partial, double *mean_amp,
                             hipStream_t stream);
-hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, float2 *out, int B, int T, int iters,
-                           hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1);
+// (`in` and `partial` as given to systolic_io_load: a failed multi-workgroup hand-over re-converts from them; `in` may be `out`)
+hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, const float2 *in, float2 *out, double *partial, int B,
+                           int T, int iters, hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1);
 }  // namespace wide
 
 }  // namespace lws

@@ -152,16 +152,20 @@ __host__ __device__ constexpr Src src_end(int P, int dr, int dk) {
 }
 
 struct SysArgs {
-    float2 *state_w;         // [B][G][64]   time-skewed spectrogram
-    const float *amp_w;      // [B][G][64]
-    float2 *state_nyq;       // [B][TpPad]
-    const float *amp_nyq;    // [B][TpPad]
+    // storage format of the skewed layout (template parameter H16 of the kernels): fp32 -- float2 / float -- or
+    // fp16 -- half2 / half, scaled per spectrogram by store_scale(amax) (LWS_STORAGE_FP16)
+    void *state_w;           // [B][G][64]   time-skewed spectrogram
+    const void *amp_w;       // [B][G][64]
+    void *state_nyq;         // [B][TpPad]
+    const void *amp_nyq;     // [B][TpPad]
     const float *thr;        // [B][n_iters] thresholds scaled by mean|S|
     const float *amax;       // [B] max target magnitude
     int n_iters, T, Tp, TpPad, Kr, G, C;
     int nwg;                 // workgroups per spectrogram (passes over HBM are dealt round-robin to them)
     unsigned *progress;      // [B][nwg] rows of the skewed state each workgroup has completed (nwg > 1)
     int *err;                // set if a workgroup gave up waiting for its producer
+    const int *gate;         // non-null: run only if *gate != 0 (the single-workgroup re-run after a hand-over time-out)
+    int spin_limit;          // polls of a producer's counter before a workgroup gives up
     unsigned long long w[4 * 8];   // W[0][r][k], r < Q, k <= L (at most 4 x 8): bit patterns of (re, im) as one 64-bit scalar
 };
 
@@ -206,27 +210,80 @@ __device__ __forceinline__ v4f lds_read128(int addr) {
 }
 __device__ __forceinline__ float2 cj(float2 v) { return make_float2(v.x, -v.y); }
 
-// Loads that must observe what another wave of this workgroup stored earlier: bypass the per-CU L1.
-__device__ __forceinline__ float2 load_l2(const float2 *p) {
-    const unsigned long long u =
-        __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float2 v;
-    v.x = __uint_as_float((unsigned)(u & 0xffffffffull));
-    v.y = __uint_as_float((unsigned)(u >> 32));
-    return v;
+// ---- storage formats of the skewed HBM layout --------------------------------------------------------------------
+// H16 = false: float2 state, float magnitudes (20 B per active bin and sweep).  H16 = true (LWS_STORAGE_FP16): half2 state
+// and half magnitudes (10 B), both multiplied by store_scale(largest magnitude of the spectrogram), a power of two that
+// brings the data to [0, 2): exact, and the whole kernel then works in that scaled domain (its thresholds are scaled the
+// same way; the weighted sums are only ever normalised, so nothing else changes).  Arithmetic and the LDS rings are fp32
+// in both formats; the rounding to half happens once per pass over HBM (NSLOTS sweeps).
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ float store_scale(float amax) {
+    unsigned b;
+    __builtin_memcpy(&b, &amax, 4);
+    const unsigned e = (b >> 23) & 0xffu;
+    const unsigned sb = (e == 0u || e == 0xffu) ? 0x3f800000u : ((e >= 254u ? 1u : 254u - e) << 23);
+    float sc;
+    __builtin_memcpy(&sc, &sb, 4);
+    return sc;
+}
+__device__ __forceinline__ float2 unpack_h2(unsigned u) {
+    const h2_t h = __builtin_bit_cast(h2_t, u);
+    return make_float2((float)h.x, (float)h.y);
+}
+__device__ __forceinline__ unsigned pack_h2(float2 v) {   // round to nearest even
+    const h2_t h = {(_Float16)v.x, (_Float16)v.y};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float unpack_h(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+__device__ __forceinline__ unsigned short pack_h(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+template <bool H16> struct Store {
+    using cplx = float2; using real = float;
+    static constexpr int CB = 8, RB = 4;
+};
+template <> struct Store<true> {
+    using cplx = unsigned; using real = unsigned short;
+    static constexpr int CB = 4, RB = 2;
+};
+
+// A complex value as it travels from the global load to its use one block later: the raw bits (a conversion at the load
+// would wait for it there and then).
+template <bool H16> __device__ __forceinline__ float2 raw_value(float2 raw) { return H16 ? unpack_h2(__float_as_uint(raw.x)) : raw; }
+template <bool H16> __device__ __forceinline__ float raw_real(float raw) { return H16 ? unpack_h((unsigned short)__float_as_uint(raw)) : raw; }
+
+// Loads that must observe what another wave of this workgroup stored earlier: bypass the per-CU L1.  Returns raw bits.
+template <bool H16> __device__ __forceinline__ float2 load_l2(const void *base, size_t idx) {
+    if constexpr (H16) {
+        const unsigned u = __hip_atomic_load(static_cast<const unsigned *>(base) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float2(__uint_as_float(u), 0.f);
+    } else {
+        const unsigned long long u =
+            __hip_atomic_load(static_cast<const unsigned long long *>(base) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float2 v;
+        v.x = __uint_as_float((unsigned)(u & 0xffffffffull));
+        v.y = __uint_as_float((unsigned)(u >> 32));
+        return v;
+    }
+}
+template <bool H16> __device__ __forceinline__ float load_real_raw(const void *base, size_t idx) {
+    if constexpr (H16) return __uint_as_float((unsigned)static_cast<const unsigned short *>(base)[idx]);
+    else return static_cast<const float *>(base)[idx];
 }
 
 // Stores another workgroup (possibly on another XCD, behind another L2) will read during this launch: write through.
 // (With one workgroup per spectrogram producer and consumer share the CU's XCD and a plain store is enough.)
-__device__ __forceinline__ void store_l2(float2 *p, float2 v, bool shared) {
+template <bool H16> __device__ __forceinline__ void store_l2(void *base, size_t idx, float2 v, bool shared) {
 #ifdef LWS_DBG_NOSTORE   // timing experiment: nothing is written back (results invalid)
     return;
 #endif
-    if (shared) {
+    if constexpr (H16) {
+        const unsigned u = pack_h2(v);
+        if (shared) __hip_atomic_store(static_cast<unsigned *>(base) + idx, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else static_cast<unsigned *>(base)[idx] = u;
+    } else if (shared) {
         const unsigned long long u = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(static_cast<unsigned long long *>(base) + idx, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        *p = v;
+        static_cast<float2 *>(base)[idx] = v;
     }
 }
 
@@ -833,10 +890,9 @@ __device__ __forceinline__ float2 project(float2 acc, float target, bool active,
 struct Carry { float2 o0, o1, o2, prev_out; };
 
 // One pair of bins (phases PA odd, PA+1) of one lane.
-template <int Q, int L, uint32_t MASK, int PA, bool MULTI>
-__device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx, int lane, int vmod, int G, Carry &cr,
-                                             const float (&amp_cur)[8], const float (&amp_nxt)[8], float2 *state_w_b,
-                                             QuadCarry<L> &qc) {
+template <int Q, int L, uint32_t MASK, int PA, bool H16>
+__device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx, Carry &cr, const float (&amp_cur)[8],
+                                             const float (&amp_nxt)[8], QuadCarry<L> &qc) {
     constexpr int K1 = L + 1;
     constexpr int PHB = (PA + 1) & 7, PBB = PA + 1;          // second bin: phase and clock relative to this block
     constexpr bool wrap = (PA == 7);                         // the second bin belongs to the next block
@@ -983,7 +1039,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     image_store<L, PA, 1>(cx.img_lo, cx.img_hi, cx.img_both, outA);
     // ---- second bin (its centre taps include the first bin's result)
     centre_sum<L, MASK, PHB, PBB>(a, cx, CP && stB, CP && enB, cr.o1, cr.o2, outA, accB);
-    const float tB = wrap ? amp_nxt[0] : amp_cur[PBB & 7];
+    const float tB = wrap ? raw_real<H16>(amp_nxt[0]) : amp_cur[PBB & 7];   // (amp_nxt holds what the loads delivered: raw bits)
     const bool liveB = wrap ? cx.nxt_live : cx.live;
     const float2 outB = project(accB, tB, liveB && (tB > (wrap ? cx.nxt_thr : cx.thr)), cr.o1);
     ring_publish(ring_addr<PBB, 0, 0, 1>(cx.ob), ring_addr<PBB, 0, 0, 1>(cx.obh), outB);
@@ -995,7 +1051,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
 }
 
 // State of the service duties (HBM loader for set 0 and the Nyquist bins of every sweep slot).
-struct ServiceState {
+struct ServiceState {      // (both as the loads delivered them: raw bits of the storage format)
     float nyq_amp_next;     // Nyquist lanes: target magnitude of the next block's Nyquist bin
     float2 nyq_in_next;     // Nyquist loader lane: previous-sweep Nyquist value of the next block's frame
 };
@@ -1003,10 +1059,10 @@ struct ServiceState {
 // Lane l < NSLOTS computes the Nyquist bin (bin C = F-1) of the frame of sweep slot l whose 512-step period ended at
 // clock t0 (phase 0 of the current block); lane NSLOTS feeds set 0 with the stored Nyquist value of that frame.
 // Called at the start of the first pair of the block, when every slot has published bins C-1, C-2, ...
-template <int Q, int L, uint32_t MASK, bool MULTI>
+template <int Q, int L, uint32_t MASK, bool MULTI, bool H16>
 __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &sv, int lane, int t0, int wg, int n_eff,
-                                                int n_groups, const float *thr_eff, float2 *state_nyq_b,
-                                                const float *amp_nyq_b) {
+                                                int n_groups, const float *thr_eff, void *state_nyq_b,
+                                                const void *amp_nyq_b) {
     constexpr int K1 = L + 1;
     const int C = a.C, Kr = a.Kr;
     const int ablk = (t0 >> 3);
@@ -1025,14 +1081,15 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     const int j = g * NSLOTS + (is_nyq_lane ? slot : -1);
     const bool valid = (v0 - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
     if (is_nyq_loader) {
-        lds_write(NYQ_OFF + rho * 8, sv.nyq_in_next);  // loaded one block ago for this frame
-        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, sv.nyq_in_next);   // and as entry "bin C" of set 0's image lane
+        const float2 nin = raw_value<H16>(sv.nyq_in_next);   // loaded one block ago for this frame
+        lds_write(NYQ_OFF + rho * 8, nin);
+        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, nin);   // and as entry "bin C" of set 0's image lane
         const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
-        if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2(state_nyq_b + me1);
+        if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2<H16>(state_nyq_b, me1);
     }
     if (is_nyq_lane) {
-        const float target = sv.nyq_amp_next;
+        const float target = raw_real<H16>(sv.nyq_amp_next);
         const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
         const float thr = thr_eff[valid ? j : 0];
         const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
@@ -1079,11 +1136,11 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         lds_write(nn[0], out);
         lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, out);   // bin C of the image lane: production time = this clock
         // (the last slot stores whatever reaches it: idle slots of the last group pass the final values on)
-        if ((slot == NSLOTS - 1) && (v0 - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2(state_nyq_b + me, out, MULTI);
+        if ((slot == NSLOTS - 1) && (v0 - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2<H16>(state_nyq_b, me, out, MULTI);
         // target magnitude of the next block's Nyquist bin
         const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
-        sv.nyq_amp_next = (vr1 >= 0 && me1 < a.Tp) ? amp_nyq_b[me1] : 0.f;
+        sv.nyq_amp_next = (vr1 >= 0 && me1 < a.Tp) ? load_real_raw<H16>(amp_nyq_b, me1) : 0.f;   // (raw zero bits = 0 in both formats)
     }
 }
 
@@ -1091,19 +1148,21 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
 __device__ unsigned long long g_dbg_timing[16 * 4];
 #endif
 // MULTI: several workgroups share a spectrogram (a.nwg > 1); the single-workgroup instantiation carries none of it
-template <int Q, int L, uint32_t MASK, bool MULTI>
+template <int Q, int L, uint32_t MASK, bool MULTI, bool H16>
 __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (a_in.gate != nullptr && __hip_atomic_load(a_in.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int nwg = MULTI ? a_in.nwg : 1;
     const int b = MULTI ? blockIdx.x / nwg : blockIdx.x, wg = MULTI ? blockIdx.x - b * nwg : 0;
     // The weighted sums are only ever normalised (project()), so the weights of this spectrogram are scaled by the power
     // of two that brings its largest magnitude to [1, 2): exact, and |acc|^2 can then be formed in fp32 without the
     // rescue path for very small (or large) data that project() would otherwise need for every bin.
+    // (With fp16 storage the data itself arrives multiplied by that power of two -- see Store -- so the weights stay as
+    // they are and the thresholds are scaled instead.)
     SysArgs a = a_in;
+    const float data_scale = store_scale(a_in.amax[b]);
     {
-        const unsigned ebits = (__float_as_uint(a_in.amax[b]) >> 23) & 0xffu;
-        const unsigned sbits = (ebits == 0u || ebits == 0xffu) ? 0x3f800000u : ((ebits >= 254u ? 1u : 254u - ebits) << 23);
-        const float sc = __uint_as_float(sbits);
+        const float sc = H16 ? 1.0f : data_scale;
 #pragma unroll
         for (int x = 0; x < 32; ++x) {
             const float re = __uint_as_float((unsigned)(a_in.w[x] & 0xffffffffull)) * sc;
@@ -1125,10 +1184,11 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     float *thr_eff = reinterpret_cast<float *>(smem + THR_OFF);
     int *meta = reinterpret_cast<int *>(smem + META_OFF);
     const int G = a.G, C = a.C, Kr = a.Kr;
-    float2 *state_w_b = a.state_w + (size_t)b * G * LANES;
-    const float *amp_w_b = a.amp_w + (size_t)b * G * LANES;
-    float2 *state_nyq_b = a.state_nyq + (size_t)b * a.TpPad;
-    const float *amp_nyq_b = a.amp_nyq + (size_t)b * a.TpPad;
+    using ST = Store<H16>;
+    void *state_w_b = static_cast<char *>(a.state_w) + (size_t)b * G * LANES * ST::CB;
+    const void *amp_w_b = static_cast<const char *>(a.amp_w) + (size_t)b * G * LANES * ST::RB;
+    void *state_nyq_b = static_cast<char *>(a.state_nyq) + (size_t)b * a.TpPad * ST::CB;
+    const void *amp_nyq_b = static_cast<const char *>(a.amp_nyq) + (size_t)b * a.TpPad * ST::RB;
     constexpr int T_START = -8;   // one block of warm-up: the pair (7, 0') of block -1 produces clock 0
 
     // sweeps whose threshold is not below the largest magnitude cannot change anything: drop them
@@ -1137,7 +1197,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         int n = 0;
         for (int i = 0; i < a.n_iters; ++i) {
             const float th = a.thr[(size_t)b * a.n_iters + i];
-            if (amax > th) thr_eff[n++] = th;
+            if (amax > th) thr_eff[n++] = H16 ? th * data_scale : th;
         }
         meta[0] = n;
     }
@@ -1169,16 +1229,21 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     // one local pass behind; its first pass reads the caller's data and waits for nobody.
     const int prod_passes = n_local - (wg ? 0 : 1);   // passes of the producer this workgroup consumes
     const int need_max = prod_passes > 0 ? (prod_passes - 1) * G + SKEW * a.Tp + C + 16 : 0;
+    bool gave_up = false;                        // the hand-over failed somewhere in this launch: stop waiting, the results
+                                                 // are discarded and the call is re-run with one workgroup per spectrogram
     auto wait_rows = [&](int need) {            // service wave: rows < need of my clock must be complete
         need -= prod_shift;
         if (need > need_max) need = need_max;
-        if (need <= 0) return;
+        if (need <= 0 || gave_up) return;
         int spins = 0;
         // data rows are written through (store_l2) and read past the L1 and the XCD's L2 (load_l2), so no cache-wide
         // write-back / invalidate is needed: a counter that is only raised after the producer's stores have completed
         while ((int)__hip_atomic_load(prod_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 21)) { if (lane == 0) *a.err = 1; break; }   // seconds: a co-scheduling failure, not a hang
+            ++spins;
+            // a co-scheduling failure (workgroups of one ring not resident together), not a hang: flag it for everybody
+            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); gave_up = true; break; }
+            if ((spins & 1023) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gave_up = true; break; }
         }
         asm volatile("" ::: "memory");
     };
@@ -1205,7 +1270,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         if constexpr (MULTI) wait_rows(8 + 40);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {   // clocks 0..7
-            const float2 v = load_l2(state_w_b + (size_t)i * LANES + lane);
+            const float2 v = load_l2<H16>(state_w_b, (size_t)i * LANES + lane);
             amp_cur[i] = v.x;
             amp_nxt[i] = v.y;
         }
@@ -1307,7 +1372,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             int vnext = vmod + 8;
             vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
 #pragma unroll
-            for (int i = 0; i < 8; ++i) amp_cur[i] = amp_nxt[i];
+            for (int i = 0; i < 8; ++i) amp_cur[i] = raw_real<H16>(amp_nxt[i]);   // (fp16 storage: the conversion takes the place of the move)
 #ifdef LWS_DBG_NOAMP   // timing experiment: no target-magnitude loads (results invalid)
 #pragma unroll
             for (int i = 0; i < 8; ++i) amp_nxt[i] = (float)(vnext + i);
@@ -1316,8 +1381,12 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             // (written as plain loads the compiler fetches into temporaries and copies -- i.e. waits -- at once: a stall
             // of one memory latency per block).  The waits are explicit: before amp_nxt[0] is first used (pair (7, 0'))
             // and at the end of the block; these are the only vector-memory operations of a sweep slot.
-            const float *ap = amp_w_b + (size_t)vnext * LANES + lane;
-#define LWS_AMP_LOAD(i) asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * LANES * 4) : "memory")
+            const char *ap = static_cast<const char *>(amp_w_b) + ((size_t)vnext * LANES + lane) * ST::RB;
+#define LWS_AMP_LOAD(i)                                                                                                             \
+    do {                                                                                                                            \
+        if constexpr (H16) asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * LANES * 2) : "memory"); \
+        else asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * LANES * 4) : "memory"); \
+    } while (0)
             LWS_AMP_LOAD(0); LWS_AMP_LOAD(1); LWS_AMP_LOAD(2); LWS_AMP_LOAD(3);
             LWS_AMP_LOAD(4); LWS_AMP_LOAD(5); LWS_AMP_LOAD(6); LWS_AMP_LOAD(7);
 #undef LWS_AMP_LOAD
@@ -1336,7 +1405,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #ifndef LWS_DBG_NOAMP
             if constexpr (PA == 7) { if (is_compute) asm volatile("s_waitcnt vmcnt(7)" : "+v"(amp_nxt[0]) : : "memory"); }   // in-order: the first of the 8
 #endif
-            if (is_compute) compute_pair<Q, L, MASK, PA, MULTI>(a, cx, lane, vmod, G, cr, amp_cur, amp_nxt, state_w_b, qc);
+            if (is_compute) compute_pair<Q, L, MASK, PA, H16>(a, cx, cr, amp_cur, amp_nxt, qc);
             if constexpr (PA == 1 && MULTI) {
                 if (is_service) {
                     // every slot has finished the previous block (flow_wait above); this wave has written back what the last
@@ -1356,7 +1425,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #else
                 if constexpr (false)
 #endif
-                    service_nyquist<Q, L, MASK, MULTI>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+                    service_nyquist<Q, L, MASK, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
                 // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
                 // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
                 int ldb[NBLK], ldu[NBLK], ldh[NBLK];
@@ -1368,8 +1437,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 }
                 const int cb0 = (t0 - SKEW * lane) & (ROWP - 1), cb1 = (t0 + 8 - SKEW * lane) & (ROWP - 1);
                 const bool l_st = cb0 == 0, l_en = cb0 == C - 8, l_stn = cb1 == 0, l_enn = cb1 == C - 8;
-                const float2 vA = make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]);
-                const float2 vB = make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]);
+                const float2 vA = raw_value<H16>(make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]));
+                const float2 vB = raw_value<H16>(make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]));
                 ring_publish(ring_addr<PA, 0>(ldb), ring_addr<PA, 0>(ldh), vA);
                 image_publish<L, PA, PA, 0>(ldu, l_st, l_en, cx.dummy, vA);
                 ring_publish(ring_addr<PA + 1, 0>(ldb), ring_addr<PA + 1, 0>(ldh), vB);
@@ -1392,8 +1461,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                     int r1 = r0 + 1;
                     r1 -= (r1 >= G) ? G : 0;
                     if (PA == 1 ? wb_prev : wb_cur) {
-                        store_l2(state_w_b + (size_t)r0 * LANES + lane, make_float2(w.x, w.y), MULTI);
-                        store_l2(state_w_b + (size_t)r1 * LANES + lane, make_float2(w.z, w.w), MULTI);
+                        store_l2<H16>(state_w_b, (size_t)r0 * LANES + lane, make_float2(w.x, w.y), MULTI);
+                        store_l2<H16>(state_w_b, (size_t)r1 * LANES + lane, make_float2(w.z, w.w), MULTI);
                     }
                 }
                 int i0 = tmod + PA + 8, i1 = tmod + PA + 9;
@@ -1402,8 +1471,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #ifdef LWS_DBG_NOLOADER   // timing experiment: the loader fetches nothing (results invalid)
                 const float2 p0 = make_float2((float)i0, 1.f), p1 = make_float2((float)i1, 2.f);
 #else
-                const float2 p0 = load_l2(state_w_b + (size_t)i0 * LANES + lane);
-                const float2 p1 = load_l2(state_w_b + (size_t)i1 * LANES + lane);
+                const float2 p0 = load_l2<H16>(state_w_b, (size_t)i0 * LANES + lane);
+                const float2 p1 = load_l2<H16>(state_w_b, (size_t)i1 * LANES + lane);
 #endif
                 amp_cur[PA & 7] = p0.x; amp_nxt[PA & 7] = p0.y;
                 amp_cur[(PA + 1) & 7] = p1.x; amp_nxt[(PA + 1) & 7] = p1.y;
@@ -1435,20 +1504,92 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 // layout a frame's bins are contiguous, in the skewed layout the 64 lanes of a time step are, so the tile is read along
 // one and written along the other and both sides of the copy are full 512-byte segments.
 // grid: (Kr * NT, B) with NT = ceil((SKEW*63 + C) / 64) time tiles per round of 64 frames; 256 threads.
+//
+// fp16 storage (H16): the values are stored multiplied by store_scale(largest magnitude), so that magnitude has to be
+// known before the first store -- a reduction pass of its own (k_amax_*) instead of the atomic maximum the fp32 kernels
+// take on the way.  On the way out the state only contributes its PHASE: a bin that some sweep could have updated is
+// returned with the fp32 target magnitude it was given (the caller's |S|), a bin no sweep could touch keeps the caller's
+// value bit for bit; so fp16 storage costs phase accuracy, never magnitude accuracy.
 constexpr int TILE = 64, TPAD = TILE + 1;
 
-__global__ void __launch_bounds__(256) k_to_skew(const float2 *state, const float *amp, float2 *state_w, float *amp_w,
-                                                  float2 *state_nyq, float *amp_nyq, unsigned *amax_bits, int T, int F,
-                                                  int L, int Q, int G, int TpPad, int NT) {
+// |S| of a complex64 input exactly as k_prep forms it (fp64 square root, rounded once)
+__device__ __forceinline__ float mag_of(float2 v, double *mag64 = nullptr) {
+    const double m = sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);
+    if (mag64) *mag64 = m;
+    return (float)m;
+}
+
+// largest magnitude of the real frames of each spectrogram; grid (blocks, B)
+__global__ void __launch_bounds__(256) k_amax_in(const float2 *in, unsigned *amax_bits, size_t n_per) {
+    __shared__ float red[256];
+    const float2 *p = in + (size_t)blockIdx.y * n_per;
+    float mx = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_per; i += (size_t)gridDim.x * 256) mx = fmaxf(mx, mag_of(p[i]));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(amax_bits + blockIdx.y, __float_as_uint(red[0]));
+}
+// the same from the extended magnitude buffer [B][Tp][Np] (real frames only; the pad columns repeat real bins)
+__global__ void __launch_bounds__(256) k_amax_ext(const float *amp, unsigned *amax_bits, int T, int Np, int Q) {
+    __shared__ float red[256];
+    const int Tp = T + 2 * (Q - 1);
+    const float *p = amp + ((size_t)blockIdx.y * Tp + (Q - 1)) * Np;
+    const size_t n_per = (size_t)T * Np;
+    float mx = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_per; i += (size_t)gridDim.x * 256) mx = fmaxf(mx, p[i]);
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(amax_bits + blockIdx.y, __float_as_uint(red[0]));
+}
+// smallest threshold of each spectrogram that any of its bins exceeds (+inf if none): a bin whose stored magnitude is not
+// above it is never updated by this call
+__global__ void __launch_bounds__(64) k_thr_min(const float *thr, const float *amax, int n_iters, float *thr_min) {
+    const int b = blockIdx.x;
+    float m = __builtin_inff();
+    for (int i = threadIdx.x; i < n_iters; i += 64) {
+        const float th = thr[(size_t)b * n_iters + i];
+        if (amax[b] > th) m = fminf(m, th);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+    if (threadIdx.x == 0) thr_min[b] = m;
+}
+// fp16 storage: could any sweep of the call have updated a bin of fp32 magnitude `a`?  (the kernel's own test, on the stored
+// half value in the scaled domain)
+__device__ __forceinline__ bool ever_active_h16(float a, float sc, float thr_min) { return unpack_h(pack_h(a * sc)) > thr_min * sc; }
+// fp16 storage: phase of the stored value v, magnitude a
+__device__ __forceinline__ float2 with_magnitude(float2 v, float a, bool *ok) {
+    const float m2 = v.x * v.x + v.y * v.y;
+    *ok = m2 > 0.f;
+    const float s = a / sqrtf(m2);
+    return make_float2(v.x * s, v.y * s);
+}
+
+template <bool H16>
+__global__ void __launch_bounds__(256) k_to_skew(const float2 *state, const float *amp, void *state_w_, void *amp_w_,
+                                                  void *state_nyq_, void *amp_nyq_, unsigned *amax_bits, int T, int F,
+                                                  int L, int Q, int G, int TpPad, int NT, const int *gate) {
+    using ST = Store<H16>;
     __shared__ float2 ts[TILE][TPAD];
     __shared__ float ta[TILE][TPAD];
     __shared__ float red[256];
+    if (gate != nullptr && *gate == 0) return;
     const int kk = blockIdx.x / NT, tt = blockIdx.x - kk * NT, b = blockIdx.y;
     const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), C = F - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;          // first production time of the tile (before the mod G)
-    float2 *sw = state_w + (size_t)b * G * LANES;
-    float *aw = amp_w + (size_t)b * G * LANES;
+    typename ST::cplx *sw = static_cast<typename ST::cplx *>(state_w_) + (size_t)b * G * LANES;
+    typename ST::real *aw = static_cast<typename ST::real *>(amp_w_) + (size_t)b * G * LANES;
+    typename ST::cplx *snq = static_cast<typename ST::cplx *>(state_nyq_) + (size_t)b * TpPad;
+    typename ST::real *anq = static_cast<typename ST::real *>(amp_nyq_) + (size_t)b * TpPad;
+    const float sc = H16 ? store_scale(__uint_as_float(amax_bits[b])) : 1.f;   // (H16: k_amax_ext ran before)
     float mx = 0.f;
     float2 vin[TILE / 4];
     float ain[TILE / 4];
@@ -1474,8 +1615,9 @@ __global__ void __launch_bounds__(256) k_to_skew(const float2 *state, const floa
         if (me < Tp) {
             const size_t i = ((size_t)b * Tp + me) * Np + L + C;
             const float av = amp[i];
-            state_nyq[(size_t)b * TpPad + me] = state[i];
-            amp_nyq[(size_t)b * TpPad + me] = av;
+            const float2 v = state[i];
+            if constexpr (H16) { snq[me] = pack_h2(make_float2(v.x * sc, v.y * sc)); anq[me] = pack_h(av * sc); }
+            else { snq[me] = v; anq[me] = av; }
             if (me >= Q - 1 && me < T + Q - 1) mx = fmaxf(mx, av);
         }
     }
@@ -1484,35 +1626,45 @@ __global__ void __launch_bounds__(256) k_to_skew(const float2 *state, const floa
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
         if (me < Tp && c >= 0 && c < C) {
             const size_t idx = (size_t)((tau0 + tl) % G) * LANES + lane;
-            sw[idx] = ts[lane][tl];
-            aw[idx] = ta[lane][tl];
+            const float2 v = ts[lane][tl];
+            if constexpr (H16) { sw[idx] = pack_h2(make_float2(v.x * sc, v.y * sc)); aw[idx] = pack_h(ta[lane][tl] * sc); }
+            else { sw[idx] = v; aw[idx] = ta[lane][tl]; }
         }
     }
-    // block max -> atomic max on the bit pattern (non-negative floats order like unsigned ints)
-    red[threadIdx.x] = mx;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+    if constexpr (!H16) {
+        // block max -> atomic max on the bit pattern (non-negative floats order like unsigned ints)
+        red[threadIdx.x] = mx;
         __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(amax_bits + b, __float_as_uint(red[0]));
     }
-    if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(amax_bits + b, __float_as_uint(red[0]));
 }
 
 // Also restores the Hermitian pad columns and the Nyquist column of the extended layout.
-__global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float2 *state_w, const float2 *state_nyq, int T,
-                                                    int F, int L, int Q, int G, int TpPad, int NT) {
+template <bool H16>
+__global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float *amp, const void *state_w_, const void *state_nyq_,
+                                                    const float *amax, const float *thr_min, int T, int F, int L, int Q, int G,
+                                                    int TpPad, int NT) {
+    using ST = Store<H16>;
     __shared__ float2 ts[TILE][TPAD];
     const int kk = blockIdx.x / NT, tt = blockIdx.x - kk * NT, b = blockIdx.y;
     const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), C = F - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;
-    const float2 *sw = state_w + (size_t)b * G * LANES;
+    const typename ST::cplx *sw = static_cast<const typename ST::cplx *>(state_w_) + (size_t)b * G * LANES;
+    const typename ST::cplx *snq = static_cast<const typename ST::cplx *>(state_nyq_) + (size_t)b * TpPad;
+    const float sc = H16 ? store_scale(amax[b]) : 1.f, tmin = H16 ? thr_min[b] : 0.f;
     float2 vin[TILE / 4];
 #pragma unroll
     for (int i = 0; i < TILE / 4; ++i) {           // all loads first
         const int tl = wave + 4 * i;
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
-        vin[i] = (me < Tp && c >= 0 && c < C) ? sw[(size_t)((tau0 + tl) % G) * LANES + lane] : make_float2(0.f, 0.f);
+        const bool in_range = me < Tp && c >= 0 && c < C;
+        if constexpr (H16) vin[i] = in_range ? unpack_h2(sw[(size_t)((tau0 + tl) % G) * LANES + lane]) : make_float2(0.f, 0.f);
+        else vin[i] = in_range ? sw[(size_t)((tau0 + tl) % G) * LANES + lane] : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < TILE / 4; ++i) ts[lane][wave + 4 * i] = vin[i];
@@ -1521,7 +1673,13 @@ __global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float2 *
         const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
         if (me < Tp && c >= 0 && c < C) {
             float2 *orow = state + ((size_t)b * Tp + me) * Np;
-            const float2 v = ts[ml][lane];
+            float2 v = ts[ml][lane];
+            if constexpr (H16) {     // phase from the fp16 state, magnitude from the fp32 target; untouched bins stay as they are
+                const float a = amp[((size_t)b * Tp + me) * Np + L + c];
+                bool ok;
+                v = with_magnitude(v, a, &ok);
+                if (!(ok && me >= Q - 1 && me < T + Q - 1 && ever_active_h16(a, sc, tmin))) continue;
+            }
             orow[L + c] = v;
             const float2 vc = make_float2(v.x, -v.y);
             if (c >= 1 && c <= L) orow[L - c] = vc;                 // image below DC
@@ -1530,26 +1688,42 @@ __global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float2 *
     }
     if (tt == 0 && wave == 0) {
         const int me = LANES * kk + lane;
-        if (me < Tp) state[((size_t)b * Tp + me) * Np + L + C] = state_nyq[(size_t)b * TpPad + me];
+        if (me < Tp) {
+            const size_t i = ((size_t)b * Tp + me) * Np + L + C;
+            if constexpr (H16) {
+                const float a = amp[i];
+                bool ok;
+                const float2 v = with_magnitude(unpack_h2(snq[me]), a, &ok);
+                if (ok && me >= Q - 1 && me < T + Q - 1 && ever_active_h16(a, sc, tmin)) state[i] = v;
+            } else {
+                state[i] = snq[me];
+            }
+        }
     }
 }
 
 // The same two conversions straight from / to the caller's unpadded [B][T][F] complex64 spectrograms, for calls that
 // are one batch stage: what k_prep + k_to_skew and k_from_skew + k_extract do in two passes each.
 // partial: [B][tiles] sums of |S| over the real frames in fp64, one per tile (block), for mean|S|.
-__global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *state_w, float *amp_w, float2 *state_nyq,
-                                                     float *amp_nyq, unsigned *amax_bits, double *partial, int T, int F,
-                                                     int Q, int G, int TpPad, int NT) {
+template <bool H16>
+__global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, void *state_w_, void *amp_w_, void *state_nyq_,
+                                                     void *amp_nyq_, unsigned *amax_bits, double *partial, int T, int F,
+                                                     int Q, int G, int TpPad, int NT, const int *gate) {
+    using ST = Store<H16>;
     __shared__ float2 ts[TILE][TPAD];
     __shared__ float ta[TILE][TPAD];
     __shared__ float red[256];
     __shared__ double dred[256];
+    if (gate != nullptr && *gate == 0) return;
     const int kk = blockIdx.x / NT, tt = blockIdx.x - kk * NT, b = blockIdx.y;
     const int Tp = T + 2 * (Q - 1), C = F - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;
-    float2 *sw = state_w + (size_t)b * G * LANES;
-    float *aw = amp_w + (size_t)b * G * LANES;
+    typename ST::cplx *sw = static_cast<typename ST::cplx *>(state_w_) + (size_t)b * G * LANES;
+    typename ST::real *aw = static_cast<typename ST::real *>(amp_w_) + (size_t)b * G * LANES;
+    typename ST::cplx *snq = static_cast<typename ST::cplx *>(state_nyq_) + (size_t)b * TpPad;
+    typename ST::real *anq = static_cast<typename ST::real *>(amp_nyq_) + (size_t)b * TpPad;
+    const float sc = H16 ? store_scale(__uint_as_float(amax_bits[b])) : 1.f;   // (H16: k_amax_in ran before)
     float mx = 0.f;
     double msum = 0.0;                                       // this thread's share of sum |S| over the real frames
     // all of a thread's loads are issued before the first one is used: 16 x 512 bytes in flight per wave
@@ -1570,8 +1744,8 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *st
         const float2 v = vin[i];
         float av = 0.f;
         if (me < Tp && c >= 0 && c < C) {
-            const double mag = sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);   // as k_prep: |S| in fp64, then rounded
-            av = (float)mag;
+            double mag;
+            av = mag_of(v, &mag);                                // as k_prep: |S| in fp64, then rounded
             if (real_frame) { mx = fmaxf(mx, av); msum += mag; }
         }
         ts[ml][lane] = v;
@@ -1583,11 +1757,12 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *st
             int src = me - (Q - 1);
             src = src < 0 ? 0 : (src > T - 1 ? T - 1 : src);
             const float2 v = in[((size_t)b * T + src) * F + C];
-            const double mag = sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);
-            state_nyq[(size_t)b * TpPad + me] = v;
-            amp_nyq[(size_t)b * TpPad + me] = (float)mag;
+            double mag;
+            const float av = mag_of(v, &mag);
+            if constexpr (H16) { snq[me] = pack_h2(make_float2(v.x * sc, v.y * sc)); anq[me] = pack_h(av * sc); }
+            else { snq[me] = v; anq[me] = av; }
             if (me >= Q - 1 && me < T + Q - 1) {
-                mx = fmaxf(mx, (float)mag);
+                mx = fmaxf(mx, av);
                 msum += mag;
             }
         }
@@ -1597,8 +1772,9 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *st
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
         if (me < Tp && c >= 0 && c < C) {
             const size_t idx = (size_t)((tau0 + tl) % G) * LANES + lane;
-            sw[idx] = ts[lane][tl];
-            aw[idx] = ta[lane][tl];
+            const float2 v = ts[lane][tl];
+            if constexpr (H16) { sw[idx] = pack_h2(make_float2(v.x * sc, v.y * sc)); aw[idx] = pack_h(ta[lane][tl] * sc); }
+            else { sw[idx] = v; aw[idx] = ta[lane][tl]; }
         }
     }
     red[threadIdx.x] = mx;
@@ -1612,7 +1788,7 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, float2 *st
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (red[0] > 0.f) atomicMax(amax_bits + b, __float_as_uint(red[0]));
+        if (!H16 && red[0] > 0.f) atomicMax(amax_bits + b, __float_as_uint(red[0]));
         partial[(size_t)b * gridDim.x + blockIdx.x] = dred[0];   // one partial sum per tile
     }
 }
@@ -1632,47 +1808,76 @@ __global__ void __launch_bounds__(256) k_mean_partials(const double *partial, do
     if (threadIdx.x == 0) mean_amp[b] = red[0] / denom;
 }
 
-// skewed layout -> unpadded [B][T][F] output (real frames only, no pad columns)
-__global__ void __launch_bounds__(256) k_skew_to_out(float2 *out, const float2 *state_w, const float2 *state_nyq, int T,
-                                                      int F, int Q, int G, int TpPad, int NT) {
+// skewed layout -> unpadded [B][T][F] output (real frames only, no pad columns).  `in`: the caller's input (fp16 storage
+// only; may be the same buffer as `out`: every element is read and written by the same thread).
+template <bool H16>
+__global__ void __launch_bounds__(256) k_skew_to_out(float2 *out, const float2 *in, const void *state_w_, const void *state_nyq_,
+                                                      const float *amax, const float *thr_min, int T, int F, int Q, int G,
+                                                      int TpPad, int NT) {
+    using ST = Store<H16>;
     __shared__ float2 ts[TILE][TPAD];
     const int kk = blockIdx.x / NT, tt = blockIdx.x - kk * NT, b = blockIdx.y;
     const int Tp = T + 2 * (Q - 1), C = F - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;
-    const float2 *sw = state_w + (size_t)b * G * LANES;
+    const typename ST::cplx *sw = static_cast<const typename ST::cplx *>(state_w_) + (size_t)b * G * LANES;
+    const typename ST::cplx *snq = static_cast<const typename ST::cplx *>(state_nyq_) + (size_t)b * TpPad;
+    const float sc = H16 ? store_scale(amax[b]) : 1.f, tmin = H16 ? thr_min[b] : 0.f;
     float2 vin[TILE / 4];
 #pragma unroll
     for (int i = 0; i < TILE / 4; ++i) {           // all loads first
         const int tl = wave + 4 * i;
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
-        vin[i] = (me < Tp && c >= 0 && c < C) ? sw[(size_t)((tau0 + tl) % G) * LANES + lane] : make_float2(0.f, 0.f);
+        const bool in_range = me < Tp && c >= 0 && c < C;
+        if constexpr (H16) vin[i] = in_range ? unpack_h2(sw[(size_t)((tau0 + tl) % G) * LANES + lane]) : make_float2(0.f, 0.f);
+        else vin[i] = in_range ? sw[(size_t)((tau0 + tl) % G) * LANES + lane] : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < TILE / 4; ++i) ts[lane][wave + 4 * i] = vin[i];
     __syncthreads();
     for (int ml = wave; ml < TILE; ml += 4) {
         const int me = LANES * kk + ml, c = tau0 + lane - SKEW * me;
-        if (me >= Q - 1 && me < T + Q - 1 && c >= 0 && c < C)
-            out[((size_t)b * T + (me - (Q - 1))) * F + c] = ts[ml][lane];
+        if (me >= Q - 1 && me < T + Q - 1 && c >= 0 && c < C) {
+            const size_t o = ((size_t)b * T + (me - (Q - 1))) * F + c;
+            if constexpr (H16) {
+                const float2 orig = in[o];
+                const float a = mag_of(orig);
+                bool ok;
+                const float2 v = with_magnitude(ts[ml][lane], a, &ok);
+                out[o] = (ok && ever_active_h16(a, sc, tmin)) ? v : orig;
+            } else {
+                out[o] = ts[ml][lane];
+            }
+        }
     }
     if (tt == 0 && wave == 0) {
         const int me = LANES * kk + lane;
-        if (me >= Q - 1 && me < T + Q - 1) out[((size_t)b * T + (me - (Q - 1))) * F + C] = state_nyq[(size_t)b * TpPad + me];
+        if (me >= Q - 1 && me < T + Q - 1) {
+            const size_t o = ((size_t)b * T + (me - (Q - 1))) * F + C;
+            if constexpr (H16) {
+                const float2 orig = in[o];
+                const float a = mag_of(orig);
+                bool ok;
+                const float2 v = with_magnitude(unpack_h2(snq[me]), a, &ok);
+                out[o] = (ok && ever_active_h16(a, sc, tmin)) ? v : orig;
+            } else {
+                out[o] = snq[me];
+            }
+        }
     }
 }
 
 constexpr uint32_t mask_all(int Q, int L) { return (Q * (L + 1) >= 32) ? 0xffffffffu : ((1u << (Q * (L + 1))) - 1u); }
 
-template <int Q, int L, uint32_t MASK, bool MULTI> hipError_t launch_km(const SysArgs &a, int grid, hipStream_t s) {
+template <int Q, int L, uint32_t MASK, bool MULTI, bool H16> hipError_t launch_km(const SysArgs &a, int grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_systolic<Q, L, MASK, MULTI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_systolic<Q, L, MASK, MULTI, H16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI, H16>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
 #ifdef LWS_DBG_TIMING
     {
         unsigned long long h[16 * 4];
@@ -1684,8 +1889,9 @@ template <int Q, int L, uint32_t MASK, bool MULTI> hipError_t launch_km(const Sy
 #endif
     return hipGetLastError();
 }
-template <int Q, int L, uint32_t MASK> hipError_t launch_k(const SysArgs &a, int grid, hipStream_t s) {
-    return a.nwg > 1 ? launch_km<Q, L, MASK, true>(a, grid, s) : launch_km<Q, L, MASK, false>(a, grid, s);
+template <int Q, int L, uint32_t MASK> hipError_t launch_k(const SysArgs &a, int grid, bool h16, hipStream_t s) {
+    if (h16) return a.nwg > 1 ? launch_km<Q, L, MASK, true, true>(a, grid, s) : launch_km<Q, L, MASK, false, true>(a, grid, s);
+    return a.nwg > 1 ? launch_km<Q, L, MASK, true, false>(a, grid, s) : launch_km<Q, L, MASK, false, false>(a, grid, s);
 }
 
 // mask bit r*(L+1)+k set <=> |W[0][r][k]| > 1e-12.  Default sqrt-Hann windows give these patterns (L = 5):
@@ -1704,8 +1910,8 @@ struct Tables {
 // =============================================================================================
 // host side
 // =============================================================================================
-hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3]) {
-    sp.F = F; sp.L = L; sp.Q = Q;
+hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3], bool fp16_storage) {
+    sp.F = F; sp.L = L; sp.Q = Q; sp.h16 = fp16_storage;
     for (int i = 0; i < 3; ++i) sp.ok[i] = false;
     const int C = F - 1;
     if (Qp != Q || !(Q == 2 || Q == 4) || L != 5) return hipSuccess;
@@ -1777,7 +1983,7 @@ void systolic_release(SystolicPlan &sp) {
 }
 
 bool systolic_supports(const SystolicPlan &sp, int wsel, int T) {
-    return wsel >= 0 && wsel < 3 && sp.ok[wsel] && T >= 1;  // iteration-count limit: SYSTOLIC_MAX_ITERS
+    return wsel >= 0 && wsel < 3 && sp.ok[wsel] && T >= 1;  // (any number of sweeps: more than SYSTOLIC_MAX_ITERS run as several launches)
 }
 
 const char *systolic_name(const SystolicPlan &sp) { return sp.name; }
@@ -1789,25 +1995,32 @@ struct Geom {
     int Tp, Kr, G, TpPad, NT, nwg;
     int n_full, nwg_rest;   // batches larger than the chip: n_full spectrograms with one workgroup each, then the rest
                             // (B - n_full, fewer than there are CUs) with nwg_rest workgroups each
-    float2 *state_w, *state_nyq;
-    float *amp_w, *amp_nyq;
+    int cb, rb;             // bytes per stored complex value / magnitude (Store<H16>)
+    char *state_w, *state_nyq;
+    char *amp_w, *amp_nyq;
     unsigned *amax_bits, *progress;
+    float *thr_min;
+    int *err;
 };
 
+// (grows the plan's scratch if needed -- a synchronising hipMalloc; systolic_reserve() does that ahead of time)
 hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
     const int Q = sp.Q, F = sp.F;
+    g.cb = sp.h16 ? Store<true>::CB : Store<false>::CB;
+    g.rb = sp.h16 ? Store<true>::RB : Store<false>::RB;
     g.Tp = T + 2 * (Q - 1);
     g.Kr = (g.Tp + LANES - 1) / LANES;
     g.G = ROWP * g.Kr;
     g.TpPad = (g.Tp + 63) & ~63;
     g.NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;   // time tiles per round of 64 frames
-    // scratch: state_w, state_nyq | amp_w, amp_nyq, amax, progress counters, error flag
+    // scratch: state_w, state_nyq | amp_w, amp_nyq, amax, smallest threshold, progress counters, error flag
     const size_t n_w = (size_t)B * g.G * LANES, n_n = (size_t)B * g.TpPad;
-    const size_t need_s = (n_w + n_n) * sizeof(float2);
+    const size_t need_s = (n_w + n_n) * g.cb;
     hipError_t e;
     // workgroups per spectrogram: as many as there are CUs to keep busy and passes to share out; every workgroup must
     // be resident (they wait for each other), which one workgroup per CU (the rings fill the LDS) and a grid no larger
-    // than the CU count guarantee
+    // than the CU count guarantee on a device this process has to itself; if they are not (a shared or partitioned
+    // device), the hand-over times out and the call is re-run with one workgroup per spectrogram (run_kernel)
     int n_cu = 0, dev = 0;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
@@ -1828,8 +2041,11 @@ hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
     // a batch that does not fill the last round of workgroups: the spectrograms of that round share the idle CUs
     g.n_full = B; g.nwg_rest = 1;
     if (nwg == 1 && B > n_cu && B % n_cu != 0 && pick(B % n_cu) > 1) { g.n_full = B - B % n_cu; g.nwg_rest = pick(B % n_cu); }
-    const size_t n_prog = (size_t)B * nwg + (size_t)(B - g.n_full) * g.nwg_rest + 1;   // progress counters + the error flag
-    const size_t need_a = (n_w + n_n) * sizeof(float) + (size_t)B * sizeof(unsigned) + n_prog * sizeof(unsigned);
+    // sized for the largest number of workgroups any iteration count can give this batch, so that the scratch of a shape
+    // does not grow with the schedule
+    const size_t n_prog = (size_t)B * (size_t)(n_cu / (B > 0 ? B : 1) + 1) + (size_t)n_cu + 8;
+    const size_t amp_bytes = ((n_w + n_n) * g.rb + 15) & ~(size_t)15;
+    const size_t need_a = amp_bytes + (size_t)B * sizeof(unsigned) + (size_t)B * sizeof(float) + n_prog * sizeof(unsigned);
     if (need_s > sp.sk_state_cap) {
         if (sp.sk_state) (void)hipFree(sp.sk_state);
         sp.sk_state = nullptr; sp.sk_state_cap = 0;
@@ -1842,65 +2058,126 @@ hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
         if ((e = hipMalloc(&sp.sk_amp, need_a)) != hipSuccess) return e;
         sp.sk_amp_cap = need_a;
     }
-    g.state_w = static_cast<float2 *>(sp.sk_state);
-    g.state_nyq = g.state_w + n_w;
-    g.amp_w = static_cast<float *>(sp.sk_amp);
-    g.amp_nyq = g.amp_w + n_w;
-    g.amax_bits = reinterpret_cast<unsigned *>(g.amp_nyq + n_n);
-    g.progress = g.amax_bits + B;
+    g.state_w = static_cast<char *>(sp.sk_state);
+    g.state_nyq = g.state_w + n_w * g.cb;
+    g.amp_w = static_cast<char *>(sp.sk_amp);
+    g.amp_nyq = g.amp_w + n_w * g.rb;
+    g.amax_bits = reinterpret_cast<unsigned *>(g.amp_w + amp_bytes);
+    g.thr_min = reinterpret_cast<float *>(g.amax_bits + B);
+    g.progress = reinterpret_cast<unsigned *>(g.thr_min + B);
+    g.err = reinterpret_cast<int *>(g.progress + (n_prog - 1));
     return hipSuccess;
 }
 
-hipError_t clear_flags(const Geom &g, int B, hipStream_t stream) {
-    const size_t n_prog = (size_t)B * g.nwg + (size_t)(B - g.n_full) * g.nwg_rest + 1;
-    return hipMemsetAsync(g.amax_bits, 0, ((size_t)B + n_prog) * sizeof(unsigned), stream);
+hipError_t clear_flags(const Geom &g, int B, hipStream_t stream) {   // amax | thr_min | progress counters | error flag
+    return hipMemsetAsync(g.amax_bits, 0, reinterpret_cast<char *>(g.err + 1) - reinterpret_cast<char *>(g.amax_bits), stream);
 }
 
-hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *thr, int B, int T, int iters,
-                      hipStream_t stream) {
+// One launch of the update kernel over spectrograms [b0, b0 + nb) with `nwg` workgroups each: n_it sweeps.
+hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float *thr, int n_it, int b0, int nb, int nwg,
+                         unsigned *progress, const int *gate, int T, hipStream_t stream) {
     const Tables *tb = static_cast<const Tables *>(sp.tables[wsel]);
     const int Q = sp.Q, L = sp.L, F = sp.F;
-    if (iters > MAX_ITERS) return hipErrorInvalidValue;  // caller checks SYSTOLIC_MAX_ITERS
-    const int nwg = g.nwg;
-    hipError_t e = hipSuccess;
-    const size_t n_prog = (size_t)B * nwg + (size_t)(B - g.n_full) * g.nwg_rest;
-    int *err = reinterpret_cast<int *>(g.progress + n_prog);
-    sp.err_dev = err; sp.last_nwg = nwg > g.nwg_rest ? nwg : g.nwg_rest;
-  for (int chunk = 0; chunk < 2; ++chunk) {
-    // chunk 0: the first n_full spectrograms (all of them unless the batch leaves a partial last round on the chip);
-    // chunk 1: the rest, with several workgroups per spectrogram
-    const int b0 = chunk == 0 ? 0 : g.n_full, nb = chunk == 0 ? g.n_full : B - g.n_full;
-    const int nwg = chunk == 0 ? g.nwg : g.nwg_rest;
-    if (nb <= 0) continue;
     SysArgs a;
-    a.state_w = g.state_w + (size_t)b0 * g.G * LANES; a.amp_w = g.amp_w + (size_t)b0 * g.G * LANES;
-    a.state_nyq = g.state_nyq + (size_t)b0 * g.TpPad; a.amp_nyq = g.amp_nyq + (size_t)b0 * g.TpPad;
-    a.thr = thr + (size_t)b0 * iters; a.amax = reinterpret_cast<const float *>(g.amax_bits) + b0;
-    a.n_iters = iters;
+    a.state_w = g.state_w + (size_t)b0 * g.G * LANES * g.cb; a.amp_w = g.amp_w + (size_t)b0 * g.G * LANES * g.rb;
+    a.state_nyq = g.state_nyq + (size_t)b0 * g.TpPad * g.cb; a.amp_nyq = g.amp_nyq + (size_t)b0 * g.TpPad * g.rb;
+    a.thr = thr + (size_t)b0 * n_it; a.amax = reinterpret_cast<const float *>(g.amax_bits) + b0;   // thr: dense [B][n_it]
+    a.n_iters = n_it;
     a.T = T; a.Tp = g.Tp; a.TpPad = g.TpPad; a.Kr = g.Kr; a.G = g.G; a.C = F - 1;
-    a.nwg = nwg; a.progress = g.progress + (chunk == 0 ? 0 : (size_t)B * g.nwg); a.err = err;
-    const int B = nb;   // the launch below is for this chunk
+    a.nwg = nwg; a.progress = progress; a.err = g.err; a.gate = gate;
+    {
+        const char *ev = getenv("LWS_SYSTOLIC_SPIN_LIMIT");   // polls (of ~0.2 us) before a workgroup gives up on its producer
+        a.spin_limit = ev ? atoi(ev) : (1 << 21);
+    }
     for (int x = 0; x < 32; ++x) {
         const float re = x < Q * (L + 1) ? tb->w[2 * x] : 0.f, im = x < Q * (L + 1) ? tb->w[2 * x + 1] : 0.f;
         unsigned ur, ui;
         memcpy(&ur, &re, 4); memcpy(&ui, &im, 4);
         a.w[x] = ((unsigned long long)ui << 32) | ur;
     }
+    const int grid = nb * nwg;
+    const bool h = sp.h16;
+    hipError_t e;
     if (Q == 4) {
-        if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hann" : "systolic_q4_l5_hann"; }
-        else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_hannmask" : "systolic_q4_l5_hannmask"; }
-        else { e = launch_k<4, 5, mask_all(4, 5)>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q4_l5_allmask" : "systolic_q4_l5_allmask"; }
+        if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q4_l5_hann_f16" : "systolic_wide_q4_l5_hann") : (h ? "systolic_q4_l5_hann_f16" : "systolic_q4_l5_hann"); }
+        else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q4_l5_hannmask_f16" : "systolic_wide_q4_l5_hannmask") : (h ? "systolic_q4_l5_hannmask_f16" : "systolic_q4_l5_hannmask"); }
+        else { e = launch_k<4, 5, mask_all(4, 5)>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q4_l5_allmask_f16" : "systolic_wide_q4_l5_allmask") : (h ? "systolic_q4_l5_allmask_f16" : "systolic_q4_l5_allmask"); }
     } else {
-        if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hann" : "systolic_q2_l5_hann"; }
-        else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_hannmask" : "systolic_q2_l5_hannmask"; }
-        else { e = launch_k<2, 5, mask_all(2, 5)>(a, B * nwg, stream); sp.name = LWS_WIDE ? "systolic_wide_q2_l5_allmask" : "systolic_q2_l5_allmask"; }
+        if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q2_l5_hann_f16" : "systolic_wide_q2_l5_hann") : (h ? "systolic_q2_l5_hann_f16" : "systolic_q2_l5_hann"); }
+        else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q2_l5_hannmask_f16" : "systolic_wide_q2_l5_hannmask") : (h ? "systolic_q2_l5_hannmask_f16" : "systolic_q2_l5_hannmask"); }
+        else { e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q2_l5_allmask_f16" : "systolic_wide_q2_l5_allmask") : (h ? "systolic_q2_l5_allmask_f16" : "systolic_q2_l5_allmask"); }
     }
-    if (e != hipSuccess) return e;
-  }
+    return e;
+}
+
+// All sweeps of a call, state in the skewed layout.  `reload(gate)` re-creates that layout from the caller's (still
+// untouched) data, as a launch that only runs if *gate != 0.
+template <typename Reload>
+hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *thr, int B, int T, int iters,
+                      hipStream_t stream, int *launches, Reload reload) {
+    hipError_t e = hipSuccess;
+    if (sp.h16) {
+        hipLaunchKernelGGL(k_thr_min, dim3(B), dim3(64), 0, stream, thr, reinterpret_cast<const float *>(g.amax_bits), iters, g.thr_min);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (iters > MAX_ITERS && (!sp.thr_chunk || sp.thr_chunk_cap < (size_t)B * MAX_ITERS * sizeof(float))) {
+        if (sp.thr_chunk) (void)hipFree(sp.thr_chunk);
+        sp.thr_chunk = nullptr; sp.thr_chunk_cap = 0;
+        if ((e = hipMalloc(&sp.thr_chunk, (size_t)B * MAX_ITERS * sizeof(float))) != hipSuccess) return e;
+        sp.thr_chunk_cap = (size_t)B * MAX_ITERS * sizeof(float);
+    }
+    int n_launch = 0;
+    bool multi = false;
+    // every sweep of the call, either with the workgroup counts of `g` or (single) with one workgroup per spectrogram
+    auto sweep_all = [&](bool single, const int *gate) -> hipError_t {
+        // more sweeps than one launch's threshold table holds: several launches over the same (resident) skewed state.
+        // Same results: a launch boundary is just a longer lag between two sweeps.
+        for (int it0 = 0; it0 < iters; it0 += MAX_ITERS) {
+            const int n_it = iters - it0 < MAX_ITERS ? iters - it0 : MAX_ITERS;
+            const float *thr_c = thr;
+            if (iters > MAX_ITERS) {   // the kernel reads a dense [B][n_iters] table: this launch's columns, copied in stream order
+                if ((e = hipMemcpy2DAsync(sp.thr_chunk, (size_t)n_it * sizeof(float), thr + it0, (size_t)iters * sizeof(float),
+                                          (size_t)n_it * sizeof(float), B, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+                thr_c = static_cast<const float *>(sp.thr_chunk);
+            }
+            for (int chunk = 0; chunk < (single ? 1 : 2); ++chunk) {
+                // chunk 0: the first n_full spectrograms (all of them unless the batch leaves a partial last round on the
+                // chip); chunk 1: the rest, with several workgroups per spectrogram
+                const int b0 = (single || chunk == 0) ? 0 : g.n_full;
+                const int nb = single ? B : (chunk == 0 ? g.n_full : B - g.n_full);
+                const int nwg = single ? 1 : (chunk == 0 ? g.nwg : g.nwg_rest);
+                if (nb <= 0) continue;
+                unsigned *progress = g.progress + (chunk == 0 ? 0 : (size_t)B * g.nwg);
+                if (nwg > 1 && n_launch > 0) {   // multi-workgroup launches re-use the counters: start them from zero again
+                    if ((e = hipMemsetAsync(progress, 0, (size_t)nb * nwg * sizeof(unsigned), stream)) != hipSuccess) return e;
+                }
+                if ((e = launch_update(sp, g, wsel, thr_c, n_it, b0, nb, nwg, progress, gate, T, stream)) != hipSuccess) return e;
+                multi |= nwg > 1;
+                if (!gate) ++n_launch;
+            }
+        }
+        return hipSuccess;
+    };
+    if ((e = sweep_all(false, nullptr)) != hipSuccess) return e;
+    if (multi) {
+        // Several workgroups per spectrogram hand rows over through HBM and need each other resident.  If one of them
+        // timed out (flag set), everything is done again with one workgroup per spectrogram, from the caller's data: the
+        // launches below are enqueued unconditionally and return at once unless the flag is set, so the call stays
+        // asynchronous and never returns the results of a failed hand-over.
+        if ((e = reload(g.err)) != hipSuccess) return e;
+        if ((e = sweep_all(true, g.err)) != hipSuccess) return e;
+    }
+    sp.err_dev = g.err; sp.last_nwg = multi ? (g.nwg > g.nwg_rest ? g.nwg : g.nwg_rest) : 1;
+    if (launches) *launches = n_launch;
     return e;
 }
 
 }  // namespace
+
+hipError_t systolic_reserve(SystolicPlan &sp, int B, int T, int iters) {
+    Geom g;
+    return prepare(sp, B, T, iters, g);
+}
 
 hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp, const float *thr, int B,
                            int T, int iters, hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1909,15 +2186,28 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
     if ((e = prepare(sp, B, T, iters, g)) != hipSuccess) return e;
     if ((e = clear_flags(g, B, stream)) != hipSuccess) return e;
     const int Q = sp.Q, L = sp.L, F = sp.F;
-    hipLaunchKernelGGL(k_to_skew, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, g.state_w, g.amp_w, g.state_nyq,
-                       g.amp_nyq, g.amax_bits, T, F, L, Q, g.G, g.TpPad, g.NT);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    auto load = [&](const int *gate) {
+        if (sp.h16) {
+            if (!gate) hipLaunchKernelGGL(k_amax_ext, dim3(64, B), dim3(256), 0, stream, amp, g.amax_bits, T, F + 2 * L, Q);
+            hipLaunchKernelGGL(k_to_skew<true>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, (void *)g.state_w, (void *)g.amp_w,
+                               (void *)g.state_nyq, (void *)g.amp_nyq, g.amax_bits, T, F, L, Q, g.G, g.TpPad, g.NT, gate);
+        } else {
+            hipLaunchKernelGGL(k_to_skew<false>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, (void *)g.state_w, (void *)g.amp_w,
+                               (void *)g.state_nyq, (void *)g.amp_nyq, g.amax_bits, T, F, L, Q, g.G, g.TpPad, g.NT, gate);
+        }
+        return hipGetLastError();
+    };
+    if ((e = load(nullptr)) != hipSuccess) return e;
     if (ev0) (void)hipEventRecord(ev0, stream);
-    if ((e = run_kernel(sp, g, wsel, thr, B, T, iters, stream)) != hipSuccess) return e;
+    if ((e = run_kernel(sp, g, wsel, thr, B, T, iters, stream, launches, load)) != hipSuccess) return e;
     if (ev1) (void)hipEventRecord(ev1, stream);
-    hipLaunchKernelGGL(k_from_skew, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, g.state_w, g.state_nyq, T, F, L, Q,
-                       g.G, g.TpPad, g.NT);
-    if (launches) *launches = 1;
+    const float *amax = reinterpret_cast<const float *>(g.amax_bits);
+    if (sp.h16)
+        hipLaunchKernelGGL(k_from_skew<true>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, (const void *)g.state_w,
+                           (const void *)g.state_nyq, amax, (const float *)g.thr_min, T, F, L, Q, g.G, g.TpPad, g.NT);
+    else
+        hipLaunchKernelGGL(k_from_skew<false>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, (const void *)g.state_w,
+                           (const void *)g.state_nyq, amax, (const float *)g.thr_min, T, F, L, Q, g.G, g.TpPad, g.NT);
     return hipGetLastError();
 }
 
@@ -1927,6 +2217,17 @@ size_t io_partials_n(int F, int T, int Q) {            // one partial sum per ti
     const int NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;
     const int Tp = T + 2 * (Q - 1), Kr = (Tp + LANES - 1) / LANES;
     return (size_t)Kr * NT;
+}
+hipError_t io_load(SystolicPlan &sp, const Geom &g, const float2 *in, int B, int T, double *partial, hipStream_t stream, const int *gate) {
+    if (sp.h16) {
+        if (!gate) hipLaunchKernelGGL(k_amax_in, dim3(64, B), dim3(256), 0, stream, in, g.amax_bits, (size_t)T * sp.F);
+        hipLaunchKernelGGL(k_in_to_skew<true>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, in, (void *)g.state_w, (void *)g.amp_w,
+                           (void *)g.state_nyq, (void *)g.amp_nyq, g.amax_bits, partial, T, sp.F, sp.Q, g.G, g.TpPad, g.NT, gate);
+    } else {
+        hipLaunchKernelGGL(k_in_to_skew<false>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, in, (void *)g.state_w, (void *)g.amp_w,
+                           (void *)g.state_nyq, (void *)g.amp_nyq, g.amax_bits, partial, T, sp.F, sp.Q, g.G, g.TpPad, g.NT, gate);
+    }
+    return hipGetLastError();
 }
 }  // namespace
 size_t systolic_io_partials(const SystolicPlan &sp, int T) { return io_partials_n(sp.F, T, sp.Q); }
@@ -1938,23 +2239,27 @@ hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, in
     if ((e = prepare(sp, B, T, iters, g)) != hipSuccess) return e;
     if ((e = clear_flags(g, B, stream)) != hipSuccess) return e;
     const size_t n = io_partials_n(sp.F, T, sp.Q);
-    hipLaunchKernelGGL(k_in_to_skew, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, in, g.state_w, g.amp_w, g.state_nyq,
-                       g.amp_nyq, g.amax_bits, partial, T, sp.F, sp.Q, g.G, g.TpPad, g.NT);
+    if ((e = io_load(sp, g, in, B, T, partial, stream, nullptr)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_mean_partials, dim3(B), dim3(256), 0, stream, partial, mean_amp, (int)n, (double)T * (double)sp.F);
     return hipGetLastError();
 }
 
-hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, float2 *out, int B, int T, int iters,
-                           hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1) {
+hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, const float2 *in, float2 *out, double *partial, int B, int T,
+                           int iters, hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1) {
     Geom g;
     hipError_t e;
     if ((e = prepare(sp, B, T, iters, g)) != hipSuccess) return e;   // same shapes: no reallocation, same pointers
     if (ev0) (void)hipEventRecord(ev0, stream);
-    if ((e = run_kernel(sp, g, wsel, thr, B, T, iters, stream)) != hipSuccess) return e;
+    auto reload = [&](const int *gate) { return io_load(sp, g, in, B, T, partial, stream, gate); };
+    if ((e = run_kernel(sp, g, wsel, thr, B, T, iters, stream, launches, reload)) != hipSuccess) return e;
     if (ev1) (void)hipEventRecord(ev1, stream);
-    hipLaunchKernelGGL(k_skew_to_out, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, out, g.state_w, g.state_nyq, T, sp.F, sp.Q,
-                       g.G, g.TpPad, g.NT);
-    if (launches) *launches = 1;
+    const float *amax = reinterpret_cast<const float *>(g.amax_bits);
+    if (sp.h16)
+        hipLaunchKernelGGL(k_skew_to_out<true>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, out, in, (const void *)g.state_w,
+                           (const void *)g.state_nyq, amax, (const float *)g.thr_min, T, sp.F, sp.Q, g.G, g.TpPad, g.NT);
+    else
+        hipLaunchKernelGGL(k_skew_to_out<false>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, out, in, (const void *)g.state_w,
+                           (const void *)g.state_nyq, amax, (const float *)g.thr_min, T, sp.F, sp.Q, g.G, g.TpPad, g.NT);
     return hipGetLastError();
 }
 

@@ -182,7 +182,7 @@ def get_thresholds(iterations, alpha, beta, gamma):
 # --------------------------------------------------------------------------------------------
 # the hot path (lws.pyx:209-375) -> HIP engine
 # --------------------------------------------------------------------------------------------
-_PLAN_DEFAULTS = {"device": 0, "precision": "fp32", "nofuture_q4_compat": True, "force_generic": False}
+_PLAN_DEFAULTS = {"device": 0, "precision": "fp32", "nofuture_q4_compat": True, "force_generic": False, "storage": "fp32"}
 
 
 def _prepare(S, W, use_simplifications, n_extra_w=()):
@@ -259,7 +259,7 @@ class lws(object):
                  online_iterations=0, online_alpha=1, online_beta=0.1, online_gamma=1,
                  batch_iterations=100, batch_alpha=100, batch_beta=0.1, batch_gamma=1,
                  symmetric_win=True, mode=None, fftsize=None, perfectrec=True, use_simplifications=True,
-                 device=0, precision="fp32", nofuture_q4_compat=True, force_generic=False):
+                 device=0, precision="fp32", nofuture_q4_compat=True, force_generic=False, storage="fp32"):
         if isinstance(awin_or_fsize, (int, np.integer)):
             awin = np.sqrt(hann(int(awin_or_fsize), symmetric=symmetric_win, use_offset=False))
             awin = np.sqrt(awin * synthwin(awin, fshift))
@@ -325,7 +325,7 @@ class lws(object):
                   'The current code uses simplifications that rely on such symmetry, so the code may not behave properly.')
         self.device = int(device)
         self._plan_kw = dict(device=device, precision=precision, nofuture_q4_compat=nofuture_q4_compat,
-                             force_generic=force_generic)
+                             force_generic=force_generic, storage=storage)
         self._plan = None
 
     # -- engine plumbing (not part of the reference surface) --

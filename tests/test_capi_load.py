@@ -74,7 +74,7 @@ def test_library_exports_the_lwslib_h_interface():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     declared = set(re.findall(r"^(?:void|const char \*)\s*([A-Za-z_0-9]+)\s*\(", text, flags=re.M))
     assert declared - {"lwslib_compat_last_error"} == set(RefLib.SYMS)
-    lib = _capi.load()
+    lib = _capi.load_raw()
     for name, sym in RefLib.SYMS.items():
         assert hasattr(lib, sym), f"{name} ({sym}) not exported"
     assert hasattr(lib, "_Z24lwslib_compat_last_errorv")

@@ -1,0 +1,50 @@
+"""GPU (-m gpu): the reference's own usage snippet (python/README.md:92-102) under the reference's module name, and the
+two bindings of the C ABI (the Cython shim and ctypes) side by side."""
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_readme_snippet_runs_unchanged():
+    import lws                                   # the reference's module name
+    x = np.random.default_rng(0).standard_normal(40000)
+    lws_processor = lws.lws(512, 128, mode="speech")      # 512: window length; 128: window shift
+    X = lws_processor.stft(x)                    # where x is a single-channel waveform
+    X0 = np.abs(X)                               # Magnitude spectrogram
+    c0 = lws_processor.get_consistency(X0)
+    X1 = lws_processor.run_lws(X0)               # reconstruction from magnitude
+    c1 = lws_processor.get_consistency(X1)
+    assert X1.dtype == np.complex128 and X1.shape == X0.shape
+    assert c1 > c0 + 5.0, (c0, c1)
+    assert np.abs(np.abs(X1) - X0).max() < 2e-6 * X0.max()
+    assert lws.__version__ == "1.2.8"
+    # module-level functions of the reference surface
+    W = lws.create_weights(lws_processor.awin, lws_processor.swin, 128, 5)
+    Y = lws.batch_lws(X0, W, lws.get_thresholds(10, 1.0, 0.1, 1))
+    assert Y.shape == X0.shape
+
+
+def test_cython_and_ctypes_bindings_agree():
+    """The default binding is the Cython shim (lws_amd/_cylws, built by make -C lws_amd/csrc); LWS_BINDING=ctypes
+    selects the ctypes one.  Same library, same results."""
+    from lws_amd import _capi
+    _capi.load()
+    assert _capi.BINDING == "cython", "the Cython shim was not built / not importable"
+    code = ("import numpy as np, lws_amd; from lws_amd import _capi; _capi.load(); "
+            "p = lws_amd.lws(64, 16, batch_iterations=5, batch_alpha=1.0); "
+            "S = np.random.default_rng(1).standard_normal((9, 33)) + 0j; "
+            "print(_capi.BINDING, repr(float(np.abs(p.batch_lws(S)).sum())), repr(complex(p.batch_lws(S)[3, 7])))")
+    outs = []
+    for binding in ("cython", "ctypes"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True,
+                           env=dict(__import__("os").environ, LWS_BINDING=binding))
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.split())
+    assert outs[0][0] == "cython" and outs[1][0] == "ctypes"
+    assert outs[0][1:] == outs[1][1:]
