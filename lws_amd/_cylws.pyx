@@ -33,6 +33,11 @@ cdef uintptr_t _addr(object x) except? 1:
     return <uintptr_t>int(v)
 
 
+cdef double _dbl(object x) except? -1.0e300:
+    """A C double from a Python number or a ctypes c_double."""
+    return float(getattr(x, "value", x))
+
+
 def lws_hip_version():
     return c.lws_hip_version()
 
@@ -101,8 +106,9 @@ def lws_nofuture_lws(plan, int wsel, S_in, S_out, int B, int T, thresholds, int 
     return rc
 
 
-def lws_online_lws(plan, S_in, S_out, int B, int T, thresholds, int iters, int LA, double qdiv):
+def lws_online_lws(plan, S_in, S_out, int B, int T, thresholds, int iters, int LA, qdiv_):
     cdef uintptr_t p = _addr(plan), i = _addr(S_in), o = _addr(S_out), t = _addr(thresholds)
+    cdef double qdiv = _dbl(qdiv_)
     cdef int rc
     with nogil:
         rc = c.lws_online_lws(<c.lws_plan *>p, <const double *>i, <double *>o, B, T, <const double *>t, iters, LA, qdiv)
@@ -110,8 +116,9 @@ def lws_online_lws(plan, S_in, S_out, int B, int T, thresholds, int iters, int L
 
 
 def lws_run_lws(plan, S_in, S_out, int B, int T, thr_nofuture, int it_nofuture, thr_online, int it_online, int LA,
-                double qdiv, thr_batch, int it_batch):
+                qdiv_, thr_batch, int it_batch):
     cdef uintptr_t p = _addr(plan), i = _addr(S_in), o = _addr(S_out)
+    cdef double qdiv = _dbl(qdiv_)
     cdef uintptr_t t0 = _addr(thr_nofuture), t1 = _addr(thr_online), t2 = _addr(thr_batch)
     cdef int rc
     with nogil:
@@ -136,8 +143,9 @@ def lws_nofuture_lws_dev(plan, int wsel, S_dev, int B, int T, thresholds, int it
     return rc
 
 
-def lws_online_lws_dev(plan, S_dev, int B, int T, thresholds, int iters, int LA, double qdiv, stream):
+def lws_online_lws_dev(plan, S_dev, int B, int T, thresholds, int iters, int LA, qdiv_, stream):
     cdef uintptr_t p = _addr(plan), s = _addr(S_dev), t = _addr(thresholds), st = _addr(stream)
+    cdef double qdiv = _dbl(qdiv_)
     cdef int rc
     with nogil:
         rc = c.lws_online_lws_dev(<c.lws_plan *>p, <void *>s, B, T, <const double *>t, iters, LA, qdiv, <void *>st)
@@ -145,8 +153,9 @@ def lws_online_lws_dev(plan, S_dev, int B, int T, thresholds, int iters, int LA,
 
 
 def lws_run_lws_dev(plan, S_dev, int B, int T, thr_nofuture, int it_nofuture, thr_online, int it_online, int LA,
-                    double qdiv, thr_batch, int it_batch, stream):
+                    qdiv_, thr_batch, int it_batch, stream):
     cdef uintptr_t p = _addr(plan), s = _addr(S_dev), st = _addr(stream)
+    cdef double qdiv = _dbl(qdiv_)
     cdef uintptr_t t0 = _addr(thr_nofuture), t1 = _addr(thr_online), t2 = _addr(thr_batch)
     cdef int rc
     with nogil:
@@ -251,9 +260,9 @@ def lws_build_asymmetric_windows(awin_swin, int fsize, int fshift, win_ai, win_a
     return c.lws_build_asymmetric_windows(<const double *>a, fsize, fshift, <double *>i, <double *>f)
 
 
-def lws_get_thresholds(int iterations, double alpha, double beta, double gamma, out):
+def lws_get_thresholds(int iterations, alpha, beta, gamma, out):
     cdef uintptr_t o = _addr(out)
-    return c.lws_get_thresholds(iterations, alpha, beta, gamma, <double *>o)
+    return c.lws_get_thresholds(iterations, _dbl(alpha), _dbl(beta), _dbl(gamma), <double *>o)
 
 
 # ---- one host thread per device (include/lws_hip.h, "multi-device") ----------------------------------------------------
@@ -288,8 +297,9 @@ def lws_multi_batch_lws(mp, int wsel, S_in, S_out, int B, int T, thresholds, int
 
 
 def lws_multi_run_lws(mp, S_in, S_out, int B, int T, thr_nofuture, int it_nofuture, thr_online, int it_online, int LA,
-                      double qdiv, thr_batch, int it_batch):
+                      qdiv_, thr_batch, int it_batch):
     cdef uintptr_t p = _addr(mp), i = _addr(S_in), o = _addr(S_out)
+    cdef double qdiv = _dbl(qdiv_)
     cdef uintptr_t t0 = _addr(thr_nofuture), t1 = _addr(thr_online), t2 = _addr(thr_batch)
     cdef int rc
     with nogil:

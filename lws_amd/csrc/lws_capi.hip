@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "lws_systolic.h"
 #include "lws_online.h"
+#include "lws_nofuture.h"
 
 namespace {
 
@@ -217,6 +218,19 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
             if (e != hipSuccess) return fail(LWS_ERR_HIP, "online launch failed: %s", hipGetErrorString(e));
             p->last_launches = 1;
             p->last_name = "online_lds_fp32";
+            return LWS_OK;
+        }
+    }
+    if constexpr (std::is_same<real, float>::value) {
+        // no-future sweeps: the last Q + 1 frames live in LDS (same results as the generic engine, bit for bit)
+        if ((mode == lws::MODE_NOFUTURE || mode == lws::MODE_NOFUTURE_Q4_COMPAT) && !(p->flags & LWS_FORCE_GENERIC) &&
+            lws::nofuture_lds_supports(a.F, a.T, a.L, a.Q, a.Qp)) {
+            begin_timing(p, s);
+            hipError_t e = lws::launch_nofuture_lds(a, B, s);
+            end_timing(p, s);
+            if (e != hipSuccess) return fail(LWS_ERR_HIP, "no-future launch failed: %s", hipGetErrorString(e));
+            p->last_launches = 1;
+            p->last_name = mode == lws::MODE_NOFUTURE_Q4_COMPAT ? "nofuture_lds_q4compat_fp32" : "nofuture_lds_fp32";
             return LWS_OK;
         }
     }

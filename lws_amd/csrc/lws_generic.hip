@@ -217,6 +217,9 @@ __global__ void __launch_bounds__(1024) k_generic(GenericArgs<real> a) {
                 for (int n0 = n_split; n0 < F + L;) {
                     int n1 = (n0 + Np - L + 1) / 2;
                     if (n1 > F + L) n1 = F + L;
+                    // a bin n <= 2L writes its image into column 2L - n; keep such bins out of rounds whose other bins could
+                    // read that column through the flat offset (only possible for F <= 3L - 1): run them one by one
+                    if (n0 <= 2 * L) n1 = n0 + 1;
                     for (int n = n0 + tid; n < n1; n += nthr)
                         update_bin_nfq4<real>(S, amp, m + Q - 1, n - L, ws, th, F, L);
                     __syncthreads();

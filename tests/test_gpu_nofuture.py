@@ -1,0 +1,84 @@
+"""GPU (-m gpu): the LDS-resident no-future kernel (lws_nofuture.hip) against the order-exact generic engine -- which the
+goldens pin to the reference (tests/test_gpu_parity.py, tests/test_gpu_compat.py) -- bit for bit in fp32, over both
+addressing modes (NoFuture_LWSanyQ semantics and the shipped NoFuture_LWSQ4's flat offset, lwslib.cpp:538-617), several
+Q and L, multi-sweep schedules and the tiny frames where the compat rounds degenerate; plus the oracle in fp64."""
+import numpy as np
+import pytest
+
+import lws_amd
+from lws_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def weights(fsize, fshift, L):
+    p = lws_amd.lws(fsize, fshift, L=L)
+    return p.W_ai, p
+
+
+@pytest.mark.parametrize("fsize,fshift,L,T,compat", [
+    (64, 16, 5, 40, True), (64, 16, 5, 40, False), (1024, 256, 5, 70, True), (1024, 256, 5, 33, False),
+    (2048, 512, 5, 20, True), (64, 32, 5, 50, False), (64, 8, 5, 30, False), (48, 16, 3, 25, False),
+    (64, 16, 3, 25, True), (64, 16, 1, 25, True), (128, 32, 7, 25, True), (16, 4, 5, 30, True), (20, 5, 5, 30, True),
+    (24, 6, 5, 30, True)])
+def test_lds_kernel_equals_generic_engine_bit_for_bit(fsize, fshift, L, T, compat):
+    rng = np.random.default_rng(fsize + T + L)
+    F = fsize // 2 + 1
+    if L > F - 2:
+        pytest.skip("L too large for F")
+    W, p = weights(fsize, fshift, L)
+    S = rng.standard_normal((3, T, F)) + 1j * rng.standard_normal((3, T, F))
+    S[2] = np.abs(S[2])                                  # zero-phase magnitudes: the run_lws(abs(X)) case
+    lds = _capi.Plan(F, W, nofuture_q4_compat=compat)
+    gen = _capi.Plan(F, W, nofuture_q4_compat=compat, force_generic=True)
+    for thr in ([0.0], [0.9, 0.4, 0.0]):
+        a = lds.nofuture(S, thr)
+        name = lds.last_kernel()["name"]
+        Q = W.shape[1]
+        assert name == ("nofuture_lds_q4compat_fp32" if (compat and Q == 4) else "nofuture_lds_fp32"), name
+        b = gen.nofuture(S, thr)
+        assert gen.last_kernel()["name"] == "generic_fp32"
+        assert np.array_equal(a, b), (fsize, fshift, L, T, compat, len(thr))
+    lds.close(); gen.close()
+
+
+@pytest.mark.parametrize("fsize,fshift", [(16, 4), (20, 5), (24, 6), (28, 7), (64, 16)])
+def test_compat_rounds_on_tiny_frames_against_the_oracle(oracle, fsize, fshift):
+    """F <= 3L - 1: a bin of the upper range writes a Hermitian image that later bins of the same frame read through the
+    flat offset; the rounds must keep the sequential order there (fp64 generic engine vs the oracle's sequential loop)."""
+    rng = np.random.default_rng(fsize)
+    F = fsize // 2 + 1
+    L = min(5, F - 2)
+    W, p = weights(fsize, fshift, L)
+    S = rng.standard_normal((30, F)) + 1j * rng.standard_normal((30, F))
+    g64 = _capi.Plan(F, W, precision="fp64")
+    for thr in ([0.0], [0.5, 0.0]):
+        ref = oracle.nofuture_lws(S, W, thr, compat=True)
+        out = g64.nofuture(S, thr)
+        # (an order violation shows up at 1e-2; what is left is re-association amplified by near-cancelling sums)
+        assert np.abs(out - ref).max() < 1e-6, (fsize, np.abs(out - ref).max())
+    g64.close()
+    lds = _capi.Plan(F, W)
+    out32 = lds.nofuture(S, [0.0])
+    assert np.linalg.norm(out32 - oracle.nofuture_lws(S, W, [0.0], compat=True)) / np.linalg.norm(S) < 1e-2
+    lds.close()
+
+
+def test_config3_nofuture_stage_time_and_values():
+    """256 x 500 x 513 (BASELINE config 3's first stage): one sweep; same bits as the generic engine on a sample."""
+    import torch
+    rng = np.random.default_rng(1)
+    p = lws_amd.lws(1024, 256, mode="music")
+    B, T, F = 64, 500, 513
+    M = np.abs(rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))).astype(np.complex64)
+    t = torch.from_numpy(M).cuda()
+    thr = lws_amd.get_thresholds(1, 1, 0.1, 1)
+    stream = torch.cuda.current_stream().cuda_stream
+    p.plan().nofuture_dev(t.data_ptr(), B, T, thr, wsel=1, stream=stream)
+    info = p.plan().last_kernel()
+    assert info["name"] == "nofuture_lds_q4compat_fp32" and info["ms"] < 9.0, info   # (the generic engine needs 17 ms)
+    pg = lws_amd.lws(1024, 256, mode="music", force_generic=True)
+    t2 = torch.from_numpy(M[:4]).cuda()
+    pg.plan().nofuture_dev(t2.data_ptr(), 4, T, thr, wsel=1, stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(t[:4], t2)
