@@ -46,10 +46,10 @@
 #include <utility>
 #include <vector>
 
-// The file is compiled twice: as is (frames of up to 513 bins: 8-step skew between lanes, 32-step ring, 7 sweep slots)
-// and with -DLWS_WIDE=1 into namespace lws::wide (frames of up to 1025 bins: a lane needs 1024 steps per frame, so the
-// 64 lanes of a round are skewed by 16 steps, the lag between sweeps and the ring are 64 steps deep and 3 sweep slots
-// fit the LDS).
+// The file is compiled twice: as is (frames of up to 513 bins: a round of 64 frames, one wave per sweep slot, 7 sweep slots)
+// and with -DLWS_WIDE=1 into namespace lws::wide (frames of up to 1025 bins: a lane needs 1024 steps per frame, so a round
+// is 128 frames = TWO waves per sweep slot on a ring row of 128 lanes, with the same 8-step skew, 32-step lag and ring
+// depth; 3 sweep slots (6 compute waves) and two service waves, one per half of the row, fit the LDS).
 #ifndef LWS_WIDE
 #define LWS_WIDE 0
 #endif
@@ -64,8 +64,12 @@
 LWS_NS_OPEN
 namespace {
 
-constexpr int LANES = 64;
-constexpr int RING = LWS_WIDE ? 64 : 32;
+constexpr int LANES = 64;                                // lanes of a wave
+constexpr int WPS = LWS_WIDE ? 2 : 1;                    // waves per sweep slot
+constexpr int ROWL = LANES * WPS;                        // lanes (frames) of a ring row = frames of a round
+constexpr int ROWL_SHIFT = LWS_WIDE ? 7 : 6;
+static_assert((1 << ROWL_SHIFT) == ROWL, "row length");
+constexpr int RING = 32;
 constexpr int NBLK = RING / 8;                           // ring blocks of 8 steps
 // ring entry of production time nu, lane l:  set + ((nu >> 1) & 15) * PAIR_BYTES + (l + HALO) * 16 + (nu & 1) * 8
 // -- two consecutive times of one lane share a 16-byte cell, so a reader fetches two adjacent taps with one
@@ -76,11 +80,11 @@ constexpr int NBLK = RING / 8;                           // ring blocks of 8 ste
 // 8m - j), lane PLR the Nyquist bin and the bins above it (times 8m + C + j), written conjugated by the lane that
 // produces the mirrored bin -- the reference's pad columns (lwslib.cpp:362-367), kept in time coordinates.  A lane
 // near a frame edge reads those cells instead of its neighbour lane's: same compile-time offsets, other base.
-constexpr int SLOT_BYTES = LANES * 8;                    // Nyquist buffer: bytes per set (64 float2)
+constexpr int SLOT_BYTES = ROWL * 8;                     // Nyquist buffer: bytes per set (one float2 per row lane)
 constexpr int HALO = 3;                                  // >= Q - 1
 constexpr int LANE_B = 16;
-constexpr int PLL = LANES + 2 * HALO, PLR = PLL + 1;      // absolute row indices of the two image pseudo-lanes
-constexpr int PAIR_BYTES = (LANES + 2 * HALO + 2) * LANE_B;  // two consecutive times x 72 row entries
+constexpr int PLL = ROWL + 2 * HALO, PLR = PLL + 1;       // absolute row indices of the two image pseudo-lanes
+constexpr int PAIR_BYTES = (ROWL + 2 * HALO + 2) * LANE_B;   // two consecutive times x 72 (136) row entries
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
 constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB
 #ifndef LWS_NSLOTS
@@ -97,13 +101,12 @@ constexpr int DUMMY_OFF = DONE_OFF + 64;               // 64 x 8 B: where predic
 constexpr int SCRATCH_OFF = DUMMY_OFF + LANES * 8;     // where the compute lanes that have no image to publish store instead (see image_base)
 constexpr int SCRATCH_BYTES = 4 * PAIR_BYTES + LANES * 8;
 constexpr int LDS_BYTES = SCRATCH_OFF + SCRATCH_BYTES;
-constexpr int SKEW = LWS_WIDE ? 16 : 8, ROWP = SKEW * LANES, LAG = RING;
+constexpr int SKEW = 8, ROWP = SKEW * ROWL, LAG = RING;
 constexpr int ROWP_SHIFT = LWS_WIDE ? 10 : 9;
 static_assert((1 << ROWP_SHIFT) == ROWP, "frame period");
-#ifndef LWS_SERVICE_WAVE
-#define LWS_SERVICE_WAVE 1   // loader + Nyquist bins run on a wave of their own
-#endif
-constexpr int NTHREADS = LANES * (NSLOTS + LWS_SERVICE_WAVE);
+constexpr int NCOMPUTE = NSLOTS * WPS;                   // compute waves; roles NCOMPUTE .. NCOMPUTE + WPS - 1 are the service waves
+constexpr int NTHREADS = LANES * (NCOMPUTE + WPS);
+static_assert(NCOMPUTE + WPS <= 16, "one progress counter per wave");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 template <int... Is, typename F>
@@ -166,21 +169,14 @@ struct SysArgs {
     int *err;                // set if a workgroup gave up waiting for its producer
     const int *gate;         // non-null: run only if *gate != 0 (the single-workgroup re-run after a hand-over time-out)
     int spin_limit;          // polls of a producer's counter before a workgroup gives up
+    int stress;              // test hook (LWS_SYSTOLIC_STRESS): role mask | pair << 16 -- the waves of the mask stall ~10 us
+                             // before that pair of every block; the flow control must make the results independent of it
     unsigned long long w[4 * 8];   // W[0][r][k], r < Q, k <= L (at most 4 x 8): bit patterns of (re, im) as one 64-bit scalar
 };
 
 // volatile: keeps every tap a separate ds_read_b64 (the backend otherwise fuses pairs into
 // ds_read2st64_b64, which moves half the bytes per LDS cycle -- MI355X_MICROARCH.md, LDS table)
-#ifndef LWS_DBG_NOLDS
-#define LWS_DBG_NOLDS 0     // timing experiment: taps come from registers instead of LDS (results invalid)
-#endif
-#ifndef LWS_DBG_NOMATH
-#define LWS_DBG_NOMATH 0    // timing experiment: one add per tap pair instead of the weighted sum (results invalid)
-#endif
 __device__ __forceinline__ float2 lds_read(int addr) {
-#if LWS_DBG_NOLDS
-    return make_float2(__int_as_float(addr), 1.0f);
-#endif
     // `addr` is a byte offset into the dynamic LDS segment, which starts at LDS address 0 (the kernel
     // has no static __shared__ objects); address space 3 keeps it a ds_ instruction
     using lds_u64 = const volatile __attribute__((address_space(3))) unsigned long long;
@@ -202,9 +198,6 @@ __device__ __forceinline__ void lds_write_i32(int addr, int v) {
 }
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4f lds_read128(int addr) {
-#if LWS_DBG_NOLDS
-    return (v4f){__int_as_float(addr), 1.0f, 2.0f, __int_as_float(addr + 1)};
-#endif
     using lds_v4 = const volatile __attribute__((address_space(3))) v4f;
     return *(lds_v4 *)(unsigned)addr;
 }
@@ -272,9 +265,6 @@ template <bool H16> __device__ __forceinline__ float load_real_raw(const void *b
 // Stores another workgroup (possibly on another XCD, behind another L2) will read during this launch: write through.
 // (With one workgroup per spectrogram producer and consumer share the CU's XCD and a plain store is enough.)
 template <bool H16> __device__ __forceinline__ void store_l2(void *base, size_t idx, float2 v, bool shared) {
-#ifdef LWS_DBG_NOSTORE   // timing experiment: nothing is written back (results invalid)
-    return;
-#endif
     if constexpr (H16) {
         const unsigned u = pack_h2(v);
         if (shared) __hip_atomic_store(static_cast<unsigned *>(base) + idx, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -296,16 +286,10 @@ template <bool H16> __device__ __forceinline__ void store_l2(void *base, size_t 
 // in LDS; LDS executes the operations of one wave in program order and all ring accesses are volatile (compiler
 // order), so "write data, then the counter" / "read the counter, then the data" is sufficient.  No barriers.
 __device__ __forceinline__ void flow_wait(int lane, int s, bool watched) {
-#ifdef LWS_DBG_NOFLOW   // timing experiment: waves do not wait for each other (results invalid)
-    return;
-#endif
     const int addr = DONE_OFF + (lane & 15) * 4;   // lane l < number of waves watches wave l
     while (true) {
         const int v = lds_read_i32(addr);
         if (__all(!watched || v >= s)) break;
-#ifdef LWS_SLEEP
-        __builtin_amdgcn_s_sleep(1);   // measured: polling without a sleep is 1 % faster
-#endif
     }
 }
 __device__ __forceinline__ void flow_publish(int lane, int wave, int s_next) {
@@ -319,7 +303,7 @@ struct LaneCtx {
                       //      the own (new) set is the next one: + SET_BYTES, a compile-time offset
     int uo[NBLK];     // [m]: wave-uniform row origin (set + block) of the old set, for the image pseudo-lanes
     int nyq_base;     // NYQ_OFF + own set row + lane*8 (taps derive the neighbour lane / set from it)
-    int halo_shift;   // +-64 lanes in bytes for the 6 lanes that also write a halo copy, else 0
+    int halo_shift;   // +-ROWL lanes in bytes for the 6 lanes that also write a halo copy, else 0
     int dummy;        // private LDS slot for predicated-off conditional writes
     int lane8;
     bool is_start, is_end, live;                 // this block (8 bins of one frame)
@@ -338,20 +322,9 @@ __host__ __device__ constexpr int floor_div8(int q) { return (q >= 0) ? q / 8 : 
 // write a lane's value and, for the first / last HALO lanes, its halo copy at the other end of the row (branch-free and
 // without per-write address arithmetic: the halo origin obh[] is the lane's own origin shifted by +-64 lanes for those six
 // lanes and unshifted for the others, so both writes use the same immediate offset)
-#ifndef LWS_DBG_NOIMG
-#define LWS_DBG_NOIMG 0     // timing experiment: no halo / image writes (results invalid)
-#endif
-#ifndef LWS_DBG_NOWRAP2
-#define LWS_DBG_NOWRAP2 0   // timing experiment: the straddling pair shares one set of fetches (results invalid)
-#endif
 __device__ __forceinline__ void ring_publish(int addr, int addr_halo, float2 v) {
-#ifdef LWS_DBG_NOPUBLISH   // timing experiment: results are not written to the rings (results invalid)
-    return;
-#endif
     lds_write(addr, v);
-#if !LWS_DBG_NOIMG
     lds_write(addr_halo, v);   // the halo copy of the first / last HALO lanes; every other lane writes its own entry twice
-#endif
 }
 
 // address of the ring entry of the lane DR frames away, produced at clock (block start + P + OFF); P may be 8
@@ -382,9 +355,6 @@ template <int P, int OFF, int LIDX, int NEWSET = 0> __device__ __forceinline__ i
 // would have been produced: 2j steps earlier / later.  `u` = wave-uniform row origins of the lane's output set.
 template <int L, int PH, int PB, int NEWSET>
 __device__ __forceinline__ void image_publish(const int (&u)[NBLK], bool st, bool en, int dummy, float2 out) {
-#if LWS_DBG_NOIMG
-    return;
-#endif
     constexpr bool lo = (PH >= 1 && PH <= L), hi = (PH >= 8 - L && PH <= 7);
     if constexpr (lo && hi) {   // a lane is at the start or at the end of a frame, never both
         const int a_lo = ring_addr_abs<PB, -2 * PH, PLL, NEWSET>(u), a_hi = ring_addr_abs<PB, 2 * (8 - PH), PLR, NEWSET>(u);
@@ -412,9 +382,6 @@ template <int PH, int NEWSET> __host__ __device__ constexpr int image_off() {   
 }
 template <int L, int PH, int NEWSET>
 __device__ __forceinline__ void image_store(int base_lo, int base_hi, int base_both, float2 out) {
-#if LWS_DBG_NOIMG
-    return;
-#endif
     constexpr bool lo = (PH >= 1 && PH <= L), hi = (PH >= 8 - L && PH <= 7);
     if constexpr (lo || hi) lds_write((lo && hi ? base_both : (lo ? base_lo : base_hi)) + image_off<PH, NEWSET>(), cj(out));
 }
@@ -470,7 +437,7 @@ template <int PA, int DR, int L, uint32_t KMASK, int MODE>
 __device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L + 2]) {
     static_assert((PA & 1) == 1 && (L & 1) == 1, "pairs start on odd phases; L odd");
     static_assert(MODE == 0 || PA == 7, "split views only for the pair that straddles two frames");
-    static_assert(LWS_DBG_NOWRAP2 || MODE != 0 || PA != 7, "the straddling pair needs split views");
+    static_assert(MODE != 0 || PA != 7, "the straddling pair needs split views");
     constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
     constexpr int q_first = PA + base_off - L;                   // even
     static_for<L + 1>([&](auto ip) {
@@ -495,10 +462,8 @@ __device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L +
             // one add per (frame, ring block) for the image cells: the lane's origin plus an offset that is zero except
             // for the lane at the frame edge (LaneCtx::wlo / whi); everything else is the instruction's immediate offset
             int base = cx.ob[m];
-#if !LWS_DBG_NOSEL
             if constexpr (img_lo) base = cx.ob[m] + (MODE == 2 ? cx.wlo_nxt[DR + 3] : cx.wlo[DR + 3]);
             if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + 3];
-#endif
             const int addr = base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES;
             if constexpr (need0 && need1) {
                 const v4f v = lds_read128(addr);
@@ -599,9 +564,6 @@ template <int ROT> __device__ __forceinline__ v2f pk_add_rot(v2f x, v2f y) {
 //   = p (b + c) + q j (b - c)   with (p, q) = (wr, wi), (-wi, wr), (-wr, -wi), (wi, -wr) for ROT = 0..3,
 //   j (dx, dy) = (-dy, dx)
 template <int ROT> __device__ __forceinline__ void pair_rot(float2 &a, wp_t w, float2 b, float2 c) {
-#if LWS_DBG_NOMATH
-    a.x += b.x; a.y += c.y; return;
-#endif
     v2f acc = vv(a), t0, t1;
     const v2f vb = vv(b), vc = vv(c);
     constexpr int R = ROT & 3;
@@ -871,17 +833,11 @@ __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
 // non-zero.  target/|acc| is evaluated as target * rsqrt(|acc|^2) with the hardware reciprocal square root (1 ulp:
 // the new magnitude is within 3e-7 relative of the target, tests/test_gpu_parity.py checks 1e-6).
 __device__ __forceinline__ float2 project(float2 acc, float target, bool active, float2 old) {
-#ifdef LWS_DBG_NOPROJECT   // timing experiment: no re-projection (results invalid)
-    return active ? make_float2(acc.x * target, acc.y * target) : old;
-#endif
     // (the weights carry a per-spectrogram power-of-two scale that keeps |acc|^2 inside the fp32 range -- k_systolic;
     // a sum more than 1e-19 below the spectrogram's largest magnitude counts as zero)
     const float m2 = acc.x * acc.x + acc.y * acc.y;
     const bool ok = active && (m2 > 0.f);
     float r = __frsqrt_rn(m2);
-#ifdef LWS_PROJECT_NEWTON   // one Newton step on the reciprocal square root: 3 more dependent operations per bin (1.2 ms per pass)
-    r = r * fmaf(-0.5f * m2 * r, r, 1.5f);
-#endif
     const float sc = target * r;
     return ok ? make_float2(acc.x * sc, acc.y * sc) : old;
 }
@@ -899,21 +855,10 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     const bool stA = cx.is_start, enA = cx.is_end;
     const bool stB = wrap ? cx.nxt_start : cx.is_start, enB = wrap ? cx.nxt_end : cx.is_end;
     // previous-sweep values of the own bins of the NEXT pair (ages 29 and 28 now, 31 and 30 by then)
-#ifdef LWS_DBG_NOCARRY   // timing experiment: the own previous-sweep values are not fetched (results invalid)
-    const float2 o3 = cr.o1, o4 = cr.o2;
-#else
     // (clocks PA+3 and PA+4 share a 16-byte cell: one conflict-free ds_read_b128 instead of two 8-byte reads)
     static_assert(((PA + 3 - LAG) & 1) == 0, "cell alignment of the carried values");
     const v4f o34 = lds_read128(ring_addr<PA, 3 - LAG>(cx.ob));
     const float2 o3 = make_float2(o34.x, o34.y), o4 = make_float2(o34.z, o34.w);
-#endif
-#ifndef LWS_DBG_NOCPATCH
-#define LWS_DBG_NOCPATCH 0   // timing experiment: centre-frame taps never use images (results invalid)
-#endif
-#ifndef LWS_DBG_NOSEL
-#define LWS_DBG_NOSEL 0      // timing experiment: row taps never use the image lanes (results invalid)
-#endif
-    constexpr bool CP = !LWS_DBG_NOCPATCH;
     // Issue priority (s_setprio; the SIMD serves the higher priority first, the older wave among equals).  The two sweep
     // slots of a SIMD run the same pair at the same time and every pair ends in a rendez-vous, so what counts is when
     // the LATER of the two publishes.  Left alone, the older wave wins every issue slot, finishes early and waits while
@@ -921,22 +866,15 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     // the pair (the serial part: last taps, two projections, the publishes) and lowering it for the bulk in between lets
     // whichever wave is in its tail go first and the two leapfrog through the bulk: 41.8 -> 39.7 ms.  The service wave,
     // which every slot meets at every pair, stays above all of them.
-#ifndef LWS_NO_PRIO
 #define LWS_SETPRIO(n) asm volatile("s_setprio " #n)
-#else
-#define LWS_SETPRIO(n)
-#endif
     LWS_SETPRIO(1);
     float2 accA = make_float2(0.f, 0.f);
-    centre_sum<L, MASK, PA, PA>(a, cx, CP && stA, CP && enA, cr.o0, cr.o1, cr.prev_out, accA);
+    centre_sum<L, MASK, PA, PA>(a, cx, stA, enA, cr.o0, cr.o1, cr.prev_out, accA);
     float2 accB = make_float2(0.f, 0.f);
     // frame pairs m-+R.  With FLAG_R13 rows 3 leave partial sums for rows 1: order 2, 3, 1 keeps them short-lived.
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
-#ifndef LWS_QUAD
-#define LWS_QUAD 1
-#endif
     // (1,2)+(3,4) in full; (5,6)+(7,0') for bin 7 only: bin 0' belongs to the lane's next frame and keeps its own fetches
-    constexpr bool quad_first = LWS_QUAD && (PA == 1 || PA == 5), quad_second = LWS_QUAD && (PA == 3 || PA == 7);
+    constexpr bool quad_first = (PA == 1 || PA == 5), quad_second = (PA == 3 || PA == 7);
     R13Partials<L> p3A, p3B;
     if constexpr (quad_first) {
         // this pair and the neighbour-frame sums of the next one, from 7-cell windows (rows_sum_ahead)
@@ -1006,10 +944,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
         constexpr int i = decltype(ir)::value;
         constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
         constexpr uint32_t kmask = (MASK >> (R * K1)) & ((1u << K1) - 1u);
-#ifdef LWS_DBG_ONLYROW   // timing experiment: only this row pair (0: none) is fetched and summed (results invalid)
-        if constexpr (R != LWS_DBG_ONLYROW) return;
-#endif
-        if constexpr (!wrap || LWS_DBG_NOWRAP2) {
+        if constexpr (!wrap) {
             float2 tu[2 * L + 2], td[2 * L + 2];
             load_row2<PA, -R, L, kmask, 0>(cx, tu);
             load_row2<PA, R, L, kmask, 0>(cx, td);
@@ -1038,7 +973,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     ring_publish(ring_addr<PA, 0, 0, 1>(cx.ob), ring_addr<PA, 0, 0, 1>(cx.obh), outA);
     image_store<L, PA, 1>(cx.img_lo, cx.img_hi, cx.img_both, outA);
     // ---- second bin (its centre taps include the first bin's result)
-    centre_sum<L, MASK, PHB, PBB>(a, cx, CP && stB, CP && enB, cr.o1, cr.o2, outA, accB);
+    centre_sum<L, MASK, PHB, PBB>(a, cx, stB, enB, cr.o1, cr.o2, outA, accB);
     const float tB = wrap ? raw_real<H16>(amp_nxt[0]) : amp_cur[PBB & 7];   // (amp_nxt holds what the loads delivered: raw bits)
     const bool liveB = wrap ? cx.nxt_live : cx.live;
     const float2 outB = project(accB, tB, liveB && (tB > (wrap ? cx.nxt_thr : cx.thr)), cr.o1);
@@ -1074,18 +1009,18 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     // every slot and for the loader: LAG and C are multiples of SKEW)
     if (((v0 - C) & (SKEW - 1)) != 0) return;
     const int vrow = (v0 - C) / SKEW;            // virtual frame whose Nyquist bin is due now (floor: SKEW | v0 - C)
-    const int rho = vrow & 63, kap = vrow >> 6;
+    const int rho = vrow & (ROWL - 1), kap = vrow >> ROWL_SHIFT;
     const int gl = kap / Kr, k = kap - gl * Kr;
     const int g = MULTI ? gl * a.nwg + wg : gl;   // global pass (this workgroup runs passes wg, wg + nwg, ...)
-    const int me = k * LANES + rho;
+    const int me = k * ROWL + rho;
     const int j = g * NSLOTS + (is_nyq_lane ? slot : -1);
     const bool valid = (v0 - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
     if (is_nyq_loader) {
         const float2 nin = raw_value<H16>(sv.nyq_in_next);   // loaded one block ago for this frame
         lds_write(NYQ_OFF + rho * 8, nin);
         lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, nin);   // and as entry "bin C" of set 0's image lane
-        const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
-        const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
+        const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
+        const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
         if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2<H16>(state_nyq_b, me1);
     }
     if (is_nyq_lane) {
@@ -1096,7 +1031,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         int nb[4][NBLK], ob[4][NBLK], nn[4], no[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int ln = ((rho - d) & 63), lo = ((rho + d) & 63);
+            const int ln = ((rho - d) & (ROWL - 1)), lo = ((rho + d) & (ROWL - 1));
             nn[d] = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln * 8;
             no[d] = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
 #pragma unroll
@@ -1138,15 +1073,12 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         // (the last slot stores whatever reaches it: idle slots of the last group pass the final values on)
         if ((slot == NSLOTS - 1) && (v0 - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2<H16>(state_nyq_b, me, out, MULTI);
         // target magnitude of the next block's Nyquist bin
-        const int vr1 = vrow + 1, rho1 = vr1 & 63, kap1 = vr1 >> 6;
-        const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * LANES + rho1;
+        const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
+        const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
         sv.nyq_amp_next = (vr1 >= 0 && me1 < a.Tp) ? load_real_raw<H16>(amp_nyq_b, me1) : 0.f;   // (raw zero bits = 0 in both formats)
     }
 }
 
-#ifdef LWS_DBG_TIMING   // timing experiment: clocks each wave of workgroup 0 spends waiting / working (scratch/exp_timing.py)
-__device__ unsigned long long g_dbg_timing[16 * 4];
-#endif
 // MULTI: several workgroups share a spectrogram (a.nwg > 1); the single-workgroup instantiation carries none of it
 template <int Q, int L, uint32_t MASK, bool MULTI, bool H16>
 __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a_in) {
@@ -1179,14 +1111,19 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #ifndef LWS_ROLE_SWAP
 #define LWS_ROLE_SWAP (!LWS_WIDE)
 #endif
+    // Wide build: a sweep slot is two waves (the lower and the upper 64 lanes of the 128-lane ring row: role = 2 slot + half)
+    // and there are two service waves, one per half (roles 6 and 7: each loads and writes back its 64 lanes; the first one
+    // also computes the Nyquist bins).
     const int hw_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // provably uniform
-    const int wave = (LWS_ROLE_SWAP && NSLOTS == 7) ? (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave)) : hw_wave;
+    const int wave = (LWS_ROLE_SWAP && NSLOTS == 7 && WPS == 1) ? (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave)) : hw_wave;
+    const int hf = wave % WPS;                     // which half of the ring row this wave's lanes are
+    const int rl = hf * LANES + lane;              // the lane's place in the ring row = its frame within a round
     float *thr_eff = reinterpret_cast<float *>(smem + THR_OFF);
     int *meta = reinterpret_cast<int *>(smem + META_OFF);
     const int G = a.G, C = a.C, Kr = a.Kr;
     using ST = Store<H16>;
-    void *state_w_b = static_cast<char *>(a.state_w) + (size_t)b * G * LANES * ST::CB;
-    const void *amp_w_b = static_cast<const char *>(a.amp_w) + (size_t)b * G * LANES * ST::RB;
+    void *state_w_b = static_cast<char *>(a.state_w) + (size_t)b * G * ROWL * ST::CB;
+    const void *amp_w_b = static_cast<const char *>(a.amp_w) + (size_t)b * G * ROWL * ST::RB;
     void *state_nyq_b = static_cast<char *>(a.state_nyq) + (size_t)b * a.TpPad * ST::CB;
     const void *amp_nyq_b = static_cast<const char *>(a.amp_nyq) + (size_t)b * a.TpPad * ST::RB;
     constexpr int T_START = -8;   // one block of warm-up: the pair (7, 0') of block -1 produces clock 0
@@ -1220,8 +1157,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     // last slot and its Nyquist lanes have completed; the loader of the next workgroup in the ring waits (acquire)
     // until the rows it is about to fetch are there.  The producer of local pass gl is the previous workgroup's local
     // pass gl, or for workgroup 0 the last workgroup's local pass gl - 1 (one pass = G rows earlier on its clock).
-    const unsigned *prod_progress = a.progress + (size_t)b * nwg + (wg ? wg - 1 : nwg - 1);
-    unsigned *my_progress = a.progress + (size_t)b * nwg + wg;
+    // (one counter per workgroup and half of the row: a service wave hands over, and waits for, its own 64 lanes)
+    const unsigned *prod_progress = a.progress + ((size_t)b * nwg + (wg ? wg - 1 : nwg - 1)) * WPS + hf;
+    unsigned *my_progress = a.progress + ((size_t)b * nwg + wg) * WPS + hf;
     const int prod_shift = wg ? 0 : G;
     // Last row, on the producer's clock, that any valid frame of my last pass reads (frame me starts SKEW*me rows into
     // a pass, so lanes are up to SKEW*63 rows apart and a pass ends later for the later frames): rows beyond it are
@@ -1248,9 +1186,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         asm volatile("" ::: "memory");
     };
 
-    const bool is_compute = wave < NSLOTS;
-    const bool is_service = (wave == NSLOTS);
-    const int slot = wave;
+    const bool is_compute = wave < NCOMPUTE;
+    const bool is_service = !is_compute;
+    const int slot = is_compute ? wave / WPS : NSLOTS;
     LaneCtx cx;
     Carry cr;
     cr.o0 = cr.o1 = cr.o2 = cr.prev_out = make_float2(0.f, 0.f);
@@ -1270,7 +1208,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         if constexpr (MULTI) wait_rows(8 + 40);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {   // clocks 0..7
-            const float2 v = load_l2<H16>(state_w_b, (size_t)i * LANES + lane);
+            const float2 v = load_l2<H16>(state_w_b, (size_t)i * ROWL + rl);
             amp_cur[i] = v.x;
             amp_nxt[i] = v.y;
         }
@@ -1278,10 +1216,15 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const int set_old = slot * SET_BYTES;   // ring set this slot reads "old" values from; it writes the next one
     // flow control: lane l watches wave l.  A compute wave waits for its producer, its consumer and the service wave;
     // the service wave for every compute wave (loader overwrites what slot 0 reads; the Nyquist lanes read every slot).
+    // (two waves per slot: also the other half of the own slot -- the lanes next to the middle of the row read each other's
+    // output -- and both halves of the neighbouring slots and of the service.  The two service waves wait for each other as
+    // well: the Nyquist lanes of the first one read, 25..29 steps back, entries of set 0 that the second one's loader
+    // rewrites two pairs later, so neither may run a pair ahead of the other.)
     bool watched = false;
-    if (lane <= NSLOTS) {
-        if (is_service) watched = lane < NSLOTS;
-        else watched = (lane == wave - 1) || (lane == wave + 1) || (lane == NSLOTS);
+    if (lane < NCOMPUTE + WPS) {
+        const int wslot = lane < NCOMPUTE ? lane / WPS : NSLOTS;     // the slot of wave `lane`
+        if (is_service) watched = lane != wave;
+        else watched = (lane != wave) && (wslot == slot - 1 || wslot == slot || wslot == slot + 1 || wslot == NSLOTS);
     }
     // Where a lane is in a block of 8 steps (which frame of which sweep, first / last bins of the frame, active at
     // all): evaluated once per block for the FOLLOWING block and shifted.  The lanes of a wave sit in at most two
@@ -1305,13 +1248,13 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             else if (++rcur.k == Kr) { rcur.k = 0; ++rcur.gl; }
             const int j = (rcur.gl * nwg + wg) * NSLOTS + slot;
             rcur.okj = is_compute && ks >= 0 && j < n_eff;
-            rcur.meb = rcur.k * LANES;
+            rcur.meb = rcur.k * ROWL;
             rcur.thr = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(thr_eff[rcur.okj ? j : 0])));
         }
         BlockInfo bi;
-        const bool here = SKEW * lane <= rem;                    // this lane's frame of the current round has started
-        const int cbase = (rem - SKEW * lane) & (ROWP - 1);
-        const int me = (here ? rcur.meb : rprev.meb) + lane;
+        const bool here = SKEW * rl <= rem;                      // this lane's frame of the current round has started
+        const int cbase = (rem - SKEW * rl) & (ROWP - 1);
+        const int me = (here ? rcur.meb : rprev.meb) + rl;
         const bool valid = (here ? rcur.okj : rprev.okj) && (me < a.Tp);
         bi.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
         bi.start = (cbase == 0);
@@ -1321,20 +1264,14 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     };
     int dlo[7];   // per-lane constants of the image-cell offsets: (PLL - HALO - DR - lane) * 16
 #pragma unroll
-    for (int d = 0; d < 7; ++d) dlo[d] = (PLL - HALO - (d - 3) - lane) * LANE_B;
+    for (int d = 0; d < 7; ++d) dlo[d] = (PLL - HALO - (d - 3) - rl) * LANE_B;
     BlockInfo nxt_bi = block_info(T_START - (slot + 1) * LAG);
     int vmod = __builtin_amdgcn_readfirstlane((((T_START - (slot + 1) * LAG) % G) + G) % G - 8);   // advanced at the loop head
     int tmod = __builtin_amdgcn_readfirstlane(((T_START % G) + G) % G - 8);
-#ifdef LWS_DBG_TIMING
-    unsigned long long tm_wait = 0, tm_work = 0, tm_pub = 0, tm_pro = 0, tm_mark = __builtin_amdgcn_s_memtime();
-#endif
     for (int t0 = T_START; t0 < t_end; t0 += 8) {
         const int v0 = t0 - (slot + 1) * LAG;  // clock of this sweep slot at phase 0 of the block (multiple of 8)
         // ---- block prologue: where is this lane in this block and in the next one?
         const int ablk = (v0 >> 3);
-#ifdef LWS_DBG_NOPROLOG   // timing experiment: the per-block bookkeeping is done once (results invalid)
-        if (t0 == T_START)
-#endif
         {
             const BlockInfo cur = nxt_bi;
             nxt_bi = block_info(v0 + 8);
@@ -1342,10 +1279,10 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             cx.nxt_live = nxt_bi.live; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end;
             cx.nxt_thr = nxt_bi.thr;
         }
-        cx.lane8 = lane * 8;
-        cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + lane * 8;
+        cx.lane8 = rl * 8;
+        cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + rl * 8;
         cx.dummy = DUMMY_OFF + lane * 8;
-        cx.halo_shift = (lane < HALO) ? LANES * LANE_B : (lane >= LANES - HALO ? -LANES * LANE_B : 0);
+        cx.halo_shift = (rl < HALO) ? ROWL * LANE_B : (rl >= ROWL - HALO ? -ROWL * LANE_B : 0);
 #pragma unroll
         for (int d = 0; d < 7; ++d) {   // (only the entries of frames that exist, |DR| <= Q-1, are ever read)
             cx.wlo[d] = cx.is_start ? dlo[d] : 0;
@@ -1356,7 +1293,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         for (int m = 0; m < NBLK; ++m) {
             const int blk = ((ablk - m) & (NBLK - 1)) * BLK_BYTES;
             cx.uo[m] = set_old + blk;
-            cx.ob[m] = set_old + blk + lane * LANE_B;
+            cx.ob[m] = set_old + blk + rl * LANE_B;
             cx.obh[m] = cx.ob[m] + cx.halo_shift;
         }
         {
@@ -1373,39 +1310,29 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
 #pragma unroll
             for (int i = 0; i < 8; ++i) amp_cur[i] = raw_real<H16>(amp_nxt[i]);   // (fp16 storage: the conversion takes the place of the move)
-#ifdef LWS_DBG_NOAMP   // timing experiment: no target-magnitude loads (results invalid)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) amp_nxt[i] = (float)(vnext + i);
-#else
             // The loads are asm statements so that they land in amp_nxt's own registers and nobody waits for them here
             // (written as plain loads the compiler fetches into temporaries and copies -- i.e. waits -- at once: a stall
             // of one memory latency per block).  The waits are explicit: before amp_nxt[0] is first used (pair (7, 0'))
             // and at the end of the block; these are the only vector-memory operations of a sweep slot.
-            const char *ap = static_cast<const char *>(amp_w_b) + ((size_t)vnext * LANES + lane) * ST::RB;
+            const char *ap = static_cast<const char *>(amp_w_b) + ((size_t)vnext * ROWL + rl) * ST::RB;
 #define LWS_AMP_LOAD(i)                                                                                                             \
     do {                                                                                                                            \
-        if constexpr (H16) asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * LANES * 2) : "memory"); \
-        else asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * LANES * 4) : "memory"); \
+        if constexpr (H16) asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * ROWL * 2) : "memory"); \
+        else asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * ROWL * 4) : "memory"); \
     } while (0)
             LWS_AMP_LOAD(0); LWS_AMP_LOAD(1); LWS_AMP_LOAD(2); LWS_AMP_LOAD(3);
             LWS_AMP_LOAD(4); LWS_AMP_LOAD(5); LWS_AMP_LOAD(6); LWS_AMP_LOAD(7);
 #undef LWS_AMP_LOAD
-#endif
         }
         // ---- 4 pairs of bins, phases static
         static_for<4>([&](auto ip) {
             constexpr int PA = 2 * decltype(ip)::value + 1;
-#ifdef LWS_DBG_TIMING
-            { const unsigned long long n = __builtin_amdgcn_s_memtime(); if (PA == 1) tm_pro += n - tm_mark; else tm_pub += n - tm_mark; tm_mark = n; }
-#endif
             flow_wait(lane, t0 + PA, watched);
-#ifdef LWS_DBG_TIMING
-            { const unsigned long long n = __builtin_amdgcn_s_memtime(); tm_wait += n - tm_mark; tm_mark = n; }
-#endif
-#ifndef LWS_DBG_NOAMP
             if constexpr (PA == 7) { if (is_compute) asm volatile("s_waitcnt vmcnt(7)" : "+v"(amp_nxt[0]) : : "memory"); }   // in-order: the first of the 8
-#endif
             if (is_compute) compute_pair<Q, L, MASK, PA, H16>(a, cx, cr, amp_cur, amp_nxt, qc);
+            if (a.stress != 0 && ((a.stress >> wave) & 1) && PA == ((a.stress >> 16) & 7)) {   // test hook, see SysArgs
+                for (int q = 0; q < 10; ++q) __builtin_amdgcn_s_sleep(32);
+            }
             if constexpr (PA == 1 && MULTI) {
                 if (is_service) {
                     // every slot has finished the previous block (flow_wait above); this wave has written back what the last
@@ -1420,11 +1347,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             if (is_service) {
                 LWS_SETPRIO(3);   // (and back to 0 with everybody else after the publish below)
                 // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
-#ifndef LWS_DBG_NONYQ   // timing experiment: no Nyquist bins (results invalid)
-                if constexpr (PA == 1)
-#else
-                if constexpr (false)
-#endif
+                if (PA == 1 && hf == 0)
                     service_nyquist<Q, L, MASK, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
                 // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
                 // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
@@ -1432,10 +1355,10 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #pragma unroll
                 for (int m = 0; m < NBLK; ++m) {
                     ldu[m] = (((t0 >> 3) - m) & (NBLK - 1)) * BLK_BYTES;
-                    ldb[m] = ldu[m] + lane * LANE_B;
+                    ldb[m] = ldu[m] + rl * LANE_B;
                     ldh[m] = ldb[m] + cx.halo_shift;
                 }
-                const int cb0 = (t0 - SKEW * lane) & (ROWP - 1), cb1 = (t0 + 8 - SKEW * lane) & (ROWP - 1);
+                const int cb0 = (t0 - SKEW * rl) & (ROWP - 1), cb1 = (t0 + 8 - SKEW * rl) & (ROWP - 1);
                 const bool l_st = cb0 == 0, l_en = cb0 == C - 8, l_stn = cb1 == 0, l_enn = cb1 == C - 8;
                 const float2 vA = raw_value<H16>(make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]));
                 const float2 vB = raw_value<H16>(make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]));
@@ -1449,10 +1372,10 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 {
                     if constexpr (PA == 1) {   // where the last slot's lanes are in this block of its clock
                         wb_prev = wb_cur;
-                        const int vv = t0 - NSLOTS * LAG - SKEW * lane;
+                        const int vv = t0 - NSLOTS * LAG - SKEW * rl;
                         const int kap = vv >> ROWP_SHIFT;
                         const int gl = (int)(((float)kap + 0.5f) * inv_kr), k = kap - gl * Kr;
-                        wb_cur = (vv >= 0) && ((vv & (ROWP - 1)) < C) && (k * LANES + lane < a.Tp) && (gl * nwg + wg < n_groups);
+                        wb_cur = (vv >= 0) && ((vv & (ROWP - 1)) < C) && (k * ROWL + rl < a.Tp) && (gl * nwg + wg < n_groups);
                     }
                     const v4f w = lds_read128(ring_addr<PA, -3>(ldb) + NSLOTS * SET_BYTES);
                     int r0 = tmod + PA - 3 - NSLOTS * LAG;
@@ -1461,40 +1384,25 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                     int r1 = r0 + 1;
                     r1 -= (r1 >= G) ? G : 0;
                     if (PA == 1 ? wb_prev : wb_cur) {
-                        store_l2<H16>(state_w_b, (size_t)r0 * LANES + lane, make_float2(w.x, w.y), MULTI);
-                        store_l2<H16>(state_w_b, (size_t)r1 * LANES + lane, make_float2(w.z, w.w), MULTI);
+                        store_l2<H16>(state_w_b, (size_t)r0 * ROWL + rl, make_float2(w.x, w.y), MULTI);
+                        store_l2<H16>(state_w_b, (size_t)r1 * ROWL + rl, make_float2(w.z, w.w), MULTI);
                     }
                 }
                 int i0 = tmod + PA + 8, i1 = tmod + PA + 9;
                 i0 -= (i0 >= G) ? G : 0;
                 i1 -= (i1 >= G) ? G : 0;
-#ifdef LWS_DBG_NOLOADER   // timing experiment: the loader fetches nothing (results invalid)
-                const float2 p0 = make_float2((float)i0, 1.f), p1 = make_float2((float)i1, 2.f);
-#else
-                const float2 p0 = load_l2<H16>(state_w_b, (size_t)i0 * LANES + lane);
-                const float2 p1 = load_l2<H16>(state_w_b, (size_t)i1 * LANES + lane);
-#endif
+                const float2 p0 = load_l2<H16>(state_w_b, (size_t)i0 * ROWL + rl);
+                const float2 p1 = load_l2<H16>(state_w_b, (size_t)i1 * ROWL + rl);
                 amp_cur[PA & 7] = p0.x; amp_nxt[PA & 7] = p0.y;
                 amp_cur[(PA + 1) & 7] = p1.x; amp_nxt[(PA + 1) & 7] = p1.y;
             }
-#ifdef LWS_DBG_TIMING
-            { const unsigned long long n = __builtin_amdgcn_s_memtime(); tm_work += n - tm_mark; tm_mark = n; }
-#endif
             flow_publish(lane, wave, t0 + PA + 2);
             LWS_SETPRIO(0);   // polling for the next pair must not take issue slots from the wave still working
         });
-#ifndef LWS_DBG_NOAMP
         if (is_compute)   // the next block's magnitudes (issued 4 pairs ago) are in their registers before anything may move them
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(amp_nxt[0]), "+v"(amp_nxt[1]), "+v"(amp_nxt[2]), "+v"(amp_nxt[3]),
                          "+v"(amp_nxt[4]), "+v"(amp_nxt[5]), "+v"(amp_nxt[6]), "+v"(amp_nxt[7]) : : "memory");
-#endif
     }
-#ifdef LWS_DBG_TIMING
-    if (blockIdx.x == 0 && lane == 0) {
-        g_dbg_timing[wave * 4 + 0] = tm_wait; g_dbg_timing[wave * 4 + 1] = tm_work;
-        g_dbg_timing[wave * 4 + 2] = tm_pub; g_dbg_timing[wave * 4 + 3] = tm_pro;
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1503,7 +1411,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 // Both directions move 64 x 64 tiles (64 frames of one lane round x 64 production times) through LDS: in the reference
 // layout a frame's bins are contiguous, in the skewed layout the 64 lanes of a time step are, so the tile is read along
 // one and written along the other and both sides of the copy are full 512-byte segments.
-// grid: (Kr * NT, B) with NT = ceil((SKEW*63 + C) / 64) time tiles per round of 64 frames; 256 threads.
+// grid: (Kt * NT, B) with Kt = ceil(Tp / 64) groups of 64 frames and NT = ceil((SKEW*63 + C) / 64) time tiles per group;
+// 256 threads.  Frame me sits in column me mod ROWL of the rows (SKEW*me + c) mod G: with two waves per sweep slot
+// (wide build) a ring row, hence a row of the layout, is 128 frames wide and two groups of 64 frames share its rows.
 //
 // fp16 storage (H16): the values are stored multiplied by store_scale(largest magnitude), so that magnitude has to be
 // known before the first store -- a reduction pass of its own (k_amax_*) instead of the atomic maximum the fp32 kernels
@@ -1585,8 +1495,8 @@ __global__ void __launch_bounds__(256) k_to_skew(const float2 *state, const floa
     const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), C = F - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;          // first production time of the tile (before the mod G)
-    typename ST::cplx *sw = static_cast<typename ST::cplx *>(state_w_) + (size_t)b * G * LANES;
-    typename ST::real *aw = static_cast<typename ST::real *>(amp_w_) + (size_t)b * G * LANES;
+    typename ST::cplx *sw = static_cast<typename ST::cplx *>(state_w_) + (size_t)b * G * ROWL;
+    typename ST::real *aw = static_cast<typename ST::real *>(amp_w_) + (size_t)b * G * ROWL;
     typename ST::cplx *snq = static_cast<typename ST::cplx *>(state_nyq_) + (size_t)b * TpPad;
     typename ST::real *anq = static_cast<typename ST::real *>(amp_nyq_) + (size_t)b * TpPad;
     const float sc = H16 ? store_scale(__uint_as_float(amax_bits[b])) : 1.f;   // (H16: k_amax_ext ran before)
@@ -1625,7 +1535,7 @@ __global__ void __launch_bounds__(256) k_to_skew(const float2 *state, const floa
     for (int tl = wave; tl < TILE; tl += 4) {                // one production time per wave: 64 consecutive lanes
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
         if (me < Tp && c >= 0 && c < C) {
-            const size_t idx = (size_t)((tau0 + tl) % G) * LANES + lane;
+            const size_t idx = (size_t)((tau0 + tl) % G) * ROWL + (me & (ROWL - 1));
             const float2 v = ts[lane][tl];
             if constexpr (H16) { sw[idx] = pack_h2(make_float2(v.x * sc, v.y * sc)); aw[idx] = pack_h(ta[lane][tl] * sc); }
             else { sw[idx] = v; aw[idx] = ta[lane][tl]; }
@@ -1654,7 +1564,7 @@ __global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float *a
     const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), C = F - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;
-    const typename ST::cplx *sw = static_cast<const typename ST::cplx *>(state_w_) + (size_t)b * G * LANES;
+    const typename ST::cplx *sw = static_cast<const typename ST::cplx *>(state_w_) + (size_t)b * G * ROWL;
     const typename ST::cplx *snq = static_cast<const typename ST::cplx *>(state_nyq_) + (size_t)b * TpPad;
     const float sc = H16 ? store_scale(amax[b]) : 1.f, tmin = H16 ? thr_min[b] : 0.f;
     float2 vin[TILE / 4];
@@ -1663,8 +1573,8 @@ __global__ void __launch_bounds__(256) k_from_skew(float2 *state, const float *a
         const int tl = wave + 4 * i;
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
         const bool in_range = me < Tp && c >= 0 && c < C;
-        if constexpr (H16) vin[i] = in_range ? unpack_h2(sw[(size_t)((tau0 + tl) % G) * LANES + lane]) : make_float2(0.f, 0.f);
-        else vin[i] = in_range ? sw[(size_t)((tau0 + tl) % G) * LANES + lane] : make_float2(0.f, 0.f);
+        if constexpr (H16) vin[i] = in_range ? unpack_h2(sw[(size_t)((tau0 + tl) % G) * ROWL + (me & (ROWL - 1))]) : make_float2(0.f, 0.f);
+        else vin[i] = in_range ? sw[(size_t)((tau0 + tl) % G) * ROWL + (me & (ROWL - 1))] : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < TILE / 4; ++i) ts[lane][wave + 4 * i] = vin[i];
@@ -1719,8 +1629,8 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, void *stat
     const int Tp = T + 2 * (Q - 1), C = F - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;
-    typename ST::cplx *sw = static_cast<typename ST::cplx *>(state_w_) + (size_t)b * G * LANES;
-    typename ST::real *aw = static_cast<typename ST::real *>(amp_w_) + (size_t)b * G * LANES;
+    typename ST::cplx *sw = static_cast<typename ST::cplx *>(state_w_) + (size_t)b * G * ROWL;
+    typename ST::real *aw = static_cast<typename ST::real *>(amp_w_) + (size_t)b * G * ROWL;
     typename ST::cplx *snq = static_cast<typename ST::cplx *>(state_nyq_) + (size_t)b * TpPad;
     typename ST::real *anq = static_cast<typename ST::real *>(amp_nyq_) + (size_t)b * TpPad;
     const float sc = H16 ? store_scale(__uint_as_float(amax_bits[b])) : 1.f;   // (H16: k_amax_in ran before)
@@ -1771,7 +1681,7 @@ __global__ void __launch_bounds__(256) k_in_to_skew(const float2 *in, void *stat
     for (int tl = wave; tl < TILE; tl += 4) {
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
         if (me < Tp && c >= 0 && c < C) {
-            const size_t idx = (size_t)((tau0 + tl) % G) * LANES + lane;
+            const size_t idx = (size_t)((tau0 + tl) % G) * ROWL + (me & (ROWL - 1));
             const float2 v = ts[lane][tl];
             if constexpr (H16) { sw[idx] = pack_h2(make_float2(v.x * sc, v.y * sc)); aw[idx] = pack_h(ta[lane][tl] * sc); }
             else { sw[idx] = v; aw[idx] = ta[lane][tl]; }
@@ -1820,7 +1730,7 @@ __global__ void __launch_bounds__(256) k_skew_to_out(float2 *out, const float2 *
     const int Tp = T + 2 * (Q - 1), C = F - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tau0 = SKEW * LANES * kk + TILE * tt;
-    const typename ST::cplx *sw = static_cast<const typename ST::cplx *>(state_w_) + (size_t)b * G * LANES;
+    const typename ST::cplx *sw = static_cast<const typename ST::cplx *>(state_w_) + (size_t)b * G * ROWL;
     const typename ST::cplx *snq = static_cast<const typename ST::cplx *>(state_nyq_) + (size_t)b * TpPad;
     const float sc = H16 ? store_scale(amax[b]) : 1.f, tmin = H16 ? thr_min[b] : 0.f;
     float2 vin[TILE / 4];
@@ -1829,8 +1739,8 @@ __global__ void __launch_bounds__(256) k_skew_to_out(float2 *out, const float2 *
         const int tl = wave + 4 * i;
         const int me = LANES * kk + lane, c = tau0 + tl - SKEW * me;
         const bool in_range = me < Tp && c >= 0 && c < C;
-        if constexpr (H16) vin[i] = in_range ? unpack_h2(sw[(size_t)((tau0 + tl) % G) * LANES + lane]) : make_float2(0.f, 0.f);
-        else vin[i] = in_range ? sw[(size_t)((tau0 + tl) % G) * LANES + lane] : make_float2(0.f, 0.f);
+        if constexpr (H16) vin[i] = in_range ? unpack_h2(sw[(size_t)((tau0 + tl) % G) * ROWL + (me & (ROWL - 1))]) : make_float2(0.f, 0.f);
+        else vin[i] = in_range ? sw[(size_t)((tau0 + tl) % G) * ROWL + (me & (ROWL - 1))] : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < TILE / 4; ++i) ts[lane][wave + 4 * i] = vin[i];
@@ -1878,15 +1788,6 @@ template <int Q, int L, uint32_t MASK, bool MULTI, bool H16> hipError_t launch_k
         attr_set = true;
     }
     hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI, H16>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
-#ifdef LWS_DBG_TIMING
-    {
-        unsigned long long h[16 * 4];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_timing), sizeof h);
-        for (int w = 0; w <= NSLOTS; ++w)
-            fprintf(stderr, "wave %d: wait %llu work %llu publish+loop %llu prologue %llu\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
-    }
-#endif
     return hipGetLastError();
 }
 template <int Q, int L, uint32_t MASK> hipError_t launch_k(const SysArgs &a, int grid, bool h16, hipStream_t s) {
@@ -1958,12 +1859,6 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
             for (int q = 0; q < (k & 3); ++q) { const double t = xr; xr = -xi; xi = t; }
             if (std::hypot(W[i][2 * (3 * K1 + k)] - xr, W[i][2 * (3 * K1 + k) + 1] - xi) > 1e-13 * scale) tb->r13 = false;
         }
-#ifdef LWS_NO_R13
-        tb->r13 = false;
-#endif
-#ifdef LWS_NO_K0REAL
-        tb->k0real = false;
-#endif
         sp.tables[i] = tb;
         sp.ok[i] = true;
     }
@@ -1992,7 +1887,7 @@ namespace {
 
 // Shapes and scratch pointers of one call.
 struct Geom {
-    int Tp, Kr, G, TpPad, NT, nwg;
+    int Tp, Kr, Kt, G, TpPad, NT, nwg;   // Kr: rounds of ROWL frames (the kernel's clock); Kt: groups of 64 frames (layout tiles)
     int n_full, nwg_rest;   // batches larger than the chip: n_full spectrograms with one workgroup each, then the rest
                             // (B - n_full, fewer than there are CUs) with nwg_rest workgroups each
     int cb, rb;             // bytes per stored complex value / magnitude (Store<H16>)
@@ -2009,12 +1904,13 @@ hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
     g.cb = sp.h16 ? Store<true>::CB : Store<false>::CB;
     g.rb = sp.h16 ? Store<true>::RB : Store<false>::RB;
     g.Tp = T + 2 * (Q - 1);
-    g.Kr = (g.Tp + LANES - 1) / LANES;
+    g.Kr = (g.Tp + ROWL - 1) / ROWL;
+    g.Kt = (g.Tp + LANES - 1) / LANES;
     g.G = ROWP * g.Kr;
     g.TpPad = (g.Tp + 63) & ~63;
     g.NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;   // time tiles per round of 64 frames
     // scratch: state_w, state_nyq | amp_w, amp_nyq, amax, smallest threshold, progress counters, error flag
-    const size_t n_w = (size_t)B * g.G * LANES, n_n = (size_t)B * g.TpPad;
+    const size_t n_w = (size_t)B * g.G * ROWL, n_n = (size_t)B * g.TpPad;
     const size_t need_s = (n_w + n_n) * g.cb;
     hipError_t e;
     // workgroups per spectrogram: as many as there are CUs to keep busy and passes to share out; every workgroup must
@@ -2043,7 +1939,7 @@ hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
     if (nwg == 1 && B > n_cu && B % n_cu != 0 && pick(B % n_cu) > 1) { g.n_full = B - B % n_cu; g.nwg_rest = pick(B % n_cu); }
     // sized for the largest number of workgroups any iteration count can give this batch, so that the scratch of a shape
     // does not grow with the schedule
-    const size_t n_prog = (size_t)B * (size_t)(n_cu / (B > 0 ? B : 1) + 1) + (size_t)n_cu + 8;
+    const size_t n_prog = ((size_t)B * (size_t)(n_cu / (B > 0 ? B : 1) + 1) + (size_t)n_cu) * WPS + 8;
     const size_t amp_bytes = ((n_w + n_n) * g.rb + 15) & ~(size_t)15;
     const size_t need_a = amp_bytes + (size_t)B * sizeof(unsigned) + (size_t)B * sizeof(float) + n_prog * sizeof(unsigned);
     if (need_s > sp.sk_state_cap) {
@@ -2079,7 +1975,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     const Tables *tb = static_cast<const Tables *>(sp.tables[wsel]);
     const int Q = sp.Q, L = sp.L, F = sp.F;
     SysArgs a;
-    a.state_w = g.state_w + (size_t)b0 * g.G * LANES * g.cb; a.amp_w = g.amp_w + (size_t)b0 * g.G * LANES * g.rb;
+    a.state_w = g.state_w + (size_t)b0 * g.G * ROWL * g.cb; a.amp_w = g.amp_w + (size_t)b0 * g.G * ROWL * g.rb;
     a.state_nyq = g.state_nyq + (size_t)b0 * g.TpPad * g.cb; a.amp_nyq = g.amp_nyq + (size_t)b0 * g.TpPad * g.rb;
     a.thr = thr + (size_t)b0 * n_it; a.amax = reinterpret_cast<const float *>(g.amax_bits) + b0;   // thr: dense [B][n_it]
     a.n_iters = n_it;
@@ -2088,6 +1984,8 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     {
         const char *ev = getenv("LWS_SYSTOLIC_SPIN_LIMIT");   // polls (of ~0.2 us) before a workgroup gives up on its producer
         a.spin_limit = ev ? atoi(ev) : (1 << 21);
+        const char *es = getenv("LWS_SYSTOLIC_STRESS");
+        a.stress = es ? atoi(es) : 0;
     }
     for (int x = 0; x < 32; ++x) {
         const float re = x < Q * (L + 1) ? tb->w[2 * x] : 0.f, im = x < Q * (L + 1) ? tb->w[2 * x + 1] : 0.f;
@@ -2147,9 +2045,9 @@ hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *th
                 const int nb = single ? B : (chunk == 0 ? g.n_full : B - g.n_full);
                 const int nwg = single ? 1 : (chunk == 0 ? g.nwg : g.nwg_rest);
                 if (nb <= 0) continue;
-                unsigned *progress = g.progress + (chunk == 0 ? 0 : (size_t)B * g.nwg);
+                unsigned *progress = g.progress + (chunk == 0 ? 0 : (size_t)B * g.nwg * WPS);
                 if (nwg > 1 && n_launch > 0) {   // multi-workgroup launches re-use the counters: start them from zero again
-                    if ((e = hipMemsetAsync(progress, 0, (size_t)nb * nwg * sizeof(unsigned), stream)) != hipSuccess) return e;
+                    if ((e = hipMemsetAsync(progress, 0, (size_t)nb * nwg * WPS * sizeof(unsigned), stream)) != hipSuccess) return e;
                 }
                 if ((e = launch_update(sp, g, wsel, thr_c, n_it, b0, nb, nwg, progress, gate, T, stream)) != hipSuccess) return e;
                 multi |= nwg > 1;
@@ -2189,10 +2087,10 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
     auto load = [&](const int *gate) {
         if (sp.h16) {
             if (!gate) hipLaunchKernelGGL(k_amax_ext, dim3(64, B), dim3(256), 0, stream, amp, g.amax_bits, T, F + 2 * L, Q);
-            hipLaunchKernelGGL(k_to_skew<true>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, (void *)g.state_w, (void *)g.amp_w,
+            hipLaunchKernelGGL(k_to_skew<true>, dim3(g.Kt * g.NT, B), dim3(256), 0, stream, state, amp, (void *)g.state_w, (void *)g.amp_w,
                                (void *)g.state_nyq, (void *)g.amp_nyq, g.amax_bits, T, F, L, Q, g.G, g.TpPad, g.NT, gate);
         } else {
-            hipLaunchKernelGGL(k_to_skew<false>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, (void *)g.state_w, (void *)g.amp_w,
+            hipLaunchKernelGGL(k_to_skew<false>, dim3(g.Kt * g.NT, B), dim3(256), 0, stream, state, amp, (void *)g.state_w, (void *)g.amp_w,
                                (void *)g.state_nyq, (void *)g.amp_nyq, g.amax_bits, T, F, L, Q, g.G, g.TpPad, g.NT, gate);
         }
         return hipGetLastError();
@@ -2203,10 +2101,10 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
     if (ev1) (void)hipEventRecord(ev1, stream);
     const float *amax = reinterpret_cast<const float *>(g.amax_bits);
     if (sp.h16)
-        hipLaunchKernelGGL(k_from_skew<true>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, (const void *)g.state_w,
+        hipLaunchKernelGGL(k_from_skew<true>, dim3(g.Kt * g.NT, B), dim3(256), 0, stream, state, amp, (const void *)g.state_w,
                            (const void *)g.state_nyq, amax, (const float *)g.thr_min, T, F, L, Q, g.G, g.TpPad, g.NT);
     else
-        hipLaunchKernelGGL(k_from_skew<false>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, state, amp, (const void *)g.state_w,
+        hipLaunchKernelGGL(k_from_skew<false>, dim3(g.Kt * g.NT, B), dim3(256), 0, stream, state, amp, (const void *)g.state_w,
                            (const void *)g.state_nyq, amax, (const float *)g.thr_min, T, F, L, Q, g.G, g.TpPad, g.NT);
     return hipGetLastError();
 }
@@ -2215,16 +2113,16 @@ hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const floa
 namespace {
 size_t io_partials_n(int F, int T, int Q) {            // one partial sum per tile of k_in_to_skew
     const int NT = (SKEW * (LANES - 1) + (F - 1) + TILE - 1) / TILE;
-    const int Tp = T + 2 * (Q - 1), Kr = (Tp + LANES - 1) / LANES;
-    return (size_t)Kr * NT;
+    const int Tp = T + 2 * (Q - 1), Kt = (Tp + LANES - 1) / LANES;
+    return (size_t)Kt * NT;
 }
 hipError_t io_load(SystolicPlan &sp, const Geom &g, const float2 *in, int B, int T, double *partial, hipStream_t stream, const int *gate) {
     if (sp.h16) {
         if (!gate) hipLaunchKernelGGL(k_amax_in, dim3(64, B), dim3(256), 0, stream, in, g.amax_bits, (size_t)T * sp.F);
-        hipLaunchKernelGGL(k_in_to_skew<true>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, in, (void *)g.state_w, (void *)g.amp_w,
+        hipLaunchKernelGGL(k_in_to_skew<true>, dim3(g.Kt * g.NT, B), dim3(256), 0, stream, in, (void *)g.state_w, (void *)g.amp_w,
                            (void *)g.state_nyq, (void *)g.amp_nyq, g.amax_bits, partial, T, sp.F, sp.Q, g.G, g.TpPad, g.NT, gate);
     } else {
-        hipLaunchKernelGGL(k_in_to_skew<false>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, in, (void *)g.state_w, (void *)g.amp_w,
+        hipLaunchKernelGGL(k_in_to_skew<false>, dim3(g.Kt * g.NT, B), dim3(256), 0, stream, in, (void *)g.state_w, (void *)g.amp_w,
                            (void *)g.state_nyq, (void *)g.amp_nyq, g.amax_bits, partial, T, sp.F, sp.Q, g.G, g.TpPad, g.NT, gate);
     }
     return hipGetLastError();
@@ -2255,10 +2153,10 @@ hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, const f
     if (ev1) (void)hipEventRecord(ev1, stream);
     const float *amax = reinterpret_cast<const float *>(g.amax_bits);
     if (sp.h16)
-        hipLaunchKernelGGL(k_skew_to_out<true>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, out, in, (const void *)g.state_w,
+        hipLaunchKernelGGL(k_skew_to_out<true>, dim3(g.Kt * g.NT, B), dim3(256), 0, stream, out, in, (const void *)g.state_w,
                            (const void *)g.state_nyq, amax, (const float *)g.thr_min, T, sp.F, sp.Q, g.G, g.TpPad, g.NT);
     else
-        hipLaunchKernelGGL(k_skew_to_out<false>, dim3(g.Kr * g.NT, B), dim3(256), 0, stream, out, in, (const void *)g.state_w,
+        hipLaunchKernelGGL(k_skew_to_out<false>, dim3(g.Kt * g.NT, B), dim3(256), 0, stream, out, in, (const void *)g.state_w,
                            (const void *)g.state_nyq, amax, (const float *)g.thr_min, T, sp.F, sp.Q, g.G, g.TpPad, g.NT);
     return hipGetLastError();
 }

@@ -113,10 +113,12 @@ def _wide_name(p):
 
 
 @pytest.mark.parametrize("fsize,fshift,T", [(2048, 512, 9), (2048, 512, 70), (2048, 1024, 40), (1536, 384, 33),
-                                            (1280, 320, 66), (1056, 264, 21)])
+                                            (1280, 320, 66), (1056, 264, 21), (2048, 512, 127), (2048, 512, 131),
+                                            (2048, 512, 250), (1040, 260, 140), (2032, 508, 60)])
 def test_wide_frames(oracle, fsize, fshift, T):
-    """F - 1 in (512, 1024], a multiple of 16: the 16-step-skew / 64-step-ring build (3 sweep slots), BASELINE
-    config 5's frame size included; T around one and two rounds of 64 lanes."""
+    """F - 1 in (512, 1024], a multiple of 8: the build with two waves per sweep slot on a 128-lane ring row (3 sweep
+    slots), BASELINE config 5's frame size included; T around one, two and three rounds of 128 frames and around the
+    middle of a row (frame 63 | 64: the two waves of a slot read each other's output there)."""
     out = run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0, 0.0], seed=fsize + T)
     p = lws_amd.lws(fsize, fshift)
     p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
@@ -129,10 +131,10 @@ def test_wide_sweep_counts_around_slot_groups(oracle, n_it):
     run_case(oracle, 2048, 512, 12, np.linspace(0.8, 0.0, n_it), seed=300 + n_it, B=2, scale=[1.0, 7.0])
 
 
-def test_wide_needs_a_multiple_of_16():
-    """F - 1 = 520 is a multiple of 8 but not of 16: generic engine."""
-    p = lws_amd.lws(1040, 260)
-    p.batch_lws(np.ones((4, 521)), thresholds=[0.0])
+def test_wide_needs_a_multiple_of_8():
+    """F - 1 = 516 is a multiple of 4 but not of 8: generic engine."""
+    p = lws_amd.lws(1032, 258)
+    p.batch_lws(np.ones((4, 517)), thresholds=[0.0])
     assert p.plan().last_kernel()["name"] == "generic_fp32"
 
 
@@ -183,6 +185,29 @@ def test_workgroup_sharing_randomised(monkeypatch):
             else:
                 monkeypatch.setenv("LWS_SYSTOLIC_NWG", nwg)
             assert np.array_equal(p.plan().batch(S, thr), ref), (trial, fs, sh, B, T, iters, nwg)
+
+
+@pytest.mark.parametrize("fsize,fshift,T", [(1024, 256, 150), (2048, 512, 150), (2048, 512, 100)])
+def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
+    """The waves of a workgroup synchronise through progress counters in LDS, not barriers.  LWS_SYSTOLIC_STRESS stalls chosen
+    waves (role mask) for ~10 us before a chosen pair of every block -- far longer than a pair takes -- so any read that is
+    only 'usually' behind its write shows up: the results must not move by a bit, whichever wave lags, with one or several
+    workgroups per spectrogram.  (Found the missing service<->service wait of the two-waves-per-slot build.)"""
+    rng = np.random.default_rng(T)
+    F = fsize // 2 + 1
+    S = np.abs(rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))).astype(np.complex128)
+    thr = np.zeros(9)
+    p = lws_amd.lws(fsize, fshift)
+    monkeypatch.setenv("LWS_SYSTOLIC_NWG", "1")
+    ref = p.plan().batch(S, thr)
+    for role in range(8):
+        for pair in (1, 3, 5, 7):
+            monkeypatch.setenv("LWS_SYSTOLIC_STRESS", str((1 << role) | (pair << 16)))
+            assert np.array_equal(p.plan().batch(S, thr), ref), (role, pair)
+    monkeypatch.setenv("LWS_SYSTOLIC_NWG", "3")
+    for mask, pair in ((0x40, 1), (0x80, 1), (0x0f, 3), (0x30, 7)):
+        monkeypatch.setenv("LWS_SYSTOLIC_STRESS", str(mask | (pair << 16)))
+        assert np.array_equal(p.plan().batch(S, thr), ref), (mask, pair)
 
 
 # ----------------------------------------------------------------------------- direct device I/O
