@@ -150,14 +150,35 @@ struct Scratch {
         return LWS_OK;
     }
 };
-struct DeviceCtx { Scratch frames, signal, rows, out, win_a, win_s; };
+// Windows and scratch of the transforms, one set per device, shared by every caller.  The entry points are asynchronous
+// on the caller's stream, so a context remembers (event) the last work enqueued with it: the next call -- possibly on
+// another stream, with another window or a larger shape -- first makes its own stream wait for that event, i.e. users of
+// one device's context are serialised ON THE DEVICE (never on the host); a buffer is only re-allocated after hipFree,
+// which waits for the device.  The host mutex covers the bookkeeping and the enqueue order.
+struct DeviceCtx {
+    Scratch frames, signal, rows, out, win_a, win_s;
+    hipEvent_t last = nullptr;
+    bool busy = false;
+};
+constexpr int MAX_DEVICES = 64;
 std::mutex g_mu;
-DeviceCtx g_ctx[16];
+DeviceCtx g_ctx[MAX_DEVICES];
+
+int ctx_enter(DeviceCtx &c, hipStream_t s) {
+    if (!c.last) STFT_TRY(hipEventCreateWithFlags(&c.last, hipEventDisableTiming));
+    if (c.busy) STFT_TRY(hipStreamWaitEvent(s, c.last, 0));
+    return LWS_OK;
+}
+int ctx_leave(DeviceCtx &c, hipStream_t s) {
+    STFT_TRY(hipEventRecord(c.last, s));
+    c.busy = true;
+    return LWS_OK;
+}
 
 int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
 int check_shape(int device, int B, int M, int N, int hop) {
-    if (device < 0 || device >= 16) return lws::set_error(LWS_ERR_INVALID, "device index %d out of range", device);
+    if (device < 0 || device >= MAX_DEVICES) return lws::set_error(LWS_ERR_INVALID, "device index %d out of range", device);
     if (B < 0 || M < 1) return lws::set_error(LWS_ERR_INVALID, "empty batch or no frames");
     if (N < MINN || N > MAXN || (N & (N - 1))) return lws::set_error(LWS_ERR_UNSUPPORTED, "frame size %d: the device FFT serves powers of two in [%d, %d]", N, MINN, MAXN);
     if (hop < 1 || hop > N) return lws::set_error(LWS_ERR_INVALID, "frame shift %d", hop);
@@ -208,12 +229,13 @@ int lws_stft_dev(int device, const float *x_dev, int B, int len, int N, int fshi
     hipStream_t s = static_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceCtx &c = g_ctx[device];
+    if ((rc = ctx_enter(c, s))) return rc;
     if ((rc = upload_window(c.win_a, awin, N, s))) return rc;
     hipLaunchKernelGGL(k_stft_frames, dim3(M, B), dim3(FFT_THREADS), 2 * N * sizeof(float2), s, x_dev, len, len,
                        perfectrec ? prepad(N, fshift) : 0, static_cast<const float *>(c.win_a.p),
                        static_cast<float2 *>(S_dev), nullptr, nullptr, M, N, ilog2(N), fshift);
     STFT_TRY(hipGetLastError());
-    return LWS_OK;
+    return ctx_leave(c, s);
 }
 
 int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *swin, int perfectrec,
@@ -226,6 +248,7 @@ int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift
     hipStream_t s = static_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceCtx &c = g_ctx[device];
+    if ((rc = ctx_enter(c, s))) return rc;
     if ((rc = upload_window(c.win_s, swin, N, s))) return rc;
     const int Tfull = fshift * (M - 1) + N, out_len = lws_istft_length(M, N, fshift, perfectrec);
     if ((rc = c.frames.ensure((size_t)B * M * N * sizeof(float)))) return rc;
@@ -240,7 +263,7 @@ int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift
     const int off = perfectrec ? prepad(N, fshift) : 0;
     STFT_TRY(hipMemcpy2DAsync(x_dev, (size_t)out_len * sizeof(float), static_cast<const float *>(c.signal.p) + off,
                               (size_t)Tfull * sizeof(float), (size_t)out_len * sizeof(float), B, hipMemcpyDeviceToDevice, s));
-    return LWS_OK;
+    return ctx_leave(c, s);
 }
 
 int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *awin,
@@ -253,6 +276,7 @@ int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int 
     hipStream_t s = static_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceCtx &c = g_ctx[device];
+    if ((rc = ctx_enter(c, s))) return rc;
     if ((rc = upload_window(c.win_a, awin, N, s))) return rc;
     if ((rc = upload_window(c.win_s, swin, N, s))) return rc;
     const int Tfull = fshift * (M - 1) + N;
@@ -276,7 +300,7 @@ int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int 
     STFT_TRY(hipGetLastError());
     STFT_TRY(hipMemcpyAsync(out, c.out.p, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     STFT_TRY(hipStreamSynchronize(s));
-    return LWS_OK;
+    return ctx_leave(c, s);
 }
 
 }  // extern "C"

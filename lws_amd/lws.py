@@ -11,6 +11,8 @@ independent spectrograms, and ``class lws`` takes ``device=`` / ``precision=`` /
 """
 from __future__ import annotations
 
+import collections
+import hashlib
 import math
 
 import numpy as np
@@ -184,6 +186,33 @@ def get_thresholds(iterations, alpha, beta, gamma):
 # --------------------------------------------------------------------------------------------
 _PLAN_DEFAULTS = {"device": 0, "precision": "fp32", "nofuture_q4_compat": True, "force_generic": False, "storage": "fp32"}
 
+# The reference's module-level functions take the weights with every call (lws.pyx:209,261,314) and user code calls them
+# in loops over spectrograms; a device plan (weight upload, table analysis, scratch, events) per call would dominate small
+# calls, so the last few plans are kept, keyed by the weights' bytes and the plan options.  `clear_plan_cache()` releases
+# their device memory.  Precision: the engine computes in fp32 by default (`precision="fp64"` selects the reference's
+# arithmetic on the order-exact generic engine; tolerances in DESIGN.md section 6); complex128 in, complex128 out either way.
+_PLAN_CACHE_SIZE = 4
+_plan_cache = collections.OrderedDict()
+
+
+def _cached_plan(F, Ws, plan_kw):
+    kw = {**_PLAN_DEFAULTS, **plan_kw}
+    key = (int(F),) + tuple(None if w is None else (w.shape, hashlib.sha1(np.ascontiguousarray(w, dtype=np.complex128).tobytes()).hexdigest())
+                            for w in Ws) + tuple(sorted(kw.items()))
+    plan = _plan_cache.pop(key, None)
+    if plan is None:
+        plan = _capi.Plan(F, *Ws, **kw)
+        while len(_plan_cache) >= _PLAN_CACHE_SIZE:
+            _plan_cache.popitem(last=False)[1].close()
+    _plan_cache[key] = plan          # most recently used last
+    return plan
+
+
+def clear_plan_cache():
+    """Destroy the plans kept for the module-level batch_lws / nofuture_lws / online_lws (frees their device memory)."""
+    while _plan_cache:
+        _plan_cache.popitem()[1].close()
+
 
 def _prepare(S, W, use_simplifications, n_extra_w=()):
     """Argument handling shared by the three wrappers (lws.pyx:212-224)."""
@@ -213,11 +242,7 @@ def batch_lws(S, W, thresholds, use_simplifications=True, **plan_kw):
     if len(thresholds) == 0:
         return S
     _check(S, W, Qp, Q, F, use_simplifications)
-    plan = _capi.Plan(F, W, **{**_PLAN_DEFAULTS, **plan_kw})
-    try:
-        return plan.batch(S, thresholds)
-    finally:
-        plan.close()
+    return _cached_plan(F, (W, None, None), plan_kw).batch(S, thresholds)
 
 
 def nofuture_lws(S, W, thresholds, use_simplifications=True, **plan_kw):
@@ -227,11 +252,7 @@ def nofuture_lws(S, W, thresholds, use_simplifications=True, **plan_kw):
     if len(thresholds) == 0:
         return S
     _check(S, W, Qp, Q, F, use_simplifications)
-    plan = _capi.Plan(F, W, **{**_PLAN_DEFAULTS, **plan_kw})
-    try:
-        return plan.nofuture(S, thresholds)
-    finally:
-        plan.close()
+    return _cached_plan(F, (W, None, None), plan_kw).nofuture(S, thresholds)
 
 
 def online_lws(S, W, W_ai, W_af, thresholds, LA, fshift, use_simplifications=True, **plan_kw):
@@ -244,11 +265,7 @@ def online_lws(S, W, W_ai, W_af, thresholds, LA, fshift, use_simplifications=Tru
         return S
     _check(S, W, Qp, Q, F, use_simplifications)
     qdiv = float(2 * (F - 1) / int(fshift))  # lws.pyx:339
-    plan = _capi.Plan(F, W, W_ai, W_af, **{**_PLAN_DEFAULTS, **plan_kw})
-    try:
-        return plan.online(S, thresholds, int(LA), qdiv)
-    finally:
-        plan.close()
+    return _cached_plan(F, (W, np.asarray(W_ai), np.asarray(W_af)), plan_kw).online(S, thresholds, int(LA), qdiv)
 
 
 class lws(object):

@@ -26,9 +26,12 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def reflib():
-    from oracle.oracle import RefLib
+    from oracle.oracle import RefLib, build
+    if not RefLib.available() and os.path.isdir(os.environ.get("LWS_REFERENCE", "/root/reference")):
+        build()   # the build container: compile the reference in place (oracle/Makefile); a failure here is a failure
+        assert RefLib.available(), "oracle/_ref/liblws_ref.so could not be built although the reference tree is mounted"
     if not RefLib.available():
-        pytest.skip("oracle/_ref/liblws_ref.so not built (reference tree absent)")
+        pytest.skip("oracle/_ref/liblws_ref.so absent and no reference tree to build it from (GPU box)")
     return RefLib()
 
 

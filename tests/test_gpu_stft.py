@@ -75,3 +75,31 @@ def test_stream_copy_probe():
     torch.cuda.synchronize()
     assert torch.equal(src, dst)
     assert lib.lws_stream_copy(dst.data_ptr(), src.data_ptr(), 24, None) == _capi.LWS_ERR_INVALID
+
+
+def test_concurrent_streams_do_not_share_windows_or_scratch():
+    """The transforms keep their windows and scratch in one context per device and are asynchronous on the caller's
+    stream: calls with different windows / shapes enqueued on two streams without any host synchronisation in between
+    must give what they give one at a time (the context serialises its users on the device)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    pa, pb = lws_amd.lws(1024, 256), lws_amd.lws(512, 128)
+    xa = torch.from_numpy(rng.standard_normal((6, 60000)).astype(np.float32)).cuda()
+    xb = torch.from_numpy(rng.standard_normal((3, 9000)).astype(np.float32)).cuda()
+    ref_a, ref_b = pa.stft_dev(xa), pb.stft_dev(xb)
+    ra, rb = pa.istft_dev(ref_a), pb.istft_dev(ref_b)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(6):
+        with torch.cuda.stream(s1):
+            A = pa.stft_dev(xa)
+            ia = pa.istft_dev(A)
+        with torch.cuda.stream(s2):
+            Bq = pb.stft_dev(xb)
+            ib = pb.istft_dev(Bq)
+        outs.append((A, ia, Bq, ib))
+    torch.cuda.synchronize()
+    for A, ia, Bq, ib in outs:
+        assert torch.equal(A, ref_a) and torch.equal(Bq, ref_b)
+        assert torch.equal(ia, ra) and torch.equal(ib, rb)

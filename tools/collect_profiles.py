@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 (rocpd sqlite) outputs of tools/profile.sh into the summaries kept under profiles/.
+usage: collect_profiles.py <prof_dir> <out_dir> <tag>     (run on the GPU box or on merged gpurun_out/)"""
+import csv, glob, json, os, sqlite3, sys
+
+prof, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(out, exist_ok=True)
+
+
+def db(sub):
+    f = glob.glob(os.path.join(prof, sub, "**", "*.db"), recursive=True)
+    return sqlite3.connect(f[0]) if f else None
+
+
+def tables(con):
+    return [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
+
+
+def find(con, prefix):
+    for t in tables(con):
+        if t == prefix or t.startswith(prefix):
+            return t
+    return None
+
+
+con = db("trace")
+if con:
+    kt = find(con, "kernels")
+    rows = con.execute(f"select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from {kt} group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+        fh.write('"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline  (MI355X; the default bench command: headline config 2 + every extra config block; durations in microseconds)"\n')
+        w = csv.writer(fh)
+        w.writerow(["kernel", "calls", "total_us", "average_us", "min_us", "max_us", "percent"])
+        for n, c, s, a, mn, mx in rows:
+            w.writerow([n[:200], c, round(s / 1e3, 3), round(a / 1e3, 3), round(mn / 1e3, 3), round(mx / 1e3, 3), round(100 * s / tot, 3)])
+
+SHAPES = {"2": (256, 500, 513, 100, 20.0), "2-T1024": (256, 1024, 513, 100, 20.0), "4shard": (1024, 500, 513, 100, 20.0),
+          "5": (64, 56250, 1025, 200, 20.0), "5-f16": (64, 56250, 1025, 200, 10.0)}
+res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE -- python bench.py --config <cfg> "
+               "--no-extras --steps 1 --warmup 1 --no-cpu-baseline (config 3: --extras 3); counters are KiB per dispatch. "
+               "MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e. reports 1/2 of the "
+               "bytes -> doubled here; WRITE_SIZE is exact.  hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) * 1024 of the LAST "
+               "launch of the update kernel (the timed step; the warm-up launch of the big shapes runs 3 sweeps only).",
+       "configs": {}}
+for cfg in list(SHAPES) + ["3"]:
+    per = {}
+    for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+        c2 = db(f"pmc_{cn}_{cfg}")
+        if not c2:
+            continue
+        ct = find(c2, "counters_collection")
+        cols = [r[1] for r in c2.execute(f"pragma table_info({ct})")]
+        order = "dispatch_id" if "dispatch_id" in cols else "rowid"
+        for n, v in c2.execute(f"select kernel_name, value from {ct} where counter_name=? order by {order}", (cn,)):
+            per.setdefault(n, {}).setdefault(cn, []).append(v)
+    if not per:
+        continue
+    ent = {}
+    for n, d in per.items():
+        key = None
+        if "k_systolic" in n: key = "batch"
+        elif "k_nofuture" in n: key = "nofuture"
+        elif "k_online" in n: key = "online"
+        if key is None or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+            continue
+        f, w = d["FETCH_SIZE"][-1], d["WRITE_SIZE"][-1]
+        ent[key] = {"kernel": n[:160], "launches_seen": len(d["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
+                    "hbm_bytes_per_launch": (2 * f + w) * 1024}
+    if cfg in SHAPES and "batch" in ent:
+        B, T, F, it, bpb = SHAPES[cfg]
+        e = ent["batch"]
+        e["algorithmic_bytes_per_launch"] = B * T * F * it * bpb
+        e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_launch"]
+        res["configs"][cfg] = e
+    elif cfg == "3":
+        res["configs"]["3"] = ent
+json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(res["configs"], indent=1)[:3000])
