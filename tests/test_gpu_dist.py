@@ -1,0 +1,99 @@
+"""GPU (-m gpu): two ranks drive the ENGINE on their shards -- the multi-GPU path of bench.py at test size.  With two or more
+GPUs each rank owns one and the residual pair is reduced over RCCL (backend "nccl"); with one GPU (the test box) the two
+ranks share it and the reduce goes over gloo: same sharding, same engine calls, same reduction.  Shard results must equal
+the single-rank results bit for bit (spectrograms are independent; nothing is exchanged during the sweeps)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem():
+    rng = np.random.default_rng(77)
+    B, T, F = 7, 90, 513
+    M = np.abs(rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))).astype(np.float32)
+    return M, B, T, F
+
+
+def _worker(rank, world, port, ngpu, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    import lws_amd
+    from lws_amd.dist import shard_range, reduce_residual
+    multi = ngpu >= world
+    dev_id = rank if multi else 0
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
+    if multi:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    M, B, T, F = _problem()
+    lo, hi = shard_range(B, rank, world)
+    p = lws_amd.lws(1024, 256, mode="music", batch_iterations=30, device=dev_id)
+    plan = p.plan()
+    t = torch.from_numpy(M[lo:hi].astype(np.complex64)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    thr = [lws_amd.get_thresholds(p.nofuture_iterations, p.nofuture_alpha, p.nofuture_beta, p.nofuture_gamma),
+           lws_amd.get_thresholds(p.online_iterations, p.online_alpha, p.online_beta, p.online_gamma),
+           lws_amd.get_thresholds(p.batch_iterations, p.batch_alpha, p.batch_beta, p.batch_gamma)]
+    plan.run_dev(t.data_ptr(), hi - lo, T, thr[0], thr[1], p.look_ahead, 4.0, thr[2], stream=st)
+    pairs = plan.residual_dev(t.data_ptr(), hi - lo, T, stream=st)
+    err, pw, db = reduce_residual(pairs, device=dev if multi else None)
+    q.put((rank, lo, hi, t.cpu().numpy(), pairs, err, pw, db, "nccl" if multi else "gloo"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_the_engine():
+    import torch
+    import torch.multiprocessing as mp
+    import lws_amd
+    ngpu = torch.cuda.device_count()
+    assert ngpu >= 1
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ngpu, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    # single rank, same engine calls on the whole batch
+    M, B, T, F = _problem()
+    p = lws_amd.lws(1024, 256, mode="music", batch_iterations=30)
+    t = torch.from_numpy(M.astype(np.complex64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    thr = [lws_amd.get_thresholds(p.nofuture_iterations, p.nofuture_alpha, p.nofuture_beta, p.nofuture_gamma),
+           lws_amd.get_thresholds(p.online_iterations, p.online_alpha, p.online_beta, p.online_gamma),
+           lws_amd.get_thresholds(p.batch_iterations, p.batch_alpha, p.batch_beta, p.batch_gamma)]
+    p.plan().run_dev(t.data_ptr(), B, T, thr[0], thr[1], p.look_ahead, 4.0, thr[2], stream=st)
+    pairs = p.plan().residual_dev(t.data_ptr(), B, T, stream=st)
+    ref = t.cpu().numpy()
+    assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == B
+    for rank, lo, hi, out, pr, err, pw, db, backend in got:
+        assert np.array_equal(out, ref[lo:hi]), "shard of rank %d differs from the single-rank result" % rank
+        assert np.array_equal(pr, pairs[lo:hi])
+        tot = pairs.sum(axis=0)
+        assert np.isclose(err, tot[0], rtol=1e-12) and np.isclose(pw, tot[1], rtol=1e-12)
+        assert backend == ("nccl" if ngpu >= world else "gloo")
+    assert got[0][5:8] == got[1][5:8]          # every rank holds the same reduced pair

@@ -17,4 +17,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_${ctr}_3 -o $TAG -- python bench.py --extras 3 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_${ctr}_3.err
 done
 python3 tools/collect_profiles.py $OUT $OUT/summary $TAG
+# the rocpd databases are tens of MiB each: only the summaries (and the error logs) travel back
+rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE_* $OUT/pmc_WRITE_SIZE_*
+find $OUT -name '*.err' -size +64k -delete
 ls -la $OUT/summary
