@@ -13,6 +13,7 @@ struct SystolicPlan {
     void *sk_state = nullptr, *sk_amp = nullptr;    // skewed-layout scratch
     size_t sk_state_cap = 0, sk_amp_cap = 0;
     const char *name = "systolic";
+    char name_buf[64] = {0};
     int *err_dev = nullptr;   // device flag of the last launch: a workgroup gave up waiting for its producer (the call was
                               // then re-run with one workgroup per spectrogram, on the device, before it completed)
     int last_nwg = 1;         // workgroups per spectrogram of the last launch

@@ -1815,7 +1815,11 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
     sp.F = F; sp.L = L; sp.Q = Q; sp.h16 = fp16_storage;
     for (int i = 0; i < 3; ++i) sp.ok[i] = false;
     const int C = F - 1;
-    if (Qp != Q || !(Q == 2 || Q == 4) || L != 5) return hipSuccess;
+    // stencil half-widths: L = 5 (every default configuration) with the specialised tap masks, L = 3 with all taps.  L must
+    // be odd (the tap windows are fetched as aligned pairs of bins) and at most SKEW - 3: a lane works on two bins per
+    // rendez-vous, so the newest tap of the pair's second bin, (m-1, c+1+L), must be at least two steps old when the pair
+    // starts (L = 7 is not: generic engine).
+    if (Qp != Q || !(Q == 2 || Q == 4) || !(L == 5 || L == 3)) return hipSuccess;
     if (C % SKEW != 0 || C > ROWP || C < 16) return hipSuccess;
     if ((Q - 1) * SKEW + L + 1 > LAG) return hipSuccess;
     const int K1 = L + 1;
@@ -1996,15 +2000,20 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     const int grid = nb * nwg;
     const bool h = sp.h16;
     hipError_t e;
-    if (Q == 4) {
-        if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q4_l5_hann_f16" : "systolic_wide_q4_l5_hann") : (h ? "systolic_q4_l5_hann_f16" : "systolic_q4_l5_hann"); }
-        else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q4_l5_hannmask_f16" : "systolic_wide_q4_l5_hannmask") : (h ? "systolic_q4_l5_hannmask_f16" : "systolic_q4_l5_hannmask"); }
-        else { e = launch_k<4, 5, mask_all(4, 5)>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q4_l5_allmask_f16" : "systolic_wide_q4_l5_allmask") : (h ? "systolic_q4_l5_allmask_f16" : "systolic_q4_l5_allmask"); }
+    const char *kind = "allmask";
+    if (L == 3) {
+        e = Q == 4 ? launch_k<4, 3, mask_all(4, 3)>(a, grid, h, stream) : launch_k<2, 3, mask_all(2, 3)>(a, grid, h, stream);
+    } else if (Q == 4) {
+        if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, grid, h, stream); kind = "hann"; }
+        else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, grid, h, stream); kind = "hannmask"; }
+        else e = launch_k<4, 5, mask_all(4, 5)>(a, grid, h, stream);
     } else {
-        if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q2_l5_hann_f16" : "systolic_wide_q2_l5_hann") : (h ? "systolic_q2_l5_hann_f16" : "systolic_q2_l5_hann"); }
-        else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q2_l5_hannmask_f16" : "systolic_wide_q2_l5_hannmask") : (h ? "systolic_q2_l5_hannmask_f16" : "systolic_q2_l5_hannmask"); }
-        else { e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream); sp.name = LWS_WIDE ? (h ? "systolic_wide_q2_l5_allmask_f16" : "systolic_wide_q2_l5_allmask") : (h ? "systolic_q2_l5_allmask_f16" : "systolic_q2_l5_allmask"); }
+        if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, grid, h, stream); kind = "hann"; }
+        else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, grid, h, stream); kind = "hannmask"; }
+        else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
+    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", LWS_WIDE ? "_wide" : "", Q, L, kind, h ? "_f16" : "");
+    sp.name = sp.name_buf;
     return e;
 }
 

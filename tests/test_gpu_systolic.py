@@ -16,8 +16,8 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
 
-def run_case(oracle, fsize, fshift, T, thr, seed, B=1, scale=None):
-    p = lws_amd.lws(fsize, fshift)
+def run_case(oracle, fsize, fshift, T, thr, seed, B=1, scale=None, L=5):
+    p = lws_amd.lws(fsize, fshift, L=L)
     F = fsize // 2 + 1
     rng = np.random.default_rng(seed)
     S = rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))
@@ -56,6 +56,22 @@ def test_bin_counts_and_q(oracle, fsize, fshift):
     """F - 1 = 32 ... 512 (frames shorter than the 512-step period leave lanes idle part of the time), Q = 4 and 2."""
     T = 70 if fsize <= 128 else 37
     run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0], seed=fsize + fshift)
+
+
+@pytest.mark.parametrize("fsize,fshift,L,T", [(64, 16, 3, 70), (1024, 256, 3, 37), (1024, 512, 3, 37), (2048, 512, 3, 140),
+                                              (128, 32, 3, 131), (2048, 1024, 3, 40)])
+def test_other_stencil_widths(oracle, fsize, fshift, L, T):
+    """class lws takes any L (lws.pyx:379); L = 3 (Q = 2, 4) runs on the systolic kernels too (all taps: the specialised
+    zero patterns are those of the default L = 5 weights), narrow and wide build.  (L = 1, 7 and even L: generic engine.)"""
+    run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], seed=fsize + L, B=2, scale=[1.0, 40.0], L=L)
+    p = lws_amd.lws(fsize, fshift, L=L)
+    p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
+    name = p.plan().last_kernel()["name"]
+    assert name.startswith("systolic") and ("_l%d_" % L) in name, name
+    for Lg in (1, 4, 7):
+        pg = lws_amd.lws(fsize, fshift, L=Lg)
+        pg.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
+        assert pg.plan().last_kernel()["name"] == "generic_fp32"
 
 
 def test_dropped_sweeps_and_mixed_schedules(oracle):
