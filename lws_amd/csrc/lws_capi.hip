@@ -83,6 +83,7 @@ struct lws_plan {
     unsigned flags = 0;
     bool fp64 = false;
     bool have[3] = {false, false, false};
+    bool twiddle_all = false;      // W, W_ai and W_af all have create_weights' twiddle structure (the online LDS engine relies on it)
     std::vector<double> hostW[3];  // complex128 interleaved copies (eligibility analysis, systolic tables)
     DevBuf w[3], wflag[3];
     DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out;
@@ -211,7 +212,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     if constexpr (std::is_same<real, float>::value) {
         // online driver: frames of the moving window live in LDS when the shape allows it
         if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) &&
-            lws::online_lds_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update)) {
+            lws::online_lds_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update, p->twiddle_all)) {
             begin_timing(p, s);
             hipError_t e = lws::launch_online_lds(a, B, s);
             end_timing(p, s);
@@ -476,6 +477,9 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
         if (hipEventCreate(&p->ev0) != hipSuccess || hipEventCreate(&p->ev1) != hipSuccess)
             rc = fail(LWS_ERR_HIP, "hipEventCreate failed");
     }
+    p->twiddle_all = rc == LWS_OK && p->have[0] && p->have[1] && p->have[2];
+    for (int i = 0; i < 3 && p->twiddle_all; ++i)
+        p->twiddle_all = lws::weights_have_twiddle_structure(p->hostW[i].data(), Q, Qp, L);
     if (rc == LWS_OK && !p->fp64 && !(flags & LWS_FORCE_GENERIC)) {
         const double *hw[3] = {p->have[0] ? p->hostW[0].data() : nullptr,
                                p->have[1] ? p->hostW[1].data() : nullptr,

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(512) k_nofuture(NfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Q = QT ? QT : a.Q, L = LT ? LT : a.L;
     const int F = a.F, T = a.T, NR = a.NR, K1 = L + 1, RQ = Q * K1;
-    const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), nyq = F + L - 1;
+    const int Np = F + 2 * L, Tp = T + 2 * (Q - 1);
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     float2 *S = reinterpret_cast<float2 *>(smem);                 // [NR][Np] ring of extended frames
     float2 *W = S + (size_t)NR * Np;                              // [Q][Q][K1]
