@@ -16,8 +16,10 @@
 // -- sums, cross-lane reduction, re-projection -- followed by a barrier.
 //
 // Work layout.  Sweep s is owned by slot s mod NSW for its whole life; a slot has (LA+1) frame positions, a frame
-// position has Q lanes; lane r sums the taps of frames rho-r / rho+r (lane 0: the centre frame), the Q partial sums
-// are combined with data-parallel-primitive moves and lane 0 re-projects and writes.
+// position has 2Q lanes: lane (r, 0) sums the taps of frame rho-r, lane (r, 1) those of frame rho+r (lane (0, 0): the
+// centre frame; lane (0, 1) idles), the 2Q partial sums are combined with data-parallel-primitive moves and lane (0, 0)
+// re-projects and writes.  Many light waves rather than few heavy ones: a step is latency, and the waves of a SIMD hide
+// each other's (4 waves of 350 instructions per step: 2400 clocks; 5: 2850 -- the fifth cost next to nothing).
 //
 // Taps live in REGISTERS.  A lane marches along its two frames, so the 2L+2 columns its pair of bins needs from each
 // are a window that slides by two columns per step: two LDS reads per frame and step instead of 2(2L+1).  That is
@@ -52,6 +54,7 @@ struct OnlineArgs {
     const float2 *w[3];  // W, W_ai, W_af: [Q][Q][L+1], zero where flagged off
     float2 tw[8];        // exp(2 pi j q / Q), q < Q
     int F, T, n_thr, LA, NSW;
+    int DS;              // steps between consecutive sweeps (>= the order-exact minimum, see shape_of)
 };
 
 __device__ __forceinline__ void pair(float2 &a, float2 w, float2 b, float2 c) {   // the generic engine's grouped form
@@ -84,7 +87,7 @@ __device__ __forceinline__ void cmacc_pk(v2f &a, v2f w, v2f v) {
 }
 __device__ __forceinline__ v2f as_v2f(float2 x) { return (v2f){x.x, x.y}; }
 
-// sum over the Q adjacent lanes of a bin (Q = 2, 4, 8; groups are aligned), in data-parallel-primitive moves
+// sum over the Q adjacent lanes of a group (Q = 4, 8, 16; groups are aligned), in data-parallel-primitive moves
 template <int Q> __device__ __forceinline__ float quad_sum(float v) {
     auto dpp = [](float x, auto ctrl) {
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
@@ -92,6 +95,7 @@ template <int Q> __device__ __forceinline__ float quad_sum(float v) {
     v += dpp(v, std::integral_constant<int, 0xB1>());                    // quad_perm [1,0,3,2]
     if constexpr (Q >= 4) v += dpp(v, std::integral_constant<int, 0x4E>());   // quad_perm [2,3,0,1]
     if constexpr (Q >= 8) v += dpp(v, std::integral_constant<int, 0x141>());  // row_half_mirror: the other quad of the 8
+    if constexpr (Q >= 16) v += dpp(v, std::integral_constant<int, 0x140>()); // row_mirror: the other half of the 16
     return v;
 }
 
@@ -115,8 +119,9 @@ __global__ void __launch_bounds__(MAXT) k_online(OnlineArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int K1 = L + 1, WN = 2 * L + 2;
     constexpr int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2;                      // >= L + 2, even
-    constexpr int DB = 2 * ((SKB * (Q - 1) + L + 3) / 2), DS = DB / 2;          // > SKB (Q-1) + L + 1, even
-    static_assert(SKB >= L + 2 && DB > SKB * (Q - 1) + L + 1, "order-exact schedule");
+    constexpr int DS_MIN = (SKB * (Q - 1) + L + 3) / 2;                         // 2 DS > SKB (Q-1) + L + 1
+    static_assert(SKB >= L + 2 && 2 * DS_MIN > SKB * (Q - 1) + L + 1, "order-exact schedule");
+    const int DS = a.DS;                                                        // >= DS_MIN (the launcher's choice)
     const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, Np = F + 2 * L, Tp = T + 2 * (Q - 1);
     const int NU = (F + 1) / 2;                                                 // pairs of bins per frame
     const int rps = LA + 1, per = a.n_thr + 1;
@@ -145,16 +150,16 @@ __global__ void __launch_bounds__(MAXT) k_online(OnlineArgs a) {
     int loaded = Q < T + Q - 1 ? Q : T + Q - 1;
     for (int i = tid; i < loaded * Np; i += nthr) { S[i] = gS[i]; A[i] = gA[i]; }
 
-    // this lane: tap group r of frame position j of sweep slot sigma
-    const int r = tid % Q, j = (tid / Q) % rps, sigma = tid / (Q * rps);
+    // this lane: side h (0: frame rho-r, 1: frame rho+r) of tap group r of frame position j of sweep slot sigma
+    const int h = tid & 1, r = (tid >> 1) % Q, j = (tid / (2 * Q)) % rps, sigma = tid / (2 * Q * rps);
     const bool lane_used = sigma < NSW;
     int s = sigma;
     // per-sweep constants of the lane
     int rho = 0, tstart = 0, t_done = 0, ts = 1, wset = 0;
-    int lfb = 0, rtb = 0, ctb = 0;      // LDS element offsets (column 0) of frames rho-r, rho+r and rho
+    int fb = 0, ctb = 0;                // LDS element offsets (column 0) of this lane's frame (rho-r or rho+r) and of frame rho
     bool valid = false, centre = false;
-    float g14 = 0.f, g23 = 0.f, thr = 0.f;
-    v2f w0[K1];                         // W[wset][0][r][k]: the base weights of this lane's frame pair
+    float gain = 0.f, thr = 0.f;
+    v2f w0[K1];                         // W[wset][0][r][k] (side 0) or its conjugate (side 1): see the sums below
     auto setup = [&]() {
         const int m = s / per, q = s - m * per;
         const int first = m - LA > 0 ? m - LA : 0;
@@ -168,23 +173,26 @@ __global__ void __launch_bounds__(MAXT) k_online(OnlineArgs a) {
         tstart = DS * s + SKS * rho;
         t_done = DS * s + SKS * m + NU - 1;     // last step of the sweep (its newest frame's last pair)
         const int e = rho + Q - 1;
-        lfb = ((e - r) & (NW - 1)) * Np;
-        rtb = ((e + r) & (NW - 1)) * Np;
+        fb = ((h ? e + r : e - r) & (NW - 1)) * Np;
         ctb = (e & (NW - 1)) * Np;
-        // Gains.  Lane 0: W[row][0][k] (S[c-k] + conj-weighted S[c+k]) of the centre frame if it takes part (the asymmetric
-        // first estimate leaves it out, lwslib.cpp:1161-1178).  Lanes r >= 1: the terms of frame rho-r always, those of frame
-        // rho+r only if that frame is usable yet (r < ts; one-sided forms of lwslib.cpp:1222-1253 otherwise).
-        g14 = (r == 0) ? (centre ? 1.f : 0.f) : 1.f;
-        g23 = (r != 0 && r < ts) ? 1.f : 0.f;
+        // Gains.  Lane (0,0): W[row][0][k] (S[c-k] + conj-weighted S[c+k]) of the centre frame if it takes part (the
+        // asymmetric first estimate leaves it out, lwslib.cpp:1161-1178).  Lanes (r>=1, 0): the terms of frame rho-r, always;
+        // lanes (r>=1, 1): those of frame rho+r if that frame is usable yet (r < ts; one-sided forms of lwslib.cpp:1222-1253
+        // otherwise).
+        if (h == 0) gain = (r == 0) ? (centre ? 1.f : 0.f) : 1.f;
+        else gain = (r != 0 && r < ts) ? 1.f : 0.f;
 #pragma unroll
-        for (int k = 0; k <= L; ++k) w0[k] = as_v2f(W[(wset * Q + 0) * Q * K1 + r * K1 + k]);
+        for (int k = 0; k <= L; ++k) {
+            const float2 w = W[(wset * Q + 0) * Q * K1 + r * K1 + k];
+            w0[k] = (v2f){w.x, h ? -w.y : w.y};
+        }
     };
     __syncthreads();
     setup();
 
-    v2f wl[WN], wr[WN];                 // columns c-L .. c+L+1 of frames rho-r / rho+r (lane 0: wl = the centre frame)
+    v2f wl[WN];                         // columns c-L .. c+L+1 of this lane's frame (lane (0,0): the centre frame)
 #pragma unroll
-    for (int i = 0; i < WN; ++i) wl[i] = wr[i] = (v2f){0.f, 0.f};
+    for (int i = 0; i < WN; ++i) wl[i] = (v2f){0.f, 0.f};
 
     const int t_end = DS * (nsweeps - 1) + SKS * (T - 1) + NU;
     int next_need = (loaded - (Q - 1)) * (DS * per + SKS);   // first step that touches row `loaded`: its frame's first sweep
@@ -195,7 +203,7 @@ __global__ void __launch_bounds__(MAXT) k_online(OnlineArgs a) {
             const bool has_b = c + 1 < F;
             const float2 zero = make_float2(0.f, 0.f);
             if constexpr (SERIAL) {
-                if (r == 0) {
+                if (r == 0 && h == 0) {
 #pragma unroll
                     for (int bb = 0; bb < 2; ++bb) {
                         const int cb = c + bb, nb = n + bb;
@@ -240,44 +248,46 @@ __global__ void __launch_bounds__(MAXT) k_online(OnlineArgs a) {
                     }
                 }
             } else {
-                // ---- the two windows: everything at the first pair of a frame, two new columns afterwards
+                // ---- the window: everything at the first pair of a frame, two new columns afterwards
                 if (u == 0) {
 #pragma unroll
-                    for (int i = 0; i < WN; ++i) { wl[i] = as_v2f(S[lfb + i]); wr[i] = as_v2f(S[rtb + i]); }
+                    for (int i = 0; i < WN; ++i) wl[i] = as_v2f(S[fb + i]);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < WN - 2; ++i) { wl[i] = wl[i + 2]; wr[i] = wr[i + 2]; }
-                    wl[WN - 2] = as_v2f(S[lfb + c + WN - 2]); wl[WN - 1] = as_v2f(S[lfb + c + WN - 1]);
-                    wr[WN - 2] = as_v2f(S[rtb + c + WN - 2]); wr[WN - 1] = as_v2f(S[rtb + c + WN - 1]);
+                    for (int i = 0; i < WN - 2; ++i) wl[i] = wl[i + 2];
+                    wl[WN - 2] = as_v2f(S[fb + c + WN - 2]); wl[WN - 1] = as_v2f(S[fb + c + WN - 1]);
                 }
-                const float2 twa = TW[((c % Q) * r) & (Q - 1)], twb = TW[(((c + 1) % Q) * r) & (Q - 1)];
-                // A1 = sum W0[k] left[c-k], A4 = sum conj(W0[k]) left[c+k], A2 = sum conj(W0[k]) right[c-k], A3 = sum W0[k] right[c+k]
-                // for the bins c (a) and c+1 (b); the term of bin c+1 that reads column c waits for bin c's result
-                v2f a14 = {0.f, 0.f}, a23 = {0.f, 0.f}, b14 = {0.f, 0.f}, b23 = {0.f, 0.f};
-                cmac_pk(a14, w0[0], wl[L]);  cmacc_pk(a23, w0[0], wr[L]);
-                cmac_pk(b14, w0[0], wl[L + 1]);  cmacc_pk(b23, w0[0], wr[L + 1]);
+                const float target_a = A[ctb + n], target_b = A[ctb + n + 1];   // (read with the window: off the dependent chain)
+                // twiddles of the two bins: W[row][r][k] = W[0][r][k] tw^(row r); side 1 carries the conjugates
+                float2 twa = TW[((c % Q) * r) & (Q - 1)], twb = TW[(((c + 1) % Q) * r) & (Q - 1)];
+                if (h) { twa.y = -twa.y; twb.y = -twb.y; }
+                // With w = W0[k] on side 0 and conj(W0[k]) on side 1 both sides form  sum w[k] X[c-k] + conj(w[k]) X[c+k]  over
+                // their frame X -- side 0: W X(left, -k) + conj(W') X(left, +k), side 1: conj(W) X(right, -k) + W' X(right, +k),
+                // the four kinds of term of lwslib.cpp:1182-1220 -- for the bins c (a) and c+1 (b); the term of bin c+1 that
+                // reads column c waits for bin c's result
+                v2f a14 = {0.f, 0.f}, b14 = {0.f, 0.f};
+                cmac_pk(a14, w0[0], wl[L]);
+                cmac_pk(b14, w0[0], wl[L + 1]);
 #pragma unroll
                 for (int k = 1; k <= L; ++k) {
                     cmac_pk(a14, w0[k], wl[L - k]);  cmacc_pk(a14, w0[k], wl[L + k]);
-                    cmacc_pk(a23, w0[k], wr[L - k]); cmac_pk(a23, w0[k], wr[L + k]);
                     if (k >= 2) cmac_pk(b14, w0[k], wl[L + 1 - k]);
                     cmacc_pk(b14, w0[k], wl[L + 1 + k]);
-                    cmacc_pk(b23, w0[k], wr[L + 1 - k]); cmac_pk(b23, w0[k], wr[L + 1 + k]);
                 }
-                // acc = tw X + conj(tw) Y,  X = g14 (A1 + A4), Y = g23 (A2 + A3)
-                auto assemble = [&](v2f x, v2f y, float2 tw) {
-                    x *= g14; y *= g23;
+                // acc = sum over the 2Q lanes of  tw_lane * gain_lane * a_lane
+                auto assemble = [&](v2f x, float2 tw) {
+                    x *= gain;
                     float2 o;
-                    o.x = fmaf(-tw.y, x.y - y.y, tw.x * (x.x + y.x));
-                    o.y = fmaf(tw.y, x.x - y.x, tw.x * (x.y + y.y));
-                    o.x = quad_sum<Q>(o.x);
-                    o.y = quad_sum<Q>(o.y);
+                    o.x = fmaf(-tw.y, x.y, tw.x * x.x);
+                    o.y = fmaf(tw.y, x.x, tw.x * x.y);
+                    o.x = quad_sum<2 * Q>(o.x);
+                    o.y = quad_sum<2 * Q>(o.y);
                     return o;
                 };
-                const float2 acc_a = assemble(a14, a23, twa);
-                if (r == 0) {
+                const float2 acc_a = assemble(a14, twa);
+                if (r == 0 && h == 0) {
                     const int li = ctb + n;
-                    const float target = A[li];
+                    const float target = target_a;
                     float2 v;
                     if (target > thr && project(acc_a, target, v)) {
                         const float2 vc = make_float2(v.x, -v.y);
@@ -306,10 +316,10 @@ __global__ void __launch_bounds__(MAXT) k_online(OnlineArgs a) {
                     }
                 }
                 cmac_pk(b14, w0[1], wl[L]);       // (lane 0: the value just written; the others: unchanged column c of frame rho-r)
-                const float2 acc_b = assemble(b14, b23, twb);
-                if (r == 0 && has_b) {
+                const float2 acc_b = assemble(b14, twb);
+                if (r == 0 && h == 0 && has_b) {
                     const int li = ctb + n + 1, cb = c + 1;
-                    const float target = A[li];
+                    const float target = target_b;
                     float2 v;
                     if (target > thr && project(acc_b, target, v)) {
                         const float2 vc = make_float2(v.x, -v.y);
@@ -366,15 +376,25 @@ template <int Q, int L, bool SERIAL> hipError_t launch_q(const OnlineArgs &a, in
     return threads <= 512 ? launch_qt<Q, L, SERIAL, 512>(a, B, threads, lds, s) : launch_qt<Q, L, SERIAL, 1024>(a, B, threads, lds, s);
 }
 
-struct Shape { int NSW, threads; size_t lds; bool ok; };
+struct Shape { int NSW, threads, DS; size_t lds; bool ok; };
 
 Shape shape_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
     Shape sh{0, 0, 0, false};
     if (Qp != Q || L != 5 || !(Q == 2 || Q == 4 || Q == 8) || LA < 0 || n_thr < 1 || T < 1) return sh;
-    const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
+    const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS_MIN = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
     const int NU = (F + 1) / 2;
+    // The lag between sweeps may be anything from the order-exact minimum up: fewer sweeps in flight, fewer lanes, but
+    // proportionally more steps.  Steps are what costs (more waves on a SIMD hide each other's latency almost for free), so
+    // take the minimum unless the lanes do not fit a workgroup.
+    int DS = 0;
+    for (int d = DS_MIN; d <= 4 * DS_MIN && DS == 0; ++d) {
+        const int nsw = (NU - 1 + SKS * LA) / d + 2;
+        if (nsw * (LA + 1) * Q * 2 <= 1024) DS = d;
+    }
+    if (DS == 0) return sh;
+    sh.DS = DS;
     sh.NSW = (NU - 1 + SKS * LA) / DS + 2;                    // > sweeps in flight
-    sh.threads = ((sh.NSW * (LA + 1) * Q + 63) / 64) * 64;
+    sh.threads = ((sh.NSW * (LA + 1) * Q * 2 + 63) / 64) * 64;   // two lanes per frame pair
     if (sh.threads > 1024) return sh;
     // Frames alive at once.  The frame loaded at the end of step t (newest frame m_new, (DS*per + SKS) m_new <= t + 1)
     // replaces the one NW rows below it, and the oldest sweep still running (of frame m_lo, t <= DS (per m_lo + per - 1)
@@ -428,7 +448,7 @@ hipError_t launch_online_lds(const GenericArgs<float> &g, int B, hipStream_t str
         if (std::fabs(sr) < 1e-15) sr = 0;
         a.tw[q] = make_float2((float)cr, (float)sr);
     }
-    a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = sh.NSW;
+    a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = sh.NSW; a.DS = sh.DS;
     const char *ev = getenv("LWS_ONLINE_SERIAL_TAPS");   // verification only, see k_online
     if (ev && ev[0] == '1') {
         if (g.Q == 4) return launch_q<4, 5, true>(a, B, sh.threads, sh.lds, stream);
