@@ -52,6 +52,8 @@ enum {
     LWS_FORCE_GENERIC = 4,         /* never use the specialised systolic batch kernel */
     LWS_NO_DIRECT_IO = 8,          /* always go through the extended buffers (prep / extract passes), even for a call
                                       that is one batch stage on device complex64 data -- for comparison */
+    LWS_GENERIC_PLAIN_LAYOUT = 32, /* generic engine: batch sweeps in the reference's layout instead of the time-skewed copy
+                                      (same results bit for bit; for comparison) */
     LWS_STORAGE_FP16 = 16          /* fp16-complex storage (BASELINE config 5): between passes over HBM the batch kernel keeps
                                       the spectrogram as half2 and the target magnitudes as half (10 B instead of 20 B per
                                       active bin and sweep), scaled per spectrogram by the power of two that brings its

@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("LWS_HIP_LIB", os.path.join(_HERE, "liblws_hip.so"))  
 LWS_OK, LWS_ERR_INVALID, LWS_ERR_HIP, LWS_ERR_NOMEM, LWS_ERR_UNSUPPORTED = range(5)
 LWS_PRECISION_FP32, LWS_PRECISION_FP64, LWS_NOFUTURE_Q4_COMPAT, LWS_FORCE_GENERIC, LWS_NO_DIRECT_IO = 0, 1, 2, 4, 8
 LWS_STORAGE_FP16 = 16
+LWS_GENERIC_PLAIN_LAYOUT = 32
 LWS_W, LWS_W_AI, LWS_W_AF = 0, 1, 2
 
 EXPORTS = (
@@ -149,7 +150,7 @@ class Plan:
     """Owns an ``lws_plan`` (device copies of W / W_ai / W_af for one (F, L, Q) shape)."""
 
     def __init__(self, F, W, W_ai=None, W_af=None, device=0, precision="fp32",
-                 nofuture_q4_compat=True, force_generic=False, direct_io=True, storage="fp32"):
+                 nofuture_q4_compat=True, force_generic=False, direct_io=True, storage="fp32", generic_plain_layout=False):
         lib = load()
         W = _c128(W)
         if W.ndim != 3:
@@ -178,6 +179,8 @@ class Plan:
             flags |= LWS_FORCE_GENERIC
         if not direct_io:
             flags |= LWS_NO_DIRECT_IO
+        if generic_plain_layout:
+            flags |= LWS_GENERIC_PLAIN_LAYOUT
         if storage == "fp16":
             flags |= LWS_STORAGE_FP16
         elif storage != "fp32":

@@ -87,6 +87,7 @@ struct lws_plan {
     std::vector<double> hostW[3];  // complex128 interleaved copies (eligibility analysis, systolic tables)
     DevBuf w[3], wflag[3];
     DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out;
+    DevBuf gsk_state, gsk_amp;     // time-skewed copy of the state for the generic engine's batch sweeps
     lws::SystolicPlan sys;         // device tables of the systolic kernel (empty if not eligible)
     lws::SystolicPlan sysw;        // ... of its wide build (frames of 521..1025 bins)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -232,6 +233,24 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
             if (e != hipSuccess) return fail(LWS_ERR_HIP, "no-future launch failed: %s", hipGetErrorString(e));
             p->last_launches = 1;
             p->last_name = mode == lws::MODE_NOFUTURE_Q4_COMPAT ? "nofuture_lds_q4compat_fp32" : "nofuture_lds_fp32";
+            return LWS_OK;
+        }
+    }
+    if (mode == lws::MODE_BATCH && !(p->flags & LWS_GENERIC_PLAIN_LAYOUT)) {
+        // batch sweeps of the generic engine run on a time-skewed copy of the state (coalesced taps; same bits) unless
+        // that copy would be unreasonably large
+        size_t ab = 0;
+        const size_t sb = lws::generic_skew_bytes<real>(B, p->F, T, p->L, p->Q, &ab);
+        if (sb + ab <= ((size_t)48 << 30)) {
+            int rc;
+            if ((rc = p->gsk_state.ensure(sb))) return rc;
+            if ((rc = p->gsk_amp.ensure(ab))) return rc;
+            begin_timing(p, s);
+            hipError_t e = lws::launch_generic_skewed<real>(a, B, p->gsk_state.p, p->gsk_amp.p, s);
+            end_timing(p, s);
+            if (e != hipSuccess) return fail(LWS_ERR_HIP, "generic (skewed) launch failed: %s", hipGetErrorString(e));
+            p->last_launches = 1;
+            p->last_name = p->fp64 ? "generic_skew_fp64" : "generic_skew_fp32";
             return LWS_OK;
         }
     }
@@ -503,7 +522,7 @@ void lws_plan_destroy(lws_plan *p) {
     for (int i = 0; i < 3; ++i) { p->w[i].release(); p->wflag[i].release(); }
     p->state.release(); p->amp.release(); p->row_sums.release(); p->mean_amp.release();
     p->thr_host_copy.release(); p->thr_scaled.release(); p->stage.release();
-    p->resid_rows.release(); p->resid_out.release();
+    p->resid_rows.release(); p->resid_out.release(); p->gsk_state.release(); p->gsk_amp.release();
     lws::systolic_release(p->sys);
     lws::wide::systolic_release(p->sysw);
     if (p->ev0) (void)hipEventDestroy(p->ev0);

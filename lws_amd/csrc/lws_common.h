@@ -43,10 +43,17 @@ template <typename real> struct GenericArgs {
     real qdiv;
     int mode;
     int group;                       // max sweeps in flight (batch / no-future)
+    int mask_rows;                   // set by launch_generic: weight rows whose flags are packed into LDS masks (0: none)
 };
 
 template <typename real>
 hipError_t launch_generic(const GenericArgs<real> &a, int B, hipStream_t stream);
+// Batch sweeps (mode == MODE_BATCH) on a time-skewed copy of the state in the scratch buffers sw / aw (sizes from
+// generic_skew_bytes): same results as launch_generic, bit for bit, with coalesced tap loads.
+template <typename real>
+hipError_t launch_generic_skewed(const GenericArgs<real> &a, int B, void *sw, void *aw, hipStream_t stream);
+template <typename real>
+size_t generic_skew_bytes(int B, int F, int T, int L, int Q, size_t *amp_bytes);
 
 // ---- prep / extract (lws_generic.hip) ----
 // in: [B][T][F] complex (double2 or float2).  Builds the extended buffer, |.|, per-spectrogram

@@ -43,53 +43,80 @@ __device__ __forceinline__ void macc(C &a, const C w, const C s) {  // a += conj
 // The local weighted sum of one bin (no write): LWSanyQ (lwslib.cpp:297-354), NoFuture_LWSanyQ
 // (634-671) and Asym_UpdatePhaseanyQ (1157-1253) in one body; `centre` / `two_sided` are the
 // reference's cframe / rframe (lwslib.cpp:1143-1151).
-template <typename real>
-__device__ __forceinline__ typename cx<real>::type accumulate(const typename cx<real>::type *ctr,
-                                                              int c, bool centre, int two_sided,
-                                                              const WeightSet<real> ws, int Np,
-                                                              int L, int Q, int Qp, bool add_self,
-                                                              real qdiv) {
+// `mk` (may be null): the participation flags of each weight row packed into one 64-bit word (bit r*(L+1)+k), built once per
+// workgroup in LDS.  The reference tests a flag per weight (lwslib.cpp:302,321,...); tested as bytes from memory, every tap
+// waits for its flag before its loads can even be issued -- ~150 serialised round trips per bin; as bits of a register the
+// tests are immediate and the tap loads of a bin are in flight together.  Same taps, same order, same arithmetic.
+struct FlagView {
+    const uint8_t *bytes;
+    unsigned long long mask;
+    bool packed;
+    __device__ __forceinline__ bool operator[](int i) const { return packed ? ((mask >> i) & 1ull) != 0 : bytes[i] != 0; }
+};
+// Where the neighbours of a bin are.  RowView: the reference's extended layout [Tp][Np] (frame dr away = dr rows away).
+// SkewView: the time-skewed layout of the batch engine below, SW[time][frame mod NL] with time = sk * frame + column:
+// the neighbour (dr, dk) of a bin is  sk*dr + dk  rows and dr lanes away, so the taps of all the bins a wavefront step
+// updates -- consecutive frames at the same time -- are consecutive elements of one row.
+template <typename C> struct RowView {
+    const C *ctr; int Np;
+    __device__ __forceinline__ C at(int dr, int dk) const { return ctr[(long)dr * Np + dk]; }
+};
+template <typename C> struct SkewView {
+    const C *sw; long row; int lane, sk, nl;   // nl: lanes of a row (power of two)
+    __device__ __forceinline__ C at(int dr, int dk) const { return sw[(row + (long)sk * dr + dk) * nl + ((lane + dr) & (nl - 1))]; }
+};
+template <typename real, typename View>
+__device__ __forceinline__ typename cx<real>::type accumulate_v(const View nb, int c, bool centre, int two_sided,
+                                                                const WeightSet<real> ws, int L, int Q, int Qp, bool add_self,
+                                                                real qdiv, const unsigned long long *mk) {
     using C = typename cx<real>::type;
     const int K1 = L + 1, RQ = Q * K1;
     const int row = c % Qp, rowneg = (Qp - row) % Qp;
     const C *wa = ws.w + (size_t)row * RQ, *wb = ws.w + (size_t)rowneg * RQ;
-    const uint8_t *fa = ws.flag + (size_t)row * RQ, *fb = ws.flag + (size_t)rowneg * RQ;
+    const FlagView fa{ws.flag + (size_t)row * RQ, mk ? mk[row] : 0ull, mk != nullptr};
+    const FlagView fb{ws.flag + (size_t)rowneg * RQ, mk ? mk[rowneg] : 0ull, mk != nullptr};
     C a;
     a.x = 0; a.y = 0;
     if (centre) {
-        if (add_self) { a.x += ctr[0].x / qdiv; a.y += ctr[0].y / qdiv; }
+        if (add_self) { const C s0 = nb.at(0, 0); a.x += s0.x / qdiv; a.y += s0.y / qdiv; }
         for (int k = 1; k <= L; ++k)
-            if (fa[k]) pair<real>(a, wa[k], ctr[-k], ctr[k]);
+            if (fa[k]) pair<real>(a, wa[k], nb.at(0, -k), nb.at(0, k));
     }
     for (int r = 1; r < Q; ++r) {
-        const C *lf = ctr - (size_t)r * Np;  // frame m-r
-        const C *rt = ctr + (size_t)r * Np;  // frame m+r
         const int u = r * K1;
         const bool both = r < two_sided;
         if (fa[u]) {
-            if (both) pair<real>(a, wa[u], lf[0], rt[0]);
-            else mac<real>(a, wa[u], lf[0]);
+            if (both) pair<real>(a, wa[u], nb.at(-r, 0), nb.at(r, 0));
+            else mac<real>(a, wa[u], nb.at(-r, 0));
         }
         for (int k = 1; k <= L; ++k) {
             if (fa[u + k]) {
-                if (both) pair<real>(a, wa[u + k], lf[-k], rt[-k]);
-                else mac<real>(a, wa[u + k], lf[-k]);
+                if (both) pair<real>(a, wa[u + k], nb.at(-r, -k), nb.at(r, -k));
+                else mac<real>(a, wa[u + k], nb.at(-r, -k));
             }
             if (fb[u + k]) {
-                if (both) pair<real>(a, wb[u + k], rt[k], lf[k]);
-                else macc<real>(a, wb[u + k], lf[k]);
+                if (both) pair<real>(a, wb[u + k], nb.at(r, k), nb.at(-r, k));
+                else macc<real>(a, wb[u + k], nb.at(-r, k));
             }
         }
     }
     return a;
 }
-
+template <typename real>
+__device__ __forceinline__ typename cx<real>::type accumulate(const typename cx<real>::type *ctr,
+                                                              int c, bool centre, int two_sided,
+                                                              const WeightSet<real> ws, int Np,
+                                                              int L, int Q, int Qp, bool add_self,
+                                                              real qdiv, const unsigned long long *mk = nullptr) {
+    using C = typename cx<real>::type;
+    return accumulate_v<real>(RowView<C>{ctr, Np}, c, centre, two_sided, ws, L, Q, Qp, add_self, qdiv, mk);
+}
 // One bin update: weighted sum, magnitude re-projection (lwslib.cpp:356-360), Hermitian image upkeep.
 template <typename real>
 __device__ __forceinline__ void update_bin(typename cx<real>::type *S, const real *amp, int m_ext,
                                            int c, bool centre, int two_sided,
                                            const WeightSet<real> ws, real thr, int F, int L, int Q,
-                                           int Qp, bool add_self, real qdiv) {
+                                           int Qp, bool add_self, real qdiv, const unsigned long long *mk = nullptr) {
     using C = typename cx<real>::type;
     const int Np = F + 2 * L;
     const int n = c + L;
@@ -97,7 +124,7 @@ __device__ __forceinline__ void update_bin(typename cx<real>::type *S, const rea
     const real target = amp[idx];
     if (!(target > thr)) return;
     C *ctr = S + idx;
-    const C a = accumulate<real>(ctr, c, centre, two_sided, ws, Np, L, Q, Qp, add_self, qdiv);
+    const C a = accumulate<real>(ctr, c, centre, two_sided, ws, Np, L, Q, Qp, add_self, qdiv, mk);
     const real mag = sqrt(a.x * a.x + a.y * a.y);
     if (!(mag > 0)) return;
     C v;
@@ -116,7 +143,7 @@ __device__ __forceinline__ void update_bin(typename cx<real>::type *S, const rea
 template <typename real>
 __device__ __forceinline__ void update_bin_nfq4(typename cx<real>::type *S, const real *amp,
                                                 int m_ext, int c, const WeightSet<real> ws,
-                                                real thr, int F, int L) {
+                                                real thr, int F, int L, const unsigned long long *mk = nullptr) {
     using C = typename cx<real>::type;
     const int Q = 4, Np = F + 2 * L, n = c + L, K1 = L + 1, RQ = Q * K1;
     const size_t idx = (size_t)m_ext * Np + n;
@@ -124,7 +151,7 @@ __device__ __forceinline__ void update_bin_nfq4(typename cx<real>::type *S, cons
     if (!(target > thr)) return;
     const int row = c % Q;
     const C *wa = ws.w + (size_t)row * RQ;
-    const uint8_t *fa = ws.flag + (size_t)row * RQ;
+    const FlagView fa{ws.flag + (size_t)row * RQ, mk ? mk[row] : 0ull, mk != nullptr};
     C a;
     a.x = 0; a.y = 0;
     for (int r = Q - 1; r > 0; --r) {
@@ -163,6 +190,24 @@ __global__ void __launch_bounds__(1024) k_generic(GenericArgs<real> a) {
     const real *thr = a.thr + (size_t)b * a.n_thr;
     const int sk = L + 1, D = Q * sk;
     const bool add_self = (a.update == 1);
+    // participation masks of the weight rows this launch uses (one 64-bit word per row; see accumulate)
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    unsigned long long *mkb = reinterpret_cast<unsigned long long *>(gsm);
+    const bool packed = a.mask_rows > 0;
+    const unsigned long long *mk[3] = {nullptr, nullptr, nullptr};
+    if (packed) {
+        const int RQ = Q * (L + 1);
+        const int first = (a.mode == MODE_ONLINE) ? 0 : a.wsel, nsets = (a.mode == MODE_ONLINE) ? 3 : 1;
+        for (int i = tid; i < nsets * Qp; i += nthr) {
+            const int set = first + i / Qp, row = i % Qp;
+            const uint8_t *f = a.w[set].flag + (size_t)row * RQ;
+            unsigned long long m = 0;
+            for (int x = 0; x < RQ; ++x) m |= (unsigned long long)(f[x] != 0) << x;
+            mkb[i] = m;
+        }
+        for (int set = 0; set < nsets; ++set) mk[first + set] = mkb + (size_t)set * Qp;
+        __syncthreads();
+    }
 
     if (a.mode == MODE_BATCH || a.mode == MODE_NOFUTURE || a.mode == MODE_ASYM) {
         const WeightSet<real> ws = a.w[a.wsel];
@@ -194,7 +239,7 @@ __global__ void __launch_bounds__(1024) k_generic(GenericArgs<real> a) {
                         if (two_sided < 1) two_sided = 1;
                     }
                     update_bin<real>(S, amp, mm + Q - 1, c, centre, two_sided, ws, thr[g0 + k], F, L,
-                                     Q, Qp, add_self, a.qdiv);
+                                     Q, Qp, add_self, a.qdiv, mk[a.wsel]);
                 }
                 __syncthreads();
             }
@@ -209,7 +254,7 @@ __global__ void __launch_bounds__(1024) k_generic(GenericArgs<real> a) {
             const real th = thr[s];
             for (int m = 0; m < T; ++m) {
                 for (int n = L + tid; n < n_split; n += nthr)
-                    update_bin_nfq4<real>(S, amp, m + Q - 1, n - L, ws, th, F, L);
+                    update_bin_nfq4<real>(S, amp, m + Q - 1, n - L, ws, th, F, L, mk[a.wsel]);
                 __syncthreads();
                 // upper bins: the flat offset of frame m-1 runs into frame m itself, columns 2n - Np +- k <= 2n - Np + L,
                 // all below n.  Bins [n0, n1) are independent of each other (and so reproduce the sequential order) as
@@ -221,7 +266,7 @@ __global__ void __launch_bounds__(1024) k_generic(GenericArgs<real> a) {
                     // read that column through the flat offset (only possible for F <= 3L - 1): run them one by one
                     if (n0 <= 2 * L) n1 = n0 + 1;
                     for (int n = n0 + tid; n < n1; n += nthr)
-                        update_bin_nfq4<real>(S, amp, m + Q - 1, n - L, ws, th, F, L);
+                        update_bin_nfq4<real>(S, amp, m + Q - 1, n - L, ws, th, F, L, mk[a.wsel]);
                     __syncthreads();
                     n0 = n1;
                 }
@@ -258,12 +303,12 @@ __global__ void __launch_bounds__(1024) k_generic(GenericArgs<real> a) {
                 const int c = (int)cl;
                 if (q == 0) {
                     update_bin<real>(S, amp, rho + Q - 1, c, false, 1, a.w[1], (real)0, F, L, Q, Qp,
-                                     add_self, a.qdiv);
+                                     add_self, a.qdiv, mk[1]);
                 } else {
                     int ts = m - rho + 1;
                     if (ts > Q) ts = Q;
                     update_bin<real>(S, amp, rho + Q - 1, c, true, ts, (rho == m) ? a.w[2] : a.w[0],
-                                     thr[q - 1], F, L, Q, Qp, add_self, a.qdiv);
+                                     thr[q - 1], F, L, Q, Qp, add_self, a.qdiv, (rho == m) ? mk[2] : mk[0]);
                 }
             }
             __syncthreads();
@@ -298,9 +343,166 @@ hipError_t launch_generic(const GenericArgs<real> &a, int B, hipStream_t stream)
         if (threads > 1024) threads = 1024;
         if (threads < 64) threads = 64;
     }
-    hipLaunchKernelGGL(k_generic<real>, dim3(B), dim3(threads), 0, stream, args);
+    // flag masks in LDS when a row's Q (L+1) flags fit one word and the rows fit the LDS
+    const size_t nsets = (a.mode == MODE_ONLINE) ? 3 : 1;
+    size_t lds = 0;
+    args.mask_rows = 0;
+    if (a.Q * (a.L + 1) <= 64 && nsets * a.Qp * 8 <= 64 * 1024) { args.mask_rows = a.Qp; lds = nsets * a.Qp * 8; }
+    hipLaunchKernelGGL(k_generic<real>, dim3(B), dim3(threads), lds, stream, args);
     return hipGetLastError();
 }
+
+// =====================================================================================
+// batch sweeps on a time-skewed copy of the state: the same wavefront, coalesced
+// =====================================================================================
+// k_generic keeps the reference's layout, in which the bins of one wavefront step (consecutive frames, each sk bins behind
+// the previous one) are Np - sk elements apart: every tap load of a wave touches 64 cache lines, and the step is bound by
+// the texture path (57 us per step for Q = 4, 258 us for Q = 8 on 500 x 513).  For batch sweeps -- the mode with the long
+// schedules -- the state is first copied to SW[time][frame mod NL], time = sk * frame + column (pad columns included, so the
+// Hermitian images stay physical entries exactly as in the reference, lwslib.cpp:362-367): all bins of a step, and each of
+// their taps, are consecutive elements of one row.  Same schedule, same arithmetic, same order of operations as
+// k_generic's batch mode: bit-identical results.  NL >= Np / sk frames are in flight at a time, so frame m and m + NL
+// never share a row.
+template <typename real>
+__global__ void __launch_bounds__(256) k_to_gskew(const typename cx<real>::type *state, const real *amp,
+                                                   typename cx<real>::type *sw, real *aw, int Tp, int Np, int sk, int NL, long rows) {
+    using C = typename cx<real>::type;
+    const int m = blockIdx.x, b = blockIdx.y;
+    const C *src = state + ((size_t)b * Tp + m) * Np;
+    const real *asrc = amp + ((size_t)b * Tp + m) * Np;
+    C *dst = sw + (size_t)b * rows * NL;
+    real *adst = aw + (size_t)b * rows * NL;
+    for (int n = threadIdx.x; n < Np; n += blockDim.x) {
+        const size_t o = ((size_t)sk * m + n) * NL + (m & (NL - 1));
+        dst[o] = src[n];
+        adst[o] = asrc[n];
+    }
+}
+template <typename real>
+__global__ void __launch_bounds__(256) k_from_gskew(typename cx<real>::type *state, const typename cx<real>::type *sw, int Tp,
+                                                     int Np, int sk, int NL, long rows) {
+    using C = typename cx<real>::type;
+    const int m = blockIdx.x, b = blockIdx.y;
+    C *dst = state + ((size_t)b * Tp + m) * Np;
+    const C *src = sw + (size_t)b * rows * NL;
+    for (int n = threadIdx.x; n < Np; n += blockDim.x) dst[n] = src[((size_t)sk * m + n) * NL + (m & (NL - 1))];
+}
+
+template <typename real>
+__global__ void __launch_bounds__(1024) k_skew_batch(GenericArgs<real> a, typename cx<real>::type *sw_all, const real *aw_all,
+                                                      int NL, long rows) {
+    using C = typename cx<real>::type;
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int F = a.F, T = a.T, L = a.L, Q = a.Q, Qp = a.Qp;
+    const int Np = F + 2 * L;
+    C *SW = sw_all + (size_t)b * rows * NL;
+    const real *AW = aw_all + (size_t)b * rows * NL;
+    const real *thr = a.thr + (size_t)b * a.n_thr;
+    const int sk = L + 1, D = Q * sk;
+    const bool add_self = (a.update == 1);
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    unsigned long long *mkb = reinterpret_cast<unsigned long long *>(gsm);
+    const unsigned long long *mk = nullptr;
+    const WeightSet<real> ws = a.w[a.wsel];
+    if (a.mask_rows > 0) {
+        const int RQ = Q * (L + 1);
+        for (int row = tid; row < Qp; row += nthr) {
+            const uint8_t *f = ws.flag + (size_t)row * RQ;
+            unsigned long long m = 0;
+            for (int x = 0; x < RQ; ++x) m |= (unsigned long long)(f[x] != 0) << x;
+            mkb[row] = m;
+        }
+        mk = mkb;
+        __syncthreads();
+    }
+    const int nsweeps = a.n_thr;
+    int lpi = (F - 1) / sk + 1;  // frames that can sit on one hyperplane
+    if (lpi > T) lpi = T;
+    const int group = a.group < 1 ? 1 : a.group;
+    const int nyq = F + L - 1;
+    for (int g0 = 0; g0 < nsweeps; g0 += group) {
+        const int ng = (nsweeps - g0 < group) ? nsweeps - g0 : group;
+        const int nsteps = F + sk * (T - 1) + D * (ng - 1);
+        for (int step = 0; step < nsteps; ++step) {
+            for (int idx = tid; idx < ng * lpi; idx += nthr) {
+                const int k = idx / lpi, j = idx - k * lpi;
+                const int u = step - D * k;
+                if (u < 0) continue;
+                int jhi = u / sk;
+                if (jhi > T - 1) jhi = T - 1;
+                // consecutive threads take consecutive frames (ascending): consecutive elements of the rows they touch
+                int jlo = (u - (F - 1) + sk - 1) / sk;
+                if (jlo < 0) jlo = 0;
+                const int mm = jlo + j;
+                if (mm > jhi) continue;
+                const int c = u - sk * mm;
+                if (c >= F) continue;
+                const int me = mm + Q - 1, n = c + L;
+                const long row = (long)sk * me + n;
+                const int lane = me & (NL - 1);
+                const real target = AW[row * NL + lane];
+                if (!(target > thr[g0 + k])) continue;
+                const C acc = accumulate_v<real>(SkewView<C>{SW, row, lane, sk, NL}, c, true, Q, ws, L, Q, Qp, add_self, a.qdiv, mk);
+                const real mag = sqrt(acc.x * acc.x + acc.y * acc.y);
+                if (!(mag > 0)) continue;
+                C v;
+                v.x = acc.x * target / mag;
+                v.y = acc.y * target / mag;
+                SW[row * NL + lane] = v;
+                C vc;
+                vc.x = v.x; vc.y = -v.y;            // Hermitian images in the pad columns (lwslib.cpp:362-367)
+                if (n >= L + 1 && n < 2 * L + 1) SW[(row + 2 * (L - n)) * NL + lane] = vc;
+                else if (n >= F - 1 && n < nyq) SW[(row + 2 * (nyq - n)) * NL + lane] = vc;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename real>
+size_t generic_skew_bytes(int B, int F, int T, int L, int Q, size_t *amp_bytes) {
+    const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), sk = L + 1;
+    int NL = 1;
+    while (NL * sk < Np) NL *= 2;
+    const size_t rows = (size_t)sk * (Tp - 1) + Np;
+    if (amp_bytes) *amp_bytes = (size_t)B * rows * NL * sizeof(real);
+    return (size_t)B * rows * NL * sizeof(typename cx<real>::type);
+}
+
+template <typename real>
+hipError_t launch_generic_skewed(const GenericArgs<real> &a, int B, void *sw, void *aw, hipStream_t stream) {
+    using C = typename cx<real>::type;
+    if (B <= 0) return hipSuccess;
+    if (a.mode != MODE_BATCH) return hipErrorInvalidValue;
+    const int Np = a.F + 2 * a.L, Tp = a.T + 2 * (a.Q - 1), sk = a.L + 1;
+    int NL = 1;
+    while (NL * sk < Np) NL *= 2;
+    const long rows = (long)sk * (Tp - 1) + Np;
+    GenericArgs<real> args = a;
+    int lpi = (a.F - 1) / sk + 1;
+    if (lpi > a.T) lpi = a.T;
+    int threads = 1024;
+    int group = threads / lpi;
+    if (group < 1) group = 1;
+    if (group > a.n_thr) group = a.n_thr;
+    threads = ((group * lpi + 63) / 64) * 64;
+    if (threads > 1024) threads = 1024;
+    if (threads < 64) threads = 64;
+    args.group = group;
+    size_t lds = 0;
+    args.mask_rows = 0;
+    if (a.Q * (a.L + 1) <= 64 && (size_t)a.Qp * 8 <= 64 * 1024) { args.mask_rows = a.Qp; lds = (size_t)a.Qp * 8; }
+    hipLaunchKernelGGL(k_to_gskew<real>, dim3(Tp, B), dim3(256), 0, stream, a.state, a.amp, static_cast<C *>(sw), static_cast<real *>(aw),
+                       Tp, Np, sk, NL, rows);
+    hipLaunchKernelGGL(k_skew_batch<real>, dim3(B), dim3(threads), lds, stream, args, static_cast<C *>(sw),
+                       static_cast<const real *>(aw), NL, rows);
+    hipLaunchKernelGGL(k_from_gskew<real>, dim3(Tp, B), dim3(256), 0, stream, a.state, static_cast<const C *>(sw), Tp, Np, sk, NL, rows);
+    return hipGetLastError();
+}
+template hipError_t launch_generic_skewed<float>(const GenericArgs<float> &, int, void *, void *, hipStream_t);
+template hipError_t launch_generic_skewed<double>(const GenericArgs<double> &, int, void *, void *, hipStream_t);
+template size_t generic_skew_bytes<float>(int, int, int, int, int, size_t *);
+template size_t generic_skew_bytes<double>(int, int, int, int, int, size_t *);
 
 template hipError_t launch_generic<float>(const GenericArgs<float> &, int, hipStream_t);
 template hipError_t launch_generic<double>(const GenericArgs<double> &, int, hipStream_t);

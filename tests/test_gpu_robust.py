@@ -106,3 +106,27 @@ def test_multi_plan_shards_equal_one_plan():
     with pytest.raises(ValueError):
         _capi.MultiPlan(513, p.W, devices=[ndev + 3])
     mp.close(); mpa.close()
+
+
+@pytest.mark.parametrize("fsize,fshift,L,T,precision", [(64, 8, 5, 40, "fp32"), (1024, 128, 5, 50, "fp32"), (48, 16, 4, 30, "fp32"),
+                                                      (1040, 260, 5, 40, "fp32"), (64, 16, 7, 33, "fp64"), (1024, 128, 5, 20, "fp64")])
+def test_generic_batch_on_the_skewed_copy_is_bit_identical(fsize, fshift, L, T, precision, oracle):
+    """Shapes the systolic kernels do not serve (Q = 8, Q = 3, L = 4 / 7, F - 1 not a multiple of 8, fp64) run their batch
+    sweeps on the generic engine -- on a time-skewed copy of the state so that the taps of a wavefront step are coalesced.
+    Same schedule and arithmetic as in the reference's layout: identical bits; and the oracle's values in fp64."""
+    rng = np.random.default_rng(fsize + L)
+    F = fsize // 2 + 1
+    p = lws_amd.lws(fsize, fshift, L=L)
+    S = rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))
+    thr = np.array([0.7, 0.3, 0.0, 0.0, 0.0])
+    skew = _capi.Plan(F, p.W, precision=precision, force_generic=True)
+    plain = _capi.Plan(F, p.W, precision=precision, force_generic=True, generic_plain_layout=True)
+    a = skew.batch(S, thr)
+    assert skew.last_kernel()["name"] == "generic_skew_" + precision
+    b = plain.batch(S, thr)
+    assert plain.last_kernel()["name"] == "generic_" + precision
+    assert np.array_equal(a, b)
+    if precision == "fp64":
+        for i in range(2):
+            assert np.abs(a[i] - oracle.batch_lws(S[i], p.W, thr)).max() < 1e-8
+    skew.close(); plain.close()

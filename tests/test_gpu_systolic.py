@@ -71,7 +71,7 @@ def test_other_stencil_widths(oracle, fsize, fshift, L, T):
     for Lg in (1, 4, 7):
         pg = lws_amd.lws(fsize, fshift, L=Lg)
         pg.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
-        assert pg.plan().last_kernel()["name"] == "generic_fp32"
+        assert pg.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
 
 
 def test_dropped_sweeps_and_mixed_schedules(oracle):
@@ -119,7 +119,7 @@ def test_weights_without_zero_pattern_use_the_allmask_kernel(oracle):
     W3 = W2.copy(); W3[1, 2, 3] *= 1.01
     plan3 = _capi.Plan(33, W3)
     out3 = plan3.batch(S, thr)
-    assert plan3.last_kernel()["name"] == "generic_fp32"
+    assert plan3.last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
     assert rel_l2(out3, oracle.batch_lws(S, W3, thr)) < 3e-3
 
 
@@ -151,7 +151,7 @@ def test_wide_needs_a_multiple_of_8():
     """F - 1 = 516 is a multiple of 4 but not of 8: generic engine."""
     p = lws_amd.lws(1032, 258)
     p.batch_lws(np.ones((4, 517)), thresholds=[0.0])
-    assert p.plan().last_kernel()["name"] == "generic_fp32"
+    assert p.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
 
 
 # ----------------------------------------------------------------------------- several workgroups per spectrogram
