@@ -254,7 +254,7 @@ def main():
             n_chk = min(B, 4)
             out = state[:n_chk]
             mg = mags[:n_chk]
-            tol = 1e-6 if storage == "fp32" else 2e-3
+            tol = 1e-6   # (fp16 storage too: the output takes its magnitudes from the fp32 targets, only the phase from the fp16 state)
             blk["checks"] = {"max_rel_magnitude_error": float(((out.abs() - mg).abs().max() / mg.max()).item()), "magnitude_tolerance": tol,
                              "finite": bool(torch.isfinite(torch.view_as_real(state)).all().item())}
             if cfg["fsize"] <= 2048:

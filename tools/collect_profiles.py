@@ -23,17 +23,20 @@ def find(con, prefix):
     return None
 
 
-con = db("trace")
-if con:
+for sub, suffix, what in (("trace", "", "python bench.py --steps 3 --warmup 1 --no-cpu-baseline  (MI355X; the default bench command: headline config 2 + every extra config block"),
+                          ("trace_headline", "_headline", "python bench.py --steps 5 --warmup 1 --no-extras --no-cpu-baseline  (MI355X; the headline workload alone: BASELINE config 2, 256 x 500 x 513, 100 dense sweeps")):
+    con = db(sub)
+    if not con:
+        continue
     kt = find(con, "kernels")
     rows = con.execute(f"select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from {kt} group by name order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows)
-    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
-        fh.write('"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline  (MI355X; the default bench command: headline config 2 + every extra config block; durations in microseconds)"\n')
+    with open(os.path.join(out, f"{tag}_kernel_stats{suffix}.csv"), "w", newline="") as fh:
+        fh.write('"# rocprofv3 --kernel-trace --stats -- %s; durations in microseconds)"\n' % what)
         w = csv.writer(fh)
         w.writerow(["kernel", "calls", "total_us", "average_us", "min_us", "max_us", "percent"])
-        for n, c, s, a, mn, mx in rows:
-            w.writerow([n[:200], c, round(s / 1e3, 3), round(a / 1e3, 3), round(mn / 1e3, 3), round(mx / 1e3, 3), round(100 * s / tot, 3)])
+        for n, c, s_, a, mn, mx in rows:
+            w.writerow([n[:200], c, round(s_ / 1e3, 3), round(a / 1e3, 3), round(mn / 1e3, 3), round(mx / 1e3, 3), round(100 * s_ / tot, 3)])
 
 SHAPES = {"2": (256, 500, 513, 100, 20.0), "2-T1024": (256, 1024, 513, 100, 20.0), "4shard": (1024, 500, 513, 100, 20.0),
           "5": (64, 56250, 1025, 200, 20.0), "5-f16": (64, 56250, 1025, 200, 10.0)}

@@ -8,6 +8,8 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.err
+# the headline workload alone (config 2 only): the per-kernel averages of this one are those of bench.py's roofline block
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_headline -o $TAG -- python bench.py --steps 5 --warmup 1 --no-extras --no-cpu-baseline > $OUT/bench_traced_headline.json 2> $OUT/trace_headline.err
 for cfg in 2 2-T1024 4shard 5 5-f16; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_${ctr}_$cfg -o $TAG -- python bench.py --config $cfg --no-extras --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_${ctr}_$cfg.err
@@ -18,6 +20,6 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/collect_profiles.py $OUT $OUT/summary $TAG
 # the rocpd databases are tens of MiB each: only the summaries (and the error logs) travel back
-rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE_* $OUT/pmc_WRITE_SIZE_*
+rm -rf $OUT/trace $OUT/trace_headline $OUT/pmc_FETCH_SIZE_* $OUT/pmc_WRITE_SIZE_*
 find $OUT -name '*.err' -size +64k -delete
 ls -la $OUT/summary
