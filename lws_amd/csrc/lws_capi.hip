@@ -89,7 +89,7 @@ struct lws_plan {
     DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out;
     DevBuf gsk_state, gsk_amp;     // time-skewed copy of the state for the generic engine's batch sweeps
     lws::SystolicPlan sys;         // device tables of the systolic kernel (empty if not eligible)
-    lws::SystolicPlan sysw;        // ... of its wide build (frames of 521..1025 bins)
+    const lws::SystolicBuild *sysb = nullptr;   // the build of it that serves this plan (narrow / Q = 8 / wide), if any
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_pending = false;
     float last_ms = 0.f;
@@ -180,18 +180,15 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     // the systolic kernel serves batch sweeps of plans it was built for (fp32, summarised weights
     // with the twiddle structure of create_weights, supported shape); everything else is generic.
     if (!p->fp64 && mode == lws::MODE_BATCH && !(p->flags & LWS_FORCE_GENERIC)) {
-        const bool narrow = lws::systolic_supports(p->sys, wsel, T);
-        const bool wide = !narrow && lws::wide::systolic_supports(p->sysw, wsel, T);
-        if (narrow || wide) {
+        if (p->sysb && p->sysb->supports(p->sys, wsel, T)) {
             int launches = 0;
             float2 *st = static_cast<float2 *>(p->state.p);
             const float *am = static_cast<const float *>(p->amp.p), *th = static_cast<const float *>(p->thr_scaled.p);
-            hipError_t e = narrow ? lws::launch_systolic(p->sys, wsel, st, am, th, B, T, iters, s, &launches, p->ev0, p->ev1)
-                                  : lws::wide::launch_systolic(p->sysw, wsel, st, am, th, B, T, iters, s, &launches, p->ev0, p->ev1);
+            hipError_t e = p->sysb->launch(p->sys, wsel, st, am, th, B, T, iters, s, &launches, p->ev0, p->ev1);
             p->timing_pending = true;
             if (e != hipSuccess) return fail(LWS_ERR_HIP, "systolic launch failed: %s", hipGetErrorString(e));
             p->last_launches = launches;
-            p->last_name = narrow ? lws::systolic_name(p->sys) : lws::wide::systolic_name(p->sysw);
+            p->last_name = p->sysb->name(p->sys);
             return LWS_OK;
         }
     }
@@ -276,28 +273,25 @@ struct StageSpec {
 // A call that is exactly one batch stage the systolic kernel can serve, on device complex64 spectrograms: the
 // spectrograms go straight into the kernel's layout and straight back (no extended buffers, no prep / extract passes).
 int run_direct_batch(lws_plan *p, const float2 *in_dev, float2 *out_dev, int B, int T, const StageSpec &st, hipStream_t s) {
-    const bool narrow = lws::systolic_supports(p->sys, st.wsel, T);
     int rc;
     if ((rc = p->mean_amp.ensure((size_t)B * sizeof(double)))) return rc;
     if ((rc = p->thr_host_copy.ensure((size_t)st.iters * sizeof(double)))) return rc;
     if ((rc = p->thr_scaled.ensure((size_t)B * st.iters * sizeof(float)))) return rc;
-    const size_t n_part = narrow ? lws::systolic_io_partials(p->sys, T) : lws::wide::systolic_io_partials(p->sysw, T);
+    const size_t n_part = p->sysb->io_partials(p->sys, T);
     if ((rc = p->row_sums.ensure((size_t)B * n_part * sizeof(double)))) return rc;
     double *partial = static_cast<double *>(p->row_sums.p), *mean = static_cast<double *>(p->mean_amp.p);
-    hipError_t e = narrow ? lws::systolic_io_load(p->sys, in_dev, B, T, st.iters, partial, mean, s)
-                          : lws::wide::systolic_io_load(p->sysw, in_dev, B, T, st.iters, partial, mean, s);
+    hipError_t e = p->sysb->io_load(p->sys, in_dev, B, T, st.iters, partial, mean, s);
     if (e != hipSuccess) return fail(LWS_ERR_HIP, "systolic load failed: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpyAsync(p->thr_host_copy.p, st.thr, sizeof(double) * st.iters, hipMemcpyHostToDevice, s));
     HIP_TRY(lws::launch_scale_thresholds<float>(static_cast<const double *>(p->thr_host_copy.p), mean,
                                                 static_cast<float *>(p->thr_scaled.p), B, st.iters, s));
     int launches = 0;
     const float *th = static_cast<const float *>(p->thr_scaled.p);
-    e = narrow ? lws::systolic_io_run(p->sys, st.wsel, th, in_dev, out_dev, partial, B, T, st.iters, s, &launches, p->ev0, p->ev1)
-               : lws::wide::systolic_io_run(p->sysw, st.wsel, th, in_dev, out_dev, partial, B, T, st.iters, s, &launches, p->ev0, p->ev1);
+    e = p->sysb->io_run(p->sys, st.wsel, th, in_dev, out_dev, partial, B, T, st.iters, s, &launches, p->ev0, p->ev1);
     p->timing_pending = true;
     if (e != hipSuccess) return fail(LWS_ERR_HIP, "systolic launch failed: %s", hipGetErrorString(e));
     p->last_launches = launches;
-    p->last_name = narrow ? lws::systolic_name(p->sys) : lws::wide::systolic_name(p->sysw);
+    p->last_name = p->sysb->name(p->sys);
     return LWS_OK;
 }
 
@@ -310,7 +304,7 @@ int run_pipeline(lws_plan *p, const io_cx *in_dev, io_cx *out_dev, const io_cx *
         for (int i = 0; i < nstages; ++i)
             if (stages[i].iters > 0) { ++active; which = i; }
         if (active == 1 && stages[which].mode == lws::MODE_BATCH && !(p->flags & (LWS_FORCE_GENERIC | LWS_NO_DIRECT_IO)) &&
-            (lws::systolic_supports(p->sys, stages[which].wsel, T) || lws::wide::systolic_supports(p->sysw, stages[which].wsel, T)))
+            p->sysb && p->sysb->supports(p->sys, stages[which].wsel, T))
             return run_direct_batch(p, in_dev, out_dev, B, T, stages[which], s);
     }
     int max_it = 1;
@@ -360,7 +354,7 @@ int need_weights(const lws_plan *p, const StageSpec *st, int n) {
 // not co-scheduled, e.g. the device was shared)?  Not an error: the call was then re-run on the device with one
 // workgroup per spectrogram before it completed (lws_systolic.hip: run_kernel); the kernel name says so.
 int check_systolic_flag(lws_plan *p) {
-    for (lws::SystolicPlan *sp : {&p->sys, &p->sysw}) {
+    for (lws::SystolicPlan *sp : {&p->sys}) {
         if (sp->last_nwg > 1 && sp->err_dev) {
             int flag = 0;
             HIP_TRY(hipMemcpy(&flag, sp->err_dev, sizeof(int), hipMemcpyDeviceToHost));
@@ -504,8 +498,11 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
                                p->have[1] ? p->hostW[1].data() : nullptr,
                                p->have[2] ? p->hostW[2].data() : nullptr};
         const bool h16 = (flags & LWS_STORAGE_FP16) != 0;
-        hipError_t e = lws::systolic_build(p->sys, F, L, Q, Qp, hw, h16);
-        if (e == hipSuccess && !(p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2])) e = lws::wide::systolic_build(p->sysw, F, L, Q, Qp, hw, h16);
+        hipError_t e = hipSuccess;
+        for (const lws::SystolicBuild *b : {&lws::systolic_entry(), &lws::q8::systolic_entry(), &lws::wide::systolic_entry()}) {
+            if ((e = b->build(p->sys, F, L, Q, Qp, hw, h16)) != hipSuccess) break;
+            if (p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2]) { p->sysb = b; break; }
+        }
         if (e != hipSuccess) rc = fail(LWS_ERR_HIP, "systolic table upload failed: %s", hipGetErrorString(e));
     }
     if (rc != LWS_OK) {
@@ -523,8 +520,7 @@ void lws_plan_destroy(lws_plan *p) {
     p->state.release(); p->amp.release(); p->row_sums.release(); p->mean_amp.release();
     p->thr_host_copy.release(); p->thr_scaled.release(); p->stage.release();
     p->resid_rows.release(); p->resid_out.release(); p->gsk_state.release(); p->gsk_amp.release();
-    lws::systolic_release(p->sys);
-    lws::wide::systolic_release(p->sysw);
+    lws::systolic_entry().release(p->sys);   // (the same code in every build)
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
@@ -619,11 +615,10 @@ int lws_plan_reserve(lws_plan *p, int B, int T, int max_iters) {
     if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
     if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
     if (!p->fp64) {
-        const bool narrow = p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2], wide = p->sysw.ok[0] || p->sysw.ok[1] || p->sysw.ok[2];
-        if (narrow || wide) {
-            const size_t n_part = narrow ? lws::systolic_io_partials(p->sys, T) : lws::wide::systolic_io_partials(p->sysw, T);
+        if (p->sysb) {
+            const size_t n_part = p->sysb->io_partials(p->sys, T);
             if ((rc = p->row_sums.ensure((size_t)B * (n_part > (size_t)T ? n_part : (size_t)T) * sizeof(double)))) return rc;
-            hipError_t e = narrow ? lws::systolic_reserve(p->sys, B, T, max_iters) : lws::wide::systolic_reserve(p->sysw, B, T, max_iters);
+            hipError_t e = p->sysb->reserve(p->sys, B, T, max_iters);
             if (e != hipSuccess) return fail(LWS_ERR_NOMEM, "systolic scratch: %s", hipGetErrorString(e));
         }
     }

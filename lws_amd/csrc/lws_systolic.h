@@ -45,27 +45,22 @@ hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, in
 hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, const float2 *in, float2 *out, double *partial, int B,
                            int T, int iters, hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1);
 
-// The same kernel compiled for frames of up to 1025 bins (lws_systolic.hip with -DLWS_WIDE=1): 16-step lane skew,
-// 64-step ring, 3 sweep slots.  Same contract.
-namespace wide {
-hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3], bool fp16_storage);
-void systolic_release(SystolicPlan &sp);
-bool systolic_supports(const SystolicPlan &sp, int wsel, int T);
-// Allocates the skewed-layout scratch for calls of up to B spectrograms x T frames (so that later calls do not).
-hipError_t systolic_reserve(SystolicPlan &sp, int B, int T, int iters);
-const char *systolic_name(const SystolicPlan &sp);
-hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp,
-                           const float *thr, int B, int T, int iters, hipStream_t stream,
-                           int *launches, hipEvent_t ev0, hipEvent_t ev1);
-// A call that consists of one batch stage on device complex64 spectrograms [B][T][F] skips the extended buffers:
-// systolic_io_load converts `in` straight to the kernel's layout and computes mean|S| (partial: scratch of
-// B * systolic_io_partials() doubles), the caller scales the thresholds, systolic_io_run runs the sweeps and writes `out`.
-size_t systolic_io_partials(const SystolicPlan &sp, int T);
-hipError_t systolic_io_load(SystolicPlan &sp, const float2 *in, int B, int T, int iters, double *partial, double *mean_amp,
-                            hipStream_t stream);
-// (`in` and `partial` as given to systolic_io_load: a failed multi-workgroup hand-over re-converts from them; `in` may be `out`)
-hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, const float2 *in, float2 *out, double *partial, int B,
-                           int T, int iters, hipStream_t stream, int *launches, hipEvent_t ev0, hipEvent_t ev1);
-}  // namespace wide
+// One compilation of lws_systolic.hip, as a table: a plan is served by the first build whose systolic_build() accepts its
+// shape and weights (lws_capi.hip tries them in the order below).
+struct SystolicBuild {
+    decltype(&systolic_build) build;
+    decltype(&systolic_release) release;
+    decltype(&systolic_supports) supports;
+    decltype(&systolic_reserve) reserve;
+    decltype(&systolic_name) name;
+    decltype(&launch_systolic) launch;
+    decltype(&systolic_io_partials) io_partials;
+    decltype(&systolic_io_load) io_load;
+    decltype(&systolic_io_run) io_run;
+};
+const SystolicBuild &systolic_entry();                            // Q in {2, 4}, frames of up to 513 bins: 7 sweep slots
+namespace q8 { const SystolicBuild &systolic_entry(); }           // -DLWS_Q8=1: Q = 8, 64-step ring, 2 sweep slots
+namespace wide { const SystolicBuild &systolic_entry(); }         // -DLWS_WIDE=1: frames of up to 1025 bins, two waves per sweep
+                                                                  // slot, 3 slots
 
 }  // namespace lws

@@ -53,8 +53,22 @@
 #ifndef LWS_WIDE
 #define LWS_WIDE 0
 #endif
+// ... and a third time with -DLWS_Q8=1 into namespace lws::q8 for Q = 8 (hop = window / 8, frames of up to 513 bins): the
+// taps reach 7 frames either way, so the lag between sweeps and the ring are 64 steps deep (LAG > 8 (Q-1) + L), the halo is
+// 7 lanes, and 2 sweep slots (one wave each) fit the LDS.  Half of the twiddles exp(2j pi (bin % 8) r / 8) are odd eighth
+// turns: a second weight set, W[0][r][k] exp(j pi / 4), serves those, and the 96 weights live in VGPRs (three waves per
+// workgroup, one per SIMD: registers are plentiful, SGPRs are not).
+#ifndef LWS_Q8
+#define LWS_Q8 0
+#endif
+#if LWS_WIDE && LWS_Q8
+#error "LWS_WIDE and LWS_Q8 are separate builds"
+#endif
 #if LWS_WIDE
 #define LWS_NS_OPEN namespace lws { namespace wide {
+#define LWS_NS_CLOSE } }
+#elif LWS_Q8
+#define LWS_NS_OPEN namespace lws { namespace q8 {
 #define LWS_NS_CLOSE } }
 #else
 #define LWS_NS_OPEN namespace lws {
@@ -69,7 +83,7 @@ constexpr int WPS = LWS_WIDE ? 2 : 1;                    // waves per sweep slot
 constexpr int ROWL = LANES * WPS;                        // lanes (frames) of a ring row = frames of a round
 constexpr int ROWL_SHIFT = LWS_WIDE ? 7 : 6;
 static_assert((1 << ROWL_SHIFT) == ROWL, "row length");
-constexpr int RING = 32;
+constexpr int RING = LWS_Q8 ? 64 : 32;
 constexpr int NBLK = RING / 8;                           // ring blocks of 8 steps
 // ring entry of production time nu, lane l:  set + ((nu >> 1) & 15) * PAIR_BYTES + (l + HALO) * 16 + (nu & 1) * 8
 // -- two consecutive times of one lane share a 16-byte cell, so a reader fetches two adjacent taps with one
@@ -81,14 +95,16 @@ constexpr int NBLK = RING / 8;                           // ring blocks of 8 ste
 // produces the mirrored bin -- the reference's pad columns (lwslib.cpp:362-367), kept in time coordinates.  A lane
 // near a frame edge reads those cells instead of its neighbour lane's: same compile-time offsets, other base.
 constexpr int SLOT_BYTES = ROWL * 8;                     // Nyquist buffer: bytes per set (one float2 per row lane)
-constexpr int HALO = 3;                                  // >= Q - 1
+constexpr int HALO = LWS_Q8 ? 7 : 3;                     // >= Q - 1
+constexpr int NDR = 2 * HALO + 1;                        // neighbour frames -HALO .. HALO
+constexpr int QMAX = HALO + 1;
 constexpr int LANE_B = 16;
 constexpr int PLL = ROWL + 2 * HALO, PLR = PLL + 1;       // absolute row indices of the two image pseudo-lanes
 constexpr int PAIR_BYTES = (ROWL + 2 * HALO + 2) * LANE_B;   // two consecutive times x 72 (136) row entries
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
-constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB
+constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB (wide: 34 KiB, Q = 8: 40 KiB)
 #ifndef LWS_NSLOTS
-#define LWS_NSLOTS (LWS_WIDE ? 3 : 7)
+#define LWS_NSLOTS (LWS_WIDE ? 3 : (LWS_Q8 ? 2 : 7))
 #endif
 constexpr int NSLOTS = LWS_NSLOTS;                       // sweeps in flight (compute waves)
 constexpr int NSETS = NSLOTS + 1;
@@ -102,6 +118,8 @@ constexpr int SCRATCH_OFF = DUMMY_OFF + LANES * 8;     // where the compute lane
 constexpr int SCRATCH_BYTES = 4 * PAIR_BYTES + LANES * 8;
 constexpr int LDS_BYTES = SCRATCH_OFF + SCRATCH_BYTES;
 constexpr int SKEW = 8, ROWP = SKEW * ROWL, LAG = RING;
+constexpr int LATE_DN = LAG / SKEW - 1;                  // frame m + LATE_DN of the previous sweep is only SKEW steps ahead of a lane (as frame m - 1 of its own sweep is)
+constexpr int NW = LWS_Q8 ? 2 * QMAX * 6 : 4 * 8;        // weights a kernel carries
 constexpr int ROWP_SHIFT = LWS_WIDE ? 10 : 9;
 static_assert((1 << ROWP_SHIFT) == ROWP, "frame period");
 constexpr int NCOMPUTE = NSLOTS * WPS;                   // compute waves; roles NCOMPUTE .. NCOMPUTE + WPS - 1 are the service waves
@@ -171,7 +189,8 @@ struct SysArgs {
     int spin_limit;          // polls of a producer's counter before a workgroup gives up
     int stress;              // test hook (LWS_SYSTOLIC_STRESS): role mask | pair << 16 -- the waves of the mask stall ~10 us
                              // before that pair of every block; the flow control must make the results independent of it
-    unsigned long long w[4 * 8];   // W[0][r][k], r < Q, k <= L (at most 4 x 8): bit patterns of (re, im) as one 64-bit scalar
+    unsigned long long w[NW];      // W[0][r][k], r < Q, k <= L (at most 4 x 8): bit patterns of (re, im) as one 64-bit scalar;
+                                   // Q = 8: [set][r][k] with set 1 = W[0][r][k] exp(j pi / 4), see widx()
 };
 
 // volatile: keeps every tap a separate ds_read_b64 (the backend otherwise fuses pairs into
@@ -311,8 +330,8 @@ struct LaneCtx {
     float thr, nxt_thr;
     // image cells: byte offset from the lane's own origin ob[m] to the pseudo-lane's, minus what the compile-time offset
     // of the neighbour frame DR adds -- for the lane at the start (lo: PLL) / end (hi: PLR) of its frame; zero for every
-    // other lane.  [DR + 3]; lo_nxt: for the first bin of the following block (second bin of the pair (7, 0'))
-    int wlo[7], whi[7], wlo_nxt[7];
+    // other lane.  [DR + HALO]; lo_nxt: for the first bin of the following block (second bin of the pair (7, 0'))
+    int wlo[NDR], whi[NDR], wlo_nxt[NDR];
     int img_lo, img_hi, img_both;   // image_base(): row origin for the image stores of this block (phases with an image below DC / above
                                     // Nyquist / both)
 };
@@ -445,8 +464,8 @@ __device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L +
         constexpr int q = q_first + j;
         constexpr auto used = [](int jj) {                        // is t[jj] needed by bin A (dk = jj-L) / bin B (dk = jj-L-1)?
             const int da = jj - L, db = jj - L - 1;
-            const bool na = MODE != 2 && da >= -L && da <= L && ((KMASK >> (da < 0 ? -da : da)) & 1u);
-            const bool nb = MODE != 1 && db >= -L && db <= L && ((KMASK >> (db < 0 ? -db : db)) & 1u);
+            const bool na = MODE != 2 && da >= -L && da <= L && ((KMASK >> (da < 0 ? -da : da)) & 1ull);
+            const bool nb = MODE != 1 && db >= -L && db <= L && ((KMASK >> (db < 0 ? -db : db)) & 1ull);
             return na || nb;
         };
         constexpr bool need0 = used(j), need1 = used(j + 1);
@@ -462,8 +481,8 @@ __device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L +
             // one add per (frame, ring block) for the image cells: the lane's origin plus an offset that is zero except
             // for the lane at the frame edge (LaneCtx::wlo / whi); everything else is the instruction's immediate offset
             int base = cx.ob[m];
-            if constexpr (img_lo) base = cx.ob[m] + (MODE == 2 ? cx.wlo_nxt[DR + 3] : cx.wlo[DR + 3]);
-            if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + 3];
+            if constexpr (img_lo) base = cx.ob[m] + (MODE == 2 ? cx.wlo_nxt[DR + HALO] : cx.wlo[DR + HALO]);
+            if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + HALO];
             const int addr = base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES;
             if constexpr (need0 && need1) {
                 const v4f v = lds_read128(addr);
@@ -483,7 +502,12 @@ __device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L +
 // float2 throughput of two scalar ones on gfx950, scratch/pk_ubench.hip).  Quarter turns, conjugation-like sign flips
 // and "broadcast one half of the (re, im) weight pair" are the instructions' own operand modifiers (op_sel / neg), which
 // the compiler does not derive from C++ (it builds the operands with v_mov / v_xor instead): hence the inline assembly.
-// A weight is wave-uniform and stays in an aligned SGPR pair.
+// A weight is wave-uniform and stays in an aligned SGPR pair (Q = 8 build: 96 weights, in VGPRs).
+#if LWS_Q8
+#define LWS_WREG "v"
+#else
+#define LWS_WREG "s"
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 using wp_t = unsigned long long;   // bit pattern of (re, im) as one 64-bit scalar
 __device__ __forceinline__ v2f vv(float2 a) { return (v2f){a.x, a.y}; }
@@ -494,7 +518,7 @@ __device__ __forceinline__ float2 ff(v2f a) { return make_float2(a.x, a.y); }
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[" #H "," #S ",0] op_sel_hi:[" #H "," LWS_NOT_##S ",1] neg_lo:[" #NL    \
         ",0,0] neg_hi:[" #NH ",0,0]"                                                                                \
         : "+v"(acc)                                                                                                 \
-        : "s"(w), "v"(v))
+        : LWS_WREG(w), "v"(v))
 #define LWS_NOT_0 "1"
 #define LWS_NOT_1 "0"
 template <int HALF, int SWZ, int NEGLO, int NEGHI> __device__ __forceinline__ v2f pk_fma_w(v2f acc, wp_t w, v2f v) {
@@ -548,17 +572,19 @@ template <int ROT> __device__ __forceinline__ v2f pk_add_rot(v2f x, v2f y) {
         "v_pk_fma_f32 %[a], %[w], %[s], %[a] " M1 "\n\t"                                                  \
         "v_pk_fma_f32 %[a], %[w], %[d], %[a] " M2                                                          \
         : [a] "+v"(acc), [s] "=&v"(t0), [d] "=&v"(t1)                                                      \
-        : [w] "s"(w), [b] "v"(vb), [c] "v"(vc))
+        : [w] LWS_WREG(w), [b] "v"(vb), [c] "v"(vc))
 // b = um +- dp, c = dm +- up, then the same
-#define LWS_QUAD_ASM(SG, M1, M2)                                                                         \
-    asm("v_pk_add_f32 %[b], %[um], %[dp]" SG "\n\t"                                                       \
-        "v_pk_add_f32 %[c], %[dm], %[up]" SG "\n\t"                                                       \
+#define LWS_SWPJ " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"   // x + j y
+#define LWS_SWMJ " op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"   // x - j y
+#define LWS_QUAD_ASM(SGB, SGC, M1, M2)                                                                   \
+    asm("v_pk_add_f32 %[b], %[um], %[dp]" SGB "\n\t"                                                      \
+        "v_pk_add_f32 %[c], %[dm], %[up]" SGC "\n\t"                                                      \
         "v_pk_add_f32 %[s], %[b], %[c]\n\t"                                                               \
         "v_pk_add_f32 %[b], %[b], %[c]" LWS_NEG2 "\n\t"                                                   \
         "v_pk_fma_f32 %[a], %[w], %[s], %[a] " M1 "\n\t"                                                  \
         "v_pk_fma_f32 %[a], %[w], %[b], %[a] " M2                                                          \
         : [a] "+v"(acc), [b] "=&v"(t0), [c] "=&v"(t1), [s] "=&v"(t2)                                       \
-        : [w] "s"(w), [um] "v"(vum), [up] "v"(vup), [dm] "v"(vdm), [dp] "v"(vdp))
+        : [w] LWS_WREG(w), [um] "v"(vum), [up] "v"(vup), [dm] "v"(vdm), [dp] "v"(vdp))
 
 // acc += w*b + conj(w)*c with w = (wr, wi) * j^ROT   (grouped form of lwslib.cpp:310-311)
 //   = p (b + c) + q j (b - c)   with (p, q) = (wr, wi), (-wi, wr), (-wr, -wi), (wi, -wr) for ROT = 0..3,
@@ -573,16 +599,26 @@ template <int ROT> __device__ __forceinline__ void pair_rot(float2 &a, wp_t w, f
     else LWS_PAIR_ASM(LWS_M1_3, LWS_M2_3);
     a = ff(acc);
 }
-// the four taps (m-R, c-k), (m-R, c+k), (m+R, c-k), (m+R, c+k) of one weight:  b = um +- dp, c = dm +- up (minus for an
-// odd quarter turn: W[-mod] = -W[mod]), then acc += w j^ROT b + conj(w j^ROT) c
-template <int ROT> __device__ __forceinline__ void quad_rot(float2 &a, wp_t w, float2 um, float2 up, float2 dm, float2 dp) {
+// the four taps (m-R, c-k), (m-R, c+k), (m+R, c-k), (m+R, c+k) of one weight.  With tau = exp(2j pi mod R / Q) the twiddle of
+// the bin, W[mod] = W0 tau multiplies (m-R, c-k) and W[-mod] = W0 conj(tau) multiplies (m+R, c+k) (conjugates for the other
+// two).  tau = j^ROT (even eighth turns): b = um +- dp, c = dm +- up (minus for an odd quarter turn: W[-mod] = -W[mod]), then
+// acc += w j^ROT b + conj(w j^ROT) c.  tau = j^ROT e^{j pi/4} (ODD, Q = 8): conj(tau) = tau rho with rho = -+j, so
+// b = um + rho dp, c = dm + conj(rho) up, then the same with w = (W0 e^{j pi/4}) -- the second weight set.
+template <int ROT, int ODD = 0> __device__ __forceinline__ void quad_rot(float2 &a, wp_t w, float2 um, float2 up, float2 dm, float2 dp) {
     v2f acc = vv(a), t0, t1, t2;
     const v2f vum = vv(um), vup = vv(up), vdm = vv(dm), vdp = vv(dp);
     constexpr int R = ROT & 3;
-    if constexpr (R == 0) LWS_QUAD_ASM("", LWS_M1_0, LWS_M2_0);
-    else if constexpr (R == 1) LWS_QUAD_ASM(LWS_NEG2, LWS_M1_1, LWS_M2_1);
-    else if constexpr (R == 2) LWS_QUAD_ASM("", LWS_M1_2, LWS_M2_2);
-    else LWS_QUAD_ASM(LWS_NEG2, LWS_M1_3, LWS_M2_3);
+    if constexpr (ODD == 0) {
+        if constexpr (R == 0) LWS_QUAD_ASM("", "", LWS_M1_0, LWS_M2_0);
+        else if constexpr (R == 1) LWS_QUAD_ASM(LWS_NEG2, LWS_NEG2, LWS_M1_1, LWS_M2_1);
+        else if constexpr (R == 2) LWS_QUAD_ASM("", "", LWS_M1_2, LWS_M2_2);
+        else LWS_QUAD_ASM(LWS_NEG2, LWS_NEG2, LWS_M1_3, LWS_M2_3);
+    } else {   // rho = (-1)^ROT (-j)
+        if constexpr (R == 0) LWS_QUAD_ASM(LWS_SWMJ, LWS_SWPJ, LWS_M1_0, LWS_M2_0);
+        else if constexpr (R == 1) LWS_QUAD_ASM(LWS_SWPJ, LWS_SWMJ, LWS_M1_1, LWS_M2_1);
+        else if constexpr (R == 2) LWS_QUAD_ASM(LWS_SWMJ, LWS_SWPJ, LWS_M1_2, LWS_M2_2);
+        else LWS_QUAD_ASM(LWS_SWPJ, LWS_SWMJ, LWS_M1_3, LWS_M2_3);
+    }
     a = ff(acc);
 }
 // Frames m-+1 and m-+3 sharing one weight (FLAG_R13): b = um +- dp, c = dm +- up, then B = p3b j^RB + b,
@@ -603,7 +639,7 @@ template <int ROT> __device__ __forceinline__ void quad_rot(float2 &a, wp_t w, f
         "v_pk_fma_f32 %[a], %[w], %[s], %[a] " M1 "\n\t"                                                  \
         "v_pk_fma_f32 %[a], %[w], %[b], %[a] " M2                                                          \
         : [a] "+v"(acc), [b] "=&v"(t0), [c] "=&v"(t1), [s] "=&v"(t2)                                       \
-        : [w] "s"(w), [um] "v"(vum), [up] "v"(vup), [dm] "v"(vdm), [dp] "v"(vdp), [pb] "v"(vpb), [pc] "v"(vpc))
+        : [w] LWS_WREG(w), [um] "v"(vum), [up] "v"(vup), [dm] "v"(vdm), [dp] "v"(vdp), [pb] "v"(vpb), [pc] "v"(vpc))
 #define LWS_R13_ROT(SG, M1, M2)                                                                          \
     do {                                                                                                 \
         if constexpr (RB == 0) LWS_R13_ASM(SG, LWS_ROTX_0, LWS_ROTX_0, M1, M2);                          \
@@ -638,7 +674,7 @@ template <int ODD> __device__ __forceinline__ void bc_pair(float2 &b, float2 &c,
     asm("v_pk_add_f32 %[t], %[b], %[c]" SG "\n\t"                                                         \
         "v_pk_fma_f32 %[a], %[w], %[t], %[a] " M                                                           \
         : [a] "+v"(acc), [t] "=&v"(t0)                                                                     \
-        : [w] "s"(w), [b] "v"(vb), [c] "v"(vc))
+        : [w] LWS_WREG(w), [b] "v"(vb), [c] "v"(vc))
 template <int ROT> __device__ __forceinline__ void pair_rot_real(float2 &a, wp_t w, float2 b, float2 c) {
     constexpr int R = ROT & 3;
     v2f acc = vv(a), t0;
@@ -653,13 +689,18 @@ template <int ROT> __device__ __forceinline__ void pair_rot_real(float2 &a, wp_t
 __device__ __forceinline__ float2 cadd(float2 p, float2 q) { return ff(vv(p) + vv(q)); }
 __device__ __forceinline__ float2 csub(float2 p, float2 q) { return ff(pk_sub(vv(p), vv(q))); }
 
+// eighth turns of the twiddle exp(2j pi mod R / Q) of frame pair R at a bin with bin % Q = mod (even unless Q = 8)
+template <int Q> __host__ __device__ constexpr int eighths(int mod, int R) { return ((mod * R) % Q) * (8 / Q); }
+// where W[0][R][k] (set 0) / W[0][R][k] exp(j pi / 4) (set 1: the odd eighth turns of Q = 8) sits in SysArgs::w
+template <int Q, int L> __host__ __device__ constexpr int widx(int set, int R, int k) { return (set * Q + R) * (L + 1) + k; }
+
 // Contribution of the centre frame (W[.,0,k] does not depend on bin % Q) to the bin at phase PH / clock PB.
-template <int L, uint32_t MASK, int PH, int PB>
+template <int L, uint64_t MASK, int PH, int PB>
 __device__ __forceinline__ void centre_sum(const SysArgs &a, const LaneCtx &cx, bool st, bool en, float2 self_old,
                                            float2 next_old, float2 prev_out, float2 &acc) {
     static_for<L>([&](auto ik) {
         constexpr int k = decltype(ik)::value + 1;
-        if constexpr ((MASK >> k) & 1u) {
+        if constexpr ((MASK >> k) & 1ull) {
             float2 lo = tap_any<PH, PB, 0, -k, 0>(cx, self_old, next_old, prev_out);
             float2 hi = tap_any<PH, PB, 0, k, 0>(cx, self_old, next_old, prev_out);
             // images, branch-free: the alternative source is fetched by every lane (the address is valid for all of
@@ -677,9 +718,9 @@ __device__ __forceinline__ void centre_sum(const SysArgs &a, const LaneCtx &cx, 
     });
 }
 
-// Structure flags carried in the top bits of the MASK template word (the tap mask itself needs Q*(L+1) <= 24 bits)
-constexpr uint32_t FLAG_K0REAL = 1u << 30;  // Im W[0][r][0] == 0 for r >= 1
-constexpr uint32_t FLAG_R13 = 1u << 31;     // Q = 4 and W[0][3][k] == j^k W[0][1][k] for 2 <= k <= L (sqrt-Hann, 75% overlap)
+// Structure flags carried in the top bits of the MASK template word (the tap mask itself needs Q*(L+1) <= 48 bits)
+constexpr uint64_t FLAG_K0REAL = 1ull << 62;  // Im W[0][r][0] == 0 for r >= 1
+constexpr uint64_t FLAG_R13 = 1ull << 63;     // Q = 4 and W[0][3][k] == j^k W[0][1][k] for 2 <= k <= L (sqrt-Hann, 75% overlap)
 
 // With FLAG_R13 the taps k >= 2 of frames m-+3 share the weight of frames m-+1 up to a quarter turn:
 //   W1 (j^mod B1 + j^(k-mod) B3) + conj(W1) (j^-mod C1 + j^(mod-k) C3),   B = um +- dp, C = dm +- up,
@@ -688,39 +729,39 @@ template <int L> struct R13Partials { float2 b[L + 1], c[L + 1]; };
 
 // one group of taps (the four taps |dk| = K of frames m-R and m+R, or the two taps dk = 0) of the bin at phase PH;
 // the bin sits at index L + OFFS of the tap windows tu (frame m-R) / td (frame m+R)
-template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS, int K, int N>
+template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int K, int N>
 __device__ __forceinline__ void rows_group(const SysArgs &a, const float2 (&tu)[N], const float2 (&td)[N],
                                            R13Partials<L> &p3, float2 &accr) {
     constexpr int K1 = L + 1;
     constexpr int mod = PH % Q;
-    constexpr int rot = ((mod * R) % Q) * (4 / Q);  // quarter turns of exp(2j*pi*mod*R/Q)
+    constexpr int e8 = eighths<Q>(mod, R), rot = e8 >> 1, odd = e8 & 1;  // exp(2j*pi*mod*R/Q) = j^rot (e^{j pi/4})^odd
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
     static_assert(L + OFFS + K < N, "tap window too short");
     // accr: the bin's running sum (every group of taps is added to it directly: no partial sums to zero and combine)
-    if constexpr (((MASK >> (R * K1 + K)) & 1u) == 0) {
+    if constexpr (((MASK >> (R * K1 + K)) & 1ull) == 0) {
         return;
     } else if constexpr (K == 0) {
-        if constexpr ((MASK & FLAG_K0REAL) != 0) pair_rot_real<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
-        else pair_rot<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
+        if constexpr ((MASK & FLAG_K0REAL) != 0 && !odd) pair_rot_real<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
+        else pair_rot<rot>(accr, a.w[widx<Q, L>(odd, R, 0)], tu[L + OFFS], td[L + OFFS]);
     } else {
         constexpr int k = K;
         // W[mod]*S[m-r,c-k] + conj(W[mod])*S[m+r,c-k] + W[-mod]*S[m+r,c+k] + conj(W[-mod])*S[m-r,c+k]
         // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
-        const wp_t w = a.w[R * K1 + k];
+        const wp_t w = a.w[widx<Q, L>(odd, R, k)];
         const float2 um = tu[L - k + OFFS], up = tu[L + k + OFFS], dm = td[L - k + OFFS], dp = td[L + k + OFFS];
         if constexpr (!(r13 && (R == 1 || R == 3) && k >= 2)) {
-            quad_rot<rot>(accr, w, um, up, dm, dp);
+            quad_rot<rot, odd>(accr, w, um, up, dm, dp);
         } else if constexpr (R == 3) {
             bc_pair<(rot & 1)>(p3.b[k], p3.c[k], um, up, dm, dp);      // rotated when rows 1 pick them up
         } else {
             // j^rot1 (B1 + j^(k+rot3-rot1) B3) and j^-rot1 (C1 + j^(rot1-k-rot3) C3): one multiply for both rows
-            constexpr int rot3 = ((mod * 3) % Q) * (4 / Q);
+            constexpr int rot3 = eighths<Q>(mod, 3) >> 1;
             r13_rot<rot, (k + rot3 - rot + 8) & 3>(accr, w, um, up, dm, dp, p3.b[k], p3.c[k]);
         }
     }
 }
 // Contribution of frames m-R and m+R to the bin at phase PH; OFFS = 0 / 1: first / second bin of the pair
-template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS, int N>
+template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int N>
 __device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[N], const float2 (&td)[N],
                                          R13Partials<L> &p3, float2 &accr) {
     static_for<L + 1>([&](auto ik) { rows_group<Q, L, MASK, PH, R, OFFS, decltype(ik)::value>(a, tu, td, p3, accr); });
@@ -739,7 +780,7 @@ __device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[N]
 template <int L> struct QuadCarry {
     float2 accA, accB;                               // neighbour-frame sums of the second pair's bins so far
     float2 um1[3], dm1[3], dp1[3], um3[3], c3[3];    // the three unfinished groups: operands of r13_rot() that are known
-    float2 g[4][3][4];                               // kernels without FLAG_R13: [R][group] the operands (um, up, dm, dp) of quad_rot()
+    float2 g[QMAX][3][4];                            // kernels without FLAG_R13: [R][group] the operands (um, up, dm, dp) of quad_rot()
 };
 // (with the 16-step skew of the wide build every frame is far enough ahead: nothing is late there)
 template <int DR> __host__ __device__ constexpr bool quad_late_frame() { return SKEW * DR - (DR > 0 ? LAG : 0) > -10; }
@@ -747,18 +788,18 @@ template <int OFFS, int K, int L> __host__ __device__ constexpr bool quad_deferr
 template <int OFFS, int K, int L> __host__ __device__ constexpr int quad_slot() { return OFFS == 2 ? 0 : (K == L - 1 ? 1 : 2); }
 
 // neighbour-frame taps of a bin of the SECOND pair (OFFS = 2, 3), summed during the first pair
-template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS, int N>
+template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int N>
 __device__ __forceinline__ void rows_sum_ahead(const SysArgs &a, const float2 (&tu)[N], const float2 (&td)[N],
                                                R13Partials<L> &p3, float2 &accr, QuadCarry<L> &qc) {
     constexpr int K1 = L + 1;
-    constexpr int rot = (((PH % Q) * R) % Q) * (4 / Q);
+    constexpr int rot = eighths<Q>(PH % Q, R) >> 1;
     static_for<L + 1>([&](auto ik) {
         constexpr int k = decltype(ik)::value;
         constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
         constexpr bool late = quad_deferred<OFFS, k, L>() && (quad_late_frame<-R>() || quad_late_frame<R>());
         if constexpr (!late) {
             rows_group<Q, L, MASK, PH, R, OFFS, k>(a, tu, td, p3, accr);
-        } else if constexpr (((MASK >> (R * K1 + k)) & 1u) == 0) {
+        } else if constexpr (((MASK >> (R * K1 + k)) & 1ull) == 0) {
         } else if constexpr (!r13) {          // the late operand is filled in by the second pair (quad_finish_plain)
             constexpr int i = quad_slot<OFFS, k, L>();
             qc.g[R][i][0] = tu[L - k + OFFS];
@@ -781,22 +822,22 @@ __device__ __forceinline__ void rows_sum_ahead(const SysArgs &a, const float2 (&
     });
 }
 // an unfinished group of a kernel without FLAG_R13: `late` is the tap that was not there yet (frame m-R's or m+R's, at +K)
-template <int Q, int L, uint32_t MASK, int PH, int R, int OFFS, int K>
+template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int K>
 __device__ __forceinline__ void quad_finish_plain(const SysArgs &a, const QuadCarry<L> &qc, float2 late, float2 &accr) {
     constexpr int K1 = L + 1;
-    constexpr int rot = (((PH % Q) * R) % Q) * (4 / Q);
+    constexpr int e8 = eighths<Q>(PH % Q, R), rot = e8 >> 1, odd = e8 & 1;
     constexpr int i = quad_slot<OFFS, K, L>();
-    if constexpr ((MASK >> (R * K1 + K)) & 1u)
-        quad_rot<rot>(accr, a.w[R * K1 + K], qc.g[R][i][0], quad_late_frame<-R>() ? late : qc.g[R][i][1], qc.g[R][i][2],
+    if constexpr ((MASK >> (R * K1 + K)) & 1ull)
+        quad_rot<rot, odd>(accr, a.w[widx<Q, L>(odd, R, K)], qc.g[R][i][0], quad_late_frame<-R>() ? late : qc.g[R][i][1], qc.g[R][i][2],
                       quad_late_frame<R>() ? late : qc.g[R][i][3]);
 }
 // the three unfinished groups, by the second pair: up1 = frame m-1's late tap, dp3 = frame m+3's
-template <int Q, int L, uint32_t MASK, int PH, int OFFS, int K>
+template <int Q, int L, uint64_t MASK, int PH, int OFFS, int K>
 __device__ __forceinline__ void quad_finish(const SysArgs &a, const QuadCarry<L> &qc, float2 up1, float2 dp3, float2 &accr) {
     constexpr int K1 = L + 1, mod = PH % Q;
-    constexpr int rot1 = ((mod * 1) % Q) * (4 / Q), rot3 = ((mod * 3) % Q) * (4 / Q);
+    constexpr int rot1 = eighths<Q>(mod, 1) >> 1, rot3 = eighths<Q>(mod, 3) >> 1;
     constexpr int i = quad_slot<OFFS, K, L>();
-    if constexpr ((MASK >> (1 * K1 + K)) & 1u) {
+    if constexpr ((MASK >> (1 * K1 + K)) & 1ull) {
         float2 b3;
         if constexpr ((rot3 & 1) == 0) b3 = cadd(qc.um3[i], dp3);
         else b3 = csub(qc.um3[i], dp3);
@@ -821,8 +862,8 @@ __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
         constexpr int within = q - 8 * fl;                       // even
         constexpr int setoff = (DR < 0) ? SET_BYTES : 0;
         int base = cx.ob[m];
-        if constexpr (img_lo) base = cx.ob[m] + cx.wlo[DR + 3];
-        if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + 3];
+        if constexpr (img_lo) base = cx.ob[m] + cx.wlo[DR + HALO];
+        if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + HALO];
         const v4f v = lds_read128(base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES);
         t[j] = make_float2(v.x, v.y);
         t[j + 1] = make_float2(v.z, v.w);
@@ -846,7 +887,7 @@ __device__ __forceinline__ float2 project(float2 acc, float target, bool active,
 struct Carry { float2 o0, o1, o2, prev_out; };
 
 // One pair of bins (phases PA odd, PA+1) of one lane.
-template <int Q, int L, uint32_t MASK, int PA, bool H16>
+template <int Q, int L, uint64_t MASK, int PA, bool H16>
 __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx, Carry &cr, const float (&amp_cur)[8],
                                              const float (&amp_nxt)[8], QuadCarry<L> &qc) {
     constexpr int K1 = L + 1;
@@ -885,8 +926,8 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             constexpr int i = decltype(ir)::value;
             constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
             float2 tu[2 * L + 4], td[2 * L + 4];
-            static_assert(quad_late_frame<-1>() == quad_late_frame<3>() && !quad_late_frame<-2>() && !quad_late_frame<2>() &&
-                          !quad_late_frame<1>() && !quad_late_frame<-3>(), "which frames are late");
+            static_assert(quad_late_frame<-1>() && quad_late_frame<LATE_DN>() && !quad_late_frame<-2>() && !quad_late_frame<LATE_DN - 1>() &&
+                          !quad_late_frame<1>() && !quad_late_frame<-LATE_DN>(), "which frames are late");
             load_cells<PA, -R, L, 0, (quad_late_frame<-R>() ? L + 1 : L + 2)>(cx, tu);    // frame m-1 cannot deliver its seventh cell yet,
             load_cells<PA, R, L, 0, (quad_late_frame<R>() ? L + 1 : L + 2)>(cx, td);      // nor can frame m+3
             rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
@@ -902,12 +943,12 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
         accA = cadd(accA, qc.accA);
         if constexpr (quad_late_frame<-1>()) {
             load_cells<PA - 2, -1, L, L + 1, 1>(cx, u1);
-            if constexpr (Q > 3) load_cells<PA - 2, 3, L, L + 1, 1>(cx, d3);
+            if constexpr (Q > LATE_DN) load_cells<PA - 2, LATE_DN, L, L + 1, 1>(cx, d3);
             if constexpr (r13) {
                 quad_finish<Q, L, MASK, PA, 2, L>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accA);
             } else {
                 quad_finish_plain<Q, L, MASK, PA, 1, 2, L>(a, qc, u1[2 * L + 2], accA);
-                if constexpr (Q > 3) quad_finish_plain<Q, L, MASK, PA, 3, 2, L>(a, qc, d3[2 * L + 2], accA);
+                if constexpr (Q > LATE_DN) quad_finish_plain<Q, L, MASK, PA, LATE_DN, 2, L>(a, qc, d3[2 * L + 2], accA);
             }
         }
         if constexpr (PA == 3) {
@@ -919,9 +960,9 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
                 } else {
                     quad_finish_plain<Q, L, MASK, PHB, 1, 3, L - 1>(a, qc, u1[2 * L + 2], accB);
                     quad_finish_plain<Q, L, MASK, PHB, 1, 3, L>(a, qc, u1[2 * L + 3], accB);
-                    if constexpr (Q > 3) {
-                        quad_finish_plain<Q, L, MASK, PHB, 3, 3, L - 1>(a, qc, d3[2 * L + 2], accB);
-                        quad_finish_plain<Q, L, MASK, PHB, 3, 3, L>(a, qc, d3[2 * L + 3], accB);
+                    if constexpr (Q > LATE_DN) {
+                        quad_finish_plain<Q, L, MASK, PHB, LATE_DN, 3, L - 1>(a, qc, d3[2 * L + 2], accB);
+                        quad_finish_plain<Q, L, MASK, PHB, LATE_DN, 3, L>(a, qc, d3[2 * L + 3], accB);
                     }
                 }
             }
@@ -930,7 +971,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             static_for<Q - 1>([&](auto ir) {
                 constexpr int i = decltype(ir)::value;
                 constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
-                constexpr uint32_t kmask = (MASK >> (R * K1)) & ((1u << K1) - 1u);
+                constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
                 float2 tu[2 * L + 2], td[2 * L + 2];
                 load_row2<PA, -R, L, kmask, 2>(cx, tu);
                 load_row2<PA, R, L, kmask, 2>(cx, td);
@@ -943,7 +984,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     static_for<Q - 1>([&](auto ir) {
         constexpr int i = decltype(ir)::value;
         constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
-        constexpr uint32_t kmask = (MASK >> (R * K1)) & ((1u << K1) - 1u);
+        constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
         if constexpr (!wrap) {
             float2 tu[2 * L + 2], td[2 * L + 2];
             load_row2<PA, -R, L, kmask, 0>(cx, tu);
@@ -994,7 +1035,7 @@ struct ServiceState {      // (both as the loads delivered them: raw bits of the
 // Lane l < NSLOTS computes the Nyquist bin (bin C = F-1) of the frame of sweep slot l whose 512-step period ended at
 // clock t0 (phase 0 of the current block); lane NSLOTS feeds set 0 with the stored Nyquist value of that frame.
 // Called at the start of the first pair of the block, when every slot has published bins C-1, C-2, ...
-template <int Q, int L, uint32_t MASK, bool MULTI, bool H16>
+template <int Q, int L, uint64_t MASK, bool MULTI, bool H16>
 __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &sv, int lane, int t0, int wg, int n_eff,
                                                 int n_groups, const float *thr_eff, void *state_nyq_b,
                                                 const void *amp_nyq_b) {
@@ -1028,9 +1069,9 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
         const float thr = thr_eff[valid ? j : 0];
         const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
-        int nb[4][NBLK], ob[4][NBLK], nn[4], no[4];
+        int nb[Q][NBLK], ob[Q][NBLK], nn[Q], no[Q];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < Q; ++d) {
             const int ln = ((rho - d) & (ROWL - 1)), lo = ((rho + d) & (ROWL - 1));
             nn[d] = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln * 8;
             no[d] = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
@@ -1046,18 +1087,18 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         // bin C: bin % Q == 0, every twiddle is 1; taps above Nyquist are conjugated images
         static_for<L>([&](auto ik) {
             constexpr int k = decltype(ik)::value + 1;
-            if constexpr ((MASK >> k) & 1u) {
+            if constexpr ((MASK >> k) & 1ull) {
                 const float2 lo = lds_read(ring_addr<0, -k>(nb[0]));
                 pair_rot<0>(acc, a.w[k], lo, cj(lo));
             }
         });
         static_for<Q - 1>([&](auto ir) {
             constexpr int r = decltype(ir)::value + 1;
-            if constexpr ((MASK >> (r * K1)) & 1u)
+            if constexpr ((MASK >> (r * K1)) & 1ull)
                 pair_rot<0>(acc, a.w[r * K1], lds_read(nn[r]), lds_read(no[r]));
             static_for<L>([&](auto ik) {
                 constexpr int k = decltype(ik)::value + 1;
-                if constexpr ((MASK >> (r * K1 + k)) & 1u) {
+                if constexpr ((MASK >> (r * K1 + k)) & 1ull) {
                     const float2 up = lds_read(ring_addr<0, -SKEW * r - k>(nb[r]));
                     const float2 dn = lds_read(ring_addr<0, SKEW * r - k - LAG>(ob[r]));
                     const float2 bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
@@ -1080,7 +1121,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
 }
 
 // MULTI: several workgroups share a spectrogram (a.nwg > 1); the single-workgroup instantiation carries none of it
-template <int Q, int L, uint32_t MASK, bool MULTI, bool H16>
+template <int Q, int L, uint64_t MASK, bool MULTI, bool H16>
 __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a_in.gate != nullptr && __hip_atomic_load(a_in.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
@@ -1096,11 +1137,15 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     {
         const float sc = H16 ? 1.0f : data_scale;
 #pragma unroll
-        for (int x = 0; x < 32; ++x) {
+        for (int x = 0; x < NW; ++x) {
             const float re = __uint_as_float((unsigned)(a_in.w[x] & 0xffffffffull)) * sc;
             const float im = __uint_as_float((unsigned)(a_in.w[x] >> 32)) * sc;
+#if LWS_Q8
+            a.w[x] = ((unsigned long long)__float_as_uint(im) << 32) | __float_as_uint(re);
+#else
             a.w[x] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(im)) << 32) |
                      (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(re));
+#endif
         }
     }
     // `wave` is the ROLE of a wave (sweep slot 0..NSLOTS-1, or NSLOTS = service), not its hardware index: hardware
@@ -1262,9 +1307,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         bi.thr = here ? rcur.thr : rprev.thr;
         return bi;
     };
-    int dlo[7];   // per-lane constants of the image-cell offsets: (PLL - HALO - DR - lane) * 16
+    int dlo[NDR];   // per-lane constants of the image-cell offsets: (PLL - HALO - DR - lane) * 16
 #pragma unroll
-    for (int d = 0; d < 7; ++d) dlo[d] = (PLL - HALO - (d - 3) - rl) * LANE_B;
+    for (int d = 0; d < NDR; ++d) dlo[d] = (PLL - HALO - (d - HALO) - rl) * LANE_B;
     BlockInfo nxt_bi = block_info(T_START - (slot + 1) * LAG);
     int vmod = __builtin_amdgcn_readfirstlane((((T_START - (slot + 1) * LAG) % G) + G) % G - 8);   // advanced at the loop head
     int tmod = __builtin_amdgcn_readfirstlane(((T_START % G) + G) % G - 8);
@@ -1284,7 +1329,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         cx.dummy = DUMMY_OFF + lane * 8;
         cx.halo_shift = (rl < HALO) ? ROWL * LANE_B : (rl >= ROWL - HALO ? -ROWL * LANE_B : 0);
 #pragma unroll
-        for (int d = 0; d < 7; ++d) {   // (only the entries of frames that exist, |DR| <= Q-1, are ever read)
+        for (int d = 0; d < NDR; ++d) {   // (only the entries of frames that exist, |DR| <= Q-1, are ever read)
             cx.wlo[d] = cx.is_start ? dlo[d] : 0;
             cx.whi[d] = cx.is_end ? dlo[d] + LANE_B : 0;   // PLR = PLL + 1
             cx.wlo_nxt[d] = cx.nxt_start ? dlo[d] : 0;
@@ -1777,9 +1822,9 @@ __global__ void __launch_bounds__(256) k_skew_to_out(float2 *out, const float2 *
     }
 }
 
-constexpr uint32_t mask_all(int Q, int L) { return (Q * (L + 1) >= 32) ? 0xffffffffu : ((1u << (Q * (L + 1))) - 1u); }
+constexpr uint64_t mask_all(int Q, int L) { return (1ull << (Q * (L + 1))) - 1ull; }
 
-template <int Q, int L, uint32_t MASK, bool MULTI, bool H16> hipError_t launch_km(const SysArgs &a, int grid, hipStream_t s) {
+template <int Q, int L, uint64_t MASK, bool MULTI, bool H16> hipError_t launch_km(const SysArgs &a, int grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_systolic<Q, L, MASK, MULTI, H16>),
@@ -1790,20 +1835,22 @@ template <int Q, int L, uint32_t MASK, bool MULTI, bool H16> hipError_t launch_k
     hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI, H16>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
     return hipGetLastError();
 }
-template <int Q, int L, uint32_t MASK> hipError_t launch_k(const SysArgs &a, int grid, bool h16, hipStream_t s) {
+template <int Q, int L, uint64_t MASK> hipError_t launch_k(const SysArgs &a, int grid, bool h16, hipStream_t s) {
     if (h16) return a.nwg > 1 ? launch_km<Q, L, MASK, true, true>(a, grid, s) : launch_km<Q, L, MASK, false, true>(a, grid, s);
     return a.nwg > 1 ? launch_km<Q, L, MASK, true, false>(a, grid, s) : launch_km<Q, L, MASK, false, false>(a, grid, s);
 }
 
+#if !LWS_Q8
 // mask bit r*(L+1)+k set <=> |W[0][r][k]| > 1e-12.  Default sqrt-Hann windows give these patterns (L = 5):
-constexpr uint32_t MASK_Q4_L5_DEFAULT = 0b111111'010111'111111'000011u;  // (r=3 | r=2 | r=1 | r=0), 6 bits each, bit k: r=0:{0,1} r=1:all r=2:{0,1,2,4} r=3:all
-constexpr uint32_t MASK_Q2_L5_DEFAULT = 0b010111'000011u;                            // r=0:{0,1} r=1:{0,1,2,4}
+constexpr uint64_t MASK_Q4_L5_DEFAULT = 0b111111'010111'111111'000011u;  // (r=3 | r=2 | r=1 | r=0), 6 bits each, bit k: r=0:{0,1} r=1:all r=2:{0,1,2,4} r=3:all
+constexpr uint64_t MASK_Q2_L5_DEFAULT = 0b010111'000011u;                            // r=0:{0,1} r=1:{0,1,2,4}
+#endif
 
 struct Tables {
     int Q, L;
-    uint32_t mask;
+    uint64_t mask;
     bool k0real, r13;  // structure the kernels can exploit (FLAG_K0REAL / FLAG_R13)
-    float w[64];
+    float w[2 * NW];   // (re, im) in the order of SysArgs::w
 };
 
 }  // namespace
@@ -1819,7 +1866,11 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
     // be odd (the tap windows are fetched as aligned pairs of bins) and at most SKEW - 3: a lane works on two bins per
     // rendez-vous, so the newest tap of the pair's second bin, (m-1, c+1+L), must be at least two steps old when the pair
     // starts (L = 7 is not: generic engine).
+#if LWS_Q8
+    if (Qp != Q || Q != 8 || L != 5) return hipSuccess;
+#else
     if (Qp != Q || !(Q == 2 || Q == 4) || !(L == 5 || L == 3)) return hipSuccess;
+#endif
     if (C % SKEW != 0 || C > ROWP || C < 16) return hipSuccess;
     if ((Q - 1) * SKEW + L + 1 > LAG) return hipSuccess;
     const int K1 = L + 1;
@@ -1846,14 +1897,20 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
             for (int k = 0; k <= L; ++k) {
                 const double wr = W[i][2 * (r * K1 + k)], wi = W[i][2 * (r * K1 + k) + 1];
                 const bool on = std::hypot(wr, wi) > 1.0e-12;  // lws.pyx:231-232
-                if (on) tb->mask |= 1u << (r * K1 + k);
+                if (on) tb->mask |= 1ull << (r * K1 + k);
                 tb->w[2 * (r * K1 + k)] = on ? (float)wr : 0.f;
                 tb->w[2 * (r * K1 + k) + 1] = on ? (float)wi : 0.f;
+#if LWS_Q8
+                // second set: W[0][r][k] exp(j pi / 4), formed in fp64 and rounded once
+                const double h = std::sqrt(0.5);
+                tb->w[2 * ((Q + r) * K1 + k)] = on ? (float)((wr - wi) * h) : 0.f;
+                tb->w[2 * ((Q + r) * K1 + k) + 1] = on ? (float)((wr + wi) * h) : 0.f;
+#endif
             }
         // structure of symmetric windows, checked on the fp64 weights well below fp32 resolution
         tb->k0real = true;
         for (int r = 1; r < Q; ++r)
-            if (((tb->mask >> (r * K1)) & 1u) && std::fabs(W[i][2 * (r * K1) + 1]) > 1e-13 * scale) tb->k0real = false;
+            if (((tb->mask >> (r * K1)) & 1ull) && std::fabs(W[i][2 * (r * K1) + 1]) > 1e-13 * scale) tb->k0real = false;
         tb->r13 = (Q == 4);
         for (int k = 2; k <= L && tb->r13; ++k) {
             const bool on1 = (tb->mask >> (1 * K1 + k)) & 1u, on3 = (tb->mask >> (3 * K1 + k)) & 1u;
@@ -1991,8 +2048,9 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         const char *es = getenv("LWS_SYSTOLIC_STRESS");
         a.stress = es ? atoi(es) : 0;
     }
-    for (int x = 0; x < 32; ++x) {
-        const float re = x < Q * (L + 1) ? tb->w[2 * x] : 0.f, im = x < Q * (L + 1) ? tb->w[2 * x + 1] : 0.f;
+    for (int x = 0; x < NW; ++x) {
+        const bool used = x < (LWS_Q8 ? 2 : 1) * Q * (L + 1);
+        const float re = used ? tb->w[2 * x] : 0.f, im = used ? tb->w[2 * x + 1] : 0.f;
         unsigned ur, ui;
         memcpy(&ur, &re, 4); memcpy(&ui, &im, 4);
         a.w[x] = ((unsigned long long)ui << 32) | ur;
@@ -2001,6 +2059,9 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     const bool h = sp.h16;
     hipError_t e;
     const char *kind = "allmask";
+#if LWS_Q8
+    e = launch_k<8, 5, mask_all(8, 5)>(a, grid, h, stream);
+#else
     if (L == 3) {
         e = Q == 4 ? launch_k<4, 3, mask_all(4, 3)>(a, grid, h, stream) : launch_k<2, 3, mask_all(2, 3)>(a, grid, h, stream);
     } else if (Q == 4) {
@@ -2012,6 +2073,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, grid, h, stream); kind = "hannmask"; }
         else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
+#endif
     snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", LWS_WIDE ? "_wide" : "", Q, L, kind, h ? "_f16" : "");
     sp.name = sp.name_buf;
     return e;
@@ -2168,6 +2230,12 @@ hipError_t systolic_io_run(SystolicPlan &sp, int wsel, const float *thr, const f
         hipLaunchKernelGGL(k_skew_to_out<false>, dim3(g.Kt * g.NT, B), dim3(256), 0, stream, out, in, (const void *)g.state_w,
                            (const void *)g.state_nyq, amax, (const float *)g.thr_min, T, sp.F, sp.Q, g.G, g.TpPad, g.NT);
     return hipGetLastError();
+}
+
+const SystolicBuild &systolic_entry() {
+    static const SystolicBuild b = {systolic_build, systolic_release, systolic_supports, systolic_reserve, systolic_name,
+                                    launch_systolic, systolic_io_partials, systolic_io_load, systolic_io_run};
+    return b;
 }
 
 LWS_NS_CLOSE

@@ -74,6 +74,19 @@ def test_other_stencil_widths(oracle, fsize, fshift, L, T):
         assert pg.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
 
 
+@pytest.mark.parametrize("fsize,fshift,T,n_it", [(64, 8, 1, 3), (64, 8, 37, 4), (64, 8, 50, 5), (64, 8, 51, 2), (64, 8, 70, 1),
+                                                 (128, 16, 131, 4), (512, 64, 64, 3), (1024, 128, 37, 4), (1024, 128, 140, 5)])
+def test_q8(oracle, fsize, fshift, T, n_it):
+    """Q = 8 (hop = window / 8, LWSanyQ in the reference): the third build of the systolic kernel -- 64-step ring and lag, halo of
+    7 frames, 2 sweeps in flight, odd eighth-turn twiddles through a second weight set.  Frame counts around the 64-lane
+    rounds (T + 14 extended frames), sweep counts around the 2-slot groups, two spectrograms of different scale."""
+    thr = np.linspace(0.6, 0.0, n_it)
+    run_case(oracle, fsize, fshift, T, thr, seed=fsize + T, B=2, scale=[1.0, 25.0])
+    p = lws_amd.lws(fsize, fshift)
+    p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
+    assert p.plan().last_kernel()["name"].startswith("systolic_q8_l5"), p.plan().last_kernel()
+
+
 def test_dropped_sweeps_and_mixed_schedules(oracle):
     """Thresholds above the largest magnitude are dropped per spectrogram; spectrograms of one launch have different
     scales, hence different sets of dropped sweeps and different scaled thresholds."""
