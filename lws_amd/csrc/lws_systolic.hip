@@ -61,6 +61,9 @@
 #ifndef LWS_Q8
 #define LWS_Q8 0
 #endif
+#ifndef LWS_SPLIT_ROLES
+#define LWS_SPLIT_ROLES 1
+#endif
 #if LWS_WIDE && LWS_Q8
 #error "LWS_WIDE and LWS_Q8 are separate builds"
 #endif
@@ -116,15 +119,34 @@ constexpr int DONE_OFF = META_OFF + 16;               // per-wave count of compl
 constexpr int DUMMY_OFF = DONE_OFF + 64;               // 64 x 8 B: where predicated-off lanes park their conditional writes
 constexpr int SCRATCH_OFF = DUMMY_OFF + LANES * 8;     // where the compute lanes that have no image to publish store instead (see image_base)
 constexpr int SCRATCH_BYTES = 4 * PAIR_BYTES + LANES * 8;
-constexpr int LDS_BYTES = SCRATCH_OFF + SCRATCH_BYTES;
+// Q = 8: a sweep slot is one MAIN wave (centre frame, frames m-+1 and m-+7, re-projection, publishing) and NHELP helper
+// waves that sum the taps of the other neighbour frames HELP_AHEAD steps ahead of it -- every tap of frames m-+2 .. m-+6 is
+// at least 10 steps old when its bin is due -- and leave the two sums of a pair of bins in a mailbox (4 pairs deep).  The
+// sums of a bin are the bulk of its ~310 instructions and one wave per SIMD issues one every ~4.4 clocks: spreading a slot
+// over three waves is what fills the other SIMDs (2 slots are all the LDS holds at this ring depth).
+constexpr int NHELP = LWS_Q8 ? 2 : 0;                    // helper waves per sweep slot
+constexpr int HELP_AHEAD = 4;
+constexpr int MBOX_OFF = SCRATCH_OFF + SCRATCH_BYTES;    // [slot][helper][pair & 3][lane]: (sum of the first bin, of the second)
+constexpr int MBOX_BYTES = NSLOTS * NHELP * 4 * LANES * 16;
+constexpr int WNYQ_OFF = MBOX_OFF + MBOX_BYTES;          // Q = 8: the Nyquist lanes' weights (the waves keep only their own in registers)
+constexpr int LDS_BYTES = WNYQ_OFF + (LWS_Q8 ? QMAX * 6 * 8 : 0);
+__host__ __device__ constexpr int mbox_addr(int slot, int h, int pair) { return MBOX_OFF + ((slot * NHELP + (h - 1)) * 4 + (pair & 3)) * LANES * 16; }
 constexpr int SKEW = 8, ROWP = SKEW * ROWL, LAG = RING;
 constexpr int LATE_DN = LAG / SKEW - 1;                  // frame m + LATE_DN of the previous sweep is only SKEW steps ahead of a lane (as frame m - 1 of its own sweep is)
-constexpr int NW = LWS_Q8 ? 2 * QMAX * 6 : 4 * 8;        // weights a kernel carries
+// weights a kernel carries.  Q = 8: every wave of a slot keeps only the weights of the frames it sums (row_owner), both weight
+// sets for the odd frames: 3 lists of up to WLIST entries, then the 48 weights of set 0 in full for the Nyquist lanes
+constexpr int WLIST = 32, WNYQ = 3 * WLIST;
+constexpr int NW = LWS_Q8 ? WNYQ + QMAX * 6 : 4 * 8;
+__host__ __device__ constexpr int row_owner(int R) {     // which wave of a slot sums frames m-+R: 0 = main, h = helper h
+    return (NHELP == 0 || R <= 1 || R == LATE_DN) ? 0 : (NHELP == 1 ? 1 : (R <= 4 ? 1 : 2));
+}
 constexpr int ROWP_SHIFT = LWS_WIDE ? 10 : 9;
 static_assert((1 << ROWP_SHIFT) == ROWP, "frame period");
 constexpr int NCOMPUTE = NSLOTS * WPS;                   // compute waves; roles NCOMPUTE .. NCOMPUTE + WPS - 1 are the service waves
-constexpr int NTHREADS = LANES * (NCOMPUTE + WPS);
-static_assert(NCOMPUTE + WPS <= 16, "one progress counter per wave");
+constexpr int NHELPERS = NSLOTS * NHELP;                 // roles NCOMPUTE + WPS .. : helper h of slot s is role NCOMPUTE + WPS + s * NHELP + h - 1
+constexpr int NWAVES = NCOMPUTE + WPS + NHELPERS;
+constexpr int NTHREADS = LANES * NWAVES;
+static_assert(NWAVES <= 16, "one progress counter per wave");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 template <int... Is, typename F>
@@ -332,6 +354,7 @@ struct LaneCtx {
     // of the neighbour frame DR adds -- for the lane at the start (lo: PLL) / end (hi: PLR) of its frame; zero for every
     // other lane.  [DR + HALO]; lo_nxt: for the first bin of the following block (second bin of the pair (7, 0'))
     int wlo[NDR], whi[NDR], wlo_nxt[NDR];
+    int mbox;                       // Q = 8: mailbox of the slot's first helper, pair 0 (own lane)
     int img_lo, img_hi, img_both;   // image_base(): row origin for the image stores of this block (phases with an image below DC / above
                                     // Nyquist / both)
 };
@@ -452,13 +475,15 @@ __device__ __forceinline__ float2 tap_any(const LaneCtx &cx, float2 self_old, fl
 // MODE 0: both bins in one frame.  The pair (7, 0') straddles two frames of the lane, and the same production times
 // hold the images above Nyquist of the old frame (pseudo-lane PLR) and the first bins of the new one (real lane):
 // MODE 1 fetches bin A's view (en = last bin of a frame), MODE 2 bin B's (st = first bin of a frame).
-template <int PA, int DR, int L, uint32_t KMASK, int MODE>
+// CO: clock of the block the pair belongs to, relative to the block `cx` addresses (0, or 8 for a helper wave working on the
+// next block)
+template <int PA, int DR, int L, uint32_t KMASK, int MODE, int CO = 0>
 __device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L + 2]) {
     static_assert((PA & 1) == 1 && (L & 1) == 1, "pairs start on odd phases; L odd");
     static_assert(MODE == 0 || PA == 7, "split views only for the pair that straddles two frames");
     static_assert(MODE != 0 || PA != 7, "the straddling pair needs split views");
     constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
-    constexpr int q_first = PA + base_off - L;                   // even
+    constexpr int q_first = PA + CO + base_off - L;              // even
     static_for<L + 1>([&](auto ip) {
         constexpr int j = 2 * decltype(ip)::value;
         constexpr int q = q_first + j;
@@ -691,8 +716,22 @@ __device__ __forceinline__ float2 csub(float2 p, float2 q) { return ff(pk_sub(vv
 
 // eighth turns of the twiddle exp(2j pi mod R / Q) of frame pair R at a bin with bin % Q = mod (even unless Q = 8)
 template <int Q> __host__ __device__ constexpr int eighths(int mod, int R) { return ((mod * R) % Q) * (8 / Q); }
-// where W[0][R][k] (set 0) / W[0][R][k] exp(j pi / 4) (set 1: the odd eighth turns of Q = 8) sits in SysArgs::w
-template <int Q, int L> __host__ __device__ constexpr int widx(int set, int R, int k) { return (set * Q + R) * (L + 1) + k; }
+// where W[0][R][k] (set 0) / W[0][R][k] exp(j pi / 4) (set 1: the odd eighth turns of Q = 8) sits in the weight registers of
+// the wave that sums frames m-+R.  Q = 8: position in that wave's list -- its frames in ascending order, set 0 then (odd
+// frames only) set 1
+template <int Q, int L> __host__ __device__ constexpr int widx(int set, int R, int k) {
+    if (!LWS_Q8) return (set * Q + R) * (L + 1) + k;
+    int idx = 0;
+    for (int r = 0; r < Q; ++r) {
+        if (row_owner(r) != row_owner(R)) continue;
+        for (int st = 0; st < 2; ++st) {
+            if (st == 1 && (r & 1) == 0) continue;
+            if (r == R && st == set) return idx + k;
+            idx += L + 1;
+        }
+    }
+    return -1;
+}
 
 // Contribution of the centre frame (W[.,0,k] does not depend on bin % Q) to the bin at phase PH / clock PB.
 template <int L, uint64_t MASK, int PH, int PB>
@@ -713,7 +752,7 @@ __device__ __forceinline__ void centre_sum(const SysArgs &a, const LaneCtx &cx, 
                 const float2 im = tap_any<PH, PB, 0, k, 2>(cx, self_old, next_old, prev_out);
                 hi.x = en ? im.x : hi.x; hi.y = en ? im.y : hi.y;
             }
-            pair_rot<0>(acc, a.w[k], lo, hi);
+            pair_rot<0>(acc, a.w[widx<8, L>(0, 0, k)], lo, hi);   // (the centre frame's weights come first in every build)
         }
     });
 }
@@ -741,7 +780,7 @@ __device__ __forceinline__ void rows_group(const SysArgs &a, const float2 (&tu)[
     if constexpr (((MASK >> (R * K1 + K)) & 1ull) == 0) {
         return;
     } else if constexpr (K == 0) {
-        if constexpr ((MASK & FLAG_K0REAL) != 0 && !odd) pair_rot_real<rot>(accr, a.w[R * K1], tu[L + OFFS], td[L + OFFS]);
+        if constexpr ((MASK & FLAG_K0REAL) != 0 && !odd) pair_rot_real<rot>(accr, a.w[widx<Q, L>(0, R, 0)], tu[L + OFFS], td[L + OFFS]);
         else pair_rot<rot>(accr, a.w[widx<Q, L>(odd, R, 0)], tu[L + OFFS], td[L + OFFS]);
     } else {
         constexpr int k = K;
@@ -847,11 +886,11 @@ __device__ __forceinline__ void quad_finish(const SysArgs &a, const QuadCarry<L>
 
 // NC consecutive cells of the taps of frame m+DR, starting at bin (PA - L): t[j] is the tap at block-relative bin PA - L + j.
 // Images of the edge lanes as in load_row2 (both bins of each cell lie in the same frame as the pair: no split views).
-template <int PA, int DR, int L, int C0, int NC, int N>
+template <int PA, int DR, int L, int C0, int NC, int CO = 0, int N = 0>
 __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
     static_assert((PA & 1) == 1 && (L & 1) == 1 && 2 * (C0 + NC) <= N, "cell window");
     constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
-    constexpr int q_first = PA + base_off - L;                   // even
+    constexpr int q_first = PA + CO + base_off - L;              // even
     static_for<NC>([&](auto ip) {
         constexpr int j = 2 * (C0 + decltype(ip)::value);
         constexpr int q = q_first + j;
@@ -910,8 +949,15 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
 #define LWS_SETPRIO(n) asm volatile("s_setprio " #n)
     LWS_SETPRIO(1);
     float2 accA = make_float2(0.f, 0.f);
-    centre_sum<L, MASK, PA, PA>(a, cx, stA, enA, cr.o0, cr.o1, cr.prev_out, accA);
     float2 accB = make_float2(0.f, 0.f);
+    if constexpr (NHELP > 0) {   // what the helper waves of this slot summed for this pair (frames row_owner() gives them)
+        static_for<NHELP>([&](auto ih) {
+            const v4f mb = lds_read128(cx.mbox + mbox_addr(0, decltype(ih)::value + 1, PA >> 1));
+            accA = cadd(accA, make_float2(mb.x, mb.y));
+            accB = cadd(accB, make_float2(mb.z, mb.w));
+        });
+    }
+    centre_sum<L, MASK, PA, PA>(a, cx, stA, enA, cr.o0, cr.o1, cr.prev_out, accA);
     // frame pairs m-+R.  With FLAG_R13 rows 3 leave partial sums for rows 1: order 2, 3, 1 keeps them short-lived.
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
     // (1,2)+(3,4) in full; (5,6)+(7,0') for bin 7 only: bin 0' belongs to the lane's next frame and keeps its own fetches
@@ -925,6 +971,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
         static_for<Q - 1>([&](auto ir) {
             constexpr int i = decltype(ir)::value;
             constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
+            if constexpr (row_owner(R) == 0) {   // (else: summed by a helper wave, in accA / accB already)
             float2 tu[2 * L + 4], td[2 * L + 4];
             static_assert(quad_late_frame<-1>() && quad_late_frame<LATE_DN>() && !quad_late_frame<-2>() && !quad_late_frame<LATE_DN - 1>() &&
                           !quad_late_frame<1>() && !quad_late_frame<-LATE_DN>(), "which frames are late");
@@ -936,6 +983,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             if constexpr (PA == 1) rows_sum_ahead<Q, L, MASK, PA + 3, R, 3>(a, tu, td, p3D, qc.accB, qc);
             if constexpr (i == 0) LWS_SETPRIO(0);
             if constexpr (i == Q - 2) LWS_SETPRIO(2);
+            }
         });
     } else if constexpr (quad_second) {
         // the sums came with the previous pair; two cells were not there yet: finish the three groups that need them
@@ -952,7 +1000,8 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             }
         }
         if constexpr (PA == 3) {
-            accB = qc.accB;
+            if constexpr (NHELP > 0) accB = cadd(accB, qc.accB);   // (on top of the helpers' sums)
+            else accB = qc.accB;
             if constexpr (quad_late_frame<-1>()) {
                 if constexpr (r13) {
                     quad_finish<Q, L, MASK, PHB, 3, L - 1>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accB);
@@ -971,43 +1020,19 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             static_for<Q - 1>([&](auto ir) {
                 constexpr int i = decltype(ir)::value;
                 constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
+                if constexpr (row_owner(R) == 0) {
                 constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
                 float2 tu[2 * L + 2], td[2 * L + 2];
                 load_row2<PA, -R, L, kmask, 2>(cx, tu);
                 load_row2<PA, R, L, kmask, 2>(cx, td);
                 rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
                 if constexpr (i == 0) LWS_SETPRIO(0);
+                }
             });
         }
         LWS_SETPRIO(2);
-    } else
-    static_for<Q - 1>([&](auto ir) {
-        constexpr int i = decltype(ir)::value;
-        constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
-        constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
-        if constexpr (!wrap) {
-            float2 tu[2 * L + 2], td[2 * L + 2];
-            load_row2<PA, -R, L, kmask, 0>(cx, tu);
-            load_row2<PA, R, L, kmask, 0>(cx, td);
-            rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
-            rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
-        } else {
-            {
-                float2 tu[2 * L + 2], td[2 * L + 2];
-                load_row2<PA, -R, L, kmask, 1>(cx, tu);
-                load_row2<PA, R, L, kmask, 1>(cx, td);
-                rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
-            }
-            {
-                float2 tu[2 * L + 2], td[2 * L + 2];
-                load_row2<PA, -R, L, kmask, 2>(cx, tu);
-                load_row2<PA, R, L, kmask, 2>(cx, td);
-                rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
-            }
-        }
-        if constexpr (i == 0 && Q > 2) LWS_SETPRIO(0);    // bulk
-        if constexpr (i == Q - 2) LWS_SETPRIO(2);         // tail: the last frame pair's taps are in flight, then the serial part
-    });
+    }
+    static_assert(quad_first || quad_second, "every pair is half of a quad");
     // ---- first bin
     const float tA = amp_cur[PA];
     const float2 outA = project(accA, tA, cx.live && (tA > cx.thr), cr.o0);
@@ -1024,6 +1049,67 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     cr.o0 = cr.o2;
     cr.o1 = o3;
     cr.o2 = o4;
+}
+
+// Q = 8: one pair of bins of a HELPER lane (helper H of its slot): the taps of the neighbour frames row_owner() gives it,
+// for the pair the slot's main wave reaches HELP_AHEAD steps from now; phases (5,6), (7,0'), then (1,2), (3,4) of the lane's
+// next block.  Same windows, same order of operations per frame pair as compute_pair; no frame of a helper is late.
+template <int Q, int L, uint64_t MASK, int PA, int H>
+__device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx, QuadCarry<L> &qc) {
+    constexpr int K1 = L + 1;
+    constexpr int PH = (PA + HELP_AHEAD) & 7, CO = PA + HELP_AHEAD - PH;   // phase of the first bin; clock of its block
+    constexpr int PHB = (PH + 1) & 7;
+    static_assert(HELP_AHEAD == 4 && (CO == 0 || CO == 8), "half a block ahead");
+    float2 accA = make_float2(0.f, 0.f), accB = make_float2(0.f, 0.f);
+    R13Partials<L> p3;   // (unused: no shared-weight rows here)
+    if constexpr (PH == 1 || PH == 5) {
+        qc.accA = make_float2(0.f, 0.f);
+        qc.accB = make_float2(0.f, 0.f);
+        static_for<Q - 1>([&](auto ir) {
+            constexpr int R = decltype(ir)::value + 1;
+            if constexpr (row_owner(R) == H) {
+            static_assert(!quad_late_frame<-R>() && !quad_late_frame<R>(), "late frames stay with the main wave");
+            // two steps ahead of the pair (rows_sum_ahead) and HELP_AHEAD ahead of the main wave: the newest tap fetched is
+            // still 2 steps old
+            static_assert(SKEW * R - L - 3 - HELP_AHEAD >= 2 && LAG - SKEW * R - L - 3 - HELP_AHEAD >= 2, "helper runs too far ahead");
+            float2 tu[2 * L + 4], td[2 * L + 4];
+            load_cells<PH, -R, L, 0, L + 2, CO>(cx, tu);
+            load_cells<PH, R, L, 0, L + 2, CO>(cx, td);
+            rows_sum<Q, L, MASK, PH, R, 0>(a, tu, td, p3, accA);
+            rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3, accB);
+            rows_sum_ahead<Q, L, MASK, PH + 2, R, 2>(a, tu, td, p3, qc.accA, qc);
+            if constexpr (PH == 1) rows_sum_ahead<Q, L, MASK, PH + 3, R, 3>(a, tu, td, p3, qc.accB, qc);
+            }
+        });
+    } else {
+        accA = qc.accA;
+        if constexpr (PH == 3) {
+            accB = qc.accB;
+        } else {   // bin 0' of the lane's next frame: its own view of the taps
+            static_for<Q - 1>([&](auto ir) {
+                constexpr int R = decltype(ir)::value + 1;
+                if constexpr (row_owner(R) == H) {
+                constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
+                float2 tu[2 * L + 2], td[2 * L + 2];
+                load_row2<PH, -R, L, kmask, 2, CO>(cx, tu);
+                load_row2<PH, R, L, kmask, 2, CO>(cx, td);
+                rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3, accB);
+                }
+            });
+        }
+    }
+    using lds_v4w = volatile __attribute__((address_space(3))) v4f;
+    *(lds_v4w *)(unsigned)(cx.mbox + mbox_addr(0, H, (PA + HELP_AHEAD) >> 1)) = (v4f){accA.x, accA.y, accB.x, accB.y};
+}
+
+// weight W[0][r][k] (x = r (L+1) + k) for the Nyquist lanes: bin F-1 is a multiple of Q, every twiddle is 1
+__device__ __forceinline__ wp_t nyq_weight(const SysArgs &a, int x) {
+#if LWS_Q8
+    using lds_u64 = const volatile __attribute__((address_space(3))) unsigned long long;
+    return *(lds_u64 *)(unsigned)(WNYQ_OFF + x * 8);   // (scaled copy made at kernel start)
+#else
+    return a.w[x];
+#endif
 }
 
 // State of the service duties (HBM loader for set 0 and the Nyquist bins of every sweep slot).
@@ -1089,13 +1175,13 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
             constexpr int k = decltype(ik)::value + 1;
             if constexpr ((MASK >> k) & 1ull) {
                 const float2 lo = lds_read(ring_addr<0, -k>(nb[0]));
-                pair_rot<0>(acc, a.w[k], lo, cj(lo));
+                pair_rot<0>(acc, nyq_weight(a, k), lo, cj(lo));
             }
         });
         static_for<Q - 1>([&](auto ir) {
             constexpr int r = decltype(ir)::value + 1;
             if constexpr ((MASK >> (r * K1)) & 1ull)
-                pair_rot<0>(acc, a.w[r * K1], lds_read(nn[r]), lds_read(no[r]));
+                pair_rot<0>(acc, nyq_weight(a, r * K1), lds_read(nn[r]), lds_read(no[r]));
             static_for<L>([&](auto ik) {
                 constexpr int k = decltype(ik)::value + 1;
                 if constexpr ((MASK >> (r * K1 + k)) & 1ull) {
@@ -1103,7 +1189,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
                     const float2 dn = lds_read(ring_addr<0, SKEW * r - k - LAG>(ob[r]));
                     const float2 bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
                     const float2 csum = make_float2(dn.x + up.x, dn.y - up.y);   // dn + conj(up)
-                    pair_rot<0>(acc, a.w[r * K1 + k], bsum, csum);
+                    pair_rot<0>(acc, nyq_weight(a, r * K1 + k), bsum, csum);
                 }
             });
         });
@@ -1136,17 +1222,32 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const float data_scale = store_scale(a_in.amax[b]);
     {
         const float sc = H16 ? 1.0f : data_scale;
+#if LWS_Q8
+        // (hardware wave -> role table below) the list of the wave's role: mains 0, helpers 1 / 2
+        const int hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int owner = (hw == 2 || hw == 3) ? 1 : ((hw == 4 || hw == 5) ? 2 : 0);
+#pragma unroll
+        for (int x = 0; x < WLIST; ++x) {
+            const unsigned long long u = owner == 0 ? a_in.w[x] : (owner == 1 ? a_in.w[WLIST + x] : a_in.w[2 * WLIST + x]);
+            const float re = __uint_as_float((unsigned)(u & 0xffffffffull)) * sc;
+            const float im = __uint_as_float((unsigned)(u >> 32)) * sc;
+            a.w[x] = ((unsigned long long)__float_as_uint(im) << 32) | __float_as_uint(re);
+        }
+        if (threadIdx.x < QMAX * 6) {   // the Nyquist lanes' table (the __syncthreads() below publishes it)
+            const unsigned long long u = a_in.w[WNYQ + threadIdx.x];
+            const float re = __uint_as_float((unsigned)(u & 0xffffffffull)) * sc;
+            const float im = __uint_as_float((unsigned)(u >> 32)) * sc;
+            reinterpret_cast<float2 *>(smem + WNYQ_OFF)[threadIdx.x] = make_float2(re, im);
+        }
+#else
 #pragma unroll
         for (int x = 0; x < NW; ++x) {
             const float re = __uint_as_float((unsigned)(a_in.w[x] & 0xffffffffull)) * sc;
             const float im = __uint_as_float((unsigned)(a_in.w[x] >> 32)) * sc;
-#if LWS_Q8
-            a.w[x] = ((unsigned long long)__float_as_uint(im) << 32) | __float_as_uint(re);
-#else
             a.w[x] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(im)) << 32) |
                      (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(re));
-#endif
         }
+#endif
     }
     // `wave` is the ROLE of a wave (sweep slot 0..NSLOTS-1, or NSLOTS = service), not its hardware index: hardware
     // waves w and w + 4 share a SIMD and the older one is served first.  Every sweep slot meets the service wave at every
@@ -1160,7 +1261,14 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     // and there are two service waves, one per half (roles 6 and 7: each loads and writes back its 64 lanes; the first one
     // also computes the Nyquist bins).
     const int hw_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // provably uniform
+#if LWS_Q8
+    // hardware waves w and w + 4 share a SIMD: main 0 | main 1 | helper 1 of slot 0 | helper 1 of slot 1 on SIMDs 0..3, then the
+    // (lighter) second helpers beside the mains and the service wave beside a first helper
+    static_assert(NSLOTS == 2 && NHELP == 2 && WPS == 1, "role table");   // (the weight lists above follow the same table)
+    const int wave = hw_wave < 2 ? hw_wave : (hw_wave == 2 ? 3 : (hw_wave == 3 ? 5 : (hw_wave == 4 ? 4 : (hw_wave == 5 ? 6 : 2))));
+#else
     const int wave = (LWS_ROLE_SWAP && NSLOTS == 7 && WPS == 1) ? (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave)) : hw_wave;
+#endif
     const int hf = wave % WPS;                     // which half of the ring row this wave's lanes are
     const int rl = hf * LANES + lane;              // the lane's place in the ring row = its frame within a round
     float *thr_eff = reinterpret_cast<float *>(smem + THR_OFF);
@@ -1185,6 +1293,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     }
     // poison-free start: rings may hold anything, but zero keeps the arithmetic of idle lanes finite
     for (int i = threadIdx.x; i < THR_OFF / 8; i += NTHREADS) reinterpret_cast<float2 *>(smem)[i] = make_float2(0.f, 0.f);
+    for (int i = threadIdx.x; i < MBOX_BYTES / 8; i += NTHREADS) reinterpret_cast<float2 *>(smem + MBOX_OFF)[i] = make_float2(0.f, 0.f);
     if (threadIdx.x < 16) reinterpret_cast<int *>(smem + DONE_OFF)[threadIdx.x] = T_START + 1;
     __syncthreads();
     const int n_eff = meta[0];
@@ -1232,8 +1341,10 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     };
 
     const bool is_compute = wave < NCOMPUTE;
-    const bool is_service = !is_compute;
-    const int slot = is_compute ? wave / WPS : NSLOTS;
+    const bool is_helper = NHELP > 0 && wave >= NCOMPUTE + WPS;
+    const bool is_service = !is_compute && !is_helper;
+    const int helper_no = is_helper ? (wave - NCOMPUTE - WPS) % (NHELP > 0 ? NHELP : 1) + 1 : 0;   // 1 .. NHELP
+    const int slot = is_compute ? wave / WPS : (is_helper ? (wave - NCOMPUTE - WPS) / (NHELP > 0 ? NHELP : 1) : NSLOTS);
     LaneCtx cx;
     Carry cr;
     cr.o0 = cr.o1 = cr.o2 = cr.prev_out = make_float2(0.f, 0.f);
@@ -1265,11 +1376,16 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     // output -- and both halves of the neighbouring slots and of the service.  The two service waves wait for each other as
     // well: the Nyquist lanes of the first one read, 25..29 steps back, entries of set 0 that the second one's loader
     // rewrites two pairs later, so neither may run a pair ahead of the other.)
+    // (Q = 8: a main wave also waits for the helpers of its slot -- their mailbox entries for this pair were written two pairs
+    // ago -- and a helper for the waves whose output it reads: the main waves of its slot and of the previous one, and the
+    // service wave.  Everybody is in the same pair at all times; a helper just works on data for two pairs later.)
     bool watched = false;
-    if (lane < NCOMPUTE + WPS) {
-        const int wslot = lane < NCOMPUTE ? lane / WPS : NSLOTS;     // the slot of wave `lane`
+    if (lane < NWAVES) {
+        const bool whelp = lane >= NCOMPUTE + WPS;
+        const int wslot = lane < NCOMPUTE ? lane / WPS : (whelp ? (lane - NCOMPUTE - WPS) / (NHELP > 0 ? NHELP : 1) : NSLOTS);   // the slot of wave `lane`
         if (is_service) watched = lane != wave;
-        else watched = (lane != wave) && (wslot == slot - 1 || wslot == slot || wslot == slot + 1 || wslot == NSLOTS);
+        else if (is_helper) watched = !whelp && (wslot == slot - 1 || wslot == slot || wslot == NSLOTS);
+        else watched = (lane != wave) && (whelp ? wslot == slot : (wslot == slot - 1 || wslot == slot || wslot == slot + 1 || wslot == NSLOTS));
     }
     // Where a lane is in a block of 8 steps (which frame of which sweep, first / last bins of the frame, active at
     // all): evaluated once per block for the FOLLOWING block and shifted.  The lanes of a wave sit in at most two
@@ -1313,141 +1429,175 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     BlockInfo nxt_bi = block_info(T_START - (slot + 1) * LAG);
     int vmod = __builtin_amdgcn_readfirstlane((((T_START - (slot + 1) * LAG) % G) + G) % G - 8);   // advanced at the loop head
     int tmod = __builtin_amdgcn_readfirstlane(((T_START % G) + G) % G - 8);
-    for (int t0 = T_START; t0 < t_end; t0 += 8) {
-        const int v0 = t0 - (slot + 1) * LAG;  // clock of this sweep slot at phase 0 of the block (multiple of 8)
-        // ---- block prologue: where is this lane in this block and in the next one?
-        const int ablk = (v0 >> 3);
-        {
-            const BlockInfo cur = nxt_bi;
-            nxt_bi = block_info(v0 + 8);
-            cx.live = cur.live; cx.is_start = cur.start; cx.is_end = cur.end; cx.thr = cur.thr;
-            cx.nxt_live = nxt_bi.live; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end;
-            cx.nxt_thr = nxt_bi.thr;
-        }
-        cx.lane8 = rl * 8;
-        cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + rl * 8;
-        cx.dummy = DUMMY_OFF + lane * 8;
-        cx.halo_shift = (rl < HALO) ? ROWL * LANE_B : (rl >= ROWL - HALO ? -ROWL * LANE_B : 0);
-#pragma unroll
-        for (int d = 0; d < NDR; ++d) {   // (only the entries of frames that exist, |DR| <= Q-1, are ever read)
-            cx.wlo[d] = cx.is_start ? dlo[d] : 0;
-            cx.whi[d] = cx.is_end ? dlo[d] + LANE_B : 0;   // PLR = PLL + 1
-            cx.wlo_nxt[d] = cx.nxt_start ? dlo[d] : 0;
-        }
-#pragma unroll
-        for (int m = 0; m < NBLK; ++m) {
-            const int blk = ((ablk - m) & (NBLK - 1)) * BLK_BYTES;
-            cx.uo[m] = set_old + blk;
-            cx.ob[m] = set_old + blk + rl * LANE_B;
-            cx.obh[m] = cx.ob[m] + cx.halo_shift;
-        }
-        {
-            const int nowhere = SCRATCH_OFF + lane * 8 - (SET_BYTES + PLL * LANE_B);
-            const int lo_row = cx.uo[ImageBlocks<L>::m_lo], hi_row = cx.uo[ImageBlocks<L>::m_hi] + LANE_B;   // PLR = PLL + 1
-            cx.img_lo = cx.is_start ? lo_row : nowhere;
-            cx.img_hi = cx.is_end ? hi_row : nowhere;
-            cx.img_both = cx.is_start ? lo_row : cx.img_hi;
-        }
-        vmod += 8; vmod -= (vmod >= G) ? G : 0;   // v0 mod G and t0 mod G (G is a multiple of 8), wave-uniform
-        tmod += 8; tmod -= (tmod >= G) ? G : 0;
-        if (is_compute) {
-            int vnext = vmod + 8;
-            vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
-#pragma unroll
-            for (int i = 0; i < 8; ++i) amp_cur[i] = raw_real<H16>(amp_nxt[i]);   // (fp16 storage: the conversion takes the place of the move)
-            // The loads are asm statements so that they land in amp_nxt's own registers and nobody waits for them here
-            // (written as plain loads the compiler fetches into temporaries and copies -- i.e. waits -- at once: a stall
-            // of one memory latency per block).  The waits are explicit: before amp_nxt[0] is first used (pair (7, 0'))
-            // and at the end of the block; these are the only vector-memory operations of a sweep slot.
-            const char *ap = static_cast<const char *>(amp_w_b) + ((size_t)vnext * ROWL + rl) * ST::RB;
-#define LWS_AMP_LOAD(i)                                                                                                             \
-    do {                                                                                                                            \
-        if constexpr (H16) asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * ROWL * 2) : "memory"); \
-        else asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * ROWL * 4) : "memory"); \
-    } while (0)
-            LWS_AMP_LOAD(0); LWS_AMP_LOAD(1); LWS_AMP_LOAD(2); LWS_AMP_LOAD(3);
-            LWS_AMP_LOAD(4); LWS_AMP_LOAD(5); LWS_AMP_LOAD(6); LWS_AMP_LOAD(7);
-#undef LWS_AMP_LOAD
-        }
-        // ---- 4 pairs of bins, phases static
-        static_for<4>([&](auto ip) {
-            constexpr int PA = 2 * decltype(ip)::value + 1;
-            flow_wait(lane, t0 + PA, watched);
-            if constexpr (PA == 7) { if (is_compute) asm volatile("s_waitcnt vmcnt(7)" : "+v"(amp_nxt[0]) : : "memory"); }   // in-order: the first of the 8
-            if (is_compute) compute_pair<Q, L, MASK, PA, H16>(a, cx, cr, amp_cur, amp_nxt, qc);
-            if (a.stress != 0 && ((a.stress >> wave) & 1) && PA == ((a.stress >> 16) & 7)) {   // test hook, see SysArgs
-                for (int q = 0; q < 10; ++q) __builtin_amdgcn_s_sleep(32);
+    // The step loop, per ROLE of the wave.  Q = 8 instantiates it once per role (main / helper 1 / helper 2 / service), so that
+    // a wave only carries the registers of its own duties (the union does not fit 256 VGPRs); the other builds run one loop
+    // with wave-uniform branches (ROLE < 0).
+    auto role_loop = [&](auto role_c) __attribute__((always_inline)) {
+        constexpr int ROLE = decltype(role_c)::value;
+        constexpr int R_SERVICE = 9;
+        const bool r_compute = ROLE < 0 ? is_compute : ROLE == 0;
+        const bool r_service = ROLE < 0 ? is_service : ROLE == R_SERVICE;
+        const bool r_helper = ROLE < 0 ? is_helper : (ROLE >= 1 && ROLE < R_SERVICE);
+        for (int t0 = T_START; t0 < t_end; t0 += 8) {
+            const int v0 = t0 - (slot + 1) * LAG;  // clock of this sweep slot at phase 0 of the block (multiple of 8)
+            // ---- block prologue: where is this lane in this block and in the next one?
+            const int ablk = (v0 >> 3);
+            {
+                const BlockInfo cur = nxt_bi;
+                nxt_bi = block_info(v0 + 8);
+                cx.live = cur.live; cx.is_start = cur.start; cx.is_end = cur.end; cx.thr = cur.thr;
+                cx.nxt_live = nxt_bi.live; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end;
+                cx.nxt_thr = nxt_bi.thr;
             }
-            if constexpr (PA == 1 && MULTI) {
-                if (is_service) {
-                    // every slot has finished the previous block (flow_wait above); this wave has written back what the last
-                    // slot produced up to 3 steps before that, and its Nyquist bins (program order + the wait below)
-                    const int done_rows = t0 - NSLOTS * LAG - 8;       // (the write-back below trails the last slot by 2..3 steps)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of the previous block
-                    if (done_rows > 0 && lane == 0)
-                        __hip_atomic_store(my_progress, (unsigned)done_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    wait_rows(t0 + 16 + 40);   // the loader fetches up to row t0 + 16 in this block, the Nyquist loader a frame ahead
-                }
+            cx.lane8 = rl * 8;
+            cx.nyq_base = NYQ_OFF + (slot + 1) * SLOT_BYTES + rl * 8;
+            cx.dummy = DUMMY_OFF + lane * 8;
+            cx.mbox = ((r_service ? 0 : slot) * NHELP * 4 * LANES + lane) * 16;
+            cx.halo_shift = (rl < HALO) ? ROWL * LANE_B : (rl >= ROWL - HALO ? -ROWL * LANE_B : 0);
+    #pragma unroll
+            for (int d = 0; d < NDR; ++d) {   // (only the entries of frames that exist, |DR| <= Q-1, are ever read)
+                cx.wlo[d] = cx.is_start ? dlo[d] : 0;
+                cx.whi[d] = cx.is_end ? dlo[d] + LANE_B : 0;   // PLR = PLL + 1
+                cx.wlo_nxt[d] = cx.nxt_start ? dlo[d] : 0;
             }
-            if (is_service) {
-                LWS_SETPRIO(3);   // (and back to 0 with everybody else after the publish below)
-                // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
-                if (PA == 1 && hf == 0)
-                    service_nyquist<Q, L, MASK, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
-                // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
-                // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
-                int ldb[NBLK], ldu[NBLK], ldh[NBLK];
-#pragma unroll
-                for (int m = 0; m < NBLK; ++m) {
-                    ldu[m] = (((t0 >> 3) - m) & (NBLK - 1)) * BLK_BYTES;
-                    ldb[m] = ldu[m] + rl * LANE_B;
-                    ldh[m] = ldb[m] + cx.halo_shift;
-                }
-                const int cb0 = (t0 - SKEW * rl) & (ROWP - 1), cb1 = (t0 + 8 - SKEW * rl) & (ROWP - 1);
-                const bool l_st = cb0 == 0, l_en = cb0 == C - 8, l_stn = cb1 == 0, l_enn = cb1 == C - 8;
-                const float2 vA = raw_value<H16>(make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]));
-                const float2 vB = raw_value<H16>(make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]));
-                ring_publish(ring_addr<PA, 0>(ldb), ring_addr<PA, 0>(ldh), vA);
-                image_publish<L, PA, PA, 0>(ldu, l_st, l_en, cx.dummy, vA);
-                ring_publish(ring_addr<PA + 1, 0>(ldb), ring_addr<PA + 1, 0>(ldh), vB);
-                image_publish<L, (PA + 1) & 7, PA + 1, 0>(ldu, PA == 7 ? l_stn : l_st, PA == 7 ? l_enn : l_en, cx.dummy, vB);
-                // write-back: the two values the last sweep slot produced at steps t0+PA-3 and t0+PA-2 (one ring cell of its
-                // output set; complete, every slot has finished the previous pair) go to the rows of its clock.  Done
-                // here, by the wave with time to spare, so that the sweep slots carry no store and no branch around one.
-                {
-                    if constexpr (PA == 1) {   // where the last slot's lanes are in this block of its clock
-                        wb_prev = wb_cur;
-                        const int vv = t0 - NSLOTS * LAG - SKEW * rl;
-                        const int kap = vv >> ROWP_SHIFT;
-                        const int gl = (int)(((float)kap + 0.5f) * inv_kr), k = kap - gl * Kr;
-                        wb_cur = (vv >= 0) && ((vv & (ROWP - 1)) < C) && (k * ROWL + rl < a.Tp) && (gl * nwg + wg < n_groups);
-                    }
-                    const v4f w = lds_read128(ring_addr<PA, -3>(ldb) + NSLOTS * SET_BYTES);
-                    int r0 = tmod + PA - 3 - NSLOTS * LAG;
-                    r0 += (r0 < 0) ? G : 0;
-                    r0 += (r0 < 0) ? G : 0;        // (G >= 512 > NSLOTS * LAG / 2)
-                    int r1 = r0 + 1;
-                    r1 -= (r1 >= G) ? G : 0;
-                    if (PA == 1 ? wb_prev : wb_cur) {
-                        store_l2<H16>(state_w_b, (size_t)r0 * ROWL + rl, make_float2(w.x, w.y), MULTI);
-                        store_l2<H16>(state_w_b, (size_t)r1 * ROWL + rl, make_float2(w.z, w.w), MULTI);
+    #pragma unroll
+            for (int m = 0; m < NBLK; ++m) {
+                const int blk = ((ablk - m) & (NBLK - 1)) * BLK_BYTES;
+                cx.uo[m] = set_old + blk;
+                cx.ob[m] = set_old + blk + rl * LANE_B;
+                cx.obh[m] = cx.ob[m] + cx.halo_shift;
+            }
+            {
+                const int nowhere = SCRATCH_OFF + lane * 8 - (SET_BYTES + PLL * LANE_B);
+                const int lo_row = cx.uo[ImageBlocks<L>::m_lo], hi_row = cx.uo[ImageBlocks<L>::m_hi] + LANE_B;   // PLR = PLL + 1
+                cx.img_lo = cx.is_start ? lo_row : nowhere;
+                cx.img_hi = cx.is_end ? hi_row : nowhere;
+                cx.img_both = cx.is_start ? lo_row : cx.img_hi;
+            }
+            vmod += 8; vmod -= (vmod >= G) ? G : 0;   // v0 mod G and t0 mod G (G is a multiple of 8), wave-uniform
+            tmod += 8; tmod -= (tmod >= G) ? G : 0;
+            if (r_compute) {
+                int vnext = vmod + 8;
+                vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) amp_cur[i] = raw_real<H16>(amp_nxt[i]);   // (fp16 storage: the conversion takes the place of the move)
+                // The loads are asm statements so that they land in amp_nxt's own registers and nobody waits for them here
+                // (written as plain loads the compiler fetches into temporaries and copies -- i.e. waits -- at once: a stall
+                // of one memory latency per block).  The waits are explicit: before amp_nxt[0] is first used (pair (7, 0'))
+                // and at the end of the block; these are the only vector-memory operations of a sweep slot.
+                const char *ap = static_cast<const char *>(amp_w_b) + ((size_t)vnext * ROWL + rl) * ST::RB;
+    #define LWS_AMP_LOAD(i)                                                                                                             \
+        do {                                                                                                                            \
+            if constexpr (H16) asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * ROWL * 2) : "memory"); \
+            else asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * ROWL * 4) : "memory"); \
+        } while (0)
+                LWS_AMP_LOAD(0); LWS_AMP_LOAD(1); LWS_AMP_LOAD(2); LWS_AMP_LOAD(3);
+                LWS_AMP_LOAD(4); LWS_AMP_LOAD(5); LWS_AMP_LOAD(6); LWS_AMP_LOAD(7);
+    #undef LWS_AMP_LOAD
+            }
+            // ---- 4 pairs of bins, phases static
+            static_for<4>([&](auto ip) {
+                constexpr int PA = 2 * decltype(ip)::value + 1;
+                flow_wait(lane, t0 + PA, watched);
+                if constexpr (PA == 7) { if (r_compute) asm volatile("s_waitcnt vmcnt(7)" : "+v"(amp_nxt[0]) : : "memory"); }   // in-order: the first of the 8
+                if (r_compute) compute_pair<Q, L, MASK, PA, H16>(a, cx, cr, amp_cur, amp_nxt, qc);
+                if constexpr (NHELP > 0) {
+                    if (r_helper) {
+                        if constexpr (PA == 5) {   // phases 1..4 of the lane's next block: that block's frame edges
+    #pragma unroll
+                            for (int d = 0; d < NDR; ++d) {
+                                cx.wlo[d] = cx.nxt_start ? dlo[d] : 0;
+                                cx.whi[d] = cx.nxt_end ? dlo[d] + LANE_B : 0;
+                            }
+                        }
+                        if constexpr (ROLE >= 1 && ROLE <= NHELP) helper_pair<Q, L, MASK, PA, ROLE>(a, cx, qc);
                     }
                 }
-                int i0 = tmod + PA + 8, i1 = tmod + PA + 9;
-                i0 -= (i0 >= G) ? G : 0;
-                i1 -= (i1 >= G) ? G : 0;
-                const float2 p0 = load_l2<H16>(state_w_b, (size_t)i0 * ROWL + rl);
-                const float2 p1 = load_l2<H16>(state_w_b, (size_t)i1 * ROWL + rl);
-                amp_cur[PA & 7] = p0.x; amp_nxt[PA & 7] = p0.y;
-                amp_cur[(PA + 1) & 7] = p1.x; amp_nxt[(PA + 1) & 7] = p1.y;
-            }
-            flow_publish(lane, wave, t0 + PA + 2);
-            LWS_SETPRIO(0);   // polling for the next pair must not take issue slots from the wave still working
-        });
-        if (is_compute)   // the next block's magnitudes (issued 4 pairs ago) are in their registers before anything may move them
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(amp_nxt[0]), "+v"(amp_nxt[1]), "+v"(amp_nxt[2]), "+v"(amp_nxt[3]),
-                         "+v"(amp_nxt[4]), "+v"(amp_nxt[5]), "+v"(amp_nxt[6]), "+v"(amp_nxt[7]) : : "memory");
-    }
+                if (a.stress != 0 && ((a.stress >> wave) & 1) && PA == ((a.stress >> 16) & 7)) {   // test hook, see SysArgs
+                    for (int q = 0; q < 10; ++q) __builtin_amdgcn_s_sleep(32);
+                }
+                if constexpr (PA == 1 && MULTI) {
+                    if (r_service) {
+                        // every slot has finished the previous block (flow_wait above); this wave has written back what the last
+                        // slot produced up to 3 steps before that, and its Nyquist bins (program order + the wait below)
+                        const int done_rows = t0 - NSLOTS * LAG - 8;       // (the write-back below trails the last slot by 2..3 steps)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of the previous block
+                        if (done_rows > 0 && lane == 0)
+                            __hip_atomic_store(my_progress, (unsigned)done_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        wait_rows(t0 + 16 + 40);   // the loader fetches up to row t0 + 16 in this block, the Nyquist loader a frame ahead
+                    }
+                }
+                if (r_service) {
+                    LWS_SETPRIO(3);   // (and back to 0 with everybody else after the publish below)
+                    // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
+                    if (PA == 1 && hf == 0)
+                        service_nyquist<Q, L, MASK, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+                    // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
+                    // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
+                    int ldb[NBLK], ldu[NBLK], ldh[NBLK];
+    #pragma unroll
+                    for (int m = 0; m < NBLK; ++m) {
+                        ldu[m] = (((t0 >> 3) - m) & (NBLK - 1)) * BLK_BYTES;
+                        ldb[m] = ldu[m] + rl * LANE_B;
+                        ldh[m] = ldb[m] + cx.halo_shift;
+                    }
+                    const int cb0 = (t0 - SKEW * rl) & (ROWP - 1), cb1 = (t0 + 8 - SKEW * rl) & (ROWP - 1);
+                    const bool l_st = cb0 == 0, l_en = cb0 == C - 8, l_stn = cb1 == 0, l_enn = cb1 == C - 8;
+                    const float2 vA = raw_value<H16>(make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]));
+                    const float2 vB = raw_value<H16>(make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]));
+                    ring_publish(ring_addr<PA, 0>(ldb), ring_addr<PA, 0>(ldh), vA);
+                    image_publish<L, PA, PA, 0>(ldu, l_st, l_en, cx.dummy, vA);
+                    ring_publish(ring_addr<PA + 1, 0>(ldb), ring_addr<PA + 1, 0>(ldh), vB);
+                    image_publish<L, (PA + 1) & 7, PA + 1, 0>(ldu, PA == 7 ? l_stn : l_st, PA == 7 ? l_enn : l_en, cx.dummy, vB);
+                    // write-back: the two values the last sweep slot produced at steps t0+PA-3 and t0+PA-2 (one ring cell of its
+                    // output set; complete, every slot has finished the previous pair) go to the rows of its clock.  Done
+                    // here, by the wave with time to spare, so that the sweep slots carry no store and no branch around one.
+                    {
+                        if constexpr (PA == 1) {   // where the last slot's lanes are in this block of its clock
+                            wb_prev = wb_cur;
+                            const int vv = t0 - NSLOTS * LAG - SKEW * rl;
+                            const int kap = vv >> ROWP_SHIFT;
+                            const int gl = (int)(((float)kap + 0.5f) * inv_kr), k = kap - gl * Kr;
+                            wb_cur = (vv >= 0) && ((vv & (ROWP - 1)) < C) && (k * ROWL + rl < a.Tp) && (gl * nwg + wg < n_groups);
+                        }
+                        const v4f w = lds_read128(ring_addr<PA, -3>(ldb) + NSLOTS * SET_BYTES);
+                        int r0 = tmod + PA - 3 - NSLOTS * LAG;
+                        r0 += (r0 < 0) ? G : 0;
+                        r0 += (r0 < 0) ? G : 0;        // (G >= 512 > NSLOTS * LAG / 2)
+                        int r1 = r0 + 1;
+                        r1 -= (r1 >= G) ? G : 0;
+                        if (PA == 1 ? wb_prev : wb_cur) {
+                            store_l2<H16>(state_w_b, (size_t)r0 * ROWL + rl, make_float2(w.x, w.y), MULTI);
+                            store_l2<H16>(state_w_b, (size_t)r1 * ROWL + rl, make_float2(w.z, w.w), MULTI);
+                        }
+                    }
+                    int i0 = tmod + PA + 8, i1 = tmod + PA + 9;
+                    i0 -= (i0 >= G) ? G : 0;
+                    i1 -= (i1 >= G) ? G : 0;
+                    const float2 p0 = load_l2<H16>(state_w_b, (size_t)i0 * ROWL + rl);
+                    const float2 p1 = load_l2<H16>(state_w_b, (size_t)i1 * ROWL + rl);
+                    amp_cur[PA & 7] = p0.x; amp_nxt[PA & 7] = p0.y;
+                    amp_cur[(PA + 1) & 7] = p1.x; amp_nxt[(PA + 1) & 7] = p1.y;
+                }
+                flow_publish(lane, wave, t0 + PA + 2);
+                LWS_SETPRIO(0);   // polling for the next pair must not take issue slots from the wave still working
+            });
+            if (r_compute)   // the next block's magnitudes (issued 4 pairs ago) are in their registers before anything may move them
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(amp_nxt[0]), "+v"(amp_nxt[1]), "+v"(amp_nxt[2]), "+v"(amp_nxt[3]),
+                             "+v"(amp_nxt[4]), "+v"(amp_nxt[5]), "+v"(amp_nxt[6]), "+v"(amp_nxt[7]) : : "memory");
+        }
+    };
+#if LWS_Q8
+    if (is_compute) role_loop(std::integral_constant<int, 0>{});
+    else if (is_helper && helper_no == 1) role_loop(std::integral_constant<int, 1>{});
+    else if (is_helper) role_loop(std::integral_constant<int, NHELP>{});
+    else role_loop(std::integral_constant<int, 9>{});
+#elif LWS_SPLIT_ROLES
+    if (is_compute) role_loop(std::integral_constant<int, 0>{});
+    else role_loop(std::integral_constant<int, 9>{});
+#else
+    role_loop(std::integral_constant<int, -1>{});
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1898,13 +2048,21 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
                 const double wr = W[i][2 * (r * K1 + k)], wi = W[i][2 * (r * K1 + k) + 1];
                 const bool on = std::hypot(wr, wi) > 1.0e-12;  // lws.pyx:231-232
                 if (on) tb->mask |= 1ull << (r * K1 + k);
+#if LWS_Q8
+                // per-wave lists (widx: position in the list of the wave that sums frames m-+r) and the full set 0 for the
+                // Nyquist lanes; second set: W[0][r][k] exp(j pi / 4), formed in fp64 and rounded once
+                const double h = std::sqrt(0.5);
+                const int x0 = row_owner(r) * WLIST + widx<8, 5>(0, r, k), xn = WNYQ + r * K1 + k;
+                tb->w[2 * x0] = tb->w[2 * xn] = on ? (float)wr : 0.f;
+                tb->w[2 * x0 + 1] = tb->w[2 * xn + 1] = on ? (float)wi : 0.f;
+                if (r & 1) {
+                    const int x1 = row_owner(r) * WLIST + widx<8, 5>(1, r, k);
+                    tb->w[2 * x1] = on ? (float)((wr - wi) * h) : 0.f;
+                    tb->w[2 * x1 + 1] = on ? (float)((wr + wi) * h) : 0.f;
+                }
+#else
                 tb->w[2 * (r * K1 + k)] = on ? (float)wr : 0.f;
                 tb->w[2 * (r * K1 + k) + 1] = on ? (float)wi : 0.f;
-#if LWS_Q8
-                // second set: W[0][r][k] exp(j pi / 4), formed in fp64 and rounded once
-                const double h = std::sqrt(0.5);
-                tb->w[2 * ((Q + r) * K1 + k)] = on ? (float)((wr - wi) * h) : 0.f;
-                tb->w[2 * ((Q + r) * K1 + k) + 1] = on ? (float)((wr + wi) * h) : 0.f;
 #endif
             }
         // structure of symmetric windows, checked on the fp64 weights well below fp32 resolution
@@ -2049,7 +2207,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         a.stress = es ? atoi(es) : 0;
     }
     for (int x = 0; x < NW; ++x) {
-        const bool used = x < (LWS_Q8 ? 2 : 1) * Q * (L + 1);
+        const bool used = LWS_Q8 || x < Q * (L + 1);
         const float re = used ? tb->w[2 * x] : 0.f, im = used ? tb->w[2 * x + 1] : 0.f;
         unsigned ur, ui;
         memcpy(&ur, &re, 4); memcpy(&ui, &im, 4);
