@@ -23,7 +23,8 @@ def report(out, ref, M):
             "mag": np.abs(np.abs(out) - M).max() / M.max()}
 
 
-@pytest.mark.parametrize("fsize,fshift,T", [(64, 16, 40), (128, 32, 130), (1024, 256, 70), (1024, 512, 65), (2048, 512, 50)])
+@pytest.mark.parametrize("fsize,fshift,T", [(64, 16, 40), (128, 32, 130), (1024, 256, 70), (1024, 512, 65), (2048, 512, 50),
+                                            (1024, 128, 40), (64, 8, 70)])
 def test_fp16_storage_structure_and_tolerance(oracle, fsize, fshift, T):
     """Complex (random-phase) input: well conditioned, so values can be compared one by one."""
     rng = np.random.default_rng(fsize + T)
@@ -43,7 +44,7 @@ def test_fp16_storage_structure_and_tolerance(oracle, fsize, fshift, T):
         r16, r32 = report(out16[b], ref, M), report(out32[b], ref, M)
         # magnitudes come from the caller's fp32 targets, not from the fp16 state: as exact as in fp32 storage
         assert r16["mag"] < 2e-6, r16
-        # 9 sweeps = 2 passes (narrow) or 3 (wide): the state was rounded to 11 bits that many times.  The typical bin
+        # 9 sweeps = 2 passes (narrow), 3 (wide) or 5 (Q = 8): the state was rounded to 11 bits that many times.  The typical bin
         # follows that rounding (median ~ 2^-11); bins whose weighted sum nearly cancels amplify it by 1/|sum| exactly as
         # they amplify fp32 rounding (the fp32 99.9th percentile times 2^13 saturates at the magnitude itself), so the
         # tails are bounded by energy, not pointwise

@@ -170,7 +170,7 @@ def test_wide_needs_a_multiple_of_8():
 # ----------------------------------------------------------------------------- several workgroups per spectrogram
 @pytest.mark.parametrize("fsize,fshift,B,T,iters", [(64, 16, 1, 200, 30), (64, 16, 3, 300, 50), (1024, 256, 2, 200, 30),
                                                     (1024, 256, 9, 300, 45), (1024, 512, 5, 260, 16),
-                                                    (2048, 512, 3, 150, 20)])
+                                                    (2048, 512, 3, 150, 20), (64, 8, 2, 300, 11), (1024, 128, 3, 200, 9)])
 def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, iters, monkeypatch):
     """When there are fewer spectrograms than CUs the passes over HBM are dealt to several workgroups per spectrogram
     that hand the skewed state to each other through HBM; the result must be bit-identical to one workgroup doing all
@@ -216,12 +216,13 @@ def test_workgroup_sharing_randomised(monkeypatch):
             assert np.array_equal(p.plan().batch(S, thr), ref), (trial, fs, sh, B, T, iters, nwg)
 
 
-@pytest.mark.parametrize("fsize,fshift,T", [(1024, 256, 150), (2048, 512, 150), (2048, 512, 100)])
+@pytest.mark.parametrize("fsize,fshift,T", [(1024, 256, 150), (2048, 512, 150), (2048, 512, 100), (1024, 128, 150), (64, 8, 70)])
 def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
     """The waves of a workgroup synchronise through progress counters in LDS, not barriers.  LWS_SYSTOLIC_STRESS stalls chosen
     waves (role mask) for ~10 us before a chosen pair of every block -- far longer than a pair takes -- so any read that is
     only 'usually' behind its write shows up: the results must not move by a bit, whichever wave lags, with one or several
-    workgroups per spectrogram.  (Found the missing service<->service wait of the two-waves-per-slot build.)"""
+    workgroups per spectrogram.  (Found the missing service<->service wait of the two-waves-per-slot build.)  Q = 8: roles 0, 1 =
+    main waves, 2 = service, 3..6 = the helper waves that sum frames m-+2..m-+6 four steps ahead."""
     rng = np.random.default_rng(T)
     F = fsize // 2 + 1
     S = np.abs(rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))).astype(np.complex128)
@@ -240,7 +241,8 @@ def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
 
 
 # ----------------------------------------------------------------------------- direct device I/O
-@pytest.mark.parametrize("fsize,fshift,B,T", [(64, 16, 3, 77), (1024, 256, 2, 130), (1024, 512, 2, 65), (2048, 512, 2, 40)])
+@pytest.mark.parametrize("fsize,fshift,B,T", [(64, 16, 3, 77), (1024, 256, 2, 130), (1024, 512, 2, 65), (2048, 512, 2, 40),
+                                              (1024, 128, 2, 70)])
 def test_direct_device_io_equals_the_padded_path(fsize, fshift, B, T):
     """A *_dev call that is one batch stage converts the caller's complex64 spectrograms straight to the kernel's
     layout and back.  Same sweeps on the same values: the result equals the path through the extended buffers bit for
