@@ -45,6 +45,8 @@ BATCH_CONFIGS = {
                     what="BASELINE config 2: %(B)d spectrograms/GPU x %(T)d frames x %(F)d bins, lws(1024,256) Q=4 L=5"),
     "2-T1024": dict(B=256, T=1024, fsize=1024, fshift=256, iters=100, storage="fp32",
                     what="north-star shape: %(B)d spectrograms/GPU of 1024 x 513, lws(1024,256) Q=4 L=5"),
+    "2-q8":    dict(B=256, T=500, fsize=1024, fshift=128, iters=100, storage="fp32",
+                    what="config 2's volume at hop 128 (Q = 8, the reference's LWSanyQ): %(B)d x %(T)d x %(F)d, lws(1024,128) L=5"),
     "4shard":  dict(B=1024, T=500, fsize=1024, fshift=256, iters=100, storage="fp32",
                     what="BASELINE config 4, one GPU's shard: %(B)d spectrograms x %(T)d x %(F)d, lws(1024,256)"),
     "5":       dict(B=64, T=56250, fsize=2048, fshift=512, iters=200, storage="fp32",
@@ -315,7 +317,7 @@ def main():
     elif args.extras is not None:
         wanted = [x for x in args.extras.split(",") if x]
     elif world == 1 and args.config == "2":
-        wanted = ["2-default", "2-single", "2-T1024", "4shard", "3", "5", "5-f16"]
+        wanted = ["2-default", "2-single", "2-T1024", "2-q8", "4shard", "3", "5", "5-f16"]
     else:
         wanted = ["4shard"] if args.config == "2" else []
     if args.no_default_schedule and "2-default" in wanted:
