@@ -353,7 +353,7 @@ struct LaneCtx {
     // image cells: byte offset from the lane's own origin ob[m] to the pseudo-lane's, minus what the compile-time offset
     // of the neighbour frame DR adds -- for the lane at the start (lo: PLL) / end (hi: PLR) of its frame; zero for every
     // other lane.  [DR + HALO]; lo_nxt: for the first bin of the following block (second bin of the pair (7, 0'))
-    int wlo[NDR], whi[NDR], wlo_nxt[NDR];
+    int wlo[NDR], whi[NDR];
     int mbox;                       // Q = 8: mailbox of the slot's first helper, pair 0 (own lane)
     int img_lo, img_hi, img_both;   // image_base(): row origin for the image stores of this block (phases with an image below DC / above
                                     // Nyquist / both)
@@ -465,61 +465,6 @@ template <int PH, int PB, int DR, int DK, int EDGE>
 __device__ __forceinline__ float2 tap_any(const LaneCtx &cx, float2 self_old, float2 next_old, float2 prev_out) {
     if constexpr (tap_in_lds<PH, DR, DK, EDGE>()) return tap_lds<PH, PB, DR, DK, EDGE>(cx);
     else return tap_reg<PH, DR, DK, EDGE>(self_old, next_old, prev_out);
-}
-
-// Taps of frame m+DR (DR != 0) for the TWO bins of a pair: bins cA-L .. cA+L+1 are 2L+2 consecutive production times
-// starting on an even one (PA and L are odd), i.e. exactly L+1 aligned 16-byte cells -- one ds_read_b128 each.
-// t[j] is the tap at bin cA - L + j: tap dk of bin A is t[dk+L], of bin B t[dk+L+1].  KMASK bit |dk|: tap used.
-// Cells are (even bin, odd bin) pairs, so a cell lies entirely inside the frame or entirely among its images; for
-// the one lane of a wave at the start (st) / end (en) of its frame the image cells come from the pseudo-lanes.
-// MODE 0: both bins in one frame.  The pair (7, 0') straddles two frames of the lane, and the same production times
-// hold the images above Nyquist of the old frame (pseudo-lane PLR) and the first bins of the new one (real lane):
-// MODE 1 fetches bin A's view (en = last bin of a frame), MODE 2 bin B's (st = first bin of a frame).
-// CO: clock of the block the pair belongs to, relative to the block `cx` addresses (0, or 8 for a helper wave working on the
-// next block)
-template <int PA, int DR, int L, uint32_t KMASK, int MODE, int CO = 0>
-__device__ __forceinline__ void load_row2(const LaneCtx &cx, float2 (&t)[2 * L + 2]) {
-    static_assert((PA & 1) == 1 && (L & 1) == 1, "pairs start on odd phases; L odd");
-    static_assert(MODE == 0 || PA == 7, "split views only for the pair that straddles two frames");
-    static_assert(MODE != 0 || PA != 7, "the straddling pair needs split views");
-    constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
-    constexpr int q_first = PA + CO + base_off - L;              // even
-    static_for<L + 1>([&](auto ip) {
-        constexpr int j = 2 * decltype(ip)::value;
-        constexpr int q = q_first + j;
-        constexpr auto used = [](int jj) {                        // is t[jj] needed by bin A (dk = jj-L) / bin B (dk = jj-L-1)?
-            const int da = jj - L, db = jj - L - 1;
-            const bool na = MODE != 2 && da >= -L && da <= L && ((KMASK >> (da < 0 ? -da : da)) & 1ull);
-            const bool nb = MODE != 1 && db >= -L && db <= L && ((KMASK >> (db < 0 ? -db : db)) & 1ull);
-            return na || nb;
-        };
-        constexpr bool need0 = used(j), need1 = used(j + 1);
-        // image cells of the edge lanes: below DC (frame start) / Nyquist and above (frame end)
-        constexpr bool img_lo = (MODE == 0) ? (j <= L - PA - 2) : (MODE == 2 ? (j <= L - 1) : false);
-        constexpr bool img_hi = (MODE == 0 || MODE == 1) ? (j >= 8 + L - PA) : false;
-        if constexpr (need0 || need1) {
-            static_assert(q >= -RING && q + 1 <= 15, "ring retention exceeded");
-            constexpr int fl = floor_div8(q);
-            constexpr int m = (-fl) & (NBLK - 1);
-            constexpr int within = q - 8 * fl;                   // even
-            constexpr int setoff = (DR < 0) ? SET_BYTES : 0;     // frames above: own sweep's set; below: previous sweep's
-            // one add per (frame, ring block) for the image cells: the lane's origin plus an offset that is zero except
-            // for the lane at the frame edge (LaneCtx::wlo / whi); everything else is the instruction's immediate offset
-            int base = cx.ob[m];
-            if constexpr (img_lo) base = cx.ob[m] + (MODE == 2 ? cx.wlo_nxt[DR + HALO] : cx.wlo[DR + HALO]);
-            if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + HALO];
-            const int addr = base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES;
-            if constexpr (need0 && need1) {
-                const v4f v = lds_read128(addr);
-                t[j] = make_float2(v.x, v.y);
-                t[j + 1] = make_float2(v.z, v.w);
-            } else if constexpr (need0) {
-                t[j] = lds_read(addr);
-            } else {
-                t[j + 1] = lds_read(addr + 8);
-            }
-        }
-    });
 }
 
 // Complex values travel as (re, im) register pairs (that is how ds_read_b128 delivers them), so sums and differences
@@ -767,7 +712,7 @@ constexpr uint64_t FLAG_R13 = 1ull << 63;     // Q = 4 and W[0][3][k] == j^k W[0
 template <int L> struct R13Partials { float2 b[L + 1], c[L + 1]; };
 
 // one group of taps (the four taps |dk| = K of frames m-R and m+R, or the two taps dk = 0) of the bin at phase PH;
-// the bin sits at index L + OFFS of the tap windows tu (frame m-R) / td (frame m+R)
+// the bin sits at index L + 1 + OFFS of the tap windows tu (frame m-R) / td (frame m+R), see load_cells
 template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int K, int N>
 __device__ __forceinline__ void rows_group(const SysArgs &a, const float2 (&tu)[N], const float2 (&td)[N],
                                            R13Partials<L> &p3, float2 &accr) {
@@ -775,19 +720,19 @@ __device__ __forceinline__ void rows_group(const SysArgs &a, const float2 (&tu)[
     constexpr int mod = PH % Q;
     constexpr int e8 = eighths<Q>(mod, R), rot = e8 >> 1, odd = e8 & 1;  // exp(2j*pi*mod*R/Q) = j^rot (e^{j pi/4})^odd
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
-    static_assert(L + OFFS + K < N, "tap window too short");
+    static_assert(L + 1 + OFFS + K < N, "tap window too short");
     // accr: the bin's running sum (every group of taps is added to it directly: no partial sums to zero and combine)
     if constexpr (((MASK >> (R * K1 + K)) & 1ull) == 0) {
         return;
     } else if constexpr (K == 0) {
-        if constexpr ((MASK & FLAG_K0REAL) != 0 && !odd) pair_rot_real<rot>(accr, a.w[widx<Q, L>(0, R, 0)], tu[L + OFFS], td[L + OFFS]);
-        else pair_rot<rot>(accr, a.w[widx<Q, L>(odd, R, 0)], tu[L + OFFS], td[L + OFFS]);
+        if constexpr ((MASK & FLAG_K0REAL) != 0 && !odd) pair_rot_real<rot>(accr, a.w[widx<Q, L>(0, R, 0)], tu[L + 1 + OFFS], td[L + 1 + OFFS]);
+        else pair_rot<rot>(accr, a.w[widx<Q, L>(odd, R, 0)], tu[L + 1 + OFFS], td[L + 1 + OFFS]);
     } else {
         constexpr int k = K;
         // W[mod]*S[m-r,c-k] + conj(W[mod])*S[m+r,c-k] + W[-mod]*S[m+r,c+k] + conj(W[-mod])*S[m-r,c+k]
         // with W[-mod] = +-W[mod] for a real / imaginary twiddle (the LWSQ2 / LWSQ4 grouping)
         const wp_t w = a.w[widx<Q, L>(odd, R, k)];
-        const float2 um = tu[L - k + OFFS], up = tu[L + k + OFFS], dm = td[L - k + OFFS], dp = td[L + k + OFFS];
+        const float2 um = tu[L + 1 - k + OFFS], up = tu[L + 1 + k + OFFS], dm = td[L + 1 - k + OFFS], dp = td[L + 1 + k + OFFS];
         if constexpr (!(r13 && (R == 1 || R == 3) && k >= 2)) {
             quad_rot<rot, odd>(accr, w, um, up, dm, dp);
         } else if constexpr (R == 3) {
@@ -799,32 +744,31 @@ __device__ __forceinline__ void rows_group(const SysArgs &a, const float2 (&tu)[
         }
     }
 }
-// Contribution of frames m-R and m+R to the bin at phase PH; OFFS = 0 / 1: first / second bin of the pair
+// Contribution of frames m-R and m+R to the bin at phase PH; OFFS = 0 .. 3: which bin of the quad
 template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int N>
 __device__ __forceinline__ void rows_sum(const SysArgs &a, const float2 (&tu)[N], const float2 (&td)[N],
                                          R13Partials<L> &p3, float2 &accr) {
     static_for<L + 1>([&](auto ik) { rows_group<Q, L, MASK, PH, R, OFFS, decltype(ik)::value>(a, tu, td, p3, accr); });
 }
 
-// ---- two pairs of bins from one set of tap windows: the pairs (1,2) + (3,4) of a block, and (5,6) + bin 7 ----------------
-// The taps of the pair (3,4) are those of the pair (1,2) moved up by one 16-byte cell: 7 cells per neighbour frame cover
-// both pairs where two separate fetches take 12.  The first pair therefore also sums the neighbour-frame taps of the
-// second pair's bins (the sums do not depend on anything the first pair produces) and hands them over in registers.
-// Two frames cannot deliver their seventh cell yet when the first pair starts -- frame m-1 (its bins are 8 steps ahead
-// of this lane's: the cell holds what it produces during this very pair) and frame m+3 (previous sweep, 32 - 24 steps
-// ahead).  Exactly three tap groups of frames m-+1 / m-+3 touch those cells: (first bin, k = L), (second bin, k = L-1),
-// (second bin, k = L).  Their other operands are handed over as well and the second pair finishes them after fetching
-// the two cells.  (Bin 0' after bin 7 belongs to the lane's next frame -- other images at the frame edge -- and keeps
-// its own fetches.)
+// ---- two pairs of bins from one set of tap windows: the quads (0,1) + (2,3) and (4,5) + (6,7) of a block ------------------
+// Pairs start on even bins, so a pair never straddles two frames of a lane (a block of 8 bins lies in one frame) and a ring
+// cell -- (even time, odd time) -- holds the two outputs of one pair.  The taps the four bins PA0 .. PA0+3 need from a
+// neighbour frame are the bins PA0-L .. PA0+3+L: L+3 cells, of the first and the last of which one half is used (8-byte
+// reads).  The first pair of a quad therefore also sums the neighbour-frame taps of the second pair's bins (the sums do not
+// depend on anything the first pair produces) and hands them over in registers.
+// Two frames cannot deliver their last (half) cell yet when the first pair starts -- frame m-1 (its bins are 8 steps ahead
+// of this lane's: the cell holds what it produces during this very pair) and frame m+LATE_DN (previous sweep, LAG - 8 LATE_DN
+// = 8 steps ahead).  One tap group of each touches it: (fourth bin, k = L).  Its other operands are handed over as well and
+// the second pair finishes it after fetching the half cell.  (L = 3: nothing is late.)
 template <int L> struct QuadCarry {
     float2 accA, accB;                               // neighbour-frame sums of the second pair's bins so far
-    float2 um1[3], dm1[3], dp1[3], um3[3], c3[3];    // the three unfinished groups: operands of r13_rot() that are known
-    float2 g[QMAX][3][4];                            // kernels without FLAG_R13: [R][group] the operands (um, up, dm, dp) of quad_rot()
+    float2 um1, dm1, dp1, um3, c3;                   // the unfinished group with FLAG_R13: the operands of r13_rot() that are known
+    float2 g[QMAX][4];                               // kernels without FLAG_R13: [R] the operands (um, up, dm, dp) of quad_rot()
 };
-// (with the 16-step skew of the wide build every frame is far enough ahead: nothing is late there)
-template <int DR> __host__ __device__ constexpr bool quad_late_frame() { return SKEW * DR - (DR > 0 ? LAG : 0) > -10; }
-template <int OFFS, int K, int L> __host__ __device__ constexpr bool quad_deferred() { return L + OFFS + K >= 2 * L + 2; }
-template <int OFFS, int K, int L> __host__ __device__ constexpr int quad_slot() { return OFFS == 2 ? 0 : (K == L - 1 ? 1 : 2); }
+// time of the last half cell of the window of frame m+DR, relative to the start of the quad's first pair: not produced yet?
+template <int DR, int L> __host__ __device__ constexpr bool quad_late_frame() { return SKEW * DR - (DR > 0 ? LAG : 0) + L + 3 >= 0; }
+template <int OFFS, int K, int L> __host__ __device__ constexpr bool quad_deferred() { return OFFS == 3 && K == L; }
 
 // neighbour-frame taps of a bin of the SECOND pair (OFFS = 2, 3), summed during the first pair
 template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int N>
@@ -835,67 +779,70 @@ __device__ __forceinline__ void rows_sum_ahead(const SysArgs &a, const float2 (&
     static_for<L + 1>([&](auto ik) {
         constexpr int k = decltype(ik)::value;
         constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
-        constexpr bool late = quad_deferred<OFFS, k, L>() && (quad_late_frame<-R>() || quad_late_frame<R>());
+        constexpr bool late = quad_deferred<OFFS, k, L>() && (quad_late_frame<-R, L>() || quad_late_frame<R, L>());
+        constexpr int c = L + 1 + OFFS;               // the bin's place in the windows
         if constexpr (!late) {
             rows_group<Q, L, MASK, PH, R, OFFS, k>(a, tu, td, p3, accr);
         } else if constexpr (((MASK >> (R * K1 + k)) & 1ull) == 0) {
         } else if constexpr (!r13) {          // the late operand is filled in by the second pair (quad_finish_plain)
-            constexpr int i = quad_slot<OFFS, k, L>();
-            qc.g[R][i][0] = tu[L - k + OFFS];
-            if constexpr (!quad_late_frame<-R>()) qc.g[R][i][1] = tu[L + k + OFFS];
-            qc.g[R][i][2] = td[L - k + OFFS];
-            if constexpr (!quad_late_frame<R>()) qc.g[R][i][3] = td[L + k + OFFS];
+            qc.g[R][0] = tu[c - k];
+            if constexpr (!quad_late_frame<-R, L>()) qc.g[R][1] = tu[c + k];
+            qc.g[R][2] = td[c - k];
+            if constexpr (!quad_late_frame<R, L>()) qc.g[R][3] = td[c + k];
         } else {
             static_assert(k >= 2 && (R == 1 || R == 3), "only the shared-weight groups reach the late cells");
-            constexpr int i = quad_slot<OFFS, k, L>();
             if constexpr (R == 3) {          // frame m+3's tap at +k is late: keep um3 and c3 = dm3 +- up3
-                qc.um3[i] = tu[L - k + OFFS];
-                if constexpr ((rot & 1) == 0) qc.c3[i] = cadd(td[L - k + OFFS], tu[L + k + OFFS]);
-                else qc.c3[i] = csub(td[L - k + OFFS], tu[L + k + OFFS]);
+                qc.um3 = tu[c - k];
+                if constexpr ((rot & 1) == 0) qc.c3 = cadd(td[c - k], tu[c + k]);
+                else qc.c3 = csub(td[c - k], tu[c + k]);
             } else {                          // frame m-1's tap at +k is late: keep the other three
-                qc.um1[i] = tu[L - k + OFFS];
-                qc.dm1[i] = td[L - k + OFFS];
-                qc.dp1[i] = td[L + k + OFFS];
+                qc.um1 = tu[c - k];
+                qc.dm1 = td[c - k];
+                qc.dp1 = td[c + k];
             }
         }
     });
 }
-// an unfinished group of a kernel without FLAG_R13: `late` is the tap that was not there yet (frame m-R's or m+R's, at +K)
-template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int K>
+// the unfinished group of a kernel without FLAG_R13: `late` is the tap that was not there yet (frame m-R's or m+R's, at +L)
+template <int Q, int L, uint64_t MASK, int PH, int R>
 __device__ __forceinline__ void quad_finish_plain(const SysArgs &a, const QuadCarry<L> &qc, float2 late, float2 &accr) {
     constexpr int K1 = L + 1;
     constexpr int e8 = eighths<Q>(PH % Q, R), rot = e8 >> 1, odd = e8 & 1;
-    constexpr int i = quad_slot<OFFS, K, L>();
-    if constexpr ((MASK >> (R * K1 + K)) & 1ull)
-        quad_rot<rot, odd>(accr, a.w[widx<Q, L>(odd, R, K)], qc.g[R][i][0], quad_late_frame<-R>() ? late : qc.g[R][i][1], qc.g[R][i][2],
-                      quad_late_frame<R>() ? late : qc.g[R][i][3]);
+    if constexpr ((MASK >> (R * K1 + L)) & 1ull)
+        quad_rot<rot, odd>(accr, a.w[widx<Q, L>(odd, R, L)], qc.g[R][0], quad_late_frame<-R, L>() ? late : qc.g[R][1], qc.g[R][2],
+                           quad_late_frame<R, L>() ? late : qc.g[R][3]);
 }
-// the three unfinished groups, by the second pair: up1 = frame m-1's late tap, dp3 = frame m+3's
-template <int Q, int L, uint64_t MASK, int PH, int OFFS, int K>
+// the unfinished group with FLAG_R13, by the second pair: up1 = frame m-1's late tap, dp3 = frame m+3's
+template <int Q, int L, uint64_t MASK, int PH>
 __device__ __forceinline__ void quad_finish(const SysArgs &a, const QuadCarry<L> &qc, float2 up1, float2 dp3, float2 &accr) {
     constexpr int K1 = L + 1, mod = PH % Q;
     constexpr int rot1 = eighths<Q>(mod, 1) >> 1, rot3 = eighths<Q>(mod, 3) >> 1;
-    constexpr int i = quad_slot<OFFS, K, L>();
-    if constexpr ((MASK >> (1 * K1 + K)) & 1ull) {
+    if constexpr ((MASK >> (1 * K1 + L)) & 1ull) {
         float2 b3;
-        if constexpr ((rot3 & 1) == 0) b3 = cadd(qc.um3[i], dp3);
-        else b3 = csub(qc.um3[i], dp3);
-        r13_rot<rot1, (K + rot3 - rot1 + 8) & 3>(accr, a.w[1 * K1 + K], qc.um1[i], up1, qc.dm1[i], qc.dp1[i], b3, qc.c3[i]);
+        if constexpr ((rot3 & 1) == 0) b3 = cadd(qc.um3, dp3);
+        else b3 = csub(qc.um3, dp3);
+        r13_rot<rot1, (L + rot3 - rot1 + 8) & 3>(accr, a.w[1 * K1 + L], qc.um1, up1, qc.dm1, qc.dp1, b3, qc.c3);
     }
 }
 
-// NC consecutive cells of the taps of frame m+DR, starting at bin (PA - L): t[j] is the tap at block-relative bin PA - L + j.
-// Images of the edge lanes as in load_row2 (both bins of each cell lie in the same frame as the pair: no split views).
-template <int PA, int DR, int L, int C0, int NC, int CO = 0, int N = 0>
+// Cells C0 .. C0+NC-1 of the taps frame m+DR contributes to the quad that starts at phase PA0 (0 or 4): t[j] is the tap at
+// block-relative bin PA0 - L - 1 + j, so bin PA0 + OFFS sits at t[L + 1 + OFFS] and cell i = (t[2i], t[2i+1]) is one aligned
+// 16-byte ring cell (even time, odd time).  The window is t[1] .. t[2L+4]: of cells 0 and L+2 only one half is read.
+// Cells are (even bin, odd bin) pairs, so a cell lies entirely inside the frame or entirely among its images; for the one
+// lane of a wave at the start / end of its frame the image cells come from the pseudo-lanes (LaneCtx::wlo / whi).
+// CO: clock of the block the quad belongs to, relative to the block `cx` addresses (0, or 8 for a helper wave working on the
+// next block)
+template <int PA0, int DR, int L, int C0, int NC, int CO = 0, int N = 0>
 __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
-    static_assert((PA & 1) == 1 && (L & 1) == 1 && 2 * (C0 + NC) <= N, "cell window");
+    static_assert((PA0 & 3) == 0 && (L & 1) == 1 && C0 + NC <= L + 3 && N >= 2 * L + 5, "cell window");
     constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
-    constexpr int q_first = PA + CO + base_off - L;              // even
+    constexpr int q_first = PA0 + CO + base_off - L - 1;         // even
     static_for<NC>([&](auto ip) {
-        constexpr int j = 2 * (C0 + decltype(ip)::value);
+        constexpr int i = C0 + decltype(ip)::value, j = 2 * i;
         constexpr int q = q_first + j;
         static_assert(q >= -RING && q + 1 <= 15, "ring retention exceeded");
-        constexpr bool img_lo = (PA - L + j + 1 < 0), img_hi = (PA - L + j >= 8);
+        constexpr int b = PA0 - L - 1 + j;                       // the cell's even bin
+        constexpr bool img_lo = (b + 1 < 0), img_hi = (b >= 8);
         constexpr int fl = floor_div8(q);
         constexpr int m = (-fl) & (NBLK - 1);
         constexpr int within = q - 8 * fl;                       // even
@@ -903,9 +850,16 @@ __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
         int base = cx.ob[m];
         if constexpr (img_lo) base = cx.ob[m] + cx.wlo[DR + HALO];
         if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + HALO];
-        const v4f v = lds_read128(base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES);
-        t[j] = make_float2(v.x, v.y);
-        t[j + 1] = make_float2(v.z, v.w);
+        const int addr = base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES;
+        if constexpr (i == 0) {
+            t[1] = lds_read(addr + 8);
+        } else if constexpr (i == L + 2) {
+            t[2 * L + 4] = lds_read(addr);
+        } else {
+            const v4f v = lds_read128(addr);
+            t[j] = make_float2(v.x, v.y);
+            t[j + 1] = make_float2(v.z, v.w);
+        }
     });
 }
 
@@ -922,31 +876,33 @@ __device__ __forceinline__ float2 project(float2 acc, float target, bool active,
     return ok ? make_float2(acc.x * sc, acc.y * sc) : old;
 }
 
-// Registers a compute lane carries from pair to pair: the previous sweep's values of its next bins and its last output.
-struct Carry { float2 o0, o1, o2, prev_out; };
+// Registers a compute lane carries from pair to pair: the previous sweep's values of its next four bins and its last output.
+struct Carry { float2 o0, o1, o2, o3, prev_out; };
 
-// One pair of bins (phases PA odd, PA+1) of one lane.
+#define LWS_SETPRIO(n) asm volatile("s_setprio " #n)
+__device__ __forceinline__ void lds_write128(int addr, float2 p, float2 q) {
+    using lds_v4w = volatile __attribute__((address_space(3))) v4f;
+    *(lds_v4w *)(unsigned)addr = (v4f){p.x, p.y, q.x, q.y};
+}
+
+// One pair of bins (phases PA even, PA+1) of one lane.
 template <int Q, int L, uint64_t MASK, int PA, bool H16>
 __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx, Carry &cr, const float (&amp_cur)[8],
-                                             const float (&amp_nxt)[8], QuadCarry<L> &qc) {
-    constexpr int K1 = L + 1;
-    constexpr int PHB = (PA + 1) & 7, PBB = PA + 1;          // second bin: phase and clock relative to this block
-    constexpr bool wrap = (PA == 7);                         // the second bin belongs to the next block
-    const bool stA = cx.is_start, enA = cx.is_end;
-    const bool stB = wrap ? cx.nxt_start : cx.is_start, enB = wrap ? cx.nxt_end : cx.is_end;
-    // previous-sweep values of the own bins of the NEXT pair (ages 29 and 28 now, 31 and 30 by then)
-    // (clocks PA+3 and PA+4 share a 16-byte cell: one conflict-free ds_read_b128 instead of two 8-byte reads)
-    static_assert(((PA + 3 - LAG) & 1) == 0, "cell alignment of the carried values");
-    const v4f o34 = lds_read128(ring_addr<PA, 3 - LAG>(cx.ob));
-    const float2 o3 = make_float2(o34.x, o34.y), o4 = make_float2(o34.z, o34.w);
+                                             QuadCarry<L> &qc) {
+    static_assert((PA & 1) == 0, "pairs start on even bins");
+    constexpr int PHB = PA + 1;                              // second bin
+    constexpr int PA0 = PA & ~2;                             // first phase of the quad
+    constexpr bool quad_first = (PA & 2) == 0;
+    const bool st = cx.is_start, en = cx.is_end;
+    // previous-sweep values of the own bins of the pair after the next one (ages LAG-4 and LAG-5 now): one ring cell
+    const v4f o45 = lds_read128(ring_addr<PA, 4 - LAG>(cx.ob));
     // Issue priority (s_setprio; the SIMD serves the higher priority first, the older wave among equals).  The two sweep
     // slots of a SIMD run the same pair at the same time and every pair ends in a rendez-vous, so what counts is when
     // the LATER of the two publishes.  Left alone, the older wave wins every issue slot, finishes early and waits while
     // the younger one runs the second half of its pair alone at single-wave pace.  Raising the priority for the tail of
-    // the pair (the serial part: last taps, two projections, the publishes) and lowering it for the bulk in between lets
+    // the pair (the serial part: last taps, two projections, the publish) and lowering it for the bulk in between lets
     // whichever wave is in its tail go first and the two leapfrog through the bulk: 41.8 -> 39.7 ms.  The service wave,
     // which every slot meets at every pair, stays above all of them.
-#define LWS_SETPRIO(n) asm volatile("s_setprio " #n)
     LWS_SETPRIO(1);
     float2 accA = make_float2(0.f, 0.f);
     float2 accB = make_float2(0.f, 0.f);
@@ -957,149 +913,103 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             accB = cadd(accB, make_float2(mb.z, mb.w));
         });
     }
-    centre_sum<L, MASK, PA, PA>(a, cx, stA, enA, cr.o0, cr.o1, cr.prev_out, accA);
+    centre_sum<L, MASK, PA, PA>(a, cx, st, en, cr.o0, cr.o1, cr.prev_out, accA);
     // frame pairs m-+R.  With FLAG_R13 rows 3 leave partial sums for rows 1: order 2, 3, 1 keeps them short-lived.
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
-    // (1,2)+(3,4) in full; (5,6)+(7,0') for bin 7 only: bin 0' belongs to the lane's next frame and keeps its own fetches
-    constexpr bool quad_first = (PA == 1 || PA == 5), quad_second = (PA == 3 || PA == 7);
-    R13Partials<L> p3A, p3B;
     if constexpr (quad_first) {
-        // this pair and the neighbour-frame sums of the next one, from 7-cell windows (rows_sum_ahead)
-        R13Partials<L> p3C, p3D;
+        // this pair and the neighbour-frame sums of the next one, from one set of windows (rows_sum_ahead)
+        R13Partials<L> p3A, p3B, p3C, p3D;
         qc.accA = make_float2(0.f, 0.f);
         qc.accB = make_float2(0.f, 0.f);
         static_for<Q - 1>([&](auto ir) {
             constexpr int i = decltype(ir)::value;
             constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
             if constexpr (row_owner(R) == 0) {   // (else: summed by a helper wave, in accA / accB already)
-            float2 tu[2 * L + 4], td[2 * L + 4];
-            static_assert(quad_late_frame<-1>() && quad_late_frame<LATE_DN>() && !quad_late_frame<-2>() && !quad_late_frame<LATE_DN - 1>() &&
-                          !quad_late_frame<1>() && !quad_late_frame<-LATE_DN>(), "which frames are late");
-            load_cells<PA, -R, L, 0, (quad_late_frame<-R>() ? L + 1 : L + 2)>(cx, tu);    // frame m-1 cannot deliver its seventh cell yet,
-            load_cells<PA, R, L, 0, (quad_late_frame<R>() ? L + 1 : L + 2)>(cx, td);      // nor can frame m+3
-            rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
-            rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
-            rows_sum_ahead<Q, L, MASK, PA + 2, R, 2>(a, tu, td, p3C, qc.accA, qc);
-            if constexpr (PA == 1) rows_sum_ahead<Q, L, MASK, PA + 3, R, 3>(a, tu, td, p3D, qc.accB, qc);
-            if constexpr (i == 0) LWS_SETPRIO(0);
-            if constexpr (i == Q - 2) LWS_SETPRIO(2);
+                float2 tu[2 * L + 6], td[2 * L + 6];
+                static_assert(quad_late_frame<-1, L>() == quad_late_frame<LATE_DN, L>() && !quad_late_frame<-2, L>() &&
+                              !quad_late_frame<LATE_DN - 1, L>() && !quad_late_frame<1, L>() && !quad_late_frame<-LATE_DN, L>(),
+                              "which frames are late");
+                load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3)>(cx, tu);   // frame m-1 cannot deliver its last half cell yet,
+                load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3)>(cx, td);     // nor can frame m+LATE_DN
+                rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
+                rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
+                rows_sum_ahead<Q, L, MASK, PA + 2, R, 2>(a, tu, td, p3C, qc.accA, qc);
+                rows_sum_ahead<Q, L, MASK, PA + 3, R, 3>(a, tu, td, p3D, qc.accB, qc);
+                if constexpr (i == 0) LWS_SETPRIO(0);
+                if constexpr (i == Q - 2) LWS_SETPRIO(2);
             }
         });
-    } else if constexpr (quad_second) {
-        // the sums came with the previous pair; two cells were not there yet: finish the three groups that need them
-        float2 u1[2 * L + 4], d3[2 * L + 4];
+    } else {
+        // the sums came with the previous pair; one half cell of two frames was not there yet: finish the group that needs it
         accA = cadd(accA, qc.accA);
-        if constexpr (quad_late_frame<-1>()) {
-            load_cells<PA - 2, -1, L, L + 1, 1>(cx, u1);
-            if constexpr (Q > LATE_DN) load_cells<PA - 2, LATE_DN, L, L + 1, 1>(cx, d3);
+        accB = cadd(accB, qc.accB);
+        if constexpr (quad_late_frame<-1, L>()) {
+            float2 u1[2 * L + 6], d3[2 * L + 6];
+            load_cells<PA0, -1, L, L + 2, 1>(cx, u1);
+            if constexpr (Q > LATE_DN) load_cells<PA0, LATE_DN, L, L + 2, 1>(cx, d3);
             if constexpr (r13) {
-                quad_finish<Q, L, MASK, PA, 2, L>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accA);
+                quad_finish<Q, L, MASK, PHB>(a, qc, u1[2 * L + 4], d3[2 * L + 4], accB);
             } else {
-                quad_finish_plain<Q, L, MASK, PA, 1, 2, L>(a, qc, u1[2 * L + 2], accA);
-                if constexpr (Q > LATE_DN) quad_finish_plain<Q, L, MASK, PA, LATE_DN, 2, L>(a, qc, d3[2 * L + 2], accA);
+                quad_finish_plain<Q, L, MASK, PHB, 1>(a, qc, u1[2 * L + 4], accB);
+                if constexpr (Q > LATE_DN) quad_finish_plain<Q, L, MASK, PHB, LATE_DN>(a, qc, d3[2 * L + 4], accB);
             }
-        }
-        if constexpr (PA == 3) {
-            if constexpr (NHELP > 0) accB = cadd(accB, qc.accB);   // (on top of the helpers' sums)
-            else accB = qc.accB;
-            if constexpr (quad_late_frame<-1>()) {
-                if constexpr (r13) {
-                    quad_finish<Q, L, MASK, PHB, 3, L - 1>(a, qc, u1[2 * L + 2], d3[2 * L + 2], accB);
-                    quad_finish<Q, L, MASK, PHB, 3, L>(a, qc, u1[2 * L + 3], d3[2 * L + 3], accB);
-                } else {
-                    quad_finish_plain<Q, L, MASK, PHB, 1, 3, L - 1>(a, qc, u1[2 * L + 2], accB);
-                    quad_finish_plain<Q, L, MASK, PHB, 1, 3, L>(a, qc, u1[2 * L + 3], accB);
-                    if constexpr (Q > LATE_DN) {
-                        quad_finish_plain<Q, L, MASK, PHB, LATE_DN, 3, L - 1>(a, qc, d3[2 * L + 2], accB);
-                        quad_finish_plain<Q, L, MASK, PHB, LATE_DN, 3, L>(a, qc, d3[2 * L + 3], accB);
-                    }
-                }
-            }
-        } else {
-            // bin 0' of the lane's next frame: its own view of the taps (images below DC for the lane that starts a frame)
-            static_for<Q - 1>([&](auto ir) {
-                constexpr int i = decltype(ir)::value;
-                constexpr int R = r13 ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i + 1;
-                if constexpr (row_owner(R) == 0) {
-                constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
-                float2 tu[2 * L + 2], td[2 * L + 2];
-                load_row2<PA, -R, L, kmask, 2>(cx, tu);
-                load_row2<PA, R, L, kmask, 2>(cx, td);
-                rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
-                if constexpr (i == 0) LWS_SETPRIO(0);
-                }
-            });
         }
         LWS_SETPRIO(2);
     }
-    static_assert(quad_first || quad_second, "every pair is half of a quad");
     // ---- first bin
     const float tA = amp_cur[PA];
     const float2 outA = project(accA, tA, cx.live && (tA > cx.thr), cr.o0);
-    ring_publish(ring_addr<PA, 0, 0, 1>(cx.ob), ring_addr<PA, 0, 0, 1>(cx.obh), outA);
     image_store<L, PA, 1>(cx.img_lo, cx.img_hi, cx.img_both, outA);
     // ---- second bin (its centre taps include the first bin's result)
-    centre_sum<L, MASK, PHB, PBB>(a, cx, stB, enB, cr.o1, cr.o2, outA, accB);
-    const float tB = wrap ? raw_real<H16>(amp_nxt[0]) : amp_cur[PBB & 7];   // (amp_nxt holds what the loads delivered: raw bits)
-    const bool liveB = wrap ? cx.nxt_live : cx.live;
-    const float2 outB = project(accB, tB, liveB && (tB > (wrap ? cx.nxt_thr : cx.thr)), cr.o1);
-    ring_publish(ring_addr<PBB, 0, 0, 1>(cx.ob), ring_addr<PBB, 0, 0, 1>(cx.obh), outB);
-    image_store<L, PHB, 1>(cx.img_lo, cx.img_hi, cx.img_both, outB);   // (phase 0 has no image: the flags of this block apply to every store)
+    centre_sum<L, MASK, PHB, PHB>(a, cx, st, en, cr.o1, cr.o2, outA, accB);
+    const float tB = amp_cur[PHB];
+    const float2 outB = project(accB, tB, cx.live && (tB > cx.thr), cr.o1);
+    // both outputs are one ring cell: nobody reads either before the pair is complete (the second bin took the first one's from
+    // its register)
+    lds_write128(ring_addr<PA, 0, 0, 1>(cx.ob), outA, outB);
+    lds_write128(ring_addr<PA, 0, 0, 1>(cx.obh), outA, outB);   // the halo copy of the first / last HALO lanes; every other lane writes its own entry twice
+    image_store<L, PHB, 1>(cx.img_lo, cx.img_hi, cx.img_both, outB);
     cr.prev_out = outB;
     cr.o0 = cr.o2;
-    cr.o1 = o3;
-    cr.o2 = o4;
+    cr.o1 = cr.o3;
+    cr.o2 = make_float2(o45.x, o45.y);
+    cr.o3 = make_float2(o45.z, o45.w);
 }
 
 // Q = 8: one pair of bins of a HELPER lane (helper H of its slot): the taps of the neighbour frames row_owner() gives it,
-// for the pair the slot's main wave reaches HELP_AHEAD steps from now; phases (5,6), (7,0'), then (1,2), (3,4) of the lane's
+// for the pair the slot's main wave reaches HELP_AHEAD steps from now; phases (4,5), (6,7), then (0,1), (2,3) of the lane's
 // next block.  Same windows, same order of operations per frame pair as compute_pair; no frame of a helper is late.
 template <int Q, int L, uint64_t MASK, int PA, int H>
 __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx, QuadCarry<L> &qc) {
-    constexpr int K1 = L + 1;
     constexpr int PH = (PA + HELP_AHEAD) & 7, CO = PA + HELP_AHEAD - PH;   // phase of the first bin; clock of its block
-    constexpr int PHB = (PH + 1) & 7;
-    static_assert(HELP_AHEAD == 4 && (CO == 0 || CO == 8), "half a block ahead");
+    constexpr int PH0 = PH & ~2;
+    static_assert(HELP_AHEAD == 4 && (CO == 0 || CO == 8) && (PH & 1) == 0, "half a block ahead");
     float2 accA = make_float2(0.f, 0.f), accB = make_float2(0.f, 0.f);
-    R13Partials<L> p3;   // (unused: no shared-weight rows here)
-    if constexpr (PH == 1 || PH == 5) {
+    if constexpr ((PH & 2) == 0) {
+        R13Partials<L> p3;   // (unused: no shared-weight rows here)
         qc.accA = make_float2(0.f, 0.f);
         qc.accB = make_float2(0.f, 0.f);
         static_for<Q - 1>([&](auto ir) {
             constexpr int R = decltype(ir)::value + 1;
             if constexpr (row_owner(R) == H) {
-            static_assert(!quad_late_frame<-R>() && !quad_late_frame<R>(), "late frames stay with the main wave");
-            // two steps ahead of the pair (rows_sum_ahead) and HELP_AHEAD ahead of the main wave: the newest tap fetched is
-            // still 2 steps old
-            static_assert(SKEW * R - L - 3 - HELP_AHEAD >= 2 && LAG - SKEW * R - L - 3 - HELP_AHEAD >= 2, "helper runs too far ahead");
-            float2 tu[2 * L + 4], td[2 * L + 4];
-            load_cells<PH, -R, L, 0, L + 2, CO>(cx, tu);
-            load_cells<PH, R, L, 0, L + 2, CO>(cx, td);
-            rows_sum<Q, L, MASK, PH, R, 0>(a, tu, td, p3, accA);
-            rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3, accB);
-            rows_sum_ahead<Q, L, MASK, PH + 2, R, 2>(a, tu, td, p3, qc.accA, qc);
-            if constexpr (PH == 1) rows_sum_ahead<Q, L, MASK, PH + 3, R, 3>(a, tu, td, p3, qc.accB, qc);
+                static_assert(!quad_late_frame<-R, L>() && !quad_late_frame<R, L>(), "late frames stay with the main wave");
+                // two steps ahead of the second pair (rows_sum_ahead) and HELP_AHEAD ahead of the main wave: the newest tap
+                // fetched (fourth bin, +L) must have been produced before this pair started
+                static_assert(SKEW * R - L - 3 - HELP_AHEAD >= 1 && LAG - SKEW * R - L - 3 - HELP_AHEAD >= 1, "helper runs too far ahead");
+                float2 tu[2 * L + 6], td[2 * L + 6];
+                load_cells<PH0, -R, L, 0, L + 3, CO>(cx, tu);
+                load_cells<PH0, R, L, 0, L + 3, CO>(cx, td);
+                rows_sum<Q, L, MASK, PH, R, 0>(a, tu, td, p3, accA);
+                rows_sum<Q, L, MASK, PH + 1, R, 1>(a, tu, td, p3, accB);
+                rows_sum_ahead<Q, L, MASK, PH + 2, R, 2>(a, tu, td, p3, qc.accA, qc);
+                rows_sum_ahead<Q, L, MASK, PH + 3, R, 3>(a, tu, td, p3, qc.accB, qc);
             }
         });
     } else {
         accA = qc.accA;
-        if constexpr (PH == 3) {
-            accB = qc.accB;
-        } else {   // bin 0' of the lane's next frame: its own view of the taps
-            static_for<Q - 1>([&](auto ir) {
-                constexpr int R = decltype(ir)::value + 1;
-                if constexpr (row_owner(R) == H) {
-                constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
-                float2 tu[2 * L + 2], td[2 * L + 2];
-                load_row2<PH, -R, L, kmask, 2, CO>(cx, tu);
-                load_row2<PH, R, L, kmask, 2, CO>(cx, td);
-                rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3, accB);
-                }
-            });
-        }
+        accB = qc.accB;
     }
-    using lds_v4w = volatile __attribute__((address_space(3))) v4f;
-    *(lds_v4w *)(unsigned)(cx.mbox + mbox_addr(0, H, (PA + HELP_AHEAD) >> 1)) = (v4f){accA.x, accA.y, accB.x, accB.y};
+    lds_write128(cx.mbox + mbox_addr(0, H, (PA + HELP_AHEAD) >> 1), accA, accB);
 }
 
 // weight W[0][r][k] (x = r (L+1) + k) for the Nyquist lanes: bin F-1 is a multiple of Q, every twiddle is 1
@@ -1279,7 +1189,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const void *amp_w_b = static_cast<const char *>(a.amp_w) + (size_t)b * G * ROWL * ST::RB;
     void *state_nyq_b = static_cast<char *>(a.state_nyq) + (size_t)b * a.TpPad * ST::CB;
     const void *amp_nyq_b = static_cast<const char *>(a.amp_nyq) + (size_t)b * a.TpPad * ST::RB;
-    constexpr int T_START = -8;   // one block of warm-up: the pair (7, 0') of block -1 produces clock 0
+    constexpr int T_START = -8;   // one block of warm-up
 
     // sweeps whose threshold is not below the largest magnitude cannot change anything: drop them
     if (threadIdx.x == 0) {
@@ -1294,7 +1204,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     // poison-free start: rings may hold anything, but zero keeps the arithmetic of idle lanes finite
     for (int i = threadIdx.x; i < THR_OFF / 8; i += NTHREADS) reinterpret_cast<float2 *>(smem)[i] = make_float2(0.f, 0.f);
     for (int i = threadIdx.x; i < MBOX_BYTES / 8; i += NTHREADS) reinterpret_cast<float2 *>(smem + MBOX_OFF)[i] = make_float2(0.f, 0.f);
-    if (threadIdx.x < 16) reinterpret_cast<int *>(smem + DONE_OFF)[threadIdx.x] = T_START + 1;
+    if (threadIdx.x < 16) reinterpret_cast<int *>(smem + DONE_OFF)[threadIdx.x] = T_START;
     __syncthreads();
     const int n_eff = meta[0];
     if (n_eff == 0) return;
@@ -1347,7 +1257,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const int slot = is_compute ? wave / WPS : (is_helper ? (wave - NCOMPUTE - WPS) / (NHELP > 0 ? NHELP : 1) : NSLOTS);
     LaneCtx cx;
     Carry cr;
-    cr.o0 = cr.o1 = cr.o2 = cr.prev_out = make_float2(0.f, 0.f);
+    cr.o0 = cr.o1 = cr.o2 = cr.o3 = cr.prev_out = make_float2(0.f, 0.f);
     // target magnitudes of the current block's 8 bins and (in flight) of the next block's: all 8 global loads of a
     // block are issued together one block ahead, so no step ever waits on HBM latency
     // (a wave is either a sweep slot or the service wave: the 16 registers below hold amp_cur[8] | amp_nxt[8] for the
@@ -1458,7 +1368,6 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             for (int d = 0; d < NDR; ++d) {   // (only the entries of frames that exist, |DR| <= Q-1, are ever read)
                 cx.wlo[d] = cx.is_start ? dlo[d] : 0;
                 cx.whi[d] = cx.is_end ? dlo[d] + LANE_B : 0;   // PLR = PLL + 1
-                cx.wlo_nxt[d] = cx.nxt_start ? dlo[d] : 0;
             }
     #pragma unroll
             for (int m = 0; m < NBLK; ++m) {
@@ -1483,8 +1392,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 for (int i = 0; i < 8; ++i) amp_cur[i] = raw_real<H16>(amp_nxt[i]);   // (fp16 storage: the conversion takes the place of the move)
                 // The loads are asm statements so that they land in amp_nxt's own registers and nobody waits for them here
                 // (written as plain loads the compiler fetches into temporaries and copies -- i.e. waits -- at once: a stall
-                // of one memory latency per block).  The waits are explicit: before amp_nxt[0] is first used (pair (7, 0'))
-                // and at the end of the block; these are the only vector-memory operations of a sweep slot.
+                // of one memory latency per block).  The wait is explicit, at the end of the block; these are the only
+                // vector-memory operations of a sweep slot.
                 const char *ap = static_cast<const char *>(amp_w_b) + ((size_t)vnext * ROWL + rl) * ST::RB;
     #define LWS_AMP_LOAD(i)                                                                                                             \
         do {                                                                                                                            \
@@ -1497,13 +1406,12 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             }
             // ---- 4 pairs of bins, phases static
             static_for<4>([&](auto ip) {
-                constexpr int PA = 2 * decltype(ip)::value + 1;
+                constexpr int PA = 2 * decltype(ip)::value;
                 flow_wait(lane, t0 + PA, watched);
-                if constexpr (PA == 7) { if (r_compute) asm volatile("s_waitcnt vmcnt(7)" : "+v"(amp_nxt[0]) : : "memory"); }   // in-order: the first of the 8
-                if (r_compute) compute_pair<Q, L, MASK, PA, H16>(a, cx, cr, amp_cur, amp_nxt, qc);
+                if (r_compute) compute_pair<Q, L, MASK, PA, H16>(a, cx, cr, amp_cur, qc);
                 if constexpr (NHELP > 0) {
                     if (r_helper) {
-                        if constexpr (PA == 5) {   // phases 1..4 of the lane's next block: that block's frame edges
+                        if constexpr (PA == 8 - HELP_AHEAD) {   // phases 0..3 of the lane's next block: that block's frame edges
     #pragma unroll
                             for (int d = 0; d < NDR; ++d) {
                                 cx.wlo[d] = cx.nxt_start ? dlo[d] : 0;
@@ -1513,14 +1421,14 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                         if constexpr (ROLE >= 1 && ROLE <= NHELP) helper_pair<Q, L, MASK, PA, ROLE>(a, cx, qc);
                     }
                 }
-                if (a.stress != 0 && ((a.stress >> wave) & 1) && PA == ((a.stress >> 16) & 7)) {   // test hook, see SysArgs
+                if (a.stress != 0 && ((a.stress >> wave) & 1) && PA + 1 == ((a.stress >> 16) & 7)) {   // test hook, see SysArgs (pairs 1, 3, 5, 7)
                     for (int q = 0; q < 10; ++q) __builtin_amdgcn_s_sleep(32);
                 }
-                if constexpr (PA == 1 && MULTI) {
+                if constexpr (PA == 0 && MULTI) {
                     if (r_service) {
                         // every slot has finished the previous block (flow_wait above); this wave has written back what the last
-                        // slot produced up to 3 steps before that, and its Nyquist bins (program order + the wait below)
-                        const int done_rows = t0 - NSLOTS * LAG - 8;       // (the write-back below trails the last slot by 2..3 steps)
+                        // slot produced up to 4 steps before that, and its Nyquist bins (program order + the wait below)
+                        const int done_rows = t0 - NSLOTS * LAG - 8;       // (the write-back below trails the last slot by one pair)
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of the previous block
                         if (done_rows > 0 && lane == 0)
                             __hip_atomic_store(my_progress, (unsigned)done_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1530,7 +1438,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 if (r_service) {
                     LWS_SETPRIO(3);   // (and back to 0 with everybody else after the publish below)
                     // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
-                    if (PA == 1 && hf == 0)
+                    if (PA == 0 && hf == 0)
                         service_nyquist<Q, L, MASK, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
                     // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
                     // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
@@ -1541,32 +1449,32 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                         ldb[m] = ldu[m] + rl * LANE_B;
                         ldh[m] = ldb[m] + cx.halo_shift;
                     }
-                    const int cb0 = (t0 - SKEW * rl) & (ROWP - 1), cb1 = (t0 + 8 - SKEW * rl) & (ROWP - 1);
-                    const bool l_st = cb0 == 0, l_en = cb0 == C - 8, l_stn = cb1 == 0, l_enn = cb1 == C - 8;
-                    const float2 vA = raw_value<H16>(make_float2(amp_cur[PA & 7], amp_nxt[PA & 7]));
-                    const float2 vB = raw_value<H16>(make_float2(amp_cur[(PA + 1) & 7], amp_nxt[(PA + 1) & 7]));
-                    ring_publish(ring_addr<PA, 0>(ldb), ring_addr<PA, 0>(ldh), vA);
+                    const int cb0 = (t0 - SKEW * rl) & (ROWP - 1);
+                    const bool l_st = cb0 == 0, l_en = cb0 == C - 8;
+                    const float2 vA = raw_value<H16>(make_float2(amp_cur[PA], amp_nxt[PA]));
+                    const float2 vB = raw_value<H16>(make_float2(amp_cur[PA + 1], amp_nxt[PA + 1]));
+                    lds_write128(ring_addr<PA, 0>(ldb), vA, vB);   // one ring cell
+                    lds_write128(ring_addr<PA, 0>(ldh), vA, vB);   // (halo copy, or the same cell again)
                     image_publish<L, PA, PA, 0>(ldu, l_st, l_en, cx.dummy, vA);
-                    ring_publish(ring_addr<PA + 1, 0>(ldb), ring_addr<PA + 1, 0>(ldh), vB);
-                    image_publish<L, (PA + 1) & 7, PA + 1, 0>(ldu, PA == 7 ? l_stn : l_st, PA == 7 ? l_enn : l_en, cx.dummy, vB);
-                    // write-back: the two values the last sweep slot produced at steps t0+PA-3 and t0+PA-2 (one ring cell of its
-                    // output set; complete, every slot has finished the previous pair) go to the rows of its clock.  Done
+                    image_publish<L, PA + 1, PA + 1, 0>(ldu, l_st, l_en, cx.dummy, vB);
+                    // write-back: the two values the last sweep slot produced in the previous pair, steps t0+PA-2 and t0+PA-1 (one
+                    // ring cell of its output set; complete, every slot has finished that pair) go to the rows of its clock.  Done
                     // here, by the wave with time to spare, so that the sweep slots carry no store and no branch around one.
                     {
-                        if constexpr (PA == 1) {   // where the last slot's lanes are in this block of its clock
+                        if constexpr (PA == 0) {   // where the last slot's lanes are in this block of its clock
                             wb_prev = wb_cur;
                             const int vv = t0 - NSLOTS * LAG - SKEW * rl;
                             const int kap = vv >> ROWP_SHIFT;
                             const int gl = (int)(((float)kap + 0.5f) * inv_kr), k = kap - gl * Kr;
                             wb_cur = (vv >= 0) && ((vv & (ROWP - 1)) < C) && (k * ROWL + rl < a.Tp) && (gl * nwg + wg < n_groups);
                         }
-                        const v4f w = lds_read128(ring_addr<PA, -3>(ldb) + NSLOTS * SET_BYTES);
-                        int r0 = tmod + PA - 3 - NSLOTS * LAG;
+                        const v4f w = lds_read128(ring_addr<PA, -2>(ldb) + NSLOTS * SET_BYTES);
+                        int r0 = tmod + PA - 2 - NSLOTS * LAG;
                         r0 += (r0 < 0) ? G : 0;
                         r0 += (r0 < 0) ? G : 0;        // (G >= 512 > NSLOTS * LAG / 2)
                         int r1 = r0 + 1;
                         r1 -= (r1 >= G) ? G : 0;
-                        if (PA == 1 ? wb_prev : wb_cur) {
+                        if (PA == 0 ? wb_prev : wb_cur) {
                             store_l2<H16>(state_w_b, (size_t)r0 * ROWL + rl, make_float2(w.x, w.y), MULTI);
                             store_l2<H16>(state_w_b, (size_t)r1 * ROWL + rl, make_float2(w.z, w.w), MULTI);
                         }
@@ -1576,8 +1484,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                     i1 -= (i1 >= G) ? G : 0;
                     const float2 p0 = load_l2<H16>(state_w_b, (size_t)i0 * ROWL + rl);
                     const float2 p1 = load_l2<H16>(state_w_b, (size_t)i1 * ROWL + rl);
-                    amp_cur[PA & 7] = p0.x; amp_nxt[PA & 7] = p0.y;
-                    amp_cur[(PA + 1) & 7] = p1.x; amp_nxt[(PA + 1) & 7] = p1.y;
+                    amp_cur[PA] = p0.x; amp_nxt[PA] = p0.y;
+                    amp_cur[PA + 1] = p1.x; amp_nxt[PA + 1] = p1.y;
                 }
                 flow_publish(lane, wave, t0 + PA + 2);
                 LWS_SETPRIO(0);   // polling for the next pair must not take issue slots from the wave still working
