@@ -126,8 +126,8 @@ def test_fp32_wrappers_vs_oracle(tag, force_generic, oracle):
     plan = _capi.Plan(F, W, W_ai, W_af, force_generic=force_generic)
     check_fp32(plan.batch(S, thr), g[f"batch_{tag}"], mean)
     name = plan.last_kernel()["name"]
-    # Q in {2,4} with create_weights' structure and F-1 a multiple of 8 -> systolic kernel unless forced
-    assert name.startswith("systolic") == ((not force_generic) and tag in ("64_16", "64_32")), name
+    # Q in {2,4,8} with create_weights' structure and F-1 a multiple of 8 -> systolic kernel unless forced
+    assert name.startswith("systolic") == ((not force_generic) and tag in ("64_16", "64_32", "64_8")), name
     check_fp32(plan.nofuture(S, thr[:2], wsel=_capi.LWS_W_AI), g[f"nofuture_{tag}"], mean)
     check_fp32(plan.online(S, thr[:3], 3, 2 * (F - 1) / fshift), g[f"online_{tag}"], mean)
     plan.close()
