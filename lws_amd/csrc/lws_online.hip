@@ -41,11 +41,20 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace lws {
 namespace {
 
 constexpr int NW = 16;  // frames in the LDS ring
+
+template <int... Is, typename F_>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F_ &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N_, typename F_> __device__ __forceinline__ void static_for(F_ &&f) {
+    static_for_impl(std::make_integer_sequence<int, N_>{}, static_cast<F_ &&>(f));
+}
 
 struct OnlineArgs {
     float2 *state;       // [B][Tp][Np]
@@ -361,6 +370,377 @@ __global__ void __launch_bounds__(MAXT) k_online(OnlineArgs a) {
     }
 }
 
+// =====================================================================================================================
+// Third layout (k_online3): one WAVE per tap group, one lane per (sweep slot, frame position).
+//
+// In the layout above every wave carries the whole dependent tail of a step -- cross-lane reduction, two re-projections,
+// the image upkeep -- for one lane in 2Q: ~2/3 of the instructions a step issues.  Here wave w < 2Q-1 sums the taps of ONE
+// frame offset (wave 0: the centre frame, waves 2r-1 / 2r: frames rho-r / rho+r) for all 64 (slot, position) units at once
+// and leaves the two partial sums of a unit in LDS; the last wave adds them up, re-projects and writes.  The tap waves work
+// ONE STEP AHEAD of it (double-buffered partial sums, one barrier per step), so the tail of step t overlaps the sums of step
+// t+1.  That is order-exact because the values a tap wave reads one step early are final already -- every writer is at
+// least L + 3 bins away from a window (2 DS >= SKB Q + 2 is required here) -- with three exceptions, which the tap waves
+// leave out (zero window slots) and the last wave adds itself:
+//   * frame rho-1 is SKB = L + 3 bins ahead: the last column of its window (bin c+1, tap +L) is being written;
+//   * the centre frame's own recent outputs: columns c-2, c-1 (previous step), c (this step's first bin, read by the
+//     second) and the Hermitian images of those three bins near the frame edges.  The centre wave reloads its window from
+//     LDS every step (the unit's own writes land inside it), minus those columns.
+// SERIAL (verification): the last wave sums every tap itself, from LDS, in the generic engine's order; same schedule.
+template <int Q, int L, bool SERIAL>
+__global__ void __launch_bounds__(2 * Q * 64) k_online3(OnlineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K1 = L + 1, WN = 2 * L + 2, NTW = 2 * Q - 1;                  // NTW tap waves, then the projection wave
+    constexpr int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2;
+    static_assert(SKB >= L + 3, "the tap waves run one step ahead");
+    const int DS = a.DS;
+    const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, Np = F + 2 * L, Tp = T + 2 * (Q - 1), N = F - 1;
+    const int NU = (F + 1) / 2;
+    const int rps = LA + 1, per = a.n_thr + 1;
+    const int nsweeps = T * per;
+    float4 *P = reinterpret_cast<float4 *>(smem);                               // [2][NTW][64]: (sum of bin c, of bin c+1)
+    float2 *S = reinterpret_cast<float2 *>(P + 2 * NTW * 64);                   // [NW][Np] (+ 2)
+    float *A = reinterpret_cast<float *>(S + (size_t)NW * Np + 2);              // [NW][Np]
+    float2 *W = reinterpret_cast<float2 *>(A + (size_t)NW * Np + ((NW * Np) & 1));   // [3][Q][Q][K1]
+    float2 *TW = W + 3 * Q * Q * K1;                                            // [Q]
+    float *thr_s = reinterpret_cast<float *>(TW + Q);                           // [n_thr]
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    float2 *gS = a.state + (size_t)b * Tp * Np;
+    const float *gA = a.amp + (size_t)b * Tp * Np;
+
+    for (int i = tid; i < 3 * Q * Q * K1; i += nthr) {
+        const int x = i % (Q * Q * K1);
+        W[i] = (x % (Q * K1) == 0) ? make_float2(0.f, 0.f) : a.w[i / (Q * Q * K1)][x];
+    }
+    if (tid < Q) TW[tid] = a.tw[tid];
+    for (int i = tid; i < NW * Np + 2; i += nthr) S[i] = make_float2(0.f, 0.f);
+    for (int i = tid; i < 2 * NTW * 64; i += nthr) P[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int i = tid; i < a.n_thr; i += nthr) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
+    int loaded = Q < T + Q - 1 ? Q : T + Q - 1;
+    for (int i = tid; i < loaded * Np; i += nthr) { S[i] = gS[i]; A[i] = gA[i]; }
+
+    // this lane's unit: frame position j of sweep slot sigma; this wave's tap group: frame offset r, side h
+    const int sigma = lane / rps, j = lane - sigma * rps;
+    const bool lane_used = sigma < NSW;
+    const bool is_proj = wave == NTW;
+    const int r = (wave + 1) >> 1, h = (wave == 0) ? 0 : ((wave + 1) & 1);
+    int s = sigma;
+    int rho = 0, tstart = 0, t_done = 0, ts = 1, wset = 0;
+    int fb = 0, ctb = 0, fbm1 = 0;
+    bool valid = false, centre = false;
+    float thr = 0.f;
+    v2f w0[K1];                         // tap waves: W[wset][0][r][k] (side 0) or its conjugate (side 1)
+    v2f twg[Q];                         // tap waves: gain * exp(2 pi j row r / Q) (conjugated on side 1), row = bin % Q
+    v2f wc[K1];                         // projection wave: centre weights W[wset][0][0][k] (zero if the centre frame takes no part)
+    v2f wlate = {0.f, 0.f};             // ... and conj W[wset][0][1][L]
+    auto setup = [&]() {
+        const int m = s / per, q = s - m * per;
+        const int first = m - LA > 0 ? m - LA : 0;
+        if (q == 0) { valid = (j == 0); rho = m; wset = 1; centre = false; ts = 1; thr = 0.f; }
+        else {
+            rho = first + j; valid = rho <= m; wset = (rho == m) ? 2 : 0; centre = true;
+            ts = m - rho + 1; if (ts > Q) ts = Q;
+            thr = thr_s[q - 1];
+        }
+        valid = valid && lane_used && s < nsweeps;
+        tstart = DS * s + SKS * rho;
+        t_done = DS * s + SKS * m + NU - 1;
+        const int e = rho + Q - 1;
+        fb = ((h ? e + r : e - r) & (NW - 1)) * Np;
+        ctb = (e & (NW - 1)) * Np;
+        fbm1 = ((e - 1) & (NW - 1)) * Np;
+        const float2 *wb = W + (wset * Q + 0) * Q * K1;
+        if (is_proj) {
+#pragma unroll
+            for (int k = 0; k <= L; ++k) wc[k] = centre ? as_v2f(wb[k]) : (v2f){0.f, 0.f};
+            const float2 wl_ = wb[1 * K1 + L];
+            wlate = (v2f){wl_.x, -wl_.y};
+        } else {
+            float gain;
+            if (h == 0) gain = (r == 0) ? (centre ? 1.f : 0.f) : 1.f;
+            else gain = (r != 0 && r < ts) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k <= L; ++k) {
+                const float2 w = wb[r * K1 + k];
+                w0[k] = (v2f){w.x, h ? -w.y : w.y};
+            }
+#pragma unroll
+            for (int row = 0; row < Q; ++row) {
+                const float2 tw = TW[(row * r) & (Q - 1)];
+                twg[row] = (v2f){gain * tw.x, gain * (h ? -tw.y : tw.y)};
+            }
+        }
+    };
+    __syncthreads();
+    setup();
+
+    const int t_end = DS * (nsweeps - 1) + SKS * (T - 1) + NU;
+    int next_need = (loaded - (Q - 1)) * (DS * per + SKS);
+    // bring in the next frame before the iteration in which a tap wave first touches it (the step after next)
+    auto load_frames = [&](int t) {
+        while (loaded < T + Q - 1 && next_need <= t + 2) {
+            const int slot = (loaded & (NW - 1)) * Np;
+            const bool evict = loaded >= NW;
+            for (int i = tid; i < Np; i += nthr) {
+                if (evict) gS[(size_t)(loaded - NW) * Np + i] = S[slot + i];
+                S[slot + i] = gS[(size_t)loaded * Np + i];
+                A[slot + i] = gA[(size_t)loaded * Np + i];
+            }
+            ++loaded;
+            next_need += DS * per + SKS;
+        }
+    };
+
+    // the sums of one step of a tap wave; KIND 0: frames rho-+r; 1: frame rho-1 (the last column of its window is still being
+    // written: left out); 2: the centre frame (its unit's own recent outputs are left out)
+    auto tap_loop = [&](auto kind_c) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind_c)::value;
+        for (int t = -1; t < t_end; ++t) {
+            const int tt = t + 1;               // the step these waves prepare
+            const int u = tt - tstart;
+            if (!SERIAL && valid && u >= 0 && u < NU) {
+                const int c = 2 * u;
+                // the window, columns c-L .. c+L+1 of this wave's frame, fresh from LDS (whatever is written concurrently is
+                // among the columns left out)
+                const float2 *src = S + fb + c;
+                v2f wl[WN];
+#pragma unroll
+                for (int i = 0; i < WN; ++i) {
+                    const bool skip = (KIND == 1 && i == WN - 1) || (KIND == 2 && i >= L - 2 && i <= L);
+                    wl[i] = skip ? (v2f){0.f, 0.f} : as_v2f(src[i]);
+                }
+                if constexpr (KIND == 2) {
+                    // images of the bins y = c-d (d = 0, 1, 2) inside the window: column -y (1 <= y) at slot L - 2c + d, column
+                    // 2N - y (N-L <= y <= N-1) at slot L + 2(N-c) + d -- a handful of (step, slot) pairs, spelled out
+                    const int g = N - c;
+                    if (2 * c <= L + 2 || 2 * g <= L + 1) {
+                        static_for<(L + 2) / 4 + 1>([&](auto iu) {
+                            constexpr int U = decltype(iu)::value, C = 2 * U;
+                            static_for<3>([&](auto id) {
+                                constexpr int D = decltype(id)::value, I = L - 2 * C + D;
+                                if constexpr (C - D >= 1 && I >= 0 && I < WN) { if (u == U) wl[I] = (v2f){0.f, 0.f}; }
+                            });
+                        });
+                        static_for<(L + 1) / 2 + 1>([&](auto ig) {
+                            constexpr int G = decltype(ig)::value;
+                            static_for<3>([&](auto id) {
+                                constexpr int D = decltype(id)::value, I = L + 2 * G + D;
+                                if constexpr (G + D >= 1 && G + D <= L && I < WN) { if (g == G) wl[I] = (v2f){0.f, 0.f}; }
+                            });
+                        });
+                    }
+                }
+                // sum w[k] X[c-k] + conj(w[k]) X[c+k] over this wave's frame X, for the bins c (a) and c+1 (b)
+                v2f a14 = {0.f, 0.f}, b14 = {0.f, 0.f};
+                if constexpr (KIND != 2) {       // (the centre frame's own bin is not a tap)
+                    cmac_pk(a14, w0[0], wl[L]);
+                    cmac_pk(b14, w0[0], wl[L + 1]);
+                }
+#pragma unroll
+                for (int k = 1; k <= L; ++k) {
+                    cmac_pk(a14, w0[k], wl[L - k]);  cmacc_pk(a14, w0[k], wl[L + k]);
+                    cmac_pk(b14, w0[k], wl[L + 1 - k]);  cmacc_pk(b14, w0[k], wl[L + 1 + k]);
+                }
+                v2f twa = twg[0], twb = twg[1 & (Q - 1)];
+#pragma unroll
+                for (int row = 2; row < Q; row += 2) {
+                    if ((c & (Q - 1)) == row) { twa = twg[row]; twb = twg[row + 1]; }
+                }
+                v2f pa = {0.f, 0.f}, pb = {0.f, 0.f};
+                cmac_pk(pa, twa, a14);
+                cmac_pk(pb, twb, b14);
+                P[((tt & 1) * NTW + wave) * 64 + lane] = make_float4(pa.x, pa.y, pb.x, pb.y);
+            }
+            if (tt >= t_done) { s += NSW; setup(); }
+            load_frames(t);
+            __syncthreads();
+        }
+    };
+    if (!is_proj) {
+        if (wave == 0) tap_loop(std::integral_constant<int, 2>{});
+        else if (wave == 1) tap_loop(std::integral_constant<int, 1>{});
+        else tap_loop(std::integral_constant<int, 0>{});
+    } else {
+        // ------------------------------------------------------------------------------------------ projection wave
+        asm volatile("s_setprio 3");            // the dependent chain of a step: ahead of the tap waves of its SIMD
+        v2f p1 = {0.f, 0.f}, p2 = {0.f, 0.f};   // current values of columns c-1, c-2 of the unit's frame
+        for (int t = -1; t < t_end; ++t) {
+            const int u = t - tstart;
+            if (t >= 0 && valid && u >= 0 && u < NU) {
+                const int c = 2 * u, n = c + L;
+                const bool has_b = c + 1 < F;
+                const int li = ctb + n;
+                if constexpr (SERIAL) {
+                    const int e = rho + Q - 1;
+                    const float2 zero = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int cb = c + bb, nb = n + bb;
+                        if (cb >= F) break;
+                        const int row = cb % Q, rowneg = (Q - row) % Q;
+                        const float2 *wa = W + wset * Q * Q * K1 + row * Q * K1;
+                        float2 acc = zero;
+                        if (centre) {
+                            const float2 *ctr = S + ctb + nb;
+#pragma unroll
+                            for (int k = 1; k <= L; ++k) pair(acc, wa[k], ctr[-k], ctr[k]);
+                        }
+#pragma unroll
+                        for (int rr = 1; rr < Q; ++rr) {
+                            const float2 *lf = S + ((e - rr) & (NW - 1)) * Np + nb;
+                            const float2 *rt = S + ((e + rr) & (NW - 1)) * Np + nb;
+                            const float2 *wa_r = W + wset * Q * Q * K1 + (row * Q + rr) * K1;
+                            const float2 *wb_r = W + wset * Q * Q * K1 + (rowneg * Q + rr) * K1;
+                            const bool two = rr < ts;
+                            pair(acc, wa_r[0], lf[0], two ? rt[0] : zero);
+#pragma unroll
+                            for (int k = 1; k <= L; ++k) {
+                                pair(acc, wa_r[k], lf[-k], two ? rt[-k] : zero);
+                                pair(acc, wb_r[k], two ? rt[k] : zero, lf[k]);
+                            }
+                        }
+                        const int lj = ctb + nb;
+                        const float target = A[lj];
+                        if (target > thr) {
+                            const float mag = sqrtf(acc.x * acc.x + acc.y * acc.y);
+                            if (mag > 0.f) {
+                                const float2 v = make_float2(acc.x * target / mag, acc.y * target / mag);
+                                const float2 vc = make_float2(v.x, -v.y);
+                                S[lj] = v;
+                                const int nyq = F + L - 1;
+                                if (nb >= L + 1 && nb < 2 * L + 1) S[lj + 2 * (L - nb)] = vc;
+                                else if (nb >= F - 1 && nb < nyq) S[lj + 2 * (nyq - nb)] = vc;
+                            }
+                        }
+                    }
+                } else {
+                    // everything the step reads, up front: one wait
+                    const float4 *pp = P + (t & 1) * NTW * 64 + lane;
+                    float4 part[NTW];
+#pragma unroll
+                    for (int w = 0; w < NTW; ++w) part[w] = pp[w * 64];
+                    const v2f oldA = as_v2f(S[li]), oldB = as_v2f(S[li + 1]);
+                    const float target_a = A[li], target_b = A[li + 1];
+                    const v2f xlate = as_v2f(S[fbm1 + c + 1 + 2 * L]);
+                    const v2f twl = as_v2f(TW[(c + 1) & (Q - 1)]);
+                    const v2f im1 = as_v2f(S[ctb + L - 1]), im2 = as_v2f(S[ctb + L - 2]);   // columns -1, -2 (images): what a frame starts with
+                    if (u == 0) { p1 = im1; p2 = im2; }
+                    v2f accA = {part[0].x, part[0].y}, accB = {part[0].z, part[0].w};
+#pragma unroll
+                    for (int w = 1; w < NTW; ++w) {
+                        accA += (v2f){part[w].x, part[w].y};
+                        accB += (v2f){part[w].z, part[w].w};
+                    }
+                    // frame rho-1, bin c+1, tap +L: the column that was being written while the tap wave summed
+                    {
+                        v2f x = {0.f, 0.f};
+                        cmac_pk(x, wlate, xlate);
+                        cmac_pk(accB, twl, x);
+                    }
+                    // the centre frame's columns c-1, c-2 (and c, below): the unit's own last outputs
+                    cmac_pk(accA, wc[1], p1);
+                    cmac_pk(accA, wc[2], p2);
+                    cmac_pk(accB, wc[2], p1);
+                    if (L >= 3) cmac_pk(accB, wc[L >= 3 ? 3 : 0], p2);
+                    // ... and their Hermitian images near the frame edges: the image of bin y = c-d is column -y, tap k = c + y of
+                    // bin c (k + 1 of bin c+1), or column 2N - y, tap k = 2(N-c) + d forwards (k - 1 of bin c+1) -- a handful
+                    // of (step, tap) pairs, spelled out so that every weight is a register
+                    const int g = N - c;
+                    const bool edge = 2 * c <= L + 2 || 2 * g <= L + 1;
+                    const v2f cjA = {oldA.x, -oldA.y}, cj1 = {p1.x, -p1.y}, cj2 = {p2.x, -p2.y};
+                    if (edge) {
+                        static_for<(L + 2) / 4 + 1>([&](auto iu) {
+                            constexpr int U = decltype(iu)::value, C = 2 * U;
+                            static_for<3>([&](auto id) {
+                                constexpr int D = decltype(id)::value, Y = C - D, K = C + Y;
+                                if constexpr (Y >= 1) {
+                                    const v2f cc = D == 0 ? cjA : (D == 1 ? cj1 : cj2);
+                                    if (u == U) {
+                                        if constexpr (K <= L) cmac_pk(accA, wc[K <= L ? K : 0], cc);
+                                        if constexpr (D > 0 && K + 1 <= L) cmac_pk(accB, wc[K + 1 <= L ? K + 1 : 0], cc);
+                                    }
+                                }
+                            });
+                        });
+                        static_for<(L + 1) / 2 + 1>([&](auto ig) {
+                            constexpr int G = decltype(ig)::value;
+                            static_for<3>([&](auto id) {
+                                constexpr int D = decltype(id)::value, K = 2 * G + D;
+                                if constexpr (G + D >= 1 && G + D <= L) {
+                                    const v2f cc = D == 0 ? cjA : (D == 1 ? cj1 : cj2);
+                                    if (g == G) {
+                                        if constexpr (K >= 1 && K <= L) cmacc_pk(accA, wc[(K >= 1 && K <= L) ? K : 0], cc);
+                                        if constexpr (D > 0 && K - 1 >= 1 && K - 1 <= L) cmacc_pk(accB, wc[(K - 1 >= 1 && K - 1 <= L) ? K - 1 : 0], cc);
+                                    }
+                                }
+                            });
+                        });
+                    }
+                    // ---- first bin
+                    v2f newA;
+                    {
+                        float m2 = accA.x * accA.x + accA.y * accA.y;
+                        v2f q = accA;
+                        if (m2 < 1e-30f) {           // too small to square in fp32 (or zero): rescale, so that "|acc| > 0" keeps its meaning
+                            q *= 0x1p60f;
+                            m2 = q.x * q.x + q.y * q.y;
+                        }
+                        const float sc = target_a * __frsqrt_rn(m2);
+                        const bool upd = target_a > thr && m2 > 0.f;
+                        newA = upd ? q * sc : oldA;
+                    }
+                    cmac_pk(accB, wc[1], newA);
+                    if (edge) {   // the image of bin c itself, as the second bin sees it
+                        const v2f cc = {newA.x, -newA.y};
+                        static_for<(L + 2) / 4 + 1>([&](auto iu) {
+                            constexpr int U = decltype(iu)::value, K = 4 * U + 1;
+                            if constexpr (U >= 1 && K <= L) { if (u == U) cmac_pk(accB, wc[K <= L ? K : 0], cc); }
+                        });
+                        static_for<(L + 1) / 2 + 1>([&](auto ig) {
+                            constexpr int G = decltype(ig)::value, K = 2 * G - 1;
+                            if constexpr (G >= 1 && K <= L) { if (g == G) cmacc_pk(accB, wc[(K >= 1 && K <= L) ? K : 0], cc); }
+                        });
+                    }
+                    // ---- second bin
+                    v2f newB;
+                    {
+                        float m2 = accB.x * accB.x + accB.y * accB.y;
+                        v2f q = accB;
+                        if (m2 < 1e-30f) {
+                            q *= 0x1p60f;
+                            m2 = q.x * q.x + q.y * q.y;
+                        }
+                        const float sc = target_b * __frsqrt_rn(m2);
+                        const bool upd = has_b && target_b > thr && m2 > 0.f;
+                        newB = upd ? q * sc : oldB;
+                    }
+                    // unchanged bins are written back as they were; Hermitian images in the pad columns (lwslib.cpp:362-367)
+                    S[li] = make_float2(newA.x, newA.y);
+                    if (has_b) S[li + 1] = make_float2(newB.x, newB.y);
+                    if (c <= L || c + 1 >= F - 1 - L) {
+                        const int cb = c + 1;
+                        if (c >= 1 && c <= L) S[li - 2 * c] = make_float2(newA.x, -newA.y);
+                        else if (c >= F - 1 - L && c <= F - 2) S[li + 2 * (F - 1 - c)] = make_float2(newA.x, -newA.y);
+                        if (cb >= 1 && cb <= L) S[li + 1 - 2 * cb] = make_float2(newB.x, -newB.y);
+                        else if (cb >= F - 1 - L && cb <= F - 2) S[li + 1 + 2 * (F - 1 - cb)] = make_float2(newB.x, -newB.y);
+                    }
+                    p2 = newA;
+                    p1 = newB;
+                }
+            }
+            if (t >= t_done) { s += NSW; setup(); }
+            load_frames(t);
+            __syncthreads();
+        }
+    }
+    const int first_row = loaded > NW ? loaded - NW : 0;
+    for (int e = first_row; e < loaded; ++e) {
+        const int slot = (e & (NW - 1)) * Np;
+        for (int i = tid; i < Np; i += nthr) gS[(size_t)e * Np + i] = S[slot + i];
+    }
+}
+
 template <int Q, int L, bool SERIAL, int MAXT> hipError_t launch_qt(const OnlineArgs &a, int B, int threads, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -379,7 +759,7 @@ template <int Q, int L, bool SERIAL> hipError_t launch_q(const OnlineArgs &a, in
 struct Shape { int NSW, threads, DS; size_t lds; bool ok; };
 
 Shape shape_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
-    Shape sh{0, 0, 0, false};
+    Shape sh{0, 0, 0, 0, false};
     if (Qp != Q || L != 5 || !(Q == 2 || Q == 4 || Q == 8) || LA < 0 || n_thr < 1 || T < 1) return sh;
     const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS_MIN = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
     const int NU = (F + 1) / 2;
@@ -409,10 +789,57 @@ Shape shape_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
     return sh;
 }
 
+// k_online3: 2Q waves, one lane per (sweep slot, frame position)
+Shape shape3_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
+    Shape sh{0, 0, 0, 0, false};
+    if (Qp != Q || L != 5 || !(Q == 2 || Q == 4 || Q == 8) || LA < 0 || LA > 63 || n_thr < 1 || T < 1) return sh;
+    const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS_MIN = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
+    const int NU = (F + 1) / 2;
+    sh.NSW = 64 / (LA + 1);
+    // order-exact lag; the tap waves run a step ahead: 2 DS >= SKB Q + 2; a slot is free again when its sweep is over:
+    // NSW DS >= SKS LA + NU
+    int DS = DS_MIN;
+    if (2 * DS < SKB * Q + 2) DS = (SKB * Q + 3) / 2;
+    const int need = (SKS * LA + NU + sh.NSW - 1) / sh.NSW;
+    if (DS < need) DS = need;
+    sh.DS = DS;
+    sh.threads = 2 * Q * 64;
+    const int window = (DS * (per - 1) + NU + 1) / (DS * per + SKS) + LA + Q;
+    if (window > NW) return sh;
+    sh.lds = (size_t)2 * (2 * Q - 1) * 64 * 16 + ((size_t)NW * Np + 2) * 8 + (size_t)NW * Np * 4 + 8 + (size_t)3 * Q * Q * (L + 1) * 8 +
+             (size_t)Q * 8 + (size_t)n_thr * 4;
+    if (sh.lds > 160 * 1024) return sh;
+    if ((double)DS * T * per + (double)SKS * T + NU > 1.0e9) return sh;
+    sh.ok = true;
+    return sh;
+}
+
+// which layout serves a shape: the wave-per-tap-group one unless it needs much more lag between sweeps (few slots: long
+// look-ahead) than the lane-group one; LWS_ONLINE_LAYOUT=2 / 3 forces one (tests)
+int pick_layout(const Shape &s2, const Shape &s3) {
+    const char *ev = getenv("LWS_ONLINE_LAYOUT");
+    if (ev && ev[0] == '2' && s2.ok) return 2;
+    if (ev && ev[0] == '3' && s3.ok) return 3;
+    if (s3.ok && (!s2.ok || 2 * s3.DS <= 3 * s2.DS)) return 3;
+    return s2.ok ? 2 : 0;
+}
+
+template <int Q, int L, bool SERIAL> hipError_t launch_3(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online3<Q, L, SERIAL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_online3<Q, L, SERIAL>), dim3(B), dim3(2 * Q * 64), lds, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update, bool twiddle_structure) {
-    return update == 2 && twiddle_structure && shape_of(F, T, L, Q, Qp, LA, n_thr).ok;
+    return update == 2 && twiddle_structure && (shape_of(F, T, L, Q, Qp, LA, n_thr).ok || shape3_of(F, T, L, Q, Qp, LA, n_thr).ok);
 }
 
 // W[p][r][k] == W[0][r][k] exp(2 pi j p r / Q) for every p, r, k (what create_weights produces, lws.pyx:160-181)
@@ -435,8 +862,10 @@ bool weights_have_twiddle_structure(const double *W, int Q, int Qp, int L) {
 }
 
 hipError_t launch_online_lds(const GenericArgs<float> &g, int B, hipStream_t stream) {
-    const Shape sh = shape_of(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr);
-    if (!sh.ok) return hipErrorInvalidValue;
+    const Shape sh2 = shape_of(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr), sh3 = shape3_of(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr);
+    const int layout = pick_layout(sh2, sh3);
+    if (layout == 0) return hipErrorInvalidValue;
+    const Shape sh = layout == 3 ? sh3 : sh2;
     OnlineArgs a;
     a.state = g.state; a.amp = g.amp; a.thr = g.thr;
     for (int i = 0; i < 3; ++i) a.w[i] = g.w[i].w;
@@ -450,6 +879,12 @@ hipError_t launch_online_lds(const GenericArgs<float> &g, int B, hipStream_t str
     }
     a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = sh.NSW; a.DS = sh.DS;
     const char *ev = getenv("LWS_ONLINE_SERIAL_TAPS");   // verification only, see k_online
+    if (layout == 3) {
+        const bool serial = ev && ev[0] == '1';
+        if (g.Q == 4) return serial ? launch_3<4, 5, true>(a, B, sh.lds, stream) : launch_3<4, 5, false>(a, B, sh.lds, stream);
+        if (g.Q == 2) return serial ? launch_3<2, 5, true>(a, B, sh.lds, stream) : launch_3<2, 5, false>(a, B, sh.lds, stream);
+        return serial ? launch_3<8, 5, true>(a, B, sh.lds, stream) : launch_3<8, 5, false>(a, B, sh.lds, stream);
+    }
     if (ev && ev[0] == '1') {
         if (g.Q == 4) return launch_q<4, 5, true>(a, B, sh.threads, sh.lds, stream);
         if (g.Q == 2) return launch_q<2, 5, true>(a, B, sh.threads, sh.lds, stream);
