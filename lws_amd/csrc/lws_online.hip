@@ -386,8 +386,17 @@ __global__ void __launch_bounds__(MAXT) k_online(OnlineArgs a) {
 //     second) and the Hermitian images of those three bins near the frame edges.  The centre wave reloads its window from
 //     LDS every step (the unit's own writes land inside it), minus those columns.
 // SERIAL (verification): the last wave sums every tap itself, from LDS, in the generic engine's order; same schedule.
+// Waves of k_online3: 2Q-1 tap waves and the projection wave; Q = 4 adds an idle ninth wave so that the projection wave --
+// the dependent chain every step waits for -- has a SIMD to itself (hardware waves w and w + 4 share one: it is wave 3, the
+// idle one wave 7).
+template <int Q> struct Online3Waves {
+    static constexpr int N = (Q == 4) ? 9 : 2 * Q;
+    static constexpr int PROJ = (Q == 8) ? 15 : 3, IDLE = (Q == 4) ? 7 : -1;
+    static __host__ __device__ constexpr int tap_of(int hw) { return hw - (hw > PROJ ? 1 : 0) - (IDLE >= 0 && hw > IDLE ? 1 : 0); }
+};
+
 template <int Q, int L, bool SERIAL>
-__global__ void __launch_bounds__(2 * Q * 64) k_online3(OnlineArgs a) {
+__global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int K1 = L + 1, WN = 2 * L + 2, NTW = 2 * Q - 1;                  // NTW tap waves, then the projection wave
     constexpr int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2;
@@ -404,7 +413,8 @@ __global__ void __launch_bounds__(2 * Q * 64) k_online3(OnlineArgs a) {
     float2 *TW = W + 3 * Q * Q * K1;                                            // [Q]
     float *thr_s = reinterpret_cast<float *>(TW + Q);                           // [n_thr]
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wave = Online3Waves<Q>::tap_of(hw_wave);   // tap group of a tap wave
     float2 *gS = a.state + (size_t)b * Tp * Np;
     const float *gA = a.amp + (size_t)b * Tp * Np;
 
@@ -423,7 +433,7 @@ __global__ void __launch_bounds__(2 * Q * 64) k_online3(OnlineArgs a) {
     // this lane's unit: frame position j of sweep slot sigma; this wave's tap group: frame offset r, side h
     const int sigma = lane / rps, j = lane - sigma * rps;
     const bool lane_used = sigma < NSW;
-    const bool is_proj = wave == NTW;
+    const bool is_proj = hw_wave == Online3Waves<Q>::PROJ, is_idle = hw_wave == Online3Waves<Q>::IDLE;
     const int r = (wave + 1) >> 1, h = (wave == 0) ? 0 : ((wave + 1) & 1);
     int s = sigma;
     int rho = 0, tstart = 0, t_done = 0, ts = 1, wset = 0;
@@ -515,19 +525,23 @@ __global__ void __launch_bounds__(2 * Q * 64) k_online3(OnlineArgs a) {
                     // 2N - y (N-L <= y <= N-1) at slot L + 2(N-c) + d -- a handful of (step, slot) pairs, spelled out
                     const int g = N - c;
                     if (2 * c <= L + 2 || 2 * g <= L + 1) {
-                        static_for<(L + 2) / 4 + 1>([&](auto iu) {
-                            constexpr int U = decltype(iu)::value, C = 2 * U;
-                            static_for<3>([&](auto id) {
-                                constexpr int D = decltype(id)::value, I = L - 2 * C + D;
-                                if constexpr (C - D >= 1 && I >= 0 && I < WN) { if (u == U) wl[I] = (v2f){0.f, 0.f}; }
-                            });
+                        static_for<(L + 2) / 4>([&](auto iu) {
+                            constexpr int U = decltype(iu)::value + 1, C = 2 * U;
+                            if (u == U) {
+                                static_for<3>([&](auto id) {
+                                    constexpr int D = decltype(id)::value, I = L - 2 * C + D;
+                                    if constexpr (C - D >= 1 && I >= 0 && I < WN) wl[I] = (v2f){0.f, 0.f};
+                                });
+                            }
                         });
                         static_for<(L + 1) / 2 + 1>([&](auto ig) {
                             constexpr int G = decltype(ig)::value;
-                            static_for<3>([&](auto id) {
-                                constexpr int D = decltype(id)::value, I = L + 2 * G + D;
-                                if constexpr (G + D >= 1 && G + D <= L && I < WN) { if (g == G) wl[I] = (v2f){0.f, 0.f}; }
-                            });
+                            if (g == G) {
+                                static_for<3>([&](auto id) {
+                                    constexpr int D = decltype(id)::value, I = L + 2 * G + D;
+                                    if constexpr (G + D >= 1 && G + D <= L && I < WN) wl[I] = (v2f){0.f, 0.f};
+                                });
+                            }
                         });
                     }
                 }
@@ -557,7 +571,9 @@ __global__ void __launch_bounds__(2 * Q * 64) k_online3(OnlineArgs a) {
             __syncthreads();
         }
     };
-    if (!is_proj) {
+    if (is_idle) {
+        for (int t = -1; t < t_end; ++t) { load_frames(t); __syncthreads(); }
+    } else if (!is_proj) {
         if (wave == 0) tap_loop(std::integral_constant<int, 2>{});
         else if (wave == 1) tap_loop(std::integral_constant<int, 1>{});
         else tap_loop(std::integral_constant<int, 0>{});
@@ -650,31 +666,31 @@ __global__ void __launch_bounds__(2 * Q * 64) k_online3(OnlineArgs a) {
                     const bool edge = 2 * c <= L + 2 || 2 * g <= L + 1;
                     const v2f cjA = {oldA.x, -oldA.y}, cj1 = {p1.x, -p1.y}, cj2 = {p2.x, -p2.y};
                     if (edge) {
-                        static_for<(L + 2) / 4 + 1>([&](auto iu) {
-                            constexpr int U = decltype(iu)::value, C = 2 * U;
-                            static_for<3>([&](auto id) {
-                                constexpr int D = decltype(id)::value, Y = C - D, K = C + Y;
-                                if constexpr (Y >= 1) {
-                                    const v2f cc = D == 0 ? cjA : (D == 1 ? cj1 : cj2);
-                                    if (u == U) {
+                        static_for<(L + 2) / 4>([&](auto iu) {
+                            constexpr int U = decltype(iu)::value + 1, C = 2 * U;   // (the first step of a frame has none)
+                            if (u == U) {
+                                static_for<3>([&](auto id) {
+                                    constexpr int D = decltype(id)::value, Y = C - D, K = C + Y;
+                                    if constexpr (Y >= 1) {
+                                        const v2f cc = D == 0 ? cjA : (D == 1 ? cj1 : cj2);
                                         if constexpr (K <= L) cmac_pk(accA, wc[K <= L ? K : 0], cc);
                                         if constexpr (D > 0 && K + 1 <= L) cmac_pk(accB, wc[K + 1 <= L ? K + 1 : 0], cc);
                                     }
-                                }
-                            });
+                                });
+                            }
                         });
                         static_for<(L + 1) / 2 + 1>([&](auto ig) {
                             constexpr int G = decltype(ig)::value;
-                            static_for<3>([&](auto id) {
-                                constexpr int D = decltype(id)::value, K = 2 * G + D;
-                                if constexpr (G + D >= 1 && G + D <= L) {
-                                    const v2f cc = D == 0 ? cjA : (D == 1 ? cj1 : cj2);
-                                    if (g == G) {
+                            if (g == G) {
+                                static_for<3>([&](auto id) {
+                                    constexpr int D = decltype(id)::value, K = 2 * G + D;
+                                    if constexpr (G + D >= 1 && G + D <= L) {
+                                        const v2f cc = D == 0 ? cjA : (D == 1 ? cj1 : cj2);
                                         if constexpr (K >= 1 && K <= L) cmacc_pk(accA, wc[(K >= 1 && K <= L) ? K : 0], cc);
                                         if constexpr (D > 0 && K - 1 >= 1 && K - 1 <= L) cmacc_pk(accB, wc[(K - 1 >= 1 && K - 1 <= L) ? K - 1 : 0], cc);
                                     }
-                                }
-                            });
+                                });
+                            }
                         });
                     }
                     // ---- first bin
@@ -803,7 +819,7 @@ Shape shape3_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
     const int need = (SKS * LA + NU + sh.NSW - 1) / sh.NSW;
     if (DS < need) DS = need;
     sh.DS = DS;
-    sh.threads = 2 * Q * 64;
+    sh.threads = (Q == 4 ? 9 : 2 * Q) * 64;
     const int window = (DS * (per - 1) + NU + 1) / (DS * per + SKS) + LA + Q;
     if (window > NW) return sh;
     sh.lds = (size_t)2 * (2 * Q - 1) * 64 * 16 + ((size_t)NW * Np + 2) * 8 + (size_t)NW * Np * 4 + 8 + (size_t)3 * Q * Q * (L + 1) * 8 +
@@ -832,7 +848,7 @@ template <int Q, int L, bool SERIAL> hipError_t launch_3(const OnlineArgs &a, in
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_online3<Q, L, SERIAL>), dim3(B), dim3(2 * Q * 64), lds, s, a);
+    hipLaunchKernelGGL((k_online3<Q, L, SERIAL>), dim3(B), dim3(Online3Waves<Q>::N * 64), lds, s, a);
     return hipGetLastError();
 }
 
