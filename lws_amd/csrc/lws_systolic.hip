@@ -832,7 +832,16 @@ __device__ __forceinline__ void quad_finish(const SysArgs &a, const QuadCarry<L>
 // lane of a wave at the start / end of its frame the image cells come from the pseudo-lanes (LaneCtx::wlo / whi).
 // CO: clock of the block the quad belongs to, relative to the block `cx` addresses (0, or 8 for a helper wave working on the
 // next block)
-template <int PA0, int DR, int L, int C0, int NC, int CO = 0, int N = 0>
+// KMASK: bit k set <=> the taps +-k of this frame pair are used (a tap nobody uses is not fetched: the ring reads are volatile,
+// and a fetch whose result is dropped still makes the next user of its register wait for it)
+template <int L> __host__ __device__ constexpr bool window_slot_used(uint32_t kmask, int j) {
+    for (int offs = 0; offs < 4; ++offs) {
+        const int d = j - (L + 1 + offs), k = d < 0 ? -d : d;
+        if (k <= L && ((kmask >> k) & 1u)) return true;
+    }
+    return false;
+}
+template <int PA0, int DR, int L, int C0, int NC, uint32_t KMASK, int CO = 0, int N = 0>
 __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
     static_assert((PA0 & 3) == 0 && (L & 1) == 1 && C0 + NC <= L + 3 && N >= 2 * L + 5, "cell window");
     constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
@@ -851,14 +860,15 @@ __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
         if constexpr (img_lo) base = cx.ob[m] + cx.wlo[DR + HALO];
         if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + HALO];
         const int addr = base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES;
-        if constexpr (i == 0) {
-            t[1] = lds_read(addr + 8);
-        } else if constexpr (i == L + 2) {
-            t[2 * L + 4] = lds_read(addr);
-        } else {
+        constexpr bool need0 = i != 0 && window_slot_used<L>(KMASK, j), need1 = i != L + 2 && window_slot_used<L>(KMASK, j + 1);
+        if constexpr (need0 && need1) {
             const v4f v = lds_read128(addr);
             t[j] = make_float2(v.x, v.y);
             t[j + 1] = make_float2(v.z, v.w);
+        } else if constexpr (need0) {
+            t[j] = lds_read(addr);
+        } else if constexpr (need1) {
+            t[j + 1] = lds_read(addr + 8);
         }
     });
 }
@@ -890,6 +900,7 @@ template <int Q, int L, uint64_t MASK, int PA, bool H16>
 __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx, Carry &cr, const float (&amp_cur)[8],
                                              QuadCarry<L> &qc) {
     static_assert((PA & 1) == 0, "pairs start on even bins");
+    constexpr int K1 = L + 1;
     constexpr int PHB = PA + 1;                              // second bin
     constexpr int PA0 = PA & ~2;                             // first phase of the quad
     constexpr bool quad_first = (PA & 2) == 0;
@@ -929,8 +940,9 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
                 static_assert(quad_late_frame<-1, L>() == quad_late_frame<LATE_DN, L>() && !quad_late_frame<-2, L>() &&
                               !quad_late_frame<LATE_DN - 1, L>() && !quad_late_frame<1, L>() && !quad_late_frame<-LATE_DN, L>(),
                               "which frames are late");
-                load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3)>(cx, tu);   // frame m-1 cannot deliver its last half cell yet,
-                load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3)>(cx, td);     // nor can frame m+LATE_DN
+                constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
+                load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3), kmask>(cx, tu);   // frame m-1 cannot deliver its last half cell yet,
+                load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3), kmask>(cx, td);     // nor can frame m+LATE_DN
                 rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
                 rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
                 rows_sum_ahead<Q, L, MASK, PA + 2, R, 2>(a, tu, td, p3C, qc.accA, qc);
@@ -945,8 +957,8 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
         accB = cadd(accB, qc.accB);
         if constexpr (quad_late_frame<-1, L>()) {
             float2 u1[2 * L + 6], d3[2 * L + 6];
-            load_cells<PA0, -1, L, L + 2, 1>(cx, u1);
-            if constexpr (Q > LATE_DN) load_cells<PA0, LATE_DN, L, L + 2, 1>(cx, d3);
+            load_cells<PA0, -1, L, L + 2, 1, (uint32_t)((MASK >> K1) & ((1ull << K1) - 1ull))>(cx, u1);
+            if constexpr (Q > LATE_DN) load_cells<PA0, LATE_DN, L, L + 2, 1, (uint32_t)((MASK >> ((Q > LATE_DN ? LATE_DN : 0) * K1)) & ((1ull << K1) - 1ull))>(cx, d3);
             if constexpr (r13) {
                 quad_finish<Q, L, MASK, PHB>(a, qc, u1[2 * L + 4], d3[2 * L + 4], accB);
             } else {
@@ -997,8 +1009,9 @@ __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx,
                 // fetched (fourth bin, +L) must have been produced before this pair started
                 static_assert(SKEW * R - L - 3 - HELP_AHEAD >= 1 && LAG - SKEW * R - L - 3 - HELP_AHEAD >= 1, "helper runs too far ahead");
                 float2 tu[2 * L + 6], td[2 * L + 6];
-                load_cells<PH0, -R, L, 0, L + 3, CO>(cx, tu);
-                load_cells<PH0, R, L, 0, L + 3, CO>(cx, td);
+                constexpr uint32_t kmask = (uint32_t)((MASK >> (R * (L + 1))) & ((1ull << (L + 1)) - 1ull));
+                load_cells<PH0, -R, L, 0, L + 3, kmask, CO>(cx, tu);
+                load_cells<PH0, R, L, 0, L + 3, kmask, CO>(cx, td);
                 rows_sum<Q, L, MASK, PH, R, 0>(a, tu, td, p3, accA);
                 rows_sum<Q, L, MASK, PH + 1, R, 1>(a, tu, td, p3, accB);
                 rows_sum_ahead<Q, L, MASK, PH + 2, R, 2>(a, tu, td, p3, qc.accA, qc);
