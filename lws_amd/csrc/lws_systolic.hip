@@ -120,12 +120,15 @@ constexpr int DUMMY_OFF = DONE_OFF + 64;               // 64 x 8 B: where predic
 constexpr int SCRATCH_OFF = DUMMY_OFF + LANES * 8;     // where the compute lanes that have no image to publish store instead (see image_base)
 constexpr int SCRATCH_BYTES = 4 * PAIR_BYTES + LANES * 8;
 // Q = 8: a sweep slot is one MAIN wave (centre frame, frames m-+1 and m-+7, re-projection, publishing) and NHELP helper
-// waves that sum the taps of the other neighbour frames HELP_AHEAD steps ahead of it -- every tap of frames m-+2 .. m-+6 is
+// waves that sum the taps of the other neighbour frames 4 or 6 steps ahead of it (help_ahead) -- every tap of frames m-+2 .. m-+6 is
 // at least 10 steps old when its bin is due -- and leave the two sums of a pair of bins in a mailbox (4 pairs deep).  The
 // sums of a bin are the bulk of its ~310 instructions and one wave per SIMD issues one every ~4.4 clocks: spreading a slot
 // over three waves is what fills the other SIMDs (2 slots are all the LDS holds at this ring depth).
 constexpr int NHELP = LWS_Q8 ? 2 : 0;                    // helper waves per sweep slot
-constexpr int HELP_AHEAD = 4;
+// how far ahead helper h works: two pairs.  (Three -- 6 steps, so that a helper sums in the pair in which the main wave of its
+// SIMD has little to do -- is legal but slower: the waves of a slot meet at every pair, and then every pair is a heavy one
+// for somebody: 143 -> 165 ms.)
+__host__ __device__ constexpr int help_ahead(int h) { return h >= 1 ? 4 : 4; }
 constexpr int MBOX_OFF = SCRATCH_OFF + SCRATCH_BYTES;    // [slot][helper][pair & 3][lane]: (sum of the first bin, of the second)
 constexpr int MBOX_BYTES = NSLOTS * NHELP * 4 * LANES * 16;
 constexpr int WNYQ_OFF = MBOX_OFF + MBOX_BYTES;          // Q = 8: the Nyquist lanes' weights (the waves keep only their own in registers)
@@ -989,13 +992,14 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
 }
 
 // Q = 8: one pair of bins of a HELPER lane (helper H of its slot): the taps of the neighbour frames row_owner() gives it,
-// for the pair the slot's main wave reaches HELP_AHEAD steps from now; phases (4,5), (6,7), then (0,1), (2,3) of the lane's
+// for the pair the slot's main wave reaches help_ahead(H) steps from now; phases (4,5), (6,7), then (0,1), (2,3) of the lane's
 // next block.  Same windows, same order of operations per frame pair as compute_pair; no frame of a helper is late.
 template <int Q, int L, uint64_t MASK, int PA, int H>
 __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx, QuadCarry<L> &qc) {
-    constexpr int PH = (PA + HELP_AHEAD) & 7, CO = PA + HELP_AHEAD - PH;   // phase of the first bin; clock of its block
+    constexpr int AHEAD = help_ahead(H);
+    constexpr int PH = (PA + AHEAD) & 7, CO = PA + AHEAD - PH;   // phase of the first bin; clock of its block
     constexpr int PH0 = PH & ~2;
-    static_assert(HELP_AHEAD == 4 && (CO == 0 || CO == 8) && (PH & 1) == 0, "half a block ahead");
+    static_assert((AHEAD == 4 || AHEAD == 6) && (CO == 0 || CO == 8) && (PH & 1) == 0, "less than a block ahead, mailbox 4 pairs deep");
     float2 accA = make_float2(0.f, 0.f), accB = make_float2(0.f, 0.f);
     if constexpr ((PH & 2) == 0) {
         R13Partials<L> p3;   // (unused: no shared-weight rows here)
@@ -1005,9 +1009,9 @@ __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx,
             constexpr int R = decltype(ir)::value + 1;
             if constexpr (row_owner(R) == H) {
                 static_assert(!quad_late_frame<-R, L>() && !quad_late_frame<R, L>(), "late frames stay with the main wave");
-                // two steps ahead of the second pair (rows_sum_ahead) and HELP_AHEAD ahead of the main wave: the newest tap
+                // two steps ahead of the second pair (rows_sum_ahead) and AHEAD ahead of the main wave: the newest tap
                 // fetched (fourth bin, +L) must have been produced before this pair started
-                static_assert(SKEW * R - L - 3 - HELP_AHEAD >= 1 && LAG - SKEW * R - L - 3 - HELP_AHEAD >= 1, "helper runs too far ahead");
+                static_assert(SKEW * R - L - 3 - AHEAD >= 1 && LAG - SKEW * R - L - 3 - AHEAD >= 1, "helper runs too far ahead");
                 float2 tu[2 * L + 6], td[2 * L + 6];
                 constexpr uint32_t kmask = (uint32_t)((MASK >> (R * (L + 1))) & ((1ull << (L + 1)) - 1ull));
                 load_cells<PH0, -R, L, 0, L + 3, kmask, CO>(cx, tu);
@@ -1022,7 +1026,7 @@ __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx,
         accA = qc.accA;
         accB = qc.accB;
     }
-    lds_write128(cx.mbox + mbox_addr(0, H, (PA + HELP_AHEAD) >> 1), accA, accB);
+    lds_write128(cx.mbox + mbox_addr(0, H, (PA + AHEAD) >> 1), accA, accB);
 }
 
 // weight W[0][r][k] (x = r (L+1) + k) for the Nyquist lanes: bin F-1 is a multiple of Q, every twiddle is 1
@@ -1424,7 +1428,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 if (r_compute) compute_pair<Q, L, MASK, PA, H16>(a, cx, cr, amp_cur, qc);
                 if constexpr (NHELP > 0) {
                     if (r_helper) {
-                        if constexpr (PA == 8 - HELP_AHEAD) {   // phases 0..3 of the lane's next block: that block's frame edges
+                        if constexpr (PA == 8 - help_ahead(ROLE >= 1 && ROLE <= NHELP ? ROLE : 1)) {   // from here on the lane's next block: that block's frame edges
     #pragma unroll
                             for (int d = 0; d < NDR; ++d) {
                                 cx.wlo[d] = cx.nxt_start ? dlo[d] : 0;
