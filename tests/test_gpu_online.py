@@ -36,8 +36,13 @@ def _online(F, W, S, thr, LA, qdiv, **kw):
     (512, 64, 60, 2, 5, 2),        # Q = 8
     (256, 64, 5, 3, 4, 1),         # fewer frames than the window
     (256, 64, 1, 3, 2, 1),         # a single frame
+    (512, 128, 40, 9, 2, 1),       # long look-ahead: few sweep slots among the 64 lanes of the wave-per-tap-group layout
 ])
-def test_serial_variant_is_bit_identical_to_generic(fsize, fshift, T, LA, iters, B, monkeypatch):
+@pytest.mark.parametrize("layout", ["2", "3"])
+def test_serial_variant_is_bit_identical_to_generic(fsize, fshift, T, LA, iters, B, layout, monkeypatch):
+    """Both lane layouts of the LDS engine (2Q lanes per bin / one wave per tap group with the projection wave a step behind;
+    LWS_ONLINE_LAYOUT forces one where it fits, else the other runs)."""
+    monkeypatch.setenv("LWS_ONLINE_LAYOUT", layout)
     rng = np.random.default_rng(fsize + T)
     p = lws_amd.lws(fsize, fshift, mode="music")
     F = fsize // 2 + 1
@@ -62,7 +67,9 @@ def test_serial_variant_is_bit_identical_to_generic(fsize, fshift, T, LA, iters,
 @pytest.mark.parametrize("tag", ["64_16", "64_32", "64_8"])
 @pytest.mark.parametrize("T", [1, 2, 3, 7, 24])
 @pytest.mark.parametrize("LA", [0, 1, 3, 5])
-def test_small_shapes_vs_oracle(tag, T, LA, oracle):
+@pytest.mark.parametrize("layout", ["2", "3"])
+def test_small_shapes_vs_oracle(tag, T, LA, layout, oracle, monkeypatch):
+    monkeypatch.setenv("LWS_ONLINE_LAYOUT", layout)
     h, g = load_golden("helpers.npz"), load_golden("wrappers.npz")
     W = (h[f"W_{tag}"], h[f"W_ai_{tag}"], h[f"W_af_{tag}"])
     fsize, fshift = [int(v) for v in tag.split("_")]
@@ -89,7 +96,7 @@ def test_fallbacks_to_generic():
     S = rng.standard_normal((9, 33)) + 1j * rng.standard_normal((9, 33))
     out, name = _online(33, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 4.0, precision="fp64")
     assert name == "generic_fp64"
-    # one iteration per frame on a wide frame: too many frames in flight for the 16-frame ring
+    # one iteration per frame on a wide frame: too many frames in flight for the 16-frame ring (either layout)
     p = lws_amd.lws(2048, 512, mode="music")
     S = rng.standard_normal((30, 1025)) + 1j * rng.standard_normal((30, 1025))
     out, name = _online(1025, (p.W, p.W_ai, p.W_af), S, [0.5], 3, 4.0)
