@@ -406,8 +406,12 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
     const int NU = (F + 1) / 2;
     const int rps = LA + 1, per = a.n_thr + 1;
     const int nsweeps = T * per;
+    // step types of the centre frame's edge terms: 0 none, 1..NLO the steps u = 1..NLO after a frame start, then N - c = 0..NHI-1
+    constexpr int NLO = (L + 2) / 4, NHI = (L + 1) / 2 + 1, NST = 1 + NLO + NHI;
     float4 *P = reinterpret_cast<float4 *>(smem);                               // [2][NTW][64]: (sum of bin c, of bin c+1)
-    float2 *S = reinterpret_cast<float2 *>(P + 2 * NTW * 64);                   // [NW][Np] (+ 2)
+    float2 *ET = reinterpret_cast<float2 *>(P + 2 * NTW * 64);                  // [3][NST][6] (padded to 64 entries): edge-term weights
+    float2 *S = ET + 192 + 64;                                                  // [NW][Np] (+ 2); the 64 entries below it: where image stores
+                                                                                // of bins without an image go
     float *A = reinterpret_cast<float *>(S + (size_t)NW * Np + 2);              // [NW][Np]
     float2 *W = reinterpret_cast<float2 *>(A + (size_t)NW * Np + ((NW * Np) & 1));   // [3][Q][Q][K1]
     float2 *TW = W + 3 * Q * Q * K1;                                            // [Q]
@@ -425,6 +429,26 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
     if (tid < Q) TW[tid] = a.tw[tid];
     for (int i = tid; i < NW * Np + 2; i += nthr) S[i] = make_float2(0.f, 0.f);
     for (int i = tid; i < 2 * NTW * 64; i += nthr) P[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // Edge-term weights of the projection wave (see there): entry [wset][type][j], j = 0..2: what multiplies the conjugate of
+    // the current value of bin c-j in the sum of bin c; 3, 4: of bins c-1, c-2 in the sum of bin c+1; 5: of (the new) bin c in
+    // the sum of bin c+1.  Low edge (image column -y, tap k = c + y backwards): W[k]; high edge (column 2N - y, tap
+    // k = 2(N-c) + d forwards): conj W[k].  W_ai (wset 1) has no centre term.
+    if (tid < 3 * NST * 6) {
+        const int ws = tid / (NST * 6), st = (tid / 6) % NST, jj = tid % 6;
+        const float2 *wb = W + (ws * Q) * Q * K1;
+        const int d = jj < 3 ? jj : (jj < 5 ? jj - 2 : 0), shift = jj < 3 ? 0 : 1;   // shift: the tap index moves by one for bin c+1
+        float2 w = make_float2(0.f, 0.f);
+        if (ws != 1 && st >= 1 && st <= NLO) {
+            const int c = 2 * st, y = c - d, k = c + y + shift;
+            if (y >= 1 && k <= L) w = wb[k];
+        } else if (ws != 1 && st > NLO) {
+            const int g = st - NLO - 1, k = 2 * g + d - shift;
+            if (g + d >= 1 && g + d <= L && k >= 1 && k <= L) w = make_float2(wb[k].x, -wb[k].y);
+        }
+        ET[tid] = w;
+    }
+    if (tid < 64) S[-64 + tid] = make_float2(0.f, 0.f);
     __syncthreads();
     for (int i = tid; i < a.n_thr; i += nthr) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
     int loaded = Q < T + Q - 1 ? Q : T + Q - 1;
@@ -641,6 +665,10 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
                     const v2f xlate = as_v2f(S[fbm1 + c + 1 + 2 * L]);
                     const v2f twl = as_v2f(TW[(c + 1) & (Q - 1)]);
                     const v2f im1 = as_v2f(S[ctb + L - 1]), im2 = as_v2f(S[ctb + L - 2]);   // columns -1, -2 (images): what a frame starts with
+                    const int g = N - c;
+                    const int stype = (u >= 1 && u <= NLO) ? u : (g < NHI ? NLO + 1 + g : 0);
+                    const float4 *et = reinterpret_cast<const float4 *>(ET + (wset * NST + stype) * 6);
+                    const float4 e01 = et[0], e23 = et[1], e45 = et[2];
                     if (u == 0) { p1 = im1; p2 = im2; }
                     v2f accA = {part[0].x, part[0].y}, accB = {part[0].z, part[0].w};
 #pragma unroll
@@ -661,37 +689,15 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
                     if (L >= 3) cmac_pk(accB, wc[L >= 3 ? 3 : 0], p2);
                     // ... and their Hermitian images near the frame edges: the image of bin y = c-d is column -y, tap k = c + y of
                     // bin c (k + 1 of bin c+1), or column 2N - y, tap k = 2(N-c) + d forwards (k - 1 of bin c+1) -- a handful
-                    // of (step, tap) pairs, spelled out so that every weight is a register
-                    const int g = N - c;
-                    const bool edge = 2 * c <= L + 2 || 2 * g <= L + 1;
-                    const v2f cjA = {oldA.x, -oldA.y}, cj1 = {p1.x, -p1.y}, cj2 = {p2.x, -p2.y};
-                    if (edge) {
-                        static_for<(L + 2) / 4>([&](auto iu) {
-                            constexpr int U = decltype(iu)::value + 1, C = 2 * U;   // (the first step of a frame has none)
-                            if (u == U) {
-                                static_for<3>([&](auto id) {
-                                    constexpr int D = decltype(id)::value, Y = C - D, K = C + Y;
-                                    if constexpr (Y >= 1) {
-                                        const v2f cc = D == 0 ? cjA : (D == 1 ? cj1 : cj2);
-                                        if constexpr (K <= L) cmac_pk(accA, wc[K <= L ? K : 0], cc);
-                                        if constexpr (D > 0 && K + 1 <= L) cmac_pk(accB, wc[K + 1 <= L ? K + 1 : 0], cc);
-                                    }
-                                });
-                            }
-                        });
-                        static_for<(L + 1) / 2 + 1>([&](auto ig) {
-                            constexpr int G = decltype(ig)::value;
-                            if (g == G) {
-                                static_for<3>([&](auto id) {
-                                    constexpr int D = decltype(id)::value, K = 2 * G + D;
-                                    if constexpr (G + D >= 1 && G + D <= L) {
-                                        const v2f cc = D == 0 ? cjA : (D == 1 ? cj1 : cj2);
-                                        if constexpr (K >= 1 && K <= L) cmacc_pk(accA, wc[(K >= 1 && K <= L) ? K : 0], cc);
-                                        if constexpr (D > 0 && K - 1 >= 1 && K - 1 <= L) cmacc_pk(accB, wc[(K - 1 >= 1 && K - 1 <= L) ? K - 1 : 0], cc);
-                                    }
-                                });
-                            }
-                        });
+                    // of (step, tap) pairs.  Their weights come from a table indexed by the kind of step (zeros for all but ~4
+                    // steps of a frame), so that the chain every step waits for has no branch here.
+                    {
+                        const v2f cjA = {oldA.x, -oldA.y}, cj1 = {p1.x, -p1.y}, cj2 = {p2.x, -p2.y};
+                        cmac_pk(accA, (v2f){e01.x, e01.y}, cjA);
+                        cmac_pk(accA, (v2f){e01.z, e01.w}, cj1);
+                        cmac_pk(accA, (v2f){e23.x, e23.y}, cj2);
+                        cmac_pk(accB, (v2f){e23.z, e23.w}, cj1);
+                        cmac_pk(accB, (v2f){e45.x, e45.y}, cj2);
                     }
                     // ---- first bin
                     v2f newA;
@@ -707,17 +713,7 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
                         newA = upd ? q * sc : oldA;
                     }
                     cmac_pk(accB, wc[1], newA);
-                    if (edge) {   // the image of bin c itself, as the second bin sees it
-                        const v2f cc = {newA.x, -newA.y};
-                        static_for<(L + 2) / 4 + 1>([&](auto iu) {
-                            constexpr int U = decltype(iu)::value, K = 4 * U + 1;
-                            if constexpr (U >= 1 && K <= L) { if (u == U) cmac_pk(accB, wc[K <= L ? K : 0], cc); }
-                        });
-                        static_for<(L + 1) / 2 + 1>([&](auto ig) {
-                            constexpr int G = decltype(ig)::value, K = 2 * G - 1;
-                            if constexpr (G >= 1 && K <= L) { if (g == G) cmacc_pk(accB, wc[(K >= 1 && K <= L) ? K : 0], cc); }
-                        });
-                    }
+                    cmac_pk(accB, (v2f){e45.z, e45.w}, (v2f){newA.x, -newA.y});   // the image of bin c itself, as the second bin sees it
                     // ---- second bin
                     v2f newB;
                     {
@@ -732,15 +728,14 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
                         newB = upd ? q * sc : oldB;
                     }
                     // unchanged bins are written back as they were; Hermitian images in the pad columns (lwslib.cpp:362-367)
+                    // (a bin without an image stores into a spare slot: no branch)
+                    const int spare = lane - 64, cb = c + 1;
+                    const int ia = (c >= 1 && c <= L) ? li - 2 * c : ((c >= N - L && c <= N - 1) ? li + 2 * (N - c) : spare);
+                    const int ib = (cb <= L) ? li + 1 - 2 * cb : ((cb >= N - L && cb <= N - 1) ? li + 1 + 2 * (N - cb) : spare);
                     S[li] = make_float2(newA.x, newA.y);
-                    if (has_b) S[li + 1] = make_float2(newB.x, newB.y);
-                    if (c <= L || c + 1 >= F - 1 - L) {
-                        const int cb = c + 1;
-                        if (c >= 1 && c <= L) S[li - 2 * c] = make_float2(newA.x, -newA.y);
-                        else if (c >= F - 1 - L && c <= F - 2) S[li + 2 * (F - 1 - c)] = make_float2(newA.x, -newA.y);
-                        if (cb >= 1 && cb <= L) S[li + 1 - 2 * cb] = make_float2(newB.x, -newB.y);
-                        else if (cb >= F - 1 - L && cb <= F - 2) S[li + 1 + 2 * (F - 1 - cb)] = make_float2(newB.x, -newB.y);
-                    }
+                    S[has_b ? li + 1 : spare] = make_float2(newB.x, newB.y);
+                    S[ia] = make_float2(newA.x, -newA.y);
+                    S[ib] = make_float2(newB.x, -newB.y);
                     p2 = newA;
                     p1 = newB;
                 }
@@ -822,7 +817,8 @@ Shape shape3_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
     sh.threads = (Q == 4 ? 9 : 2 * Q) * 64;
     const int window = (DS * (per - 1) + NU + 1) / (DS * per + SKS) + LA + Q;
     if (window > NW) return sh;
-    sh.lds = (size_t)2 * (2 * Q - 1) * 64 * 16 + ((size_t)NW * Np + 2) * 8 + (size_t)NW * Np * 4 + 8 + (size_t)3 * Q * Q * (L + 1) * 8 +
+    if (F - 1 < 2 * (L + 3)) return sh;   // frame edges (Hermitian image terms) at least a few steps apart
+    sh.lds = (size_t)2 * (2 * Q - 1) * 64 * 16 + (192 + 64) * 8 + ((size_t)NW * Np + 2) * 8 + (size_t)NW * Np * 4 + 8 + (size_t)3 * Q * Q * (L + 1) * 8 +
              (size_t)Q * 8 + (size_t)n_thr * 4;
     if (sh.lds > 160 * 1024) return sh;
     if ((double)DS * T * per + (double)SKS * T + NU > 1.0e9) return sh;
