@@ -530,6 +530,9 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
     // written: left out); 2: the centre frame (its unit's own recent outputs are left out)
     auto tap_loop = [&](auto kind_c) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_c)::value;
+        v2f wl[WN];
+#pragma unroll
+        for (int i = 0; i < WN; ++i) wl[i] = (v2f){0.f, 0.f};
         for (int t = -1; t < t_end; ++t) {
             const int tt = t + 1;               // the step these waves prepare
             const int u = tt - tstart;
@@ -538,11 +541,19 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
                 // the window, columns c-L .. c+L+1 of this wave's frame, fresh from LDS (whatever is written concurrently is
                 // among the columns left out)
                 const float2 *src = S + fb + c;
-                v2f wl[WN];
+                if (KIND == 2 || u == 0) {
 #pragma unroll
-                for (int i = 0; i < WN; ++i) {
-                    const bool skip = (KIND == 1 && i == WN - 1) || (KIND == 2 && i >= L - 2 && i <= L);
-                    wl[i] = skip ? (v2f){0.f, 0.f} : as_v2f(src[i]);
+                    for (int i = 0; i < WN; ++i) {
+                        const bool skip = (KIND == 1 && i == WN - 1) || (KIND == 2 && i >= L - 2 && i <= L);
+                        wl[i] = skip ? (v2f){0.f, 0.f} : as_v2f(src[i]);
+                    }
+                } else {   // the window slides by two columns per step (no writer comes near it: see the header)
+                    constexpr int LG = KIND == 1 ? 1 : 0;
+#pragma unroll
+                    for (int i = 0; i < WN - 2; ++i) wl[i] = wl[i + 2];
+                    wl[WN - 2 - LG] = as_v2f(src[WN - 2 - LG]);
+                    wl[WN - 1 - LG] = as_v2f(src[WN - 1 - LG]);
+                    if (LG) wl[WN - 1] = (v2f){0.f, 0.f};
                 }
                 if constexpr (KIND == 2) {
                     // images of the bins y = c-d (d = 0, 1, 2) inside the window: column -y (1 <= y) at slot L - 2c + d, column
