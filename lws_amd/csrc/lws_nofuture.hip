@@ -106,9 +106,86 @@ __device__ __forceinline__ void nf_update(int n, int me, float th, const float2 
     else if (n >= F - 1 && n < nyq) cur[2 * nyq - n] = vc;
 }
 
-// QT / LT: compile-time Q and L (0: use the run-time values); COMPAT: NoFuture_LWSQ4's flat addressing (Q = 4 only)
-template <int QT, int LT, bool COMPAT>
-__global__ void __launch_bounds__(512) k_nofuture(NfArgs a) {
+// sum over the 8 adjacent lanes of a group (groups are aligned), in data-parallel-primitive moves
+__device__ __forceinline__ float group_sum8(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>());    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>());    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>());   // row_half_mirror: the other quad of the 8
+    return v;
+}
+
+// The same bin by EIGHT lanes (production variant): lane j sums the tap groups j, j+8, ... (group t = (r-1)(L+1) + k: the two
+// taps +-k of frame me-r, or its tap 0), the partial sums are combined across the lanes, lane 0 re-projects and writes.
+// A round of the chained NoFuture_LWSQ4 rounds is latency: ~33 dependent taps per lane become ~5.  Same arithmetic per tap as
+// nf_update; the order of the sum differs (rounding level).
+template <int QT, int LT, bool COMPAT, bool UNI>
+__device__ __forceinline__ void nf_update_split(int n, int j, int me, float th, const float2 *S, const float2 *W,
+                                                const unsigned long long *Mk, unsigned long long m_uni, const float *amp_cur,
+                                                float2 *cur, int Q_, int L_, int F, int Np, int NR) {
+    const int Q = QT ? QT : Q_, L = LT ? LT : L_, K1 = L + 1, RQ = Q * K1, nyq = F + L - 1;
+    const int c = n - L;
+    const float target = amp_cur[n];
+    if (!(target > th)) return;                         // (the same for the 8 lanes of a bin)
+    const int row = c % Q;
+    const float2 *wa = W + row * RQ;
+    const int rowneg = (Q - row) % Q;
+    const unsigned long long ma = UNI ? m_uni : Mk[row], mb = UNI ? m_uni : Mk[rowneg];
+    const float2 *wb = W + rowneg * RQ;
+    const int nterms = (Q - 1) * K1, wrap_at = Np - 2 * n;
+    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < ((QT ? QT : 8) - 1) * ((LT ? LT : 7) + 1) / 8 + 1; ++i) {
+        const int t = j + 8 * i;
+        if (t < nterms) {
+            const int r = t / K1 + 1, k = t - (r - 1) * K1, u = r * K1;
+            if constexpr (COMPAT) {
+                const int i0 = ((me - r) & (NR - 1)) * Np + 2 * n, i1 = ((me - r + 1) & (NR - 1)) * Np + 2 * n - Np;
+                const float sgn = ((c & 1) && (r & 1)) ? -1.f : 1.f;
+                if (k == 0) {
+                    if ((ma >> u) & 1ull) mac(acc, wa[u], S[0 >= wrap_at ? i1 : i0]);
+                } else if ((ma >> (u + k)) & 1ull) {
+                    float2 hi = S[k >= wrap_at ? i1 + k : i0 + k];
+                    hi.x *= sgn; hi.y *= sgn;
+                    pair(acc, wa[u + k], S[-k >= wrap_at ? i1 - k : i0 - k], hi);
+                }
+            } else {
+                const float2 *lf = S + (size_t)((me - r) & (NR - 1)) * Np + n;
+                if (k == 0) {
+                    if ((ma >> u) & 1ull) mac(acc, wa[u], lf[0]);
+                } else {
+                    if ((ma >> (u + k)) & 1ull) mac(acc, wa[u + k], lf[-k]);
+                    if ((mb >> (u + k)) & 1ull) macc(acc, wb[u + k], lf[k]);
+                }
+            }
+        }
+    }
+    acc.x = group_sum8(acc.x);
+    acc.y = group_sum8(acc.y);
+    if (j != 0) return;
+    // target / |acc| as target * rsqrt(|acc|^2) (hardware reciprocal square root, 1 ulp: a round is a dependent chain, and the
+    // exact square root and the two divisions of the reference form are a third of it); sums too small to square in fp32
+    // are rescaled first so that "|acc| > 0" keeps its meaning
+    float m2 = acc.x * acc.x + acc.y * acc.y;
+    if (m2 < 1e-30f) {
+        acc.x *= 0x1p60f; acc.y *= 0x1p60f;
+        m2 = acc.x * acc.x + acc.y * acc.y;
+    }
+    if (!(m2 > 0.f)) return;
+    const float sc = target * __frsqrt_rn(m2);
+    const float2 v = make_float2(acc.x * sc, acc.y * sc);
+    cur[n] = v;
+    const float2 vc = make_float2(v.x, -v.y);
+    if (n >= L + 1 && n < 2 * L + 1) cur[2 * L - n] = vc;
+    else if (n >= F - 1 && n < nyq) cur[2 * nyq - n] = vc;
+}
+
+// QT / LT: compile-time Q and L (0: use the run-time values); COMPAT: NoFuture_LWSQ4's flat addressing (Q = 4 only);
+// SPLIT: eight lanes per bin (production) or one (the verification variant, bit-identical to the generic engine)
+template <int QT, int LT, bool COMPAT, bool SPLIT>
+__global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Q = QT ? QT : a.Q, L = LT ? LT : a.L;
     const int F = a.F, T = a.T, NR = a.NR, K1 = L + 1, RQ = Q * K1;
@@ -166,12 +243,20 @@ __global__ void __launch_bounds__(512) k_nofuture(NfArgs a) {
                 nxt[j] = (have_next && i < Np) ? load_state(gS + (size_t)(me + 1) * Np + i) : make_float2(0.f, 0.f);
                 anxt[j] = (have_next && i < Np) ? gA[(size_t)(me + 1) * Np + i] : 0.f;
             }
+            // bins are dealt to lanes (SPLIT: to groups of 8 lanes)
+            constexpr int LPB = SPLIT ? 8 : 1;
+            const int slot = tid / LPB, nslots = nthr / LPB, jl = tid % LPB;
             auto update = [&](int n) __attribute__((always_inline)) {
-                if (uni) nf_update<QT, LT, COMPAT, true>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
-                else nf_update<QT, LT, COMPAT, false>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
+                if constexpr (SPLIT) {
+                    if (uni) nf_update_split<QT, LT, COMPAT, true>(n, jl, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
+                    else nf_update_split<QT, LT, COMPAT, false>(n, jl, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
+                } else {
+                    if (uni) nf_update<QT, LT, COMPAT, true>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
+                    else nf_update<QT, LT, COMPAT, false>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
+                }
             };
             if constexpr (COMPAT) {
-                for (int n = L + tid; n < n_split; n += nthr) update(n);
+                for (int n = L + slot; n < n_split; n += nslots) update(n);
                 __syncthreads();
                 for (int n0 = n_split; n0 < F + L;) {
                     int n1 = (n0 + Np - L + 1) / 2;
@@ -179,12 +264,12 @@ __global__ void __launch_bounds__(512) k_nofuture(NfArgs a) {
                     // a bin n <= 2L writes its image into column 2L - n; keep such bins out of rounds whose other bins could
                     // read that column through the flat offset (only possible for F <= 3L - 1): run them one by one
                     if (n0 <= 2 * L) n1 = n0 + 1;
-                    for (int n = n0 + tid; n < n1; n += nthr) update(n);
+                    for (int n = n0 + slot; n < n1; n += nslots) update(n);
                     __syncthreads();
                     n0 = n1;
                 }
             } else {
-                for (int n = L + tid; n < F + L; n += nthr) update(n);
+                for (int n = L + slot; n < F + L; n += nslots) update(n);
                 __syncthreads();
             }
             // frame me is final for this sweep: write it out (pad columns included), bring the next frame into the ring
@@ -202,17 +287,26 @@ __global__ void __launch_bounds__(512) k_nofuture(NfArgs a) {
     }
 }
 
-template <int QT, int LT, bool COMPAT>
-hipError_t launch_t(const NfArgs &a, int B, int threads, size_t lds, hipStream_t s) {
+template <int QT, int LT, bool COMPAT, bool SPLIT>
+hipError_t launch_ts(const NfArgs &a, int B, int threads, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nofuture<QT, LT, COMPAT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nofuture<QT, LT, COMPAT, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_nofuture<QT, LT, COMPAT>), dim3(B), dim3(threads), lds, s, a);
+    hipLaunchKernelGGL((k_nofuture<QT, LT, COMPAT, SPLIT>), dim3(B), dim3(threads), lds, s, a);
     return hipGetLastError();
+}
+// threads: of the one-lane-per-bin variant; the eight-lane one takes up to 1024
+template <int QT, int LT, bool COMPAT>
+hipError_t launch_t(const NfArgs &a, int B, int threads, size_t lds, hipStream_t s) {
+    const char *ev = getenv("LWS_NOFUTURE_SERIAL_TAPS");   // verification only: one lane sums every tap, in the generic engine's order
+    if (ev && ev[0] == '1') return launch_ts<QT, LT, COMPAT, false>(a, B, threads, lds, s);
+    int t8 = threads * 4;
+    if (t8 > 1024) t8 = 1024;
+    return launch_ts<QT, LT, COMPAT, true>(a, B, t8, lds, s);
 }
 
 struct NfShape { int NR, threads; size_t lds; bool ok; };

@@ -1,7 +1,9 @@
 """GPU (-m gpu): the LDS-resident no-future kernel (lws_nofuture.hip) against the order-exact generic engine -- which the
-goldens pin to the reference (tests/test_gpu_parity.py, tests/test_gpu_compat.py) -- bit for bit in fp32, over both
-addressing modes (NoFuture_LWSanyQ semantics and the shipped NoFuture_LWSQ4's flat offset, lwslib.cpp:538-617), several
-Q and L, multi-sweep schedules and the tiny frames where the compat rounds degenerate; plus the oracle in fp64."""
+goldens pin to the reference (tests/test_gpu_parity.py, tests/test_gpu_compat.py) -- over both addressing modes
+(NoFuture_LWSanyQ semantics and the shipped NoFuture_LWSQ4's flat offset, lwslib.cpp:538-617), several Q and L, multi-sweep
+schedules and the tiny frames where the compat rounds degenerate; plus the oracle in fp64.  The kernel's verification variant
+(LWS_NOFUTURE_SERIAL_TAPS=1: one lane sums the taps of a bin in the generic engine's order) must match bit for bit in fp32;
+the production variant (eight lanes per bin, partial sums combined across lanes) re-associates the sum."""
 import numpy as np
 import pytest
 
@@ -21,7 +23,7 @@ def weights(fsize, fshift, L):
     (2048, 512, 5, 20, True), (64, 32, 5, 50, False), (64, 8, 5, 30, False), (48, 16, 3, 25, False),
     (64, 16, 3, 25, True), (64, 16, 1, 25, True), (128, 32, 7, 25, True), (16, 4, 5, 30, True), (20, 5, 5, 30, True),
     (24, 6, 5, 30, True)])
-def test_lds_kernel_equals_generic_engine_bit_for_bit(fsize, fshift, L, T, compat):
+def test_lds_kernel_equals_generic_engine_bit_for_bit(fsize, fshift, L, T, compat, monkeypatch):
     rng = np.random.default_rng(fsize + T + L)
     F = fsize // 2 + 1
     if L > F - 2:
@@ -32,6 +34,7 @@ def test_lds_kernel_equals_generic_engine_bit_for_bit(fsize, fshift, L, T, compa
     lds = _capi.Plan(F, W, nofuture_q4_compat=compat)
     gen = _capi.Plan(F, W, nofuture_q4_compat=compat, force_generic=True)
     for thr in ([0.0], [0.9, 0.4, 0.0]):
+        monkeypatch.setenv("LWS_NOFUTURE_SERIAL_TAPS", "1")
         a = lds.nofuture(S, thr)
         name = lds.last_kernel()["name"]
         Q = W.shape[1]
@@ -39,6 +42,23 @@ def test_lds_kernel_equals_generic_engine_bit_for_bit(fsize, fshift, L, T, compa
         b = gen.nofuture(S, thr)
         assert gen.last_kernel()["name"] == "generic_fp32"
         assert np.array_equal(a, b), (fsize, fshift, L, T, compat, len(thr))
+        # production variant: the same bins updated to the same magnitudes; values within rounding where rounding stays
+        # rounding (the shipped Q4 addressing chains the bins of a frame and amplifies it: median only)
+        monkeypatch.delenv("LWS_NOFUTURE_SERIAL_TAPS")
+        c = lds.nofuture(S, thr)
+        assert lds.last_kernel()["name"] == name
+        assert np.abs(np.abs(c) - np.abs(b)).max() < 2e-6 * np.abs(S).max()
+        S32 = S.astype(np.complex64)
+        assert np.array_equal(c == S32, b == S32)                   # the same bins were left alone
+        err = np.abs(c - b)
+        if compat and Q == 4:
+            # the shipped addressing is chaotic from frame to frame (two correct fp32 engines, or fp32 and fp64, decorrelate
+            # within ~30 frames: rel-L2 1.0 between the fp32 generic engine and the fp64 oracle): values on the first frames
+            assert np.median(err[:, :2]) < 2e-6 * np.mean(np.abs(S)) and np.quantile(err[:, 0], 0.99) < 1e-3 * np.mean(np.abs(S))
+        else:
+            # (rounding grows from frame to frame here too, only slower: 1e-7 on the first frames, 1e-3 after 40)
+            assert np.median(err[:, :2]) < 2e-6 * np.mean(np.abs(S)) and np.median(err) < 1e-4 * np.mean(np.abs(S))
+            assert np.linalg.norm(err) < 5e-2 * np.linalg.norm(b), np.linalg.norm(err) / np.linalg.norm(b)
     lds.close(); gen.close()
 
 
@@ -62,8 +82,9 @@ def test_compat_rounds_on_tiny_frames_against_the_oracle(oracle, fsize, fshift):
     # frame, and rounding is amplified along the chain until single fp32 values say little -- tests/test_gpu_parity.py)
 
 
-def test_config3_nofuture_stage_time_and_values():
-    """256 x 500 x 513 (BASELINE config 3's first stage): one sweep; same bits as the generic engine on a sample."""
+def test_config3_nofuture_stage_time_and_values(monkeypatch):
+    """256 x 500 x 513 (BASELINE config 3's first stage): one sweep; the verification variant gives the generic engine's bits
+    on a sample, the production variant the same magnitudes."""
     import torch
     rng = np.random.default_rng(1)
     p = lws_amd.lws(1024, 256, mode="music")
@@ -74,9 +95,14 @@ def test_config3_nofuture_stage_time_and_values():
     stream = torch.cuda.current_stream().cuda_stream
     p.plan().nofuture_dev(t.data_ptr(), B, T, thr, wsel=1, stream=stream)
     info = p.plan().last_kernel()
-    assert info["name"] == "nofuture_lds_q4compat_fp32" and info["ms"] < 9.0, info   # (the generic engine needs 17 ms)
+    assert info["name"] == "nofuture_lds_q4compat_fp32" and info["ms"] < 5.6, info   # (the generic engine needs 17 ms, one lane per bin 6.2)
     pg = lws_amd.lws(1024, 256, mode="music", force_generic=True)
     t2 = torch.from_numpy(M[:4]).cuda()
     pg.plan().nofuture_dev(t2.data_ptr(), 4, T, thr, wsel=1, stream=stream)
     torch.cuda.synchronize()
-    assert torch.equal(t[:4], t2)
+    assert float((t[:4].abs() - t2.abs()).abs().max()) < 2e-6 * float(np.abs(M).max())
+    monkeypatch.setenv("LWS_NOFUTURE_SERIAL_TAPS", "1")
+    t3 = torch.from_numpy(M[:4]).cuda()
+    p.plan().nofuture_dev(t3.data_ptr(), 4, T, thr, wsel=1, stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(t3, t2)
