@@ -1133,6 +1133,92 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     }
 }
 
+#if LWS_Q8
+// The same with one lane per (sweep slot, frame offset r): 48 weights in one lane's dependent chain cost the service wave as
+// much as a helper wave's frame pair, in the very pair in which the helpers sum.  Lane slot*Q + r sums the taps of frames
+// m-+r (r = 0: the frame's own bins C-k and their images), the Q partial sums are combined across the lanes, lane r = 0
+// re-projects and stores.  (Weights from the LDS table: the row is a per-lane index.)
+template <int Q, int L, bool MULTI, bool H16>
+__device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceState &sv, int lane, int t0, int wg, int n_eff,
+                                                     int n_groups, const float *thr_eff, void *state_nyq_b,
+                                                     const void *amp_nyq_b) {
+    static_assert(Q == 8 && NSLOTS * Q < LANES, "one lane per (slot, frame offset), then the loader lane");
+    constexpr int K1 = L + 1;
+    const int C = a.C, Kr = a.Kr;
+    const int ablk = (t0 >> 3);
+    const int slot = lane / Q, r = lane - slot * Q;
+    const bool is_nyq_lane = lane < NSLOTS * Q;
+    const bool is_nyq_loader = lane == NSLOTS * Q;
+    const int v0 = t0 - (is_nyq_lane ? (slot + 1) * LAG : 0);
+    const int vrow = (v0 - C) / SKEW;            // virtual frame whose Nyquist bin is due now (SKEW | v0 - C)
+    const int rho = vrow & (ROWL - 1), kap = vrow >> ROWL_SHIFT;
+    const int gl = kap / Kr, k_ = kap - gl * Kr;
+    const int g = MULTI ? gl * a.nwg + wg : gl;
+    const int me = k_ * ROWL + rho;
+    const int j = g * NSLOTS + (is_nyq_lane ? slot : -1);
+    const bool valid = (v0 - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
+    if (is_nyq_loader) {
+        const float2 nin = raw_value<H16>(sv.nyq_in_next);
+        lds_write(NYQ_OFF + rho * 8, nin);
+        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, nin);
+        const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
+        const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
+        if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2<H16>(state_nyq_b, me1);
+    }
+    if (is_nyq_lane) {
+        const float target = raw_real<H16>(sv.nyq_amp_next);
+        const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
+        const float thr = thr_eff[valid ? j : 0];
+        const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
+        const int ln = (rho - r) & (ROWL - 1), lo = (rho + r) & (ROWL - 1);
+        // the taps at times -SKEW r - k (frame m-r, this sweep) and SKEW r - k - LAG (frame m+r, previous sweep): r whole ring
+        // blocks before / after the block of time -k
+        const int bn = set_new + ((ablk - r - 1) & (NBLK - 1)) * BLK_BYTES + (ln + HALO) * LANE_B;
+        const int bo = set_old + ((ablk + r - 1) & (NBLK - 1)) * BLK_BYTES + (lo + HALO) * LANE_B;
+        const int nn = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln * 8, no = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
+        const bool centre = r == 0;                 // its "frame m+r" terms are the images: dn = 0 below gives b = up, c = conj(up)
+        const float2 zero = make_float2(0.f, 0.f);
+        float2 acc = zero;
+        {
+            const float2 un = lds_read(nn), dn = lds_read(no);
+            pair_rot<0>(acc, nyq_weight(a, r * K1), centre ? zero : un, centre ? zero : dn);
+        }
+        static_for<L>([&](auto ik) {
+            constexpr int k = decltype(ik)::value + 1, within = 8 - k;
+            constexpr int off = (within >> 1) * PAIR_BYTES + (within & 1) * 8;
+            const float2 up = lds_read(bn + off);
+            float2 dn = lds_read(bo + off);
+            dn = centre ? zero : dn;
+            const float2 bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
+            const float2 csum = make_float2(dn.x + up.x, dn.y - up.y);   // dn + conj(up)
+            pair_rot<0>(acc, nyq_weight(a, r * K1 + k), bsum, csum);
+        });
+        auto dpp = [](float x, auto ctrl) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+        };
+        auto sum8 = [&](float v) {
+            v += dpp(v, std::integral_constant<int, 0xB1>());    // quad_perm [1,0,3,2]
+            v += dpp(v, std::integral_constant<int, 0x4E>());    // quad_perm [2,3,0,1]
+            v += dpp(v, std::integral_constant<int, 0x141>());   // row_half_mirror
+            return v;
+        };
+        acc.x = sum8(acc.x);
+        acc.y = sum8(acc.y);
+        const float2 old = lds_read(no);            // (lane r = 0: the frame's own previous value)
+        const bool active = real_row && (target > thr);
+        const float2 out = project(acc, target, active, old);
+        if (centre) {
+            lds_write(nn, out);
+            lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, out);
+            if ((slot == NSLOTS - 1) && (v0 - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2<H16>(state_nyq_b, me, out, MULTI);
+        }
+        const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
+        const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
+        sv.nyq_amp_next = (vr1 >= 0 && me1 < a.Tp) ? load_real_raw<H16>(amp_nyq_b, me1) : 0.f;
+    }
+}
+#endif
+
 // MULTI: several workgroups share a spectrogram (a.nwg > 1); the single-workgroup instantiation carries none of it
 template <int Q, int L, uint64_t MASK, bool MULTI, bool H16>
 __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a_in) {
@@ -1455,8 +1541,13 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 if (r_service) {
                     LWS_SETPRIO(3);   // (and back to 0 with everybody else after the publish below)
                     // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
+#if LWS_Q8
+                    if (PA == 0 && hf == 0)
+                        service_nyquist_rows<Q, L, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+#else
                     if (PA == 0 && hf == 0)
                         service_nyquist<Q, L, MASK, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+#endif
                     // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
                     // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
                     int ldb[NBLK], ldu[NBLK], ldh[NBLK];
