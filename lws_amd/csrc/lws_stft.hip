@@ -1,7 +1,9 @@
 // lws_stft.hip -- the steps either side of the LWS path, on the device: STFT, inverse STFT and the consistency measure
 // 20 log10(|S| / |STFT(iSTFT(S)) - S|) of lws.pyx:43-144, for batches of independent signals / spectrograms.
 //
-// One workgroup per frame runs a radix-2 Stockham FFT of the frame size N (a power of two, 32..4096) in LDS, fp32;
+// One workgroup per frame runs a radix-2 Stockham FFT of the frame size N (a power of two, 32..2048) in LDS, fp32 -- or, for
+// the other even frame sizes lws.pyx:43-90 accepts (e.g. 48, 1536), a direct DFT against a twiddle table in LDS: N^2 instead
+// of N log N operations per frame, a correct fallback rather than a fast path;
 // the overlap-add is a gather (each output sample sums the <= ceil(N/hop) frames that cover it), so there are no
 // atomics and the result does not depend on scheduling.  Sums of squares for the consistency are accumulated in fp64
 // per frame and reduced in a fixed order.
@@ -29,8 +31,33 @@ constexpr int MAXN = 2048, MINN = 32, FFT_THREADS = 256;   // two N-point comple
 // Complex FFT of n = 2^logn points held in LDS (x: data, y: scratch of the same size), by all threads of the block;
 // Stockham auto-sort, decimation in frequency, natural order in and out.  sign = -1 forward, +1 inverse
 // (unnormalised).  Returns the buffer that holds the result.
+// logn < 0: n is not a power of two -- direct DFT; y then holds 2n entries (the result, then exp(-2 pi j i / n)).
 __device__ float2 *fft_lds(float2 *x, float2 *y, int n, int logn, float sign) {
     const int tid = threadIdx.x, nthr = blockDim.x;
+    if (logn < 0) {
+        float2 *tw = y + n;
+        for (int i = tid; i < n; i += nthr) {
+            float sn, cs;
+            sincospif(2.0f * (float)i / (float)n, &sn, &cs);
+            tw[i] = make_float2(cs, -sn);
+        }
+        __syncthreads();
+        for (int k = tid; k < n; k += nthr) {
+            float ar = 0.f, ai = 0.f;
+            int idx = 0;                                 // (k * i) mod n
+            for (int i = 0; i < n; ++i) {
+                const float2 v = x[i], w = tw[idx];
+                const float wi = sign < 0.f ? w.y : -w.y;
+                ar += v.x * w.x - v.y * wi;
+                ai += v.x * wi + v.y * w.x;
+                idx += k;
+                if (idx >= n) idx -= n;
+            }
+            y[k] = make_float2(ar, ai);
+        }
+        __syncthreads();
+        return y;
+    }
     int ncur = n, s = 1;
     for (int st = 0; st < logn; ++st) {
         const int m = ncur >> 1;
@@ -175,12 +202,13 @@ int ctx_leave(DeviceCtx &c, hipStream_t s) {
     return LWS_OK;
 }
 
-int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+int ilog2(int n) { if (n & (n - 1)) return -1; int l = 0; while ((1 << l) < n) ++l; return l; }   // -1: not a power of two (direct DFT)
+size_t fft_lds_bytes(int N) { return (size_t)((N & (N - 1)) ? 3 : 2) * N * sizeof(float2); }
 
 int check_shape(int device, int B, int M, int N, int hop) {
     if (device < 0 || device >= MAX_DEVICES) return lws::set_error(LWS_ERR_INVALID, "device index %d out of range", device);
     if (B < 0 || M < 1) return lws::set_error(LWS_ERR_INVALID, "empty batch or no frames");
-    if (N < MINN || N > MAXN || (N & (N - 1))) return lws::set_error(LWS_ERR_UNSUPPORTED, "frame size %d: the device FFT serves powers of two in [%d, %d]", N, MINN, MAXN);
+    if (N < MINN || N > MAXN || (N & 1)) return lws::set_error(LWS_ERR_UNSUPPORTED, "frame size %d: the device transform serves even sizes in [%d, %d]", N, MINN, MAXN);
     if (hop < 1 || hop > N) return lws::set_error(LWS_ERR_INVALID, "frame shift %d", hop);
     return LWS_OK;
 }
@@ -231,7 +259,7 @@ int lws_stft_dev(int device, const float *x_dev, int B, int len, int N, int fshi
     DeviceCtx &c = g_ctx[device];
     if ((rc = ctx_enter(c, s))) return rc;
     if ((rc = upload_window(c.win_a, awin, N, s))) return rc;
-    hipLaunchKernelGGL(k_stft_frames, dim3(M, B), dim3(FFT_THREADS), 2 * N * sizeof(float2), s, x_dev, len, len,
+    hipLaunchKernelGGL(k_stft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s, x_dev, len, len,
                        perfectrec ? prepad(N, fshift) : 0, static_cast<const float *>(c.win_a.p),
                        static_cast<float2 *>(S_dev), nullptr, nullptr, M, N, ilog2(N), fshift);
     STFT_TRY(hipGetLastError());
@@ -253,7 +281,7 @@ int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift
     const int Tfull = fshift * (M - 1) + N, out_len = lws_istft_length(M, N, fshift, perfectrec);
     if ((rc = c.frames.ensure((size_t)B * M * N * sizeof(float)))) return rc;
     if ((rc = c.signal.ensure((size_t)B * Tfull * sizeof(float)))) return rc;
-    hipLaunchKernelGGL(k_istft_frames, dim3(M, B), dim3(FFT_THREADS), 2 * N * sizeof(float2), s,
+    hipLaunchKernelGGL(k_istft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s,
                        static_cast<const float2 *>(S_dev), static_cast<float *>(c.frames.p),
                        static_cast<const float *>(c.win_s.p), M, N, ilog2(N));
     hipLaunchKernelGGL(k_overlap_add, dim3((Tfull + 255) / 256, B), dim3(256), 0, s, static_cast<const float *>(c.frames.p),
@@ -285,14 +313,14 @@ int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int 
     if ((rc = c.rows.ensure((size_t)B * M * 2 * sizeof(double)))) return rc;
     if ((rc = c.out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
     const float2 *S = static_cast<const float2 *>(S_dev);
-    hipLaunchKernelGGL(k_istft_frames, dim3(M, B), dim3(FFT_THREADS), 2 * N * sizeof(float2), s, S,
+    hipLaunchKernelGGL(k_istft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s, S,
                        static_cast<float *>(c.frames.p), static_cast<const float *>(c.win_s.p), M, N, ilog2(N));
     // with perfectrec the reference cuts the first prepad and the last N - hop samples and the forward transform pads
     // zeros back in their place (same frame count): the full overlap-add signal with those samples zeroed
     hipLaunchKernelGGL(k_overlap_add, dim3((Tfull + 255) / 256, B), dim3(256), 0, s, static_cast<const float *>(c.frames.p),
                        static_cast<float *>(c.signal.p), M, N, fshift, Tfull, perfectrec ? prepad(N, fshift) : 0,
                        perfectrec ? N - fshift : 0);
-    hipLaunchKernelGGL(k_stft_frames, dim3(M, B), dim3(FFT_THREADS), 2 * N * sizeof(float2), s,
+    hipLaunchKernelGGL(k_stft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s,
                        static_cast<const float *>(c.signal.p), Tfull, Tfull, 0, static_cast<const float *>(c.win_a.p),
                        static_cast<float2 *>(nullptr), S, static_cast<double *>(c.rows.p), M, N, ilog2(N), fshift);
     hipLaunchKernelGGL(k_sum_rows, dim3((B + 63) / 64), dim3(64), 0, s, static_cast<const double *>(c.rows.p),

@@ -10,7 +10,8 @@ import lws_amd
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fsize,fshift", [(64, 16), (128, 64), (512, 128), (1024, 256), (2048, 512), (256, 96)])
+@pytest.mark.parametrize("fsize,fshift", [(64, 16), (128, 64), (512, 128), (1024, 256), (2048, 512), (256, 96),
+                                          (48, 16), (1536, 384), (1000, 250)])   # (the last three: not powers of two, direct DFT)
 @pytest.mark.parametrize("perfectrec", [True, False])
 def test_stft_istft_match_host(fsize, fshift, perfectrec):
     rng = np.random.default_rng(fsize + fshift)
@@ -30,7 +31,7 @@ def test_stft_istft_match_host(fsize, fshift, perfectrec):
     assert np.abs(p.istft_dev(ref[1]).cpu().numpy() - yref[1]).max() < 3e-6 * np.abs(yref).max()
 
 
-@pytest.mark.parametrize("fsize,fshift", [(64, 16), (512, 128), (1024, 256), (1024, 512)])
+@pytest.mark.parametrize("fsize,fshift", [(64, 16), (512, 128), (1024, 256), (1024, 512), (48, 16), (1536, 384)])
 @pytest.mark.parametrize("perfectrec", [True, False])
 def test_consistency_matches_host(fsize, fshift, perfectrec):
     rng = np.random.default_rng(3 * fsize + fshift)
@@ -58,9 +59,9 @@ def test_consistency_matches_host(fsize, fshift, perfectrec):
 
 
 def test_unsupported_frame_sizes_raise():
-    p = lws_amd.lws(48, 16)                      # not a power of two
+    p = lws_amd.lws(4096, 1024)                  # beyond the LDS-resident transform
     with pytest.raises(lws_amd.LwsHipError):
-        p.get_consistency_dev(np.ones((5, 25), complex))
+        p.get_consistency_dev(np.ones((5, 2049), complex))
 
 
 @pytest.mark.gpu
