@@ -4,7 +4,7 @@
 // One workgroup (8 waves = 2 per SIMD: 7 sweep slots and a service wave that loads from HBM, computes the Nyquist
 // bins and writes the results back) owns one spectrogram and keeps I = 7 consecutive sweeps in flight.  A lane is a
 // (sweep, frame) processor that marches along the bins of its frame,
-// one bin per step; the 64 lanes of compute wave i work on 64 consecutive frames of sweep
+// one bin per step (two per rendez-vous: pairs of an even and an odd bin); the 64 lanes of compute wave i work on 64 consecutive frames of sweep
 // "iteration g*I + i", frame m trailing frame m-1 by SKEW = 8 bins, and sweep j+1 trailing sweep j
 // by LAG = 32 steps:
 //
@@ -33,8 +33,9 @@
 // computed by the service wave (one lane per sweep in flight), which also runs the loader.
 //
 // Scope of this kernel: summarised weights with the twiddle structure create_weights produces
-// (lws.pyx:160-181: W[p][r][k] = W[0][r][k]*exp(2j*pi*p*r/Q)), Q in {2,4}, L <= 7 and (Q-1)*8+L+1 <= 32,
-// F-1 a multiple of 8 and <= 512, fp32.  Anything else is served by the generic engine.
+// (lws.pyx:160-181: W[p][r][k] = W[0][r][k]*exp(2j*pi*p*r/Q)), Q in {2,4} with L in {3,5}, or Q = 8 with L = 5 (its own
+// build: 64-step ring, a main and two helper waves per sweep slot), F-1 a multiple of 8 and <= 512 (<= 1024: the wide build),
+// fp32 arithmetic, fp32 or fp16 storage.  Anything else is served by the generic engine.
 #include "lws_systolic.h"
 
 #include <cmath>
@@ -322,9 +323,9 @@ template <bool H16> __device__ __forceinline__ void store_l2(void *base, size_t 
 }
 
 // ---- synchronisation between the waves of a workgroup -----------------------------------------------------
-// The step loop works on PAIRS of consecutive bins (phases 1+2, 3+4, 5+6, 7+0'): every tap of both bins, except the
-// lane's own previous output, is at least 2 steps old when the pair starts, and nothing older than 30 steps is
-// ever read while a ring slot is rewritten after 32.  A wave may therefore start a pair as soon as the waves it
+// The step loop works on PAIRS of consecutive bins (phases 0+1, 2+3, 4+5, 6+7): every tap of both bins, except the
+// lane's own previous output, was produced before the pair starts (the newest one -- frame m-1, tap +L of the second bin --
+// in the pair before), and nothing older than RING - 2 steps is ever read while a ring slot is rewritten after RING.  A wave may therefore start a pair as soon as the waves it
 // exchanges data with -- its producer (previous slot, or the service wave), its consumer (next slot) and the
 // service wave -- have completed the previous pair.  Each wave publishes the first step it has not completed yet
 // in LDS; LDS executes the operations of one wave in program order and all ring accesses are volatile (compiler
@@ -355,7 +356,7 @@ struct LaneCtx {
     float thr, nxt_thr;
     // image cells: byte offset from the lane's own origin ob[m] to the pseudo-lane's, minus what the compile-time offset
     // of the neighbour frame DR adds -- for the lane at the start (lo: PLL) / end (hi: PLR) of its frame; zero for every
-    // other lane.  [DR + HALO]; lo_nxt: for the first bin of the following block (second bin of the pair (7, 0'))
+    // other lane.  [DR + HALO]
     int wlo[NDR], whi[NDR];
     int mbox;                       // Q = 8: mailbox of the slot's first helper, pair 0 (own lane)
     int img_lo, img_hi, img_both;   // image_base(): row origin for the image stores of this block (phases with an image below DC / above
@@ -1368,7 +1369,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     float amp_cur[8], amp_nxt[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) amp_cur[i] = amp_nxt[i] = 0.f;
-    QuadCarry<L> qc;   // sweep slots: what the pair (1,2) of a block hands to the pair (3,4)
+    QuadCarry<L> qc;   // sweep slots: what the first pair of a quad hands to the second
     bool wb_cur = false, wb_prev = false;   // service wave: does the last slot's lane have a bin to write back in this / the previous block
     ServiceState sv;
     sv.nyq_amp_next = 0.f;
