@@ -33,7 +33,7 @@
 // computed by the service wave (one lane per sweep in flight), which also runs the loader.
 //
 // Scope of this kernel: summarised weights with the twiddle structure create_weights produces
-// (lws.pyx:160-181: W[p][r][k] = W[0][r][k]*exp(2j*pi*p*r/Q)), Q in {2,4} with L in {3,5}, or Q = 8 with L = 5 (its own
+// (lws.pyx:160-181: W[p][r][k] = W[0][r][k]*exp(2j*pi*p*r/Q)), Q in {2,4} with L in {1,3,5}, or Q = 8 with L = 5 (its own
 // build: 64-step ring, a main and two helper waves per sweep slot), F-1 a multiple of 8 and <= 512 (<= 1024: the wide build),
 // fp32 arithmetic, fp32 or fp16 storage.  Anything else is served by the generic engine.
 #include "lws_systolic.h"
@@ -2036,7 +2036,7 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
 #if LWS_Q8
     if (Qp != Q || Q != 8 || L != 5) return hipSuccess;
 #else
-    if (Qp != Q || !(Q == 2 || Q == 4) || !(L == 5 || L == 3)) return hipSuccess;
+    if (Qp != Q || !(Q == 2 || Q == 4) || !(L == 5 || L == 3 || L == 1)) return hipSuccess;
 #endif
     if (C % SKEW != 0 || C > ROWP || C < 16) return hipSuccess;
     if ((Q - 1) * SKEW + L + 1 > LAG) return hipSuccess;
@@ -2239,6 +2239,8 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
 #else
     if (L == 3) {
         e = Q == 4 ? launch_k<4, 3, mask_all(4, 3)>(a, grid, h, stream) : launch_k<2, 3, mask_all(2, 3)>(a, grid, h, stream);
+    } else if (L == 1) {
+        e = Q == 4 ? launch_k<4, 1, mask_all(4, 1)>(a, grid, h, stream) : launch_k<2, 1, mask_all(2, 1)>(a, grid, h, stream);
     } else if (Q == 4) {
         if (tb->mask == MASK_Q4_L5_DEFAULT && tb->k0real && tb->r13) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT | FLAG_K0REAL | FLAG_R13>(a, grid, h, stream); kind = "hann"; }
         else if (tb->mask == MASK_Q4_L5_DEFAULT) { e = launch_k<4, 5, MASK_Q4_L5_DEFAULT>(a, grid, h, stream); kind = "hannmask"; }

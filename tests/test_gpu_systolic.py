@@ -59,16 +59,18 @@ def test_bin_counts_and_q(oracle, fsize, fshift):
 
 
 @pytest.mark.parametrize("fsize,fshift,L,T", [(64, 16, 3, 70), (1024, 256, 3, 37), (1024, 512, 3, 37), (2048, 512, 3, 140),
-                                              (128, 32, 3, 131), (2048, 1024, 3, 40)])
+                                              (128, 32, 3, 131), (2048, 1024, 3, 40), (64, 16, 1, 70), (1024, 256, 1, 37),
+                                              (1024, 512, 1, 37), (2048, 512, 1, 40)])
 def test_other_stencil_widths(oracle, fsize, fshift, L, T):
-    """class lws takes any L (lws.pyx:379); L = 3 (Q = 2, 4) runs on the systolic kernels too (all taps: the specialised
-    zero patterns are those of the default L = 5 weights), narrow and wide build.  (L = 1, 7 and even L: generic engine.)"""
+    """class lws takes any L (lws.pyx:379); L = 1 and 3 (Q = 2, 4) run on the systolic kernels too (all taps: the specialised
+    zero patterns are those of the default L = 5 weights), narrow and wide build.  (L = 7 -- its newest tap would be produced
+    in the very pair that reads it -- and even L: generic engine.)"""
     run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], seed=fsize + L, B=2, scale=[1.0, 40.0], L=L)
     p = lws_amd.lws(fsize, fshift, L=L)
     p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
     name = p.plan().last_kernel()["name"]
     assert name.startswith("systolic") and ("_l%d_" % L) in name, name
-    for Lg in (1, 4, 7):
+    for Lg in (4, 7):
         pg = lws_amd.lws(fsize, fshift, L=Lg)
         pg.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
         assert pg.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
