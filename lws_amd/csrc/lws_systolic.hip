@@ -970,7 +970,8 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
                 if constexpr (Q > LATE_DN) quad_finish_plain<Q, L, MASK, PHB, LATE_DN>(a, qc, d3[2 * L + 4], accB);
             }
         }
-        LWS_SETPRIO(2);
+        // (the light pair of a quad is all tail; one wave per slot: 33.6 -> 33.3 ms at the service wave's priority)
+        if constexpr (LWS_WIDE || LWS_Q8) LWS_SETPRIO(2); else LWS_SETPRIO(3);
     }
     // ---- first bin
     const float tA = amp_cur[PA];
