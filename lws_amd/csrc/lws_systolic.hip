@@ -970,8 +970,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
                 if constexpr (Q > LATE_DN) quad_finish_plain<Q, L, MASK, PHB, LATE_DN>(a, qc, d3[2 * L + 4], accB);
             }
         }
-        // (the light pair of a quad is all tail; one wave per slot: 33.6 -> 33.3 ms at the service wave's priority)
-        if constexpr (LWS_WIDE || LWS_Q8) LWS_SETPRIO(2); else LWS_SETPRIO(3);
+        LWS_SETPRIO(2);   // (priority 3 here measured the same within run-to-run noise on one box)
     }
     // ---- first bin
     const float tA = amp_cur[PA];
