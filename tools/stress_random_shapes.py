@@ -1,0 +1,44 @@
+"""Random shapes and schedules: the systolic kernels (all three builds, fp32 and fp16 storage, L in {1, 3, 5}) against the
+order-exact generic engine in fp32; a few sweeps, so that rounding differences stay small -- except from a zero-phase start
+(real, non-negative input: the run_lws(abs(X)) case), where weighted sums nearly cancel and two correct fp32 engines, or fp32
+and fp64, drift apart from some frame on (rel-L2 of a percent or more after one sweep): there the typical bin is checked.  usage: PYTHONPATH=. python
+tools/stress_random_shapes.py [cases] [seed]"""
+import sys
+import numpy as np
+import lws_amd
+from lws_amd import _capi
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+cfgs = [(64, 16), (64, 32), (64, 8), (128, 32), (128, 64), (128, 16), (256, 64), (256, 32), (512, 128), (512, 64), (1024, 256),
+        (1024, 512), (1024, 128), (2048, 512), (2048, 1024), (1536, 384), (1040, 260)]
+worst, bad = 0.0, 0
+for it in range(cases):
+    fs, sh = cfgs[rng.integers(len(cfgs))]
+    Q = fs // sh
+    L = 5 if Q == 8 else int(rng.choice([1, 3, 5, 5, 5]))
+    F = fs // 2 + 1
+    T = int(rng.integers(1, 200 if fs <= 1100 else 120))
+    B = int(rng.integers(1, 4))
+    n = int(rng.integers(1, 16))
+    p = lws_amd.lws(fs, sh, L=L)
+    S = rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))
+    zero_phase = rng.random() < 0.3
+    if zero_phase:
+        S = np.abs(S) + 0j
+    S *= 10.0 ** rng.uniform(-3, 3)
+    thr = np.sort(rng.random(n) * 1.5)[::-1].copy()
+    a = p.plan().batch(S, thr)
+    name = p.plan().last_kernel()["name"]
+    g = _capi.Plan(F, p.W, force_generic=True)
+    b = g.batch(S, thr)
+    g.close()
+    rel = np.linalg.norm(a - b) / np.linalg.norm(b)
+    mag = np.abs(np.abs(a) - np.abs(b)).max() / np.abs(S).max()
+    med = np.median(np.abs(a - b)) / np.mean(np.abs(S))
+    ok = (rel < (0.3 if zero_phase else 3e-3)) and med < 2e-6 and mag < 2e-6 and np.isfinite(a).all()
+    worst = max(worst, rel)
+    bad += not ok
+    print(f"{fs:5d} {sh:4d} L={L} B={B} T={T:4d} n={n:2d} {name:30s} rel {rel:.2e} mag {mag:.1e}{'' if ok else '   <<<<<<<<'}", flush=True)
+print("worst rel", worst, "failures", bad)
+sys.exit(1 if bad else 0)
