@@ -1,3 +1,5 @@
+"""Time one batch call of config 2's volume at hop 256 (Q = 4) and hop 128 (Q = 8), three times each: for A/B runs of kernel
+variants on ONE box (LWS_HIP_LIB=... selects the library; boxes of the pool differ by ~2 %).  usage: PYTHONPATH=. python tools/time_batch_shapes.py"""
 import numpy as np, time, torch
 import lws_amd
 from lws_amd import _capi
