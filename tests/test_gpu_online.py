@@ -85,6 +85,27 @@ def test_small_shapes_vs_oracle(tag, T, LA, layout, oracle, monkeypatch):
     assert np.abs(np.abs(out) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
 
 
+@pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(1024, 256, 10, 3, 2), (1024, 256, 16, 3, 3), (512, 128, 12, 3, 3),
+                                                    (1024, 512, 12, 3, 3), (512, 64, 10, 2, 2)])
+@pytest.mark.parametrize("layout", ["2", "3"])
+def test_production_variant_vs_oracle_at_full_frame_sizes(fsize, fshift, T, LA, iters, layout, oracle, monkeypatch):
+    """The production tap order (per-lane / per-wave partial sums, windows in registers, the projection wave's late terms)
+    against the fp64 oracle at the frame sizes of the BASELINE configs, on runs short enough (a dozen frames, 2-3
+    iterations) for fp32 rounding to stay rounding: values, not just magnitudes."""
+    monkeypatch.setenv("LWS_ONLINE_LAYOUT", layout)
+    rng = np.random.default_rng(fsize + T)
+    p = lws_amd.lws(fsize, fshift, mode="music")
+    F = fsize // 2 + 1
+    S = rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.1, 1)
+    ref = oracle.online_lws(S, p.W, p.W_ai, p.W_af, thr, LA, fshift)
+    out, name = _online(F, (p.W, p.W_ai, p.W_af), S, thr, LA, fsize / fshift)
+    assert name == "online_lds_fp32"
+    err, scale = np.abs(out - ref), np.mean(np.abs(S))
+    assert np.median(err) < 1e-6 * scale and np.linalg.norm(err) < 2e-4 * np.linalg.norm(ref)
+    assert np.abs(np.abs(out) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
+
+
 def test_fallbacks_to_generic():
     """Shapes the LDS ring cannot hold, and fp64 plans, stay on the generic engine."""
     rng = np.random.default_rng(0)
