@@ -2235,7 +2235,10 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     hipError_t e;
     const char *kind = "allmask";
 #if LWS_Q8
-    e = launch_k<8, 5, mask_all(8, 5)>(a, grid, h, stream);
+    // default sqrt-Hann weights at hop = window / 8: r = 0: {0,1}, r = 4: {0,1,2,4}, every other row all six taps
+    constexpr uint64_t MASK_Q8_L5_DEFAULT = 0b111111'111111'111111'010111'111111'111111'111111'000011ull;
+    if (tb->mask == MASK_Q8_L5_DEFAULT && tb->k0real) { e = launch_k<8, 5, MASK_Q8_L5_DEFAULT | FLAG_K0REAL>(a, grid, h, stream); kind = "hann"; }
+    else e = launch_k<8, 5, mask_all(8, 5)>(a, grid, h, stream);
 #else
     if (L == 3) {
         e = Q == 4 ? launch_k<4, 3, mask_all(4, 3)>(a, grid, h, stream) : launch_k<2, 3, mask_all(2, 3)>(a, grid, h, stream);

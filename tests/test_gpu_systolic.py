@@ -86,7 +86,7 @@ def test_q8(oracle, fsize, fshift, T, n_it):
     run_case(oracle, fsize, fshift, T, thr, seed=fsize + T, B=2, scale=[1.0, 25.0])
     p = lws_amd.lws(fsize, fshift)
     p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
-    assert p.plan().last_kernel()["name"].startswith("systolic_q8_l5"), p.plan().last_kernel()
+    assert p.plan().last_kernel()["name"] == "systolic_q8_l5_hann", p.plan().last_kernel()
 
 
 def test_dropped_sweeps_and_mixed_schedules(oracle):
