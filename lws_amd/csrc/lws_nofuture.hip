@@ -136,8 +136,11 @@ __device__ __forceinline__ void nf_update_split(int n, int j, int me, float th, 
     const float2 *wb = W + rowneg * RQ;
     const int nterms = (Q - 1) * K1, wrap_at = Np - 2 * n;
     float2 acc = make_float2(0.f, 0.f);
+    // tap groups t = j, j + 8, ... < nterms = (Q-1)(L+1); with a run-time L or Q only the bound of shape_of is known
+    // (Q (L+1) <= 64: one participation mask per weight row), so eight rounds cover every admitted shape
+    constexpr int NIT = (QT && LT) ? ((QT - 1) * (LT + 1) + 7) / 8 : 8;
 #pragma unroll
-    for (int i = 0; i < ((QT ? QT : 8) - 1) * ((LT ? LT : 7) + 1) / 8 + 1; ++i) {
+    for (int i = 0; i < NIT; ++i) {
         const int t = j + 8 * i;
         if (t < nterms) {
             const int r = t / K1 + 1, k = t - (r - 1) * K1, u = r * K1;

@@ -44,6 +44,18 @@
 #include <utility>
 
 namespace lws {
+#ifdef LWS_LAB   // tools/lab/online_lab.hip: per-wave phase stamps (block 0), clocks summed over the steps
+#define LAB_N 256
+__device__ unsigned long long g_lab[LAB_N];
+__device__ __forceinline__ unsigned long long lab_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define LAB(...) __VA_ARGS__
+#else
+#define LAB(...)
+#endif
 namespace {
 
 constexpr int NW = 16;  // frames in the LDS ring
@@ -533,9 +545,11 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
         v2f wl[WN];
 #pragma unroll
         for (int i = 0; i < WN; ++i) wl[i] = (v2f){0.f, 0.f};
+        LAB(unsigned long long lab_acc[4] = {0, 0, 0, 0};)
         for (int t = -1; t < t_end; ++t) {
             const int tt = t + 1;               // the step these waves prepare
             const int u = tt - tstart;
+            LAB(const unsigned long long lt0 = lab_now(); unsigned long long lt1 = lt0;)
             if (!SERIAL && valid && u >= 0 && u < NU) {
                 const int c = 2 * u;
                 // the window, columns c-L .. c+L+1 of this wave's frame, fresh from LDS (whatever is written concurrently is
@@ -580,6 +594,7 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
                         });
                     }
                 }
+                LAB(lt1 = lab_now();)
                 // sum w[k] X[c-k] + conj(w[k]) X[c+k] over this wave's frame X, for the bins c (a) and c+1 (b)
                 v2f a14 = {0.f, 0.f}, b14 = {0.f, 0.f};
                 if constexpr (KIND != 2) {       // (the centre frame's own bin is not a tap)
@@ -601,10 +616,14 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
                 cmac_pk(pb, twb, b14);
                 P[((tt & 1) * NTW + wave) * 64 + lane] = make_float4(pa.x, pa.y, pb.x, pb.y);
             }
+            LAB(const unsigned long long lt2 = lab_now();)
             if (tt >= t_done) { s += NSW; setup(); }
             load_frames(t);
+            LAB(const unsigned long long lt3 = lab_now();)
             __syncthreads();
+            LAB(const unsigned long long lt4 = lab_now(); lab_acc[0] += lt1 - lt0; lab_acc[1] += lt2 - lt1; lab_acc[2] += lt3 - lt2; lab_acc[3] += lt4 - lt3;)
         }
+        LAB(if (b == 0 && lane == 0) { for (int i = 0; i < 4; ++i) g_lab[8 + hw_wave * 8 + i] = lab_acc[i]; })
     };
     if (is_idle) {
         for (int t = -1; t < t_end; ++t) { load_frames(t); __syncthreads(); }
@@ -616,8 +635,10 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
         // ------------------------------------------------------------------------------------------ projection wave
         asm volatile("s_setprio 3");            // the dependent chain of a step: ahead of the tap waves of its SIMD
         v2f p1 = {0.f, 0.f}, p2 = {0.f, 0.f};   // current values of columns c-1, c-2 of the unit's frame
+        LAB(unsigned long long lab_acc[4] = {0, 0, 0, 0};)
         for (int t = -1; t < t_end; ++t) {
             const int u = t - tstart;
+            LAB(const unsigned long long lt0 = lab_now(); unsigned long long lt1 = lt0;)
             if (t >= 0 && valid && u >= 0 && u < NU) {
                 const int c = 2 * u, n = c + L;
                 const bool has_b = c + 1 < F;
@@ -680,6 +701,7 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
                     const int stype = (u >= 1 && u <= NLO) ? u : (g < NHI ? NLO + 1 + g : 0);
                     const float4 *et = reinterpret_cast<const float4 *>(ET + (wset * NST + stype) * 6);
                     const float4 e01 = et[0], e23 = et[1], e45 = et[2];
+                    LAB(lt1 = lab_now();)
                     if (u == 0) { p1 = im1; p2 = im2; }
                     v2f accA = {part[0].x, part[0].y}, accB = {part[0].z, part[0].w};
 #pragma unroll
@@ -751,10 +773,14 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
                     p1 = newB;
                 }
             }
+            LAB(const unsigned long long lt2 = lab_now();)
             if (t >= t_done) { s += NSW; setup(); }
             load_frames(t);
+            LAB(const unsigned long long lt3 = lab_now();)
             __syncthreads();
+            LAB(const unsigned long long lt4 = lab_now(); lab_acc[0] += lt1 - lt0; lab_acc[1] += lt2 - lt1; lab_acc[2] += lt3 - lt2; lab_acc[3] += lt4 - lt3;)
         }
+        LAB(if (b == 0 && lane == 0) { for (int i = 0; i < 4; ++i) g_lab[8 + hw_wave * 8 + i] = lab_acc[i]; g_lab[0] = t_end + 1; })
     }
     const int first_row = loaded > NW ? loaded - NW : 0;
     for (int e = first_row; e < loaded; ++e) {

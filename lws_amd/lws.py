@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import collections
 import hashlib
+import threading
 import math
 
 import numpy as np
@@ -192,26 +193,39 @@ _PLAN_DEFAULTS = {"device": 0, "precision": "fp32", "nofuture_q4_compat": True, 
 # their device memory.  Precision: the engine computes in fp32 by default (`precision="fp64"` selects the reference's
 # arithmetic on the order-exact generic engine; tolerances in DESIGN.md section 6); complex128 in, complex128 out either way.
 _PLAN_CACHE_SIZE = 4
-_plan_cache = collections.OrderedDict()
+# One cache per calling thread: the bindings release the GIL around the C call and an lws_plan (scratch, events, stage
+# buffers) serves one call at a time, so a plan shared between threads could be used -- or evicted and destroyed -- while
+# another thread is inside the library with it.  A thread's plans die with the thread (Plan.__del__).
+_plan_tls = threading.local()
+
+
+def _thread_cache():
+    cache = getattr(_plan_tls, "cache", None)
+    if cache is None:
+        cache = _plan_tls.cache = collections.OrderedDict()
+    return cache
 
 
 def _cached_plan(F, Ws, plan_kw):
     kw = {**_PLAN_DEFAULTS, **plan_kw}
     key = (int(F),) + tuple(None if w is None else (w.shape, hashlib.sha1(np.ascontiguousarray(w, dtype=np.complex128).tobytes()).hexdigest())
                             for w in Ws) + tuple(sorted(kw.items()))
-    plan = _plan_cache.pop(key, None)
+    cache = _thread_cache()
+    plan = cache.pop(key, None)
     if plan is None:
         plan = _capi.Plan(F, *Ws, **kw)
-        while len(_plan_cache) >= _PLAN_CACHE_SIZE:
-            _plan_cache.popitem(last=False)[1].close()
-    _plan_cache[key] = plan          # most recently used last
+        while len(cache) >= _PLAN_CACHE_SIZE:
+            cache.popitem(last=False)[1].close()   # (this thread's own plan, and it is not inside a call)
+    cache[key] = plan          # most recently used last
     return plan
 
 
 def clear_plan_cache():
-    """Destroy the plans kept for the module-level batch_lws / nofuture_lws / online_lws (frees their device memory)."""
-    while _plan_cache:
-        _plan_cache.popitem()[1].close()
+    """Destroy the calling thread's plans kept for the module-level batch_lws / nofuture_lws / online_lws (frees their
+    device memory)."""
+    cache = _thread_cache()
+    while cache:
+        cache.popitem()[1].close()
 
 
 def _prepare(S, W, use_simplifications, n_extra_w=()):

@@ -22,7 +22,9 @@ def weights(fsize, fshift, L):
     (64, 16, 5, 40, True), (64, 16, 5, 40, False), (1024, 256, 5, 70, True), (1024, 256, 5, 33, False),
     (2048, 512, 5, 20, True), (64, 32, 5, 50, False), (64, 8, 5, 30, False), (48, 16, 3, 25, False),
     (64, 16, 3, 25, True), (64, 16, 1, 25, True), (128, 32, 7, 25, True), (16, 4, 5, 30, True), (20, 5, 5, 30, True),
-    (24, 6, 5, 30, True)])
+    (24, 6, 5, 30, True),
+    # (Q-1)(L+1) > 32 tap groups: every round of the eight-lane sum is needed (round-2 advisor finding)
+    (256, 64, 10, 25, True), (256, 64, 12, 20, True), (128, 32, 15, 20, True), (256, 64, 12, 20, False)])
 def test_lds_kernel_equals_generic_engine_bit_for_bit(fsize, fshift, L, T, compat, monkeypatch):
     rng = np.random.default_rng(fsize + T + L)
     F = fsize // 2 + 1
