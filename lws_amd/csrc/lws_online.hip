@@ -76,6 +76,7 @@ struct OnlineArgs {
     float2 tw[8];        // exp(2 pi j q / Q), q < Q
     int F, T, n_thr, LA, NSW;
     int DS;              // steps between consecutive sweeps (>= the order-exact minimum, see shape_of)
+    int NWR, NPS;        // k_online4: frames in its LDS ring, row stride (elements, even)
 };
 
 __device__ __forceinline__ void pair(float2 &a, float2 w, float2 b, float2 c) {   // the generic engine's grouped form
@@ -789,6 +790,524 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
     }
 }
 
+
+// =====================================================================================================================
+// Fourth layout (k_online4; default when it fits).  k_online3 is bound by vector-ALU issue on the SIMD that carries three of
+// its seven tap waves (profiles/r03_pmc_sq_online*.json: 863 vector instructions per step and workgroup, of which 7 x 32 are
+// the register moves of the sliding windows and ~7 x 26 index / predicate arithmetic).  Same roles -- one wave per tap group,
+// one projection wave, tap waves one step ahead -- with the per-step overhead removed:
+//   * EVEN lag between sweeps (DS even; SKS is even already), so that every lane of the workgroup is at an even bin pair
+//     u = t - tstart in even steps and at an odd one in odd steps.  The step loop is unrolled by two: the twiddle of a bin
+//     (bin mod Q) is static, and a neighbour-frame tap wave works on a TWO-step window of 2L + 4 columns whose register names
+//     are fixed: no window slides.  Rows of the LDS ring have an even stride, windows start at even columns: every window
+//     read is an aligned 16-byte cell.  At the end of a pair the next pair's first cells -- values the wave already holds --
+//     are simply read again under their new names (LDS has the bandwidth to spare, the vector ALU has not); that read is
+//     issued before the barrier.  A lane that starts a frame needs no special case (it starts at an even step).
+//   * tap waves carry no validity predicate: a lane without work computes on clamped addresses and nobody reads its sums.
+//   * 2Q waves, two per SIMD for Q = 4: the centre-frame wave shares the projection wave's SIMD (no idle wave).
+//   * the ring holds NWR frames (run-time, not a power of two), as many as the look-ahead needs: 2048-point frames fit.
+// SERIAL (verification): as in k_online3, the projection wave sums every tap itself in the generic engine's order.
+template <int Q> struct Online4Waves {
+    static constexpr int N = 2 * Q;
+    static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : 7;
+    static __host__ __device__ constexpr int tap_of(int hw) { return hw == CENTRE ? 0 : hw - (hw > PROJ ? 1 : 0) - (hw > CENTRE ? 1 : 0) + 1; }
+};
+
+// w * v and conj(w) * v as one v_pk_mul_f32 + one v_pk_fma_f32 (no zeroed accumulator)
+__device__ __forceinline__ v2f cmul_pk(v2f w, v2f v) {
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(r) : "v"(w), "v"(v));
+    return r;
+}
+__device__ __forceinline__ v2f cmulc_pk(v2f w, v2f v) {
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
+        : "=&v"(r) : "v"(w), "v"(v));
+    return r;
+}
+// a += w * conj(v)
+__device__ __forceinline__ void cmac_cv_pk(v2f &a, v2f w, v2f v) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "+v"(a) : "v"(w), "v"(v));
+}
+
+template <int Q, int L, bool SERIAL>
+__global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K1 = L + 1, WN = 2 * L + 2, NTW = 2 * Q - 1;
+    constexpr int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2;
+    constexpr int NCELL = WN / 2 + 1;                   // 16-byte cells (two columns) of a two-step window
+    static_assert(SKB >= L + 3 && (SKS & 1) == 0 && (WN & 3) == 0, "two-step windows of aligned cells");
+    const int DS = a.DS;                                // even
+    const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, Np = F + 2 * L, Tp = T + 2 * (Q - 1), N = F - 1;
+    const int NWR = a.NWR, NPS = a.NPS;
+    const int NU = (F + 1) / 2;
+    const int rps = LA + 1, per = a.n_thr + 1;
+    const int nsweeps = T * per;
+    constexpr int NLO = (L + 2) / 4, NHI = (L + 1) / 2 + 1, NST = 1 + NLO + NHI;
+    float4 *P = reinterpret_cast<float4 *>(smem);                               // [2][NTW][64]: (sum of bin c, of bin c+1)
+    float2 *ET = reinterpret_cast<float2 *>(P + 2 * NTW * 64);                  // [3][NST][6] (padded to 192 entries)
+    float2 *S = ET + 192 + 64;                                                  // [NWR][NPS] (+ 8); the 64 entries below it: spare slots
+    float *A = reinterpret_cast<float *>(S + (size_t)NWR * NPS + 8);            // [NWR][NPS]
+    float2 *W = reinterpret_cast<float2 *>(A + (size_t)NWR * NPS);              // [3][Q][Q][K1]
+    float2 *TW = W + 3 * Q * Q * K1;                                            // [Q]
+    float *thr_s = reinterpret_cast<float *>(TW + Q);                           // [n_thr]
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool is_proj = hw_wave == Online4Waves<Q>::PROJ;
+    const int wave = Online4Waves<Q>::tap_of(hw_wave);   // tap group of a tap wave (0: the centre frame)
+    float2 *gS = a.state + (size_t)b * Tp * Np;
+    const float *gA = a.amp + (size_t)b * Tp * Np;
+
+    for (int i = tid; i < 3 * Q * Q * K1; i += nthr) {
+        const int x = i % (Q * Q * K1);
+        W[i] = (x % (Q * K1) == 0) ? make_float2(0.f, 0.f) : a.w[i / (Q * Q * K1)][x];
+    }
+    if (tid < Q) TW[tid] = a.tw[tid];
+    for (int i = tid; i < NWR * NPS + 8; i += nthr) S[i] = make_float2(0.f, 0.f);
+    for (int i = tid; i < NWR * NPS; i += nthr) A[i] = 0.f;
+    for (int i = tid; i < 2 * NTW * 64; i += nthr) P[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (tid < 3 * NST * 6) {   // edge-term weights of the projection wave: as in k_online3
+        const int ws = tid / (NST * 6), st = (tid / 6) % NST, jj = tid % 6;
+        const float2 *wb = W + (ws * Q) * Q * K1;
+        const int d = jj < 3 ? jj : (jj < 5 ? jj - 2 : 0), shift = jj < 3 ? 0 : 1;
+        float2 w = make_float2(0.f, 0.f);
+        if (ws != 1 && st >= 1 && st <= NLO) {
+            const int c = 2 * st, y = c - d, k = c + y + shift;
+            if (y >= 1 && k <= L) w = wb[k];
+        } else if (ws != 1 && st > NLO) {
+            const int g = st - NLO - 1, k = 2 * g + d - shift;
+            if (g + d >= 1 && g + d <= L && k >= 1 && k <= L) w = make_float2(wb[k].x, -wb[k].y);
+        }
+        ET[tid] = w;
+    }
+    if (tid < 64) S[-64 + tid] = make_float2(0.f, 0.f);
+    __syncthreads();
+    for (int i = tid; i < a.n_thr; i += nthr) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
+    int loaded = Q < T + Q - 1 ? Q : T + Q - 1;
+    for (int r0 = 0; r0 < loaded; ++r0)
+        for (int i = tid; i < Np; i += nthr) { S[r0 * NPS + i] = gS[(size_t)r0 * Np + i]; A[r0 * NPS + i] = gA[(size_t)r0 * Np + i]; }
+
+    const int sigma = lane / rps, j = lane - sigma * rps;
+    const bool lane_used = sigma < NSW;
+    const int r = (wave + 1) >> 1, h = (wave == 0) ? 0 : ((wave + 1) & 1);
+    int s = sigma;
+    int rho = 0, tstart = 0, t_done = 0, ts = 1, wset = 0;
+    int fb = 0, ctb = 0, fbm1 = 0;
+    bool valid = false, centre = false;
+    float thr = 0.f;
+    v2f w0[K1];                         // tap waves: W[wset][0][r][k] (side 0) or its conjugate (side 1)
+    v2f twg[Q];                         // tap waves: gain * exp(2 pi j row r / Q) (conjugated on side 1), row = bin % Q
+    v2f wc[K1];                         // projection wave: centre weights W[wset][0][0][k] (zero if the centre frame takes no part)
+    v2f wlate = {0.f, 0.f};             // ... and conj W[wset][0][1][L]
+    auto setup = [&]() {
+        const int m = s / per, q = s - m * per;
+        const int first = m - LA > 0 ? m - LA : 0;
+        if (q == 0) { valid = (j == 0); rho = m; wset = 1; centre = false; ts = 1; thr = 0.f; }
+        else {
+            rho = first + j; valid = rho <= m; wset = (rho == m) ? 2 : 0; centre = true;
+            ts = m - rho + 1; if (ts > Q) ts = Q;
+            thr = thr_s[q - 1];
+        }
+        valid = valid && lane_used && s < nsweeps;
+        tstart = DS * s + SKS * rho;
+        t_done = DS * s + SKS * m + NU - 1;     // even: DS and SKS are, NU is odd
+        const int e = rho + Q - 1;
+        fb = ((h ? e + r : e - r) % NWR) * NPS;
+        ctb = (e % NWR) * NPS;
+        fbm1 = ((e - 1) % NWR) * NPS;
+        const float2 *wb = W + (wset * Q + 0) * Q * K1;
+        if (is_proj) {
+#pragma unroll
+            for (int k = 0; k <= L; ++k) wc[k] = centre ? as_v2f(wb[k]) : (v2f){0.f, 0.f};
+            const float2 wl_ = wb[1 * K1 + L];
+            wlate = (v2f){wl_.x, -wl_.y};
+        } else {
+            float gain;
+            if (h == 0) gain = (r == 0) ? (centre ? 1.f : 0.f) : 1.f;
+            else gain = (r != 0 && r < ts) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k <= L; ++k) {
+                const float2 w = wb[r * K1 + k];
+                w0[k] = (v2f){w.x, h ? -w.y : w.y};
+            }
+#pragma unroll
+            for (int row = 0; row < Q; ++row) {
+                const float2 tw = TW[(row * r) & (Q - 1)];
+                twg[row] = (v2f){gain * tw.x, gain * (h ? -tw.y : tw.y)};
+            }
+        }
+    };
+    __syncthreads();
+    setup();
+
+    const int t_end = DS * (nsweeps - 1) + SKS * (T - 1) + NU;
+    const int n_it = (t_end + 2) & ~1;                  // barrier intervals (t = -1 .. n_it - 2), an even number of them
+    const int frame_period = DS * per + SKS;
+    int next_need = (loaded - (Q - 1)) * frame_period;
+    // bring in the next frame three intervals before its first sweep starts (a tap wave prefetches for the step after next)
+    auto load_frames = [&](int t) {
+        while (loaded < T + Q - 1 && next_need <= t + 4) {
+            const int slot = (loaded % NWR) * NPS;
+            const bool evict = loaded >= NWR;
+            for (int i = tid; i < Np; i += nthr) {
+                if (evict) gS[(size_t)(loaded - NWR) * Np + i] = S[slot + i];
+                S[slot + i] = gS[(size_t)loaded * Np + i];
+                A[slot + i] = gA[(size_t)loaded * Np + i];
+            }
+            ++loaded;
+            next_need += frame_period;
+        }
+    };
+    // rows of the weights' twiddles used by the two bins of a step: (2 PH, 2 PH + 1) mod Q, plus 4 for every other pair when Q = 8
+    auto tw_of = [&](auto ph_c, int u_even, v2f &twa, v2f &twb) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_c)::value;
+        constexpr int R0 = (2 * PH) & (Q - 1);
+        twa = twg[R0]; twb = twg[(R0 + 1) & (Q - 1)];
+        if constexpr (Q == 8) {
+            const bool hi = (u_even & 2) != 0;
+            twa = hi ? twg[R0 + 4] : twa;
+            twb = hi ? twg[R0 + 5] : twb;
+        }
+    };
+
+    // ---- neighbour-frame tap waves.  KIND 0: frames rho-+r, r >= 2, and rho+1; 1: frame rho-1, whose window ends in a column
+    // that is being written (left out, the projection wave adds it) and whose column before that is final only now.
+    auto tap_loop = [&](auto kind_c) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr int NPRE = KIND == 1 ? NCELL - 3 : NCELL - 2;     // cells that may be read a step early
+        v2f wl[2 * NCELL];
+        float4 *pw0 = P + (0 * NTW + wave) * 64 + lane, *pw1 = P + (1 * NTW + wave) * 64 + lane;
+        int ue = 0 - tstart;                                        // bin pair of this lane at the even step of the pair
+        auto cells = [&](int u_even) __attribute__((always_inline)) {
+            const int uc = u_even > -8 ? u_even : -8;               // (a lane far from its start reads in range)
+            return reinterpret_cast<const float4 *>(S + fb + 2 * uc);
+        };
+        auto ld = [&](const float4 *w, auto ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            const float4 q = w[I];
+            wl[2 * I] = (v2f){q.x, q.y}; wl[2 * I + 1] = (v2f){q.z, q.w};
+        };
+        // sums over this wave's frame X for the bins at window columns C0 + L (a) and C0 + L + 1 (b):
+        //   sum_k w[k] X[c-k] + conj(w[k]) X[c+k]
+        auto sums = [&](auto c0_c, v2f twa, v2f twb, float4 *pw) __attribute__((always_inline)) {
+            constexpr int C0 = decltype(c0_c)::value;
+            v2f am = cmul_pk(w0[0], wl[C0 + L]), ap = cmulc_pk(w0[1], wl[C0 + L + 1]);
+            v2f bm = cmul_pk(w0[0], wl[C0 + L + 1]), bp = cmulc_pk(w0[1], wl[C0 + L + 2]);
+            cmac_pk(am, w0[1], wl[C0 + L - 1]);
+            cmac_pk(bm, w0[1], wl[C0 + L]);
+#pragma unroll
+            for (int k = 2; k <= L; ++k) {
+                cmac_pk(am, w0[k], wl[C0 + L - k]);   cmacc_pk(ap, w0[k], wl[C0 + L + k]);
+                cmac_pk(bm, w0[k], wl[C0 + L + 1 - k]);
+                if (!(KIND == 1 && k == L)) cmacc_pk(bp, w0[k], wl[C0 + L + 1 + k]);
+            }
+            const v2f pa = cmul_pk(twa, am + ap), pb = cmul_pk(twb, bm + bp);
+            *pw = make_float4(pa.x, pa.y, pb.x, pb.y);
+        };
+        {   // the first pair's early cells
+            const float4 *w = cells(ue);
+            static_for<NPRE>([&](auto ic) { ld(w, ic); });
+        }
+        LAB(unsigned long long lab_acc[4] = {0, 0, 0, 0};)
+        for (int it = 0; it < n_it; it += 2) {
+            // ---- even step tt = it (interval t = it - 1)
+            LAB(const unsigned long long lt0 = lab_now();)
+            {
+                const float4 *w = cells(ue);
+                static_for<NCELL - 1 - NPRE>([&](auto ic) { ld(w, std::integral_constant<int, NPRE + decltype(ic)::value>{}); });
+                // frame rho-1 is SKB bins ahead, but the Hermitian images of its bins 4 and 5 (columns 1, 0: this lane's first
+                // window) are stored only SKB - 3 bins before this lane starts: final now, not yet when the early cells were read
+                if constexpr (KIND == 1) ld(w, std::integral_constant<int, 0>{});
+                LAB(const unsigned long long lt1 = lab_now(); lab_acc[0] += lt1 - lt0;)
+                v2f twa, twb;
+                tw_of(std::integral_constant<int, 0>{}, ue, twa, twb);
+                if (!SERIAL) sums(std::integral_constant<int, 0>{}, twa, twb, pw0);
+                LAB(lab_acc[1] += lab_now() - lt1;)
+            }
+            LAB(const unsigned long long lt2 = lab_now();)
+            if (it >= t_done) { s += NSW; setup(); ue = it - tstart; }
+            load_frames(it - 1);
+            LAB(const unsigned long long lt3 = lab_now(); lab_acc[2] += lt3 - lt2;)
+            __syncthreads();
+            LAB(const unsigned long long lt4 = lab_now(); lab_acc[3] += lt4 - lt3;)
+            // ---- odd step tt = it + 1
+            {
+                const float4 *w = cells(ue);
+                if constexpr (KIND == 1) ld(w, std::integral_constant<int, NCELL - 2>{});   // its last column is final now
+                ld(w, std::integral_constant<int, NCELL - 1>{});
+                LAB(const unsigned long long lt5 = lab_now(); lab_acc[0] += lt5 - lt4;)
+                v2f twa, twb;
+                tw_of(std::integral_constant<int, 1>{}, ue, twa, twb);
+                if (!SERIAL) sums(std::integral_constant<int, 2>{}, twa, twb, pw1);
+                LAB(lab_acc[1] += lab_now() - lt5;)
+            }
+            LAB(const unsigned long long lt6 = lab_now();)
+            ue += 2;
+            {   // the next pair's early cells: columns this wave has used already, under their new names
+                const float4 *w = cells(ue);
+                static_for<NPRE>([&](auto ic) { ld(w, ic); });
+            }
+            load_frames(it);
+            LAB(const unsigned long long lt7 = lab_now(); lab_acc[2] += lt7 - lt6;)
+            __syncthreads();
+            LAB(lab_acc[3] += lab_now() - lt7;)
+        }
+        LAB(if (b == 0 && lane == 0) { for (int i = 0; i < 4; ++i) g_lab[8 + hw_wave * 8 + i] = lab_acc[i]; })
+    };
+
+    // ---- centre-frame tap wave: its unit's own outputs of this step and the last (columns c-2 .. c, and their Hermitian
+    // images near the frame edges) are left out; the window is read afresh every step
+    auto centre_loop = [&]() __attribute__((always_inline)) {
+        float4 *pw0 = P + (0 * NTW + wave) * 64 + lane, *pw1 = P + (1 * NTW + wave) * 64 + lane;
+        int u = 0 - tstart;
+        auto half = [&](auto ph_c, float4 *pw) __attribute__((always_inline)) {
+            const int uc = u > -8 ? u : -8;
+            const float4 *w = reinterpret_cast<const float4 *>(S + ctb + 2 * uc);
+            v2f wl[WN];
+#pragma unroll
+            for (int i = 0; i < WN / 2; ++i) {
+                const float4 q = w[i];
+                wl[2 * i] = (v2f){q.x, q.y}; wl[2 * i + 1] = (v2f){q.z, q.w};
+            }
+            const int c = 2 * u, g = N - c;
+            if (2 * c <= L + 2 || 2 * g <= L + 1) {
+                static_for<(L + 2) / 4>([&](auto iu) {
+                    constexpr int U = decltype(iu)::value + 1, C = 2 * U;
+                    if (u == U) {
+                        static_for<3>([&](auto id) {
+                            constexpr int D = decltype(id)::value, I = L - 2 * C + D;
+                            if constexpr (C - D >= 1 && I >= 0 && I < WN) wl[I] = (v2f){0.f, 0.f};
+                        });
+                    }
+                });
+                static_for<(L + 1) / 2 + 1>([&](auto ig) {
+                    constexpr int G = decltype(ig)::value;
+                    if (g == G) {
+                        static_for<3>([&](auto id) {
+                            constexpr int D = decltype(id)::value, I = L + 2 * G + D;
+                            if constexpr (G + D >= 1 && G + D <= L && I < WN) wl[I] = (v2f){0.f, 0.f};
+                        });
+                    }
+                });
+            }
+            // bin a (column L): taps -1, -2 are columns L-1, L-2 (left out); bin b (column L+1): taps -1 .. -3 are columns L .. L-2
+            // (at a frame start those columns are the images of bins 1 and 2 as the previous sweep left them: taken here)
+            const bool start = u == 0;
+            const v2f zero = {0.f, 0.f}, s1 = start ? wl[L - 1] : zero, s2 = start ? wl[L - 2] : zero;
+            v2f ap = cmulc_pk(w0[1], wl[L + 1]), bp = cmulc_pk(w0[1], wl[L + 2]);
+            v2f am = cmul_pk(w0[1], s1), bm = cmul_pk(w0[2], s1);
+            cmac_pk(am, w0[2], s2);
+            if (L >= 3) cmac_pk(bm, w0[L >= 3 ? 3 : 0], s2);
+#pragma unroll
+            for (int k = 2; k <= L; ++k) {
+                if (k >= 3) cmac_pk(am, w0[k], wl[L - k]);
+                cmacc_pk(ap, w0[k], wl[L + k]);
+                if (k >= 4) cmac_pk(bm, w0[k], wl[L + 1 - k]);
+                cmacc_pk(bp, w0[k], wl[L + 1 + k]);
+            }
+            v2f twa, twb;
+            tw_of(ph_c, u & ~1, twa, twb);
+            const v2f pa = cmul_pk(twa, am + ap), pb = cmul_pk(twb, bm + bp);
+            if (!SERIAL) *pw = make_float4(pa.x, pa.y, pb.x, pb.y);
+        };
+        for (int it = 0; it < n_it; it += 2) {
+            half(std::integral_constant<int, 0>{}, pw0);
+            if (it >= t_done) { s += NSW; setup(); u = it - tstart; }
+            load_frames(it - 1);
+            __syncthreads();
+            ++u;
+            half(std::integral_constant<int, 1>{}, pw1);
+            ++u;
+            load_frames(it);
+            __syncthreads();
+        }
+    };
+
+    if (!is_proj) {
+        if (wave == 0) centre_loop();
+        else if (wave == 1) tap_loop(std::integral_constant<int, 1>{});
+        else tap_loop(std::integral_constant<int, 0>{});
+    } else {
+        // ------------------------------------------------------------------------------------------ projection wave
+        // The chain every step waits for, so: as few instructions as possible, and no latency in the open.  Per step:
+        // issue the reads of the tap waves' sums; while they are in flight form the unit's own terms (operands fetched
+        // before the barrier); add up; re-project the two bins; store; fetch the operands of the next step; barrier.
+        asm volatile("s_setprio 3");
+        if constexpr (SERIAL) {
+            for (int t = -1; t < n_it - 1; ++t) {
+                const int u = t - tstart;
+                if (t >= 0 && valid && u >= 0 && u < NU) {
+                    const int c = 2 * u, n = c + L;
+                const int e = rho + Q - 1;
+                const float2 zero = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int cb = c + bb, nb = n + bb;
+                    if (cb >= F) break;
+                    const int row = cb % Q, rowneg = (Q - row) % Q;
+                    const float2 *wa = W + wset * Q * Q * K1 + row * Q * K1;
+                    float2 acc = zero;
+                    if (centre) {
+                        const float2 *ctr = S + ctb + nb;
+#pragma unroll
+                        for (int k = 1; k <= L; ++k) pair(acc, wa[k], ctr[-k], ctr[k]);
+                    }
+#pragma unroll
+                    for (int rr = 1; rr < Q; ++rr) {
+                        const float2 *lf = S + ((e - rr) % NWR) * NPS + nb;
+                        const float2 *rt = S + ((e + rr) % NWR) * NPS + nb;
+                        const float2 *wa_r = W + wset * Q * Q * K1 + (row * Q + rr) * K1;
+                        const float2 *wb_r = W + wset * Q * Q * K1 + (rowneg * Q + rr) * K1;
+                        const bool two = rr < ts;
+                        pair(acc, wa_r[0], lf[0], two ? rt[0] : zero);
+#pragma unroll
+                        for (int k = 1; k <= L; ++k) {
+                            pair(acc, wa_r[k], lf[-k], two ? rt[-k] : zero);
+                            pair(acc, wb_r[k], two ? rt[k] : zero, lf[k]);
+                        }
+                    }
+                    const int lj = ctb + nb;
+                    const float target = A[lj];
+                    if (target > thr) {
+                        const float mag = sqrtf(acc.x * acc.x + acc.y * acc.y);
+                        if (mag > 0.f) {
+                            const float2 v = make_float2(acc.x * target / mag, acc.y * target / mag);
+                            const float2 vc = make_float2(v.x, -v.y);
+                            S[lj] = v;
+                            const int nyq = F + L - 1;
+                            if (nb >= L + 1 && nb < 2 * L + 1) S[lj + 2 * (L - nb)] = vc;
+                            else if (nb >= F - 1 && nb < nyq) S[lj + 2 * (nyq - nb)] = vc;
+                        }
+                    }
+                }
+                }
+                if (t >= t_done) { s += NSW; setup(); }
+                load_frames(t);
+                __syncthreads();
+            }
+        } else {
+            v2f p1 = {0.f, 0.f}, p2 = {0.f, 0.f};   // current values of columns c-1, c-2 of the unit's frame (zero at a frame start:
+                                                    // the centre wave reads the images there itself)
+            // operands of the coming step, fetched before the barrier
+            v2f oldA, oldB, xlate;
+            float target_a, target_b;
+            float4 e01, e23, e45;
+            int li = 0, ia = 0, ib = 0, sbi = 0;
+            bool act = false;
+            auto fetch = [&](int t) __attribute__((always_inline)) {
+                const int u = t - tstart;
+                act = valid && (unsigned)u < (unsigned)NU;
+                const int uc = u < 0 ? 0 : (u > NU - 1 ? NU - 1 : u);
+                const int c = 2 * uc, g = N - c, cb = c + 1;
+                li = ctb + c + L;
+                oldA = as_v2f(S[li]); oldB = as_v2f(S[li + 1]);
+                target_a = A[li]; target_b = A[li + 1];
+                xlate = as_v2f(S[fbm1 + c + 1 + 2 * L]);
+                const int stype = (uc >= 1 && uc <= NLO) ? uc : (g < NHI ? NLO + 1 + g : 0);
+                const float4 *et = reinterpret_cast<const float4 *>(ET + (wset * NST + stype) * 6);
+                e01 = et[0]; e23 = et[1]; e45 = et[2];
+                const int spare = lane - 64;
+                ia = (c >= 1 && c <= L) ? li - 2 * c : ((c >= N - L && c <= N - 1) ? li + 2 * (N - c) : spare);
+                ib = (cb <= L) ? li + 1 - 2 * cb : ((cb >= N - L && cb <= N - 1) ? li + 1 + 2 * (N - cb) : spare);
+                sbi = cb < F ? li + 1 : spare;
+            };
+            LAB(unsigned long long lab_acc[4] = {0, 0, 0, 0};)
+            auto step = [&](auto ph_c, int t) __attribute__((always_inline)) {   // PH: parity of t (and of u)
+                constexpr int PH = decltype(ph_c)::value;
+                LAB(const unsigned long long lt0 = lab_now();)
+                const float4 *pp = P + (PH * NTW) * 64 + lane;
+                float4 part[NTW];
+#pragma unroll
+                for (int w = 0; w < NTW; ++w) part[w] = pp[w * 64];
+                // the unit's own history (columns c-1, c-2, their images, the image of bin c) and frame rho-1's late column
+                v2f twl = as_v2f(a.tw[(2 * PH + 1) & (Q - 1)]);
+                if constexpr (Q == 8) twl = ((t - tstart) & 2) ? as_v2f(a.tw[(2 * PH + 5) & (Q - 1)]) : twl;
+                v2f ownA = cmul_pk(wc[1], p1), ownB = cmul_pk(wc[2], p1);
+                cmac_pk(ownA, wc[2], p2);
+                if (L >= 3) cmac_pk(ownB, wc[L >= 3 ? 3 : 0], p2);
+                {
+                    const v2f x = cmul_pk(wlate, xlate);
+                    cmac_pk(ownB, twl, x);
+                }
+                cmac_cv_pk(ownA, (v2f){e01.x, e01.y}, oldA);
+                cmac_cv_pk(ownA, (v2f){e01.z, e01.w}, p1);
+                cmac_cv_pk(ownA, (v2f){e23.x, e23.y}, p2);
+                cmac_cv_pk(ownB, (v2f){e23.z, e23.w}, p1);
+                cmac_cv_pk(ownB, (v2f){e45.x, e45.y}, p2);
+                LAB(const unsigned long long lt1 = lab_now();)
+                // the tap waves' partial sums, as a tree
+                v2f sa[NTW], sb[NTW];
+#pragma unroll
+                for (int w = 0; w < NTW; ++w) { sa[w] = (v2f){part[w].x, part[w].y}; sb[w] = (v2f){part[w].z, part[w].w}; }
+#pragma unroll
+                for (int n2 = NTW; n2 > 1; n2 = (n2 + 1) / 2)
+#pragma unroll
+                    for (int w = 0; w < n2 / 2; ++w) { sa[w] += sa[n2 - 1 - w]; sb[w] += sb[n2 - 1 - w]; }
+                if (act) {
+                    v2f accA = sa[0] + ownA, accB = sb[0] + ownB;
+                    v2f newA;
+                    {
+                        float m2 = accA.x * accA.x + accA.y * accA.y;
+                        v2f q = accA;
+                        if (m2 < 1e-30f) {           // too small to square in fp32 (or zero): rescale, so that "|acc| > 0" keeps its meaning
+                            q *= 0x1p60f;
+                            m2 = q.x * q.x + q.y * q.y;
+                        }
+                        const float sc = target_a * __frsqrt_rn(m2);
+                        const bool upd = target_a > thr && m2 > 0.f;
+                        newA = upd ? q * sc : oldA;
+                    }
+                    cmac_pk(accB, wc[1], newA);
+                    cmac_cv_pk(accB, (v2f){e45.z, e45.w}, newA);   // the image of bin c itself, as the second bin sees it
+                    v2f newB;
+                    {
+                        float m2 = accB.x * accB.x + accB.y * accB.y;
+                        v2f q = accB;
+                        if (m2 < 1e-30f) {
+                            q *= 0x1p60f;
+                            m2 = q.x * q.x + q.y * q.y;
+                        }
+                        const float sc = target_b * __frsqrt_rn(m2);
+                        const bool upd = target_b > thr && m2 > 0.f;   // (a frame's last pair has no second bin: stored to a spare slot)
+                        newB = upd ? q * sc : oldB;
+                    }
+                    // unchanged bins are written back as they were; Hermitian images in the pad columns (lwslib.cpp:362-367)
+                    S[li] = make_float2(newA.x, newA.y);
+                    S[sbi] = make_float2(newB.x, newB.y);
+                    S[ia] = make_float2(newA.x, -newA.y);
+                    S[ib] = make_float2(newB.x, -newB.y);
+                    p2 = newA;
+                    p1 = newB;
+                }
+                LAB(const unsigned long long lt2 = lab_now();)
+                if (t >= t_done) { s += NSW; setup(); p1 = (v2f){0.f, 0.f}; p2 = (v2f){0.f, 0.f}; }
+                fetch(t + 1);
+                load_frames(t);
+                LAB(const unsigned long long lt3 = lab_now();)
+                __syncthreads();
+                LAB(const unsigned long long lt4 = lab_now(); lab_acc[0] += lt1 - lt0; lab_acc[1] += lt2 - lt1; lab_acc[2] += lt3 - lt2; lab_acc[3] += lt4 - lt3;)
+            };
+            fetch(-1);
+            for (int it = 0; it < n_it; it += 2) {
+                step(std::integral_constant<int, 1>{}, it - 1);
+                step(std::integral_constant<int, 0>{}, it);
+            }
+            LAB(if (b == 0 && lane == 0) { for (int i = 0; i < 4; ++i) g_lab[8 + hw_wave * 8 + i] = lab_acc[i]; g_lab[0] = n_it; })
+        }
+    }
+    const int first_row = loaded > NWR ? loaded - NWR : 0;
+    for (int e = first_row; e < loaded; ++e) {
+        const int slot = (e % NWR) * NPS;
+        for (int i = tid; i < Np; i += nthr) gS[(size_t)e * Np + i] = S[slot + i];
+    }
+}
+
 template <int Q, int L, bool SERIAL, int MAXT> hipError_t launch_qt(const OnlineArgs &a, int B, int threads, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -863,14 +1382,64 @@ Shape shape3_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
     return sh;
 }
 
+// k_online4: 2Q waves, one lane per (sweep slot, frame position), even lag, ring of NWR frames with an even row stride
+struct Shape4 { Shape sh; int NWR, NPS; };
+Shape4 shape4_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
+    Shape4 r{{0, 0, 0, 0, false}, 0, 0};
+    Shape &sh = r.sh;
+    if (Qp != Q || L != 5 || !(Q == 2 || Q == 4 || Q == 8) || LA < 0 || LA > 63 || n_thr < 1 || T < 1) return r;
+    const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS_MIN = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
+    const int NU = (F + 1) / 2;
+    sh.NSW = 64 / (LA + 1);
+    // order-exact lag with the tap waves a step ahead (2 DS >= SKB Q + 2); a slot is free again, with two steps to spare,
+    // when its sweep is over (NSW DS >= SKS LA + NU + 2); even
+    int DS = DS_MIN;
+    if (2 * DS < SKB * Q + 2) DS = (SKB * Q + 3) / 2;
+    const int need = (SKS * LA + NU + 2 + sh.NSW - 1) / sh.NSW;
+    if (DS < need) DS = need;
+    DS += DS & 1;
+    sh.DS = DS;
+    sh.threads = 2 * Q * 64;
+    if (F - 1 < 2 * (L + 3)) return r;
+    r.NPS = Np + (Np & 1);
+    auto lds_of = [&](int nwr) {
+        return (size_t)2 * (2 * Q - 1) * 64 * 16 + (192 + 64) * 8 + ((size_t)nwr * r.NPS + 8) * 8 + (size_t)nwr * r.NPS * 4 +
+               (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4;
+    };
+    int nwr_max = 16;
+    while (nwr_max > 0 && lds_of(nwr_max) > 160 * 1024) --nwr_max;
+    // Frames alive at once (see shape_of; frames are brought in three intervals before their first sweep).  Few iterations
+    // per frame on a long frame mean many frames in flight: a longer lag between sweeps trades steps for ring space.
+    auto window_of = [&](int ds) { return (ds * (per - 1) + NU + 3) / (ds * per + SKS) + LA + Q; };
+    while (window_of(DS) > nwr_max && DS < 16 * sh.DS) DS += 2;
+    if (window_of(DS) > nwr_max) return r;
+    sh.DS = DS;
+    const int window = window_of(DS);
+    r.NWR = window + 1 <= nwr_max ? window + 1 : window;
+    sh.lds = lds_of(r.NWR);
+    if ((double)DS * T * per + (double)SKS * T + NU > 1.0e9) return r;
+    sh.ok = true;
+    return r;
+}
+
 // which layout serves a shape: the wave-per-tap-group one unless it needs much more lag between sweeps (few slots: long
 // look-ahead) than the lane-group one; LWS_ONLINE_LAYOUT=2 / 3 forces one (tests)
-int pick_layout(const Shape &s2, const Shape &s3) {
+int pick_layout(const Shape &s2, const Shape &s3, const Shape &s4) {
     const char *ev = getenv("LWS_ONLINE_LAYOUT");
     if (ev && ev[0] == '2' && s2.ok) return 2;
     if (ev && ev[0] == '3' && s3.ok) return 3;
+    if (ev && ev[0] == '4' && s4.ok) return 4;
+    if (s4.ok && (!s2.ok || 2 * s4.DS <= 3 * s2.DS)) return 4;
     if (s3.ok && (!s2.ok || 2 * s3.DS <= 3 * s2.DS)) return 3;
     return s2.ok ? 2 : 0;
+}
+
+template <int Q, int L, bool SERIAL> hipError_t launch_4(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online4<Q, L, SERIAL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // (per device: not cached)
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_online4<Q, L, SERIAL>), dim3(B), dim3(Online4Waves<Q>::N * 64), lds, s, a);
+    return hipGetLastError();
 }
 
 template <int Q, int L, bool SERIAL> hipError_t launch_3(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
@@ -888,7 +1457,8 @@ template <int Q, int L, bool SERIAL> hipError_t launch_3(const OnlineArgs &a, in
 }  // namespace
 
 bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update, bool twiddle_structure) {
-    return update == 2 && twiddle_structure && (shape_of(F, T, L, Q, Qp, LA, n_thr).ok || shape3_of(F, T, L, Q, Qp, LA, n_thr).ok);
+    return update == 2 && twiddle_structure && (shape_of(F, T, L, Q, Qp, LA, n_thr).ok || shape3_of(F, T, L, Q, Qp, LA, n_thr).ok ||
+                                                shape4_of(F, T, L, Q, Qp, LA, n_thr).sh.ok);
 }
 
 // W[p][r][k] == W[0][r][k] exp(2 pi j p r / Q) for every p, r, k (what create_weights produces, lws.pyx:160-181)
@@ -912,9 +1482,10 @@ bool weights_have_twiddle_structure(const double *W, int Q, int Qp, int L) {
 
 hipError_t launch_online_lds(const GenericArgs<float> &g, int B, hipStream_t stream) {
     const Shape sh2 = shape_of(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr), sh3 = shape3_of(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr);
-    const int layout = pick_layout(sh2, sh3);
+    const Shape4 sh4 = shape4_of(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr);
+    const int layout = pick_layout(sh2, sh3, sh4.sh);
     if (layout == 0) return hipErrorInvalidValue;
-    const Shape sh = layout == 3 ? sh3 : sh2;
+    const Shape sh = layout == 4 ? sh4.sh : (layout == 3 ? sh3 : sh2);
     OnlineArgs a;
     a.state = g.state; a.amp = g.amp; a.thr = g.thr;
     for (int i = 0; i < 3; ++i) a.w[i] = g.w[i].w;
@@ -927,7 +1498,14 @@ hipError_t launch_online_lds(const GenericArgs<float> &g, int B, hipStream_t str
         a.tw[q] = make_float2((float)cr, (float)sr);
     }
     a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = sh.NSW; a.DS = sh.DS;
+    a.NWR = sh4.NWR; a.NPS = sh4.NPS;
     const char *ev = getenv("LWS_ONLINE_SERIAL_TAPS");   // verification only, see k_online
+    if (layout == 4) {
+        const bool serial = ev && ev[0] == '1';
+        if (g.Q == 4) return serial ? launch_4<4, 5, true>(a, B, sh.lds, stream) : launch_4<4, 5, false>(a, B, sh.lds, stream);
+        if (g.Q == 2) return serial ? launch_4<2, 5, true>(a, B, sh.lds, stream) : launch_4<2, 5, false>(a, B, sh.lds, stream);
+        return serial ? launch_4<8, 5, true>(a, B, sh.lds, stream) : launch_4<8, 5, false>(a, B, sh.lds, stream);
+    }
     if (layout == 3) {
         const bool serial = ev && ev[0] == '1';
         if (g.Q == 4) return serial ? launch_3<4, 5, true>(a, B, sh.lds, stream) : launch_3<4, 5, false>(a, B, sh.lds, stream);

@@ -38,10 +38,11 @@ def _online(F, W, S, thr, LA, qdiv, **kw):
     (256, 64, 1, 3, 2, 1),         # a single frame
     (512, 128, 40, 9, 2, 1),       # long look-ahead: few sweep slots among the 64 lanes of the wave-per-tap-group layout
 ])
-@pytest.mark.parametrize("layout", ["2", "3"])
+@pytest.mark.parametrize("layout", ["2", "3", "4"])
 def test_serial_variant_is_bit_identical_to_generic(fsize, fshift, T, LA, iters, B, layout, monkeypatch):
-    """Both lane layouts of the LDS engine (2Q lanes per bin / one wave per tap group with the projection wave a step behind;
-    LWS_ONLINE_LAYOUT forces one where it fits, else the other runs)."""
+    """The lane layouts of the LDS engine (2: 2Q lanes per bin; 3: one wave per tap group with the projection wave a step behind;
+    4: the same roles on two-step windows of aligned cells, even lag, run-time ring -- the default; LWS_ONLINE_LAYOUT forces one
+    where it fits, else another runs)."""
     monkeypatch.setenv("LWS_ONLINE_LAYOUT", layout)
     rng = np.random.default_rng(fsize + T)
     p = lws_amd.lws(fsize, fshift, mode="music")
@@ -67,7 +68,7 @@ def test_serial_variant_is_bit_identical_to_generic(fsize, fshift, T, LA, iters,
 @pytest.mark.parametrize("tag", ["64_16", "64_32", "64_8"])
 @pytest.mark.parametrize("T", [1, 2, 3, 7, 24])
 @pytest.mark.parametrize("LA", [0, 1, 3, 5])
-@pytest.mark.parametrize("layout", ["2", "3"])
+@pytest.mark.parametrize("layout", ["2", "3", "4"])
 def test_small_shapes_vs_oracle(tag, T, LA, layout, oracle, monkeypatch):
     monkeypatch.setenv("LWS_ONLINE_LAYOUT", layout)
     h, g = load_golden("helpers.npz"), load_golden("wrappers.npz")
@@ -87,7 +88,7 @@ def test_small_shapes_vs_oracle(tag, T, LA, layout, oracle, monkeypatch):
 
 @pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(1024, 256, 10, 3, 2), (1024, 256, 16, 3, 3), (512, 128, 12, 3, 3),
                                                     (1024, 512, 12, 3, 3), (512, 64, 10, 2, 2)])
-@pytest.mark.parametrize("layout", ["2", "3"])
+@pytest.mark.parametrize("layout", ["2", "3", "4"])
 def test_production_variant_vs_oracle_at_full_frame_sizes(fsize, fshift, T, LA, iters, layout, oracle, monkeypatch):
     """The production tap order (per-lane / per-wave partial sums, windows in registers, the projection wave's late terms)
     against the fp64 oracle at the frame sizes of the BASELINE configs, on runs short enough (a dozen frames, 2-3
@@ -117,8 +118,29 @@ def test_fallbacks_to_generic():
     S = rng.standard_normal((9, 33)) + 1j * rng.standard_normal((9, 33))
     out, name = _online(33, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 4.0, precision="fp64")
     assert name == "generic_fp64"
-    # one iteration per frame on a wide frame: too many frames in flight for the 16-frame ring (either layout)
+
+
+@pytest.mark.parametrize("iters,T", [(1, 30), (3, 14), (10, 8)])
+def test_wide_frames_stay_on_the_lds_engine(iters, T, oracle, monkeypatch):
+    """2048-point frames (BASELINE config 5's frame size, lws(2048,512, mode='music')): the run-time ring of the fourth layout
+    holds them -- with one iteration per frame by lengthening the lag between sweeps -- where the 16-frame rings of the other
+    layouts sent them to the generic engine.  Serial-taps variant bit-identical to the generic engine, production variant
+    against the fp64 oracle (short runs: values)."""
+    rng = np.random.default_rng(iters)
     p = lws_amd.lws(2048, 512, mode="music")
-    S = rng.standard_normal((30, 1025)) + 1j * rng.standard_normal((30, 1025))
-    out, name = _online(1025, (p.W, p.W_ai, p.W_af), S, [0.5], 3, 4.0)
+    S = rng.standard_normal((T, 1025)) + 1j * rng.standard_normal((T, 1025))
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.1, 1)
+    W = (p.W, p.W_ai, p.W_af)
+    out, name = _online(1025, W, S, thr, 3, 4.0)
+    assert name == "online_lds_fp32"
+    ref = oracle.online_lws(S, *W, thr, 3, 512)
+    gen, name = _online(1025, W, S, thr, 3, 4.0, force_generic=True)
     assert name == "generic_fp32"
+    err, scale = np.abs(out - ref), np.mean(np.abs(S))
+    # (30 frames of one iteration each amplify fp32 rounding: the order-exact generic fp32 engine is the yardstick there)
+    gen_l2 = np.linalg.norm(gen - ref) / np.linalg.norm(ref)
+    assert np.median(err) < 1e-6 * scale and np.linalg.norm(err) < max(1e-3, 3 * gen_l2) * np.linalg.norm(ref), gen_l2
+    assert np.abs(np.abs(out) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
+    monkeypatch.setenv("LWS_ONLINE_SERIAL_TAPS", "1")
+    ser, name = _online(1025, W, S, thr, 3, 4.0)
+    assert name == "online_lds_fp32" and np.array_equal(ser, gen)
