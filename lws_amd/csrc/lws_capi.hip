@@ -14,6 +14,12 @@
 #include <type_traits>
 #include "lws_systolic.h"
 #include "lws_online.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include "lws_nofuture.h"
 
 namespace {
@@ -77,6 +83,61 @@ struct DevBuf {
 
 }  // namespace
 
+// Staging of the complex128 host entry points of an fp32 plan (run_host_pipelined): pinned host buffers for complex64
+// chunks on their way up and down, the device buffers the chunks are processed in (in place), copy / compute streams.
+struct HostPipe {
+    void *up[2] = {nullptr, nullptr}, *down[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    DevBuf io[2];
+    hipStream_t s_up = nullptr, s_down = nullptr, s_comp = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+    int ensure(size_t bytes) {
+        if (!s_up) {
+            if (hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking) != hipSuccess)
+                return fail(LWS_ERR_HIP, "hipStreamCreate failed");
+            for (int i = 0; i < 2; ++i)
+                if (hipEventCreateWithFlags(&ev_up[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_comp[i], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ev_down[i], hipEventDisableTiming) != hipSuccess)
+                    return fail(LWS_ERR_HIP, "hipEventCreate failed");
+        }
+        if (bytes > cap) {
+            for (int i = 0; i < 2; ++i) {
+                if (up[i]) (void)hipHostFree(up[i]);
+                if (down[i]) (void)hipHostFree(down[i]);
+                up[i] = down[i] = nullptr;
+            }
+            cap = 0;
+            for (int i = 0; i < 2; ++i)
+                if (hipHostMalloc(&up[i], bytes, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&down[i], bytes, hipHostMallocDefault) != hipSuccess)
+                    return fail(LWS_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+            cap = bytes;
+        }
+        for (int i = 0; i < 2; ++i) {
+            int rc = io[i].ensure(bytes);
+            if (rc) return rc;
+        }
+        return LWS_OK;
+    }
+    void release() {
+        for (int i = 0; i < 2; ++i) {
+            if (up[i]) (void)hipHostFree(up[i]);
+            if (down[i]) (void)hipHostFree(down[i]);
+            up[i] = down[i] = nullptr;
+            io[i].release();
+            if (ev_up[i]) (void)hipEventDestroy(ev_up[i]);
+            if (ev_comp[i]) (void)hipEventDestroy(ev_comp[i]);
+            if (ev_down[i]) (void)hipEventDestroy(ev_down[i]);
+            ev_up[i] = ev_comp[i] = ev_down[i] = nullptr;
+        }
+        cap = 0;
+        if (s_up) (void)hipStreamDestroy(s_up);
+        if (s_down) (void)hipStreamDestroy(s_down);
+        if (s_comp) (void)hipStreamDestroy(s_comp);
+        s_up = s_down = s_comp = nullptr;
+    }
+};
+
 struct lws_plan {
     int device = 0;
     int F = 0, L = 0, Q = 0, Qp = 0;
@@ -88,6 +149,7 @@ struct lws_plan {
     DevBuf w[3], wflag[3];
     DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out;
     DevBuf gsk_state, gsk_amp;     // time-skewed copy of the state for the generic engine's batch sweeps
+    HostPipe pipe;                 // host-array entry points: pinned staging, chunk buffers, streams
     lws::SystolicPlan sys;         // device tables of the systolic kernel (empty if not eligible)
     const lws::SystolicBuild *sysb = nullptr;   // the build of it that serves this plan (narrow / Q = 8 / wide), if any
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -365,6 +427,158 @@ int check_systolic_flag(lws_plan *p) {
     return LWS_OK;
 }
 
+// ---- host-array entry points of an fp32 plan -----------------------------------------------------------------------------
+// What a user of the drop-in calls is lws.lws(...).run_lws(numpy) (lws.pyx:495-499, python/README.md:96-100): complex128 in
+// pageable host memory, complex128 out.  One pageable copy of 16 B/bin each way around the kernels costs several times the
+// kernels themselves, so the batch is cut into chunks of whole spectrograms that flow through a pipeline:
+//     host threads: complex128 -> complex64 into a pinned buffer   |  H2D (copy stream)  |  stages, in place (compute stream)
+//     |  D2H (copy stream) into a pinned buffer  |  host threads: complex64 -> complex128 into the caller's array
+// -- 8 B/bin over the bus instead of 16, both directions and the host passes overlapped with the kernels of the neighbouring
+// chunks.  A bin no sweep updated comes back as the caller's complex128 value, bit for bit (the rule of launch_extract:
+// "the state still equals the rounded original"), applied here on the way up.  Thresholds are scaled by the mean magnitude
+// of the complex64 values, as in the *_dev entry points.
+class HostWorkers {
+  public:
+    explicit HostWorkers(int n) {
+        for (int i = 1; i < n; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~HostWorkers() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int size() const { return (int)th_.size() + 1; }
+    // f(i) for i in [0, n), on the workers and the calling thread; returns when all are done
+    void run(int n, const std::function<void(int)> &f) {
+        if (n <= 0) return;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            f_ = &f; n_ = n; next_ = 0; left_ = n; ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return left_ == 0; });
+        f_ = nullptr;
+    }
+
+  private:
+    void work() {
+        for (;;) {
+            int i;
+            const std::function<void(int)> *f;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (!f_ || next_ >= n_) return;
+                i = next_++;
+                f = f_;
+            }
+            (*f)(i);
+            std::lock_guard<std::mutex> g(m_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        unsigned seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *f_ = nullptr;
+    int n_ = 0, next_ = 0, left_ = 0;
+    unsigned gen_ = 0;
+    bool stop_ = false;
+};
+
+void narrow_c128(const double *in, float *out, size_t lo, size_t hi) {   // bins [lo, hi)
+    for (size_t i = 2 * lo; i < 2 * hi; ++i) out[i] = (float)in[i];
+}
+void widen_c64(const float *dev, const double *orig, double *out, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+        const float vr = dev[2 * i], vi = dev[2 * i + 1];
+        const double orr = orig[2 * i], oi = orig[2 * i + 1];
+        const bool same = (float)orr == vr && (float)oi == vi;      // never updated: the caller's value, bit for bit
+        out[2 * i] = same ? orr : (double)vr;
+        out[2 * i + 1] = same ? oi : (double)vi;
+    }
+}
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, int T, const StageSpec *st, int n) {
+    const size_t per = (size_t)T * p->F;                       // bins of a spectrogram
+    const size_t total = per * (size_t)B;
+    // chunks of whole spectrograms, ~8M bins each (64 MB of complex64): long enough for the kernels to fill the GPU, short
+    // enough for the first upload and the last download -- which nothing overlaps -- to be a small part of the call
+    const size_t target = (size_t)std::max(1, env_int("LWS_HOST_CHUNK_BINS", 8 << 20));
+    int Bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (target + per / 2) / per));
+    if (total <= target + target / 2) Bc = B;
+    const int nch = (B + Bc - 1) / Bc;
+    int nthreads = env_int("LWS_HOST_THREADS", (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
+    if (total < ((size_t)1 << 20)) nthreads = 1;
+    nthreads = std::max(1, std::min(nthreads, 64));
+    HIP_TRY(hipSetDevice(p->device));
+    HostPipe &hp = p->pipe;
+    int rc = hp.ensure((size_t)Bc * per * sizeof(float2));
+    if (rc) return rc;
+    HostWorkers pool(nthreads);
+    const int slices = pool.size() == 1 ? 1 : 4 * pool.size();
+    auto chunk_bins = [&](int c) { return (size_t)std::min(Bc, B - c * Bc) * per; };
+    // host passes: narrow chunk cu (if any) into up[cu & 1] and widen chunk cd (if any) from down[cd & 1], together
+    auto host_pass = [&](int cu, int cd) {
+        const int nu = (cu >= 0 && cu < nch) ? slices : 0, nd = (cd >= 0 && cd < nch) ? slices : 0;
+        pool.run(nu + nd, [&](int i) {
+            if (i < nu) {
+                const size_t nb = chunk_bins(cu), lo = nb * i / slices, hi = nb * (i + 1) / slices, off = (size_t)cu * Bc * per;
+                narrow_c128(S_in + 2 * off, static_cast<float *>(hp.up[cu & 1]), lo, hi);
+            } else {
+                const int k = i - nu;
+                const size_t nb = chunk_bins(cd), lo = nb * k / slices, hi = nb * (k + 1) / slices, off = (size_t)cd * Bc * per;
+                widen_c64(static_cast<const float *>(hp.down[cd & 1]), S_in + 2 * off, S_out + 2 * off, lo, hi);
+            }
+        });
+    };
+    host_pass(0, -1);
+    for (int c = 0; c < nch; ++c) {
+        const int slot = c & 1, bc = std::min(Bc, B - c * Bc);
+        const size_t bytes = chunk_bins(c) * sizeof(float2);
+        float2 *io = static_cast<float2 *>(hp.io[slot].p);
+        if (c >= 2) HIP_TRY(hipStreamWaitEvent(hp.s_up, hp.ev_down[slot], 0));        // chunk c-2 has left this device buffer
+        HIP_TRY(hipMemcpyAsync(io, hp.up[slot], bytes, hipMemcpyHostToDevice, hp.s_up));
+        HIP_TRY(hipEventRecord(hp.ev_up[slot], hp.s_up));
+        HIP_TRY(hipStreamWaitEvent(hp.s_comp, hp.ev_up[slot], 0));
+        rc = run_pipeline<float, float2>(p, io, io, io, bc, T, st, n, hp.s_comp);
+        if (rc) { (void)hipDeviceSynchronize(); return rc; }
+        HIP_TRY(hipEventRecord(hp.ev_comp[slot], hp.s_comp));
+        HIP_TRY(hipStreamWaitEvent(hp.s_down, hp.ev_comp[slot], 0));
+        HIP_TRY(hipMemcpyAsync(hp.down[slot], io, bytes, hipMemcpyDeviceToHost, hp.s_down));
+        HIP_TRY(hipEventRecord(hp.ev_down[slot], hp.s_down));
+        // while the device works on chunk c: the next chunk on its way up (its pinned buffer is free once chunk c-1 has been
+        // uploaded), the previous one on its way out (once it has arrived)
+        if (c + 1 < nch && c >= 1) HIP_TRY(hipEventSynchronize(hp.ev_up[(c + 1) & 1]));
+        if (c >= 1) HIP_TRY(hipEventSynchronize(hp.ev_down[(c - 1) & 1]));
+        host_pass(c + 1, c - 1);
+    }
+    HIP_TRY(hipEventSynchronize(hp.ev_down[(nch - 1) & 1]));
+    host_pass(-1, nch - 1);
+    return check_systolic_flag(p);
+}
+
 // host complex128 in/out
 int run_host(lws_plan *p, const double *S_in, double *S_out, int B, int T, const StageSpec *st, int n) {
     if (!S_in || !S_out) return fail(LWS_ERR_INVALID, "null spectrogram pointer");
@@ -377,6 +591,8 @@ int run_host(lws_plan *p, const double *S_in, double *S_out, int B, int T, const
         if (S_out != S_in) memcpy(S_out, S_in, count * 2 * sizeof(double));
         return LWS_OK;
     }
+    if (!p->fp64 && !env_int("LWS_HOST_MONOLITHIC", 0)) return run_host_pipelined(p, S_in, S_out, B, T, st, n);
+    // fp64 plans (the reference's arithmetic; the parity anchor): one complex128 copy each way around the stages
     HIP_TRY(hipSetDevice(p->device));
     if ((rc = p->stage.ensure(count * sizeof(double2)))) return rc;
     hipStream_t s = nullptr;
@@ -520,6 +736,7 @@ void lws_plan_destroy(lws_plan *p) {
     p->state.release(); p->amp.release(); p->row_sums.release(); p->mean_amp.release();
     p->thr_host_copy.release(); p->thr_scaled.release(); p->stage.release();
     p->resid_rows.release(); p->resid_out.release(); p->gsk_state.release(); p->gsk_amp.release();
+    p->pipe.release();
     lws::systolic_entry().release(p->sys);   // (the same code in every build)
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);

@@ -44,7 +44,7 @@
 #include <utility>
 
 namespace lws {
-#ifdef LWS_LAB   // tools/lab/online_lab.hip: per-wave phase stamps (block 0), clocks summed over the steps
+#ifdef LWS_LAB   // tools/lab/online_lab.hip: per-wave phase stamps of k_online3 (block 0), clocks summed over the steps
 #define LAB_N 256
 __device__ unsigned long long g_lab[LAB_N];
 __device__ __forceinline__ unsigned long long lab_now() {
@@ -808,9 +808,16 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
 //   * the ring holds NWR frames (run-time, not a power of two), as many as the look-ahead needs: 2048-point frames fit.
 // SERIAL (verification): as in k_online3, the projection wave sums every tap itself in the generic engine's order.
 template <int Q> struct Online4Waves {
+#ifndef LWS_ONLINE4_IDLE_WAVE   // (tried: an idle wave on the projection wave's SIMD and the centre wave elsewhere: 57.8 vs 50.9 ms)
     static constexpr int N = 2 * Q;
-    static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : 7;
-    static __host__ __device__ constexpr int tap_of(int hw) { return hw == CENTRE ? 0 : hw - (hw > PROJ ? 1 : 0) - (hw > CENTRE ? 1 : 0) + 1; }
+    static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : 7, IDLE = -1;
+#else
+    static constexpr int N = (Q == 4) ? 9 : 2 * Q;
+    static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : (Q == 4 ? 8 : 7), IDLE = (Q == 4) ? 7 : -1;
+#endif
+    static __host__ __device__ constexpr int tap_of(int hw) {
+        return hw == CENTRE ? 0 : hw - (hw > PROJ ? 1 : 0) - (hw > CENTRE ? 1 : 0) - (IDLE >= 0 && hw > IDLE ? 1 : 0) + 1;
+    }
 };
 
 // w * v and conj(w) * v as one v_pk_mul_f32 + one v_pk_fma_f32 (no zeroed accumulator)
@@ -849,13 +856,17 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     const int rps = LA + 1, per = a.n_thr + 1;
     const int nsweeps = T * per;
     constexpr int NLO = (L + 2) / 4, NHI = (L + 1) / 2 + 1, NST = 1 + NLO + NHI;
+    // LDS layout (byte offsets; lds_of in shape4_of is the same sum)
+    const unsigned oET = 2u * NTW * 64 * 16, oS = oET + (192 + 64) * 8, oA = oS + ((unsigned)NWR * NPS + 8) * 8, oW = oA + (unsigned)NWR * NPS * 4,
+                   oTW = oW + 3u * Q * Q * K1 * 8, oThr = oTW + Q * 8, oTAB = (oThr + (unsigned)a.n_thr * 4 + 15u) & ~15u;
     float4 *P = reinterpret_cast<float4 *>(smem);                               // [2][NTW][64]: (sum of bin c, of bin c+1)
-    float2 *ET = reinterpret_cast<float2 *>(P + 2 * NTW * 64);                  // [3][NST][6] (padded to 192 entries)
-    float2 *S = ET + 192 + 64;                                                  // [NWR][NPS] (+ 8); the 64 entries below it: spare slots
-    float *A = reinterpret_cast<float *>(S + (size_t)NWR * NPS + 8);            // [NWR][NPS]
-    float2 *W = reinterpret_cast<float2 *>(A + (size_t)NWR * NPS);              // [3][Q][Q][K1]
-    float2 *TW = W + 3 * Q * Q * K1;                                            // [Q]
-    float *thr_s = reinterpret_cast<float *>(TW + Q);                           // [n_thr]
+    float2 *ET = reinterpret_cast<float2 *>(smem + oET);                        // [3][NST][6] (padded to 192 entries): edge-term weights
+    float2 *S = reinterpret_cast<float2 *>(smem + oS);                          // [NWR][NPS] (+ 8); the 64 entries below it: spare slots
+    float *A = reinterpret_cast<float *>(smem + oA);                            // [NWR][NPS]
+    float2 *W = reinterpret_cast<float2 *>(smem + oW);                          // [3][Q][Q][K1]
+    float2 *TW = reinterpret_cast<float2 *>(smem + oTW);                        // [Q]
+    float *thr_s = reinterpret_cast<float *>(smem + oThr);                      // [n_thr]
+    int4 *TAB = reinterpret_cast<int4 *>(smem + oTAB);                          // [NU] step table of the projection wave, by bin pair
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool is_proj = hw_wave == Online4Waves<Q>::PROJ;
@@ -887,6 +898,15 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         ET[tid] = w;
     }
     if (tid < 64) S[-64 + tid] = make_float2(0.f, 0.f);
+    // step table: x = byte offset of the pair's edge-term set in ET (within a weight set), y / z = byte offsets of the Hermitian
+    // images of the pair's bins relative to the bins themselves (0: no image), w = sign bit if the pair has no second bin
+    for (int uu = tid; uu < NU; uu += nthr) {
+        const int c = 2 * uu, cb = c + 1, g = N - c;
+        const int stype = (uu >= 1 && uu <= NLO) ? uu : (g < NHI ? NLO + 1 + g : 0);
+        const int da = (c >= 1 && c <= L) ? -16 * c : ((c >= N - L && c <= N - 1) ? 16 * (N - c) : 0);
+        const int db = (cb <= L) ? -16 * cb : ((cb >= N - L && cb <= N - 1) ? 16 * (N - cb) : 0);
+        TAB[uu] = make_int4(stype * 48, da, db, cb < F ? 0 : (int)0x80000000);
+    }
     __syncthreads();
     for (int i = tid; i < a.n_thr; i += nthr) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
     int loaded = Q < T + Q - 1 ? Q : T + Q - 1;
@@ -960,6 +980,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 S[slot + i] = gS[(size_t)loaded * Np + i];
                 A[slot + i] = gA[(size_t)loaded * Np + i];
             }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the projection wave's barrier wait is a counted one)
             ++loaded;
             next_need += frame_period;
         }
@@ -1014,51 +1035,38 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             const float4 *w = cells(ue);
             static_for<NPRE>([&](auto ic) { ld(w, ic); });
         }
-        LAB(unsigned long long lab_acc[4] = {0, 0, 0, 0};)
         for (int it = 0; it < n_it; it += 2) {
             // ---- even step tt = it (interval t = it - 1)
-            LAB(const unsigned long long lt0 = lab_now();)
             {
                 const float4 *w = cells(ue);
                 static_for<NCELL - 1 - NPRE>([&](auto ic) { ld(w, std::integral_constant<int, NPRE + decltype(ic)::value>{}); });
                 // frame rho-1 is SKB bins ahead, but the Hermitian images of its bins 4 and 5 (columns 1, 0: this lane's first
                 // window) are stored only SKB - 3 bins before this lane starts: final now, not yet when the early cells were read
                 if constexpr (KIND == 1) ld(w, std::integral_constant<int, 0>{});
-                LAB(const unsigned long long lt1 = lab_now(); lab_acc[0] += lt1 - lt0;)
                 v2f twa, twb;
                 tw_of(std::integral_constant<int, 0>{}, ue, twa, twb);
                 if (!SERIAL) sums(std::integral_constant<int, 0>{}, twa, twb, pw0);
-                LAB(lab_acc[1] += lab_now() - lt1;)
             }
-            LAB(const unsigned long long lt2 = lab_now();)
             if (it >= t_done) { s += NSW; setup(); ue = it - tstart; }
             load_frames(it - 1);
-            LAB(const unsigned long long lt3 = lab_now(); lab_acc[2] += lt3 - lt2;)
             __syncthreads();
-            LAB(const unsigned long long lt4 = lab_now(); lab_acc[3] += lt4 - lt3;)
             // ---- odd step tt = it + 1
             {
                 const float4 *w = cells(ue);
                 if constexpr (KIND == 1) ld(w, std::integral_constant<int, NCELL - 2>{});   // its last column is final now
                 ld(w, std::integral_constant<int, NCELL - 1>{});
-                LAB(const unsigned long long lt5 = lab_now(); lab_acc[0] += lt5 - lt4;)
                 v2f twa, twb;
                 tw_of(std::integral_constant<int, 1>{}, ue, twa, twb);
                 if (!SERIAL) sums(std::integral_constant<int, 2>{}, twa, twb, pw1);
-                LAB(lab_acc[1] += lab_now() - lt5;)
             }
-            LAB(const unsigned long long lt6 = lab_now();)
             ue += 2;
             {   // the next pair's early cells: columns this wave has used already, under their new names
                 const float4 *w = cells(ue);
                 static_for<NPRE>([&](auto ic) { ld(w, ic); });
             }
             load_frames(it);
-            LAB(const unsigned long long lt7 = lab_now(); lab_acc[2] += lt7 - lt6;)
             __syncthreads();
-            LAB(lab_acc[3] += lab_now() - lt7;)
         }
-        LAB(if (b == 0 && lane == 0) { for (int i = 0; i < 4; ++i) g_lab[8 + hw_wave * 8 + i] = lab_acc[i]; })
     };
 
     // ---- centre-frame tap wave: its unit's own outputs of this step and the last (columns c-2 .. c, and their Hermitian
@@ -1129,15 +1137,15 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         }
     };
 
-    if (!is_proj) {
+    if (hw_wave == Online4Waves<Q>::IDLE) {
+        for (int it = 0; it < n_it; it += 2) { load_frames(it - 1); __syncthreads(); load_frames(it); __syncthreads(); }
+    } else if (!is_proj) {
         if (wave == 0) centre_loop();
         else if (wave == 1) tap_loop(std::integral_constant<int, 1>{});
         else tap_loop(std::integral_constant<int, 0>{});
     } else {
         // ------------------------------------------------------------------------------------------ projection wave
-        // The chain every step waits for, so: as few instructions as possible, and no latency in the open.  Per step:
-        // issue the reads of the tap waves' sums; while they are in flight form the unit's own terms (operands fetched
-        // before the barrier); add up; re-project the two bins; store; fetch the operands of the next step; barrier.
+        // The chain every step waits for, so: as few instructions as possible, and as little latency in the open as possible.
         asm volatile("s_setprio 3");
         if constexpr (SERIAL) {
             for (int t = -1; t < n_it - 1; ++t) {
@@ -1192,55 +1200,73 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 __syncthreads();
             }
         } else {
-            v2f p1 = {0.f, 0.f}, p2 = {0.f, 0.f};   // current values of columns c-1, c-2 of the unit's frame (zero at a frame start:
-                                                    // the centre wave reads the images there itself)
-            // operands of the coming step, fetched before the barrier
-            v2f oldA, oldB, xlate;
-            float target_a, target_b;
-            float4 e01, e23, e45;
-            int li = 0, ia = 0, ib = 0, sbi = 0;
+            // Per step: read the tap waves' sums; while they are in flight form the unit's own terms from operands fetched before
+            // the barrier; add up (a tree); re-project the two bins; store; fetch the next step's operands; barrier.  The
+            // step-table entry (edge-term set, image offsets, "the pair has a second bin") is fetched a step before it is
+            // needed, so that no address waits for a load.  (Tried on top of this, measured, dropped: the next step's operands
+            // fetched at the start of a step instead of its end, +1.6 ms; the sums of step t+1 read before the barrier, with a
+            // counter the tap waves bump to say whether they were complete, +6 ms -- the centre wave shares this wave's SIMD
+            // and is rarely done in time; the tap waves sleeping 64-192 clocks after a barrier to let this wave's reads go
+            // first, +0.3-1.7 ms; an idle ninth wave instead of the centre wave on this SIMD, +7 ms; a row stride that spreads
+            // the window cells of a ds_read_b128 group over all 16 bank slots, +0.8 ms.  Times: DESIGN 4c.)
+            v2f p1 = {0.f, 0.f}, p2 = {0.f, 0.f};   // current values of columns c-1, c-2 of the unit's frame; zero while the lane
+                                                    // has no work and at a frame start (the centre wave reads the images there itself)
+            auto lds = [&](unsigned off) __attribute__((always_inline)) { return smem + off; };
+            v2f oldA = {0.f, 0.f}, oldB = {0.f, 0.f}, xlate = {0.f, 0.f};
+            float target_a = 0.f, target_b = 0.f;
+            float4 e01 = make_float4(0.f, 0.f, 0.f, 0.f), e23 = e01, e45 = e01;
+            unsigned li_b = oS, ia_b = oS, ib_b = oS;
             bool act = false;
-            auto fetch = [&](int t) __attribute__((always_inline)) {
-                const int u = t - tstart;
-                act = valid && (unsigned)u < (unsigned)NU;
-                const int uc = u < 0 ? 0 : (u > NU - 1 ? NU - 1 : u);
-                const int c = 2 * uc, g = N - c, cb = c + 1;
-                li = ctb + c + L;
-                oldA = as_v2f(S[li]); oldB = as_v2f(S[li + 1]);
-                target_a = A[li]; target_b = A[li + 1];
-                xlate = as_v2f(S[fbm1 + c + 1 + 2 * L]);
-                const int stype = (uc >= 1 && uc <= NLO) ? uc : (g < NHI ? NLO + 1 + g : 0);
-                const float4 *et = reinterpret_cast<const float4 *>(ET + (wset * NST + stype) * 6);
-                e01 = et[0]; e23 = et[1]; e45 = et[2];
-                const int spare = lane - 64;
-                ia = (c >= 1 && c <= L) ? li - 2 * c : ((c >= N - L && c <= N - 1) ? li + 2 * (N - c) : spare);
-                ib = (cb <= L) ? li + 1 - 2 * cb : ((cb >= N - L && cb <= N - 1) ? li + 1 + 2 * (N - cb) : spare);
-                sbi = cb < F ? li + 1 : spare;
+            int4 tab1 = make_int4(0, 0, 0, 0), tab2 = make_int4(0, 0, 0, 0);   // table entries of bin pairs u + 1, u + 2
+            unsigned li0 = oS, ai0 = oA, xl0 = oS, et0 = oET;     // per-sweep bases of the lane (byte offsets)
+            int u = -1 - tstart;                       // bin pair of the step about to run
+            auto derive = [&]() __attribute__((always_inline)) {
+                li0 = oS + 8u * (unsigned)(ctb + L);
+                ai0 = oA + 4u * (unsigned)(ctb + L);
+                xl0 = oS + 8u * (unsigned)(fbm1 + 1 + 2 * L);
+                et0 = oET + (unsigned)(wset * NST * 48);
             };
-            LAB(unsigned long long lab_acc[4] = {0, 0, 0, 0};)
+            auto clampu = [&](int un) __attribute__((always_inline)) { return un < 0 ? 0 : (un > NU - 1 ? NU - 1 : un); };
+            auto fetch_tab = [&](int un) __attribute__((always_inline)) {
+                return *reinterpret_cast<const int4 *>(lds(oTAB + 16u * (unsigned)clampu(un)));
+            };
+            auto fetch = [&](int un, int4 tab) __attribute__((always_inline)) {   // operands of bin pair un, whose table entry is `tab`
+                act = valid && (unsigned)un < (unsigned)NU;
+                const unsigned uc = (unsigned)clampu(un);
+                li_b = li0 + 16u * uc;
+                const float2 *so = reinterpret_cast<const float2 *>(lds(li_b));
+                oldA = as_v2f(so[0]); oldB = as_v2f(so[1]);
+                const float *ta = reinterpret_cast<const float *>(lds(ai0 + 8u * uc));
+                target_a = ta[0];
+                target_b = __int_as_float(__float_as_int(ta[1]) | tab.w);       // (no second bin: a negative target is never above a threshold)
+                const float4 *et = reinterpret_cast<const float4 *>(lds(et0 + (unsigned)tab.x));
+                e01 = et[0]; e23 = et[1]; e45 = et[2];
+                ia_b = li_b + (unsigned)tab.y;
+                ib_b = li_b + 8u + (unsigned)tab.z;
+                xlate = as_v2f(*reinterpret_cast<const float2 *>(lds(xl0 + 16u * uc)));
+            };
             auto step = [&](auto ph_c, int t) __attribute__((always_inline)) {   // PH: parity of t (and of u)
                 constexpr int PH = decltype(ph_c)::value;
-                LAB(const unsigned long long lt0 = lab_now();)
                 const float4 *pp = P + (PH * NTW) * 64 + lane;
                 float4 part[NTW];
 #pragma unroll
                 for (int w = 0; w < NTW; ++w) part[w] = pp[w * 64];
+                __builtin_amdgcn_sched_barrier(0);   // (the reads first: the own terms below cover part of their latency)
                 // the unit's own history (columns c-1, c-2, their images, the image of bin c) and frame rho-1's late column
                 v2f twl = as_v2f(a.tw[(2 * PH + 1) & (Q - 1)]);
-                if constexpr (Q == 8) twl = ((t - tstart) & 2) ? as_v2f(a.tw[(2 * PH + 5) & (Q - 1)]) : twl;
+                if constexpr (Q == 8) twl = (u & 2) ? as_v2f(a.tw[(2 * PH + 5) & (Q - 1)]) : twl;
                 v2f ownA = cmul_pk(wc[1], p1), ownB = cmul_pk(wc[2], p1);
                 cmac_pk(ownA, wc[2], p2);
                 if (L >= 3) cmac_pk(ownB, wc[L >= 3 ? 3 : 0], p2);
-                {
-                    const v2f x = cmul_pk(wlate, xlate);
-                    cmac_pk(ownB, twl, x);
-                }
                 cmac_cv_pk(ownA, (v2f){e01.x, e01.y}, oldA);
                 cmac_cv_pk(ownA, (v2f){e01.z, e01.w}, p1);
                 cmac_cv_pk(ownA, (v2f){e23.x, e23.y}, p2);
                 cmac_cv_pk(ownB, (v2f){e23.z, e23.w}, p1);
                 cmac_cv_pk(ownB, (v2f){e45.x, e45.y}, p2);
-                LAB(const unsigned long long lt1 = lab_now();)
+                {
+                    const v2f x = cmul_pk(wlate, xlate);
+                    cmac_pk(ownB, twl, x);
+                }
                 // the tap waves' partial sums, as a tree
                 v2f sa[NTW], sb[NTW];
 #pragma unroll
@@ -1249,56 +1275,72 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 for (int n2 = NTW; n2 > 1; n2 = (n2 + 1) / 2)
 #pragma unroll
                     for (int w = 0; w < n2 / 2; ++w) { sa[w] += sa[n2 - 1 - w]; sb[w] += sb[n2 - 1 - w]; }
-                if (act) {
-                    v2f accA = sa[0] + ownA, accB = sb[0] + ownB;
-                    v2f newA;
-                    {
-                        float m2 = accA.x * accA.x + accA.y * accA.y;
-                        v2f q = accA;
-                        if (m2 < 1e-30f) {           // too small to square in fp32 (or zero): rescale, so that "|acc| > 0" keeps its meaning
-                            q *= 0x1p60f;
-                            m2 = q.x * q.x + q.y * q.y;
-                        }
-                        const float sc = target_a * __frsqrt_rn(m2);
-                        const bool upd = target_a > thr && m2 > 0.f;
-                        newA = upd ? q * sc : oldA;
+                v2f accA = sa[0] + ownA, accB = sb[0] + ownB;
+                v2f newA;
+                {
+                    float m2 = accA.x * accA.x + accA.y * accA.y;
+                    v2f q = accA;
+                    if (m2 < 1e-30f) {           // too small to square in fp32 (or zero): rescale, so that "|acc| > 0" keeps its meaning
+                        q *= 0x1p60f;
+                        m2 = q.x * q.x + q.y * q.y;
                     }
-                    cmac_pk(accB, wc[1], newA);
-                    cmac_cv_pk(accB, (v2f){e45.z, e45.w}, newA);   // the image of bin c itself, as the second bin sees it
-                    v2f newB;
-                    {
-                        float m2 = accB.x * accB.x + accB.y * accB.y;
-                        v2f q = accB;
-                        if (m2 < 1e-30f) {
-                            q *= 0x1p60f;
-                            m2 = q.x * q.x + q.y * q.y;
-                        }
-                        const float sc = target_b * __frsqrt_rn(m2);
-                        const bool upd = target_b > thr && m2 > 0.f;   // (a frame's last pair has no second bin: stored to a spare slot)
-                        newB = upd ? q * sc : oldB;
-                    }
-                    // unchanged bins are written back as they were; Hermitian images in the pad columns (lwslib.cpp:362-367)
-                    S[li] = make_float2(newA.x, newA.y);
-                    S[sbi] = make_float2(newB.x, newB.y);
-                    S[ia] = make_float2(newA.x, -newA.y);
-                    S[ib] = make_float2(newB.x, -newB.y);
-                    p2 = newA;
-                    p1 = newB;
+                    const float sc = target_a * __frsqrt_rn(m2);
+                    const bool upd = target_a > thr && m2 > 0.f;
+                    newA = upd ? q * sc : oldA;
                 }
-                LAB(const unsigned long long lt2 = lab_now();)
-                if (t >= t_done) { s += NSW; setup(); p1 = (v2f){0.f, 0.f}; p2 = (v2f){0.f, 0.f}; }
-                fetch(t + 1);
+                cmac_pk(accB, wc[1], newA);
+                cmac_cv_pk(accB, (v2f){e45.z, e45.w}, newA);   // the image of bin c itself, as the second bin sees it
+                v2f newB;
+                {
+                    float m2 = accB.x * accB.x + accB.y * accB.y;
+                    v2f q = accB;
+                    if (m2 < 1e-30f) {
+                        q *= 0x1p60f;
+                        m2 = q.x * q.x + q.y * q.y;
+                    }
+                    const float sc = target_b * __frsqrt_rn(m2);
+                    const bool upd = target_b > thr && m2 > 0.f;
+                    newB = upd ? q * sc : oldB;
+                }
+                // Unchanged bins are written back as they were.  Hermitian images in the pad columns (lwslib.cpp:362-367): a bin
+                // without an image has offset 0 -- its conjugate goes to the bin's own place FIRST and is overwritten at once
+                // (one wave's LDS stores land in order).  A frame's last pair has no second bin: that place is an image column
+                // and gets its old value back (it was read after the store of the step before).
+                if (act) {
+                    *reinterpret_cast<float2 *>(lds(ia_b)) = make_float2(newA.x, -newA.y);
+                    *reinterpret_cast<float2 *>(lds(ib_b)) = make_float2(newB.x, -newB.y);
+                    float2 *sn = reinterpret_cast<float2 *>(lds(li_b));
+                    sn[0] = make_float2(newA.x, newA.y);
+                    sn[1] = make_float2(newB.x, newB.y);
+                }
+                const v2f zero = {0.f, 0.f};
+                p2 = act ? newA : zero;
+                p1 = act ? newB : zero;
                 load_frames(t);
-                LAB(const unsigned long long lt3 = lab_now();)
-                __syncthreads();
-                LAB(const unsigned long long lt4 = lab_now(); lab_acc[0] += lt1 - lt0; lab_acc[1] += lt2 - lt1; lab_acc[2] += lt3 - lt2; lab_acc[3] += lt4 - lt3;)
+                // (a lane that changes sweeps has at least two steps without work ahead of it -- NSW DS >= SKS LA + NU + 2 in
+                // shape4_of -- : the table entries in flight, which still belong to the old sweep, are used for those two only)
+                if (t >= t_done) { s += NSW; setup(); derive(); u = t - tstart; }
+                ++u;
+                // The stores above must have landed when the other waves pass the barrier; the reads below need not have.  A
+                // wave's LDS operations complete in order, so "all but the youngest 7" covers the stores as long as at least 7
+                // LDS reads follow them (tests/test_online_isa.py checks the compiled order).  Never more than 15 LDS / scalar
+                // memory operations in flight: the counter s_waitcnt tests has four bits (with 16 the engine returned stale
+                // registers).
+                asm volatile("" ::: "memory");
+                const int4 tab3 = fetch_tab(u + 2);
+                fetch(u, tab1);
+                tab1 = tab2;
+                tab2 = tab3;
+                asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
             };
-            fetch(-1);
+            derive();
+            fetch(u, fetch_tab(u));
+            tab1 = fetch_tab(u + 1);
+            tab2 = fetch_tab(u + 2);
             for (int it = 0; it < n_it; it += 2) {
                 step(std::integral_constant<int, 1>{}, it - 1);
                 step(std::integral_constant<int, 0>{}, it);
             }
-            LAB(if (b == 0 && lane == 0) { for (int i = 0; i < 4; ++i) g_lab[8 + hw_wave * 8 + i] = lab_acc[i]; g_lab[0] = n_it; })
         }
     }
     const int first_row = loaded > NWR ? loaded - NWR : 0;
@@ -1399,12 +1441,12 @@ Shape4 shape4_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
     if (DS < need) DS = need;
     DS += DS & 1;
     sh.DS = DS;
-    sh.threads = 2 * Q * 64;
+    sh.threads = Online4Waves<4>::N == 9 && Q == 4 ? 9 * 64 : 2 * Q * 64;
     if (F - 1 < 2 * (L + 3)) return r;
     r.NPS = Np + (Np & 1);
     auto lds_of = [&](int nwr) {
         return (size_t)2 * (2 * Q - 1) * 64 * 16 + (192 + 64) * 8 + ((size_t)nwr * r.NPS + 8) * 8 + (size_t)nwr * r.NPS * 4 +
-               (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4;
+               (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4 + 16 + (size_t)NU * 16;
     };
     int nwr_max = 16;
     while (nwr_max > 0 && lds_of(nwr_max) > 160 * 1024) --nwr_max;

@@ -23,3 +23,20 @@ for it in range(1, iters + 1):
     print("  per frame max:", e2.max(axis=1))
     bad = np.argwhere(e2 > 1e-5)
     print("  bins with err > 1e-5: %d; first 40 (frame, bin):" % len(bad), [tuple(int(v) for v in x) for x in bad[:40]])
+if os.environ.get("DUMP"):
+    r2 = Oracle().online_lws(S, *W, thr[:1], LA, fshift)
+    o2 = plan.online(S, thr[:1], LA, fsize / fshift)
+    np.set_printoptions(linewidth=250, precision=4, suppress=True)
+    print("ref  frame0 tail:", r2[0, -10:])
+    print("out  frame0 tail:", o2[0, -10:])
+    print("in   frame0 tail:", S[0, -10:])
+    print("|out| - |in| tail:", np.abs(o2[0, -10:]) - np.abs(S[0, -10:]))
+
+if os.environ.get("LWS_HIP_LIB") and os.environ.get("LABDBG"):
+    import ctypes as C
+    lib = C.CDLL(os.environ["LWS_HIP_LIB"])
+    buf = (C.c_ulonglong * 256)()
+    lib.lws_lab_read(buf, 256)
+    n = buf[0]
+    print("mismatches between sums read before / after the barrier (accumulated over the calls above):", n)
+    print([(buf[i] >> 32, (buf[i] >> 8) & 0xffffff, buf[i] & 0xff) for i in range(1, min(int(n), 60) + 1)])

@@ -51,10 +51,19 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("B=%d T=%d F=%d LA=%d it=%d: %.3f ms\n", B, T, F, LA, iters, ms);
     }
-    std::vector<float2> out(Np * 8);
-    CK(hipMemcpy(out.data(), ds + (size_t)(Q - 1 + T / 2) * Np, out.size() * 8, hipMemcpyDeviceToHost));
-    double cs = 0; for (auto &v : out) cs += fabs(v.x) + fabs(v.y);
-    printf("checksum %.9e\n", cs);
+    std::vector<float2> out((size_t)Tp * Np);
+    CK(hipMemcpy(out.data(), ds, out.size() * 8, hipMemcpyDeviceToHost));
+    double cs = 0; for (auto &v : out) cs += fabs(v.x) * 1.25 + fabs(v.y);
+    printf("checksum (spectrogram 0) %.12e\n", cs);
+#if 0
+    {
+        std::vector<unsigned long long> lab(LAB_N);
+        CK(hipMemcpyFromSymbol(lab.data(), HIP_SYMBOL(lws::g_lab), LAB_N * 8));
+        printf("mismatches %llu; first:", lab[0]);
+        for (int i = 1; i < 40 && i <= (int)lab[0]; ++i) printf(" (t=%llu lane=%llu w=%llu)", lab[i] >> 32, (lab[i] >> 8) & 0xffffff, lab[i] & 0xff);
+        printf("\n");
+    }
+#endif
 #ifdef LWS_LAB
     std::vector<unsigned long long> lab(LAB_N);
     CK(hipMemcpyFromSymbol(lab.data(), HIP_SYMBOL(lws::g_lab), LAB_N * 8));

@@ -45,8 +45,9 @@ if "SQ_WAVE_CYCLES" in c and "SQ_WAVES" in c and c["SQ_WAVES"]:
     cu_quads = wave_quads * min(wg, 256.0)                        # CU-time available (one workgroup per CU)
     der["valu_busy_fraction_of_simd_time"] = c.get("SQ_ACTIVE_INST_VALU", 0) / (4 * cu_quads)
     der["lds_instruction_active_fraction_per_cu"] = c.get("SQ_ACTIVE_INST_LDS", 0) / cu_quads
-    der["lds_index_active_fraction_per_cu"] = c.get("SQ_LDS_IDX_ACTIVE", 0) / cu_quads
-    der["lds_bank_conflict_fraction_of_cycles_per_cu"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / cu_quads
+    # SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT count LDS-array cycles (4 per ds_read_b128), not quad-cycles
+    der["lds_array_active_fraction_per_cu"] = c.get("SQ_LDS_IDX_ACTIVE", 0) / (4 * cu_quads)
+    der["lds_bank_conflict_fraction_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, c.get("SQ_LDS_IDX_ACTIVE", 0))
     der["wave_fraction_waiting_any"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]
     der["wave_fraction_issue_stalled"] = c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]
     der["wave_fraction_issuing"] = c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]
