@@ -523,9 +523,9 @@ int env_int(const char *name, int dflt) {
 int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, int T, const StageSpec *st, int n) {
     const size_t per = (size_t)T * p->F;                       // bins of a spectrogram
     const size_t total = per * (size_t)B;
-    // chunks of whole spectrograms, ~8M bins each (64 MB of complex64): long enough for the kernels to fill the GPU, short
+    // chunks of whole spectrograms, ~16M bins each (128 MB of complex64; measured on 256 x 500 x 513: 8M 65 ms, 16M 60 ms, 32M 72 ms): long enough for the kernels to fill the GPU, short
     // enough for the first upload and the last download -- which nothing overlaps -- to be a small part of the call
-    const size_t target = (size_t)std::max(1, env_int("LWS_HOST_CHUNK_BINS", 8 << 20));
+    const size_t target = (size_t)std::max(1, env_int("LWS_HOST_CHUNK_BINS", 16 << 20));
     int Bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (target + per / 2) / per));
     if (total <= target + target / 2) Bc = B;
     const int nch = (B + Bc - 1) / Bc;

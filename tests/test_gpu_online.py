@@ -138,8 +138,9 @@ def test_wide_frames_stay_on_the_lds_engine(iters, T, oracle, monkeypatch):
     assert name == "generic_fp32"
     err, scale = np.abs(out - ref), np.mean(np.abs(S))
     # (30 frames of one iteration each amplify fp32 rounding: the order-exact generic fp32 engine is the yardstick there)
-    gen_l2 = np.linalg.norm(gen - ref) / np.linalg.norm(ref)
-    assert np.median(err) < 1e-6 * scale and np.linalg.norm(err) < max(1e-3, 3 * gen_l2) * np.linalg.norm(ref), gen_l2
+    gen_l2, gen_med = np.linalg.norm(gen - ref) / np.linalg.norm(ref), np.median(np.abs(gen - ref))
+    assert np.median(err) < max(1e-6 * scale, 3 * gen_med), (np.median(err), gen_med)
+    assert np.linalg.norm(err) < max(1e-3, 3 * gen_l2) * np.linalg.norm(ref), gen_l2
     assert np.abs(np.abs(out) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
     monkeypatch.setenv("LWS_ONLINE_SERIAL_TAPS", "1")
     ser, name = _online(1025, W, S, thr, 3, 4.0)
