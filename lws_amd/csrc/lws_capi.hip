@@ -3,6 +3,7 @@
 // HIP-event timing of the update kernels.
 #include "../../include/lws_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -300,10 +301,17 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
         // that copy would be unreasonably large
         size_t ab = 0;
         const size_t sb = lws::generic_skew_bytes<real>(B, p->F, T, p->L, p->Q, &ab);
-        if (sb + ab <= ((size_t)48 << 30)) {
-            int rc;
-            if ((rc = p->gsk_state.ensure(sb))) return rc;
-            if ((rc = p->gsk_amp.ensure(ab))) return rc;
+        // (what the copy may take: half of what is free now plus what the plan already holds for it, 48 GiB at most)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const size_t limit = std::min((size_t)48 << 30, free_b / 2 + p->gsk_state.cap + p->gsk_amp.cap);
+        bool have_copy = sb + ab <= limit;
+        if (have_copy && (p->gsk_state.ensure(sb) != LWS_OK || p->gsk_amp.ensure(ab) != LWS_OK)) {
+            // no room after all: give back what was taken and run in the plain layout (same results, bit for bit)
+            p->gsk_state.release(); p->gsk_amp.release();
+            have_copy = false;
+        }
+        if (have_copy) {
             begin_timing(p, s);
             hipError_t e = lws::launch_generic_skewed<real>(a, B, p->gsk_state.p, p->gsk_amp.p, s);
             end_timing(p, s);
@@ -520,11 +528,18 @@ int env_int(const char *name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// (Tried and dropped: four child plans with a quarter of the CUs each, working on a chunk each at the same time -- one
+// workgroup per spectrogram in every launch, a chunk's kernels starting when ITS upload is done.  Kernels of different
+// streams do overlap -- 2 x 64 spectrograms on two streams take the time of one, 33 ms -- but a process gets four hardware
+// queues by default and twelve streams share them: 170 ms instead of 61; with one stream per lane the gain over this
+// pipeline is bounded by ~10 %, the exposed first upload and last download being what they are.)
 int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, int T, const StageSpec *st, int n) {
     const size_t per = (size_t)T * p->F;                       // bins of a spectrogram
     const size_t total = per * (size_t)B;
-    // chunks of whole spectrograms, ~16M bins each (128 MB of complex64; measured on 256 x 500 x 513: 8M 65 ms, 16M 60 ms, 32M 72 ms): long enough for the kernels to fill the GPU, short
-    // enough for the first upload and the last download -- which nothing overlaps -- to be a small part of the call
+    // chunks of whole spectrograms, ~16M bins each (128 MB of complex64; measured on 256 x 500 x 513: 8M 65 ms, 16M 60 ms,
+    // 32M 72 ms): long enough for the kernels to fill the device -- a launch of 32 spectrograms takes 6.7 ms, of 64 10.5, of
+    // 256 33.9: fewer spectrograms than CUs run several workgroups each, 70-85 % as efficient -- short enough for the first
+    // upload and the last download, which nothing overlaps, to be a small part of the call
     const size_t target = (size_t)std::max(1, env_int("LWS_HOST_CHUNK_BINS", 16 << 20));
     int Bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (target + per / 2) / per));
     if (total <= target + target / 2) Bc = B;

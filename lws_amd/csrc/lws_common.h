@@ -5,7 +5,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace lws {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device; the launchers keep one bit per device in a function-local
+// atomic (lws_multi_* launches the same kernels from one host thread per device).  Returns true if this device still needs
+// the call; a lost race only repeats it.
+inline bool attr_needed(std::atomic<unsigned long long> &done, int *dev_out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    *dev_out = dev;
+    return dev < 0 || dev >= 64 || !((done.load(std::memory_order_relaxed) >> dev) & 1ull);
+}
+inline void attr_done(std::atomic<unsigned long long> &done, int dev) {
+    if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_relaxed);
+}
 
 // records the text lws_last_error() returns and passes `code` through (lws_capi.hip)
 int set_error(int code, const char *fmt, ...);

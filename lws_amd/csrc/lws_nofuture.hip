@@ -292,12 +292,13 @@ __global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
 
 template <int QT, int LT, bool COMPAT, bool SPLIT>
 hipError_t launch_ts(const NfArgs &a, int B, int threads, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};   // one bit per device
+    int attr_dev;
+    if (lws::attr_needed(attr_set, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nofuture<QT, LT, COMPAT, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        lws::attr_done(attr_set, attr_dev);
     }
     hipLaunchKernelGGL((k_nofuture<QT, LT, COMPAT, SPLIT>), dim3(B), dim3(threads), lds, s, a);
     return hipGetLastError();

@@ -1351,12 +1351,13 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
 }
 
 template <int Q, int L, bool SERIAL, int MAXT> hipError_t launch_qt(const OnlineArgs &a, int B, int threads, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};   // one bit per device
+    int attr_dev;
+    if (lws::attr_needed(attr_set, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online<Q, L, SERIAL, MAXT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        lws::attr_done(attr_set, attr_dev);
     }
     hipLaunchKernelGGL((k_online<Q, L, SERIAL, MAXT>), dim3(B), dim3(threads), lds, s, a);
     return hipGetLastError();
@@ -1485,12 +1486,13 @@ template <int Q, int L, bool SERIAL> hipError_t launch_4(const OnlineArgs &a, in
 }
 
 template <int Q, int L, bool SERIAL> hipError_t launch_3(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};   // one bit per device
+    int attr_dev;
+    if (lws::attr_needed(attr_set, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online3<Q, L, SERIAL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        lws::attr_done(attr_set, attr_dev);
     }
     hipLaunchKernelGGL((k_online3<Q, L, SERIAL>), dim3(B), dim3(Online3Waves<Q>::N * 64), lds, s, a);
     return hipGetLastError();

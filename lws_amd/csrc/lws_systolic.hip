@@ -36,6 +36,7 @@
 // (lws.pyx:160-181: W[p][r][k] = W[0][r][k]*exp(2j*pi*p*r/Q)), Q in {2,4} with L in {1,3,5}, or Q = 8 with L = 5 (its own
 // build: 64-step ring, a main and two helper waves per sweep slot), F-1 a multiple of 8 and <= 512 (<= 1024: the wide build),
 // fp32 arithmetic, fp32 or fp16 storage.  Anything else is served by the generic engine.
+#include "lws_common.h"
 #include "lws_systolic.h"
 
 #include <cmath>
@@ -1992,12 +1993,13 @@ __global__ void __launch_bounds__(256) k_skew_to_out(float2 *out, const float2 *
 constexpr uint64_t mask_all(int Q, int L) { return (1ull << (Q * (L + 1))) - 1ull; }
 
 template <int Q, int L, uint64_t MASK, bool MULTI, bool H16> hipError_t launch_km(const SysArgs &a, int grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};   // one bit per device
+    int attr_dev;
+    if (lws::attr_needed(attr_set, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_systolic<Q, L, MASK, MULTI, H16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        lws::attr_done(attr_set, attr_dev);
     }
     hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI, H16>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
     return hipGetLastError();
@@ -2109,8 +2111,9 @@ void systolic_release(SystolicPlan &sp) {
     }
     if (sp.sk_state) (void)hipFree(sp.sk_state);
     if (sp.sk_amp) (void)hipFree(sp.sk_amp);
-    sp.sk_state = sp.sk_amp = nullptr;
-    sp.sk_state_cap = sp.sk_amp_cap = 0;
+    if (sp.thr_chunk) (void)hipFree(sp.thr_chunk);
+    sp.sk_state = sp.sk_amp = sp.thr_chunk = nullptr;
+    sp.sk_state_cap = sp.sk_amp_cap = sp.thr_chunk_cap = 0;
 }
 
 bool systolic_supports(const SystolicPlan &sp, int wsel, int T) {
@@ -2133,6 +2136,17 @@ struct Geom {
     float *thr_min;
     int *err;
 };
+
+// dense threshold table of one launch of a schedule longer than MAX_ITERS sweeps (a synchronising hipMalloc when it grows)
+hipError_t ensure_thr_chunk(SystolicPlan &sp, int B, int iters) {
+    const size_t need = (size_t)B * MAX_ITERS * sizeof(float);
+    if (iters <= MAX_ITERS || (sp.thr_chunk && sp.thr_chunk_cap >= need)) return hipSuccess;
+    if (sp.thr_chunk) (void)hipFree(sp.thr_chunk);
+    sp.thr_chunk = nullptr; sp.thr_chunk_cap = 0;
+    hipError_t e = hipMalloc(&sp.thr_chunk, need);
+    if (e == hipSuccess) sp.thr_chunk_cap = need;
+    return e;
+}
 
 // (grows the plan's scratch if needed -- a synchronising hipMalloc; systolic_reserve() does that ahead of time)
 hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
@@ -2269,12 +2283,7 @@ hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *th
         hipLaunchKernelGGL(k_thr_min, dim3(B), dim3(64), 0, stream, thr, reinterpret_cast<const float *>(g.amax_bits), iters, g.thr_min);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (iters > MAX_ITERS && (!sp.thr_chunk || sp.thr_chunk_cap < (size_t)B * MAX_ITERS * sizeof(float))) {
-        if (sp.thr_chunk) (void)hipFree(sp.thr_chunk);
-        sp.thr_chunk = nullptr; sp.thr_chunk_cap = 0;
-        if ((e = hipMalloc(&sp.thr_chunk, (size_t)B * MAX_ITERS * sizeof(float))) != hipSuccess) return e;
-        sp.thr_chunk_cap = (size_t)B * MAX_ITERS * sizeof(float);
-    }
+    if ((e = ensure_thr_chunk(sp, B, iters)) != hipSuccess) return e;
     int n_launch = 0;
     bool multi = false;
     // every sweep of the call, either with the workgroup counts of `g` or (single) with one workgroup per spectrogram
@@ -2325,7 +2334,9 @@ hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *th
 
 hipError_t systolic_reserve(SystolicPlan &sp, int B, int T, int iters) {
     Geom g;
-    return prepare(sp, B, T, iters, g);
+    hipError_t e = prepare(sp, B, T, iters, g);
+    if (e != hipSuccess) return e;
+    return ensure_thr_chunk(sp, B, iters);   // (schedules longer than one launch's table: sized here, not in the first call)
 }
 
 hipError_t launch_systolic(SystolicPlan &sp, int wsel, float2 *state, const float *amp, const float *thr, int B,
