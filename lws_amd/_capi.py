@@ -193,6 +193,23 @@ class Plan:
                                   ptrs[0], ptrs[1], ptrs[2], flags))
         self._h = h
         self._lib = lib
+        self._expect_generic = bool(force_generic) or precision == "fp64"
+        self._warned = False
+
+    def _note_engine(self):
+        """The generic engine serves every shape and weight tensor the reference accepts, 20-40x slower than the kernels
+        built for the common ones: say so once per plan instead of leaving lws_last_kernel_name as the only tell."""
+        if self._warned or self._expect_generic:
+            return
+        name = self._lib.lws_last_kernel_name(self._h).decode()      # (no synchronisation: a string set at launch time)
+        if name.startswith("generic"):
+            self._warned = True
+            import warnings
+            warnings.warn(
+                "lws_amd: this plan (F=%d bins, Q=%d, L=%d%s) runs on the order-exact generic engine (%s), 20-40x slower than "
+                "the systolic / LDS kernels; those serve fp32 plans with summarised create_weights() tensors, Q in {2,4,8}, "
+                "L in {1,3,5} (batch) or 5 (online), and for batch sweeps F-1 a multiple of 8 up to 1024"
+                % (self.F, self.Q, self.L, "" if self.Qp == self.Q else ", general weights", name), RuntimeWarning, stacklevel=3)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -229,6 +246,7 @@ class Plan:
         t, tp = self._thr(thresholds)
         check(self._lib.lws_batch_lws(self._h, wsel, S3.ctypes.data, out.ctypes.data, S3.shape[0],
                                       S3.shape[1], tp, t.size))
+        self._note_engine()
         return out.reshape(S.shape)
 
     def nofuture(self, S, thresholds, wsel=LWS_W):
@@ -236,6 +254,7 @@ class Plan:
         t, tp = self._thr(thresholds)
         check(self._lib.lws_nofuture_lws(self._h, wsel, S3.ctypes.data, out.ctypes.data,
                                          S3.shape[0], S3.shape[1], tp, t.size))
+        self._note_engine()
         return out.reshape(S.shape)
 
     def online(self, S, thresholds, LA, qdiv):
@@ -243,6 +262,7 @@ class Plan:
         t, tp = self._thr(thresholds)
         check(self._lib.lws_online_lws(self._h, S3.ctypes.data, out.ctypes.data, S3.shape[0],
                                        S3.shape[1], tp, t.size, int(LA), float(qdiv)))
+        self._note_engine()
         return out.reshape(S.shape)
 
     def run(self, S, thr_nofuture, thr_online, LA, qdiv, thr_batch):
@@ -252,26 +272,31 @@ class Plan:
         t2, p2 = self._thr(thr_batch)
         check(self._lib.lws_run_lws(self._h, S3.ctypes.data, out.ctypes.data, S3.shape[0], S3.shape[1],
                                     p0, t0.size, p1, t1.size, int(LA), float(qdiv), p2, t2.size))
+        self._note_engine()
         return out.reshape(S.shape)
 
     # ---- device-resident entry points (raw pointers: torch tensors pass .data_ptr()) ----
     def batch_dev(self, ptr, B, T, thresholds, wsel=LWS_W, stream=None):
         t, tp = self._thr(thresholds)
         check(self._lib.lws_batch_lws_dev(self._h, wsel, ptr, B, T, tp, t.size, stream))
+        self._note_engine()
 
     def nofuture_dev(self, ptr, B, T, thresholds, wsel=LWS_W, stream=None):
         t, tp = self._thr(thresholds)
         check(self._lib.lws_nofuture_lws_dev(self._h, wsel, ptr, B, T, tp, t.size, stream))
+        self._note_engine()
 
     def online_dev(self, ptr, B, T, thresholds, LA, qdiv, stream=None):
         t, tp = self._thr(thresholds)
         check(self._lib.lws_online_lws_dev(self._h, ptr, B, T, tp, t.size, int(LA), float(qdiv), stream))
+        self._note_engine()
 
     def run_dev(self, ptr, B, T, thr_nofuture, thr_online, LA, qdiv, thr_batch, stream=None):
         t0, p0 = self._thr(thr_nofuture)
         t1, p1 = self._thr(thr_online)
         t2, p2 = self._thr(thr_batch)
         check(self._lib.lws_run_lws_dev(self._h, ptr, B, T, p0, t0.size, p1, t1.size, int(LA), float(qdiv), p2, t2.size, stream))
+        self._note_engine()
 
     def reserve(self, B, T, max_iters):
         """Pre-size all scratch so that later *_dev calls of up to this shape only enqueue work (no hipMalloc)."""

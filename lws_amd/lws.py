@@ -282,6 +282,36 @@ def online_lws(S, W, W_ai, W_af, thresholds, LA, fshift, use_simplifications=Tru
     return _cached_plan(F, (W, np.asarray(W_ai), np.asarray(W_af)), plan_kw).online(S, thresholds, int(LA), qdiv)
 
 
+# ---- construction of an lws object: helpers ------------------------------------------------------------------------------
+# (the keyword surface, defaults, printed notices and attribute names are the reference's interface, lws.pyx:379-455)
+_STAGES = ("nofuture", "online", "batch")
+_SCHEDULE_KEYS = ("iterations", "alpha", "beta", "gamma")
+# what `mode` overrides (lws.pyx:437-442): stage -> iterations
+_MODES = {None: {}, "speech": {"nofuture": 0, "online": 0}, "music": {"nofuture": 1, "online": 10}}
+
+
+def _resolve_windows(awin_or_fsize, fshift, swin, fftsize, symmetric_win):
+    """Analysis window (a frame size stands for the reference's default window: the square root of a Hann window,
+    renormalised with its synthesis partner) zero-padded symmetrically to `fftsize`, and the synthesis window the caller
+    passed, padded the same way.  Returns (awin, swin or None, padded samples per side)."""
+    if isinstance(awin_or_fsize, (int, np.integer)):
+        root = np.sqrt(hann(int(awin_or_fsize), symmetric=symmetric_win, use_offset=False))
+        awin = np.sqrt(root * synthwin(root, fshift))
+    else:
+        awin = np.asarray(awin_or_fsize)
+        if awin.ndim > 1:   # (lws.pyx:391 compares a shape tuple with an int -- a TypeError on Python 3; the intent is clear)
+            if awin.ndim > 2 or min(awin.shape) > 1:
+                raise ValueError('The analysis window should be flat')
+            awin = awin.ravel()
+    extra = 0 if fftsize is None else int(fftsize) - len(awin)
+    if extra <= 0:
+        return awin, swin, 0
+    if extra % 2:
+        raise ValueError('The zero-padding should add even length to the original window.')
+    side = np.zeros(extra // 2)
+    return np.hstack((side, awin, side)), (None if swin is None else np.hstack((side, swin, side))), extra // 2
+
+
 class lws(object):
     """Configuration object of the reference (lws.pyx:378-499), same keyword arguments."""
 
@@ -291,66 +321,36 @@ class lws(object):
                  batch_iterations=100, batch_alpha=100, batch_beta=0.1, batch_gamma=1,
                  symmetric_win=True, mode=None, fftsize=None, perfectrec=True, use_simplifications=True,
                  device=0, precision="fp32", nofuture_q4_compat=True, force_generic=False, storage="fp32"):
-        if isinstance(awin_or_fsize, (int, np.integer)):
-            awin = np.sqrt(hann(int(awin_or_fsize), symmetric=symmetric_win, use_offset=False))
-            awin = np.sqrt(awin * synthwin(awin, fshift))
-        else:
-            awin = np.asarray(awin_or_fsize)
-        if awin.ndim > 1:
-            # lws.pyx:391 compares a shape tuple with an int (TypeError on Python 3); the intent is clear
-            if awin.ndim > 2 or min(awin.shape) > 1:
-                raise ValueError('The analysis window should be flat')
-            awin = awin.flatten()
-        if fftsize is None:
-            fftsize = len(awin)
-        if fftsize > len(awin):
-            if (fftsize - len(awin)) % 2 != 0:
-                raise ValueError('The zero-padding should add even length to the original window.')
-            pad_length = (fftsize - len(awin)) // 2
+        schedule = {"nofuture": (nofuture_iterations, nofuture_alpha, nofuture_beta, nofuture_gamma),
+                    "online": (online_iterations, online_alpha, online_beta, online_gamma),
+                    "batch": (batch_iterations, batch_alpha, batch_beta, batch_gamma)}
+        # windows
+        awin, swin_given, padded = _resolve_windows(awin_or_fsize, fshift, swin, fftsize, symmetric_win)
+        if padded:
             print('Zero-padding symmetrically around the original windows.\n'
                   'WARNING: for code simplicity, a consequence is that the first/last '
-                  '{} samples of the signal will not be '.format(pad_length) +
+                  '{} samples of the signal will not be '.format(padded) +
                   'in the perfect reconstruction region.')
-            pad = np.zeros(pad_length)
-            awin = np.hstack((pad, awin, pad))
-            if swin is not None:
-                swin = np.hstack((pad, swin, pad))
-        self.awin = awin
-        if swin is not None:
+        if swin_given is not None:
             print('Provided synthesis window is renormalized for perfect reconstruction.')
-        self.swin = synthwin(awin, fshift, swin=swin)
-        self.fshift = fshift
-        self.fsize = len(awin)
-        self.perfectrec = perfectrec
-        self.L = L
-        self.Q = int(self.fsize / self.fshift) if self.fsize % self.fshift == 0 else self.fsize / self.fshift
-        self.use_simplifications = use_simplifications
-        self.W = create_weights(self.awin, self.swin, self.fshift, self.L,
-                                use_summarized_weights=self.use_simplifications)
+        self.awin, self.fshift, self.fsize = awin, fshift, len(awin)
+        self.swin = synthwin(awin, fshift, swin=swin_given)
+        self.perfectrec, self.L, self.use_simplifications, self.look_ahead = perfectrec, L, use_simplifications, look_ahead
+        q = self.fsize / self.fshift
+        self.Q = int(q) if self.fsize % self.fshift == 0 else q
+        # weights of the three sweeps: symmetric windows, and the two asymmetric envelopes of RTISI-LA
         self.win_ai, self.win_af = build_asymmetric_windows(self.awin * self.swin, self.fshift)
-        self.W_ai = create_weights(self.win_ai, self.swin, self.fshift, self.L,
-                                   use_summarized_weights=self.use_simplifications)
-        self.W_af = create_weights(self.win_af, self.swin, self.fshift, self.L,
-                                   use_summarized_weights=self.use_simplifications)
-        self.look_ahead = look_ahead
-        if mode == 'speech':
-            nofuture_iterations = 0
-            online_iterations = 0
-        elif mode == 'music':
-            nofuture_iterations = 1
-            online_iterations = 10
-        self.batch_iterations = batch_iterations
-        self.batch_alpha = batch_alpha
-        self.batch_beta = batch_beta
-        self.batch_gamma = batch_gamma
-        self.online_iterations = online_iterations
-        self.online_alpha = online_alpha
-        self.online_beta = online_beta
-        self.online_gamma = online_gamma
-        self.nofuture_iterations = nofuture_iterations
-        self.nofuture_alpha = nofuture_alpha
-        self.nofuture_beta = nofuture_beta
-        self.nofuture_gamma = nofuture_gamma
+        for attr, win in (("W", self.awin), ("W_ai", self.win_ai), ("W_af", self.win_af)):
+            setattr(self, attr, create_weights(win, self.swin, self.fshift, self.L, use_summarized_weights=use_simplifications))
+        # schedules: <stage>_iterations / _alpha / _beta / _gamma; `mode` presets the first two stages
+        if mode not in _MODES:
+            mode = None          # (the reference ignores an unknown mode)
+        for stage in _STAGES:
+            values = list(schedule[stage])
+            if stage in _MODES[mode]:
+                values[0] = _MODES[mode][stage]
+            for key, value in zip(_SCHEDULE_KEYS, values):
+                setattr(self, "%s_%s" % (stage, key), value)
         if not np.allclose(awin, awin[::-1]):
             print('WARNING: It appears you are using an analysis window that is not symmetric.\n'
                   'The current code uses simplifications that rely on such symmetry, so the code may not behave properly.')
