@@ -144,8 +144,8 @@ int lws_stream_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stre
 /* Name of the update kernel the last call dispatched ("generic_fp32", "systolic_q4", ...). */
 const char *lws_last_kernel_name(lws_plan *plan);
 
-/* ---- the steps either side of the path, on the device (lws.pyx:43-144; float32, frame size N a power of two in
- *      [32, 2048], fftsize == fsize).  Windows are host arrays of N doubles, already normalised the way the caller
+/* ---- the steps either side of the path, on the device (lws.pyx:43-144; float32, any even frame size N in [32, 4096]
+ *      -- an odd factor times a power of two: radix-2 stages and one stage of odd-point DFTs --, fftsize == fsize).  Windows are host arrays of N doubles, already normalised the way the caller
  *      wants them (class lws: awin and synthwin(awin, fshift)).  perfectrec as in lws.pyx:55-67,130-137. ---- */
 
 /* Frames stft() produces for a signal of `len` samples (lws.pyx:55-76); < 1 if the signal is too short. */

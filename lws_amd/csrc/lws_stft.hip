@@ -1,9 +1,11 @@
 // lws_stft.hip -- the steps either side of the LWS path, on the device: STFT, inverse STFT and the consistency measure
 // 20 log10(|S| / |STFT(iSTFT(S)) - S|) of lws.pyx:43-144, for batches of independent signals / spectrograms.
 //
-// One workgroup per frame runs a radix-2 Stockham FFT of the frame size N (a power of two, 32..2048) in LDS, fp32 -- or, for
-// the other even frame sizes lws.pyx:43-90 accepts (e.g. 48, 1536), a direct DFT against a twiddle table in LDS: N^2 instead
-// of N log N operations per frame, a correct fallback rather than a fast path;
+// One workgroup per frame transforms it in LDS, fp32, for any even frame size N in [32, 4096] (lws.pyx:43-90 accepts any even
+// size).  N = m 2^a with m odd: the m interleaved subsequences of length 2^a go through a radix-2 Stockham FFT (all of them in
+// every butterfly stage), then one stage of m-point DFTs with the twiddles exp(-2 pi j r k / N) combines them (Cooley-Tukey,
+// decimation in time): N (a + m) operations -- N log2 N for a power of two, 2.6 N log2 N for 1536 = 3 x 512, N^2 / 8 for
+// 1000 = 125 x 8 (round 2 ran a direct N^2 DFT for every size that is not a power of two);
 // the overlap-add is a gather (each output sample sums the <= ceil(N/hop) frames that cover it), so there are no
 // atomics and the result does not depend on scheduling.  Sums of squares for the consistency are accumulated in fp64
 // per frame and reduced in a fixed order.
@@ -11,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -19,7 +22,7 @@
 
 namespace {
 
-constexpr int MAXN = 2048, MINN = 32, FFT_THREADS = 256;   // two N-point complex buffers + the reduction scratch stay under 64 KB of LDS
+constexpr int MAXN = 4096, MINN = 32, FFT_THREADS = 256;   // two N-point complex buffers (three if N is not a power of two): <= 96 KB of LDS
 
 #define STFT_TRY(expr)                                                                                              \
     do {                                                                                                            \
@@ -28,59 +31,68 @@ constexpr int MAXN = 2048, MINN = 32, FFT_THREADS = 256;   // two N-point comple
             return lws::set_error(LWS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-// Complex FFT of n = 2^logn points held in LDS (x: data, y: scratch of the same size), by all threads of the block;
-// Stockham auto-sort, decimation in frequency, natural order in and out.  sign = -1 forward, +1 inverse
-// (unnormalised).  Returns the buffer that holds the result.
-// logn < 0: n is not a power of two -- direct DFT; y then holds 2n entries (the result, then exp(-2 pi j i / n)).
-__device__ float2 *fft_lds(float2 *x, float2 *y, int n, int logn, float sign) {
+// Complex DFT of n = m 2^a points held in LDS (x: data, y: scratch of the same size, followed -- if m > 1 -- by n entries for
+// the twiddle table), by all threads of the block; natural order in and out.  sign = -1 forward, +1 inverse (unnormalised).
+// Returns the buffer that holds the result.
+__device__ float2 *fft_lds(float2 *x, float2 *y, int n, int m, int a, float sign) {
     const int tid = threadIdx.x, nthr = blockDim.x;
-    if (logn < 0) {
-        float2 *tw = y + n;
+    const int n2 = n / m;                                // 2^a
+    float2 *tw = y + n;
+    if (m > 1) {
+        // exp(sign 2 pi j i / n), and the m interleaved subsequences side by side: y[r n2 + j] = x[m j + r]
         for (int i = tid; i < n; i += nthr) {
             float sn, cs;
             sincospif(2.0f * (float)i / (float)n, &sn, &cs);
-            tw[i] = make_float2(cs, -sn);
-        }
-        __syncthreads();
-        for (int k = tid; k < n; k += nthr) {
-            float ar = 0.f, ai = 0.f;
-            int idx = 0;                                 // (k * i) mod n
-            for (int i = 0; i < n; ++i) {
-                const float2 v = x[i], w = tw[idx];
-                const float wi = sign < 0.f ? w.y : -w.y;
-                ar += v.x * w.x - v.y * wi;
-                ai += v.x * wi + v.y * w.x;
-                idx += k;
-                if (idx >= n) idx -= n;
-            }
-            y[k] = make_float2(ar, ai);
-        }
-        __syncthreads();
-        return y;
-    }
-    int ncur = n, s = 1;
-    for (int st = 0; st < logn; ++st) {
-        const int m = ncur >> 1;
-        for (int i = tid; i < n / 2; i += nthr) {
-            const int p = i / s, q = i - p * s;          // s is a power of two: shifts
-            float sn, cs;
-            sincospif(sign * 2.0f * (float)p / (float)ncur, &sn, &cs);
-            const float2 a = x[q + s * p], b = x[q + s * (p + m)];
-            const float2 d = make_float2(a.x - b.x, a.y - b.y);
-            y[q + s * (2 * p)] = make_float2(a.x + b.x, a.y + b.y);
-            y[q + s * (2 * p + 1)] = make_float2(d.x * cs - d.y * sn, d.x * sn + d.y * cs);
+            tw[i] = make_float2(cs, sign * sn);
+            const int j = i / m, r = i - j * m;
+            y[r * n2 + j] = x[i];
         }
         __syncthreads();
         float2 *t = x; x = y; y = t;
-        ncur = m;
+    }
+    // radix-2 Stockham (auto-sort, decimation in frequency) of the m blocks of n2 points, all blocks in every stage
+    int ncur = n2, s = 1;
+    for (int st = 0; st < a; ++st) {
+        const int h = ncur >> 1;
+        for (int i0 = tid; i0 < n / 2; i0 += nthr) {
+            const int blk = i0 / (n2 / 2), i = i0 - blk * (n2 / 2);
+            const int p = i / s, q = i - p * s;          // s is a power of two: shifts
+            float sn, cs;
+            sincospif(sign * 2.0f * (float)p / (float)ncur, &sn, &cs);
+            const float2 *xb = x + blk * n2;
+            float2 *yb = y + blk * n2;
+            const float2 u = xb[q + s * p], v = xb[q + s * (p + h)];
+            const float2 d = make_float2(u.x - v.x, u.y - v.y);
+            yb[q + s * (2 * p)] = make_float2(u.x + v.x, u.y + v.y);
+            yb[q + s * (2 * p + 1)] = make_float2(d.x * cs - d.y * sn, d.x * sn + d.y * cs);
+        }
+        __syncthreads();
+        float2 *t = x; x = y; y = t;
+        ncur = h;
         s <<= 1;
     }
-    return x;
+    if (m == 1) return x;
+    // X[k + n2 q] = sum_r exp(sign 2 pi j r (k + n2 q) / n) Y_r[k]
+    for (int o = tid; o < n; o += nthr) {
+        const int k = o % n2;
+        float ar = 0.f, ai = 0.f;
+        int idx = 0;                                     // (r o) mod n
+        for (int r = 0; r < m; ++r) {
+            const float2 v = x[r * n2 + k], w = tw[idx];
+            ar += v.x * w.x - v.y * w.y;
+            ai += v.x * w.y + v.y * w.x;
+            idx += o;
+            if (idx >= n) idx -= n;
+        }
+        y[o] = make_float2(ar, ai);
+    }
+    __syncthreads();
+    return y;
 }
 
 // lws.pyx:118-128: one frame = inverse FFT of the Hermitian completion, first N samples, times the synthesis window
 __global__ void __launch_bounds__(FFT_THREADS) k_istft_frames(const float2 *S, float *frames, const float *swin, int M,
-                                                               int N, int logn) {
+                                                               int N, int odd, int log2e) {
     extern __shared__ float2 lds[];
     const int m = blockIdx.x, b = blockIdx.y, F = N / 2 + 1;
     const float2 *row = S + ((size_t)b * M + m) * F;
@@ -91,7 +103,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_istft_frames(const float2 *S, f
         x[k] = v;
     }
     __syncthreads();
-    const float2 *r = fft_lds(x, y, N, logn, 1.0f);
+    const float2 *r = fft_lds(x, y, N, odd, log2e, 1.0f);
     const float inv = 1.0f / (float)N;
     float *out = frames + ((size_t)b * M + m) * N;
     for (int n = threadIdx.x; n < N; n += blockDim.x) out[n] = r[n].x * inv * swin[n];
@@ -119,7 +131,7 @@ __global__ void k_overlap_add(const float *frames, float *signal, int M, int N, 
 // S_out != null: write the spectrogram.  rows != null: accumulate |X - S_ref|^2 and |S_ref|^2 of the frame in fp64.
 __global__ void __launch_bounds__(FFT_THREADS) k_stft_frames(const float *x, int len, int pitch, int pre, const float *awin,
                                                               float2 *S_out, const float2 *S_ref, double *rows, int M,
-                                                              int N, int logn, int hop) {
+                                                              int N, int odd, int log2e, int hop) {
     extern __shared__ float2 lds[];
     __shared__ double red[2][FFT_THREADS];
     const int m = blockIdx.x, b = blockIdx.y, F = N / 2 + 1;
@@ -130,7 +142,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_stft_frames(const float *x, int
         xa[n] = make_float2((i >= 0 && i < len) ? sig[i] * awin[n] : 0.f, 0.f);
     }
     __syncthreads();
-    const float2 *r = fft_lds(xa, ya, N, logn, -1.0f);
+    const float2 *r = fft_lds(xa, ya, N, odd, log2e, -1.0f);
     if (S_out) {
         float2 *o = S_out + ((size_t)b * M + m) * F;
         for (int k = threadIdx.x; k < F; k += blockDim.x) o[k] = r[k];
@@ -202,14 +214,30 @@ int ctx_leave(DeviceCtx &c, hipStream_t s) {
     return LWS_OK;
 }
 
-int ilog2(int n) { if (n & (n - 1)) return -1; int l = 0; while ((1 << l) < n) ++l; return l; }   // -1: not a power of two (direct DFT)
-size_t fft_lds_bytes(int N) { return (size_t)((N & (N - 1)) ? 3 : 2) * N * sizeof(float2); }
+// N = odd * 2^log2e
+struct Factors { int odd, log2e; };
+Factors factor(int n) { Factors f{n, 0}; while (!(f.odd & 1)) { f.odd >>= 1; ++f.log2e; } return f; }
+size_t fft_lds_bytes(int N) { return (size_t)(factor(N).odd > 1 ? 3 : 2) * N * sizeof(float2); }
+// frames of more than 2048 points need more dynamic LDS than a kernel gets by default
+template <typename K> hipError_t allow_lds(K kernel) {
+    static std::atomic<unsigned long long> done{0};   // one bit per device
+    int dev;
+    if (!lws::attr_needed(done, &dev)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * MAXN * (int)sizeof(float2));
+    if (e == hipSuccess) lws::attr_done(done, dev);
+    return e;
+}
 
 int check_shape(int device, int B, int M, int N, int hop) {
     if (device < 0 || device >= MAX_DEVICES) return lws::set_error(LWS_ERR_INVALID, "device index %d out of range", device);
     if (B < 0 || M < 1) return lws::set_error(LWS_ERR_INVALID, "empty batch or no frames");
     if (N < MINN || N > MAXN || (N & 1)) return lws::set_error(LWS_ERR_UNSUPPORTED, "frame size %d: the device transform serves even sizes in [%d, %d]", N, MINN, MAXN);
     if (hop < 1 || hop > N) return lws::set_error(LWS_ERR_INVALID, "frame shift %d", hop);
+    return LWS_OK;
+}
+int allow_lds_all() {
+    STFT_TRY(allow_lds(k_stft_frames));
+    STFT_TRY(allow_lds(k_istft_frames));
     return LWS_OK;
 }
 
@@ -258,10 +286,11 @@ int lws_stft_dev(int device, const float *x_dev, int B, int len, int N, int fshi
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceCtx &c = g_ctx[device];
     if ((rc = ctx_enter(c, s))) return rc;
+    if ((rc = allow_lds_all())) return rc;
     if ((rc = upload_window(c.win_a, awin, N, s))) return rc;
     hipLaunchKernelGGL(k_stft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s, x_dev, len, len,
                        perfectrec ? prepad(N, fshift) : 0, static_cast<const float *>(c.win_a.p),
-                       static_cast<float2 *>(S_dev), nullptr, nullptr, M, N, ilog2(N), fshift);
+                       static_cast<float2 *>(S_dev), nullptr, nullptr, M, N, factor(N).odd, factor(N).log2e, fshift);
     STFT_TRY(hipGetLastError());
     return ctx_leave(c, s);
 }
@@ -277,13 +306,14 @@ int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceCtx &c = g_ctx[device];
     if ((rc = ctx_enter(c, s))) return rc;
+    if ((rc = allow_lds_all())) return rc;
     if ((rc = upload_window(c.win_s, swin, N, s))) return rc;
     const int Tfull = fshift * (M - 1) + N, out_len = lws_istft_length(M, N, fshift, perfectrec);
     if ((rc = c.frames.ensure((size_t)B * M * N * sizeof(float)))) return rc;
     if ((rc = c.signal.ensure((size_t)B * Tfull * sizeof(float)))) return rc;
     hipLaunchKernelGGL(k_istft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s,
                        static_cast<const float2 *>(S_dev), static_cast<float *>(c.frames.p),
-                       static_cast<const float *>(c.win_s.p), M, N, ilog2(N));
+                       static_cast<const float *>(c.win_s.p), M, N, factor(N).odd, factor(N).log2e);
     hipLaunchKernelGGL(k_overlap_add, dim3((Tfull + 255) / 256, B), dim3(256), 0, s, static_cast<const float *>(c.frames.p),
                        static_cast<float *>(c.signal.p), M, N, fshift, Tfull, 0, 0);
     STFT_TRY(hipGetLastError());
@@ -305,6 +335,7 @@ int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int 
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceCtx &c = g_ctx[device];
     if ((rc = ctx_enter(c, s))) return rc;
+    if ((rc = allow_lds_all())) return rc;
     if ((rc = upload_window(c.win_a, awin, N, s))) return rc;
     if ((rc = upload_window(c.win_s, swin, N, s))) return rc;
     const int Tfull = fshift * (M - 1) + N;
@@ -314,7 +345,7 @@ int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int 
     if ((rc = c.out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
     const float2 *S = static_cast<const float2 *>(S_dev);
     hipLaunchKernelGGL(k_istft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s, S,
-                       static_cast<float *>(c.frames.p), static_cast<const float *>(c.win_s.p), M, N, ilog2(N));
+                       static_cast<float *>(c.frames.p), static_cast<const float *>(c.win_s.p), M, N, factor(N).odd, factor(N).log2e);
     // with perfectrec the reference cuts the first prepad and the last N - hop samples and the forward transform pads
     // zeros back in their place (same frame count): the full overlap-add signal with those samples zeroed
     hipLaunchKernelGGL(k_overlap_add, dim3((Tfull + 255) / 256, B), dim3(256), 0, s, static_cast<const float *>(c.frames.p),
@@ -322,7 +353,7 @@ int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int 
                        perfectrec ? N - fshift : 0);
     hipLaunchKernelGGL(k_stft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s,
                        static_cast<const float *>(c.signal.p), Tfull, Tfull, 0, static_cast<const float *>(c.win_a.p),
-                       static_cast<float2 *>(nullptr), S, static_cast<double *>(c.rows.p), M, N, ilog2(N), fshift);
+                       static_cast<float2 *>(nullptr), S, static_cast<double *>(c.rows.p), M, N, factor(N).odd, factor(N).log2e, fshift);
     hipLaunchKernelGGL(k_sum_rows, dim3((B + 63) / 64), dim3(64), 0, s, static_cast<const double *>(c.rows.p),
                        static_cast<double *>(c.out.p), M, B);
     STFT_TRY(hipGetLastError());

@@ -387,7 +387,7 @@ class lws(object):
     def stft(self, S):
         return stft(S, self.fsize, self.fshift, self.awin, perfectrec=self.perfectrec)
 
-    # ---- device versions of the three helpers above (float32 transforms; frame size a power of two, 32..2048).
+    # ---- device versions of the three helpers above (float32 transforms; any even frame size in 32..4096).
     # Arguments are torch CUDA tensors (complex64 spectrograms (B, T, F) / float32 signals (B, len)) or numpy arrays,
     # which are moved to the plan's device through torch -- PyTorch is only the owner of the device memory here.
     def _to_dev(self, a, dtype):

@@ -10,8 +10,9 @@ import lws_amd
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fsize,fshift", [(64, 16), (128, 64), (512, 128), (1024, 256), (2048, 512), (256, 96),
-                                          (48, 16), (1536, 384), (1000, 250)])   # (the last three: not powers of two, direct DFT)
+@pytest.mark.parametrize("fsize,fshift", [(64, 16), (128, 64), (512, 128), (1024, 256), (2048, 512), (256, 96), (4096, 1024),
+                                          # not powers of two: an odd factor (3, 125, 129, 5) times a power of two
+                                          (48, 16), (1536, 384), (1000, 250), (1032, 258), (3840, 960)])
 @pytest.mark.parametrize("perfectrec", [True, False])
 def test_stft_istft_match_host(fsize, fshift, perfectrec):
     rng = np.random.default_rng(fsize + fshift)
@@ -59,9 +60,18 @@ def test_consistency_matches_host(fsize, fshift, perfectrec):
 
 
 def test_unsupported_frame_sizes_raise():
-    p = lws_amd.lws(4096, 1024)                  # beyond the LDS-resident transform
+    p = lws_amd.lws(8192, 2048)                  # beyond the LDS-resident transform (even sizes up to 4096)
     with pytest.raises(lws_amd.LwsHipError):
-        p.get_consistency_dev(np.ones((5, 2049), complex))
+        p.get_consistency_dev(np.ones((5, 4097), complex))
+
+
+def test_consistency_at_4096():
+    rng = np.random.default_rng(5)
+    p = lws_amd.lws(4096, 1024)
+    X = p.stft(rng.standard_normal(10 * 4096))
+    S = rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape)
+    assert abs(p.get_consistency_dev(S) - p.get_consistency(S)) < 0.01
+    assert p.get_consistency_dev(X) > 100.0
 
 
 @pytest.mark.gpu
