@@ -567,14 +567,30 @@ def run_config1(lws_amd, local_rank):
             walls.append(1e3 * (time.perf_counter() - t3))
         thr = lws_amd.get_thresholds(10, kw.get("batch_alpha", 100), 0.1, 1)
         orc = Oracle()
+        ref = orc.batch_lws(M.astype(np.complex128), p.W, thr)           # the checker
+        cpu_kind = "port (oracle/lws_oracle.c, fp64, 1 thread)"
         tc = time.perf_counter()
-        ref = orc.batch_lws(M.astype(np.complex128), p.W, thr)
+        if RefLib.available():   # the reference's own LWSQ4 (lwslib.cpp:153-280), compiled in place: the 10 sweeps of batch_lws
+            import ctypes as C
+            from oracle.oracle import split_weights
+            rl = RefLib()
+            wr, wi, wf = split_weights(p.W)
+            er, ei = orc.extend(M.astype(np.complex128), p.L, int(p.Q))
+            amp = np.ascontiguousarray(np.abs(er + 1j * ei))
+            mean = float(M.mean())
+            tc = time.perf_counter()
+            for t_i in thr:
+                rl.fn["LWSQ4"](C.c_void_p(er.ctypes.data), C.c_void_p(ei.ctypes.data), C.c_void_p(wr.ctypes.data), C.c_void_p(wi.ctypes.data),
+                               C.c_void_p(wf.ctypes.data), C.c_void_p(amp.ctypes.data), int(M.shape[1]), int(M.shape[0]), int(p.L), float(t_i * mean))
+            cpu_kind = "reference (oracle/_ref: lwslib.cpp LWSQ4, fp64, 1 thread; the sweeps only, without the wrapper's preparation)"
+        else:
+            orc.batch_lws(M.astype(np.complex128), p.W, thr)
         cpu_ms = 1e3 * (time.perf_counter() - tc)
         err = np.abs(Y - ref)
         out[label] = {"frames": int(M.shape[0]), "bins": int(M.shape[1]), "first_call_ms_incl_plan_creation": 1e3 * (t2 - t1),
                       "wall_ms": min(walls), "value": float(M.size) * 10 / (min(walls) * 1e-3),
                       "kernel": p.plan().last_kernel()["name"],
-                      "cpu_reference_ms": cpu_ms, "cpu_kind": "port (oracle/lws_oracle.c, fp64, 1 thread)",
+                      "cpu_reference_ms": cpu_ms, "cpu_kind": cpu_kind,
                       "updated_bins_fraction": float(np.mean(Y != M)),
                       "checks": {"rel_l2_vs_cpu": float(np.linalg.norm(err) / max(np.linalg.norm(ref), 1e-300)),
                                  "max_rel_magnitude_error": float(np.abs(np.abs(Y) - M).max() / M.max())}}
