@@ -842,6 +842,28 @@ __device__ __forceinline__ void cmac_cv_pk(v2f &a, v2f w, v2f v) {
         : "+v"(a) : "v"(w), "v"(v));
 }
 
+// acc += M (px, py)^T with the 2 x 2 real matrix M = (col0 | col1) held as (col0.x, col0.y, col1.x, col1.y): what
+// w p + e conj(p) is for complex w, e -- col0 = (w.x + e.x, w.y + e.y), col1 = (e.y - w.y, w.x - e.x) -- in two instructions
+__device__ __forceinline__ void mat_mac_pk(v2f &a, float4 M, v2f p) {
+    const v2f c0 = {M.x, M.y}, c1 = {M.z, M.w};
+    asm("v_pk_fma_f32 %0, %1, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(a) : "v"(c0), "v"(c1), "v"(p));
+}
+__device__ __forceinline__ v2f mat_mul_pk(float4 M, v2f p) {
+    const v2f c0 = {M.x, M.y}, c1 = {M.z, M.w};
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %3 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "=&v"(r) : "v"(c0), "v"(c1), "v"(p));
+    return r;
+}
+// the power of two that brings a positive normal number to [1, 2) (1 for zero, denormals, infinities)
+__device__ __forceinline__ float pow2_to_unit(float amax) {
+    const unsigned e = (__float_as_uint(amax) >> 23) & 0xffu;
+    return (e == 0u || e == 0xffu) ? 1.0f : __uint_as_float((e >= 254u ? 1u : 254u - e) << 23);
+}
+
 template <int Q, int L, bool SERIAL>
 __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -857,10 +879,11 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     const int nsweeps = T * per;
     constexpr int NLO = (L + 2) / 4, NHI = (L + 1) / 2 + 1, NST = 1 + NLO + NHI;
     // LDS layout (byte offsets; lds_of in shape4_of is the same sum)
-    const unsigned oET = 2u * NTW * 64 * 16, oS = oET + (192 + 64) * 8, oA = oS + ((unsigned)NWR * NPS + 8) * 8, oW = oA + (unsigned)NWR * NPS * 4,
+    const unsigned oET = 2u * NTW * 64 * 16, oS = oET + (224 + 64) * 8, oA = oS + ((unsigned)NWR * NPS + 8) * 8, oW = oA + (unsigned)NWR * NPS * 4,
                    oTW = oW + 3u * Q * Q * K1 * 8, oThr = oTW + Q * 8, oTAB = (oThr + (unsigned)a.n_thr * 4 + 15u) & ~15u;
     float4 *P = reinterpret_cast<float4 *>(smem);                               // [2][NTW][64]: (sum of bin c, of bin c+1)
-    float2 *ET = reinterpret_cast<float2 *>(smem + oET);                        // [3][NST][6] (padded to 192 entries): edge-term weights
+    float4 *MT = reinterpret_cast<float4 *>(smem + oET);                        // [3][NST][6]: own-history matrices of the projection wave (below)
+    static_assert(3 * NST * 6 * 16 <= 224 * 8, "matrix table");
     float2 *S = reinterpret_cast<float2 *>(smem + oS);                          // [NWR][NPS] (+ 8); the 64 entries below it: spare slots
     float *A = reinterpret_cast<float *>(smem + oA);                            // [NWR][NPS]
     float2 *W = reinterpret_cast<float2 *>(smem + oW);                          // [3][Q][Q][K1]
@@ -874,38 +897,79 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     float2 *gS = a.state + (size_t)b * Tp * Np;
     const float *gA = a.amp + (size_t)b * Tp * Np;
 
+    // The weighted sums are only ever normalised, so the weights of this spectrogram are scaled by the power of two that
+    // brings its largest target magnitude to [1, 2) -- exact -- and |sum|^2 can be formed in fp32 for data of any scale
+    // without the rescue path (rescale and square again when the square underflows) both re-projections of a step carried.
+    // (A sum below 1e-19 of the data's scale now counts as zero -- no update -- where the reference, in fp64, would still
+    // take its phase; fp32 rounding decides that phase long before.)  Not in the verification variant: bit for bit the
+    // generic engine.
+    float wscale = 1.0f;
+    if constexpr (!SERIAL) {
+        float mx = 0.f;
+        for (int i = tid; i < Tp * Np; i += nthr) mx = fmaxf(mx, gA[i]);
+        float *red = reinterpret_cast<float *>(smem);                // (P: not in use yet)
+        red[tid] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < nthr; ++i) mx = fmaxf(mx, red[i]);
+            red[0] = pow2_to_unit(mx);
+        }
+        __syncthreads();
+        wscale = red[0];
+        __syncthreads();
+    }
     for (int i = tid; i < 3 * Q * Q * K1; i += nthr) {
         const int x = i % (Q * Q * K1);
-        W[i] = (x % (Q * K1) == 0) ? make_float2(0.f, 0.f) : a.w[i / (Q * Q * K1)][x];
+        const float2 w = a.w[i / (Q * Q * K1)][x];
+        W[i] = (x % (Q * K1) == 0) ? make_float2(0.f, 0.f) : make_float2(w.x * wscale, w.y * wscale);
     }
     if (tid < Q) TW[tid] = a.tw[tid];
     for (int i = tid; i < NWR * NPS + 8; i += nthr) S[i] = make_float2(0.f, 0.f);
     for (int i = tid; i < NWR * NPS; i += nthr) A[i] = 0.f;
     for (int i = tid; i < 2 * NTW * 64; i += nthr) P[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    if (tid < 3 * NST * 6) {   // edge-term weights of the projection wave: as in k_online3
-        const int ws = tid / (NST * 6), st = (tid / 6) % NST, jj = tid % 6;
+    // Own-history terms of the projection wave, per weight set and kind of step (0: none of the edge terms; 1..NLO: the steps
+    // u = 1..NLO after a frame start; then N - c = 0..NHI-1), as 2 x 2 matrices (mat_mac_pk): entry 0 / 1: what bins c-1 / c-2
+    // contribute to the sum of bin c -- the centre weight W[k] times the value plus the edge weight times its conjugate
+    // (the Hermitian image of that bin as a tap near a frame edge: low edge, image column -y, tap k = c + y backwards: W[k];
+    // high edge, column 2N - y, tap k = 2(N-c) + d forwards: conj W[k]); 2 / 3: the same two bins in the sum of bin c+1;
+    // 4: the new bin c in the sum of bin c+1; 5: (x, y) = weight of the conjugate of the OLD value of bin c in the sum of
+    // bin c (its own image).  W_ai (set 1: first estimate of a frame) has no centre term.
+    if (tid < 3 * NST) {
+        const int ws = tid / NST, st = tid % NST;
         const float2 *wb = W + (ws * Q) * Q * K1;
-        const int d = jj < 3 ? jj : (jj < 5 ? jj - 2 : 0), shift = jj < 3 ? 0 : 1;
-        float2 w = make_float2(0.f, 0.f);
-        if (ws != 1 && st >= 1 && st <= NLO) {
-            const int c = 2 * st, y = c - d, k = c + y + shift;
-            if (y >= 1 && k <= L) w = wb[k];
-        } else if (ws != 1 && st > NLO) {
-            const int g = st - NLO - 1, k = 2 * g + d - shift;
-            if (g + d >= 1 && g + d <= L && k >= 1 && k <= L) w = make_float2(wb[k].x, -wb[k].y);
-        }
-        ET[tid] = w;
+        auto edge = [&](int jj) {   // jj = 0..2: conj of bin c-jj in the sum of bin c; 3, 4: of bins c-1, c-2 in the sum of bin c+1; 5: of the new bin c there
+            const int d = jj < 3 ? jj : (jj < 5 ? jj - 2 : 0), shift = jj < 3 ? 0 : 1;
+            float2 w = make_float2(0.f, 0.f);
+            if (ws != 1 && st >= 1 && st <= NLO) {
+                const int c = 2 * st, y = c - d, k = c + y + shift;
+                if (y >= 1 && k <= L) w = wb[k];
+            } else if (ws != 1 && st > NLO) {
+                const int g = st - NLO - 1, k = 2 * g + d - shift;
+                if (g + d >= 1 && g + d <= L && k >= 1 && k <= L) w = make_float2(wb[k].x, -wb[k].y);
+            }
+            return w;
+        };
+        auto centre_w = [&](int k) { return (ws != 1 && k <= L) ? wb[k] : make_float2(0.f, 0.f); };
+        auto mat = [](float2 w, float2 e) { return make_float4(w.x + e.x, w.y + e.y, e.y - w.y, w.x - e.x); };
+        float4 *mt = MT + (size_t)tid * 6;
+        mt[0] = mat(centre_w(1), edge(1));
+        mt[1] = mat(centre_w(2), edge(2));
+        mt[2] = mat(centre_w(2), edge(3));
+        mt[3] = mat(centre_w(3), edge(4));
+        mt[4] = mat(centre_w(1), edge(5));
+        const float2 e0 = edge(0);
+        mt[5] = make_float4(e0.x, e0.y, 0.f, 0.f);
     }
     if (tid < 64) S[-64 + tid] = make_float2(0.f, 0.f);
-    // step table: x = byte offset of the pair's edge-term set in ET (within a weight set), y / z = byte offsets of the Hermitian
+    // step table: x = byte offset of the pair's matrices in MT (within a weight set), y / z = byte offsets of the Hermitian
     // images of the pair's bins relative to the bins themselves (0: no image), w = sign bit if the pair has no second bin
     for (int uu = tid; uu < NU; uu += nthr) {
         const int c = 2 * uu, cb = c + 1, g = N - c;
         const int stype = (uu >= 1 && uu <= NLO) ? uu : (g < NHI ? NLO + 1 + g : 0);
         const int da = (c >= 1 && c <= L) ? -16 * c : ((c >= N - L && c <= N - 1) ? 16 * (N - c) : 0);
         const int db = (cb <= L) ? -16 * cb : ((cb >= N - L && cb <= N - 1) ? 16 * (N - cb) : 0);
-        TAB[uu] = make_int4(stype * 48, da, db, cb < F ? 0 : (int)0x80000000);
+        TAB[uu] = make_int4(stype * 96, da, db, cb < F ? 0 : (int)0x80000000);
     }
     __syncthreads();
     for (int i = tid; i < a.n_thr; i += nthr) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
@@ -1214,7 +1278,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             auto lds = [&](unsigned off) __attribute__((always_inline)) { return smem + off; };
             v2f oldA = {0.f, 0.f}, oldB = {0.f, 0.f}, xlate = {0.f, 0.f};
             float target_a = 0.f, target_b = 0.f;
-            float4 e01 = make_float4(0.f, 0.f, 0.f, 0.f), e23 = e01, e45 = e01;
+            float4 mA1 = make_float4(0.f, 0.f, 0.f, 0.f), mA2 = mA1, mB1 = mA1, mB2 = mA1, mC = mA1, eA = mA1;   // MT entries 0..5 of the step
             unsigned li_b = oS, ia_b = oS, ib_b = oS;
             bool act = false;
             int4 tab1 = make_int4(0, 0, 0, 0), tab2 = make_int4(0, 0, 0, 0);   // table entries of bin pairs u + 1, u + 2
@@ -1224,7 +1288,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 li0 = oS + 8u * (unsigned)(ctb + L);
                 ai0 = oA + 4u * (unsigned)(ctb + L);
                 xl0 = oS + 8u * (unsigned)(fbm1 + 1 + 2 * L);
-                et0 = oET + (unsigned)(wset * NST * 48);
+                et0 = oET + (unsigned)(wset * NST * 96);
             };
             auto clampu = [&](int un) __attribute__((always_inline)) { return un < 0 ? 0 : (un > NU - 1 ? NU - 1 : un); };
             auto fetch_tab = [&](int un) __attribute__((always_inline)) {
@@ -1239,8 +1303,8 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 const float *ta = reinterpret_cast<const float *>(lds(ai0 + 8u * uc));
                 target_a = ta[0];
                 target_b = __int_as_float(__float_as_int(ta[1]) | tab.w);       // (no second bin: a negative target is never above a threshold)
-                const float4 *et = reinterpret_cast<const float4 *>(lds(et0 + (unsigned)tab.x));
-                e01 = et[0]; e23 = et[1]; e45 = et[2];
+                const float4 *mt = reinterpret_cast<const float4 *>(lds(et0 + (unsigned)tab.x));
+                mA1 = mt[0]; mA2 = mt[1]; mB1 = mt[2]; mB2 = mt[3]; mC = mt[4]; eA = mt[5];
                 ia_b = li_b + (unsigned)tab.y;
                 ib_b = li_b + 8u + (unsigned)tab.z;
                 xlate = as_v2f(*reinterpret_cast<const float2 *>(lds(xl0 + 16u * uc)));
@@ -1255,14 +1319,10 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 // the unit's own history (columns c-1, c-2, their images, the image of bin c) and frame rho-1's late column
                 v2f twl = as_v2f(a.tw[(2 * PH + 1) & (Q - 1)]);
                 if constexpr (Q == 8) twl = (u & 2) ? as_v2f(a.tw[(2 * PH + 5) & (Q - 1)]) : twl;
-                v2f ownA = cmul_pk(wc[1], p1), ownB = cmul_pk(wc[2], p1);
-                cmac_pk(ownA, wc[2], p2);
-                if (L >= 3) cmac_pk(ownB, wc[L >= 3 ? 3 : 0], p2);
-                cmac_cv_pk(ownA, (v2f){e01.x, e01.y}, oldA);
-                cmac_cv_pk(ownA, (v2f){e01.z, e01.w}, p1);
-                cmac_cv_pk(ownA, (v2f){e23.x, e23.y}, p2);
-                cmac_cv_pk(ownB, (v2f){e23.z, e23.w}, p1);
-                cmac_cv_pk(ownB, (v2f){e45.x, e45.y}, p2);
+                v2f ownA = mat_mul_pk(mA1, p1), ownB = mat_mul_pk(mB1, p1);
+                mat_mac_pk(ownA, mA2, p2);
+                mat_mac_pk(ownB, mB2, p2);
+                cmac_cv_pk(ownA, (v2f){eA.x, eA.y}, oldA);
                 {
                     const v2f x = cmul_pk(wlate, xlate);
                     cmac_pk(ownB, twl, x);
@@ -1278,29 +1338,18 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 v2f accA = sa[0] + ownA, accB = sb[0] + ownB;
                 v2f newA;
                 {
-                    float m2 = accA.x * accA.x + accA.y * accA.y;
-                    v2f q = accA;
-                    if (m2 < 1e-30f) {           // too small to square in fp32 (or zero): rescale, so that "|acc| > 0" keeps its meaning
-                        q *= 0x1p60f;
-                        m2 = q.x * q.x + q.y * q.y;
-                    }
+                    const float m2 = accA.x * accA.x + accA.y * accA.y;      // (in range: the weights carry the spectrogram's scale)
                     const float sc = target_a * __frsqrt_rn(m2);
                     const bool upd = target_a > thr && m2 > 0.f;
-                    newA = upd ? q * sc : oldA;
+                    newA = upd ? accA * sc : oldA;
                 }
-                cmac_pk(accB, wc[1], newA);
-                cmac_cv_pk(accB, (v2f){e45.z, e45.w}, newA);   // the image of bin c itself, as the second bin sees it
+                mat_mac_pk(accB, mC, newA);        // bin c as tap -1 of bin c+1, and its image as the second bin sees it
                 v2f newB;
                 {
-                    float m2 = accB.x * accB.x + accB.y * accB.y;
-                    v2f q = accB;
-                    if (m2 < 1e-30f) {
-                        q *= 0x1p60f;
-                        m2 = q.x * q.x + q.y * q.y;
-                    }
+                    const float m2 = accB.x * accB.x + accB.y * accB.y;
                     const float sc = target_b * __frsqrt_rn(m2);
                     const bool upd = target_b > thr && m2 > 0.f;
-                    newB = upd ? q * sc : oldB;
+                    newB = upd ? accB * sc : oldB;
                 }
                 // Unchanged bins are written back as they were.  Hermitian images in the pad columns (lwslib.cpp:362-367): a bin
                 // without an image has offset 0 -- its conjugate goes to the bin's own place FIRST and is overwritten at once
@@ -1446,7 +1495,7 @@ Shape4 shape4_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
     if (F - 1 < 2 * (L + 3)) return r;
     r.NPS = Np + (Np & 1);
     auto lds_of = [&](int nwr) {
-        return (size_t)2 * (2 * Q - 1) * 64 * 16 + (192 + 64) * 8 + ((size_t)nwr * r.NPS + 8) * 8 + (size_t)nwr * r.NPS * 4 +
+        return (size_t)2 * (2 * Q - 1) * 64 * 16 + (224 + 64) * 8 + ((size_t)nwr * r.NPS + 8) * 8 + (size_t)nwr * r.NPS * 4 +
                (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4 + 16 + (size_t)NU * 16;
     };
     int nwr_max = 16;
