@@ -528,6 +528,13 @@ int env_int(const char *name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// spectrograms per chunk of the pipeline below (`per`: bins of one spectrogram)
+int host_chunk(size_t per, int B) {
+    const size_t target = (size_t)std::max(1, env_int("LWS_HOST_CHUNK_BINS", 16 << 20));
+    if (per * (size_t)B <= target + target / 2) return B;
+    return (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (target + per / 2) / per));
+}
+
 // (Tried and dropped: four child plans with a quarter of the CUs each, working on a chunk each at the same time -- one
 // workgroup per spectrogram in every launch, a chunk's kernels starting when ITS upload is done.  Kernels of different
 // streams do overlap -- 2 x 64 spectrograms on two streams take the time of one, 33 ms -- but a process gets four hardware
@@ -540,9 +547,7 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     // 32M 72 ms): long enough for the kernels to fill the device -- a launch of 32 spectrograms takes 6.7 ms, of 64 10.5, of
     // 256 33.9: fewer spectrograms than CUs run several workgroups each, 70-85 % as efficient -- short enough for the first
     // upload and the last download, which nothing overlaps, to be a small part of the call
-    const size_t target = (size_t)std::max(1, env_int("LWS_HOST_CHUNK_BINS", 16 << 20));
-    int Bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (target + per / 2) / per));
-    if (total <= target + target / 2) Bc = B;
+    const int Bc = host_chunk(per, B);
     const int nch = (B + Bc - 1) / Bc;
     int nthreads = env_int("LWS_HOST_THREADS", (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
     if (total < ((size_t)1 << 20)) nthreads = 1;
@@ -843,7 +848,12 @@ int lws_plan_reserve(lws_plan *p, int B, int T, int max_iters) {
     int rc = p->fp64 ? ensure_scratch<double>(p, B, T, max_iters) : ensure_scratch<float>(p, B, T, max_iters);
     if (rc) return rc;
     const size_t count = (size_t)B * T * p->F;
-    if ((rc = p->stage.ensure(count * sizeof(double2)))) return rc;          // host entry points stage complex128 here
+    if ((rc = p->stage.ensure(count * sizeof(double2)))) return rc;          // complex128 staging (fp64 plans' host entry points, lws_residual)
+    if (!p->fp64) {   // host entry points of an fp32 plan: pinned buffers, chunk buffers and streams of the pipeline, so that the
+                      // first call does not pay for them (hipHostMalloc of 4 x 128 MB: ~50 ms)
+        const size_t per = (size_t)T * p->F;
+        if ((rc = p->pipe.ensure((size_t)host_chunk(per, B) * per * sizeof(float2)))) return rc;
+    }
     if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
     if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
     if (!p->fp64) {

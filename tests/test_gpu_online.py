@@ -145,3 +145,27 @@ def test_wide_frames_stay_on_the_lds_engine(iters, T, oracle, monkeypatch):
     monkeypatch.setenv("LWS_ONLINE_SERIAL_TAPS", "1")
     ser, name = _online(1025, W, S, thr, 3, 4.0)
     assert name == "online_lds_fp32" and np.array_equal(ser, gen)
+
+
+def test_config3_online_stage_at_full_size(monkeypatch):
+    """BASELINE config 3's online stage at its full per-spectrogram size -- 500 frames x 513 bins, 10 iterations, look-ahead 3,
+    magnitudes with zero phase as run_lws feeds them -- on the default (fourth) layout: the verification variant reproduces the
+    order-exact generic engine bit for bit over all 5500 sweeps (schedule, frame ring, slots, step table), and the production
+    variant -- which only re-associates sums -- keeps every magnitude and reaches the same consistency."""
+    rng = np.random.default_rng(33)
+    p = lws_amd.lws(1024, 256, mode="music")
+    B, T, F = 2, 500, 513
+    S = np.abs(rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))).astype(np.complex128)
+    thr = lws_amd.get_thresholds(10, 1.0, 0.1, 1)
+    W = (p.W, p.W_ai, p.W_af)
+    gen, name = _online(F, W, S, thr, 3, 4.0, force_generic=True)
+    assert name == "generic_fp32"
+    monkeypatch.setenv("LWS_ONLINE_SERIAL_TAPS", "1")
+    ser, name = _online(F, W, S, thr, 3, 4.0)
+    assert name == "online_lds_fp32" and np.array_equal(ser, gen)
+    monkeypatch.delenv("LWS_ONLINE_SERIAL_TAPS")
+    prod, name = _online(F, W, S, thr, 3, 4.0)
+    assert name == "online_lds_fp32"
+    assert np.abs(np.abs(prod) - np.abs(S)).max() < 2e-6 * np.abs(S).max()
+    for b in range(B):
+        assert abs(p.get_consistency(prod[b]) - p.get_consistency(gen[b])) < 0.03
