@@ -34,7 +34,7 @@
 //
 // Scope of this kernel: summarised weights with the twiddle structure create_weights produces
 // (lws.pyx:160-181: W[p][r][k] = W[0][r][k]*exp(2j*pi*p*r/Q)), Q in {2,4} with L in {1,3,5}, or Q = 8 with L = 5 (its own
-// build: 64-step ring, a main and two helper waves per sweep slot), F-1 a multiple of 8 and <= 512 (<= 1024: the wide build),
+// build: 64-step ring, a main and two helper waves per sweep slot), F-1 even -- a multiple of 8, or a frame end inside a block of 8 steps, one more build per phase (th0) -- and <= 512 (<= 1024: the wide build),
 // fp32 arithmetic, fp32 or fp16 storage.  Anything else is served by the generic engine.
 #include "lws_common.h"
 #include "lws_systolic.h"
@@ -186,10 +186,9 @@ __host__ __device__ constexpr Src src_start(int P, int dr, int dk) {
     const bool is_new = dr < 0 || (dr == 0 && cm < P);
     return Src{K_RING, is_new ? 1 : 0, off0 - (is_new ? 0 : LAG), 1};
 }
-// reader at bin c = C - 8 + P (last bins of a frame), tap at c + dk >= C: the Nyquist bin (dk == e) or
-// the image of bin 2C - (c+dk), conjugated; e = C - c = 8 - P
-__host__ __device__ constexpr Src src_end(int P, int dr, int dk) {
-    const int e = 8 - P;
+// reader at bin c = C - e (last bins of a frame), tap at c + dk >= C: the Nyquist bin (dk == e) or
+// the image of bin 2C - (c+dk), conjugated
+__host__ __device__ constexpr Src src_end(int e, int dr, int dk) {
     if (dk == e) return Src{K_NYQ, dr < 0 ? 1 : 0, 0, 0};
     const int d = 2 * e - dk;            // mirrored bin minus reader bin
     if (dr == 0 && d == 0) return Src{K_SELF, 0, 0, 1};
@@ -198,6 +197,23 @@ __host__ __device__ constexpr Src src_end(int P, int dr, int dk) {
     const bool is_new = dr < 0 || (dr == 0 && d < 0);
     return Src{K_RING, is_new ? 1 : 0, SKEW * dr + d - (is_new ? 0 : LAG), 1};
 }
+
+// Frame ends.  RE = (F-1) mod 8, even.  The block of a frame that holds its last bin C-1 -- the "end block" -- sees bin C at
+// block-relative position th0 = 8 (RE = 0: the frame ends with a full block) or RE (the last block has only RE bins, its
+// phases RE..7 are dead: they run like any other step, on a target magnitude of -inf, and what they leave in the ring is
+// never read); the block before it sees bin C at th1 = th0 + 8, which matters when RE < L.
+__host__ __device__ constexpr int th0(int RE) { return RE ? RE : 8; }
+__host__ __device__ constexpr int th1(int RE) { return th0(RE) + 8; }
+// which images the bin at phase PH leaves behind: bin -PH (first block of a frame), bin C + j0 (end block), bin C + j1 (the
+// block before it)
+template <int L, int PH, int RE> struct ImagePhase {
+    static constexpr bool lo = (PH >= 1 && PH <= L);
+    static constexpr int j0 = th0(RE) - PH, j1 = th1(RE) - PH;
+    // (RE != 0: bin C+L is a tap of nobody below bin C -- the Nyquist lanes take their taps from the bins themselves -- and is
+    // not kept; the RE = 0 build stores it as it always did)
+    static constexpr int JMAX = RE ? L - 1 : L;
+    static constexpr bool hi0 = (j0 >= 1 && j0 <= JMAX), hi1 = (RE != 0 && j1 >= 1 && j1 <= JMAX);
+};
 
 struct SysArgs {
     // storage format of the skewed layout (template parameter H16 of the kernels): fp32 -- float2 / float -- or
@@ -352,13 +368,15 @@ struct LaneCtx {
     int halo_shift;   // +-ROWL lanes in bytes for the 6 lanes that also write a halo copy, else 0
     int dummy;        // private LDS slot for predicated-off conditional writes
     int lane8;
-    bool is_start, is_end, live;                 // this block (8 bins of one frame)
+    bool is_start, is_end, live;                 // this block (8 bins of one frame); is_end: the frame's end block
+    bool is_end1;                                // the block before the end block (RE != 0 builds)
     bool nxt_start, nxt_end, nxt_live;           // the following block (possibly the next frame of the lane)
     float thr, nxt_thr;
     // image cells: byte offset from the lane's own origin ob[m] to the pseudo-lane's, minus what the compile-time offset
     // of the neighbour frame DR adds -- for the lane at the start (lo: PLL) / end (hi: PLR) of its frame; zero for every
     // other lane.  [DR + HALO]
     int wlo[NDR], whi[NDR];
+    int whi1[NDR];                  // RE != 0: the same as whi for the lane in the block before its end block (cells from th1 on)
     int mbox;                       // Q = 8: mailbox of the slot's first helper, pair 0 (own lane)
     int img_lo, img_hi, img_both;   // image_base(): row origin for the image stores of this block (phases with an image below DC / above
                                     // Nyquist / both)
@@ -400,10 +418,21 @@ template <int P, int OFF, int LIDX, int NEWSET = 0> __device__ __forceinline__ i
 // Hermitian image upkeep (lwslib.cpp:362-367 in time coordinates): the lane that has just produced bin j in 1..L of
 // its frame (phase PH = j, flag st) or bin C-j (phase PH = 8-j, flag en) stores the conjugate where bin -j / C+j
 // would have been produced: 2j steps earlier / later.  `u` = wave-uniform row origins of the lane's output set.
-template <int L, int PH, int PB, int NEWSET>
-__device__ __forceinline__ void image_publish(const int (&u)[NBLK], bool st, bool en, int dummy, float2 out) {
+// RE != 0 (see th0): the image of bin C-j goes 2j steps later whichever block bin C-j is in; en1 = the lane is in the block
+// before its end block.
+template <int L, int PH, int PB, int NEWSET, int RE = 0>
+__device__ __forceinline__ void image_publish(const int (&u)[NBLK], bool st, bool en, int dummy, float2 out, bool en1 = false) {
     constexpr bool lo = (PH >= 1 && PH <= L), hi = (PH >= 8 - L && PH <= 7);
-    if constexpr (lo && hi) {   // a lane is at the start or at the end of a frame, never both
+    if constexpr (RE != 0) {
+        using IP = ImagePhase<L, PH, RE>;
+        if constexpr (IP::lo || IP::hi0 || IP::hi1) {
+            int addr = dummy;
+            if constexpr (IP::hi1) addr = en1 ? ring_addr_abs<PB, 2 * IP::j1, PLR, NEWSET>(u) : addr;
+            if constexpr (IP::hi0) addr = en ? ring_addr_abs<PB, 2 * IP::j0, PLR, NEWSET>(u) : addr;
+            if constexpr (IP::lo) addr = st ? ring_addr_abs<PB, -2 * PH, PLL, NEWSET>(u) : addr;
+            lds_write(addr, cj(out));
+        }
+    } else if constexpr (lo && hi) {   // a lane is at the start or at the end of a frame, never both
         const int a_lo = ring_addr_abs<PB, -2 * PH, PLL, NEWSET>(u), a_hi = ring_addr_abs<PB, 2 * (8 - PH), PLR, NEWSET>(u);
         lds_write(st ? a_lo : (en ? a_hi : dummy), cj(out));
     } else if constexpr (lo) {
@@ -433,8 +462,9 @@ __device__ __forceinline__ void image_store(int base_lo, int base_hi, int base_b
     if constexpr (lo || hi) lds_write((lo && hi ? base_both : (lo ? base_lo : base_hi)) + image_off<PH, NEWSET>(), cj(out));
 }
 
+// EDGE: 0 normal, 1 first bins of a frame, 1 + e (e >= 1): last bins of a frame, the reader's bin is C - e
 template <int PH, int DR, int DK, int EDGE> __host__ __device__ constexpr Src tap_src() {
-    return (EDGE == 0) ? src_normal(DR, DK) : (EDGE == 1 ? src_start(PH, DR, DK) : src_end(PH, DR, DK));
+    return (EDGE == 0) ? src_normal(DR, DK) : (EDGE == 1 ? src_start(PH, DR, DK) : src_end(EDGE - 1, DR, DK));
 }
 template <int PH, int DR, int DK, int EDGE> __host__ __device__ constexpr bool tap_in_lds() {
     constexpr Src s = tap_src<PH, DR, DK, EDGE>();
@@ -442,7 +472,7 @@ template <int PH, int DR, int DK, int EDGE> __host__ __device__ constexpr bool t
 }
 // One tap fetched from LDS.  PH: bin phase the tap belongs to (decides which taps are images / the Nyquist bin);
 // PB: clock of that bin relative to the start of the current block (PH, or 8 for phase 0 of the next block).
-template <int PH, int PB, int DR, int DK, int EDGE>  // EDGE: 0 normal, 1 frame start, 2 frame end
+template <int PH, int PB, int DR, int DK, int EDGE>  // EDGE: see tap_src
 __device__ __forceinline__ float2 tap_lds(const LaneCtx &cx) {
     constexpr Src s = tap_src<PH, DR, DK, EDGE>();
     static_assert(s.kind == K_RING || s.kind == K_NYQ, "register-sourced tap");
@@ -684,7 +714,7 @@ template <int Q, int L> __host__ __device__ constexpr int widx(int set, int R, i
 }
 
 // Contribution of the centre frame (W[.,0,k] does not depend on bin % Q) to the bin at phase PH / clock PB.
-template <int L, uint64_t MASK, int PH, int PB>
+template <int L, uint64_t MASK, int PH, int PB, int RE = 0>
 __device__ __forceinline__ void centre_sum(const SysArgs &a, const LaneCtx &cx, bool st, bool en, float2 self_old,
                                            float2 next_old, float2 prev_out, float2 &acc) {
     static_for<L>([&](auto ik) {
@@ -698,9 +728,13 @@ __device__ __forceinline__ void centre_sum(const SysArgs &a, const LaneCtx &cx, 
                 const float2 im = tap_any<PH, PB, 0, -k, 1>(cx, self_old, next_old, prev_out);
                 lo.x = st ? im.x : lo.x; lo.y = st ? im.y : lo.y;
             }
-            if constexpr (PH + k >= 8) {       // last bins of a frame: Nyquist bin or an image
-                const float2 im = tap_any<PH, PB, 0, k, 2>(cx, self_old, next_old, prev_out);
+            if constexpr (PH < th0(RE) && PH + k >= th0(RE)) {   // last bins of a frame: Nyquist bin or an image
+                const float2 im = tap_any<PH, PB, 0, k, 1 + th0(RE) - PH>(cx, self_old, next_old, prev_out);
                 hi.x = en ? im.x : hi.x; hi.y = en ? im.y : hi.y;
+            }
+            if constexpr (RE != 0 && PH + k >= th1(RE)) {        // the same from the block before the end block
+                const float2 im = tap_any<PH, PB, 0, k, 1 + th1(RE) - PH>(cx, self_old, next_old, prev_out);
+                hi.x = cx.is_end1 ? im.x : hi.x; hi.y = cx.is_end1 ? im.y : hi.y;
             }
             pair_rot<0>(acc, a.w[widx<8, L>(0, 0, k)], lo, hi);   // (the centre frame's weights come first in every build)
         }
@@ -846,7 +880,7 @@ template <int L> __host__ __device__ constexpr bool window_slot_used(uint32_t km
     }
     return false;
 }
-template <int PA0, int DR, int L, int C0, int NC, uint32_t KMASK, int CO = 0, int N = 0>
+template <int PA0, int DR, int L, int C0, int NC, uint32_t KMASK, int CO = 0, int RE = 0, int N = 0>
 __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
     static_assert((PA0 & 3) == 0 && (L & 1) == 1 && C0 + NC <= L + 3 && N >= 2 * L + 5, "cell window");
     constexpr int base_off = SKEW * DR - (DR > 0 ? LAG : 0);
@@ -856,7 +890,8 @@ __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
         constexpr int q = q_first + j;
         static_assert(q >= -RING && q + 1 <= 15, "ring retention exceeded");
         constexpr int b = PA0 - L - 1 + j;                       // the cell's even bin
-        constexpr bool img_lo = (b + 1 < 0), img_hi = (b >= 8);
+        // (RE != 0, see th0: image cells start at bin C wherever it sits in the lane's block or the next one)
+        constexpr bool img_lo = (b + 1 < 0), img_hi = (b >= th0(RE)) && (RE == 0 || b < th1(RE)), img_hi1 = (RE != 0) && (b >= th1(RE));
         constexpr int fl = floor_div8(q);
         constexpr int m = (-fl) & (NBLK - 1);
         constexpr int within = q - 8 * fl;                       // even
@@ -864,6 +899,7 @@ __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
         int base = cx.ob[m];
         if constexpr (img_lo) base = cx.ob[m] + cx.wlo[DR + HALO];
         if constexpr (img_hi) base = cx.ob[m] + cx.whi[DR + HALO];
+        if constexpr (img_hi1) base = cx.ob[m] + cx.whi1[DR + HALO];
         const int addr = base + (HALO + DR) * LANE_B + setoff + (within >> 1) * PAIR_BYTES;
         constexpr bool need0 = i != 0 && window_slot_used<L>(KMASK, j), need1 = i != L + 2 && window_slot_used<L>(KMASK, j + 1);
         if constexpr (need0 && need1) {
@@ -901,7 +937,7 @@ __device__ __forceinline__ void lds_write128(int addr, float2 p, float2 q) {
 }
 
 // One pair of bins (phases PA even, PA+1) of one lane.
-template <int Q, int L, uint64_t MASK, int PA, bool H16>
+template <int Q, int L, uint64_t MASK, int PA, bool H16, int RE = 0>
 __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx, Carry &cr, const float (&amp_cur)[8],
                                              QuadCarry<L> &qc) {
     static_assert((PA & 1) == 0, "pairs start on even bins");
@@ -929,7 +965,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             accB = cadd(accB, make_float2(mb.z, mb.w));
         });
     }
-    centre_sum<L, MASK, PA, PA>(a, cx, st, en, cr.o0, cr.o1, cr.prev_out, accA);
+    centre_sum<L, MASK, PA, PA, RE>(a, cx, st, en, cr.o0, cr.o1, cr.prev_out, accA);
     // frame pairs m-+R.  With FLAG_R13 rows 3 leave partial sums for rows 1: order 2, 3, 1 keeps them short-lived.
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
     if constexpr (quad_first) {
@@ -946,8 +982,8 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
                               !quad_late_frame<LATE_DN - 1, L>() && !quad_late_frame<1, L>() && !quad_late_frame<-LATE_DN, L>(),
                               "which frames are late");
                 constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
-                load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3), kmask>(cx, tu);   // frame m-1 cannot deliver its last half cell yet,
-                load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3), kmask>(cx, td);     // nor can frame m+LATE_DN
+                load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, tu);   // frame m-1 cannot deliver its last half cell yet,
+                load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, td);     // nor can frame m+LATE_DN
                 rows_sum<Q, L, MASK, PA, R, 0>(a, tu, td, p3A, accA);
                 rows_sum<Q, L, MASK, PHB, R, 1>(a, tu, td, p3B, accB);
                 rows_sum_ahead<Q, L, MASK, PA + 2, R, 2>(a, tu, td, p3C, qc.accA, qc);
@@ -962,8 +998,8 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
         accB = cadd(accB, qc.accB);
         if constexpr (quad_late_frame<-1, L>()) {
             float2 u1[2 * L + 6], d3[2 * L + 6];
-            load_cells<PA0, -1, L, L + 2, 1, (uint32_t)((MASK >> K1) & ((1ull << K1) - 1ull))>(cx, u1);
-            if constexpr (Q > LATE_DN) load_cells<PA0, LATE_DN, L, L + 2, 1, (uint32_t)((MASK >> ((Q > LATE_DN ? LATE_DN : 0) * K1)) & ((1ull << K1) - 1ull))>(cx, d3);
+            load_cells<PA0, -1, L, L + 2, 1, (uint32_t)((MASK >> K1) & ((1ull << K1) - 1ull)), 0, RE>(cx, u1);
+            if constexpr (Q > LATE_DN) load_cells<PA0, LATE_DN, L, L + 2, 1, (uint32_t)((MASK >> ((Q > LATE_DN ? LATE_DN : 0) * K1)) & ((1ull << K1) - 1ull)), 0, RE>(cx, d3);
             if constexpr (r13) {
                 quad_finish<Q, L, MASK, PHB>(a, qc, u1[2 * L + 4], d3[2 * L + 4], accB);
             } else {
@@ -976,16 +1012,18 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     // ---- first bin
     const float tA = amp_cur[PA];
     const float2 outA = project(accA, tA, cx.live && (tA > cx.thr), cr.o0);
-    image_store<L, PA, 1>(cx.img_lo, cx.img_hi, cx.img_both, outA);
+    if constexpr (RE == 0) image_store<L, PA, 1>(cx.img_lo, cx.img_hi, cx.img_both, outA);
+    else image_publish<L, PA, PA, 1, RE>(cx.uo, st, en, cx.dummy, outA, cx.is_end1);
     // ---- second bin (its centre taps include the first bin's result)
-    centre_sum<L, MASK, PHB, PHB>(a, cx, st, en, cr.o1, cr.o2, outA, accB);
+    centre_sum<L, MASK, PHB, PHB, RE>(a, cx, st, en, cr.o1, cr.o2, outA, accB);
     const float tB = amp_cur[PHB];
     const float2 outB = project(accB, tB, cx.live && (tB > cx.thr), cr.o1);
     // both outputs are one ring cell: nobody reads either before the pair is complete (the second bin took the first one's from
     // its register)
     lds_write128(ring_addr<PA, 0, 0, 1>(cx.ob), outA, outB);
     lds_write128(ring_addr<PA, 0, 0, 1>(cx.obh), outA, outB);   // the halo copy of the first / last HALO lanes; every other lane writes its own entry twice
-    image_store<L, PHB, 1>(cx.img_lo, cx.img_hi, cx.img_both, outB);
+    if constexpr (RE == 0) image_store<L, PHB, 1>(cx.img_lo, cx.img_hi, cx.img_both, outB);
+    else image_publish<L, PHB, PHB, 1, RE>(cx.uo, st, en, cx.dummy, outB, cx.is_end1);
     cr.prev_out = outB;
     cr.o0 = cr.o2;
     cr.o1 = cr.o3;
@@ -1045,12 +1083,19 @@ __device__ __forceinline__ wp_t nyq_weight(const SysArgs &a, int x) {
 struct ServiceState {      // (both as the loads delivered them: raw bits of the storage format)
     float nyq_amp_next;     // Nyquist lanes: target magnitude of the next block's Nyquist bin
     float2 nyq_in_next;     // Nyquist loader lane: previous-sweep Nyquist value of the next block's frame
+    float2 nyq_acc;         // Nyquist lanes, two-part call: the neighbour frames' taps, summed one pair ahead
 };
 
 // Lane l < NSLOTS computes the Nyquist bin (bin C = F-1) of the frame of sweep slot l whose 512-step period ended at
 // clock t0 (phase 0 of the current block); lane NSLOTS feeds set 0 with the stored Nyquist value of that frame.
 // Called at the start of the first pair of the block, when every slot has published bins C-1, C-2, ...
-template <int Q, int L, uint64_t MASK, bool MULTI, bool H16>
+// RE = C mod 8 != 0: t0 is still phase 0 of the block, the frames end at its phase RE and the call comes in the pair that
+// starts there; bin C is then a multiple of Q only if RE is, hence the quarter turns of the weights below.
+// PART: 0 = everything.  When the frames end in the second pair of a quad of bins (RE = 2, 6) that pair is a light one for
+// the sweep slots and they would wait for the Nyquist lanes' ~26 dependent weights in it: the neighbour frames' taps (all at
+// least 8 steps old) are then summed one pair earlier, where the slots are busy with the quad's tap windows (PART 1), and the
+// call in the frame-end pair only adds the frame's own last bins and re-projects (PART 2).
+template <int Q, int L, uint64_t MASK, bool MULTI, bool H16, int RE = 0, int PART = 0>
 __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &sv, int lane, int t0, int wg, int n_eff,
                                                 int n_groups, const float *thr_eff, void *state_nyq_b,
                                                 const void *amp_nyq_b) {
@@ -1063,18 +1108,18 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     const int v0 = t0 - (is_nyq_lane ? (slot + 1) * LAG : 0);
     // a frame ends every SKEW clocks; with a skew of two blocks only every other block has one (the same blocks for
     // every slot and for the loader: LAG and C are multiples of SKEW)
-    if (((v0 - C) & (SKEW - 1)) != 0) return;
-    const int vrow = (v0 - C) / SKEW;            // virtual frame whose Nyquist bin is due now (floor: SKEW | v0 - C)
+    if (((v0 + RE - C) & (SKEW - 1)) != 0) return;
+    const int vrow = (v0 + RE - C) / SKEW;            // virtual frame whose Nyquist bin is due now (floor: SKEW | v0 - C)
     const int rho = vrow & (ROWL - 1), kap = vrow >> ROWL_SHIFT;
     const int gl = kap / Kr, k = kap - gl * Kr;
     const int g = MULTI ? gl * a.nwg + wg : gl;   // global pass (this workgroup runs passes wg, wg + nwg, ...)
     const int me = k * ROWL + rho;
     const int j = g * NSLOTS + (is_nyq_lane ? slot : -1);
-    const bool valid = (v0 - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
-    if (is_nyq_loader) {
+    const bool valid = (v0 + RE - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
+    if (is_nyq_loader && PART != 1) {
         const float2 nin = raw_value<H16>(sv.nyq_in_next);   // loaded one block ago for this frame
         lds_write(NYQ_OFF + rho * 8, nin);
-        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, nin);   // and as entry "bin C" of set 0's image lane
+        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, nin);   // and as entry "bin C" of set 0's image lane
         const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
         if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2<H16>(state_nyq_b, me1);
@@ -1098,36 +1143,42 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
             }
         }
         const float2 old = lds_read(no[0]);
-        float2 acc = make_float2(0.f, 0.f);
+        float2 acc = PART == 2 ? sv.nyq_acc : make_float2(0.f, 0.f);
         // bin C: bin % Q == 0, every twiddle is 1; taps above Nyquist are conjugated images
-        static_for<L>([&](auto ik) {
+        if constexpr (PART != 1) static_for<L>([&](auto ik) {
             constexpr int k = decltype(ik)::value + 1;
             if constexpr ((MASK >> k) & 1ull) {
-                const float2 lo = lds_read(ring_addr<0, -k>(nb[0]));
+                const float2 lo = lds_read(ring_addr<RE, -k>(nb[0]));
                 pair_rot<0>(acc, nyq_weight(a, k), lo, cj(lo));
             }
         });
-        static_for<Q - 1>([&](auto ir) {
+        if constexpr (PART != 2) static_for<Q - 1>([&](auto ir) {
             constexpr int r = decltype(ir)::value + 1;
+            constexpr int rot = eighths<Q>(RE % Q, r) >> 1;    // twiddle exp(2j pi (C mod Q) r / Q) = j^rot, rot even (RE is)
+            static_assert((eighths<Q>(RE % Q, r) & 3) == 0, "half turns only");
             if constexpr ((MASK >> (r * K1)) & 1ull)
-                pair_rot<0>(acc, nyq_weight(a, r * K1), lds_read(nn[r]), lds_read(no[r]));
+                pair_rot<rot>(acc, nyq_weight(a, r * K1), lds_read(nn[r]), lds_read(no[r]));
             static_for<L>([&](auto ik) {
                 constexpr int k = decltype(ik)::value + 1;
                 if constexpr ((MASK >> (r * K1 + k)) & 1ull) {
-                    const float2 up = lds_read(ring_addr<0, -SKEW * r - k>(nb[r]));
-                    const float2 dn = lds_read(ring_addr<0, SKEW * r - k - LAG>(ob[r]));
+                    const float2 up = lds_read(ring_addr<RE, -SKEW * r - k>(nb[r]));
+                    const float2 dn = lds_read(ring_addr<RE, SKEW * r - k - LAG>(ob[r]));
                     const float2 bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
                     const float2 csum = make_float2(dn.x + up.x, dn.y - up.y);   // dn + conj(up)
-                    pair_rot<0>(acc, nyq_weight(a, r * K1 + k), bsum, csum);
+                    pair_rot<rot>(acc, nyq_weight(a, r * K1 + k), bsum, csum);
                 }
             });
         });
+        if constexpr (PART == 1) {
+            sv.nyq_acc = acc;
+            return;
+        }
         const bool active = real_row && (target > thr);
         const float2 out = project(acc, target, active, old);
         lds_write(nn[0], out);
-        lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, out);   // bin C of the image lane: production time = this clock
+        lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, out);   // bin C of the image lane: production time = this clock
         // (the last slot stores whatever reaches it: idle slots of the last group pass the final values on)
-        if ((slot == NSLOTS - 1) && (v0 - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2<H16>(state_nyq_b, me, out, MULTI);
+        if ((slot == NSLOTS - 1) && (v0 + RE - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2<H16>(state_nyq_b, me, out, MULTI);
         // target magnitude of the next block's Nyquist bin
         const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
@@ -1222,8 +1273,10 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
 #endif
 
 // MULTI: several workgroups share a spectrogram (a.nwg > 1); the single-workgroup instantiation carries none of it
-template <int Q, int L, uint64_t MASK, bool MULTI, bool H16>
+// RE = (F-1) mod 8 (see th0)
+template <int Q, int L, uint64_t MASK, bool MULTI, bool H16, int RE = 0>
 __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a_in) {
+    static_assert((RE & 1) == 0 && RE >= 0 && RE < 8 && (RE == 0 || !LWS_Q8), "frame end phase");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a_in.gate != nullptr && __hip_atomic_load(a_in.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int nwg = MULTI ? a_in.nwg : 1;
@@ -1375,6 +1428,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     ServiceState sv;
     sv.nyq_amp_next = 0.f;
     sv.nyq_in_next = make_float2(0.f, 0.f);
+    sv.nyq_acc = make_float2(0.f, 0.f);
     if (is_service) {
         if constexpr (MULTI) wait_rows(8 + 40);
 #pragma unroll
@@ -1414,7 +1468,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     rcur.gl = 0; rcur.k = 0; rcur.meb = 0; rcur.okj = false; rcur.thr = 0.f;
     rprev = rcur;
     int ks_state = (T_START - (slot + 1) * LAG) >> ROWP_SHIFT;     // round of lane 0 at the last evaluation (negative: not started)
-    struct BlockInfo { bool live, start, end; float thr; };
+    struct BlockInfo { bool live, start, end, end1; float thr; };
     auto block_info = [&](int vblock) {      // vblock: the slot's clock at phase 0 of the block (wave-uniform)
         const int rem = vblock & (ROWP - 1), ks = vblock >> ROWP_SHIFT;
         if (ks != ks_state) {                 // once per 64 (128) blocks
@@ -1434,7 +1488,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         const bool valid = (here ? rcur.okj : rprev.okj) && (me < a.Tp);
         bi.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
         bi.start = (cbase == 0);
-        bi.end = (cbase == C - 8);
+        bi.end = (cbase == C - th0(RE));
+        bi.end1 = (RE != 0) && (cbase == C - th1(RE));
         bi.thr = here ? rcur.thr : rprev.thr;
         return bi;
     };
@@ -1460,7 +1515,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             {
                 const BlockInfo cur = nxt_bi;
                 nxt_bi = block_info(v0 + 8);
-                cx.live = cur.live; cx.is_start = cur.start; cx.is_end = cur.end; cx.thr = cur.thr;
+                cx.live = cur.live; cx.is_start = cur.start; cx.is_end = cur.end; cx.is_end1 = cur.end1; cx.thr = cur.thr;
                 cx.nxt_live = nxt_bi.live; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end;
                 cx.nxt_thr = nxt_bi.thr;
             }
@@ -1473,6 +1528,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             for (int d = 0; d < NDR; ++d) {   // (only the entries of frames that exist, |DR| <= Q-1, are ever read)
                 cx.wlo[d] = cx.is_start ? dlo[d] : 0;
                 cx.whi[d] = cx.is_end ? dlo[d] + LANE_B : 0;   // PLR = PLL + 1
+                if constexpr (RE != 0) cx.whi1[d] = cx.is_end1 ? dlo[d] + LANE_B : 0;
             }
     #pragma unroll
             for (int m = 0; m < NBLK; ++m) {
@@ -1495,6 +1551,10 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
     #pragma unroll
                 for (int i = 0; i < 8; ++i) amp_cur[i] = raw_real<H16>(amp_nxt[i]);   // (fp16 storage: the conversion takes the place of the move)
+                if constexpr (RE != 0) {   // the dead phases of a frame's last block: never above any threshold
+    #pragma unroll
+                    for (int i = RE; i < 8; ++i) amp_cur[i] = cx.is_end ? -__builtin_inff() : amp_cur[i];
+                }
                 // The loads are asm statements so that they land in amp_nxt's own registers and nobody waits for them here
                 // (written as plain loads the compiler fetches into temporaries and copies -- i.e. waits -- at once: a stall
                 // of one memory latency per block).  The wait is explicit, at the end of the block; these are the only
@@ -1513,7 +1573,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             static_for<4>([&](auto ip) {
                 constexpr int PA = 2 * decltype(ip)::value;
                 flow_wait(lane, t0 + PA, watched);
-                if (r_compute) compute_pair<Q, L, MASK, PA, H16>(a, cx, cr, amp_cur, qc);
+                if (r_compute) compute_pair<Q, L, MASK, PA, H16, RE>(a, cx, cr, amp_cur, qc);
                 if constexpr (NHELP > 0) {
                     if (r_helper) {
                         if constexpr (PA == 8 - help_ahead(ROLE >= 1 && ROLE <= NHELP ? ROLE : 1)) {   // from here on the lane's next block: that block's frame edges
@@ -1547,8 +1607,11 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                     if (PA == 0 && hf == 0)
                         service_nyquist_rows<Q, L, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
 #else
-                    if (PA == 0 && hf == 0)
-                        service_nyquist<Q, L, MASK, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+                    constexpr bool nyq_split = (RE & 2) != 0;   // frames ending in the second pair of a quad: see service_nyquist
+                    if (PA == RE && hf == 0)   // (RE != 0: the frames end at phase RE of the block)
+                        service_nyquist<Q, L, MASK, MULTI, H16, RE, (nyq_split ? 2 : 0)>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+                    if (nyq_split && PA == RE - 2 && hf == 0)
+                        service_nyquist<Q, L, MASK, MULTI, H16, RE, 1>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
 #endif
                     // loader: feed set 0 with the values the virtual previous sweep would produce at clocks PA, PA+1
                     // (the loader is sweep slot -1: its lanes sit at bin (t0 - 8*lane) mod 512 of their frames)
@@ -1560,13 +1623,13 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                         ldh[m] = ldb[m] + cx.halo_shift;
                     }
                     const int cb0 = (t0 - SKEW * rl) & (ROWP - 1);
-                    const bool l_st = cb0 == 0, l_en = cb0 == C - 8;
+                    const bool l_st = cb0 == 0, l_en = cb0 == C - th0(RE), l_en1 = (RE != 0) && cb0 == C - th1(RE);
                     const float2 vA = raw_value<H16>(make_float2(amp_cur[PA], amp_nxt[PA]));
                     const float2 vB = raw_value<H16>(make_float2(amp_cur[PA + 1], amp_nxt[PA + 1]));
                     lds_write128(ring_addr<PA, 0>(ldb), vA, vB);   // one ring cell
                     lds_write128(ring_addr<PA, 0>(ldh), vA, vB);   // (halo copy, or the same cell again)
-                    image_publish<L, PA, PA, 0>(ldu, l_st, l_en, cx.dummy, vA);
-                    image_publish<L, PA + 1, PA + 1, 0>(ldu, l_st, l_en, cx.dummy, vB);
+                    image_publish<L, PA, PA, 0, RE>(ldu, l_st, l_en, cx.dummy, vA, l_en1);
+                    image_publish<L, PA + 1, PA + 1, 0, RE>(ldu, l_st, l_en, cx.dummy, vB, l_en1);
                     // write-back: the two values the last sweep slot produced in the previous pair, steps t0+PA-2 and t0+PA-1 (one
                     // ring cell of its output set; complete, every slot has finished that pair) go to the rows of its clock.  Done
                     // here, by the wave with time to spare, so that the sweep slots carry no store and no branch around one.
@@ -1992,21 +2055,33 @@ __global__ void __launch_bounds__(256) k_skew_to_out(float2 *out, const float2 *
 
 constexpr uint64_t mask_all(int Q, int L) { return (1ull << (Q * (L + 1))) - 1ull; }
 
-template <int Q, int L, uint64_t MASK, bool MULTI, bool H16> hipError_t launch_km(const SysArgs &a, int grid, hipStream_t s) {
+template <int Q, int L, uint64_t MASK, bool MULTI, bool H16, int RE> hipError_t launch_km(const SysArgs &a, int grid, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};   // one bit per device
     int attr_dev;
     if (lws::attr_needed(attr_set, &attr_dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_systolic<Q, L, MASK, MULTI, H16>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_systolic<Q, L, MASK, MULTI, H16, RE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         lws::attr_done(attr_set, attr_dev);
     }
-    hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI, H16>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI, H16, RE>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
     return hipGetLastError();
 }
+template <int Q, int L, uint64_t MASK, int RE> hipError_t launch_kr(const SysArgs &a, int grid, bool h16, hipStream_t s) {
+    if (h16) return a.nwg > 1 ? launch_km<Q, L, MASK, true, true, RE>(a, grid, s) : launch_km<Q, L, MASK, false, true, RE>(a, grid, s);
+    return a.nwg > 1 ? launch_km<Q, L, MASK, true, false, RE>(a, grid, s) : launch_km<Q, L, MASK, false, false, RE>(a, grid, s);
+}
+// one build of the kernel per phase of the block at which the frames end, (F-1) mod 8 (see th0)
 template <int Q, int L, uint64_t MASK> hipError_t launch_k(const SysArgs &a, int grid, bool h16, hipStream_t s) {
-    if (h16) return a.nwg > 1 ? launch_km<Q, L, MASK, true, true>(a, grid, s) : launch_km<Q, L, MASK, false, true>(a, grid, s);
-    return a.nwg > 1 ? launch_km<Q, L, MASK, true, false>(a, grid, s) : launch_km<Q, L, MASK, false, false>(a, grid, s);
+#if !LWS_Q8
+    switch (a.C & 7) {
+    case 2: return launch_kr<Q, L, MASK, 2>(a, grid, h16, s);
+    case 4: return launch_kr<Q, L, MASK, 4>(a, grid, h16, s);
+    case 6: return launch_kr<Q, L, MASK, 6>(a, grid, h16, s);
+    default: break;
+    }
+#endif
+    return launch_kr<Q, L, MASK, 0>(a, grid, h16, s);
 }
 
 #if !LWS_Q8
@@ -2040,7 +2115,9 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
 #else
     if (Qp != Q || !(Q == 2 || Q == 4) || !(L == 5 || L == 3 || L == 1)) return hipSuccess;
 #endif
-    if (C % SKEW != 0 || C > ROWP || C < 16) return hipSuccess;
+    // F-1 even (a pair of bins never straddles bin C); not a multiple of 8: the frames end inside a block (th0), and the block
+    // before that one must not be the frame's first
+    if ((C & 1) != 0 || C > ROWP || C < 16 || (C % SKEW != 0 && (LWS_Q8 || C < 24))) return hipSuccess;
     if ((Q - 1) * SKEW + L + 1 > LAG) return hipSuccess;
     const int K1 = L + 1;
     for (int i = 0; i < 3; ++i) {

@@ -24,7 +24,7 @@ def report(out, ref, M):
 
 
 @pytest.mark.parametrize("fsize,fshift,T", [(64, 16, 40), (128, 32, 130), (1024, 256, 70), (1024, 512, 65), (2048, 512, 50),
-                                            (1024, 128, 40), (64, 8, 70)])
+                                            (1024, 128, 40), (64, 8, 70), (1000, 250, 70), (2004, 501, 50), (60, 15, 40)])
 def test_fp16_storage_structure_and_tolerance(oracle, fsize, fshift, T):
     """Complex (random-phase) input: well conditioned, so values can be compared one by one."""
     rng = np.random.default_rng(fsize + T)
@@ -73,7 +73,7 @@ def test_fp16_workgroup_counts_and_device_io(monkeypatch):
     device path (complex64 in place) equals the path through the extended buffers."""
     import torch
     rng = np.random.default_rng(11)
-    for fsize, fshift, T in ((1024, 256, 260), (2048, 512, 150)):
+    for fsize, fshift, T in ((1024, 256, 260), (2048, 512, 150), (1000, 250, 260), (1012, 253, 200)):
         F = fsize // 2 + 1
         p = lws_amd.lws(fsize, fshift, storage="fp16")
         S = np.abs(rng.standard_normal((3, T, F)) + 1j * rng.standard_normal((3, T, F))).astype(np.complex128)

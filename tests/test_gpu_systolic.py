@@ -60,7 +60,9 @@ def test_bin_counts_and_q(oracle, fsize, fshift):
 
 @pytest.mark.parametrize("fsize,fshift,L,T", [(64, 16, 3, 70), (1024, 256, 3, 37), (1024, 512, 3, 37), (2048, 512, 3, 140),
                                               (128, 32, 3, 131), (2048, 1024, 3, 40), (64, 16, 1, 70), (1024, 256, 1, 37),
-                                              (1024, 512, 1, 37), (2048, 512, 1, 40)])
+                                              (1024, 512, 1, 37), (2048, 512, 1, 40), (1000, 250, 3, 37), (60, 15, 1, 70),
+                                              (2004, 501, 3, 40), (100, 25, 3, 70), (1004, 502, 1, 37), (1032, 516, 3, 33),
+                                              (1012, 253, 1, 37), (76, 19, 3, 66)])
 def test_other_stencil_widths(oracle, fsize, fshift, L, T):
     """class lws takes any L (lws.pyx:379); L = 1 and 3 (Q = 2, 4) run on the systolic kernels too (all taps: the specialised
     zero patterns are those of the default L = 5 weights), narrow and wide build.  (L = 7 -- its newest tap would be produced
@@ -162,17 +164,38 @@ def test_wide_sweep_counts_around_slot_groups(oracle, n_it):
     run_case(oracle, 2048, 512, 12, np.linspace(0.8, 0.0, n_it), seed=300 + n_it, B=2, scale=[1.0, 7.0])
 
 
-def test_wide_needs_a_multiple_of_8():
-    """F - 1 = 516 is a multiple of 4 but not of 8: generic engine."""
-    p = lws_amd.lws(1032, 258)
-    p.batch_lws(np.ones((4, 517)), thresholds=[0.0])
-    assert p.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
+@pytest.mark.parametrize("fsize,fshift,T", [(1000, 250, 37), (1000, 250, 131), (100, 25, 70), (60, 15, 70), (52, 13, 131),
+                                            (1004, 502, 37), (76, 38, 70), (1012, 253, 66), (996, 249, 40), (1032, 258, 66),
+                                            (2004, 501, 40), (1100, 275, 130), (2044, 1022, 21), (56, 14, 64), (1020, 255, 65)])
+def test_frames_that_end_inside_a_block(oracle, fsize, fshift, T):
+    """F - 1 even but not a multiple of 8 (`lws(1000, 250)`: F - 1 = 500): the frames end at phase 2, 4 or 6 of a block of 8
+    steps -- one kernel build per phase, the frame's last block partly dead, the Hermitian images and the Nyquist lanes shifted
+    with it (and F - 1 is then not a multiple of Q = 4 when the phase is 2 or 6: the Nyquist bin's weights carry a twiddle).
+    Narrow and wide build, Q = 2 and 4, against the oracle."""
+    out = run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], seed=fsize + T, B=2, scale=[1.0, 300.0])
+    assert (fsize // 2) % 8 != 0 and out.shape == (2, T, fsize // 2 + 1)
+    p = lws_amd.lws(fsize, fshift)
+    p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
+    assert _wide_name(p).startswith("systolic_wide_q" if fsize > 1026 else "systolic_q"), _wide_name(p)
+
+
+def test_what_still_needs_the_generic_engine():
+    """F - 1 below 24 with a frame end inside a block.  (F - 1 is always even: the library rejects an even number of bins
+    as the reference does, lws.pyx:223-224.)"""
+    with pytest.raises(ValueError):
+        _capi.Plan(502, lws_amd.lws(1000, 250).W).batch(np.ones((4, 502), dtype=np.complex128), [0.0])
+    for fsize, fshift in ((44, 11), (36, 9)):
+        p = lws_amd.lws(fsize, fshift)
+        p.batch_lws(np.ones((4, fsize // 2 + 1)), thresholds=[0.0])
+        assert p.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32"), (fsize, fshift)
 
 
 # ----------------------------------------------------------------------------- several workgroups per spectrogram
 @pytest.mark.parametrize("fsize,fshift,B,T,iters", [(64, 16, 1, 200, 30), (64, 16, 3, 300, 50), (1024, 256, 2, 200, 30),
                                                     (1024, 256, 9, 300, 45), (1024, 512, 5, 260, 16),
-                                                    (2048, 512, 3, 150, 20), (64, 8, 2, 300, 11), (1024, 128, 3, 200, 9)])
+                                                    (2048, 512, 3, 150, 20), (64, 8, 2, 300, 11), (1024, 128, 3, 200, 9),
+                                                    (1000, 250, 2, 200, 30), (60, 15, 3, 300, 50), (1004, 502, 5, 260, 16),
+                                                    (2004, 501, 3, 150, 20)])
 def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, iters, monkeypatch):
     """When there are fewer spectrograms than CUs the passes over HBM are dealt to several workgroups per spectrogram
     that hand the skewed state to each other through HBM; the result must be bit-identical to one workgroup doing all
@@ -218,7 +241,8 @@ def test_workgroup_sharing_randomised(monkeypatch):
             assert np.array_equal(p.plan().batch(S, thr), ref), (trial, fs, sh, B, T, iters, nwg)
 
 
-@pytest.mark.parametrize("fsize,fshift,T", [(1024, 256, 150), (2048, 512, 150), (2048, 512, 100), (1024, 128, 150), (64, 8, 70)])
+@pytest.mark.parametrize("fsize,fshift,T", [(1024, 256, 150), (2048, 512, 150), (2048, 512, 100), (1024, 128, 150), (64, 8, 70),
+                                             (1000, 250, 150), (1012, 253, 150), (2004, 501, 100)])
 def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
     """The waves of a workgroup synchronise through progress counters in LDS, not barriers.  LWS_SYSTOLIC_STRESS stalls chosen
     waves (role mask) for ~10 us before a chosen pair of every block -- far longer than a pair takes -- so any read that is
@@ -244,7 +268,8 @@ def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
 
 # ----------------------------------------------------------------------------- direct device I/O
 @pytest.mark.parametrize("fsize,fshift,B,T", [(64, 16, 3, 77), (1024, 256, 2, 130), (1024, 512, 2, 65), (2048, 512, 2, 40),
-                                              (1024, 128, 2, 70)])
+                                              (1024, 128, 2, 70), (1000, 250, 2, 130), (60, 15, 3, 77), (2004, 501, 2, 40),
+                                              (1004, 502, 2, 65)])
 def test_direct_device_io_equals_the_padded_path(fsize, fshift, B, T):
     """A *_dev call that is one batch stage converts the caller's complex64 spectrograms straight to the kernel's
     layout and back.  Same sweeps on the same values: the result equals the path through the extended buffers bit for
