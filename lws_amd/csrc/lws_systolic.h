@@ -9,6 +9,8 @@ constexpr int SYSTOLIC_MAX_ITERS = 440;  // thresholds of one launch live in LDS
 struct SystolicPlan {
     bool ok[3] = {false, false, false};  // per weight tensor: kernel applicable
     int F = 0, L = 0, Q = 0;
+    int Lk = 0;               // stencil half-width of the kernel build that serves the plan: L, or L + 1 for an even L (the
+                              // windows are fetched as pairs of bins; the extra tap has weight zero and is never fetched)
     void *tables[3] = {nullptr, nullptr, nullptr};  // device weight tables
     void *sk_state = nullptr, *sk_amp = nullptr;    // skewed-layout scratch
     size_t sk_state_cap = 0, sk_amp_cap = 0;

@@ -2102,12 +2102,16 @@ struct Tables {
 // =============================================================================================
 // host side
 // =============================================================================================
-hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const double *const W[3], bool fp16_storage) {
-    sp.F = F; sp.L = L; sp.Q = Q; sp.h16 = fp16_storage;
+hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const double *const W[3], bool fp16_storage) {
+    // Lu: the caller's stencil half-width (its weight tensors have Lu + 1 columns, its extended buffers 2 Lu pad columns);
+    // L: that of the kernel build -- the next odd number, the extra tap with weight zero (its mask bit is clear: never fetched)
+    const int L = Lu | 1, K1u = Lu + 1;
+    sp.F = F; sp.L = Lu; sp.Lk = L; sp.Q = Q; sp.h16 = fp16_storage;
     for (int i = 0; i < 3; ++i) sp.ok[i] = false;
+    if (Lu < 0) return hipSuccess;
     const int C = F - 1;
-    // stencil half-widths: L = 5 (every default configuration) with the specialised tap masks, L = 3 with all taps.  L must
-    // be odd (the tap windows are fetched as aligned pairs of bins) and at most SKEW - 3: a lane works on two bins per
+    // stencil half-widths: L = 5 (every default configuration) with the specialised tap masks, L = 3 and 1 with all taps.  The
+    // kernel's L is odd (the tap windows are fetched as aligned pairs of bins) and at most SKEW - 3: a lane works on two bins per
     // rendez-vous, so the newest tap of the pair's second bin, (m-1, c+1+L), must be at least two steps old when the pair
     // starts (L = 7 is not: generic engine).
 #if LWS_Q8
@@ -2125,15 +2129,18 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
         // twiddle structure: W[p][r][k] == W[0][r][k] * exp(2j*pi*p*r/Q)
         bool ok = true;
         double scale = 0;
-        for (int x = 0; x < Q * Q * K1; ++x) scale = std::fmax(scale, std::hypot(W[i][2 * x], W[i][2 * x + 1]));
+        for (int x = 0; x < Q * Q * K1u; ++x) scale = std::fmax(scale, std::hypot(W[i][2 * x], W[i][2 * x + 1]));
+        // W[p][r][k] of the caller's tensor; zero for the tap an even Lu does not have
+        auto wre = [&](int p, int r, int k) { return k <= Lu ? W[i][2 * ((p * Q + r) * K1u + k)] : 0.0; };
+        auto wim = [&](int p, int r, int k) { return k <= Lu ? W[i][2 * ((p * Q + r) * K1u + k) + 1] : 0.0; };
         for (int p = 0; p < Q && ok; ++p)
             for (int r = 0; r < Q && ok; ++r)
                 for (int k = 0; k <= L; ++k) {
                     if (r == 0 && k == 0) continue;  // never read by the kernels
                     const double ang = 2.0 * M_PI * p * r / Q;
-                    const double br = W[i][2 * ((0 * Q + r) * K1 + k)], bi = W[i][2 * ((0 * Q + r) * K1 + k) + 1];
+                    const double br = wre(0, r, k), bi = wim(0, r, k);
                     const double er = br * std::cos(ang) - bi * std::sin(ang), ei = br * std::sin(ang) + bi * std::cos(ang);
-                    const double wr = W[i][2 * ((p * Q + r) * K1 + k)], wi = W[i][2 * ((p * Q + r) * K1 + k) + 1];
+                    const double wr = wre(p, r, k), wi = wim(p, r, k);
                     if (std::hypot(wr - er, wi - ei) > 1e-9 * scale) { ok = false; break; }
                 }
         if (!ok) continue;
@@ -2141,7 +2148,7 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
         tb->Q = Q; tb->L = L; tb->mask = 0;
         for (int r = 0; r < Q; ++r)
             for (int k = 0; k <= L; ++k) {
-                const double wr = W[i][2 * (r * K1 + k)], wi = W[i][2 * (r * K1 + k) + 1];
+                const double wr = wre(0, r, k), wi = wim(0, r, k);
                 const bool on = std::hypot(wr, wi) > 1.0e-12;  // lws.pyx:231-232
                 if (on) tb->mask |= 1ull << (r * K1 + k);
 #if LWS_Q8
@@ -2164,15 +2171,15 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int L, int Q, int Qp, const d
         // structure of symmetric windows, checked on the fp64 weights well below fp32 resolution
         tb->k0real = true;
         for (int r = 1; r < Q; ++r)
-            if (((tb->mask >> (r * K1)) & 1ull) && std::fabs(W[i][2 * (r * K1) + 1]) > 1e-13 * scale) tb->k0real = false;
+            if (((tb->mask >> (r * K1)) & 1ull) && std::fabs(wim(0, r, 0)) > 1e-13 * scale) tb->k0real = false;
         tb->r13 = (Q == 4);
         for (int k = 2; k <= L && tb->r13; ++k) {
             const bool on1 = (tb->mask >> (1 * K1 + k)) & 1u, on3 = (tb->mask >> (3 * K1 + k)) & 1u;
             if (on1 != on3) { tb->r13 = false; break; }
             if (!on1) continue;
-            double xr = W[i][2 * (1 * K1 + k)], xi = W[i][2 * (1 * K1 + k) + 1];   // W1 * j^k
+            double xr = wre(0, 1, k), xi = wim(0, 1, k);   // W1 * j^k
             for (int q = 0; q < (k & 3); ++q) { const double t = xr; xr = -xi; xi = t; }
-            if (std::hypot(W[i][2 * (3 * K1 + k)] - xr, W[i][2 * (3 * K1 + k) + 1] - xi) > 1e-13 * scale) tb->r13 = false;
+            if (std::hypot(wre(0, 3, k) - xr, wim(0, 3, k) - xi) > 1e-13 * scale) tb->r13 = false;
         }
         sp.tables[i] = tb;
         sp.ok[i] = true;
@@ -2300,7 +2307,7 @@ hipError_t clear_flags(const Geom &g, int B, hipStream_t stream) {   // amax | t
 hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float *thr, int n_it, int b0, int nb, int nwg,
                          unsigned *progress, const int *gate, int T, hipStream_t stream) {
     const Tables *tb = static_cast<const Tables *>(sp.tables[wsel]);
-    const int Q = sp.Q, L = sp.L, F = sp.F;
+    const int Q = sp.Q, L = sp.Lk, F = sp.F;
     SysArgs a;
     a.state_w = g.state_w + (size_t)b0 * g.G * ROWL * g.cb; a.amp_w = g.amp_w + (size_t)b0 * g.G * ROWL * g.rb;
     a.state_nyq = g.state_nyq + (size_t)b0 * g.TpPad * g.cb; a.amp_nyq = g.amp_nyq + (size_t)b0 * g.TpPad * g.rb;

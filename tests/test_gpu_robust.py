@@ -111,7 +111,7 @@ def test_multi_plan_shards_equal_one_plan():
 @pytest.mark.parametrize("fsize,fshift,L,T,precision", [(64, 8, 5, 40, "fp32"), (1024, 128, 5, 50, "fp32"), (48, 16, 4, 30, "fp32"),
                                                       (1040, 260, 5, 40, "fp32"), (64, 16, 7, 33, "fp64"), (1024, 128, 5, 20, "fp64")])
 def test_generic_batch_on_the_skewed_copy_is_bit_identical(fsize, fshift, L, T, precision, oracle):
-    """Shapes the systolic kernels do not serve (Q = 8, Q = 3, L = 4 / 7, F - 1 not a multiple of 8, fp64) run their batch
+    """Shapes the systolic kernels do not serve (Q = 3, L = 7, general weights, fp64 -- or here: forced) run their batch
     sweeps on the generic engine -- on a time-skewed copy of the state so that the taps of a wavefront step are coalesced.
     Same schedule and arithmetic as in the reference's layout: identical bits; and the oracle's values in fp64."""
     rng = np.random.default_rng(fsize + L)
