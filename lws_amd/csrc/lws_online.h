@@ -5,7 +5,7 @@
 namespace lws {
 
 // true if launch_online_lds can run this shape (summarised weights with the twiddle structure of create_weights in all
-// three tensors, L = 5, Q in {2,4,8}, the window of frames the sweeps in flight need fits the LDS ring); otherwise the
+// three tensors, L <= 5 (L = 5 for the first three layouts), Q in {2,4,8}, the window of frames the sweeps in flight need fits the LDS ring); otherwise the
 // caller uses the generic engine.
 bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update, bool twiddle_structure);
 // host check on one complex128 weight tensor [Qp][Q][L+1]: W[p][r][k] == W[0][r][k] exp(2 pi j p r / Q)

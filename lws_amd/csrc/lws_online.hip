@@ -77,6 +77,8 @@ struct OnlineArgs {
     int F, T, n_thr, LA, NSW;
     int DS;              // steps between consecutive sweeps (>= the order-exact minimum, see shape_of)
     int NWR, NPS;        // k_online4: frames in its LDS ring, row stride (elements, even)
+    int Lu;              // k_online4: the caller's stencil half-width (<= the kernel's L): its buffers have 2 Lu pad columns and
+                         // its weight tensors Lu + 1 columns; the taps it does not have carry weight zero in the kernel's table
 };
 
 __device__ __forceinline__ void pair(float2 &a, float2 w, float2 b, float2 c) {   // the generic engine's grouped form
@@ -872,8 +874,8 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     constexpr int NCELL = WN / 2 + 1;                   // 16-byte cells (two columns) of a two-step window
     static_assert(SKB >= L + 3 && (SKS & 1) == 0 && (WN & 3) == 0, "two-step windows of aligned cells");
     const int DS = a.DS;                                // even
-    const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, Np = F + 2 * L, Tp = T + 2 * (Q - 1), N = F - 1;
-    const int NWR = a.NWR, NPS = a.NPS;
+    const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, Tp = T + 2 * (Q - 1), N = F - 1;
+    const int NWR = a.NWR, NPS = a.NPS;                 // (a row of the ring: F + 2 L columns, rounded up to even)
     const int NU = (F + 1) / 2;
     const int rps = LA + 1, per = a.n_thr + 1;
     const int nsweeps = T * per;
@@ -894,8 +896,11 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool is_proj = hw_wave == Online4Waves<Q>::PROJ;
     const int wave = Online4Waves<Q>::tap_of(hw_wave);   // tap group of a tap wave (0: the centre frame)
-    float2 *gS = a.state + (size_t)b * Tp * Np;
-    const float *gA = a.amp + (size_t)b * Tp * Np;
+    // the caller's extended buffers: Lu <= L pad columns on either side (bin c of the kernel's rows is column c + L, of the
+    // caller's c + Lu: its columns sit dL further right in a row of the ring; the outer 2 dL columns only ever meet zero weights)
+    const int Npu = F + 2 * a.Lu, dL = L - a.Lu, K1u = a.Lu + 1;
+    float2 *gS = a.state + (size_t)b * Tp * Npu;
+    const float *gA = a.amp + (size_t)b * Tp * Npu;
 
     // The weighted sums are only ever normalised, so the weights of this spectrogram are scaled by the power of two that
     // brings its largest target magnitude to [1, 2) -- exact -- and |sum|^2 can be formed in fp32 for data of any scale
@@ -906,7 +911,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     float wscale = 1.0f;
     if constexpr (!SERIAL) {
         float mx = 0.f;
-        for (int i = tid; i < Tp * Np; i += nthr) mx = fmaxf(mx, gA[i]);
+        for (int i = tid; i < Tp * Npu; i += nthr) mx = fmaxf(mx, gA[i]);
         float *red = reinterpret_cast<float *>(smem);                // (P: not in use yet)
         red[tid] = mx;
         __syncthreads();
@@ -919,8 +924,8 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         __syncthreads();
     }
     for (int i = tid; i < 3 * Q * Q * K1; i += nthr) {
-        const int x = i % (Q * Q * K1);
-        const float2 w = a.w[i / (Q * Q * K1)][x];
+        const int x = i % (Q * Q * K1), pr = x / K1, k = x - pr * K1;
+        const float2 w = k < K1u ? a.w[i / (Q * Q * K1)][pr * K1u + k] : make_float2(0.f, 0.f);
         W[i] = (x % (Q * K1) == 0) ? make_float2(0.f, 0.f) : make_float2(w.x * wscale, w.y * wscale);
     }
     if (tid < Q) TW[tid] = a.tw[tid];
@@ -975,7 +980,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     for (int i = tid; i < a.n_thr; i += nthr) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
     int loaded = Q < T + Q - 1 ? Q : T + Q - 1;
     for (int r0 = 0; r0 < loaded; ++r0)
-        for (int i = tid; i < Np; i += nthr) { S[r0 * NPS + i] = gS[(size_t)r0 * Np + i]; A[r0 * NPS + i] = gA[(size_t)r0 * Np + i]; }
+        for (int i = tid; i < Npu; i += nthr) { S[r0 * NPS + dL + i] = gS[(size_t)r0 * Npu + i]; A[r0 * NPS + dL + i] = gA[(size_t)r0 * Npu + i]; }
 
     const int sigma = lane / rps, j = lane - sigma * rps;
     const bool lane_used = sigma < NSW;
@@ -1039,10 +1044,10 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         while (loaded < T + Q - 1 && next_need <= t + 4) {
             const int slot = (loaded % NWR) * NPS;
             const bool evict = loaded >= NWR;
-            for (int i = tid; i < Np; i += nthr) {
-                if (evict) gS[(size_t)(loaded - NWR) * Np + i] = S[slot + i];
-                S[slot + i] = gS[(size_t)loaded * Np + i];
-                A[slot + i] = gA[(size_t)loaded * Np + i];
+            for (int i = tid; i < Npu; i += nthr) {
+                if (evict) gS[(size_t)(loaded - NWR) * Npu + i] = S[slot + dL + i];
+                S[slot + dL + i] = gS[(size_t)loaded * Npu + i];
+                A[slot + dL + i] = gA[(size_t)loaded * Npu + i];
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the projection wave's barrier wait is a counted one)
             ++loaded;
@@ -1395,7 +1400,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     const int first_row = loaded > NWR ? loaded - NWR : 0;
     for (int e = first_row; e < loaded; ++e) {
         const int slot = (e % NWR) * NPS;
-        for (int i = tid; i < Np; i += nthr) gS[(size_t)e * Np + i] = S[slot + i];
+        for (int i = tid; i < Npu; i += nthr) gS[(size_t)e * Npu + i] = S[slot + dL + i];
     }
 }
 
@@ -1476,10 +1481,13 @@ Shape shape3_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
 
 // k_online4: 2Q waves, one lane per (sweep slot, frame position), even lag, ring of NWR frames with an even row stride
 struct Shape4 { Shape sh; int NWR, NPS; };
-Shape4 shape4_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
+Shape4 shape4_of(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
     Shape4 r{{0, 0, 0, 0, false}, 0, 0};
     Shape &sh = r.sh;
-    if (Qp != Q || L != 5 || !(Q == 2 || Q == 4 || Q == 8) || LA < 0 || LA > 63 || n_thr < 1 || T < 1) return r;
+    // any stencil half-width up to the kernel's: narrower ones run as L = 5 with zero weights for the taps they do not have
+    // (OnlineArgs::Lu) -- the same sums, on a schedule that is order-exact for the wider stencil
+    if (Qp != Q || Lu < 1 || Lu > 5 || !(Q == 2 || Q == 4 || Q == 8) || LA < 0 || LA > 63 || n_thr < 1 || T < 1) return r;
+    const int L = 5;
     const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS_MIN = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
     const int NU = (F + 1) / 2;
     sh.NSW = 64 / (LA + 1);
@@ -1591,7 +1599,7 @@ hipError_t launch_online_lds(const GenericArgs<float> &g, int B, hipStream_t str
         a.tw[q] = make_float2((float)cr, (float)sr);
     }
     a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = sh.NSW; a.DS = sh.DS;
-    a.NWR = sh4.NWR; a.NPS = sh4.NPS;
+    a.NWR = sh4.NWR; a.NPS = sh4.NPS; a.Lu = g.L;
     const char *ev = getenv("LWS_ONLINE_SERIAL_TAPS");   // verification only, see k_online
     if (layout == 4) {
         const bool serial = ev && ev[0] == '1';

@@ -107,6 +107,36 @@ def test_production_variant_vs_oracle_at_full_frame_sizes(fsize, fshift, T, LA, 
     assert np.abs(np.abs(out) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
 
 
+@pytest.mark.parametrize("fsize,fshift,L,T,LA,iters,B", [(1024, 256, 3, 60, 3, 6, 2), (512, 128, 1, 40, 3, 4, 1),
+                                                         (1024, 512, 4, 50, 2, 5, 2), (512, 64, 3, 40, 2, 4, 1),
+                                                         (1000, 250, 2, 45, 3, 5, 1), (2048, 512, 3, 12, 3, 3, 1)])
+def test_narrower_stencils(fsize, fshift, L, T, LA, iters, B, oracle, monkeypatch):
+    """`lws(..., L=3, mode='music')` (lws.pyx:379 takes any L): stencils narrower than the kernel's run as L = 5 with zero
+    weights for the taps they do not have, on the caller's narrower pad columns.  Serial-taps variant bit-identical to the
+    generic engine; production variant: same magnitudes, and the oracle's values on a short run."""
+    rng = np.random.default_rng(fsize + T + L)
+    p = lws_amd.lws(fsize, fshift, L=L, mode="music")
+    F = fsize // 2 + 1
+    S = rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.1, 1)
+    W = (p.W, p.W_ai, p.W_af)
+    ref, name = _online(F, W, S, thr, LA, fsize / fshift, force_generic=True)
+    assert name == "generic_fp32"
+    monkeypatch.setenv("LWS_ONLINE_SERIAL_TAPS", "1")
+    out, name = _online(F, W, S, thr, LA, fsize / fshift)
+    assert name == "online_lds_fp32"
+    assert np.array_equal(out, ref)
+    monkeypatch.delenv("LWS_ONLINE_SERIAL_TAPS")
+    prod, name = _online(F, W, S, thr, LA, fsize / fshift)
+    assert name == "online_lds_fp32"
+    assert np.abs(np.abs(prod) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
+    Ts = min(T, 10)
+    short, _ = _online(F, W, S[0, :Ts], thr[:2], LA, fsize / fshift)
+    o = oracle.online_lws(S[0, :Ts], *W, thr[:2], LA, fshift)
+    err = np.abs(short - o)
+    assert np.median(err) < 2e-6 * np.mean(np.abs(S)) and np.linalg.norm(err) < 5e-3 * np.linalg.norm(o)
+
+
 def test_fallbacks_to_generic():
     """Shapes the LDS ring cannot hold, and fp64 plans, stay on the generic engine."""
     rng = np.random.default_rng(0)
