@@ -17,10 +17,12 @@
 #include "lws_online.h"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <sys/mman.h>
 #include "lws_nofuture.h"
 
 namespace {
@@ -92,6 +94,9 @@ struct HostPipe {
     DevBuf io[2];
     hipStream_t s_up = nullptr, s_down = nullptr, s_comp = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+    hipEvent_t ev_load[2] = {nullptr, nullptr};   // a chunk's light first kernels (layout, mean, thresholds) are done
+    static constexpr int PIECES = 4;              // the first upload and the last download go in pieces, the host pass of a piece
+    hipEvent_t ev_piece[PIECES] = {nullptr, nullptr, nullptr, nullptr};   // ... beside the copy of its neighbour
     int ensure(size_t bytes) {
         if (!s_up) {
             if (hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking) != hipSuccess ||
@@ -99,8 +104,11 @@ struct HostPipe {
                 return fail(LWS_ERR_HIP, "hipStreamCreate failed");
             for (int i = 0; i < 2; ++i)
                 if (hipEventCreateWithFlags(&ev_up[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_comp[i], hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&ev_down[i], hipEventDisableTiming) != hipSuccess)
+                    hipEventCreateWithFlags(&ev_down[i], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ev_load[i], hipEventDisableTiming) != hipSuccess)
                     return fail(LWS_ERR_HIP, "hipEventCreate failed");
+            for (int i = 0; i < PIECES; ++i)
+                if (hipEventCreateWithFlags(&ev_piece[i], hipEventDisableTiming) != hipSuccess) return fail(LWS_ERR_HIP, "hipEventCreate failed");
         }
         if (bytes > cap) {
             for (int i = 0; i < 2; ++i) {
@@ -129,9 +137,14 @@ struct HostPipe {
             if (ev_up[i]) (void)hipEventDestroy(ev_up[i]);
             if (ev_comp[i]) (void)hipEventDestroy(ev_comp[i]);
             if (ev_down[i]) (void)hipEventDestroy(ev_down[i]);
-            ev_up[i] = ev_comp[i] = ev_down[i] = nullptr;
+            if (ev_load[i]) (void)hipEventDestroy(ev_load[i]);
+            ev_up[i] = ev_comp[i] = ev_down[i] = ev_load[i] = nullptr;
         }
         cap = 0;
+        for (int i = 0; i < PIECES; ++i) {
+            if (ev_piece[i]) (void)hipEventDestroy(ev_piece[i]);
+            ev_piece[i] = nullptr;
+        }
         if (s_up) (void)hipStreamDestroy(s_up);
         if (s_down) (void)hipStreamDestroy(s_down);
         if (s_comp) (void)hipStreamDestroy(s_comp);
@@ -154,6 +167,9 @@ struct lws_plan {
     lws::SystolicPlan sys;         // device tables of the systolic kernel (empty if not eligible)
     const lws::SystolicBuild *sysb = nullptr;   // the build of it that serves this plan (narrow / Q = 8 / wide), if any
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *host_pool = nullptr;     // HostWorkers of the host-array entry points (kept between calls: 32 thread starts cost ~1 ms)
+    int host_pool_n = 0;
+    hipEvent_t ev_after_load = nullptr;   // if set: recorded by run_pipeline between its light first kernels and the update kernels
     bool timing_pending = false;
     float last_ms = 0.f;
     int last_launches = 0;
@@ -355,6 +371,7 @@ int run_direct_batch(lws_plan *p, const float2 *in_dev, float2 *out_dev, int B, 
     HIP_TRY(hipMemcpyAsync(p->thr_host_copy.p, st.thr, sizeof(double) * st.iters, hipMemcpyHostToDevice, s));
     HIP_TRY(lws::launch_scale_thresholds<float>(static_cast<const double *>(p->thr_host_copy.p), mean,
                                                 static_cast<float *>(p->thr_scaled.p), B, st.iters, s));
+    if (p->ev_after_load) HIP_TRY(hipEventRecord(p->ev_after_load, s));
     int launches = 0;
     const float *th = static_cast<const float *>(p->thr_scaled.p);
     e = p->sysb->io_run(p->sys, st.wsel, th, in_dev, out_dev, partial, B, T, st.iters, s, &launches, p->ev0, p->ev1);
@@ -387,6 +404,7 @@ int run_pipeline(lws_plan *p, const io_cx *in_dev, io_cx *out_dev, const io_cx *
                                            static_cast<double *>(p->row_sums.p),
                                            static_cast<double *>(p->mean_amp.p), B, T, p->F, p->L,
                                            p->Q, s)));
+    if (p->ev_after_load) HIP_TRY(hipEventRecord(p->ev_after_load, s));
     bool dirty = false;
     for (int i = 0; i < nstages; ++i) {
         if (stages[i].iters <= 0) continue;  // "return S" of lws.pyx:219-220 / 272-273 / 332-333
@@ -529,10 +547,21 @@ int env_int(const char *name, int dflt) {
 }
 
 // spectrograms per chunk of the pipeline below (`per`: bins of one spectrogram)
-int host_chunk(size_t per, int B) {
+int host_chunk(size_t per, int B, int n_cu) {
     const size_t target = (size_t)std::max(1, env_int("LWS_HOST_CHUNK_BINS", 16 << 20));
     if (per * (size_t)B <= target + target / 2) return B;
-    return (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (target + per / 2) / per));
+    int bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (target + per / 2) / per));
+    // a launch of fewer spectrograms than CUs gives each floor(CUs / spectrograms) workgroups (lws_systolic.hip: prepare):
+    // 65 spectrograms on 256 CUs keep 195 of them busy, 64 all of them -- round to a divisor / multiple of the CU count
+    if (n_cu > 1 && !env_int("LWS_HOST_CHUNK_EXACT", 0)) {
+        if (bc >= n_cu) bc -= bc % n_cu;
+        else bc = std::max(1, n_cu / ((n_cu + bc - 1) / bc));
+    }
+    return std::min(bc, B);
+}
+int cu_count(int device) {
+    int n = 0;
+    return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess ? n : 0;
 }
 
 // (Tried and dropped: four child plans with a quarter of the CUs each, working on a chunk each at the same time -- one
@@ -547,7 +576,7 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     // 32M 72 ms): long enough for the kernels to fill the device -- a launch of 32 spectrograms takes 6.7 ms, of 64 10.5, of
     // 256 33.9: fewer spectrograms than CUs run several workgroups each, 70-85 % as efficient -- short enough for the first
     // upload and the last download, which nothing overlaps, to be a small part of the call
-    const int Bc = host_chunk(per, B);
+    const int Bc = host_chunk(per, B, cu_count(p->device));
     const int nch = (B + Bc - 1) / Bc;
     int nthreads = env_int("LWS_HOST_THREADS", (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
     if (total < ((size_t)1 << 20)) nthreads = 1;
@@ -556,46 +585,121 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     HostPipe &hp = p->pipe;
     int rc = hp.ensure((size_t)Bc * per * sizeof(float2));
     if (rc) return rc;
-    HostWorkers pool(nthreads);
+    if (p->host_pool && p->host_pool_n != nthreads) { delete static_cast<HostWorkers *>(p->host_pool); p->host_pool = nullptr; }
+    if (!p->host_pool) { p->host_pool = new HostWorkers(nthreads); p->host_pool_n = nthreads; }
+    HostWorkers &pool = *static_cast<HostWorkers *>(p->host_pool);
     const int slices = pool.size() == 1 ? 1 : 4 * pool.size();
     auto chunk_bins = [&](int c) { return (size_t)std::min(Bc, B - c * Bc) * per; };
+    // LWS_HOST_TRACE=1: where the call's wall time goes, on stderr (ms since the call began)
+    const bool trace = env_int("LWS_HOST_TRACE", 0) != 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what, int c) {
+        if (trace) fprintf(stderr, "[lws host] %7.2f ms  %s %d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), what, c);
+    };
     // host passes: narrow chunk cu (if any) into up[cu & 1] and widen chunk cd (if any) from down[cd & 1], together
-    auto host_pass = [&](int cu, int cd) {
-        const int nu = (cu >= 0 && cu < nch) ? slices : 0, nd = (cd >= 0 && cd < nch) ? slices : 0;
+    // ... of the bins [ulo, uhi) of chunk cu and [dlo, dhi) of chunk cd
+    auto host_ranges = [&](int cu, size_t ulo, size_t uhi, int cd, size_t dlo, size_t dhi) {
+        const int nu = uhi > ulo ? slices : 0, nd = dhi > dlo ? slices : 0;
         pool.run(nu + nd, [&](int i) {
             if (i < nu) {
-                const size_t nb = chunk_bins(cu), lo = nb * i / slices, hi = nb * (i + 1) / slices, off = (size_t)cu * Bc * per;
+                const size_t nb = uhi - ulo, lo = ulo + nb * i / slices, hi = ulo + nb * (i + 1) / slices, off = (size_t)cu * Bc * per;
                 narrow_c128(S_in + 2 * off, static_cast<float *>(hp.up[cu & 1]), lo, hi);
             } else {
                 const int k = i - nu;
-                const size_t nb = chunk_bins(cd), lo = nb * k / slices, hi = nb * (k + 1) / slices, off = (size_t)cd * Bc * per;
+                const size_t nb = dhi - dlo, lo = dlo + nb * k / slices, hi = dlo + nb * (k + 1) / slices, off = (size_t)cd * Bc * per;
                 widen_c64(static_cast<const float *>(hp.down[cd & 1]), S_in + 2 * off, S_out + 2 * off, lo, hi);
             }
         });
     };
-    host_pass(0, -1);
+    auto host_pass = [&](int cu, int cd) {
+        host_ranges(cu, 0, (cu >= 0 && cu < nch) ? chunk_bins(cu) : 0, cd, 0, (cd >= 0 && cd < nch) ? chunk_bins(cd) : 0);
+    };
+    constexpr int NP = HostPipe::PIECES;
+    auto piece = [&](int c, int q) { return chunk_bins(c) * (size_t)q / NP; };   // first bin of piece q of chunk c
+    hipEvent_t tr0[16], tr1[16];   // (trace only) around the stages of each chunk, on the compute stream
+    mark("pool up, chunks:", nch);
+    // the first chunk goes up in pieces: piece q + 1 is narrowed while piece q is on the bus
+    for (int q = 0; q < NP; ++q) {
+        const size_t lo = piece(0, q), hi = piece(0, q + 1);
+        host_ranges(0, lo, hi, -1, 0, 0);
+        if (hi > lo) HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(hp.io[0].p) + lo, static_cast<const float2 *>(hp.up[0]) + lo, (hi - lo) * sizeof(float2), hipMemcpyHostToDevice, hp.s_up));
+    }
+    mark("narrowed and on its way", 0);
+    // D2H of chunk c: a blit kernel of the runtime that fills the device.  Started when chunk c is done it would run against
+    // the light first kernels of chunk c+1 (memsets, layout pass, mean: 0.2 ms alone, 2.5 ms beside it); so it waits for
+    // those as well and runs beside chunk c+1's update kernel instead, which leaves it the wave slots it needs.
+    auto enqueue_down = [&](int c, bool after_next_load) -> int {
+        const int slot = c & 1;
+        HIP_TRY(hipStreamWaitEvent(hp.s_down, hp.ev_comp[slot], 0));
+        if (after_next_load) HIP_TRY(hipStreamWaitEvent(hp.s_down, hp.ev_load[(c + 1) & 1], 0));
+        HIP_TRY(hipMemcpyAsync(hp.down[slot], hp.io[slot].p, chunk_bins(c) * sizeof(float2), hipMemcpyDeviceToHost, hp.s_down));
+        HIP_TRY(hipEventRecord(hp.ev_down[slot], hp.s_down));
+        return LWS_OK;
+    };
     for (int c = 0; c < nch; ++c) {
         const int slot = c & 1, bc = std::min(Bc, B - c * Bc);
         const size_t bytes = chunk_bins(c) * sizeof(float2);
         float2 *io = static_cast<float2 *>(hp.io[slot].p);
         if (c >= 2) HIP_TRY(hipStreamWaitEvent(hp.s_up, hp.ev_down[slot], 0));        // chunk c-2 has left this device buffer
-        HIP_TRY(hipMemcpyAsync(io, hp.up[slot], bytes, hipMemcpyHostToDevice, hp.s_up));
+        if (c >= 1) HIP_TRY(hipMemcpyAsync(io, hp.up[slot], bytes, hipMemcpyHostToDevice, hp.s_up));   // (chunk 0: above)
         HIP_TRY(hipEventRecord(hp.ev_up[slot], hp.s_up));
         HIP_TRY(hipStreamWaitEvent(hp.s_comp, hp.ev_up[slot], 0));
+        if (trace && c < 16) { HIP_TRY(hipEventCreate(&tr0[c])); HIP_TRY(hipEventCreate(&tr1[c])); HIP_TRY(hipEventRecord(tr0[c], hp.s_comp)); }
+        p->ev_after_load = hp.ev_load[slot];
         rc = run_pipeline<float, float2>(p, io, io, io, bc, T, st, n, hp.s_comp);
+        p->ev_after_load = nullptr;
         if (rc) { (void)hipDeviceSynchronize(); return rc; }
+        if (trace && c < 16) HIP_TRY(hipEventRecord(tr1[c], hp.s_comp));
         HIP_TRY(hipEventRecord(hp.ev_comp[slot], hp.s_comp));
-        HIP_TRY(hipStreamWaitEvent(hp.s_down, hp.ev_comp[slot], 0));
-        HIP_TRY(hipMemcpyAsync(hp.down[slot], io, bytes, hipMemcpyDeviceToHost, hp.s_down));
-        HIP_TRY(hipEventRecord(hp.ev_down[slot], hp.s_down));
+        if (c >= 1 && (rc = enqueue_down(c - 1, true))) { (void)hipDeviceSynchronize(); return rc; }
+        if (c == nch - 1) {   // the last chunk comes down in pieces: piece q is widened while piece q + 1 is on the bus
+            HIP_TRY(hipStreamWaitEvent(hp.s_down, hp.ev_comp[slot], 0));
+            for (int q = 0; q < NP; ++q) {
+                const size_t lo = piece(c, q), hi = piece(c, q + 1);
+                if (hi > lo) HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(hp.down[slot]) + lo, io + lo, (hi - lo) * sizeof(float2), hipMemcpyDeviceToHost, hp.s_down));
+                HIP_TRY(hipEventRecord(hp.ev_piece[q], hp.s_down));
+            }
+            HIP_TRY(hipEventRecord(hp.ev_down[slot], hp.s_down));
+        }
         // while the device works on chunk c: the next chunk on its way up (its pinned buffer is free once chunk c-1 has been
         // uploaded), the previous one on its way out (once it has arrived)
+        mark("enqueued", c);
+        if (c == 0 && static_cast<const void *>(S_out) != static_cast<const void *>(S_in)) {
+            // A result array fresh from the allocator has no pages yet: 256K first-touch faults for 1 GB, which the widening
+            // passes would take one by one on the critical path (and 32 threads faulting on one address space queue up in the
+            // kernel: 8.5 ms for the last chunk alone).  Populate it now, eight ways, while the device works on chunk 0.
+            char *lo = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(S_out) + 4095) & ~(uintptr_t)4095);
+            char *hi = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(S_out) + total * 16) & ~(uintptr_t)4095);
+            const int ways = std::min(8, pool.size());
+            if (hi > lo && env_int("LWS_HOST_PREFAULT", 1))
+                pool.run(ways, [&](int i) {
+                    const size_t pages = (size_t)(hi - lo) >> 12, a = pages * i / ways, b = pages * (i + 1) / ways;
+                    if (b > a && madvise(lo + (a << 12), (b - a) << 12, 23 /* MADV_POPULATE_WRITE, Linux 5.14 */) != 0) {
+                        // older kernel: nothing is lost but the head start (the passes fault the pages in themselves)
+                    }
+                });
+            mark("result pages populated", 0);
+        }
         if (c + 1 < nch && c >= 1) HIP_TRY(hipEventSynchronize(hp.ev_up[(c + 1) & 1]));
         if (c >= 1) HIP_TRY(hipEventSynchronize(hp.ev_down[(c - 1) & 1]));
+        mark("arrived", c - 1);
         host_pass(c + 1, c - 1);
+        mark("host pass done: narrowed c+1, widened c-1; c =", c);
     }
-    HIP_TRY(hipEventSynchronize(hp.ev_down[(nch - 1) & 1]));
-    host_pass(-1, nch - 1);
+    for (int q = 0; q < NP; ++q) {
+        HIP_TRY(hipEventSynchronize(hp.ev_piece[q]));
+        host_ranges(-1, 0, 0, nch - 1, piece(nch - 1, q), piece(nch - 1, q + 1));
+    }
+    mark("arrived and widened", nch - 1);
+    if (trace) {
+        for (int c = 0; c < nch && c < 16; ++c) {
+            float ms = 0.f, since = 0.f;
+            (void)hipEventElapsedTime(&ms, tr0[c], tr1[c]);
+            (void)hipEventElapsedTime(&since, tr0[0], tr0[c]);
+            fprintf(stderr, "[lws host] chunk %d: stages %.2f ms on the device, started %.2f ms after chunk 0\n", c, ms, since);
+        }
+        for (int c = 0; c < nch && c < 16; ++c) { (void)hipEventDestroy(tr0[c]); (void)hipEventDestroy(tr1[c]); }
+    }
     return check_systolic_flag(p);
 }
 
@@ -757,6 +861,8 @@ void lws_plan_destroy(lws_plan *p) {
     p->thr_host_copy.release(); p->thr_scaled.release(); p->stage.release();
     p->resid_rows.release(); p->resid_out.release(); p->gsk_state.release(); p->gsk_amp.release();
     p->pipe.release();
+    delete static_cast<HostWorkers *>(p->host_pool);
+    p->host_pool = nullptr;
     lws::systolic_entry().release(p->sys);   // (the same code in every build)
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -852,7 +958,7 @@ int lws_plan_reserve(lws_plan *p, int B, int T, int max_iters) {
     if (!p->fp64) {   // host entry points of an fp32 plan: pinned buffers, chunk buffers and streams of the pipeline, so that the
                       // first call does not pay for them (hipHostMalloc of 4 x 128 MB: ~50 ms)
         const size_t per = (size_t)T * p->F;
-        if ((rc = p->pipe.ensure((size_t)host_chunk(per, B) * per * sizeof(float2)))) return rc;
+        if ((rc = p->pipe.ensure((size_t)host_chunk(per, B, cu_count(p->device)) * per * sizeof(float2)))) return rc;
     }
     if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
     if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;

@@ -1,5 +1,6 @@
 import os, sys, time
 import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import lws_amd
 B, T, F = 12, 200, 513
 p = lws_amd.lws(1024, 256)

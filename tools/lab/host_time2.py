@@ -1,5 +1,6 @@
 import os, sys, time
 import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import lws_amd
 from lws_amd import _capi
 B, T, F, iters = 256, 500, 513, 100
