@@ -90,14 +90,14 @@ struct DevBuf {
 // chunks on their way up and down, the device buffers the chunks are processed in (in place), copy / compute streams.
 struct HostPipe {
     void *up[2] = {nullptr, nullptr}, *down[2] = {nullptr, nullptr};
-    size_t cap = 0;
+    size_t cap[2] = {0, 0};
     DevBuf io[2];
     hipStream_t s_up = nullptr, s_down = nullptr, s_comp = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     hipEvent_t ev_load[2] = {nullptr, nullptr};   // a chunk's light first kernels (layout, mean, thresholds) are done
     static constexpr int PIECES = 4;              // the first upload and the last download go in pieces, the host pass of a piece
     hipEvent_t ev_piece[PIECES] = {nullptr, nullptr, nullptr, nullptr};   // ... beside the copy of its neighbour
-    int ensure(size_t bytes) {
+    int ensure(size_t bytes, int slots = 2) {   // slots: 1 for a call that is a single chunk
         if (!s_up) {
             if (hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking) != hipSuccess)
@@ -110,19 +110,16 @@ struct HostPipe {
             for (int i = 0; i < PIECES; ++i)
                 if (hipEventCreateWithFlags(&ev_piece[i], hipEventDisableTiming) != hipSuccess) return fail(LWS_ERR_HIP, "hipEventCreate failed");
         }
-        if (bytes > cap) {
-            for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < slots && i < 2; ++i) {
+            if (bytes > cap[i]) {
                 if (up[i]) (void)hipHostFree(up[i]);
                 if (down[i]) (void)hipHostFree(down[i]);
                 up[i] = down[i] = nullptr;
-            }
-            cap = 0;
-            for (int i = 0; i < 2; ++i)
+                cap[i] = 0;
                 if (hipHostMalloc(&up[i], bytes, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&down[i], bytes, hipHostMallocDefault) != hipSuccess)
                     return fail(LWS_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
-            cap = bytes;
-        }
-        for (int i = 0; i < 2; ++i) {
+                cap[i] = bytes;
+            }
             int rc = io[i].ensure(bytes);
             if (rc) return rc;
         }
@@ -140,7 +137,7 @@ struct HostPipe {
             if (ev_load[i]) (void)hipEventDestroy(ev_load[i]);
             ev_up[i] = ev_comp[i] = ev_down[i] = ev_load[i] = nullptr;
         }
-        cap = 0;
+        cap[0] = cap[1] = 0;
         for (int i = 0; i < PIECES; ++i) {
             if (ev_piece[i]) (void)hipEventDestroy(ev_piece[i]);
             ev_piece[i] = nullptr;
@@ -547,10 +544,14 @@ int env_int(const char *name, int dflt) {
 }
 
 // spectrograms per chunk of the pipeline below (`per`: bins of one spectrogram)
-int host_chunk(size_t per, int B, int n_cu) {
+// whole_device: some stage of the call runs ONE workgroup per spectrogram (no-future, online, the generic engine): a launch of
+// fewer spectrograms than CUs takes as long as one of a full device's worth, so chunks hold multiples of the CU count
+// (config 3, 256 spectrograms: four chunks of 64 took 259 ms, one of 256 takes 105)
+int host_chunk(size_t per, int B, int n_cu, bool whole_device = false) {
     const size_t target = (size_t)std::max(1, env_int("LWS_HOST_CHUNK_BINS", 16 << 20));
     if (per * (size_t)B <= target + target / 2) return B;
     int bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (target + per / 2) / per));
+    if (whole_device && n_cu > 1 && !env_int("LWS_HOST_CHUNK_EXACT", 0)) return std::min(B, std::max(n_cu, bc - bc % n_cu));
     // a launch of fewer spectrograms than CUs gives each floor(CUs / spectrograms) workgroups (lws_systolic.hip: prepare):
     // 65 spectrograms on 256 CUs keep 195 of them busy, 64 all of them -- round to a divisor / multiple of the CU count
     if (n_cu > 1 && !env_int("LWS_HOST_CHUNK_EXACT", 0)) {
@@ -576,14 +577,18 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     // 32M 72 ms): long enough for the kernels to fill the device -- a launch of 32 spectrograms takes 6.7 ms, of 64 10.5, of
     // 256 33.9: fewer spectrograms than CUs run several workgroups each, 70-85 % as efficient -- short enough for the first
     // upload and the last download, which nothing overlaps, to be a small part of the call
-    const int Bc = host_chunk(per, B, cu_count(p->device));
+    bool whole_device = false;
+    for (int i = 0; i < n; ++i)
+        if (st[i].iters > 0 && (st[i].mode != lws::MODE_BATCH || (p->flags & LWS_FORCE_GENERIC) || !p->sysb || !p->sysb->supports(p->sys, st[i].wsel, T)))
+            whole_device = true;
+    const int Bc = host_chunk(per, B, cu_count(p->device), whole_device);
     const int nch = (B + Bc - 1) / Bc;
     int nthreads = env_int("LWS_HOST_THREADS", (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
     if (total < ((size_t)1 << 20)) nthreads = 1;
     nthreads = std::max(1, std::min(nthreads, 64));
     HIP_TRY(hipSetDevice(p->device));
     HostPipe &hp = p->pipe;
-    int rc = hp.ensure((size_t)Bc * per * sizeof(float2));
+    int rc = hp.ensure((size_t)Bc * per * sizeof(float2), nch > 1 ? 2 : 1);
     if (rc) return rc;
     if (p->host_pool && p->host_pool_n != nthreads) { delete static_cast<HostWorkers *>(p->host_pool); p->host_pool = nullptr; }
     if (!p->host_pool) { p->host_pool = new HostWorkers(nthreads); p->host_pool_n = nthreads; }
@@ -958,7 +963,9 @@ int lws_plan_reserve(lws_plan *p, int B, int T, int max_iters) {
     if (!p->fp64) {   // host entry points of an fp32 plan: pinned buffers, chunk buffers and streams of the pipeline, so that the
                       // first call does not pay for them (hipHostMalloc of 4 x 128 MB: ~50 ms)
         const size_t per = (size_t)T * p->F;
-        if ((rc = p->pipe.ensure((size_t)host_chunk(per, B, cu_count(p->device)) * per * sizeof(float2)))) return rc;
+        // (sized for a call with a one-workgroup-per-spectrogram stage: the larger chunks)
+        const int bc = host_chunk(per, B, cu_count(p->device), true);
+        if ((rc = p->pipe.ensure((size_t)bc * per * sizeof(float2), bc < B ? 2 : 1))) return rc;
     }
     if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
     if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
