@@ -39,6 +39,7 @@
 #include "lws_common.h"
 #include "lws_systolic.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -66,10 +67,26 @@
 #ifndef LWS_SPLIT_ROLES
 #define LWS_SPLIT_ROLES 1
 #endif
-#if LWS_WIDE && LWS_Q8
-#error "LWS_WIDE and LWS_Q8 are separate builds"
+// ... and with -DLWS_SPW=2 (namespace lws::half) / -DLWS_SPW=4 (lws::quarter) for SHORT frames, of up to 257 / 129 bins (512- and
+// 256-point STFTs: 16 kHz speech).  A lane of the narrow build needs 512 steps per frame whatever its length, so a 257-bin
+// frame left it idle half of the time.  Here a round is 32 (16) frames = 256 (128) steps, and a wave carries SPW sweep slots
+// side by side: lanes [32 s, 32 s + 32) of compute wave w are the 32 frames of sweep slot w SPW + s, which trails slot
+// w SPW + s - 1 -- its neighbours in the same wave, or the last slot of the wave before -- by the usual 32 steps.  Same skew,
+// lag, ring depth and per-bin code; 14 (24) sweep slots per pass over HBM instead of 7; the two halves of a wave are always
+// in the same pair, so the flow control between waves is unchanged.
+#ifndef LWS_SPW
+#define LWS_SPW 1
 #endif
-#if LWS_WIDE
+#if (LWS_WIDE && LWS_Q8) || (LWS_SPW != 1 && (LWS_WIDE || LWS_Q8))
+#error "LWS_WIDE, LWS_Q8 and LWS_SPW are separate builds"
+#endif
+#if LWS_SPW == 2
+#define LWS_NS_OPEN namespace lws { namespace half {
+#define LWS_NS_CLOSE } }
+#elif LWS_SPW == 4
+#define LWS_NS_OPEN namespace lws { namespace quarter {
+#define LWS_NS_CLOSE } }
+#elif LWS_WIDE
 #define LWS_NS_OPEN namespace lws { namespace wide {
 #define LWS_NS_CLOSE } }
 #elif LWS_Q8
@@ -85,8 +102,9 @@ namespace {
 
 constexpr int LANES = 64;                                // lanes of a wave
 constexpr int WPS = LWS_WIDE ? 2 : 1;                    // waves per sweep slot
-constexpr int ROWL = LANES * WPS;                        // lanes (frames) of a ring row = frames of a round
-constexpr int ROWL_SHIFT = LWS_WIDE ? 7 : 6;
+constexpr int SPW = LWS_SPW;                             // sweep slots per wave (short-frame builds)
+constexpr int ROWL = LANES * WPS / SPW;                  // lanes (frames) of a ring row = frames of a round
+constexpr int ROWL_SHIFT = LWS_WIDE ? 7 : (SPW == 4 ? 4 : (SPW == 2 ? 5 : 6));
 static_assert((1 << ROWL_SHIFT) == ROWL, "row length");
 constexpr int RING = LWS_Q8 ? 64 : 32;
 constexpr int NBLK = RING / 8;                           // ring blocks of 8 steps
@@ -109,7 +127,7 @@ constexpr int PAIR_BYTES = (ROWL + 2 * HALO + 2) * LANE_B;   // two consecutive 
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
 constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB (wide: 34 KiB, Q = 8: 40 KiB)
 #ifndef LWS_NSLOTS
-#define LWS_NSLOTS (LWS_WIDE ? 3 : (LWS_Q8 ? 2 : 7))
+#define LWS_NSLOTS (LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
 #endif
 constexpr int NSLOTS = LWS_NSLOTS;                       // sweeps in flight (compute waves)
 constexpr int NSETS = NSLOTS + 1;
@@ -145,9 +163,10 @@ constexpr int NW = LWS_Q8 ? WNYQ + QMAX * 6 : 4 * 8;
 __host__ __device__ constexpr int row_owner(int R) {     // which wave of a slot sums frames m-+R: 0 = main, h = helper h
     return (NHELP == 0 || R <= 1 || R == LATE_DN) ? 0 : (NHELP == 1 ? 1 : (R <= 4 ? 1 : 2));
 }
-constexpr int ROWP_SHIFT = LWS_WIDE ? 10 : 9;
+constexpr int ROWP_SHIFT = ROWL_SHIFT + 3;
 static_assert((1 << ROWP_SHIFT) == ROWP, "frame period");
-constexpr int NCOMPUTE = NSLOTS * WPS;                   // compute waves; roles NCOMPUTE .. NCOMPUTE + WPS - 1 are the service waves
+static_assert(NSLOTS % SPW == 0 && (SPW == 1 || (WPS == 1 && NHELP == 0)) && ROWL >= 2 * HALO + 2, "slots per wave");
+constexpr int NCOMPUTE = NSLOTS * WPS / SPW;             // compute waves; roles NCOMPUTE .. NCOMPUTE + WPS - 1 are the service waves
 constexpr int NHELPERS = NSLOTS * NHELP;                 // roles NCOMPUTE + WPS .. : helper h of slot s is role NCOMPUTE + WPS + s * NHELP + h - 1
 constexpr int NWAVES = NCOMPUTE + WPS + NHELPERS;
 constexpr int NTHREADS = LANES * NWAVES;
@@ -1335,10 +1354,11 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     static_assert(NSLOTS == 2 && NHELP == 2 && WPS == 1, "role table");   // (the weight lists above follow the same table)
     const int wave = hw_wave < 2 ? hw_wave : (hw_wave == 2 ? 3 : (hw_wave == 3 ? 5 : (hw_wave == 4 ? 4 : (hw_wave == 5 ? 6 : 2))));
 #else
-    const int wave = (LWS_ROLE_SWAP && NSLOTS == 7 && WPS == 1) ? (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave)) : hw_wave;
+    const int wave = (LWS_ROLE_SWAP && NCOMPUTE == 7 && WPS == 1) ? (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave)) : hw_wave;
 #endif
     const int hf = wave % WPS;                     // which half of the ring row this wave's lanes are
-    const int rl = hf * LANES + lane;              // the lane's place in the ring row = its frame within a round
+    const int sub = SPW > 1 ? lane / ROWL : 0;     // short-frame builds: which of the wave's sweep slots the lane belongs to
+    const int rl = SPW > 1 ? lane % ROWL : hf * LANES + lane;   // the lane's place in the ring row = its frame within a round
     float *thr_eff = reinterpret_cast<float *>(smem + THR_OFF);
     int *meta = reinterpret_cast<int *>(smem + META_OFF);
     const int G = a.G, C = a.C, Kr = a.Kr;
@@ -1412,7 +1432,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const bool is_helper = NHELP > 0 && wave >= NCOMPUTE + WPS;
     const bool is_service = !is_compute && !is_helper;
     const int helper_no = is_helper ? (wave - NCOMPUTE - WPS) % (NHELP > 0 ? NHELP : 1) + 1 : 0;   // 1 .. NHELP
-    const int slot = is_compute ? wave / WPS : (is_helper ? (wave - NCOMPUTE - WPS) / (NHELP > 0 ? NHELP : 1) : NSLOTS);
+    // slot0: the wave's (first) sweep slot, wave-uniform; slot: the lane's (SPW > 1: slot0 + sub for a compute wave)
+    const int slot0 = is_compute ? (wave / WPS) * SPW : (is_helper ? (wave - NCOMPUTE - WPS) / (NHELP > 0 ? NHELP : 1) : NSLOTS);
+    const int slot = (SPW > 1 && is_compute) ? slot0 + sub : slot0;
     LaneCtx cx;
     Carry cr;
     cr.o0 = cr.o1 = cr.o2 = cr.o3 = cr.prev_out = make_float2(0.f, 0.f);
@@ -1451,10 +1473,11 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     bool watched = false;
     if (lane < NWAVES) {
         const bool whelp = lane >= NCOMPUTE + WPS;
-        const int wslot = lane < NCOMPUTE ? lane / WPS : (whelp ? (lane - NCOMPUTE - WPS) / (NHELP > 0 ? NHELP : 1) : NSLOTS);   // the slot of wave `lane`
+        // the (first) slot of wave `lane`, and this wave's: neighbouring waves hold neighbouring slots in every build
+        const int wslot = lane < NCOMPUTE ? (lane / WPS) * SPW : (whelp ? (lane - NCOMPUTE - WPS) / (NHELP > 0 ? NHELP : 1) : NSLOTS);
         if (is_service) watched = lane != wave;
-        else if (is_helper) watched = !whelp && (wslot == slot - 1 || wslot == slot || wslot == NSLOTS);
-        else watched = (lane != wave) && (whelp ? wslot == slot : (wslot == slot - 1 || wslot == slot || wslot == slot + 1 || wslot == NSLOTS));
+        else if (is_helper) watched = !whelp && (wslot == slot0 - 1 || wslot == slot0 || wslot == NSLOTS);
+        else watched = (lane != wave) && (whelp ? wslot == slot0 : (wslot == slot0 - SPW || wslot == slot0 || wslot == slot0 + SPW || wslot == NSLOTS));
     }
     // Where a lane is in a block of 8 steps (which frame of which sweep, first / last bins of the frame, active at
     // all): evaluated once per block for the FOLLOWING block and shifted.  The lanes of a wave sit in at most two
@@ -1464,41 +1487,58 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     // lane only selects between the two.
     const float inv_kr = 1.0f / (float)Kr;   // (service wave: one division per block in floating point, exact for these magnitudes)
     struct Round { int gl, k, meb; bool okj; float thr; };    // wave-uniform: local pass, round within it, first frame, sweep valid, its threshold
-    Round rcur, rprev;
-    rcur.gl = 0; rcur.k = 0; rcur.meb = 0; rcur.okj = false; rcur.thr = 0.f;
-    rprev = rcur;
-    int ks_state = (T_START - (slot + 1) * LAG) >> ROWP_SHIFT;     // round of lane 0 at the last evaluation (negative: not started)
+    // (one set of this state per sweep slot of the wave: SPW > 1, the short-frame builds)
+    Round rcur[SPW], rprev[SPW];
+    int ks_state[SPW];                       // round of lane 0 at the last evaluation (negative: not started)
+#pragma unroll
+    for (int q = 0; q < SPW; ++q) {
+        rcur[q].gl = 0; rcur[q].k = 0; rcur[q].meb = 0; rcur[q].okj = false; rcur[q].thr = 0.f;
+        rprev[q] = rcur[q];
+        ks_state[q] = (T_START - (slot0 + q + 1) * LAG) >> ROWP_SHIFT;
+    }
     struct BlockInfo { bool live, start, end, end1; float thr; };
-    auto block_info = [&](int vblock) {      // vblock: the slot's clock at phase 0 of the block (wave-uniform)
-        const int rem = vblock & (ROWP - 1), ks = vblock >> ROWP_SHIFT;
-        if (ks != ks_state) {                 // once per 64 (128) blocks
-            ks_state = ks;
-            rprev = rcur;
-            if (ks <= 0) { rcur.gl = 0; rcur.k = 0; }
-            else if (++rcur.k == Kr) { rcur.k = 0; ++rcur.gl; }
-            const int j = (rcur.gl * nwg + wg) * NSLOTS + slot;
-            rcur.okj = is_compute && ks >= 0 && j < n_eff;
-            rcur.meb = rcur.k * ROWL;
-            rcur.thr = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(thr_eff[rcur.okj ? j : 0])));
-        }
+    auto block_info = [&](int vblock0) {      // vblock0: the clock of the wave's first slot at phase 0 of the block (wave-uniform)
         BlockInfo bi;
-        const bool here = SKEW * rl <= rem;                      // this lane's frame of the current round has started
-        const int cbase = (rem - SKEW * rl) & (ROWP - 1);
-        const int me = (here ? rcur.meb : rprev.meb) + rl;
-        const bool valid = (here ? rcur.okj : rprev.okj) && (me < a.Tp);
-        bi.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
-        bi.start = (cbase == 0);
-        bi.end = (cbase == C - th0(RE));
-        bi.end1 = (RE != 0) && (cbase == C - th1(RE));
-        bi.thr = here ? rcur.thr : rprev.thr;
+        bi.live = bi.start = bi.end = bi.end1 = false; bi.thr = 0.f;
+        static_for<SPW>([&](auto iq) {
+            constexpr int q = decltype(iq)::value;
+            const int vblock = vblock0 - q * LAG;      // slot slot0 + q trails slot0 by q lags
+            const int rem = vblock & (ROWP - 1), ks = vblock >> ROWP_SHIFT;
+            if (ks != ks_state[q]) {                 // once per round: ROWL blocks
+                ks_state[q] = ks;
+                rprev[q] = rcur[q];
+                if (ks <= 0) { rcur[q].gl = 0; rcur[q].k = 0; }
+                else if (++rcur[q].k == Kr) { rcur[q].k = 0; ++rcur[q].gl; }
+                const int j = (rcur[q].gl * nwg + wg) * NSLOTS + slot0 + q;
+                rcur[q].okj = is_compute && ks >= 0 && j < n_eff;
+                rcur[q].meb = rcur[q].k * ROWL;
+                rcur[q].thr = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(thr_eff[rcur[q].okj ? j : 0])));
+            }
+            const bool here = SKEW * rl <= rem;                      // this lane's frame of the current round has started
+            const int cbase = (rem - SKEW * rl) & (ROWP - 1);
+            const int me = (here ? rcur[q].meb : rprev[q].meb) + rl;
+            const bool valid = (here ? rcur[q].okj : rprev[q].okj) && (me < a.Tp);
+            const bool mine = SPW == 1 || sub == q;
+            BlockInfo b1;
+            b1.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
+            b1.start = (cbase == 0);
+            b1.end = (cbase == C - th0(RE));
+            b1.end1 = (RE != 0) && (cbase == C - th1(RE));
+            b1.thr = here ? rcur[q].thr : rprev[q].thr;
+            if constexpr (SPW == 1) bi = b1;
+            else { bi.live = mine ? b1.live : bi.live; bi.start = mine ? b1.start : bi.start; bi.end = mine ? b1.end : bi.end;
+                   bi.end1 = mine ? b1.end1 : bi.end1; bi.thr = mine ? b1.thr : bi.thr; }
+        });
         return bi;
     };
     int dlo[NDR];   // per-lane constants of the image-cell offsets: (PLL - HALO - DR - lane) * 16
 #pragma unroll
     for (int d = 0; d < NDR; ++d) dlo[d] = (PLL - HALO - (d - HALO) - rl) * LANE_B;
-    BlockInfo nxt_bi = block_info(T_START - (slot + 1) * LAG);
-    int vmod = __builtin_amdgcn_readfirstlane((((T_START - (slot + 1) * LAG) % G) + G) % G - 8);   // advanced at the loop head
+    BlockInfo nxt_bi = block_info(T_START - (slot0 + 1) * LAG);
+    int vmod = __builtin_amdgcn_readfirstlane((((T_START - (slot0 + 1) * LAG) % G) + G) % G - 8);   // advanced at the loop head
     int tmod = __builtin_amdgcn_readfirstlane(((T_START % G) + G) % G - 8);
+    // short-frame builds: the last slot's clock mod G (the rows of the write-back; NSLOTS * LAG can be several G there)
+    int wmod = __builtin_amdgcn_readfirstlane((((T_START - NSLOTS * LAG) % G) + G) % G - 8);
     // The step loop, per ROLE of the wave.  Q = 8 instantiates it once per role (main / helper 1 / helper 2 / service), so that
     // a wave only carries the registers of its own duties (the union does not fit 256 VGPRs); the other builds run one loop
     // with wave-uniform branches (ROLE < 0).
@@ -1509,7 +1549,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         const bool r_service = ROLE < 0 ? is_service : ROLE == R_SERVICE;
         const bool r_helper = ROLE < 0 ? is_helper : (ROLE >= 1 && ROLE < R_SERVICE);
         for (int t0 = T_START; t0 < t_end; t0 += 8) {
-            const int v0 = t0 - (slot + 1) * LAG;  // clock of this sweep slot at phase 0 of the block (multiple of 8)
+            const int v0 = t0 - (slot0 + 1) * LAG;  // clock of the wave's (first) sweep slot at phase 0 of the block (multiple of 8; its
+                                                    // other slots trail by whole rings: same ring block, same phase)
             // ---- block prologue: where is this lane in this block and in the next one?
             const int ablk = (v0 >> 3);
             {
@@ -1546,6 +1587,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             }
             vmod += 8; vmod -= (vmod >= G) ? G : 0;   // v0 mod G and t0 mod G (G is a multiple of 8), wave-uniform
             tmod += 8; tmod -= (tmod >= G) ? G : 0;
+            if constexpr (SPW > 1) { wmod += 8; wmod -= (wmod >= G) ? G : 0; }
             if (r_compute) {
                 int vnext = vmod + 8;
                 vnext -= (vnext >= G) ? G : 0;     // G is a multiple of 8: the next block does not wrap inside
@@ -1559,6 +1601,10 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 // (written as plain loads the compiler fetches into temporaries and copies -- i.e. waits -- at once: a stall
                 // of one memory latency per block).  The wait is explicit, at the end of the block; these are the only
                 // vector-memory operations of a sweep slot.
+                if constexpr (SPW > 1) {           // the lane's own slot is `sub` lags behind the wave's first
+                    vnext -= sub * LAG;
+                    vnext += (vnext < 0) ? G : 0;
+                }
                 const char *ap = static_cast<const char *>(amp_w_b) + ((size_t)vnext * ROWL + rl) * ST::RB;
     #define LWS_AMP_LOAD(i)                                                                                                             \
         do {                                                                                                                            \
@@ -1642,9 +1688,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                             wb_cur = (vv >= 0) && ((vv & (ROWP - 1)) < C) && (k * ROWL + rl < a.Tp) && (gl * nwg + wg < n_groups);
                         }
                         const v4f w = lds_read128(ring_addr<PA, -2>(ldb) + NSLOTS * SET_BYTES);
-                        int r0 = tmod + PA - 2 - NSLOTS * LAG;
+                        int r0 = SPW > 1 ? wmod + PA - 2 : tmod + PA - 2 - NSLOTS * LAG;
                         r0 += (r0 < 0) ? G : 0;
-                        r0 += (r0 < 0) ? G : 0;        // (G >= 512 > NSLOTS * LAG / 2)
+                        if constexpr (SPW == 1) r0 += (r0 < 0) ? G : 0;        // (G >= 512 > NSLOTS * LAG / 2)
                         int r1 = r0 + 1;
                         r1 -= (r1 >= G) ? G : 0;
                         if (PA == 0 ? wb_prev : wb_cur) {
@@ -2238,7 +2284,11 @@ hipError_t prepare(SystolicPlan &sp, int B, int T, int iters, Geom &g) {
     g.cb = sp.h16 ? Store<true>::CB : Store<false>::CB;
     g.rb = sp.h16 ? Store<true>::RB : Store<false>::RB;
     g.Tp = T + 2 * (Q - 1);
-    g.Kr = (g.Tp + ROWL - 1) / ROWL;
+    // rounds of ROWL frames per pass; at least so many that a pass (G rows) is longer than the lag of the last sweep slot behind
+    // the loader plus what the loader reads ahead: pass g+1 follows pass g on the same clock and reads the rows pass g's last
+    // slot has written (only the short-frame builds, with their 14 / 24 slots and short rounds, ever need the padding)
+    constexpr int KR_MIN = (NSLOTS * LAG + 96 + ROWP - 1) / ROWP;
+    g.Kr = std::max((g.Tp + ROWL - 1) / ROWL, KR_MIN);
     g.Kt = (g.Tp + LANES - 1) / LANES;
     g.G = ROWP * g.Kr;
     g.TpPad = (g.Tp + 63) & ~63;
@@ -2352,7 +2402,8 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
 #endif
-    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", LWS_WIDE ? "_wide" : "", Q, L, kind, h ? "_f16" : "");
+    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
+             h ? "_f16" : "");
     sp.name = sp.name_buf;
     return e;
 }

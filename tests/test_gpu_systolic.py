@@ -3,6 +3,8 @@ frame counts around the 64-lane rounds, bin counts below the 512-step frame peri
 7-slot groups, dropped (no-op) sweeps, per-spectrogram thresholds in one launch, Q = 2 and Q = 4.
 Every case is also run through the generic engine in fp64 (<= 1e-8 vs the oracle: schedule) so that a failure
 here isolates the systolic kernel."""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,7 +26,21 @@ def run_case(oracle, fsize, fshift, T, thr, seed, B=1, scale=None, L=5):
     if scale is not None:
         S *= np.asarray(scale)[:, None, None]
     out = p.plan().batch(S, thr)
-    assert p.plan().last_kernel()["name"].startswith("systolic"), p.plan().last_kernel()
+    name = p.plan().last_kernel()["name"]
+    assert name.startswith("systolic"), p.plan().last_kernel()
+    if F <= 257 and fsize // fshift in (2, 4):
+        # short frames run on the builds with two / four sweep slots per wave (<= 257 / 129 bins); the build with one slot per wave
+        # (LWS_SYSTOLIC_NO_SHORT=1, read at plan creation) does the same arithmetic per bin in the same order: identical bits
+        assert ("_quarter_" if F <= 129 else "_half_") in name, name
+        os.environ["LWS_SYSTOLIC_NO_SHORT"] = "1"
+        try:
+            narrow = _capi.Plan(F, p.W)
+        finally:
+            del os.environ["LWS_SYSTOLIC_NO_SHORT"]
+        ref_narrow = narrow.batch(S, thr)
+        n2 = narrow.last_kernel()["name"]
+        assert n2.startswith("systolic_q") and np.array_equal(out, ref_narrow), (name, n2)
+        narrow.close()
     p64 = _capi.Plan(F, p.W, precision="fp64")
     for b in range(B):
         ref = oracle.batch_lws(S[b], p.W, thr)
@@ -141,7 +157,7 @@ def test_weights_without_zero_pattern_use_the_allmask_kernel(oracle):
     thr = [0.4, 0.0, 0.0]
     plan = _capi.Plan(33, W2)
     out = plan.batch(S, thr)
-    assert plan.last_kernel()["name"] == "systolic_q4_l5_allmask"
+    assert plan.last_kernel()["name"] == "systolic_quarter_q4_l5_allmask"
     ref = oracle.batch_lws(S, W2, thr)
     assert rel_l2(out, ref) < 3e-3
     # weights that break the structure fall back to the generic engine
@@ -188,7 +204,8 @@ def test_frames_that_end_inside_a_block(oracle, fsize, fshift, T):
     assert (fsize // 2) % 8 != 0 and out.shape == (2, T, fsize // 2 + 1)
     p = lws_amd.lws(fsize, fshift)
     p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
-    assert _wide_name(p).startswith("systolic_wide_q" if fsize > 1026 else "systolic_q"), _wide_name(p)
+    F = fsize // 2 + 1
+    assert _wide_name(p).startswith("systolic_wide_q" if F > 513 else ("systolic_q" if F > 257 else ("systolic_half_q" if F > 129 else "systolic_quarter_q"))), _wide_name(p)
 
 
 def test_what_still_needs_the_generic_engine():
