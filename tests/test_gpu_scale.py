@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import lws_amd
+from lws_amd import _capi
 
 pytestmark = pytest.mark.gpu
 
@@ -84,6 +85,50 @@ def test_north_star_shape_1024_frames(oracle):
     ref = oracle.batch_lws(M, p.W, thr)
     out = one[0].cpu().numpy().astype(np.complex128)
     assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 1e-3 and np.median(np.abs(out - ref)) < 1e-6 * M.mean()
+
+
+@pytest.mark.parametrize("fsize,fshift,B,T,kernel", [(512, 128, 512, 500, "systolic_half_q4_l5_hann"), (256, 64, 300, 1000, "systolic_quarter_q4_l5_hann"),
+                                                    (1000, 250, 256, 500, "systolic_q4_l5_hann")])
+def test_config2_volume_at_other_frame_sizes(oracle, fsize, fshift, B, T, kernel, monkeypatch):
+    """Round 3's new fast paths at config 2's volume: 257- and 129-bin frames (BASELINE config 1's frame size: two / four sweep
+    slots per wave) and 501-bin frames (frame ends inside a block).  100 default-schedule sweeps from zero phase: batch position
+    must not matter, untouched bins stay bit-identical, consistency as for 513 bins, spectrogram 0 against the oracle value by
+    value; and the short-frame builds against the one-slot-per-wave build, bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    F = fsize // 2 + 1
+    p = lws_amd.lws(fsize, fshift)
+    mags = rayleigh(torch, dev, B, T, F, 3)
+    for b in (B // 3, B - 1):
+        mags[b] = mags[0]
+    state = mags.to(torch.complex64)
+    thr = lws_amd.get_thresholds(100, 100, 0.1, 1)
+    stream = torch.cuda.current_stream().cuda_stream
+    p.plan().batch_dev(state.data_ptr(), B, T, thr, stream=stream)
+    info = p.plan().last_kernel()
+    assert info["name"] == kernel and info["launches"] in (1, 2), info   # (2: a partial last round of workgroups shares the chip)
+    assert torch.isfinite(torch.view_as_real(state)).all()
+    assert float(((state.abs() - mags).abs().max() / mags.max()).item()) < 1e-6
+    for b in (B // 3, B - 1):
+        assert torch.equal(state[b], state[0])
+    mean = mags.mean(dim=(1, 2), keepdim=True)
+    quiet = mags < 0.999 * float(thr.min()) * mean
+    assert quiet.any() and torch.equal(state.real[quiet], mags[quiet]) and not state.imag[quiet].any()
+    c = consistency_db(p, state, [0, B // 2, B - 1])
+    assert (c > 9.5).all() and (c < 13.5).all(), c
+    M = mags[0].cpu().numpy().astype(np.float64)
+    ref = oracle.batch_lws(M, p.W, thr)
+    out = state[0].cpu().numpy().astype(np.complex128)
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 1e-3 and np.median(np.abs(out - ref)) < 1e-6 * M.mean()
+    if F <= 257:
+        monkeypatch.setenv("LWS_SYSTOLIC_NO_SHORT", "1")
+        narrow = _capi.Plan(F, p.W)
+        monkeypatch.delenv("LWS_SYSTOLIC_NO_SHORT")
+        again = mags[:64].to(torch.complex64)
+        narrow.batch_dev(again.data_ptr(), 64, T, thr, stream=stream)
+        assert narrow.last_kernel()["name"] == "systolic_q4_l5_hann"
+        assert torch.equal(again, state[:64])
+        narrow.close()
 
 
 @pytest.mark.parametrize("storage", ["fp32", "fp16"])
