@@ -249,6 +249,7 @@ struct SysArgs {
     int *err;                // set if a workgroup gave up waiting for its producer
     const int *gate;         // non-null: run only if *gate != 0 (the single-workgroup re-run after a hand-over time-out)
     int spin_limit;          // polls of a producer's counter before a workgroup gives up
+    int rolemap;             // experiment hook (LWS_SYSTOLIC_ROLEMAP): which hardware wave takes which role, wide build
     int stress;              // test hook (LWS_SYSTOLIC_STRESS): role mask | pair << 16 -- the waves of the mask stall ~10 us
                              // before that pair of every block; the flow control must make the results independent of it
     unsigned long long w[NW];      // W[0][r][k], r < Q, k <= L (at most 4 x 8): bit patterns of (re, im) as one 64-bit scalar;
@@ -1354,7 +1355,19 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     static_assert(NSLOTS == 2 && NHELP == 2 && WPS == 1, "role table");   // (the weight lists above follow the same table)
     const int wave = hw_wave < 2 ? hw_wave : (hw_wave == 2 ? 3 : (hw_wave == 3 ? 5 : (hw_wave == 4 ? 4 : (hw_wave == 5 ? 6 : 2))));
 #else
-    const int wave = (LWS_ROLE_SWAP && NCOMPUTE == 7 && WPS == 1) ? (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave)) : hw_wave;
+#ifndef LWS_WIDE_ROLEMAP
+#define LWS_WIDE_ROLEMAP LWS_WIDE
+#endif
+    // Wide build (round 3): hardware waves h and h + 4 -- one SIMD -- carry the two halves of one slot, SIMD 3 both service waves.
+    // With role = hardware wave the service waves shared their SIMDs with the halves of slot 1 and got every other issue slot
+    // there, and every slot meets them at every pair: 38.0 -> 40.6 % (64 x 6000 x 1025, 60 sweeps).
+    const int rm = a_in.rolemap;   // (experiment hook, LWS_SYSTOLIC_ROLEMAP)
+    const int wave = (LWS_WIDE_ROLEMAP && WPS == 2 && NWAVES == 8)
+                         ? (rm == 1 ? hw_wave
+                            : rm == 2 ? ((hw_wave & 3) == 3 ? 6 + (hw_wave >> 2) : ((hw_wave & 3) == 2 ? 4 + (hw_wave >> 2) : (hw_wave & 3) + 2 * (hw_wave >> 2)))
+                            : rm == 3 ? ((hw_wave & 3) == 3 ? 6 + (hw_wave >> 2) : (hw_wave & 3) * 2 + 1 - (hw_wave >> 2))
+                            : ((hw_wave & 3) * 2 + (hw_wave >> 2)))
+                   : ((LWS_ROLE_SWAP && NCOMPUTE == 7 && WPS == 1) ? (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave)) : hw_wave);
 #endif
     const int hf = wave % WPS;                     // which half of the ring row this wave's lanes are
     const int sub = SPW > 1 ? lane / ROWL : 0;     // short-frame builds: which of the wave's sweep slots the lane belongs to
@@ -2370,6 +2383,8 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         a.spin_limit = ev ? atoi(ev) : (1 << 21);
         const char *es = getenv("LWS_SYSTOLIC_STRESS");
         a.stress = es ? atoi(es) : 0;
+        const char *er = getenv("LWS_SYSTOLIC_ROLEMAP");
+        a.rolemap = er ? atoi(er) : 0;
     }
     for (int x = 0; x < NW; ++x) {
         const bool used = LWS_Q8 || x < Q * (L + 1);
