@@ -1367,7 +1367,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                             : rm == 2 ? ((hw_wave & 3) == 3 ? 6 + (hw_wave >> 2) : ((hw_wave & 3) == 2 ? 4 + (hw_wave >> 2) : (hw_wave & 3) + 2 * (hw_wave >> 2)))
                             : rm == 3 ? ((hw_wave & 3) == 3 ? 6 + (hw_wave >> 2) : (hw_wave & 3) * 2 + 1 - (hw_wave >> 2))
                             : ((hw_wave & 3) * 2 + (hw_wave >> 2)))
-                   : ((LWS_ROLE_SWAP && NCOMPUTE == 7 && WPS == 1) ? (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave)) : hw_wave);
+                   : ((LWS_ROLE_SWAP && NCOMPUTE == 7 && WPS == 1 && rm != 1) ? (rm == 2 ? (hw_wave == 0 ? 7 : (hw_wave == 7 ? 0 : hw_wave)) : (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave))) : hw_wave);
 #endif
     const int hf = wave % WPS;                     // which half of the ring row this wave's lanes are
     const int sub = SPW > 1 ? lane / ROWL : 0;     // short-frame builds: which of the wave's sweep slots the lane belongs to
