@@ -86,6 +86,9 @@
 #elif LWS_SPW == 4
 #define LWS_NS_OPEN namespace lws { namespace quarter {
 #define LWS_NS_CLOSE } }
+#elif LWS_WIDE == 2
+#define LWS_NS_OPEN namespace lws { namespace xwide {
+#define LWS_NS_CLOSE } }
 #elif LWS_WIDE
 #define LWS_NS_OPEN namespace lws { namespace wide {
 #define LWS_NS_CLOSE } }
@@ -101,10 +104,13 @@ LWS_NS_OPEN
 namespace {
 
 constexpr int LANES = 64;                                // lanes of a wave
-constexpr int WPS = LWS_WIDE ? 2 : 1;                    // waves per sweep slot
+// (-DLWS_WIDE=2, namespace lws::xwide: frames of up to 2049 bins -- a 4096-point STFT -- on a ring row of 256 lanes = FOUR waves per
+//  sweep slot; the LDS holds the loader's set and one slot's, so every sweep is a pass over HBM, with four compute waves each
+//  alone on its SIMD beside a service wave: a quarter of the narrow build's rate per bin, four times the generic engine's)
+constexpr int WPS = LWS_WIDE == 2 ? 4 : (LWS_WIDE ? 2 : 1);   // waves per sweep slot
 constexpr int SPW = LWS_SPW;                             // sweep slots per wave (short-frame builds)
 constexpr int ROWL = LANES * WPS / SPW;                  // lanes (frames) of a ring row = frames of a round
-constexpr int ROWL_SHIFT = LWS_WIDE ? 7 : (SPW == 4 ? 4 : (SPW == 2 ? 5 : 6));
+constexpr int ROWL_SHIFT = LWS_WIDE == 2 ? 8 : (LWS_WIDE ? 7 : (SPW == 4 ? 4 : (SPW == 2 ? 5 : 6)));
 static_assert((1 << ROWL_SHIFT) == ROWL, "row length");
 constexpr int RING = LWS_Q8 ? 64 : 32;
 constexpr int NBLK = RING / 8;                           // ring blocks of 8 steps
@@ -127,7 +133,7 @@ constexpr int PAIR_BYTES = (ROWL + 2 * HALO + 2) * LANE_B;   // two consecutive 
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
 constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB (wide: 34 KiB, Q = 8: 40 KiB)
 #ifndef LWS_NSLOTS
-#define LWS_NSLOTS (LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
+#define LWS_NSLOTS (LWS_WIDE == 2 ? 1 : LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
 #endif
 constexpr int NSLOTS = LWS_NSLOTS;                       // sweeps in flight (compute waves)
 constexpr int NSETS = NSLOTS + 1;
@@ -1619,10 +1625,15 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                     vnext += (vnext < 0) ? G : 0;
                 }
                 const char *ap = static_cast<const char *>(amp_w_b) + ((size_t)vnext * ROWL + rl) * ST::RB;
+                // (the instruction's offset field holds 12 bits: rows 4..7 of a 256-lane row go through a second base)
+                constexpr bool far_rows = 7 * ROWL * 4 > 4095;
+                const char *ap4 = far_rows ? ap + 4 * ROWL * ST::RB : ap;
     #define LWS_AMP_LOAD(i)                                                                                                             \
         do {                                                                                                                            \
-            if constexpr (H16) asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * ROWL * 2) : "memory"); \
-            else asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ap), "i"((i) * ROWL * 4) : "memory"); \
+            constexpr int io_ = (far_rows && (i) >= 4) ? (i) - 4 : (i);                                                                 \
+            const char *ab_ = (far_rows && (i) >= 4) ? ap4 : ap;                                                                        \
+            if constexpr (H16) asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ab_), "i"(io_ * ROWL * 2) : "memory"); \
+            else asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(amp_nxt[i]) : "v"(ab_), "i"(io_ * ROWL * 4) : "memory"); \
         } while (0)
                 LWS_AMP_LOAD(0); LWS_AMP_LOAD(1); LWS_AMP_LOAD(2); LWS_AMP_LOAD(3);
                 LWS_AMP_LOAD(4); LWS_AMP_LOAD(5); LWS_AMP_LOAD(6); LWS_AMP_LOAD(7);
@@ -2417,7 +2428,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
 #endif
-    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
+    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
              h ? "_f16" : "");
     sp.name = sp.name_buf;
     return e;

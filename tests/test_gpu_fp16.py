@@ -24,7 +24,7 @@ def report(out, ref, M):
 
 
 @pytest.mark.parametrize("fsize,fshift,T", [(64, 16, 40), (128, 32, 130), (1024, 256, 70), (1024, 512, 65), (2048, 512, 50),
-                                            (1024, 128, 40), (64, 8, 70), (1000, 250, 70), (2004, 501, 50), (60, 15, 40)])
+                                            (1024, 128, 40), (64, 8, 70), (1000, 250, 70), (2004, 501, 50), (60, 15, 40), (4096, 1024, 40), (512, 128, 70)])
 def test_fp16_storage_structure_and_tolerance(oracle, fsize, fshift, T):
     """Complex (random-phase) input: well conditioned, so values can be compared one by one."""
     rng = np.random.default_rng(fsize + T)

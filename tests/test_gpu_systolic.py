@@ -187,6 +187,19 @@ def test_wide_frames(oracle, fsize, fshift, T):
     assert out.shape == (1, T, fsize // 2 + 1)
 
 
+@pytest.mark.parametrize("fsize,fshift,T", [(4096, 1024, 9), (4096, 1024, 70), (4096, 2048, 40), (3072, 768, 33), (4096, 1024, 255),
+                                            (4096, 1024, 258), (3000, 750, 40), (2100, 525, 66), (4092, 1023, 21), (2056, 514, 130)])
+def test_extra_wide_frames(oracle, fsize, fshift, T):
+    """F - 1 in (1024, 2048] -- a 4096-point STFT: the build with FOUR waves per sweep slot on a 256-lane ring row (one sweep slot:
+    every sweep is a pass over HBM), frame ends inside a block included; T around one round of 256 frames and the quarters of
+    a row.  (Round 2: generic engine, 30x slower.)"""
+    out = run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0], seed=fsize + T, B=2, scale=[1.0, 50.0])
+    p = lws_amd.lws(fsize, fshift)
+    p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
+    assert _wide_name(p).startswith("systolic_xwide_q"), _wide_name(p)
+    assert out.shape == (2, T, fsize // 2 + 1)
+
+
 @pytest.mark.parametrize("n_it", [1, 3, 4, 7, 10])
 def test_wide_sweep_counts_around_slot_groups(oracle, n_it):
     run_case(oracle, 2048, 512, 12, np.linspace(0.8, 0.0, n_it), seed=300 + n_it, B=2, scale=[1.0, 7.0])
@@ -224,7 +237,7 @@ def test_what_still_needs_the_generic_engine():
                                                     (1024, 256, 9, 300, 45), (1024, 512, 5, 260, 16),
                                                     (2048, 512, 3, 150, 20), (64, 8, 2, 300, 11), (1024, 128, 3, 200, 9),
                                                     (1000, 250, 2, 200, 30), (60, 15, 3, 300, 50), (1004, 502, 5, 260, 16),
-                                                    (2004, 501, 3, 150, 20)])
+                                                    (2004, 501, 3, 150, 20), (4096, 1024, 2, 300, 9), (3000, 750, 3, 270, 7)])
 def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, iters, monkeypatch):
     """When there are fewer spectrograms than CUs the passes over HBM are dealt to several workgroups per spectrogram
     that hand the skewed state to each other through HBM; the result must be bit-identical to one workgroup doing all
@@ -271,7 +284,8 @@ def test_workgroup_sharing_randomised(monkeypatch):
 
 
 @pytest.mark.parametrize("fsize,fshift,T", [(1024, 256, 150), (2048, 512, 150), (2048, 512, 100), (1024, 128, 150), (64, 8, 70),
-                                             (1000, 250, 150), (1012, 253, 150), (2004, 501, 100)])
+                                             (1000, 250, 150), (1012, 253, 150), (2004, 501, 100), (4096, 1024, 60),
+                                             (512, 128, 150), (256, 64, 150)])
 def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
     """The waves of a workgroup synchronise through progress counters in LDS, not barriers.  LWS_SYSTOLIC_STRESS stalls chosen
     waves (role mask) for ~10 us before a chosen pair of every block -- far longer than a pair takes -- so any read that is
@@ -298,7 +312,7 @@ def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
 # ----------------------------------------------------------------------------- direct device I/O
 @pytest.mark.parametrize("fsize,fshift,B,T", [(64, 16, 3, 77), (1024, 256, 2, 130), (1024, 512, 2, 65), (2048, 512, 2, 40),
                                               (1024, 128, 2, 70), (1000, 250, 2, 130), (60, 15, 3, 77), (2004, 501, 2, 40),
-                                              (1004, 502, 2, 65)])
+                                              (1004, 502, 2, 65), (4096, 1024, 2, 40), (512, 128, 3, 77)])
 def test_direct_device_io_equals_the_padded_path(fsize, fshift, B, T):
     """A *_dev call that is one batch stage converts the caller's complex64 spectrograms straight to the kernel's
     layout and back.  Same sweeps on the same values: the result equals the path through the extended buffers bit for
