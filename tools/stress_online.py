@@ -2,13 +2,15 @@
 generic engine's fp32 result bit for bit (schedule, frame ring, sweep slots), the production variant the same magnitudes.
 usage: PYTHONPATH=. python tools/stress_online.py [cases] [seed]"""
 import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
 import lws_amd
 from lws_amd import _capi
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-cfgs = [(64, 16), (64, 32), (64, 8), (128, 32), (256, 64), (256, 32), (512, 128), (512, 64), (1024, 256), (1024, 512), (1024, 128)]
+cfgs = [(64, 16), (64, 32), (64, 8), (128, 32), (256, 64), (256, 32), (512, 128), (512, 64), (1024, 256), (1024, 512), (1024, 128),
+        (1000, 250), (2048, 512), (60, 15)]
 bad = 0
 for it in range(cases):
     fs, sh = cfgs[rng.integers(len(cfgs))]
@@ -18,7 +20,9 @@ for it in range(cases):
     iters = int(rng.integers(1, 9))
     B = int(rng.integers(1, 3))
     layout = str(rng.choice(["2", "3"]))
-    p = lws_amd.lws(fs, sh, mode="music")
+    L = int(rng.choice([5, 5, 5, 1, 2, 3, 4]))          # (stencils narrower than the kernel's run on the fourth layout with zero weights)
+    layout = "4" if L != 5 else str(rng.choice(["2", "3", "4"]))
+    p = lws_amd.lws(fs, sh, L=L, mode="music")
     W = (p.W, p.W_ai, p.W_af)
     S = rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))
     if rng.random() < 0.3:

@@ -15,14 +15,16 @@ cfgs = [(64, 16), (64, 32), (64, 8), (128, 32), (128, 64), (128, 16), (256, 64),
         (1024, 512), (1024, 128), (2048, 512), (2048, 1024), (1536, 384), (1040, 260),
         # frames that end inside a block of 8 steps (F-1 = 2, 4, 6 mod 8), all builds
         (1000, 250), (1012, 253), (1020, 255), (1004, 502), (60, 15), (100, 25), (52, 13), (76, 38), (500, 125), (252, 126), (200, 50),
-        (2004, 501), (1100, 275), (1032, 258), (2044, 1022), (300, 75), (420, 105), (516, 129)]
+        (2004, 501), (1100, 275), (1032, 258), (2044, 1022), (300, 75), (420, 105), (516, 129),
+        # frames of up to 2049 bins (four waves per sweep slot)
+        (4096, 1024), (4096, 2048), (3000, 750), (2100, 525), (3072, 768)]
 worst, bad = 0.0, 0
 for it in range(cases):
     fs, sh = cfgs[rng.integers(len(cfgs))]
     Q = fs // sh
     L = 5 if Q == 8 else int(rng.choice([1, 2, 3, 4, 5, 5, 5]))
     F = fs // 2 + 1
-    T = int(rng.integers(1, 200 if fs <= 1100 else 120))
+    T = int(rng.integers(1, 200 if fs <= 1100 else (120 if fs <= 2100 else 60)))
     B = int(rng.integers(1, 4))
     n = int(rng.integers(1, 16))
     p = lws_amd.lws(fs, sh, L=L)
