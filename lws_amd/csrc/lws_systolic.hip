@@ -2175,7 +2175,7 @@ struct Tables {
 hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const double *const W[3], bool fp16_storage) {
     // Lu: the caller's stencil half-width (its weight tensors have Lu + 1 columns, its extended buffers 2 Lu pad columns);
     // L: that of the kernel build -- the next odd number, the extra tap with weight zero (its mask bit is clear: never fetched)
-    const int L = Lu | 1, K1u = Lu + 1;
+    const int L = LWS_Q8 ? (Lu <= 5 ? 5 : Lu) : (Lu | 1), K1u = Lu + 1;   // (the Q = 8 build exists for L = 5 only: narrower stencils run on it)
     sp.F = F; sp.L = Lu; sp.Lk = L; sp.Q = Q; sp.h16 = fp16_storage;
     for (int i = 0; i < 3; ++i) sp.ok[i] = false;
     if (Lu < 0) return hipSuccess;

@@ -119,6 +119,15 @@ def test_q8(oracle, fsize, fshift, T, n_it):
     assert p.plan().last_kernel()["name"] == "systolic_q8_l5_hann", p.plan().last_kernel()
 
 
+@pytest.mark.parametrize("fsize,fshift,L,T", [(64, 8, 3, 40), (512, 64, 1, 33), (1024, 128, 4, 37), (128, 16, 2, 70)])
+def test_q8_narrower_stencils(oracle, fsize, fshift, L, T):
+    """Q = 8 with L < 5: the L = 5 build with zero weights (clear mask bits) for the taps the caller's tensors do not have."""
+    run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0, 0.0], seed=fsize + L, B=2, scale=[1.0, 40.0], L=L)
+    p = lws_amd.lws(fsize, fshift, L=L)
+    p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
+    assert p.plan().last_kernel()["name"].startswith("systolic_q8_l5_"), p.plan().last_kernel()
+
+
 def test_dropped_sweeps_and_mixed_schedules(oracle):
     """Thresholds above the largest magnitude are dropped per spectrogram; spectrograms of one launch have different
     scales, hence different sets of dropped sweeps and different scaled thresholds."""
