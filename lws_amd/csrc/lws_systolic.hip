@@ -77,10 +77,22 @@
 #ifndef LWS_SPW
 #define LWS_SPW 1
 #endif
-#if (LWS_WIDE && LWS_Q8) || (LWS_SPW != 1 && (LWS_WIDE || LWS_Q8))
-#error "LWS_WIDE, LWS_Q8 and LWS_SPW are separate builds"
+// ... and with -DLWS_L7=1 (namespace lws::l7) for stencils of half-width 6 and 7 (Q in {2, 4}, frames of up to 513 bins).  A lane
+// works on two bins per rendez-vous, so the newest tap of a pair's second bin, (m-1, c+1+L), must be two steps old when the
+// pair starts: with the usual skew of 8 steps between frames that holds for L <= 5 only.  Here frame m trails frame m-1 by
+// SKEW = 16 steps (two blocks): the tap is 8 steps old, no frame is "late", the lag between sweeps and the ring are 64 steps
+// (LAG > 16 (Q-1) + L), three sweep slots fit the LDS, and a lane's frame period is 1024 steps -- a lane is idle at least
+// half of the time.  A quarter of the narrow build's rate; the generic engine these shapes used to get is 5x slower still.
+#ifndef LWS_L7
+#define LWS_L7 0
 #endif
-#if LWS_SPW == 2
+#if (LWS_WIDE && LWS_Q8) || ((LWS_SPW != 1 || LWS_L7) && (LWS_WIDE || LWS_Q8)) || (LWS_SPW != 1 && LWS_L7)
+#error "LWS_WIDE, LWS_Q8, LWS_SPW and LWS_L7 are separate builds"
+#endif
+#if LWS_L7
+#define LWS_NS_OPEN namespace lws { namespace l7 {
+#define LWS_NS_CLOSE } }
+#elif LWS_SPW == 2
 #define LWS_NS_OPEN namespace lws { namespace half {
 #define LWS_NS_CLOSE } }
 #elif LWS_SPW == 4
@@ -112,7 +124,7 @@ constexpr int SPW = LWS_SPW;                             // sweep slots per wave
 constexpr int ROWL = LANES * WPS / SPW;                  // lanes (frames) of a ring row = frames of a round
 constexpr int ROWL_SHIFT = LWS_WIDE == 2 ? 8 : (LWS_WIDE ? 7 : (SPW == 4 ? 4 : (SPW == 2 ? 5 : 6)));
 static_assert((1 << ROWL_SHIFT) == ROWL, "row length");
-constexpr int RING = LWS_Q8 ? 64 : 32;
+constexpr int RING = (LWS_Q8 || LWS_L7) ? 64 : 32;
 constexpr int NBLK = RING / 8;                           // ring blocks of 8 steps
 // ring entry of production time nu, lane l:  set + ((nu >> 1) & 15) * PAIR_BYTES + (l + HALO) * 16 + (nu & 1) * 8
 // -- two consecutive times of one lane share a 16-byte cell, so a reader fetches two adjacent taps with one
@@ -133,7 +145,7 @@ constexpr int PAIR_BYTES = (ROWL + 2 * HALO + 2) * LANE_B;   // two consecutive 
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
 constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB (wide: 34 KiB, Q = 8: 40 KiB)
 #ifndef LWS_NSLOTS
-#define LWS_NSLOTS (LWS_WIDE == 2 ? 1 : LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
+#define LWS_NSLOTS (LWS_L7 ? 3 : LWS_WIDE == 2 ? 1 : LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
 #endif
 constexpr int NSLOTS = LWS_NSLOTS;                       // sweeps in flight (compute waves)
 constexpr int NSETS = NSLOTS + 1;
@@ -160,7 +172,7 @@ constexpr int MBOX_BYTES = NSLOTS * NHELP * 4 * LANES * 16;
 constexpr int WNYQ_OFF = MBOX_OFF + MBOX_BYTES;          // Q = 8: the Nyquist lanes' weights (the waves keep only their own in registers)
 constexpr int LDS_BYTES = WNYQ_OFF + (LWS_Q8 ? QMAX * 6 * 8 : 0);
 __host__ __device__ constexpr int mbox_addr(int slot, int h, int pair) { return MBOX_OFF + ((slot * NHELP + (h - 1)) * 4 + (pair & 3)) * LANES * 16; }
-constexpr int SKEW = 8, ROWP = SKEW * ROWL, LAG = RING;
+constexpr int SKEW = LWS_L7 ? 16 : 8, ROWP = SKEW * ROWL, LAG = RING;
 constexpr int LATE_DN = LAG / SKEW - 1;                  // frame m + LATE_DN of the previous sweep is only SKEW steps ahead of a lane (as frame m - 1 of its own sweep is)
 // weights a kernel carries.  Q = 8: every wave of a slot keeps only the weights of the frames it sums (row_owner), both weight
 // sets for the odd frames: 3 lists of up to WLIST entries, then the 48 weights of set 0 in full for the Nyquist lanes
@@ -169,7 +181,7 @@ constexpr int NW = LWS_Q8 ? WNYQ + QMAX * 6 : 4 * 8;
 __host__ __device__ constexpr int row_owner(int R) {     // which wave of a slot sums frames m-+R: 0 = main, h = helper h
     return (NHELP == 0 || R <= 1 || R == LATE_DN) ? 0 : (NHELP == 1 ? 1 : (R <= 4 ? 1 : 2));
 }
-constexpr int ROWP_SHIFT = ROWL_SHIFT + 3;
+constexpr int ROWP_SHIFT = ROWL_SHIFT + (LWS_L7 ? 4 : 3);
 static_assert((1 << ROWP_SHIFT) == ROWP, "frame period");
 static_assert(NSLOTS % SPW == 0 && (SPW == 1 || (WPS == 1 && NHELP == 0)) && ROWL >= 2 * HALO + 2, "slots per wave");
 constexpr int NCOMPUTE = NSLOTS * WPS / SPW;             // compute waves; roles NCOMPUTE .. NCOMPUTE + WPS - 1 are the service waves
@@ -434,7 +446,7 @@ template <int P, int OFF, int DR = 0, int NEWSET = 0> __device__ __forceinline__
 // the same for an absolute row index (halo copies, image pseudo-lanes); base[m] is the row origin (set + block)
 template <int P, int OFF, int LIDX, int NEWSET = 0> __device__ __forceinline__ int ring_addr_abs(const int (&base)[NBLK]) {
     constexpr int q = P + OFF;
-    static_assert(q >= -RING && q <= 15, "ring retention exceeded");
+    static_assert(q >= -RING && q <= (NBLK > 4 ? 31 : 15), "ring retention exceeded");   // (images are written up to 2(L-1) steps ahead of their time)
     constexpr int fl = floor_div8(q);
     constexpr int m = (-fl) & (NBLK - 1);
     constexpr int within = q - 8 * fl;
@@ -2186,12 +2198,14 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
     // starts (L = 7 is not: generic engine).
 #if LWS_Q8
     if (Qp != Q || Q != 8 || L != 5) return hipSuccess;
+#elif LWS_L7
+    if (Qp != Q || !(Q == 2 || Q == 4) || L != 7) return hipSuccess;      // (Lu = 6: the extra tap has weight zero)
 #else
     if (Qp != Q || !(Q == 2 || Q == 4) || !(L == 5 || L == 3 || L == 1)) return hipSuccess;
 #endif
     // F-1 even (a pair of bins never straddles bin C); not a multiple of 8: the frames end inside a block (th0), and the block
     // before that one must not be the frame's first
-    if ((C & 1) != 0 || C > ROWP || C < 16 || (C % SKEW != 0 && (LWS_Q8 || C < 24))) return hipSuccess;
+    if ((C & 1) != 0 || C > ROWP || C < 16 || (C % 8 != 0 && (LWS_Q8 || C < 24)) || (LWS_L7 && C > 512)) return hipSuccess;
     if ((Q - 1) * SKEW + L + 1 > LAG) return hipSuccess;
     const int K1 = L + 1;
     for (int i = 0; i < 3; ++i) {
@@ -2413,6 +2427,8 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     constexpr uint64_t MASK_Q8_L5_DEFAULT = 0b111111'111111'111111'010111'111111'111111'111111'000011ull;
     if (tb->mask == MASK_Q8_L5_DEFAULT && tb->k0real) { e = launch_k<8, 5, MASK_Q8_L5_DEFAULT | FLAG_K0REAL>(a, grid, h, stream); kind = "hann"; }
     else e = launch_k<8, 5, mask_all(8, 5)>(a, grid, h, stream);
+#elif LWS_L7
+    e = Q == 4 ? launch_k<4, 7, mask_all(4, 7)>(a, grid, h, stream) : launch_k<2, 7, mask_all(2, 7)>(a, grid, h, stream);
 #else
     if (L == 3) {
         e = Q == 4 ? launch_k<4, 3, mask_all(4, 3)>(a, grid, h, stream) : launch_k<2, 3, mask_all(2, 3)>(a, grid, h, stream);

@@ -28,7 +28,7 @@ def run_case(oracle, fsize, fshift, T, thr, seed, B=1, scale=None, L=5):
     out = p.plan().batch(S, thr)
     name = p.plan().last_kernel()["name"]
     assert name.startswith("systolic"), p.plan().last_kernel()
-    if F <= 257 and fsize // fshift in (2, 4):
+    if F <= 257 and fsize // fshift in (2, 4) and L <= 5:
         # short frames run on the builds with two / four sweep slots per wave (<= 257 / 129 bins); the build with one slot per wave
         # (LWS_SYSTOLIC_NO_SHORT=1, read at plan creation) does the same arithmetic per bin in the same order: identical bits
         assert ("_quarter_" if F <= 129 else "_half_") in name, name
@@ -88,9 +88,24 @@ def test_other_stencil_widths(oracle, fsize, fshift, L, T):
     p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
     name = p.plan().last_kernel()["name"]
     assert name.startswith("systolic") and ("_l%d_" % L) in name, name
-    pg = lws_amd.lws(fsize, fshift, L=7)
+    pg = lws_amd.lws(fsize, fshift, L=8)
     pg.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
     assert pg.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
+
+
+@pytest.mark.parametrize("fsize,fshift,L,T", [(64, 16, 7, 70), (1024, 256, 7, 37), (1024, 512, 7, 66), (1000, 250, 7, 33), (512, 128, 6, 131),
+                                              (100, 25, 7, 66), (1012, 253, 6, 20), (128, 64, 7, 140), (1024, 256, 6, 129)])
+def test_stencils_of_half_width_6_and_7(oracle, fsize, fshift, L, T):
+    """L = 6, 7 (`lws(..., L=7)`, lws.pyx:379 takes any L): the build whose frames are 16 steps apart (the newest tap of a pair's
+    second bin is then 8 steps old), 64-step ring, three sweep slots; frames of up to 513 bins, Q = 2 and 4, frame ends
+    inside a block included.  (Round 2: generic engine.)  Wider frames with such a stencil still run there."""
+    run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0, 0.0], seed=fsize + L, B=2, scale=[1.0, 40.0], L=L)
+    p = lws_amd.lws(fsize, fshift, L=L)
+    p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
+    assert p.plan().last_kernel()["name"].startswith("systolic_q%d_l7_" % (fsize // fshift)), p.plan().last_kernel()
+    pw = lws_amd.lws(2048, 512, L=7)
+    pw.batch_lws(np.ones((3, 1025)), thresholds=[0.0])
+    assert pw.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
 
 
 @pytest.mark.parametrize("fsize,fshift,L,T", [(64, 16, 4, 70), (1024, 256, 4, 37), (1024, 512, 2, 37), (2048, 512, 4, 40),
@@ -247,6 +262,7 @@ def test_what_still_needs_the_generic_engine():
                                                     (2048, 512, 3, 150, 20), (64, 8, 2, 300, 11), (1024, 128, 3, 200, 9),
                                                     (1000, 250, 2, 200, 30), (60, 15, 3, 300, 50), (1004, 502, 5, 260, 16),
                                                     (2004, 501, 3, 150, 20), (4096, 1024, 2, 300, 9), (3000, 750, 3, 270, 7)])
+# (L = 7 build: test_stencils_of_half_width_6_and_7 and tests/test_gpu_robust.py)
 def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, iters, monkeypatch):
     """When there are fewer spectrograms than CUs the passes over HBM are dealt to several workgroups per spectrogram
     that hand the skewed state to each other through HBM; the result must be bit-identical to one workgroup doing all
@@ -316,6 +332,31 @@ def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
     for mask, pair in ((0x40, 1), (0x80, 1), (0x0f, 3), (0x30, 7)):
         monkeypatch.setenv("LWS_SYSTOLIC_STRESS", str(mask | (pair << 16)))
         assert np.array_equal(p.plan().batch(S, thr), ref), (mask, pair)
+
+
+def test_l7_build_workgroups_and_stalls(monkeypatch):
+    """The build for L = 6, 7 (frames 16 steps apart): several workgroups per spectrogram and stalled waves change no bit."""
+    rng = np.random.default_rng(7)
+    for fsize, fshift, T in ((1024, 256, 200), (100, 25, 150)):
+        F = fsize // 2 + 1
+        S = np.abs(rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))).astype(np.complex128)
+        thr = lws_amd.get_thresholds(11, 3.0, 0.15, 1)
+        p = lws_amd.lws(fsize, fshift, L=7)
+        monkeypatch.setenv("LWS_SYSTOLIC_NWG", "1")
+        ref = p.plan().batch(S, thr)
+        assert "_l7_" in p.plan().last_kernel()["name"]
+        for role in range(4):
+            for pair in (1, 3, 5, 7):
+                monkeypatch.setenv("LWS_SYSTOLIC_STRESS", str((1 << role) | (pair << 16)))
+                assert np.array_equal(p.plan().batch(S, thr), ref), (role, pair)
+        monkeypatch.delenv("LWS_SYSTOLIC_STRESS")
+        for nwg in ("2", "3"):
+            monkeypatch.setenv("LWS_SYSTOLIC_NWG", nwg)
+            assert np.array_equal(p.plan().batch(S, thr), ref), nwg
+        monkeypatch.setenv("LWS_SYSTOLIC_STRESS", str(0x8 | (3 << 16)))
+        assert np.array_equal(p.plan().batch(S, thr), ref)
+        monkeypatch.delenv("LWS_SYSTOLIC_STRESS")
+        monkeypatch.delenv("LWS_SYSTOLIC_NWG")
 
 
 # ----------------------------------------------------------------------------- direct device I/O
