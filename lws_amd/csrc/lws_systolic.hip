@@ -409,6 +409,7 @@ struct LaneCtx {
     bool is_start, is_end, live;                 // this block (8 bins of one frame); is_end: the frame's end block
     bool is_end1;                                // the block before the end block (RE != 0 builds)
     bool nxt_start, nxt_end, nxt_live;           // the following block (possibly the next frame of the lane)
+    bool nxt_end1;
     float thr, nxt_thr;
     // image cells: byte offset from the lane's own origin ob[m] to the pseudo-lane's, minus what the compile-time offset
     // of the neighbour frame DR adds -- for the lane at the start (lo: PLL) / end (hi: PLR) of its frame; zero for every
@@ -1072,7 +1073,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
 // Q = 8: one pair of bins of a HELPER lane (helper H of its slot): the taps of the neighbour frames row_owner() gives it,
 // for the pair the slot's main wave reaches help_ahead(H) steps from now; phases (4,5), (6,7), then (0,1), (2,3) of the lane's
 // next block.  Same windows, same order of operations per frame pair as compute_pair; no frame of a helper is late.
-template <int Q, int L, uint64_t MASK, int PA, int H>
+template <int Q, int L, uint64_t MASK, int PA, int H, int RE = 0>
 __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx, QuadCarry<L> &qc) {
     constexpr int AHEAD = help_ahead(H);
     constexpr int PH = (PA + AHEAD) & 7, CO = PA + AHEAD - PH;   // phase of the first bin; clock of its block
@@ -1092,8 +1093,8 @@ __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx,
                 static_assert(SKEW * R - L - 3 - AHEAD >= 1 && LAG - SKEW * R - L - 3 - AHEAD >= 1, "helper runs too far ahead");
                 float2 tu[2 * L + 6], td[2 * L + 6];
                 constexpr uint32_t kmask = (uint32_t)((MASK >> (R * (L + 1))) & ((1ull << (L + 1)) - 1ull));
-                load_cells<PH0, -R, L, 0, L + 3, kmask, CO>(cx, tu);
-                load_cells<PH0, R, L, 0, L + 3, kmask, CO>(cx, td);
+                load_cells<PH0, -R, L, 0, L + 3, kmask, CO, RE>(cx, tu);
+                load_cells<PH0, R, L, 0, L + 3, kmask, CO, RE>(cx, td);
                 rows_sum<Q, L, MASK, PH, R, 0>(a, tu, td, p3, accA);
                 rows_sum<Q, L, MASK, PH + 1, R, 1>(a, tu, td, p3, accB);
                 rows_sum_ahead<Q, L, MASK, PH + 2, R, 2>(a, tu, td, p3, qc.accA, qc);
@@ -1229,7 +1230,10 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
 // much as a helper wave's frame pair, in the very pair in which the helpers sum.  Lane slot*Q + r sums the taps of frames
 // m-+r (r = 0: the frame's own bins C-k and their images), the Q partial sums are combined across the lanes, lane r = 0
 // re-projects and stores.  (Weights from the LDS table: the row is a per-lane index.)
-template <int Q, int L, bool MULTI, bool H16>
+// RE = C mod 8 != 0 (frames that end inside a block, see service_nyquist): the call comes in the pair that starts at phase RE,
+// and bin C is then not a multiple of Q: lane r's weights carry the twiddle exp(2j pi RE r / 8) = j^(RE r / 2) -- whole quarter
+// turns, RE being even -- applied to each weight as it is fetched (the frame offset, hence the turn, is a per-lane value here).
+template <int Q, int L, bool MULTI, bool H16, int RE = 0>
 __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceState &sv, int lane, int t0, int wg, int n_eff,
                                                      int n_groups, const float *thr_eff, void *state_nyq_b,
                                                      const void *amp_nyq_b) {
@@ -1241,17 +1245,17 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
     const bool is_nyq_lane = lane < NSLOTS * Q;
     const bool is_nyq_loader = lane == NSLOTS * Q;
     const int v0 = t0 - (is_nyq_lane ? (slot + 1) * LAG : 0);
-    const int vrow = (v0 - C) / SKEW;            // virtual frame whose Nyquist bin is due now (SKEW | v0 - C)
+    const int vrow = (v0 + RE - C) / SKEW;       // virtual frame whose Nyquist bin is due now (SKEW | v0 + RE - C)
     const int rho = vrow & (ROWL - 1), kap = vrow >> ROWL_SHIFT;
     const int gl = kap / Kr, k_ = kap - gl * Kr;
     const int g = MULTI ? gl * a.nwg + wg : gl;
     const int me = k_ * ROWL + rho;
     const int j = g * NSLOTS + (is_nyq_lane ? slot : -1);
-    const bool valid = (v0 - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
+    const bool valid = (v0 + RE - C >= 0) && (me < a.Tp) && (is_nyq_lane ? (j < n_eff) : (is_nyq_loader && g < n_groups));
     if (is_nyq_loader) {
         const float2 nin = raw_value<H16>(sv.nyq_in_next);
         lds_write(NYQ_OFF + rho * 8, nin);
-        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, nin);
+        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, nin);
         const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
         if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2<H16>(state_nyq_b, me1);
@@ -1266,23 +1270,43 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
         // blocks before / after the block of time -k
         const int bn = set_new + ((ablk - r - 1) & (NBLK - 1)) * BLK_BYTES + (ln + HALO) * LANE_B;
         const int bo = set_old + ((ablk + r - 1) & (NBLK - 1)) * BLK_BYTES + (lo + HALO) * LANE_B;
+        // (RE != 0: the taps k <= RE lie in the block of the frame end itself, one ring block later)
+        const int bn1 = set_new + ((ablk - r) & (NBLK - 1)) * BLK_BYTES + (ln + HALO) * LANE_B;
+        const int bo1 = set_old + ((ablk + r) & (NBLK - 1)) * BLK_BYTES + (lo + HALO) * LANE_B;
+        const int rot = RE ? ((RE * r) >> 1) & 3 : 0;        // quarter turns of this lane's weights
+        const float sg = (rot & 1) ? -1.f : 1.f;             // b = um +- dp, c = dm +- up: minus for an odd quarter turn
+        auto turned = [&](wp_t w) -> wp_t {
+            if constexpr (RE == 0) return w;
+            float wr = __uint_as_float((unsigned)(w & 0xffffffffull)), wi = __uint_as_float((unsigned)(w >> 32));
+            const float t = wr;
+            wr = (rot & 1) ? -wi : wr; wi = (rot & 1) ? t : wi;
+            wr = (rot & 2) ? -wr : wr; wi = (rot & 2) ? -wi : wi;
+            return ((unsigned long long)__float_as_uint(wi) << 32) | __float_as_uint(wr);
+        };
         const int nn = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln * 8, no = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
         const bool centre = r == 0;                 // its "frame m+r" terms are the images: dn = 0 below gives b = up, c = conj(up)
         const float2 zero = make_float2(0.f, 0.f);
         float2 acc = zero;
         {
             const float2 un = lds_read(nn), dn = lds_read(no);
-            pair_rot<0>(acc, nyq_weight(a, r * K1), centre ? zero : un, centre ? zero : dn);
+            pair_rot<0>(acc, turned(nyq_weight(a, r * K1)), centre ? zero : un, centre ? zero : dn);
         }
         static_for<L>([&](auto ik) {
-            constexpr int k = decltype(ik)::value + 1, within = 8 - k;
+            constexpr int k = decltype(ik)::value + 1, within = (RE - k) & 7;   // time RE - k of the block, or of the one before
+            constexpr bool same_block = RE - k >= 0;
             constexpr int off = (within >> 1) * PAIR_BYTES + (within & 1) * 8;
-            const float2 up = lds_read(bn + off);
-            float2 dn = lds_read(bo + off);
+            const float2 up = lds_read((same_block ? bn1 : bn) + off);
+            float2 dn = lds_read((same_block ? bo1 : bo) + off);
             dn = centre ? zero : dn;
-            const float2 bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
-            const float2 csum = make_float2(dn.x + up.x, dn.y - up.y);   // dn + conj(up)
-            pair_rot<0>(acc, nyq_weight(a, r * K1 + k), bsum, csum);
+            float2 bsum, csum;
+            if constexpr (RE == 0) {
+                bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
+                csum = make_float2(dn.x + up.x, dn.y - up.y);   // dn + conj(up)
+            } else {
+                bsum = make_float2(up.x + sg * dn.x, up.y - sg * dn.y);   // up +- conj(dn)
+                csum = make_float2(dn.x + sg * up.x, dn.y - sg * up.y);   // dn +- conj(up)
+            }
+            pair_rot<0>(acc, turned(nyq_weight(a, r * K1 + k)), bsum, csum);
         });
         auto dpp = [](float x, auto ctrl) {
             return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
@@ -1300,8 +1324,8 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
         const float2 out = project(acc, target, active, old);
         if (centre) {
             lds_write(nn, out);
-            lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B, out);
-            if ((slot == NSLOTS - 1) && (v0 - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2<H16>(state_nyq_b, me, out, MULTI);
+            lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, out);
+            if ((slot == NSLOTS - 1) && (v0 + RE - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2<H16>(state_nyq_b, me, out, MULTI);
         }
         const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
@@ -1314,7 +1338,7 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
 // RE = (F-1) mod 8 (see th0)
 template <int Q, int L, uint64_t MASK, bool MULTI, bool H16, int RE = 0>
 __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(SysArgs a_in) {
-    static_assert((RE & 1) == 0 && RE >= 0 && RE < 8 && (RE == 0 || !LWS_Q8), "frame end phase");
+    static_assert((RE & 1) == 0 && RE >= 0 && RE < 8, "frame end phase");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a_in.gate != nullptr && __hip_atomic_load(a_in.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int nwg = MULTI ? a_in.nwg : 1;
@@ -1588,7 +1612,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 const BlockInfo cur = nxt_bi;
                 nxt_bi = block_info(v0 + 8);
                 cx.live = cur.live; cx.is_start = cur.start; cx.is_end = cur.end; cx.is_end1 = cur.end1; cx.thr = cur.thr;
-                cx.nxt_live = nxt_bi.live; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end;
+                cx.nxt_live = nxt_bi.live; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end; cx.nxt_end1 = nxt_bi.end1;
                 cx.nxt_thr = nxt_bi.thr;
             }
             cx.lane8 = rl * 8;
@@ -1663,9 +1687,10 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                             for (int d = 0; d < NDR; ++d) {
                                 cx.wlo[d] = cx.nxt_start ? dlo[d] : 0;
                                 cx.whi[d] = cx.nxt_end ? dlo[d] + LANE_B : 0;
+                                if constexpr (RE != 0) cx.whi1[d] = cx.nxt_end1 ? dlo[d] + LANE_B : 0;
                             }
                         }
-                        if constexpr (ROLE >= 1 && ROLE <= NHELP) helper_pair<Q, L, MASK, PA, ROLE>(a, cx, qc);
+                        if constexpr (ROLE >= 1 && ROLE <= NHELP) helper_pair<Q, L, MASK, PA, ROLE, RE>(a, cx, qc);
                     }
                 }
                 if (a.stress != 0 && ((a.stress >> wave) & 1) && PA + 1 == ((a.stress >> 16) & 7)) {   // test hook, see SysArgs (pairs 1, 3, 5, 7)
@@ -1686,8 +1711,8 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                     LWS_SETPRIO(3);   // (and back to 0 with everybody else after the publish below)
                     // Nyquist bins of the frames that ended at phase 0 of this block (every slot has published bin C-1 now)
 #if LWS_Q8
-                    if (PA == 0 && hf == 0)
-                        service_nyquist_rows<Q, L, MULTI, H16>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
+                    if (PA == RE && hf == 0)
+                        service_nyquist_rows<Q, L, MULTI, H16, RE>(a, sv, lane, t0, wg, n_eff, n_groups, thr_eff, state_nyq_b, amp_nyq_b);
 #else
                     constexpr bool nyq_split = (RE & 2) != 0;   // frames ending in the second pair of a quad: see service_nyquist
                     if (PA == RE && hf == 0)   // (RE != 0: the frames end at phase RE of the block)
@@ -2155,7 +2180,11 @@ template <int Q, int L, uint64_t MASK, int RE> hipError_t launch_kr(const SysArg
 }
 // one build of the kernel per phase of the block at which the frames end, (F-1) mod 8 (see th0)
 template <int Q, int L, uint64_t MASK> hipError_t launch_k(const SysArgs &a, int grid, bool h16, hipStream_t s) {
-#if !LWS_Q8
+#if LWS_Q8
+    // (the hop is an eighth of the frame size: F-1 is a multiple of 4, the frames end at phase 0 or 4)
+    if ((a.C & 7) == 4) return launch_kr<Q, L, MASK, 4>(a, grid, h16, s);
+    if ((a.C & 7) != 0) return hipErrorInvalidValue;
+#else
     switch (a.C & 7) {
     case 2: return launch_kr<Q, L, MASK, 2>(a, grid, h16, s);
     case 4: return launch_kr<Q, L, MASK, 4>(a, grid, h16, s);
@@ -2205,7 +2234,7 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
 #endif
     // F-1 even (a pair of bins never straddles bin C); not a multiple of 8: the frames end inside a block (th0), and the block
     // before that one must not be the frame's first
-    if ((C & 1) != 0 || C > ROWP || C < 16 || (C % 8 != 0 && (LWS_Q8 || C < 24)) || (LWS_L7 && C > 512)) return hipSuccess;
+    if ((C & 1) != 0 || C > ROWP || C < 16 || (C % 8 != 0 && (C < 24 || (LWS_Q8 && C % 8 != 4))) || (LWS_L7 && C > 512)) return hipSuccess;
     if ((Q - 1) * SKEW + L + 1 > LAG) return hipSuccess;
     const int K1 = L + 1;
     for (int i = 0; i < 3; ++i) {

@@ -143,6 +143,17 @@ def test_q8_narrower_stencils(oracle, fsize, fshift, L, T):
     assert p.plan().last_kernel()["name"].startswith("systolic_q8_l5_"), p.plan().last_kernel()
 
 
+@pytest.mark.parametrize("fsize,fshift,T,n_it", [(1000, 125, 37, 4), (1000, 125, 140, 3), (1016, 127, 70, 5), (104, 13, 131, 4), (56, 7, 70, 3),
+                                                 (1000, 125, 64, 2)])
+def test_q8_frames_that_end_inside_a_block(oracle, fsize, fshift, T, n_it):
+    """Q = 8 with F - 1 = 4 mod 8 (`lws(1000, 125)`): the frames end at phase 4 of a block; the Nyquist lanes (one per sweep slot and
+    frame offset) fetch across two ring blocks and turn their weights by exp(2 pi j 4 r / 8) = (-1)^r."""
+    run_case(oracle, fsize, fshift, T, np.linspace(0.6, 0.0, n_it), seed=fsize + T, B=2, scale=[1.0, 40.0])
+    p = lws_amd.lws(fsize, fshift)
+    p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
+    assert p.plan().last_kernel()["name"] == "systolic_q8_l5_hann", p.plan().last_kernel()
+
+
 def test_dropped_sweeps_and_mixed_schedules(oracle):
     """Thresholds above the largest magnitude are dropped per spectrogram; spectrograms of one launch have different
     scales, hence different sets of dropped sweeps and different scaled thresholds."""
@@ -261,7 +272,7 @@ def test_what_still_needs_the_generic_engine():
                                                     (1024, 256, 9, 300, 45), (1024, 512, 5, 260, 16),
                                                     (2048, 512, 3, 150, 20), (64, 8, 2, 300, 11), (1024, 128, 3, 200, 9),
                                                     (1000, 250, 2, 200, 30), (60, 15, 3, 300, 50), (1004, 502, 5, 260, 16),
-                                                    (2004, 501, 3, 150, 20), (4096, 1024, 2, 300, 9), (3000, 750, 3, 270, 7)])
+                                                    (2004, 501, 3, 150, 20), (4096, 1024, 2, 300, 9), (3000, 750, 3, 270, 7), (1000, 125, 2, 200, 9)])
 # (L = 7 build: test_stencils_of_half_width_6_and_7 and tests/test_gpu_robust.py)
 def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, iters, monkeypatch):
     """When there are fewer spectrograms than CUs the passes over HBM are dealt to several workgroups per spectrogram
@@ -310,7 +321,7 @@ def test_workgroup_sharing_randomised(monkeypatch):
 
 @pytest.mark.parametrize("fsize,fshift,T", [(1024, 256, 150), (2048, 512, 150), (2048, 512, 100), (1024, 128, 150), (64, 8, 70),
                                              (1000, 250, 150), (1012, 253, 150), (2004, 501, 100), (4096, 1024, 60),
-                                             (512, 128, 150), (256, 64, 150)])
+                                             (512, 128, 150), (256, 64, 150), (1000, 125, 150)])
 def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
     """The waves of a workgroup synchronise through progress counters in LDS, not barriers.  LWS_SYSTOLIC_STRESS stalls chosen
     waves (role mask) for ~10 us before a chosen pair of every block -- far longer than a pair takes -- so any read that is
