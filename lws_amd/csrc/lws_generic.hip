@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(1024) k_skew_batch(GenericArgs<real> a, typena
     using C = typename cx<real>::type;
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int F = a.F, T = a.T, L = a.L, Q = a.Q, Qp = a.Qp;
-    const int Np = F + 2 * L;
+    [[maybe_unused]] const int Np = F + 2 * L;
     C *SW = sw_all + (size_t)b * rows * NL;
     const real *AW = aw_all + (size_t)b * rows * NL;
     const real *thr = a.thr + (size_t)b * a.n_thr;

@@ -1486,7 +1486,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const bool is_compute = wave < NCOMPUTE;
     const bool is_helper = NHELP > 0 && wave >= NCOMPUTE + WPS;
     const bool is_service = !is_compute && !is_helper;
-    const int helper_no = is_helper ? (wave - NCOMPUTE - WPS) % (NHELP > 0 ? NHELP : 1) + 1 : 0;   // 1 .. NHELP
+    [[maybe_unused]] const int helper_no = is_helper ? (wave - NCOMPUTE - WPS) % (NHELP > 0 ? NHELP : 1) + 1 : 0;   // 1 .. NHELP
     // slot0: the wave's (first) sweep slot, wave-uniform; slot: the lane's (SPW > 1: slot0 + sub for a compute wave)
     const int slot0 = is_compute ? (wave / WPS) * SPW : (is_helper ? (wave - NCOMPUTE - WPS) / (NHELP > 0 ? NHELP : 1) : NSLOTS);
     const int slot = (SPW > 1 && is_compute) ? slot0 + sub : slot0;
@@ -2195,7 +2195,7 @@ template <int Q, int L, uint64_t MASK> hipError_t launch_k(const SysArgs &a, int
     return launch_kr<Q, L, MASK, 0>(a, grid, h16, s);
 }
 
-#if !LWS_Q8
+#if !LWS_Q8 && !LWS_L7
 // mask bit r*(L+1)+k set <=> |W[0][r][k]| > 1e-12.  Default sqrt-Hann windows give these patterns (L = 5):
 constexpr uint64_t MASK_Q4_L5_DEFAULT = 0b111111'010111'111111'000011u;  // (r=3 | r=2 | r=1 | r=0), 6 bits each, bit k: r=0:{0,1} r=1:all r=2:{0,1,2,4} r=3:all
 constexpr uint64_t MASK_Q2_L5_DEFAULT = 0b010111'000011u;                            // r=0:{0,1} r=1:{0,1,2,4}
