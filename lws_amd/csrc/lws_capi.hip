@@ -23,6 +23,11 @@
 #include <mutex>
 #include <thread>
 #include <sys/mman.h>
+#ifdef MADV_POPULATE_WRITE
+#define LWS_MADV_POPULATE_WRITE MADV_POPULATE_WRITE
+#else
+#define LWS_MADV_POPULATE_WRITE 23   // Linux 5.14; older kernels answer EINVAL and the pages are faulted in by their first use
+#endif
 #include "lws_nofuture.h"
 
 namespace {
@@ -669,21 +674,26 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
         // while the device works on chunk c: the next chunk on its way up (its pinned buffer is free once chunk c-1 has been
         // uploaded), the previous one on its way out (once it has arrived)
         mark("enqueued", c);
-        if (c == 0 && static_cast<const void *>(S_out) != static_cast<const void *>(S_in)) {
+        // (after the second chunk is on its way, so that the device never waits for this: it takes ~10 ms for 1 GB)
+        if (c == std::min(1, nch - 1) && static_cast<const void *>(S_out) != static_cast<const void *>(S_in)) {
             // A result array fresh from the allocator has no pages yet: 256K first-touch faults for 1 GB, which the widening
             // passes would take one by one on the critical path (and 32 threads faulting on one address space queue up in the
-            // kernel: 8.5 ms for the last chunk alone).  Populate it now, eight ways, while the device works on chunk 0.
+            // kernel: 8.5 ms for the last chunk alone).  Populate it now, eight ways, while the device works on the first chunks.
             char *lo = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(S_out) + 4095) & ~(uintptr_t)4095);
             char *hi = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(S_out) + total * 16) & ~(uintptr_t)4095);
             const int ways = std::min(8, pool.size());
+            std::atomic<bool> populate_fallback{false};
             if (hi > lo && env_int("LWS_HOST_PREFAULT", 1))
                 pool.run(ways, [&](int i) {
                     const size_t pages = (size_t)(hi - lo) >> 12, a = pages * i / ways, b = pages * (i + 1) / ways;
-                    if (b > a && madvise(lo + (a << 12), (b - a) << 12, 23 /* MADV_POPULATE_WRITE, Linux 5.14 */) != 0) {
-                        // older kernel: nothing is lost but the head start (the passes fault the pages in themselves)
+                    if (b > a && madvise(lo + (a << 12), (b - a) << 12, LWS_MADV_POPULATE_WRITE) != 0) {
+                        // (older kernel, or a mapping it refuses) touch the pages instead: the array is all output -- nothing of
+                        // it is read before the widening passes overwrite every element
+                        for (size_t pg = a; pg < b; ++pg) *reinterpret_cast<volatile char *>(lo + (pg << 12)) = 0;
+                        populate_fallback.store(true, std::memory_order_relaxed);
                     }
                 });
-            mark("result pages populated", 0);
+            mark(populate_fallback.load() ? "result pages touched (madvise refused)" : "result pages populated", 0);
         }
         if (c + 1 < nch && c >= 1) HIP_TRY(hipEventSynchronize(hp.ev_up[(c + 1) & 1]));
         if (c >= 1) HIP_TRY(hipEventSynchronize(hp.ev_down[(c - 1) & 1]));
