@@ -53,6 +53,24 @@ def test_fp16_storage_structure_and_tolerance(oracle, fsize, fshift, T):
         assert r32["rel_l2"] < 3e-3
 
 
+@pytest.mark.parametrize("fsize,fshift,L,T", [(1024, 256, 7, 40), (1000, 250, 4, 40), (1000, 125, 5, 40), (512, 128, 3, 70), (4096, 1024, 2, 20)])
+def test_fp16_storage_on_the_other_builds(oracle, fsize, fshift, L, T):
+    """fp16 storage with the stencil widths / frame ends / frame sizes that got their systolic builds in round 3 (L = 7, even L,
+    Q = 8 with F - 1 = 4 mod 8, short and extra wide frames): same bounds as above."""
+    rng = np.random.default_rng(fsize + T + L)
+    F = fsize // 2 + 1
+    S = rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))
+    thr = np.array([1.2, 0.6, 0.3, 0.1, 0.0, 0.0, 0.0])
+    p16 = lws_amd.lws(fsize, fshift, L=L, storage="fp16")
+    out16 = p16.plan().batch(S, thr)
+    name = p16.plan().last_kernel()["name"]
+    assert name.startswith("systolic") and name.endswith("_f16"), name
+    for b in range(2):
+        ref = oracle.batch_lws(S[b], p16.W, thr)
+        r16 = report(out16[b], ref, np.abs(S[b]))
+        assert r16["mag"] < 2e-6 and r16["median"] < 2e-3 and r16["rel_l2"] < 0.3, r16
+
+
 def test_never_updated_bins_are_bit_identical_and_noop_schedules():
     rng = np.random.default_rng(3)
     p = lws_amd.lws(1024, 256, storage="fp16")
