@@ -978,9 +978,10 @@ int lws_plan_reserve(lws_plan *p, int B, int T, int max_iters) {
     if (!p->fp64) {   // host entry points of an fp32 plan: pinned buffers, chunk buffers and streams of the pipeline, so that the
                       // first call does not pay for them (hipHostMalloc of 4 x 128 MB: ~50 ms)
         const size_t per = (size_t)T * p->F;
-        // (sized for a call with a one-workgroup-per-spectrogram stage: the larger chunks)
-        const int bc = host_chunk(per, B, cu_count(p->device), true);
-        if ((rc = p->pipe.ensure((size_t)bc * per * sizeof(float2), bc < B ? 2 : 1))) return rc;
+        // (both chunkings: a call that is one batch stage, and one with a one-workgroup-per-spectrogram stage -- larger chunks)
+        const int bc0 = host_chunk(per, B, cu_count(p->device), false), bc1 = host_chunk(per, B, cu_count(p->device), true);
+        if ((rc = p->pipe.ensure((size_t)bc0 * per * sizeof(float2), bc0 < B ? 2 : 1))) return rc;
+        if ((rc = p->pipe.ensure((size_t)bc1 * per * sizeof(float2), bc1 < B ? 2 : 1))) return rc;
     }
     if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
     if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;

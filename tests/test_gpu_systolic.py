@@ -370,6 +370,21 @@ def test_l7_build_workgroups_and_stalls(monkeypatch):
         monkeypatch.delenv("LWS_SYSTOLIC_NWG")
 
 
+@pytest.mark.parametrize("fsize,fshift,T", [(2048, 512, 140), (1024, 256, 100), (512, 128, 100)])
+def test_role_maps_change_nothing(fsize, fshift, T, monkeypatch):
+    """Which hardware wave takes which role (LWS_SYSTOLIC_ROLEMAP: a comparison hook; the wide build's default map puts the two halves
+    of a slot on one SIMD and both service waves on the fourth) is scheduling only: identical bits for every map."""
+    rng = np.random.default_rng(fsize)
+    F = fsize // 2 + 1
+    S = np.abs(rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))).astype(np.complex128)
+    thr = lws_amd.get_thresholds(12, 3.0, 0.15, 1)
+    p = lws_amd.lws(fsize, fshift)
+    ref = p.plan().batch(S, thr)
+    for m in ("1", "2", "3"):
+        monkeypatch.setenv("LWS_SYSTOLIC_ROLEMAP", m)
+        assert np.array_equal(p.plan().batch(S, thr), ref), m
+
+
 # ----------------------------------------------------------------------------- direct device I/O
 @pytest.mark.parametrize("fsize,fshift,B,T", [(64, 16, 3, 77), (1024, 256, 2, 130), (1024, 512, 2, 65), (2048, 512, 2, 40),
                                               (1024, 128, 2, 70), (1000, 250, 2, 130), (60, 15, 3, 77), (2004, 501, 2, 40),
