@@ -1553,12 +1553,10 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     }
     struct BlockInfo { bool live, start, end, end1; float thr; };
     auto block_info = [&](int vblock0) {      // vblock0: the clock of the wave's first slot at phase 0 of the block (wave-uniform)
-        BlockInfo bi;
-        bi.live = bi.start = bi.end = bi.end1 = false; bi.thr = 0.f;
+        // the round bookkeeping of each of the wave's slots: wave-uniform, once per round
         static_for<SPW>([&](auto iq) {
             constexpr int q = decltype(iq)::value;
-            const int vblock = vblock0 - q * LAG;      // slot slot0 + q trails slot0 by q lags
-            const int rem = vblock & (ROWP - 1), ks = vblock >> ROWP_SHIFT;
+            const int ks = (vblock0 - q * LAG) >> ROWP_SHIFT;      // slot slot0 + q trails slot0 by q lags
             if (ks != ks_state[q]) {                 // once per round: ROWL blocks
                 ks_state[q] = ks;
                 rprev[q] = rcur[q];
@@ -1569,21 +1567,29 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 rcur[q].meb = rcur[q].k * ROWL;
                 rcur[q].thr = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(thr_eff[rcur[q].okj ? j : 0])));
             }
-            const bool here = SKEW * rl <= rem;                      // this lane's frame of the current round has started
-            const int cbase = (rem - SKEW * rl) & (ROWP - 1);
-            const int me = (here ? rcur[q].meb : rprev[q].meb) + rl;
-            const bool valid = (here ? rcur[q].okj : rprev[q].okj) && (me < a.Tp);
-            const bool mine = SPW == 1 || sub == q;
-            BlockInfo b1;
-            b1.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
-            b1.start = (cbase == 0);
-            b1.end = (cbase == C - th0(RE));
-            b1.end1 = (RE != 0) && (cbase == C - th1(RE));
-            b1.thr = here ? rcur[q].thr : rprev[q].thr;
-            if constexpr (SPW == 1) bi = b1;
-            else { bi.live = mine ? b1.live : bi.live; bi.start = mine ? b1.start : bi.start; bi.end = mine ? b1.end : bi.end;
-                   bi.end1 = mine ? b1.end1 : bi.end1; bi.thr = mine ? b1.thr : bi.thr; }
         });
+        // the lane's own slot (SPW > 1: picked from the wave's SPW sets of round state), then its place in the block
+        int meb_c = rcur[0].meb, meb_p = rprev[0].meb;
+        bool ok_c = rcur[0].okj, ok_p = rprev[0].okj;
+        float thr_c = rcur[0].thr, thr_p = rprev[0].thr;
+        static_for<SPW - 1>([&](auto iq) {
+            constexpr int q = decltype(iq)::value + 1;
+            const bool mine = sub == q;
+            meb_c = mine ? rcur[q].meb : meb_c; meb_p = mine ? rprev[q].meb : meb_p;
+            ok_c = mine ? rcur[q].okj : ok_c; ok_p = mine ? rprev[q].okj : ok_p;
+            thr_c = mine ? rcur[q].thr : thr_c; thr_p = mine ? rprev[q].thr : thr_p;
+        });
+        const int rem = (vblock0 - (SPW > 1 ? sub * LAG : 0)) & (ROWP - 1);
+        const bool here = SKEW * rl <= rem;                      // this lane's frame of the current round has started
+        const int cbase = (rem - SKEW * rl) & (ROWP - 1);
+        const int me = (here ? meb_c : meb_p) + rl;
+        const bool valid = (here ? ok_c : ok_p) && (me < a.Tp);
+        BlockInfo bi;
+        bi.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
+        bi.start = (cbase == 0);
+        bi.end = (cbase == C - th0(RE));
+        bi.end1 = (RE != 0) && (cbase == C - th1(RE));
+        bi.thr = here ? thr_c : thr_p;
         return bi;
     };
     int dlo[NDR];   // per-lane constants of the image-cell offsets: (PLL - HALO - DR - lane) * 16
