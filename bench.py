@@ -13,6 +13,7 @@ the launch stream, algorithmic bytes, fraction of 8 TB/s) and the property check
     2-T1024  the literal north-star shape 1024 x 513 (256 spectrograms of 1024 frames)
     4shard   config 4's per-GPU shard: 1024 spectrograms of 500 x 513
     3        run_lws(mode='music'): no-future -> online -> batch, stage by stage
+    3-b1024  the same on 1024 spectrograms (the one-workgroup-per-spectrogram stages then run two per CU)
     5        64 clips of 56 250 frames x 1025 bins (2048-point STFT), 200 sweeps
     5-f16    the same with fp16-complex storage (fp32 arithmetic)
     2-q2 / 2-q8   config 2's volume at hop 512 (Q = 2, the reference's LWSQ2) and hop 128 (Q = 8, LWSanyQ)
@@ -375,7 +376,7 @@ def main():
     elif args.extras is not None:
         wanted = [x for x in args.extras.split(",") if x]
     elif world == 1 and args.config == "2":
-        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-f501", "2-f257", "4shard", "3", "host_api", "1", "5", "5-f16"]
+        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-f501", "2-f257", "4shard", "3", "3-b1024", "host_api", "1", "5", "5-f16"]
     else:
         wanted = ["4shard"] if args.config == "2" else []
     if args.no_default_schedule and "2-default" in wanted:
@@ -396,6 +397,10 @@ def main():
                 del keep
             elif name == "3":
                 cfgs["3"] = run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, args.force_generic)
+            elif name == "3-b1024":
+                # config 3's pipeline on 1024 spectrograms: the no-future and online stages run one workgroup per spectrogram, two of
+                # them per CU side by side when the batch is larger than the chip
+                cfgs["3-b1024"] = run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, args.force_generic, B=1024)
             elif name == "host_api":
                 cfgs["host_api"] = run_host_api(torch, lws_amd, dev, local_rank)
             elif name == "1":
@@ -491,7 +496,7 @@ def run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, force_g
             wall = 1e3 * (time.perf_counter() - t0)
             act, nominal = work[name]
             alg = 16.0 * act + 4.0 * nominal
-            traffic, tsrc = load_traffic(info["name"], "3", stage=name)
+            traffic, tsrc = load_traffic(info["name"], "3" if B == 256 else "3-b%d" % B, stage=name)
             Wst = pm.W_ai if name == "nofuture" else pm.W      # (the online stage mixes W, W_ai, W_af: priced with W)
             c3[name] = {"wall_ms": wall, "kernel_ms": info["ms"], "kernel": info["name"], "bin_sweeps": nominal, "active_bin_sweeps": act,
                         # batch: vector-ALU issue; no-future / online: the dependent chain of a step (barrier rounds, LDS round

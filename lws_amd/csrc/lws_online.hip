@@ -1516,6 +1516,12 @@ Shape4 shape4_of(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
     sh.DS = DS;
     const int window = window_of(DS);
     r.NWR = window + 1 <= nwr_max ? window + 1 : window;
+    // two workgroups fit a CU (half of its LDS each) without the spare ring frame but not with it: drop it -- batches of more
+    // spectrograms than CUs then run two chains per CU side by side (LWS_ONLINE_SPARE_FRAME=1 keeps it: comparison runs)
+    {
+        const char *ev = getenv("LWS_ONLINE_SPARE_FRAME");
+        if (r.NWR == window + 1 && lds_of(window + 1) > 80 * 1024 && lds_of(window) <= 80 * 1024 && !(ev && ev[0] == '1')) r.NWR = window;
+    }
     sh.lds = lds_of(r.NWR);
     if ((double)DS * T * per + (double)SKS * T + NU > 1.0e9) return r;
     sh.ok = true;
