@@ -144,6 +144,11 @@ int lws_stream_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stre
 /* Name of the update kernel the last call dispatched ("generic_fp32", "systolic_q4", ...). */
 const char *lws_last_kernel_name(lws_plan *plan);
 
+/* Which stage of this plan's calls ("batch", "no-future", "online") last ran on the order-exact generic engine -- 20-40x slower than
+ * the kernels built for the common shapes -- or "" if none ever has.  (lws_last_kernel_name only names the LAST stage of a
+ * run_lws pipeline.) */
+const char *lws_generic_stage(lws_plan *plan);
+
 /* ---- the steps either side of the path, on the device (lws.pyx:43-144; float32, any even frame size N in [32, 4096]
  *      -- an odd factor times a power of two: radix-2 stages and one stage of odd-point DFTs --, fftsize == fsize).  Windows are host arrays of N doubles, already normalised the way the caller
  *      wants them (class lws: awin and synthwin(awin, fshift)).  perfectrec as in lws.pyx:55-67,130-137. ---- */

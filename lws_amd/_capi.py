@@ -29,7 +29,7 @@ EXPORTS = (
     "lws_hip_version", "lws_last_error", "lws_device_count", "lws_plan_create", "lws_plan_destroy",
     "lws_batch_lws", "lws_nofuture_lws", "lws_online_lws", "lws_run_lws", "lws_batch_lws_dev",
     "lws_nofuture_lws_dev", "lws_online_lws_dev", "lws_residual_dev", "lws_last_kernel_time",
-    "lws_last_kernel_name", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev",
+    "lws_last_kernel_name", "lws_generic_stage", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev",
     "lws_consistency_dev", "lws_hann", "lws_synthwin", "lws_weights_shape", "lws_create_weights",
     "lws_build_asymmetric_windows", "lws_get_thresholds", "lws_plan_create_from_windows", "lws_stream_copy",
     "lws_run_lws_dev", "lws_plan_reserve", "lws_residual", "lws_multi_plan_create", "lws_multi_plan_destroy",
@@ -93,6 +93,8 @@ def load():
     lib.lws_last_kernel_name.argtypes = [vp]
     lib.lws_stream_copy.argtypes = [vp, vp, C.c_size_t, vp]
     lib.lws_last_kernel_name.restype = C.c_char_p
+    lib.lws_generic_stage.argtypes = [vp]
+    lib.lws_generic_stage.restype = C.c_char_p
     lib.lws_stft_frames.argtypes = [ip, ip, ip, ip]
     lib.lws_istft_length.argtypes = [ip, ip, ip, ip]
     lib.lws_stft_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp]
@@ -202,7 +204,10 @@ class Plan:
         if self._warned or self._expect_generic:
             return
         name = self._lib.lws_last_kernel_name(self._h).decode()      # (no synchronisation: a string set at launch time)
-        if name.startswith("generic"):
+        stage = self._lib.lws_generic_stage(self._h).decode()        # any stage of a pipeline, not just the last one
+        if name.startswith("generic") or stage:
+            if not name.startswith("generic"):
+                name = "the %s stage" % stage
             self._warned = True
             import warnings
             warnings.warn(

@@ -194,6 +194,12 @@ def lws_last_kernel_name(plan):
     return <bytes>s if s != NULL else b"none"
 
 
+def lws_generic_stage(plan):
+    cdef uintptr_t p = _addr(plan)
+    cdef const char *s = c.lws_generic_stage(<c.lws_plan *>p)
+    return <bytes>s if s != NULL else b""
+
+
 def lws_stream_copy(dst_dev, src_dev, size_t nbytes, stream):
     cdef uintptr_t d = _addr(dst_dev), s = _addr(src_dev), st = _addr(stream)
     cdef int rc

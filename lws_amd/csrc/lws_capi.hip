@@ -176,6 +176,7 @@ struct lws_plan {
     float last_ms = 0.f;
     int last_launches = 0;
     const char *last_name = "none";
+    const char *generic_stage = "";   // the stage ("batch", "no-future", "online") that last ran on the generic engine; "" if none has
 };
 
 namespace {
@@ -336,6 +337,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
             if (e != hipSuccess) return fail(LWS_ERR_HIP, "generic (skewed) launch failed: %s", hipGetErrorString(e));
             p->last_launches = 1;
             p->last_name = p->fp64 ? "generic_skew_fp64" : "generic_skew_fp32";
+            p->generic_stage = "batch";
             return LWS_OK;
         }
     }
@@ -345,6 +347,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     if (e != hipSuccess) return fail(LWS_ERR_HIP, "generic launch failed: %s", hipGetErrorString(e));
     p->last_launches = 1;
     p->last_name = p->fp64 ? "generic_fp64" : "generic_fp32";
+    p->generic_stage = mode == lws::MODE_BATCH ? "batch" : (mode == lws::MODE_ONLINE ? "online" : "no-future");
     return LWS_OK;
 }
 
@@ -1085,5 +1088,7 @@ int lws_last_kernel_time(lws_plan *p, float *ms, int *launches) {
 }
 
 const char *lws_last_kernel_name(lws_plan *p) { return p ? p->last_name : "none"; }
+
+const char *lws_generic_stage(lws_plan *p) { return p ? p->generic_stage : ""; }
 
 }  // extern "C"

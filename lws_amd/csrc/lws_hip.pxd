@@ -37,6 +37,7 @@ cdef extern from "lws_hip.h" nogil:
     int lws_residual(lws_plan *plan, const double *S, int B, int T, double *out)
     int lws_last_kernel_time(lws_plan *plan, float *ms, int *launches)
     const char *lws_last_kernel_name(lws_plan *plan)
+    const char *lws_generic_stage(lws_plan *plan)
     int lws_stream_copy(void *dst_dev, const void *src_dev, size_t nbytes, void *stream)
     int lws_stft_frames(int length, int N, int fshift, int perfectrec)
     int lws_istft_length(int M, int N, int fshift, int perfectrec)

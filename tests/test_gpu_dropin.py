@@ -66,3 +66,16 @@ def test_generic_engine_fallback_warns_once():
         p.batch_lws(S)                                            # second call of the same plan: no warning
         lws_amd.lws(1000, 250, L=9, batch_iterations=3, batch_alpha=1.0, precision="fp64").batch_lws(S)
         lws_amd.lws(1024, 256, batch_iterations=3, batch_alpha=1.0).batch_lws(np.abs(rng.standard_normal((6, 513))))
+
+
+def test_a_generic_stage_inside_a_pipeline_warns_too():
+    """run_lws(mode='music') on 4096-point frames: the batch stage has its systolic build (four waves per sweep slot), the online
+    stage's frame ring does not fit the LDS and runs on the generic engine -- the last kernel's name does not say so, the warning
+    does (lws_generic_stage)."""
+    import lws_amd
+    rng = np.random.default_rng(1)
+    p = lws_amd.lws(4096, 1024, mode="music", online_iterations=2, batch_iterations=3, batch_alpha=1.0)
+    S = np.abs(rng.standard_normal((5, 2049)) + 1j * rng.standard_normal((5, 2049)))
+    with pytest.warns(RuntimeWarning, match="online stage"):
+        p.run_lws(S)
+    assert p.plan().last_kernel()["name"].startswith("systolic_xwide")
