@@ -86,10 +86,20 @@
 #ifndef LWS_L7
 #define LWS_L7 0
 #endif
-#if (LWS_WIDE && LWS_Q8) || ((LWS_SPW != 1 || LWS_L7) && (LWS_WIDE || LWS_Q8)) || (LWS_SPW != 1 && LWS_L7)
-#error "LWS_WIDE, LWS_Q8, LWS_SPW and LWS_L7 are separate builds"
+// ... and with -DLWS_R16=1 (namespace lws::q2) for Q = 2 (hop = half a frame, the reference's LWSQ2; frames of up to 513 bins).  The
+// taps reach one frame either way, so a lag of 16 steps between sweeps is enough (LAG > 8 (Q-1) + L = 13) and the ring is 16
+// steps deep: sets of 9 KB instead of 18, FIFTEEN sweep slots in the same LDS -- one wave each, four waves per SIMD (the Q = 2
+// kernels need ~115 VGPRs).  Throughput follows the number of waves that run a dependent chain.
+#ifndef LWS_R16
+#define LWS_R16 0
 #endif
-#if LWS_L7
+#if (LWS_WIDE && LWS_Q8) || ((LWS_SPW != 1 || LWS_L7) && (LWS_WIDE || LWS_Q8)) || (LWS_SPW != 1 && LWS_L7) || (LWS_R16 && (LWS_WIDE || LWS_Q8 || LWS_L7 || LWS_SPW != 1))
+#error "LWS_WIDE, LWS_Q8, LWS_SPW, LWS_L7 and LWS_R16 are separate builds"
+#endif
+#if LWS_R16
+#define LWS_NS_OPEN namespace lws { namespace q2 {
+#define LWS_NS_CLOSE } }
+#elif LWS_L7
 #define LWS_NS_OPEN namespace lws { namespace l7 {
 #define LWS_NS_CLOSE } }
 #elif LWS_SPW == 2
@@ -124,7 +134,7 @@ constexpr int SPW = LWS_SPW;                             // sweep slots per wave
 constexpr int ROWL = LANES * WPS / SPW;                  // lanes (frames) of a ring row = frames of a round
 constexpr int ROWL_SHIFT = LWS_WIDE == 2 ? 8 : (LWS_WIDE ? 7 : (SPW == 4 ? 4 : (SPW == 2 ? 5 : 6)));
 static_assert((1 << ROWL_SHIFT) == ROWL, "row length");
-constexpr int RING = (LWS_Q8 || LWS_L7) ? 64 : 32;
+constexpr int RING = (LWS_Q8 || LWS_L7) ? 64 : (LWS_R16 ? 16 : 32);
 constexpr int NBLK = RING / 8;                           // ring blocks of 8 steps
 // ring entry of production time nu, lane l:  set + ((nu >> 1) & 15) * PAIR_BYTES + (l + HALO) * 16 + (nu & 1) * 8
 // -- two consecutive times of one lane share a 16-byte cell, so a reader fetches two adjacent taps with one
@@ -145,7 +155,7 @@ constexpr int PAIR_BYTES = (ROWL + 2 * HALO + 2) * LANE_B;   // two consecutive 
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
 constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB (wide: 34 KiB, Q = 8: 40 KiB)
 #ifndef LWS_NSLOTS
-#define LWS_NSLOTS (LWS_L7 ? 3 : LWS_WIDE == 2 ? 1 : LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
+#define LWS_NSLOTS (LWS_R16 ? 15 : LWS_L7 ? 3 : LWS_WIDE == 2 ? 1 : LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
 #endif
 constexpr int NSLOTS = LWS_NSLOTS;                       // sweeps in flight (compute waves)
 constexpr int NSETS = NSLOTS + 1;
@@ -883,12 +893,13 @@ __device__ __forceinline__ void rows_sum_ahead(const SysArgs &a, const float2 (&
 }
 // the unfinished group of a kernel without FLAG_R13: `late` is the tap that was not there yet (frame m-R's or m+R's, at +L)
 template <int Q, int L, uint64_t MASK, int PH, int R>
-__device__ __forceinline__ void quad_finish_plain(const SysArgs &a, const QuadCarry<L> &qc, float2 late, float2 &accr) {
+__device__ __forceinline__ void quad_finish_plain(const SysArgs &a, const QuadCarry<L> &qc, float2 late, float2 &accr, float2 late_dn = make_float2(0.f, 0.f)) {
+    // (late_dn: with a 16-step lag both frames of the pair R = 1 are late -- m-1 delivers `late`, m+1 `late_dn`)
     constexpr int K1 = L + 1;
     constexpr int e8 = eighths<Q>(PH % Q, R), rot = e8 >> 1, odd = e8 & 1;
     if constexpr ((MASK >> (R * K1 + L)) & 1ull)
         quad_rot<rot, odd>(accr, a.w[widx<Q, L>(odd, R, L)], qc.g[R][0], quad_late_frame<-R, L>() ? late : qc.g[R][1], qc.g[R][2],
-                           quad_late_frame<R, L>() ? late : qc.g[R][3]);
+                           quad_late_frame<R, L>() ? ((quad_late_frame<-R, L>() && LATE_DN == R) ? late_dn : late) : qc.g[R][3]);
 }
 // the unfinished group with FLAG_R13, by the second pair: up1 = frame m-1's late tap, dp3 = frame m+3's
 template <int Q, int L, uint64_t MASK, int PH>
@@ -1018,8 +1029,8 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             if constexpr (row_owner(R) == 0) {   // (else: summed by a helper wave, in accA / accB already)
                 float2 tu[2 * L + 6], td[2 * L + 6];
                 static_assert(quad_late_frame<-1, L>() == quad_late_frame<LATE_DN, L>() && !quad_late_frame<-2, L>() &&
-                              !quad_late_frame<LATE_DN - 1, L>() && !quad_late_frame<1, L>() && !quad_late_frame<-LATE_DN, L>(),
-                              "which frames are late");
+                              (LATE_DN == 1 || (!quad_late_frame<LATE_DN - 1, L>() && !quad_late_frame<1, L>() && !quad_late_frame<-LATE_DN, L>())),
+                              "which frames are late");   // (16-step lag: frames m-1 and m+1, the only neighbours Q = 2 has)
                 constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
                 load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, tu);   // frame m-1 cannot deliver its last half cell yet,
                 load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, td);     // nor can frame m+LATE_DN
@@ -1042,8 +1053,12 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             if constexpr (r13) {
                 quad_finish<Q, L, MASK, PHB>(a, qc, u1[2 * L + 4], d3[2 * L + 4], accB);
             } else {
-                quad_finish_plain<Q, L, MASK, PHB, 1>(a, qc, u1[2 * L + 4], accB);
-                if constexpr (Q > LATE_DN) quad_finish_plain<Q, L, MASK, PHB, LATE_DN>(a, qc, d3[2 * L + 4], accB);
+                if constexpr (LATE_DN == 1) {   // (16-step lag: one group, both of its late taps)
+                    quad_finish_plain<Q, L, MASK, PHB, 1>(a, qc, u1[2 * L + 4], accB, d3[2 * L + 4]);
+                } else {
+                    quad_finish_plain<Q, L, MASK, PHB, 1>(a, qc, u1[2 * L + 4], accB);
+                    if constexpr (Q > LATE_DN) quad_finish_plain<Q, L, MASK, PHB, LATE_DN>(a, qc, d3[2 * L + 4], accB);
+                }
             }
         }
         LWS_SETPRIO(2);   // (priority 3 here measured the same within run-to-run noise on one box)
@@ -1409,6 +1424,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                             : rm == 2 ? ((hw_wave & 3) == 3 ? 6 + (hw_wave >> 2) : ((hw_wave & 3) == 2 ? 4 + (hw_wave >> 2) : (hw_wave & 3) + 2 * (hw_wave >> 2)))
                             : rm == 3 ? ((hw_wave & 3) == 3 ? 6 + (hw_wave >> 2) : (hw_wave & 3) * 2 + 1 - (hw_wave >> 2))
                             : ((hw_wave & 3) * 2 + (hw_wave >> 2)))
+                   : (LWS_R16 && NWAVES == 16 && rm != 1) ? (hw_wave == 3 ? 15 : (hw_wave == 15 ? 3 : hw_wave))
                    : ((LWS_ROLE_SWAP && NCOMPUTE == 7 && WPS == 1 && rm != 1) ? (rm == 2 ? (hw_wave == 0 ? 7 : (hw_wave == 7 ? 0 : hw_wave)) : (hw_wave == 3 ? 7 : (hw_wave == 7 ? 3 : hw_wave))) : hw_wave);
 #endif
     const int hf = wave % WPS;                     // which half of the ring row this wave's lanes are
@@ -1448,7 +1464,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     const int n_local = (wg < n_groups) ? (n_groups - wg + nwg - 1) / nwg : 0;
     if (n_local == 0) return;
     // slot i runs on clock v_i = t - (i+1)*LAG; the loader (virtual slot -1) on clock t
-    const int t_end = (n_local - 1) * G + (NSLOTS + 1) * LAG + SKEW * a.Tp + ROWP + 8;
+    // (the + 8 + ...: the last rows a consumer workgroup waits for -- need_max below, frames of ROWP bins -- must be covered by
+    //  the progress this workgroup publishes before it leaves the loop: LAG + ROWP - 8 >= C + 16 needs 16 more steps at a 16-step lag)
+    const int t_end = (n_local - 1) * G + (NSLOTS + 1) * LAG + SKEW * a.Tp + ROWP + 8 + (LAG < 32 ? 32 - LAG : 0);
     // ---- hand-over between the workgroups of a spectrogram (nwg > 1).  Row r of the skewed state written by pass g is
     // read by pass g + 1.  A workgroup publishes (release, agent scope) the number of rows -- in its own clock -- its
     // last slot and its Nyquist lanes have completed; the loader of the next workgroup in the ring waits (acquire)
@@ -2233,6 +2251,8 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
     // starts (L = 7 is not: generic engine).
 #if LWS_Q8
     if (Qp != Q || Q != 8 || L != 5) return hipSuccess;
+#elif LWS_R16
+    if (Qp != Q || Q != 2 || !(L == 5 || L == 3 || L == 1)) return hipSuccess;
 #elif LWS_L7
     if (Qp != Q || !(Q == 2 || Q == 4) || L != 7) return hipSuccess;      // (Lu = 6: the extra tap has weight zero)
 #else
@@ -2462,6 +2482,12 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     constexpr uint64_t MASK_Q8_L5_DEFAULT = 0b111111'111111'111111'010111'111111'111111'111111'000011ull;
     if (tb->mask == MASK_Q8_L5_DEFAULT && tb->k0real) { e = launch_k<8, 5, MASK_Q8_L5_DEFAULT | FLAG_K0REAL>(a, grid, h, stream); kind = "hann"; }
     else e = launch_k<8, 5, mask_all(8, 5)>(a, grid, h, stream);
+#elif LWS_R16
+    if (L == 3) e = launch_k<2, 3, mask_all(2, 3)>(a, grid, h, stream);
+    else if (L == 1) e = launch_k<2, 1, mask_all(2, 1)>(a, grid, h, stream);
+    else if (tb->mask == MASK_Q2_L5_DEFAULT && tb->k0real) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT | FLAG_K0REAL>(a, grid, h, stream); kind = "hann"; }
+    else if (tb->mask == MASK_Q2_L5_DEFAULT) { e = launch_k<2, 5, MASK_Q2_L5_DEFAULT>(a, grid, h, stream); kind = "hannmask"; }
+    else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
 #elif LWS_L7
     e = Q == 4 ? launch_k<4, 7, mask_all(4, 7)>(a, grid, h, stream) : launch_k<2, 7, mask_all(2, 7)>(a, grid, h, stream);
 #else
@@ -2479,7 +2505,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
 #endif
-    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
+    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
              h ? "_f16" : "");
     sp.name = sp.name_buf;
     return e;
