@@ -2195,6 +2195,24 @@ template <int Q, int L, uint64_t MASK, bool MULTI, bool H16, int RE> hipError_t 
         if (e != hipSuccess) return e;
         lws::attr_done(attr_set, attr_dev);
     }
+    if constexpr (MULTI) {
+        // The workgroups of a spectrogram wait for each other: all of the grid must be resident at once.  prepare() sizes the
+        // grid to at most one workgroup per CU; here the other half of that argument is checked against the runtime's own
+        // occupancy figure for this very kernel (once per kernel and process): a grid it cannot hold is refused, not launched.
+        // (What no query sees -- a device shared with another process -- is covered by the hand-over time-out and the
+        // device-side re-run with one workgroup per spectrogram, run_kernel.)
+        static std::atomic<int> per_cu{-1};
+        int occ = per_cu.load(std::memory_order_relaxed);
+        if (occ < 0) {
+            int q = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_systolic<Q, L, MASK, MULTI, H16, RE>, NTHREADS, LDS_BYTES) != hipSuccess) q = 0;
+            per_cu.store(q, std::memory_order_relaxed);
+            occ = q;
+        }
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorUnknown;
+        if (occ < 1 || (long)grid > (long)occ * n_cu) return hipErrorLaunchOutOfResources;
+    }
     hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI, H16, RE>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
     return hipGetLastError();
 }
