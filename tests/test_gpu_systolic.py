@@ -41,7 +41,7 @@ def run_case(oracle, fsize, fshift, T, thr, seed, B=1, scale=None, L=5):
         n2 = narrow.last_kernel()["name"]
         assert (n2.startswith("systolic_q") or n2.startswith("systolic_r16_q")) and np.array_equal(out, ref_narrow), (name, n2)
         narrow.close()
-    if 257 < F <= 513 and fsize // fshift == 2 and L <= 5:
+    if 257 < F <= 1025 and fsize // fshift == 2 and L <= 5:
         # Q = 2: the build with a 16-step ring (fifteen sweep slots) against the 32-step one (seven): identical bits
         assert "_r16_" in name, name
         os.environ["LWS_SYSTOLIC_NO_R16"] = "1"
@@ -51,7 +51,7 @@ def run_case(oracle, fsize, fshift, T, thr, seed, B=1, scale=None, L=5):
             del os.environ["LWS_SYSTOLIC_NO_R16"]
         ref7 = seven.batch(S, thr)
         n7 = seven.last_kernel()["name"]
-        assert n7.startswith("systolic_q2") and np.array_equal(out, ref7), (name, n7)
+        assert (n7.startswith("systolic_q2") or n7.startswith("systolic_wide_q2")) and np.array_equal(out, ref7), (name, n7)
         seven.close()
     p64 = _capi.Plan(F, p.W, precision="fp64")
     for b in range(B):
@@ -230,7 +230,7 @@ def test_wide_frames(oracle, fsize, fshift, T):
     out = run_case(oracle, fsize, fshift, T, [0.5, 0.1, 0.0, 0.0, 0.0], seed=fsize + T)
     p = lws_amd.lws(fsize, fshift)
     p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
-    assert _wide_name(p).startswith("systolic_wide_q"), _wide_name(p)
+    assert _wide_name(p).startswith("systolic_wide_r16_q2" if fsize // fshift == 2 else "systolic_wide_q"), _wide_name(p)
     assert out.shape == (1, T, fsize // 2 + 1)
 
 
@@ -266,7 +266,7 @@ def test_frames_that_end_inside_a_block(oracle, fsize, fshift, T):
     p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
     F = fsize // 2 + 1
     narrow = "systolic_r16_q" if fsize // fshift == 2 else "systolic_q"      # (Q = 2: the build with a 16-step ring)
-    assert _wide_name(p).startswith("systolic_wide_q" if F > 513 else (narrow if F > 257 else ("systolic_half_q" if F > 129 else "systolic_quarter_q"))), _wide_name(p)
+    assert _wide_name(p).startswith(("systolic_wide_r16_q" if fsize // fshift == 2 else "systolic_wide_q") if F > 513 else (narrow if F > 257 else ("systolic_half_q" if F > 129 else "systolic_quarter_q"))), _wide_name(p)
 
 
 def test_what_still_needs_the_generic_engine():

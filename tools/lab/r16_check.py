@@ -27,3 +27,16 @@ for env in ("0", "1"):
     for _ in range(3):
         plan.batch_dev(S.data_ptr(), B, T, np.zeros(iters)); torch.cuda.synchronize(); ms.append(plan.last_kernel()["ms"])
     print(plan.last_kernel()["name"], " ".join("%.2f" % m for m in ms), flush=True)
+for args in ((2048,1024,5,1,1),(2048,1024,5,70,3),(2048,1024,5,140,20),(2048,1024,3,200,9),(2004,1002,5,66,15),(1100,550,5,130,8),(2048,1024,4,257,22)):
+    chk(*args)
+B,T,F,iters=64,6000,1025,60
+p = lws_amd.lws(2048,1024)
+S = torch.from_numpy((np.random.default_rng(0).standard_normal((B,T,F)) + 0j).astype(np.complex64)).cuda()
+for env in ("0", "1"):
+    os.environ["LWS_SYSTOLIC_NO_R16"] = env
+    plan = _capi.Plan(F, p.W)
+    plan.batch_dev(S.data_ptr(), B, T, np.zeros(iters)); torch.cuda.synchronize()
+    ms=[]
+    for _ in range(2):
+        plan.batch_dev(S.data_ptr(), B, T, np.zeros(iters)); torch.cuda.synchronize(); ms.append(plan.last_kernel()["ms"])
+    print(plan.last_kernel()["name"], " ".join("%.2f" % m for m in ms), flush=True)
