@@ -1,4 +1,4 @@
-"""Random shapes and schedules: the systolic kernels (all five builds, L in 1..5, frames that end inside a block) against the
+"""Random shapes and schedules: the systolic kernels (every build, L in 1..5, frames that end inside a block) against the
 order-exact generic engine in fp32; a few sweeps, so that rounding differences stay small -- except from a zero-phase start
 (real, non-negative input: the run_lws(abs(X)) case), where weighted sums nearly cancel and two correct fp32 engines, or fp32
 and fp64, drift apart from some frame on (rel-L2 of a percent or more after one sweep): there the typical bin is checked.  usage: PYTHONPATH=. python
