@@ -860,10 +860,14 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
         // the first build that takes the shape: short frames (<= 129 / 257 bins: four / two sweep slots per wave), up to 513 bins,
         // Q = 8, up to 1025 bins.  LWS_SYSTOLIC_NO_SHORT=1 skips the short-frame builds (comparison runs)
         const bool no_short = env_int("LWS_SYSTOLIC_NO_SHORT", 0) != 0;
-        for (const lws::SystolicBuild *b : {&lws::quarter::systolic_entry(), &lws::half::systolic_entry(), &lws::q2::systolic_entry(), &lws::systolic_entry(),
+        for (const lws::SystolicBuild *b : {&lws::quarter_q2::systolic_entry(), &lws::quarter::systolic_entry(), &lws::half_q2::systolic_entry(), &lws::half::systolic_entry(),
+                                            &lws::q2::systolic_entry(), &lws::systolic_entry(),
                                             &lws::q8::systolic_entry(), &lws::wide_q2::systolic_entry(), &lws::wide::systolic_entry(), &lws::xwide::systolic_entry(), &lws::l7::systolic_entry()}) {
-            if (no_short && (b == &lws::quarter::systolic_entry() || b == &lws::half::systolic_entry())) continue;
-            if ((b == &lws::q2::systolic_entry() || b == &lws::wide_q2::systolic_entry()) && env_int("LWS_SYSTOLIC_NO_R16", 0)) continue;   // (comparison runs)
+            const bool is_short = b == &lws::quarter::systolic_entry() || b == &lws::half::systolic_entry() || b == &lws::quarter_q2::systolic_entry() ||
+                                  b == &lws::half_q2::systolic_entry();
+            const bool is_r16 = b == &lws::q2::systolic_entry() || b == &lws::wide_q2::systolic_entry() || b == &lws::quarter_q2::systolic_entry() ||
+                                b == &lws::half_q2::systolic_entry();
+            if ((no_short && is_short) || (is_r16 && env_int("LWS_SYSTOLIC_NO_R16", 0))) continue;   // (comparison runs)
             if ((e = b->build(p->sys, F, L, Q, Qp, hw, h16)) != hipSuccess) break;
             if (p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2]) { p->sysb = b; break; }
         }

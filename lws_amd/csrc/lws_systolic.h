@@ -67,6 +67,8 @@ namespace wide { const SystolicBuild &systolic_entry(); }         // -DLWS_WIDE=
 namespace xwide { const SystolicBuild &systolic_entry(); }        // -DLWS_WIDE=2: frames of up to 2049 bins, four waves per sweep slot, 1 slot
 namespace q2 { const SystolicBuild &systolic_entry(); }           // -DLWS_R16=1: Q = 2 with a 16-step ring: 15 sweep slots, frames <= 513 bins
 namespace wide_q2 { const SystolicBuild &systolic_entry(); }      // -DLWS_WIDE=1 -DLWS_R16=1: the same for frames of up to 1025 bins (7 slots of two waves)
+namespace half_q2 { const SystolicBuild &systolic_entry(); }      // -DLWS_SPW=2 -DLWS_R16=1: ... of up to 257 bins (26 slots on 13 waves)
+namespace quarter_q2 { const SystolicBuild &systolic_entry(); }   // -DLWS_SPW=4 -DLWS_R16=1: ... of up to 129 bins (44 slots on 11 waves)
 namespace l7 { const SystolicBuild &systolic_entry(); }           // -DLWS_L7=1: L = 6, 7 (frames 16 steps apart, 64-step ring, 3 slots), <= 513 bins
 namespace half { const SystolicBuild &systolic_entry(); }         // -DLWS_SPW=2: frames of up to 257 bins, two sweep slots per wave (14)
 namespace quarter { const SystolicBuild &systolic_entry(); }      // -DLWS_SPW=4: frames of up to 129 bins, four sweep slots per wave (24)

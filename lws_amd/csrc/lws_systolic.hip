@@ -95,11 +95,18 @@
 #endif
 // (LWS_R16 also combines with LWS_WIDE=1 -- namespace lws::wide_q2, frames of up to 1025 bins: seven sweep slots of two waves
 //  instead of three)
-#if (LWS_WIDE && LWS_Q8) || ((LWS_SPW != 1 || LWS_L7) && (LWS_WIDE || LWS_Q8)) || (LWS_SPW != 1 && LWS_L7) || (LWS_R16 && (LWS_WIDE == 2 || LWS_Q8 || LWS_L7 || LWS_SPW != 1))
-#error "LWS_WIDE, LWS_Q8, LWS_SPW, LWS_L7 and LWS_R16 are separate builds (LWS_R16 goes with LWS_WIDE=1)"
+// (... and with LWS_SPW=2 / 4 -- lws::half_q2, lws::quarter_q2, frames of up to 257 / 129 bins: 26 / 44 sweep slots)
+#if (LWS_WIDE && LWS_Q8) || ((LWS_SPW != 1 || LWS_L7) && (LWS_WIDE || LWS_Q8)) || (LWS_SPW != 1 && LWS_L7) || (LWS_R16 && (LWS_WIDE == 2 || LWS_Q8 || LWS_L7))
+#error "LWS_WIDE, LWS_Q8, LWS_SPW, LWS_L7 and LWS_R16 are separate builds (LWS_R16 goes with LWS_WIDE=1 or LWS_SPW)"
 #endif
 #if LWS_R16 && LWS_WIDE
 #define LWS_NS_OPEN namespace lws { namespace wide_q2 {
+#define LWS_NS_CLOSE } }
+#elif LWS_R16 && LWS_SPW == 2
+#define LWS_NS_OPEN namespace lws { namespace half_q2 {
+#define LWS_NS_CLOSE } }
+#elif LWS_R16 && LWS_SPW == 4
+#define LWS_NS_OPEN namespace lws { namespace quarter_q2 {
 #define LWS_NS_CLOSE } }
 #elif LWS_R16
 #define LWS_NS_OPEN namespace lws { namespace q2 {
@@ -160,7 +167,7 @@ constexpr int PAIR_BYTES = (ROWL + 2 * HALO + 2) * LANE_B;   // two consecutive 
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
 constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB (wide: 34 KiB, Q = 8: 40 KiB)
 #ifndef LWS_NSLOTS
-#define LWS_NSLOTS ((LWS_R16 && LWS_WIDE) ? 7 : LWS_R16 ? 15 : LWS_L7 ? 3 : LWS_WIDE == 2 ? 1 : LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
+#define LWS_NSLOTS ((LWS_R16 && LWS_WIDE) ? 7 : (LWS_R16 && LWS_SPW == 2) ? 26 : (LWS_R16 && LWS_SPW == 4) ? 44 : LWS_R16 ? 15 : LWS_L7 ? 3 : LWS_WIDE == 2 ? 1 : LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
 #endif
 constexpr int NSLOTS = LWS_NSLOTS;                       // sweeps in flight (compute waves)
 constexpr int NSETS = NSLOTS + 1;
@@ -2528,7 +2535,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
 #endif
-    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_R16 && LWS_WIDE) ? "_wide_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
+    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_R16 && LWS_WIDE) ? "_wide_r16" : (LWS_R16 && SPW == 2) ? "_half_r16" : (LWS_R16 && SPW == 4) ? "_quarter_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
              h ? "_f16" : "");
     sp.name = sp.name_buf;
     return e;

@@ -265,8 +265,9 @@ def test_frames_that_end_inside_a_block(oracle, fsize, fshift, T):
     p = lws_amd.lws(fsize, fshift)
     p.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
     F = fsize // 2 + 1
-    narrow = "systolic_r16_q" if fsize // fshift == 2 else "systolic_q"      # (Q = 2: the build with a 16-step ring)
-    assert _wide_name(p).startswith(("systolic_wide_r16_q" if fsize // fshift == 2 else "systolic_wide_q") if F > 513 else (narrow if F > 257 else ("systolic_half_q" if F > 129 else "systolic_quarter_q"))), _wide_name(p)
+    r16 = "r16_" if fsize // fshift == 2 else ""             # (Q = 2: the builds with a 16-step ring)
+    build = "wide_" if F > 513 else ("" if F > 257 else ("half_" if F > 129 else "quarter_"))
+    assert _wide_name(p).startswith("systolic_" + build + r16 + "q"), _wide_name(p)
 
 
 def test_what_still_needs_the_generic_engine():
