@@ -335,7 +335,8 @@ def test_workgroup_sharing_randomised(monkeypatch):
 
 @pytest.mark.parametrize("fsize,fshift,T", [(1024, 256, 150), (2048, 512, 150), (2048, 512, 100), (1024, 128, 150), (64, 8, 70),
                                              (1000, 250, 150), (1012, 253, 150), (2004, 501, 100), (4096, 1024, 60),
-                                             (512, 128, 150), (256, 64, 150), (1000, 125, 150)])
+                                             (512, 128, 150), (256, 64, 150), (1000, 125, 150), (1024, 512, 150), (2048, 1024, 100),
+                                             (512, 256, 150), (252, 126, 150)])
 def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
     """The waves of a workgroup synchronise through progress counters in LDS, not barriers.  LWS_SYSTOLIC_STRESS stalls chosen
     waves (role mask) for ~10 us before a chosen pair of every block -- far longer than a pair takes -- so any read that is
@@ -349,7 +350,8 @@ def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
     p = lws_amd.lws(fsize, fshift)
     monkeypatch.setenv("LWS_SYSTOLIC_NWG", "1")
     ref = p.plan().batch(S, thr)
-    for role in range(8):
+    n_roles = 16 if "_r16_" in p.plan().last_kernel()["name"] else 8      # (Q = 2 on a 16-step ring: up to sixteen waves)
+    for role in range(n_roles):
         for pair in (1, 3, 5, 7):
             monkeypatch.setenv("LWS_SYSTOLIC_STRESS", str((1 << role) | (pair << 16)))
             assert np.array_equal(p.plan().batch(S, thr), ref), (role, pair)
