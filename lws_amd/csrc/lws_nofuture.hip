@@ -323,7 +323,13 @@ NfShape shape_of(int F, int T, int L, int Q, int Qp) {
     while (NR < Q + 1) NR *= 2;          // frames me - Q + 1 .. me and the prefetched me + 1
     sh.NR = NR;
     sh.threads = Np >= 384 ? 512 : (Np >= 192 ? 256 : (Np >= 96 ? 128 : 64));
-    if (3 * sh.threads < Np) return sh;  // three elements of a frame per thread at most
+    // three elements of a frame per thread at most (the prefetch of the next frame): the eight-lanes-per-bin variant runs up to
+    // 1024 threads (frames of up to 3072 columns: 4096-point STFTs), the one-lane verification variant `threads`
+    {
+        const char *ev = getenv("LWS_NOFUTURE_SERIAL_TAPS");
+        const int launched = (ev && ev[0] == '1') ? sh.threads : (4 * sh.threads > 1024 ? 1024 : 4 * sh.threads);
+        if (3 * launched < Np) return sh;
+    }
     if (Q * (L + 1) > 64) return sh;     // one 64-bit participation mask per weight row
     sh.lds = (size_t)NR * Np * 8 + (size_t)Q * Q * (L + 1) * 8 + (size_t)(Q + 1) * 8 + (size_t)2 * Np * 4 + 16;
     if (sh.lds > 160 * 1024) return sh;

@@ -84,6 +84,33 @@ def test_compat_rounds_on_tiny_frames_against_the_oracle(oracle, fsize, fshift):
     # frame, and rounding is amplified along the chain until single fp32 values say little -- tests/test_gpu_parity.py)
 
 
+@pytest.mark.parametrize("fsize,fshift,T", [(4096, 1024, 30), (3000, 750, 25), (4096, 2048, 20)])
+def test_frames_of_4096_points(fsize, fshift, T, monkeypatch):
+    """Frames of up to 3072 columns (4096-point STFTs) run on the LDS kernel's eight-lanes-per-bin variant (1024 threads: three
+    columns of the prefetched frame each); the one-lane verification variant has 512 and sends them to the generic engine.
+    Same magnitudes, same bins left alone, the generic engine's values on the first frames (see above for the later ones)."""
+    rng = np.random.default_rng(T)
+    F = fsize // 2 + 1
+    p = lws_amd.lws(fsize, fshift, mode="music")
+    S = rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))
+    thr = [0.3, 0.0]
+    lds = _capi.Plan(F, p.W, p.W_ai, p.W_af)
+    gen = _capi.Plan(F, p.W, p.W_ai, p.W_af, force_generic=True)
+    a, b = lds.nofuture(S, thr, wsel=1), gen.nofuture(S, thr, wsel=1)
+    assert lds.last_kernel()["name"].startswith("nofuture_lds") and gen.last_kernel()["name"] == "generic_fp32"
+    assert np.abs(np.abs(a) - np.abs(b)).max() < 2e-6 * np.abs(S).max()
+    S32 = S.astype(np.complex64)
+    assert np.array_equal(a == S32, b == S32)
+    err = np.abs(a - b)
+    assert np.median(err[:, :2]) < 2e-6 * np.mean(np.abs(S)) and np.quantile(err[:, 0], 0.99) < 1e-3 * np.mean(np.abs(S))
+    monkeypatch.setenv("LWS_NOFUTURE_SERIAL_TAPS", "1")
+    ser = _capi.Plan(F, p.W, p.W_ai, p.W_af)
+    c = ser.nofuture(S, thr, wsel=1)
+    # (one lane per bin: 512 threads x 3 columns -- a frame of more than 1536 columns goes to the generic engine; the same bits either way)
+    assert ser.last_kernel()["name"] == ("generic_fp32" if F + 10 > 1536 else "nofuture_lds_q4compat_fp32") and np.array_equal(c, b)
+    lds.close(); gen.close(); ser.close()
+
+
 def test_config3_nofuture_stage_time_and_values(monkeypatch):
     """256 x 500 x 513 (BASELINE config 3's first stage): one sweep; the verification variant gives the generic engine's bits
     on a sample, the production variant the same magnitudes."""
