@@ -866,8 +866,13 @@ __device__ __forceinline__ float pow2_to_unit(float amax) {
     return (e == 0u || e == 0xffu) ? 1.0f : __uint_as_float((e >= 254u ? 1u : 254u - e) << 23);
 }
 
-template <int Q, int L, bool SERIAL>
+// BIG: frames too long for the ring to hold their target magnitudes and the step table as well (4096-point STFTs: a ring of eight
+// 2060-column frames is 132 KB of values).  The magnitudes are then read from the caller's buffer, one step ahead (a global load on
+// the projection wave's chain: slower steps, 10x faster than the generic engine such frames used to get), and the step table's
+// entries are computed instead of fetched.  Production variant only.
+template <int Q, int L, bool SERIAL, bool BIG = false>
 __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs a) {
+    static_assert(!(BIG && SERIAL), "the verification variant keeps everything in LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int K1 = L + 1, WN = 2 * L + 2, NTW = 2 * Q - 1;
     constexpr int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2;
@@ -881,7 +886,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     const int nsweeps = T * per;
     constexpr int NLO = (L + 2) / 4, NHI = (L + 1) / 2 + 1, NST = 1 + NLO + NHI;
     // LDS layout (byte offsets; lds_of in shape4_of is the same sum)
-    const unsigned oET = 2u * NTW * 64 * 16, oS = oET + (224 + 64) * 8, oA = oS + ((unsigned)NWR * NPS + 8) * 8, oW = oA + (unsigned)NWR * NPS * 4,
+    const unsigned oET = 2u * NTW * 64 * 16, oS = oET + (224 + 64) * 8, oA = oS + ((unsigned)NWR * NPS + 8) * 8, oW = oA + (BIG ? 0u : (unsigned)NWR * NPS * 4),
                    oTW = oW + 3u * Q * Q * K1 * 8, oThr = oTW + Q * 8, oTAB = (oThr + (unsigned)a.n_thr * 4 + 15u) & ~15u;
     float4 *P = reinterpret_cast<float4 *>(smem);                               // [2][NTW][64]: (sum of bin c, of bin c+1)
     float4 *MT = reinterpret_cast<float4 *>(smem + oET);                        // [3][NST][6]: own-history matrices of the projection wave (below)
@@ -930,7 +935,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     }
     if (tid < Q) TW[tid] = a.tw[tid];
     for (int i = tid; i < NWR * NPS + 8; i += nthr) S[i] = make_float2(0.f, 0.f);
-    for (int i = tid; i < NWR * NPS; i += nthr) A[i] = 0.f;
+    if constexpr (!BIG) for (int i = tid; i < NWR * NPS; i += nthr) A[i] = 0.f;
     for (int i = tid; i < 2 * NTW * 64; i += nthr) P[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     // Own-history terms of the projection wave, per weight set and kind of step (0: none of the edge terms; 1..NLO: the steps
@@ -974,13 +979,16 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         const int stype = (uu >= 1 && uu <= NLO) ? uu : (g < NHI ? NLO + 1 + g : 0);
         const int da = (c >= 1 && c <= L) ? -16 * c : ((c >= N - L && c <= N - 1) ? 16 * (N - c) : 0);
         const int db = (cb <= L) ? -16 * cb : ((cb >= N - L && cb <= N - 1) ? 16 * (N - cb) : 0);
-        TAB[uu] = make_int4(stype * 96, da, db, cb < F ? 0 : (int)0x80000000);
+        if constexpr (!BIG) TAB[uu] = make_int4(stype * 96, da, db, cb < F ? 0 : (int)0x80000000);
     }
     __syncthreads();
     for (int i = tid; i < a.n_thr; i += nthr) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
     int loaded = Q < T + Q - 1 ? Q : T + Q - 1;
     for (int r0 = 0; r0 < loaded; ++r0)
-        for (int i = tid; i < Npu; i += nthr) { S[r0 * NPS + dL + i] = gS[(size_t)r0 * Npu + i]; A[r0 * NPS + dL + i] = gA[(size_t)r0 * Npu + i]; }
+        for (int i = tid; i < Npu; i += nthr) {
+            S[r0 * NPS + dL + i] = gS[(size_t)r0 * Npu + i];
+            if constexpr (!BIG) A[r0 * NPS + dL + i] = gA[(size_t)r0 * Npu + i];
+        }
 
     const int sigma = lane / rps, j = lane - sigma * rps;
     const bool lane_used = sigma < NSW;
@@ -988,6 +996,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     int s = sigma;
     int rho = 0, tstart = 0, t_done = 0, ts = 1, wset = 0;
     int fb = 0, ctb = 0, fbm1 = 0;
+    int e_own = 0;                      // BIG: the lane's frame (row of the caller's magnitude buffer)
     bool valid = false, centre = false;
     float thr = 0.f;
     v2f w0[K1];                         // tap waves: W[wset][0][r][k] (side 0) or its conjugate (side 1)
@@ -1007,6 +1016,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         tstart = DS * s + SKS * rho;
         t_done = DS * s + SKS * m + NU - 1;     // even: DS and SKS are, NU is odd
         const int e = rho + Q - 1;
+        e_own = e;
         fb = ((h ? e + r : e - r) % NWR) * NPS;
         ctb = (e % NWR) * NPS;
         fbm1 = ((e - 1) % NWR) * NPS;
@@ -1047,7 +1057,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             for (int i = tid; i < Npu; i += nthr) {
                 if (evict) gS[(size_t)(loaded - NWR) * Npu + i] = S[slot + dL + i];
                 S[slot + dL + i] = gS[(size_t)loaded * Npu + i];
-                A[slot + dL + i] = gA[(size_t)loaded * Npu + i];
+                if constexpr (!BIG) A[slot + dL + i] = gA[(size_t)loaded * Npu + i];
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the projection wave's barrier wait is a counted one)
             ++loaded;
@@ -1289,15 +1299,25 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             int4 tab1 = make_int4(0, 0, 0, 0), tab2 = make_int4(0, 0, 0, 0);   // table entries of bin pairs u + 1, u + 2
             unsigned li0 = oS, ai0 = oA, xl0 = oS, et0 = oET;     // per-sweep bases of the lane (byte offsets)
             int u = -1 - tstart;                       // bin pair of the step about to run
+            const float *ga0 = gA;      // BIG: magnitudes of the lane's frame, bin 0
             auto derive = [&]() __attribute__((always_inline)) {
                 li0 = oS + 8u * (unsigned)(ctb + L);
                 ai0 = oA + 4u * (unsigned)(ctb + L);
+                if constexpr (BIG) ga0 = gA + (size_t)e_own * Npu + a.Lu;
                 xl0 = oS + 8u * (unsigned)(fbm1 + 1 + 2 * L);
                 et0 = oET + (unsigned)(wset * NST * 96);
             };
             auto clampu = [&](int un) __attribute__((always_inline)) { return un < 0 ? 0 : (un > NU - 1 ? NU - 1 : un); };
             auto fetch_tab = [&](int un) __attribute__((always_inline)) {
-                return *reinterpret_cast<const int4 *>(lds(oTAB + 16u * (unsigned)clampu(un)));
+                if constexpr (BIG) {            // the table entry of bin pair un, computed (same formulas as where TAB is filled)
+                    const int uu = clampu(un), c = 2 * uu, cb = c + 1, g = N - c;
+                    const int stype = (uu >= 1 && uu <= NLO) ? uu : (g < NHI ? NLO + 1 + g : 0);
+                    const int da = (c >= 1 && c <= L) ? -16 * c : ((c >= N - L && c <= N - 1) ? 16 * (N - c) : 0);
+                    const int db = (cb <= L) ? -16 * cb : ((cb >= N - L && cb <= N - 1) ? 16 * (N - cb) : 0);
+                    return make_int4(stype * 96, da, db, cb < F ? 0 : (int)0x80000000);
+                } else {
+                    return *reinterpret_cast<const int4 *>(lds(oTAB + 16u * (unsigned)clampu(un)));
+                }
             };
             auto fetch = [&](int un, int4 tab) __attribute__((always_inline)) {   // operands of bin pair un, whose table entry is `tab`
                 act = valid && (unsigned)un < (unsigned)NU;
@@ -1305,9 +1325,15 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 li_b = li0 + 16u * uc;
                 const float2 *so = reinterpret_cast<const float2 *>(lds(li_b));
                 oldA = as_v2f(so[0]); oldB = as_v2f(so[1]);
-                const float *ta = reinterpret_cast<const float *>(lds(ai0 + 8u * uc));
-                target_a = ta[0];
-                target_b = __int_as_float(__float_as_int(ta[1]) | tab.w);       // (no second bin: a negative target is never above a threshold)
+                if constexpr (BIG) {
+                    // (bin 2 uc + 1 of the last pair is one past the frame's bins: the caller's buffer has a pad column there)
+                    target_a = ga0[2 * uc];
+                    target_b = __int_as_float(__float_as_int(ga0[2 * uc + 1]) | tab.w);
+                } else {
+                    const float *ta = reinterpret_cast<const float *>(lds(ai0 + 8u * uc));
+                    target_a = ta[0];
+                    target_b = __int_as_float(__float_as_int(ta[1]) | tab.w);       // (no second bin: a negative target is never above a threshold)
+                }
                 const float4 *mt = reinterpret_cast<const float4 *>(lds(et0 + (unsigned)tab.x));
                 mA1 = mt[0]; mA2 = mt[1]; mB1 = mt[2]; mB2 = mt[3]; mC = mt[4]; eA = mt[5];
                 ia_b = li_b + (unsigned)tab.y;
@@ -1480,9 +1506,10 @@ Shape shape3_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
 }
 
 // k_online4: 2Q waves, one lane per (sweep slot, frame position), even lag, ring of NWR frames with an even row stride
-struct Shape4 { Shape sh; int NWR, NPS; };
-Shape4 shape4_of(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
-    Shape4 r{{0, 0, 0, 0, false}, 0, 0};
+struct Shape4 { Shape sh; int NWR, NPS; bool big; };
+// big: the kernel's BIG variant (target magnitudes and step table not in LDS)
+Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool big) {
+    Shape4 r{{0, 0, 0, 0, false}, 0, 0, big};
     Shape &sh = r.sh;
     // any stencil half-width up to the kernel's: narrower ones run as L = 5 with zero weights for the taps they do not have
     // (OnlineArgs::Lu) -- the same sums, on a schedule that is order-exact for the wider stencil
@@ -1503,8 +1530,8 @@ Shape4 shape4_of(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
     if (F - 1 < 2 * (L + 3)) return r;
     r.NPS = Np + (Np & 1);
     auto lds_of = [&](int nwr) {
-        return (size_t)2 * (2 * Q - 1) * 64 * 16 + (224 + 64) * 8 + ((size_t)nwr * r.NPS + 8) * 8 + (size_t)nwr * r.NPS * 4 +
-               (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4 + 16 + (size_t)NU * 16;
+        return (size_t)2 * (2 * Q - 1) * 64 * 16 + (224 + 64) * 8 + ((size_t)nwr * r.NPS + 8) * 8 + (big ? 0 : (size_t)nwr * r.NPS * 4) +
+               (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4 + 16 + (big ? 0 : (size_t)NU * 16);
     };
     int nwr_max = 16;
     while (nwr_max > 0 && lds_of(nwr_max) > 160 * 1024) --nwr_max;
@@ -1527,6 +1554,12 @@ Shape4 shape4_of(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
     sh.ok = true;
     return r;
 }
+Shape4 shape4_of(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
+    Shape4 r = shape4_try(F, T, Lu, Q, Qp, LA, n_thr, false);
+    const char *ev = getenv("LWS_ONLINE_SERIAL_TAPS");   // (the verification variant has no BIG build)
+    if (!r.sh.ok && !(ev && ev[0] == '1')) r = shape4_try(F, T, Lu, Q, Qp, LA, n_thr, true);
+    return r;
+}
 
 // which layout serves a shape: the wave-per-tap-group one unless it needs much more lag between sweeps (few slots: long
 // look-ahead) than the lane-group one; LWS_ONLINE_LAYOUT=2 / 3 forces one (tests)
@@ -1540,11 +1573,11 @@ int pick_layout(const Shape &s2, const Shape &s3, const Shape &s4) {
     return s2.ok ? 2 : 0;
 }
 
-template <int Q, int L, bool SERIAL> hipError_t launch_4(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online4<Q, L, SERIAL>),
+template <int Q, int L, bool SERIAL, bool BIG = false> hipError_t launch_4(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online4<Q, L, SERIAL, BIG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // (per device: not cached)
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_online4<Q, L, SERIAL>), dim3(B), dim3(Online4Waves<Q>::N * 64), lds, s, a);
+    hipLaunchKernelGGL((k_online4<Q, L, SERIAL, BIG>), dim3(B), dim3(Online4Waves<Q>::N * 64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1609,6 +1642,12 @@ hipError_t launch_online_lds(const GenericArgs<float> &g, int B, hipStream_t str
     const char *ev = getenv("LWS_ONLINE_SERIAL_TAPS");   // verification only, see k_online
     if (layout == 4) {
         const bool serial = ev && ev[0] == '1';
+        if (sh4.big) {
+            if (serial) return hipErrorInvalidValue;
+            if (g.Q == 4) return launch_4<4, 5, false, true>(a, B, sh.lds, stream);
+            if (g.Q == 2) return launch_4<2, 5, false, true>(a, B, sh.lds, stream);
+            return launch_4<8, 5, false, true>(a, B, sh.lds, stream);
+        }
         if (g.Q == 4) return serial ? launch_4<4, 5, true>(a, B, sh.lds, stream) : launch_4<4, 5, false>(a, B, sh.lds, stream);
         if (g.Q == 2) return serial ? launch_4<2, 5, true>(a, B, sh.lds, stream) : launch_4<2, 5, false>(a, B, sh.lds, stream);
         return serial ? launch_4<8, 5, true>(a, B, sh.lds, stream) : launch_4<8, 5, false>(a, B, sh.lds, stream);

@@ -69,13 +69,13 @@ def test_generic_engine_fallback_warns_once():
 
 
 def test_a_generic_stage_inside_a_pipeline_warns_too():
-    """run_lws(mode='music') on 4096-point frames: the batch stage has its systolic build (four waves per sweep slot), the online
-    stage's frame ring does not fit the LDS and runs on the generic engine -- the last kernel's name does not say so, the warning
-    does (lws_generic_stage)."""
+    """run_lws(mode='music') with L = 7: the batch stage has its systolic build (frames 16 steps apart), the online stage has no
+    kernel for that stencil and runs on the generic engine -- the last kernel's name does not say so, the warning does
+    (lws_generic_stage)."""
     import lws_amd
     rng = np.random.default_rng(1)
-    p = lws_amd.lws(4096, 1024, mode="music", online_iterations=2, batch_iterations=3, batch_alpha=1.0)
-    S = np.abs(rng.standard_normal((5, 2049)) + 1j * rng.standard_normal((5, 2049)))
+    p = lws_amd.lws(1024, 256, L=7, mode="music", online_iterations=2, batch_iterations=3, batch_alpha=1.0)
+    S = np.abs(rng.standard_normal((9, 513)) + 1j * rng.standard_normal((9, 513)))
     with pytest.warns(RuntimeWarning, match="online stage"):
         p.run_lws(S)
-    assert p.plan().last_kernel()["name"].startswith("systolic_xwide")
+    assert "_l7_" in p.plan().last_kernel()["name"]

@@ -137,6 +137,37 @@ def test_narrower_stencils(fsize, fshift, L, T, LA, iters, B, oracle, monkeypatc
     assert np.median(err) < 2e-6 * np.mean(np.abs(S)) and np.linalg.norm(err) < 5e-3 * np.linalg.norm(o)
 
 
+@pytest.mark.parametrize("fsize,fshift,T,iters,LA", [(4096, 1024, 12, 2, 3), (3000, 750, 14, 3, 3), (4096, 2048, 16, 3, 2), (4000, 1000, 11, 2, 3)])
+def test_frames_of_4096_points(fsize, fshift, T, iters, LA, oracle, monkeypatch):
+    """Frames too long for the LDS ring to hold their target magnitudes and the step table beside the values (a ring of eight
+    2060-column frames is 132 KB): the kernel's BIG variant reads the magnitudes from the caller's buffer and computes the table
+    entries, with a sweep lag long enough for eight ring frames.  Against the fp64 oracle on short runs (values), same magnitudes as
+    the generic engine; the serial-taps verification variant has no such build and runs on the generic engine."""
+    rng = np.random.default_rng(fsize + T)
+    p = lws_amd.lws(fsize, fshift, mode="music")
+    F = fsize // 2 + 1
+    S = rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.1, 1)
+    W = (p.W, p.W_ai, p.W_af)
+    out, name = _online(F, W, S, thr, LA, fsize / fshift)
+    assert name == "online_lds_fp32"
+    ref = oracle.online_lws(S, *W, thr, LA, fshift)
+    gen, name = _online(F, W, S, thr, LA, fsize / fshift, force_generic=True)
+    assert name == "generic_fp32"
+    err, scale = np.abs(out - ref), np.mean(np.abs(S))
+    gen_l2, gen_med = np.linalg.norm(gen - ref) / np.linalg.norm(ref), np.median(np.abs(gen - ref))
+    assert np.median(err) < max(1e-6 * scale, 3 * gen_med), (np.median(err), gen_med)
+    assert np.linalg.norm(err) < max(1e-3, 3 * gen_l2) * np.linalg.norm(ref), (np.linalg.norm(err) / np.linalg.norm(ref), gen_l2)
+    assert np.abs(np.abs(out) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
+    monkeypatch.setenv("LWS_ONLINE_SERIAL_TAPS", "1")
+    ser, name = _online(F, W, S, thr, LA, fsize / fshift)
+    # (where the frames still fit the ring with their magnitudes -- 1501 bins, or Q = 2 -- the verification variant runs on the LDS
+    #  kernel; either way: the generic engine's bits)
+    assert name in ("generic_fp32", "online_lds_fp32") and np.array_equal(ser, gen)
+    if fsize == 4096 and fshift == 1024:
+        assert name == "generic_fp32"
+
+
 def test_fallbacks_to_generic():
     """Shapes the LDS ring cannot hold, and fp64 plans, stay on the generic engine."""
     rng = np.random.default_rng(0)
