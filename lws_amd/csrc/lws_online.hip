@@ -1300,6 +1300,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             unsigned li0 = oS, ai0 = oA, xl0 = oS, et0 = oET;     // per-sweep bases of the lane (byte offsets)
             int u = -1 - tstart;                       // bin pair of the step about to run
             const float *ga0 = gA;      // BIG: magnitudes of the lane's frame, bin 0
+            float tq_a = 0.f, tq_b = 0.f;   // ... and those of the pair after the one being fetched, in flight
             auto derive = [&]() __attribute__((always_inline)) {
                 li0 = oS + 8u * (unsigned)(ctb + L);
                 ai0 = oA + 4u * (unsigned)(ctb + L);
@@ -1326,9 +1327,14 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 const float2 *so = reinterpret_cast<const float2 *>(lds(li_b));
                 oldA = as_v2f(so[0]); oldB = as_v2f(so[1]);
                 if constexpr (BIG) {
+                    // the magnitudes of this pair were requested one fetch ago; those of the next pair are requested now (a lane
+                    // that changes frames has two idle steps ahead of it: the queue holds the new frame's values when it needs them).
                     // (bin 2 uc + 1 of the last pair is one past the frame's bins: the caller's buffer has a pad column there)
-                    target_a = ga0[2 * uc];
-                    target_b = __int_as_float(__float_as_int(ga0[2 * uc + 1]) | tab.w);
+                    target_a = tq_a;
+                    target_b = __int_as_float(__float_as_int(tq_b) | tab.w);
+                    const unsigned u1 = (unsigned)clampu(un + 1);
+                    tq_a = ga0[2 * u1];
+                    tq_b = ga0[2 * u1 + 1];
                 } else {
                     const float *ta = reinterpret_cast<const float *>(lds(ai0 + 8u * uc));
                     target_a = ta[0];
