@@ -1304,7 +1304,8 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             auto derive = [&]() __attribute__((always_inline)) {
                 li0 = oS + 8u * (unsigned)(ctb + L);
                 ai0 = oA + 4u * (unsigned)(ctb + L);
-                if constexpr (BIG) ga0 = gA + (size_t)e_own * Npu + a.Lu;
+                // (a lane whose slot holds no sweep, or a frame past the last one, still fetches: keep its row inside the buffer)
+                if constexpr (BIG) ga0 = gA + (size_t)(e_own < 0 ? 0 : (e_own > Tp - 1 ? Tp - 1 : e_own)) * Npu + a.Lu;
                 xl0 = oS + 8u * (unsigned)(fbm1 + 1 + 2 * L);
                 et0 = oET + (unsigned)(wset * NST * 96);
             };

@@ -10,12 +10,12 @@ from lws_amd import _capi
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 cfgs = [(64, 16), (64, 32), (64, 8), (128, 32), (256, 64), (256, 32), (512, 128), (512, 64), (1024, 256), (1024, 512), (1024, 128),
-        (1000, 250), (2048, 512), (60, 15)]
+        (1000, 250), (2048, 512), (60, 15), (4096, 1024), (3000, 750), (4096, 2048)]
 bad = 0
 for it in range(cases):
     fs, sh = cfgs[rng.integers(len(cfgs))]
     F = fs // 2 + 1
-    T = int(rng.integers(1, 60))
+    T = int(rng.integers(1, 60 if fs <= 2048 else 24))
     LA = int(rng.integers(0, 8))
     iters = int(rng.integers(1, 9))
     B = int(rng.integers(1, 3))
