@@ -44,7 +44,7 @@
 #include <utility>
 
 namespace lws {
-#ifdef LWS_LAB   // tools/lab/online_lab.hip: per-wave phase stamps of k_online3 (block 0), clocks summed over the steps
+#ifdef LWS_LAB   // tools/online_lab.hip: per-wave phase stamps of k_online3 (block 0), clocks summed over the steps
 #define LAB_N 256
 __device__ unsigned long long g_lab[LAB_N];
 __device__ __forceinline__ unsigned long long lab_now() {

@@ -1,0 +1,73 @@
+"""CPU: the ONE line bench.py prints for the driver stays compact and strict JSON (round 3's 24 KB line came back unparsed),
+and config 4's 8-way split is what lws_amd/dist.py produces."""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (torch is only imported inside bench.main)
+
+
+def _canned(world):
+    W = np.zeros((4, 4, 6), dtype=np.complex128)
+    W[:, :, :] = 0.1 + 0.2j
+    head = {"value": 1.970123456789e11 * world, "ms_per_step": 33.312345678, "storage": "fp32", "batch_per_gpu": 256, "frames": 500,
+            "bins": 513, "iters": 100, "schedule": "dense", "fshift": 256,
+            "workload": "x" * 400, "data": "y" * 200}
+    roof = bench.roofline_block(131.328e9, 32.4123456, 6.5664e9, W, 2.034e10, "profiles/r04_pmc_traffic.json (" + "z" * 300 + ")",
+                                "systolic_q4_l5_hann_with_a_rather_long_kernel_name", 1.0, "valu")
+    roof["frac_of_measured_copy"] = 0.654321
+    cpu = {"value": 3.68e7, "unit": "bin*iter/s", "cores": 1, "kind": "reference", "sample": "1 spectrogram 500x513, 23 dense sweeps, fp64, single thread",
+           "all_cores_value": 3.66e8, "all_cores": 256}
+    return head, roof, cpu
+
+
+def test_final_line_is_compact_strict_json():
+    for world in (1, 2, 4, 8):
+        head, roof, cpu = _canned(world)
+        txt = bench.final_line(head, world, 20, 5, 1024, roof, cpu, "gpurun_out/bench_extra.json", "n" * 500)
+        assert len(txt) < 2048 and "\n" not in txt
+        d = json.loads(txt, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))     # NaN / Infinity would raise
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, k
+        assert d["n_gpus"] == world and d["config"]["parallelism"] == "shard%d" % world and "workload" in d["config"]
+        r = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_per_step", "algorithmic_bytes_per_launch"):
+            assert k in r, k
+        assert math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-4)
+        assert math.isclose(r["achieved"], 131.328e9 / 32.4123456e-3 / 1e9, rel_tol=1e-4)
+        assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "reference"
+
+
+def test_non_finite_numbers_become_null():
+    head, roof, cpu = _canned(1)
+    roof["traffic"] = float("nan")
+    roof["hbm_measured_frac"] = float("inf")
+    txt = bench.final_line(head, 1, 3, 1, 1024, roof, None)
+    d = json.loads(txt)
+    assert d["roofline"]["traffic"] is None and d["roofline"]["hbm_measured_frac"] is None and d["cpu_baseline"] is None
+    assert "NaN" not in txt and "Infinity" not in txt
+
+
+def test_summary_lines_are_short_and_never_json_objects():
+    extra = {"configs": {"5": {"ms_per_step": 4500.0, "roofline": {"frac": 0.41, "valu": {"frac_naive": 0.5}, "kernel_ms_per_step": 4480.0, "kernel": "k" * 500}},
+                         "bad": {"error": "e" * 1000}, "odd": {"roofline": {}}}}
+    ls = bench.summary_lines(extra)
+    assert ls and all(len(l) <= 300 and l.startswith("#") for l in ls)
+
+
+def test_config4_split_is_eight_contiguous_shards_of_1024():
+    from lws_amd.dist import shard_range
+    got = [shard_range(8192, r, 8) for r in range(8)]
+    assert got == [(1024 * r, 1024 * (r + 1)) for r in range(8)]
+    # ragged totals: contiguous, complete, sizes differ by at most one
+    for n, w in ((8191, 8), (5, 8), (1000, 3)):
+        rs = [shard_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in rs]
+        assert max(sizes) - min(sizes) <= 1

@@ -109,16 +109,20 @@ def test_bench_py_runs_its_multi_rank_branch():
     env = dict(os.environ, LWS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--extra-file", os.path.join(ROOT, "gpurun_out", "bench_extra_2ranks.json")]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE JSON line
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 2048      # the LAST line, compact (the driver parses it)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "shard2"
     B, T, F, it = d["config"]["batch_per_gpu"], d["config"]["frames"], d["config"]["bins"], d["config"]["iters"]
     assert np.isclose(d["value"], 2.0 * B * T * F * it / (d["ms_per_step"] * 1e-3), rtol=1e-9)   # whole job: both ranks' units
     assert d["roofline"]["frac"] > 0 and d["roofline"]["valu"]["frac_naive"] > 0
-    assert "4shard" in d["extra"]["configs"] and d["extra"]["configs"]["4shard"]["batch_per_gpu"] == 1024
-    assert np.isfinite(d["extra"]["residual_db_after"]) and np.isfinite(d["extra"]["consistency_db_after"])
-    assert d["extra"]["headline_checks"]["max_rel_magnitude_error"] < 1e-6
+    full = json.load(open(os.path.join(ROOT, d["extra_file"])))     # everything that is not the contract's line
+    ex = full["extra"]
+    assert "4shard" in ex["configs"] and ex["configs"]["4shard"]["batch_per_gpu"] == 1024
+    assert np.isfinite(ex["residual_db_after"]) and np.isfinite(ex["consistency_db_after"])
+    assert ex["headline_checks"]["max_rel_magnitude_error"] < 1e-6

@@ -1,7 +1,7 @@
 // online_lab.hip -- timing harness for the online LDS kernels (lws_online.hip) on BASELINE config 3's shape, without Python:
 // random state / magnitudes / weights (timing does not depend on the values), launch_online_lds directly, HIP events, and --
 // when built with -DLWS_LAB -- the per-wave phase stamps the kernel leaves in g_lab.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DLWS_LAB -I include -I lws_amd/csrc tools/lab/online_lab.hip -o online_lab
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DLWS_LAB -I include -I lws_amd/csrc tools/online_lab.hip -o online_lab
 //   ./online_lab [B] [T] [F] [LA] [iters] [reps]
 #include "../../lws_amd/csrc/lws_online.hip"
 #include <cstdio>

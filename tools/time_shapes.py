@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import time, numpy as np, torch, lws_amd
 from lws_amd import _capi
 def t(fsize, fshift, B=256, T=500, iters=100):
