@@ -172,6 +172,11 @@ struct lws_plan {
     void *host_pool = nullptr;     // HostWorkers of the host-array entry points (kept between calls: 32 thread starts cost ~1 ms)
     int host_pool_n = 0;
     hipEvent_t ev_after_load = nullptr;   // if set: recorded by run_pipeline between its light first kernels and the update kernels
+    // The plan's scratch (state, amp, thresholds, the skewed layouts, progress counters) is shared by all of its calls.  A *_dev
+    // call only enqueues work; the next call of the plan -- on another stream, or a host-array call on the pipeline's private
+    // streams -- must run after it: every call records ev_busy behind its last kernel and waits for the previous one's.
+    hipEvent_t ev_busy = nullptr;
+    bool busy = false;
     bool timing_pending = false;
     float last_ms = 0.f;
     int last_launches = 0;
@@ -329,6 +334,8 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
             // no room after all: give back what was taken and run in the plain layout (same results, bit for bit)
             p->gsk_state.release(); p->gsk_amp.release();
             have_copy = false;
+            (void)hipGetLastError();   // the refused hipMalloc must not be what the plain-layout launch below reports
+            g_err.clear();
         }
         if (have_copy) {
             begin_timing(p, s);
@@ -559,7 +566,14 @@ int host_chunk(size_t per, int B, int n_cu, bool whole_device = false) {
     const size_t target = (size_t)std::max(1, env_int("LWS_HOST_CHUNK_BINS", 16 << 20));
     if (per * (size_t)B <= target + target / 2) return B;
     int bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, (target + per / 2) / per));
-    if (whole_device && n_cu > 1 && !env_int("LWS_HOST_CHUNK_EXACT", 0)) return std::min(B, std::max(n_cu, bc - bc % n_cu));
+    if (whole_device && n_cu > 1 && !env_int("LWS_HOST_CHUNK_EXACT", 0)) {
+        bc = std::min(B, std::max(n_cu, bc - bc % n_cu));
+        // ... but the pipeline pins four host buffers of a chunk each (and holds two on the device): long spectrograms are cut
+        // below a device's worth (half, a quarter, ... of the CUs busy in the one-workgroup stages) rather than pin tens of GB
+        const size_t pin_limit = (size_t)std::max(1, env_int("LWS_HOST_PIN_MB", 2048)) << 20;
+        while (bc > 1 && (size_t)bc * per * sizeof(float2) > pin_limit) bc = (bc + 1) / 2;
+        return bc;
+    }
     // a launch of fewer spectrograms than CUs gives each floor(CUs / spectrograms) workgroups (lws_systolic.hip: prepare):
     // 65 spectrograms on 256 CUs keep 195 of them busy, 64 all of them -- round to a divisor / multiple of the CU count
     if (n_cu > 1 && !env_int("LWS_HOST_CHUNK_EXACT", 0)) {
@@ -578,6 +592,21 @@ int cu_count(int device) {
 // streams do overlap -- 2 x 64 spectrograms on two streams take the time of one, 33 ms -- but a process gets four hardware
 // queues by default and twelve streams share them: 170 ms instead of 61; with one stream per lane the gain over this
 // pipeline is bounded by ~10 %, the exposed first upload and last download being what they are.)
+// the stream `s` is about to use the plan's scratch: after whatever the plan enqueued last
+int order_after_plan_work(lws_plan *p, hipStream_t s) {
+    if (p->busy) HIP_TRY(hipStreamWaitEvent(s, p->ev_busy, 0));
+    return LWS_OK;
+}
+// ... and `s` now carries the plan's latest work
+int note_plan_work(lws_plan *p, hipStream_t s) {
+    if (!p->ev_busy) HIP_TRY(hipEventCreateWithFlags(&p->ev_busy, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->ev_busy, s));
+    p->busy = true;
+    return LWS_OK;
+}
+
+int run_host_monolithic(lws_plan *p, const double *S_in, double *S_out, int B, int T, const StageSpec *st, int n);
+
 int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, int T, const StageSpec *st, int n) {
     const size_t per = (size_t)T * p->F;                       // bins of a spectrogram
     const size_t total = per * (size_t)B;
@@ -597,7 +626,16 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     HIP_TRY(hipSetDevice(p->device));
     HostPipe &hp = p->pipe;
     int rc = hp.ensure((size_t)Bc * per * sizeof(float2), nch > 1 ? 2 : 1);
+    if (rc == LWS_ERR_NOMEM) {
+        // no room for the pinned staging buffers (a one-workgroup-per-spectrogram stage makes chunks of at least a device's
+        // worth of spectrograms): the unpipelined path needs no pinned memory
+        hp.release();
+        (void)hipGetLastError();
+        g_err.clear();
+        return run_host_monolithic(p, S_in, S_out, B, T, st, n);
+    }
     if (rc) return rc;
+    if ((rc = order_after_plan_work(p, hp.s_comp))) return rc;   // (*_dev calls enqueued earlier use the same scratch)
     if (p->host_pool && p->host_pool_n != nthreads) { delete static_cast<HostWorkers *>(p->host_pool); p->host_pool = nullptr; }
     if (!p->host_pool) { p->host_pool = new HostWorkers(nthreads); p->host_pool_n = nthreads; }
     HostWorkers &pool = *static_cast<HostWorkers *>(p->host_pool);
@@ -718,6 +756,7 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
         }
         for (int c = 0; c < nch && c < 16; ++c) { (void)hipEventDestroy(tr0[c]); (void)hipEventDestroy(tr1[c]); }
     }
+    p->busy = false;     // every chunk has come down: nothing of this plan is in flight
     return check_systolic_flag(p);
 }
 
@@ -734,10 +773,18 @@ int run_host(lws_plan *p, const double *S_in, double *S_out, int B, int T, const
         return LWS_OK;
     }
     if (!p->fp64 && !env_int("LWS_HOST_MONOLITHIC", 0)) return run_host_pipelined(p, S_in, S_out, B, T, st, n);
-    // fp64 plans (the reference's arithmetic; the parity anchor): one complex128 copy each way around the stages
+    return run_host_monolithic(p, S_in, S_out, B, T, st, n);
+}
+
+// fp64 plans (the reference's arithmetic; the parity anchor), and fp32 plans without room for pinned staging: one complex128
+// copy each way around the stages
+int run_host_monolithic(lws_plan *p, const double *S_in, double *S_out, int B, int T, const StageSpec *st, int n) {
+    const size_t count = (size_t)B * T * p->F;
+    int rc;
     HIP_TRY(hipSetDevice(p->device));
     if ((rc = p->stage.ensure(count * sizeof(double2)))) return rc;
     hipStream_t s = nullptr;
+    if ((rc = order_after_plan_work(p, s))) return rc;
     HIP_TRY(hipMemcpyAsync(p->stage.p, S_in, count * sizeof(double2), hipMemcpyHostToDevice, s));
     double2 *io = static_cast<double2 *>(p->stage.p);
     if (p->fp64) rc = run_pipeline<double, double2>(p, io, io, io, B, T, st, n, s);
@@ -745,6 +792,7 @@ int run_host(lws_plan *p, const double *S_in, double *S_out, int B, int T, const
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(S_out, p->stage.p, count * sizeof(double2), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    p->busy = false;
     return check_systolic_flag(p);
 }
 
@@ -758,12 +806,16 @@ int run_dev(lws_plan *p, void *S_dev, int B, int T, const StageSpec *st, int n, 
     if (!any || B == 0) return LWS_OK;
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = order_after_plan_work(p, s))) return rc;   // (a no-op on the stream that carries the previous call)
     if (p->fp64) {
         double2 *io = static_cast<double2 *>(S_dev);
-        return run_pipeline<double, double2>(p, io, io, io, B, T, st, n, s);
+        rc = run_pipeline<double, double2>(p, io, io, io, B, T, st, n, s);
+    } else {
+        float2 *io = static_cast<float2 *>(S_dev);
+        rc = run_pipeline<float, float2>(p, io, io, io, B, T, st, n, s);
     }
-    float2 *io = static_cast<float2 *>(S_dev);
-    return run_pipeline<float, float2>(p, io, io, io, B, T, st, n, s);
+    if (rc) return rc;
+    return note_plan_work(p, s);
 }
 
 }  // namespace
@@ -892,6 +944,7 @@ void lws_plan_destroy(lws_plan *p) {
     delete static_cast<HostWorkers *>(p->host_pool);
     p->host_pool = nullptr;
     lws::systolic_entry().release(p->sys);   // (the same code in every build)
+    if (p->ev_busy) (void)hipEventDestroy(p->ev_busy);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;

@@ -1418,7 +1418,10 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 fetch(u, tab1);
                 tab1 = tab2;
                 tab2 = tab3;
-                asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
+                // (BIG: the step-table entry is computed and the targets come from global memory -- two LDS reads fewer follow the
+                // stores, ~8 remain: a count of 5 keeps a margin of three instructions against a reordering by the compiler)
+                if constexpr (BIG) asm volatile("s_waitcnt lgkmcnt(5)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
             };
             derive();
             fetch(u, fetch_tab(u));

@@ -2213,16 +2213,17 @@ template <int Q, int L, uint64_t MASK, bool MULTI, bool H16, int RE> hipError_t 
         // occupancy figure for this very kernel (once per kernel and process): a grid it cannot hold is refused, not launched.
         // (What no query sees -- a device shared with another process -- is covered by the hand-over time-out and the
         // device-side re-run with one workgroup per spectrogram, run_kernel.)
-        static std::atomic<int> per_cu{-1};
-        int occ = per_cu.load(std::memory_order_relaxed);
+        static std::atomic<int> per_cu[64];             // per device (zero-initialised: 0 = not asked yet, else figure + 1)
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorUnknown;
+        std::atomic<int> &slot = per_cu[dev & 63];
+        int occ = slot.load(std::memory_order_relaxed) - 1;
         if (occ < 0) {
             int q = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_systolic<Q, L, MASK, MULTI, H16, RE>, NTHREADS, LDS_BYTES) != hipSuccess) q = 0;
-            per_cu.store(q, std::memory_order_relaxed);
+            slot.store(q + 1, std::memory_order_relaxed);
             occ = q;
         }
-        int dev = 0, n_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorUnknown;
         if (occ < 1 || (long)grid > (long)occ * n_cu) return hipErrorLaunchOutOfResources;
     }
     hipLaunchKernelGGL((k_systolic<Q, L, MASK, MULTI, H16, RE>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
@@ -2553,7 +2554,7 @@ hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *th
     }
     if ((e = ensure_thr_chunk(sp, B, iters)) != hipSuccess) return e;
     int n_launch = 0;
-    bool multi = false;
+    bool multi = false, refused0 = false, refused1 = false;
     // every sweep of the call, either with the workgroup counts of `g` or (single) with one workgroup per spectrogram
     auto sweep_all = [&](bool single, const int *gate) -> hipError_t {
         // more sweeps than one launch's threshold table holds: several launches over the same (resident) skewed state.
@@ -2577,8 +2578,17 @@ hipError_t run_kernel(SystolicPlan &sp, const Geom &g, int wsel, const float *th
                 if (nwg > 1 && n_launch > 0) {   // multi-workgroup launches re-use the counters: start them from zero again
                     if ((e = hipMemsetAsync(progress, 0, (size_t)nb * nwg * WPS * sizeof(unsigned), stream)) != hipSuccess) return e;
                 }
-                if ((e = launch_update(sp, g, wsel, thr_c, n_it, b0, nb, nwg, progress, gate, T, stream)) != hipSuccess) return e;
-                multi |= nwg > 1;
+                e = launch_update(sp, g, wsel, thr_c, n_it, b0, nb, nwg, progress, gate, T, stream);
+                if (e == hipErrorLaunchOutOfResources && nwg > 1 && it0 == 0) {
+                    // the occupancy guard refused a grid of several workgroups per spectrogram (launch_km): nothing was launched for
+                    // these spectrograms -- serve them with one workgroup each (same results), here and in the launches that follow
+                    (void)hipGetLastError();
+                    if (chunk == 0) refused0 = true; else refused1 = true;
+                }
+                if ((chunk == 0 ? refused0 : refused1) && nwg > 1)
+                    e = launch_update(sp, g, wsel, thr_c, n_it, b0, nb, 1, progress, gate, T, stream);
+                else multi |= nwg > 1;
+                if (e != hipSuccess) return e;
                 if (!gate) ++n_launch;
             }
         }
