@@ -914,9 +914,13 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
         const bool no_short = env_int("LWS_SYSTOLIC_NO_SHORT", 0) != 0;
         for (const lws::SystolicBuild *b : {&lws::quarter_q2::systolic_entry(), &lws::quarter::systolic_entry(), &lws::half_q2::systolic_entry(), &lws::half::systolic_entry(),
                                             &lws::q2::systolic_entry(), &lws::systolic_entry(),
-                                            &lws::q8::systolic_entry(), &lws::wide_q2::systolic_entry(), &lws::wide::systolic_entry(), &lws::xwide::systolic_entry(), &lws::l7::systolic_entry()}) {
+                                            &lws::q8::systolic_entry(), &lws::wide_q2::systolic_entry(), &lws::wide::systolic_entry(), &lws::xwide::systolic_entry(), &lws::l7::systolic_entry(),
+                                            // ... then the table-twiddle builds: Q = 3, and general weights of a hop that does not divide the frame
+                                            &lws::tw_half::systolic_entry(), &lws::tw::systolic_entry()}) {
             const bool is_short = b == &lws::quarter::systolic_entry() || b == &lws::half::systolic_entry() || b == &lws::quarter_q2::systolic_entry() ||
-                                  b == &lws::half_q2::systolic_entry();
+                                  b == &lws::half_q2::systolic_entry() || b == &lws::tw_half::systolic_entry();
+            const bool is_tw = b == &lws::tw_half::systolic_entry() || b == &lws::tw::systolic_entry();
+            if (is_tw && env_int("LWS_SYSTOLIC_NO_TW", 0)) continue;                                 // (comparison runs)
             const bool is_r16 = b == &lws::q2::systolic_entry() || b == &lws::wide_q2::systolic_entry() || b == &lws::quarter_q2::systolic_entry() ||
                                 b == &lws::half_q2::systolic_entry();
             if ((no_short && is_short) || (is_r16 && env_int("LWS_SYSTOLIC_NO_R16", 0))) continue;   // (comparison runs)
@@ -943,7 +947,7 @@ void lws_plan_destroy(lws_plan *p) {
     p->pipe.release();
     delete static_cast<HostWorkers *>(p->host_pool);
     p->host_pool = nullptr;
-    lws::systolic_entry().release(p->sys);   // (the same code in every build)
+    (p->sysb ? p->sysb : &lws::systolic_entry())->release(p->sys);
     if (p->ev_busy) (void)hipEventDestroy(p->ev_busy);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);

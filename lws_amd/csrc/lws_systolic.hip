@@ -96,10 +96,32 @@
 // (LWS_R16 also combines with LWS_WIDE=1 -- namespace lws::wide_q2, frames of up to 1025 bins: seven sweep slots of two waves
 //  instead of three)
 // (... and with LWS_SPW=2 / 4 -- lws::half_q2, lws::quarter_q2, frames of up to 257 / 129 bins: 26 / 44 sweep slots)
+// ... and with -DLWS_TW=1 (namespace lws::tw; with -DLWS_SPW=2: lws::tw_half) for weights whose twiddle is NOT a multiple of an
+// eighth turn: Q = 3 (hop = a third of the frame), and the "general" weights create_weights builds for a hop that does not
+// divide the frame (lws.pyx:164-181: Q' = N rows, one per bin; e.g. 25 ms frames every 10 ms, lws(400, 160): Q = 3, Qfloat = 2.5),
+// the reference's LWSanyQ with Q = 3 and its LWSfractionalQ (lwslib.cpp:283-467).  Those tensors still are
+//     W[p][r][k] = W[0][r][k] tau_r(p),   tau_r(p) = exp(2 pi j p r s / P),   s / P = hop / frame in lowest terms,
+// so the kernel keeps the base weights W[0][r][k] in scalar registers as ever and takes tau_r(bin) -- now a per-lane value that
+// no unrolling of the step loop makes static -- from a table in LDS ((P + 8) rows of Q - 1 twiddles; a lane carries the row of
+// its block's first bin).  The taps of frames m-r and m+r are summed separately (U, D: every tap its own multiply-add, as
+// LWSanyQ does, instead of the grouped LWSQ4 form) and enter the bin's sum as tau U + conj(tau) D.  Same schedule, rings,
+// images and flow control as the narrow build; ~1.4x its instructions per tap.
+#ifndef LWS_TW
+#define LWS_TW 0
+#endif
+#if LWS_TW && (LWS_WIDE || LWS_Q8 || LWS_L7 || LWS_R16 || LWS_SPW == 4)
+#error "LWS_TW goes with the narrow build or with LWS_SPW=2"
+#endif
 #if (LWS_WIDE && LWS_Q8) || ((LWS_SPW != 1 || LWS_L7) && (LWS_WIDE || LWS_Q8)) || (LWS_SPW != 1 && LWS_L7) || (LWS_R16 && (LWS_WIDE == 2 || LWS_Q8 || LWS_L7))
 #error "LWS_WIDE, LWS_Q8, LWS_SPW, LWS_L7 and LWS_R16 are separate builds (LWS_R16 goes with LWS_WIDE=1 or LWS_SPW)"
 #endif
-#if LWS_R16 && LWS_WIDE
+#if LWS_TW && LWS_SPW == 2
+#define LWS_NS_OPEN namespace lws { namespace tw_half {
+#define LWS_NS_CLOSE } }
+#elif LWS_TW
+#define LWS_NS_OPEN namespace lws { namespace tw {
+#define LWS_NS_CLOSE } }
+#elif LWS_R16 && LWS_WIDE
 #define LWS_NS_OPEN namespace lws { namespace wide_q2 {
 #define LWS_NS_CLOSE } }
 #elif LWS_R16 && LWS_SPW == 2
@@ -192,7 +214,15 @@ __host__ __device__ constexpr int help_ahead(int h) { return h >= 1 ? 4 : 4; }
 constexpr int MBOX_OFF = SCRATCH_OFF + SCRATCH_BYTES;    // [slot][helper][pair & 3][lane]: (sum of the first bin, of the second)
 constexpr int MBOX_BYTES = NSLOTS * NHELP * 4 * LANES * 16;
 constexpr int WNYQ_OFF = MBOX_OFF + MBOX_BYTES;          // Q = 8: the Nyquist lanes' weights (the waves keep only their own in registers)
-constexpr int LDS_BYTES = WNYQ_OFF + (LWS_Q8 ? QMAX * 6 * 8 : 0);
+constexpr int LDS_BASE_BYTES = WNYQ_OFF + (LWS_Q8 ? QMAX * 6 * 8 : 0);
+// LWS_TW: the twiddle table, [row][r - 1] float2 with row = bin mod P, rows 0 .. P + 7 (a lane holds the row of its block's first
+// bin; the other seven bins of the block are compile-time offsets from it); a row is TW_ROW bytes: tau_1, tau_2, tau_3, unused
+constexpr bool TW = LWS_TW != 0;
+constexpr int TW_ROW = 32;
+constexpr int TW_OFF = (LDS_BASE_BYTES + 15) & ~15;
+constexpr int TW_PMAX = TW ? ((160 * 1024 - TW_OFF) / TW_ROW - 8 < 128 ? (160 * 1024 - TW_OFF) / TW_ROW - 8 : 128) : 0;   // longest twiddle period served
+constexpr int LDS_BYTES = TW ? TW_OFF + (TW_PMAX + 8) * TW_ROW : LDS_BASE_BYTES;
+static_assert(!TW || TW_PMAX >= 16, "no room for a twiddle table");
 __host__ __device__ constexpr int mbox_addr(int slot, int h, int pair) { return MBOX_OFF + ((slot * NHELP + (h - 1)) * 4 + (pair & 3)) * LANES * 16; }
 constexpr int SKEW = LWS_L7 ? 16 : 8, ROWP = SKEW * ROWL, LAG = RING;
 constexpr int LATE_DN = LAG / SKEW - 1;                  // frame m + LATE_DN of the previous sweep is only SKEW steps ahead of a lane (as frame m - 1 of its own sweep is)
@@ -292,6 +322,11 @@ struct SysArgs {
     int rolemap;             // experiment hook (LWS_SYSTOLIC_ROLEMAP): which hardware wave takes which role, wide build
     int stress;              // test hook (LWS_SYSTOLIC_STRESS): role mask | pair << 16 -- the waves of the mask stall ~10 us
                              // before that pair of every block; the flow control must make the results independent of it
+    // LWS_TW: twiddles tau_r(p) = exp(2 pi j p r s / P) of general weights
+    const float *tw_table;   // device: [(P + 8)][4] float2, row p: tau_1(p), tau_2(p), tau_3(p), 0
+    int tw_P;                // period of the twiddles in bins
+    float tw_invP;
+    unsigned long long tw_nyq[4];  // tau_r(F-1), r = 0..3, for the Nyquist lanes: bit patterns of (re, im)
     unsigned long long w[NW];      // W[0][r][k], r < Q, k <= L (at most 4 x 8): bit patterns of (re, im) as one 64-bit scalar;
                                    // Q = 8: [set][r][k] with set 1 = W[0][r][k] exp(j pi / 4), see widx()
 };
@@ -439,6 +474,7 @@ struct LaneCtx {
     int wlo[NDR], whi[NDR];
     int whi1[NDR];                  // RE != 0: the same as whi for the lane in the block before its end block (cells from th1 on)
     int mbox;                       // Q = 8: mailbox of the slot's first helper, pair 0 (own lane)
+    int tw;                         // LWS_TW: LDS address of the twiddle-table row of this block's first bin
     int img_lo, img_hi, img_both;   // image_base(): row origin for the image stores of this block (phases with an image below DC / above
                                     // Nyquist / both)
 };
@@ -752,6 +788,35 @@ template <int ROT> __device__ __forceinline__ void pair_rot_real(float2 &a, wp_t
     else LWS_REAL_ASM(LWS_NEG2, LWS_M2_3);
     a = ff(acc);
 }
+// ---- LWS_TW (per-lane twiddles) ----------------------------------------------------------------------------------
+// acc += w b + conj(w) c with the weight in a VGPR pair: the twiddle of the lane's bin
+__device__ __forceinline__ void pair_v(float2 &a, float2 wv, float2 b, float2 c) {
+    v2f acc = vv(a), t0, t1;
+    const v2f vb = vv(b), vc = vv(c), w = vv(wv);
+    asm("v_pk_add_f32 %[s], %[b], %[c]\n\t"
+        "v_pk_add_f32 %[d], %[b], %[c]" LWS_NEG2 "\n\t"
+        "v_pk_fma_f32 %[a], %[w], %[s], %[a] " LWS_M1_0 "\n\t"
+        "v_pk_fma_f32 %[a], %[w], %[d], %[a] " LWS_M2_0
+        : [a] "+v"(acc), [s] "=&v"(t0), [d] "=&v"(t1)
+        : [w] "v"(w), [b] "v"(vb), [c] "v"(vc));
+    a = ff(acc);
+}
+// acc += w v (CONJ = 0) or conj(w) v (CONJ = 1), w a base weight
+template <int CONJ> __device__ __forceinline__ void cmul_w(float2 &a, wp_t w, float2 v) {
+    v2f acc = vv(a);
+    const v2f x = vv(v);
+    if constexpr (CONJ == 0)
+        asm("v_pk_fma_f32 %[a], %[w], %[v], %[a] " LWS_M1_0 "\n\t"
+            "v_pk_fma_f32 %[a], %[w], %[v], %[a] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+            : [a] "+v"(acc) : [w] LWS_WREG(w), [v] "v"(x));
+    else
+        asm("v_pk_fma_f32 %[a], %[w], %[v], %[a] " LWS_M1_0 "\n\t"
+            "v_pk_fma_f32 %[a], %[w], %[v], %[a] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
+            : [a] "+v"(acc) : [w] LWS_WREG(w), [v] "v"(x));
+    a = ff(acc);
+}
+__device__ __forceinline__ float2 cmulf(float2 p, float2 q) { return make_float2(p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x); }
+__device__ __forceinline__ float2 wp_value(wp_t w) { return make_float2(__uint_as_float((unsigned)(w & 0xffffffffull)), __uint_as_float((unsigned)(w >> 32))); }
 __device__ __forceinline__ float2 cadd(float2 p, float2 q) { return ff(vv(p) + vv(q)); }
 __device__ __forceinline__ float2 csub(float2 p, float2 q) { return ff(pk_sub(vv(p), vv(q))); }
 
@@ -926,6 +991,49 @@ __device__ __forceinline__ void quad_finish(const SysArgs &a, const QuadCarry<L>
     }
 }
 
+// LWS_TW: contribution of frames m-R and m+R to the bin at phase PH (bin OFFS of the quad), twiddle from the table:
+//   tau U + conj(tau) D,   U = sum_k W0[R][k] S[m-R,c-k] + conj(W0[R][k]) S[m-R,c+k],   D = sum_k W0[R][k] S[m+R,c+k] + conj(W0[R][k]) S[m+R,c-k]
+// (lwslib.cpp:321-352 with W[mod] = W0 tau, W[modneg] = W0 conj(tau)).  The one group whose last operand is not in the ring yet
+// (fourth bin, k = L, frames m-1 / m+LATE_DN) is left to the second pair as in the other builds (QuadCarry::g, tw_finish).
+template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int N>
+__device__ __forceinline__ void tw_rows(const SysArgs &a, const LaneCtx &cx, const float2 (&tu)[N], const float2 (&td)[N],
+                                        float2 &accr, QuadCarry<L> &qc) {
+    constexpr int K1 = L + 1, c = L + 1 + OFFS;
+    static_assert(c + L < N && PH >= 0 && PH < 8, "tap window too short");
+    float2 U = make_float2(0.f, 0.f), D = make_float2(0.f, 0.f);
+    static_for<L + 1>([&](auto ik) {
+        constexpr int k = decltype(ik)::value;
+        if constexpr (((MASK >> (R * K1 + k)) & 1ull) != 0) {
+            const wp_t w = a.w[widx<Q, L>(0, R, k)];
+            if constexpr (k == 0) {
+                cmul_w<0>(U, w, tu[c]);
+                cmul_w<1>(D, w, td[c]);
+            } else if constexpr (quad_deferred<OFFS, k, L>() && (quad_late_frame<-R, L>() || quad_late_frame<R, L>())) {
+                qc.g[R][0] = tu[c - k];
+                if constexpr (!quad_late_frame<-R, L>()) qc.g[R][1] = tu[c + k];
+                qc.g[R][2] = td[c - k];
+                if constexpr (!quad_late_frame<R, L>()) qc.g[R][3] = td[c + k];
+            } else {
+                pair_rot<0>(U, w, tu[c - k], tu[c + k]);
+                pair_rot<0>(D, w, td[c + k], td[c - k]);
+            }
+        }
+    });
+    pair_v(accr, lds_read(cx.tw + PH * TW_ROW + (R - 1) * 8), U, D);
+}
+// ... and the deferred group, by the second pair: `late` is the tap that was not there yet (frame m-R's or m+R's, at +L)
+template <int Q, int L, uint64_t MASK, int PH, int R>
+__device__ __forceinline__ void tw_finish(const SysArgs &a, const LaneCtx &cx, const QuadCarry<L> &qc, float2 late, float2 &accr) {
+    constexpr int K1 = L + 1;
+    if constexpr ((MASK >> (R * K1 + L)) & 1ull) {
+        const wp_t w = a.w[widx<Q, L>(0, R, L)];
+        float2 U = make_float2(0.f, 0.f), D = make_float2(0.f, 0.f);
+        pair_rot<0>(U, w, qc.g[R][0], quad_late_frame<-R, L>() ? late : qc.g[R][1]);
+        pair_rot<0>(D, w, quad_late_frame<R, L>() ? late : qc.g[R][3], qc.g[R][2]);
+        pair_v(accr, lds_read(cx.tw + PH * TW_ROW + (R - 1) * 8), U, D);
+    }
+}
+
 // Cells C0 .. C0+NC-1 of the taps frame m+DR contributes to the quad that starts at phase PA0 (0 or 4): t[j] is the tap at
 // block-relative bin PA0 - L - 1 + j, so bin PA0 + OFFS sits at t[L + 1 + OFFS] and cell i = (t[2i], t[2i+1]) is one aligned
 // 16-byte ring cell (even time, odd time).  The window is t[1] .. t[2L+4]: of cells 0 and L+2 only one half is read.
@@ -1030,7 +1138,38 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     centre_sum<L, MASK, PA, PA, RE>(a, cx, st, en, cr.o0, cr.o1, cr.prev_out, accA);
     // frame pairs m-+R.  With FLAG_R13 rows 3 leave partial sums for rows 1: order 2, 3, 1 keeps them short-lived.
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
-    if constexpr (quad_first) {
+    if constexpr (TW && quad_first) {
+        // (LWS_TW: the same windows; per frame pair the sums U, D of each of the quad's four bins, turned by the bin's twiddle)
+        static_assert(LATE_DN != 1 && NHELP == 0 && !r13, "narrow geometry");
+        qc.accA = make_float2(0.f, 0.f);
+        qc.accB = make_float2(0.f, 0.f);
+        static_for<Q - 1>([&](auto ir) {
+            constexpr int R = decltype(ir)::value + 1;
+            float2 tu[2 * L + 6], td[2 * L + 6];
+            constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
+            load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, tu);
+            load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, td);
+            tw_rows<Q, L, MASK, PA, R, 0>(a, cx, tu, td, accA, qc);
+            tw_rows<Q, L, MASK, PA + 1, R, 1>(a, cx, tu, td, accB, qc);
+            tw_rows<Q, L, MASK, PA + 2, R, 2>(a, cx, tu, td, qc.accA, qc);
+            tw_rows<Q, L, MASK, PA + 3, R, 3>(a, cx, tu, td, qc.accB, qc);
+            if constexpr (R == 1) LWS_SETPRIO(0);
+            if constexpr (R == Q - 1) LWS_SETPRIO(2);
+        });
+    } else if constexpr (TW) {
+        accA = cadd(accA, qc.accA);
+        accB = cadd(accB, qc.accB);
+        if constexpr (quad_late_frame<-1, L>()) {
+            float2 u1[2 * L + 6], d3[2 * L + 6];
+            load_cells<PA0, -1, L, L + 2, 1, (uint32_t)((MASK >> K1) & ((1ull << K1) - 1ull)), 0, RE>(cx, u1);
+            tw_finish<Q, L, MASK, PHB, 1>(a, cx, qc, u1[2 * L + 4], accB);
+            if constexpr (Q > LATE_DN) {
+                load_cells<PA0, LATE_DN, L, L + 2, 1, (uint32_t)((MASK >> ((Q > LATE_DN ? LATE_DN : 0) * K1)) & ((1ull << K1) - 1ull)), 0, RE>(cx, d3);
+                tw_finish<Q, L, MASK, PHB, (Q > LATE_DN ? LATE_DN : 1)>(a, cx, qc, d3[2 * L + 4], accB);
+            }
+        }
+        LWS_SETPRIO(2);
+    } else if constexpr (quad_first) {
         // this pair and the neighbour-frame sums of the next one, from one set of windows (rows_sum_ahead)
         R13Partials<L> p3A, p3B, p3C, p3D;
         qc.accA = make_float2(0.f, 0.f);
@@ -1218,7 +1357,24 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
                 pair_rot<0>(acc, nyq_weight(a, k), lo, cj(lo));
             }
         });
-        if constexpr (PART != 2) static_for<Q - 1>([&](auto ir) {
+        if constexpr (TW && PART != 2) static_for<Q - 1>([&](auto ir) {
+            // (LWS_TW) twiddle tau_r(C) of the Nyquist bin: any angle, the same for every lane
+            constexpr int r = decltype(ir)::value + 1;
+            const float2 tau = wp_value(a.tw_nyq[r]);
+            if constexpr ((MASK >> (r * K1)) & 1ull)
+                pair_rot<0>(acc, nyq_weight(a, r * K1), cmulf(tau, lds_read(nn[r])), cmulf(cj(tau), lds_read(no[r])));
+            static_for<L>([&](auto ik) {
+                constexpr int k = decltype(ik)::value + 1;
+                if constexpr ((MASK >> (r * K1 + k)) & 1ull) {
+                    const float2 up = lds_read(ring_addr<RE, -SKEW * r - k>(nb[r]));
+                    const float2 dn = lds_read(ring_addr<RE, SKEW * r - k - LAG>(ob[r]));
+                    // W0 tau up + conj(W0 tau) dn + W0 conj(tau) conj(dn) + conj(W0 conj(tau)) conj(up) = W0 X + conj(W0) conj(X)
+                    const float2 x = cadd(cmulf(tau, up), cj(cmulf(tau, dn)));
+                    pair_rot<0>(acc, nyq_weight(a, r * K1 + k), x, cj(x));
+                }
+            });
+        });
+        if constexpr (!TW && PART != 2) static_for<Q - 1>([&](auto ir) {
             constexpr int r = decltype(ir)::value + 1;
             constexpr int rot = eighths<Q>(RE % Q, r) >> 1;    // twiddle exp(2j pi (C mod Q) r / Q) = j^rot, rot even (RE is)
             static_assert((eighths<Q>(RE % Q, r) & 3) == 0, "half turns only");
@@ -1466,6 +1622,9 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
     for (int i = threadIdx.x; i < THR_OFF / 8; i += NTHREADS) reinterpret_cast<float2 *>(smem)[i] = make_float2(0.f, 0.f);
     for (int i = threadIdx.x; i < MBOX_BYTES / 8; i += NTHREADS) reinterpret_cast<float2 *>(smem + MBOX_OFF)[i] = make_float2(0.f, 0.f);
     if (threadIdx.x < 16) reinterpret_cast<int *>(smem + DONE_OFF)[threadIdx.x] = T_START;
+    if constexpr (TW)   // the twiddle table: (P + 8) rows of four float2
+        for (int i = threadIdx.x; i < (a_in.tw_P + 8) * (TW_ROW / 8); i += NTHREADS)
+            reinterpret_cast<float2 *>(smem + TW_OFF)[i] = reinterpret_cast<const float2 *>(a_in.tw_table)[i];
     __syncthreads();
     const int n_eff = meta[0];
     if (n_eff == 0) return;
@@ -1581,7 +1740,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         rprev[q] = rcur[q];
         ks_state[q] = (T_START - (slot0 + q + 1) * LAG) >> ROWP_SHIFT;
     }
-    struct BlockInfo { bool live, start, end, end1; float thr; };
+    struct BlockInfo { bool live, start, end, end1; float thr; int tw; };
     auto block_info = [&](int vblock0) {      // vblock0: the clock of the wave's first slot at phase 0 of the block (wave-uniform)
         // the round bookkeeping of each of the wave's slots: wave-uniform, once per round
         static_for<SPW>([&](auto iq) {
@@ -1620,6 +1779,13 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         bi.end = (cbase == C - th0(RE));
         bi.end1 = (RE != 0) && (cbase == C - th1(RE));
         bi.thr = here ? thr_c : thr_p;
+        bi.tw = 0;
+        if constexpr (TW) {   // the block's first bin mod P (cbase < 4096: the float quotient is off by one at most)
+            int r = cbase - (int)((float)cbase * a.tw_invP) * a.tw_P;
+            r += (r < 0) ? a.tw_P : 0;
+            r -= (r >= a.tw_P) ? a.tw_P : 0;
+            bi.tw = TW_OFF + r * TW_ROW;
+        }
         return bi;
     };
     int dlo[NDR];   // per-lane constants of the image-cell offsets: (PLL - HALO - DR - lane) * 16
@@ -1648,6 +1814,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 const BlockInfo cur = nxt_bi;
                 nxt_bi = block_info(v0 + 8);
                 cx.live = cur.live; cx.is_start = cur.start; cx.is_end = cur.end; cx.is_end1 = cur.end1; cx.thr = cur.thr;
+                cx.tw = cur.tw;
                 cx.nxt_live = nxt_bi.live; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end; cx.nxt_end1 = nxt_bi.end1;
                 cx.nxt_thr = nxt_bi.thr;
             }
@@ -2250,7 +2417,7 @@ template <int Q, int L, uint64_t MASK> hipError_t launch_k(const SysArgs &a, int
     return launch_kr<Q, L, MASK, 0>(a, grid, h16, s);
 }
 
-#if !LWS_Q8 && !LWS_L7
+#if !LWS_Q8 && !LWS_L7 && !LWS_TW
 // mask bit r*(L+1)+k set <=> |W[0][r][k]| > 1e-12.  Default sqrt-Hann windows give these patterns (L = 5):
 constexpr uint64_t MASK_Q4_L5_DEFAULT = 0b111111'010111'111111'000011u;  // (r=3 | r=2 | r=1 | r=0), 6 bits each, bit k: r=0:{0,1} r=1:all r=2:{0,1,2,4} r=3:all
 constexpr uint64_t MASK_Q2_L5_DEFAULT = 0b010111'000011u;                            // r=0:{0,1} r=1:{0,1,2,4}
@@ -2260,8 +2427,55 @@ struct Tables {
     int Q, L;
     uint64_t mask;
     bool k0real, r13;  // structure the kernels can exploit (FLAG_K0REAL / FLAG_R13)
+    // W[p][r][k] = W[0][r][k] exp(2 pi j p r tw_s / tw_P); LWS_TW: the table of the kernel on the device
+    // (these fields sit at the same offsets in every build of this file -- w[] below does not have the same length in all)
+    int tw_P = 0, tw_s = 0;
+    float *tw_dev = nullptr;
+    float tw_nyq[8] = {0};   // tau_r(F-1), r = 0..3
     float w[2 * NW];   // (re, im) in the order of SysArgs::w
 };
+
+// Twiddle structure of a weight tensor W[Qp][Q][K1u] (complex128 interleaved): is there a turn theta = s / P per bin and frame
+// offset such that W[p][r][k] = W[0][r][k] exp(2 pi j p r s / P) for every row p?  create_weights (lws.pyx:160-181) builds
+// exactly that, with s / P = hop / frame size in lowest terms -- P = Q, s = 1 for the summarised tensors (Qp = Q rows, row =
+// bin mod Q), anything for the general ones (Qp = N rows, row = bin).  P <= pmax.  Checked in fp64 on every element.
+bool twiddle_structure(const double *W, int Qp, int Q, int K1u, int pmax, int *P_out, int *s_out) {
+    double scale = 0;
+    for (size_t x = 0; x < (size_t)Qp * Q * K1u; ++x) scale = std::fmax(scale, std::hypot(W[2 * x], W[2 * x + 1]));
+    if (!(scale > 0) || Q < 2 || Qp < 1) return false;
+    auto at = [&](int p, int r, int k, int c) { return W[2 * (((size_t)p * Q + r) * K1u + k) + c]; };
+    int P = 1, sgn = 0;
+    if (Qp > 1) {
+        // theta from row 1 against row 0, on the largest weight of frame offset 1
+        int kb = 0;
+        for (int k = 1; k < K1u; ++k)
+            if (std::hypot(at(0, 1, k, 0), at(0, 1, k, 1)) > std::hypot(at(0, 1, kb, 0), at(0, 1, kb, 1))) kb = k;
+        const double br = at(0, 1, kb, 0), bi = at(0, 1, kb, 1), wr = at(1, 1, kb, 0), wi = at(1, 1, kb, 1);
+        if (std::hypot(br, bi) < 1e-6 * scale) return false;
+        double theta = std::atan2(wi * br - wr * bi, wr * br + wi * bi) / (2.0 * M_PI);   // arg(w / b) in turns
+        theta -= std::floor(theta);
+        bool found = false;
+        for (P = 1; P <= pmax; ++P) {
+            const double sp = theta * P, sr = std::round(sp);
+            if (std::fabs(sp - sr) < 1e-7) { sgn = (int)sr % P; found = true; break; }
+        }
+        if (!found) return false;
+    }
+    // the rows a kernel reads besides p = bin: p = Qp - bin (modneg, lwslib.cpp:300,408) must carry the conjugate twiddle
+    if (((long long)Qp * sgn) % P != 0) return false;
+    for (int p = 0; p < Qp; ++p)
+        for (int r = 0; r < Q; ++r) {
+            const double ang = 2.0 * M_PI * (double)(((long long)p * r * sgn) % P) / P;
+            const double cs = std::cos(ang), sn = std::sin(ang);
+            for (int k = 0; k < K1u; ++k) {
+                if (r == 0 && k == 0) continue;   // never read by the kernels
+                const double br = at(0, r, k, 0), bi = at(0, r, k, 1);
+                if (std::hypot(at(p, r, k, 0) - (br * cs - bi * sn), at(p, r, k, 1) - (br * sn + bi * cs)) > 1e-9 * scale) return false;
+            }
+        }
+    *P_out = P; *s_out = sgn;
+    return true;
+}
 
 }  // namespace
 
@@ -2271,7 +2485,7 @@ struct Tables {
 hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const double *const W[3], bool fp16_storage) {
     // Lu: the caller's stencil half-width (its weight tensors have Lu + 1 columns, its extended buffers 2 Lu pad columns);
     // L: that of the kernel build -- the next odd number, the extra tap with weight zero (its mask bit is clear: never fetched)
-    const int L = LWS_Q8 ? (Lu <= 5 ? 5 : Lu) : (Lu | 1), K1u = Lu + 1;   // (the Q = 8 build exists for L = 5 only: narrower stencils run on it)
+    const int L = (LWS_Q8 || LWS_TW) ? (Lu <= 5 ? 5 : Lu) : (Lu | 1), K1u = Lu + 1;   // (the Q = 8 and table-twiddle builds exist for L = 5 only: narrower stencils run on them)
     sp.F = F; sp.L = Lu; sp.Lk = L; sp.Q = Q; sp.h16 = fp16_storage;
     for (int i = 0; i < 3; ++i) sp.ok[i] = false;
     if (Lu < 0) return hipSuccess;
@@ -2280,14 +2494,19 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
     // kernel's L is odd (the tap windows are fetched as aligned pairs of bins) and at most SKEW - 3: a lane works on two bins per
     // rendez-vous, so the newest tap of the pair's second bin, (m-1, c+1+L), must be at least two steps old when the pair
     // starts (L = 7 is not: generic engine).
-#if LWS_Q8
-    if (Qp != Q || Q != 8 || L != 5) return hipSuccess;
+    // Qp: rows of the weight tensors -- Q (summarised: row = bin mod Q) or N = 2 (F-1) (general: row = bin; use_simplifications =
+    // False or a hop that does not divide the frame, lws.pyx:164-168).  Either way the kernels want the twiddle structure, below.
+    if (Qp != Q && Qp != 2 * (F - 1)) return hipSuccess;
+#if LWS_TW
+    if (Q < 3 || Q > 4 || Lu > 5) return hipSuccess;     // (stencils narrower than L = 5 run with zero weights)
+#elif LWS_Q8
+    if (Q != 8 || L != 5) return hipSuccess;
 #elif LWS_R16
-    if (Qp != Q || Q != 2 || !(L == 5 || L == 3 || L == 1)) return hipSuccess;
+    if (Q != 2 || !(L == 5 || L == 3 || L == 1)) return hipSuccess;
 #elif LWS_L7
-    if (Qp != Q || !(Q == 2 || Q == 4) || L != 7) return hipSuccess;      // (Lu = 6: the extra tap has weight zero)
+    if (!(Q == 2 || Q == 4) || L != 7) return hipSuccess;      // (Lu = 6: the extra tap has weight zero)
 #else
-    if (Qp != Q || !(Q == 2 || Q == 4) || !(L == 5 || L == 3 || L == 1)) return hipSuccess;
+    if (!(Q == 2 || Q == 4) || !(L == 5 || L == 3 || L == 1)) return hipSuccess;
 #endif
     // F-1 even (a pair of bins never straddles bin C); not a multiple of 8: the frames end inside a block (th0), and the block
     // before that one must not be the frame's first
@@ -2296,26 +2515,43 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
     const int K1 = L + 1;
     for (int i = 0; i < 3; ++i) {
         if (!W[i]) continue;
-        // twiddle structure: W[p][r][k] == W[0][r][k] * exp(2j*pi*p*r/Q)
-        bool ok = true;
+        // twiddle structure: W[p][r][k] == W[0][r][k] * exp(2j*pi*p*r*s/P) for every row p of the tensor
         double scale = 0;
-        for (int x = 0; x < Q * Q * K1u; ++x) scale = std::fmax(scale, std::hypot(W[i][2 * x], W[i][2 * x + 1]));
+        for (size_t x = 0; x < (size_t)Q * Q * K1u; ++x) scale = std::fmax(scale, std::hypot(W[i][2 * x], W[i][2 * x + 1]));
         // W[p][r][k] of the caller's tensor; zero for the tap an even Lu does not have
         auto wre = [&](int p, int r, int k) { return k <= Lu ? W[i][2 * ((p * Q + r) * K1u + k)] : 0.0; };
         auto wim = [&](int p, int r, int k) { return k <= Lu ? W[i][2 * ((p * Q + r) * K1u + k) + 1] : 0.0; };
-        for (int p = 0; p < Q && ok; ++p)
-            for (int r = 0; r < Q && ok; ++r)
-                for (int k = 0; k <= L; ++k) {
-                    if (r == 0 && k == 0) continue;  // never read by the kernels
-                    const double ang = 2.0 * M_PI * p * r / Q;
-                    const double br = wre(0, r, k), bi = wim(0, r, k);
-                    const double er = br * std::cos(ang) - bi * std::sin(ang), ei = br * std::sin(ang) + bi * std::cos(ang);
-                    const double wr = wre(p, r, k), wi = wim(p, r, k);
-                    if (std::hypot(wr - er, wi - ei) > 1e-9 * scale) { ok = false; break; }
-                }
-        if (!ok) continue;
+        int twP = 0, twS = 0;
+        if (!twiddle_structure(W[i], Qp, Q, K1u, TW ? TW_PMAX : Q, &twP, &twS)) continue;
+#if LWS_TW
+        // (tensors whose twiddles are the eighth turns of the static builds are theirs: tried before this one, lws_capi.hip)
+#else
+        // the static builds: the twiddle of a bin is exp(2 pi j (bin mod Q) r / Q), compiled into the unrolled step loop
+        if (twP != Q || twS != 1) continue;
+#endif
         Tables *tb = new Tables();
         tb->Q = Q; tb->L = L; tb->mask = 0;
+        tb->tw_P = twP; tb->tw_s = twS;
+#if LWS_TW
+        {
+            // the kernel's table: row p (p = 0 .. P + 7, periodic) = tau_1(p), tau_2(p), tau_3(p), 0; formed in fp64, rounded once
+            std::vector<float> tab((size_t)(twP + 8) * 8, 0.f);
+            for (int pp = 0; pp < twP + 8; ++pp)
+                for (int r = 1; r < Q; ++r) {
+                    const double ang = 2.0 * M_PI * (double)(((long long)pp * r * twS) % twP) / twP;
+                    tab[(size_t)pp * 8 + 2 * (r - 1)] = (float)std::cos(ang);
+                    tab[(size_t)pp * 8 + 2 * (r - 1) + 1] = (float)std::sin(ang);
+                }
+            for (int r = 0; r < 4; ++r) {
+                const double ang = 2.0 * M_PI * (double)(((long long)C * r * twS) % twP) / twP;
+                tb->tw_nyq[2 * r] = (float)std::cos(ang);
+                tb->tw_nyq[2 * r + 1] = (float)std::sin(ang);
+            }
+            hipError_t e = hipMalloc(&tb->tw_dev, tab.size() * sizeof(float));
+            if (e == hipSuccess) e = hipMemcpy(tb->tw_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { if (tb->tw_dev) (void)hipFree(tb->tw_dev); delete tb; return e; }
+        }
+#endif
         for (int r = 0; r < Q; ++r)
             for (int k = 0; k <= L; ++k) {
                 const double wr = wre(0, r, k), wi = wim(0, r, k);
@@ -2359,6 +2595,7 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
 
 void systolic_release(SystolicPlan &sp) {
     for (int i = 0; i < 3; ++i) {
+        if (sp.tables[i] && static_cast<Tables *>(sp.tables[i])->tw_dev) (void)hipFree(static_cast<Tables *>(sp.tables[i])->tw_dev);
         delete static_cast<Tables *>(sp.tables[i]);
         sp.tables[i] = nullptr;
         sp.ok[i] = false;
@@ -2497,6 +2734,12 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         const char *er = getenv("LWS_SYSTOLIC_ROLEMAP");
         a.rolemap = er ? atoi(er) : 0;
     }
+    a.tw_table = tb->tw_dev; a.tw_P = tb->tw_P > 0 ? tb->tw_P : 1; a.tw_invP = 1.0f / (float)a.tw_P;
+    for (int r = 0; r < 4; ++r) {
+        unsigned ur, ui;
+        memcpy(&ur, &tb->tw_nyq[2 * r], 4); memcpy(&ui, &tb->tw_nyq[2 * r + 1], 4);
+        a.tw_nyq[r] = ((unsigned long long)ui << 32) | ur;
+    }
     for (int x = 0; x < NW; ++x) {
         const bool used = LWS_Q8 || x < Q * (L + 1);
         const float re = used ? tb->w[2 * x] : 0.f, im = used ? tb->w[2 * x + 1] : 0.f;
@@ -2508,7 +2751,10 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     const bool h = sp.h16;
     hipError_t e;
     const char *kind = "allmask";
-#if LWS_Q8
+#if LWS_TW
+    kind = "tw";
+    e = Q == 4 ? launch_k<4, 5, mask_all(4, 5)>(a, grid, h, stream) : launch_k<3, 5, mask_all(3, 5)>(a, grid, h, stream);
+#elif LWS_Q8
     // default sqrt-Hann weights at hop = window / 8: r = 0: {0,1}, r = 4: {0,1,2,4}, every other row all six taps
     constexpr uint64_t MASK_Q8_L5_DEFAULT = 0b111111'111111'111111'010111'111111'111111'111111'000011ull;
     if (tb->mask == MASK_Q8_L5_DEFAULT && tb->k0real) { e = launch_k<8, 5, MASK_Q8_L5_DEFAULT | FLAG_K0REAL>(a, grid, h, stream); kind = "hann"; }
@@ -2536,7 +2782,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
 #endif
-    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_R16 && LWS_WIDE) ? "_wide_r16" : (LWS_R16 && SPW == 2) ? "_half_r16" : (LWS_R16 && SPW == 4) ? "_quarter_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
+    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_TW && SPW == 2) ? "_half" : LWS_TW ? "" : (LWS_R16 && LWS_WIDE) ? "_wide_r16" : (LWS_R16 && SPW == 2) ? "_half_r16" : (LWS_R16 && SPW == 4) ? "_quarter_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
              h ? "_f16" : "");
     sp.name = sp.name_buf;
     return e;

@@ -119,7 +119,7 @@ def test_bench_py_runs_its_multi_rank_branch():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "shard2"
     B, T, F, it = d["config"]["batch_per_gpu"], d["config"]["frames"], d["config"]["bins"], d["config"]["iters"]
-    assert np.isclose(d["value"], 2.0 * B * T * F * it / (d["ms_per_step"] * 1e-3), rtol=1e-9)   # whole job: both ranks' units
+    assert np.isclose(d["value"], 2.0 * B * T * F * it / (d["ms_per_step"] * 1e-3), rtol=1e-5)   # whole job: both ranks' units
     assert d["roofline"]["frac"] > 0 and d["roofline"]["valu"]["frac_naive"] > 0
     full = json.load(open(os.path.join(ROOT, d["extra_file"])))     # everything that is not the contract's line
     ex = full["extra"]

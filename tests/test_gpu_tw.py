@@ -1,0 +1,192 @@
+"""GPU (-m gpu): the table-twiddle builds of the systolic kernel (lws_systolic.hip -DLWS_TW=1: namespaces lws::tw, lws::tw_half)
+-- Q = 3 (the reference's LWSanyQ) and the general weights create_weights builds when the hop does not divide the frame
+(lws.pyx:164-168: Q' = N rows, LWSfractionalQ, lwslib.cpp:376-467; e.g. 25 ms frames every 10 ms = lws(400, 160)) -- against the
+oracle, whose fractional path is pinned by tests/golden/general_weights.npz (with the reference's out-of-bounds weight row N
+defined as row 0).  Same bars as tests/test_gpu_systolic.py::run_case; the fp64 generic engine pins the
+schedule for every case."""
+import os
+
+import numpy as np
+import pytest
+
+import lws_amd
+from conftest import load_golden
+from lws_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def tw_case(oracle, fsize, fshift, T, thr, seed, B=2, scale=(1.0, 40.0), L=5, use_simplifications=True, expect="tw"):
+    p = lws_amd.lws(fsize, fshift, L=L, use_simplifications=use_simplifications)
+    F = fsize // 2 + 1
+    rng = np.random.default_rng(seed)
+    S = rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))
+    S *= np.asarray(scale)[:B, None, None]
+    plan = _capi.Plan(F, p.W)
+    out = plan.batch(S, thr)
+    name = plan.last_kernel()["name"]
+    assert name.startswith("systolic") and name.endswith("_" + expect), name
+    if expect == "tw":
+        assert ("_half_" in name) == (F <= 257), name
+    if expect == "tw" and F <= 257:
+        # the build with two sweep slots per wave does the arithmetic of the one-slot build in the same order: identical bits
+        os.environ["LWS_SYSTOLIC_NO_SHORT"] = "1"
+        try:
+            narrow = _capi.Plan(F, p.W)
+        finally:
+            del os.environ["LWS_SYSTOLIC_NO_SHORT"]
+        assert np.array_equal(narrow.batch(S, thr), out) and "_half_" not in narrow.last_kernel()["name"], narrow.last_kernel()
+        narrow.close()
+    p64 = _capi.Plan(F, p.W, precision="fp64")
+    worst = 0.0
+    for b in range(B):
+        ref = oracle.batch_lws(S[b], p.W, thr)
+        assert np.abs(p64.batch(S[b], thr) - ref).max() < 1e-8
+        mean = np.mean(np.abs(S[b]))
+        d = np.abs(out[b] - ref)
+        worst = max(worst, rel_l2(out[b], ref))
+        assert rel_l2(out[b], ref) < 3e-3, (fsize, fshift, T, b, rel_l2(out[b], ref))
+        assert np.median(d) < 2e-6 * mean
+        assert np.abs(np.abs(out[b]) - np.abs(S[b])).max() < 2e-6 * np.abs(S[b]).max()
+    p64.close(); plan.close()
+    return out, name
+
+
+THR = [0.5, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("fsize,fshift,T", [(48, 16, 70), (96, 32, 131), (384, 128, 37), (768, 256, 66), (1008, 336, 40), (60, 20, 64),
+                                            (1020, 340, 33), (996, 332, 37), (984, 328, 40)])
+def test_q3_summarised_weights(oracle, fsize, fshift, T):
+    """hop = a third of the frame: Q = 3, summarised weights W[3][3][L+1] with twiddle exp(2 pi j (bin mod 3) r / 3) -- the
+    reference's LWSanyQ (lws.pyx:252-253, lwslib.cpp:283-373).  Frame ends at every phase of a block."""
+    tw_case(oracle, fsize, fshift, T, THR, seed=fsize + T)
+
+
+@pytest.mark.parametrize("fsize,fshift,T", [(400, 160, 70), (400, 160, 131), (512, 160, 66), (1000, 400, 37), (1024, 384, 40), (600, 250, 65),
+                                            (80, 32, 70), (1024, 320, 21), (644, 230, 50), (1012, 368, 33)])
+def test_fractional_q_general_weights(oracle, fsize, fshift, T):
+    """A hop that does not divide the frame: create_weights returns one weight row per bin (Q' = N) and batch_lws dispatches to
+    LWSfractionalQ (lws.pyx:246-247).  25 ms / 10 ms speech framing is lws(400, 160): Q = 3 frames, twiddle period 5 bins."""
+    out, name = tw_case(oracle, fsize, fshift, T, THR, seed=fsize + T)
+    p = lws_amd.lws(fsize, fshift)
+    assert p.W.shape[0] == fsize and not float(p.Q).is_integer()
+
+
+@pytest.mark.parametrize("fsize,fshift", [(64, 16), (1024, 256), (1024, 512), (1024, 128), (2048, 512), (512, 128)])
+def test_general_weights_of_an_integer_q_use_the_static_builds(oracle, fsize, fshift):
+    """use_simplifications=False with a hop that divides the frame: N weight rows that are periodic copies of the Q summarised ones
+    (SURVEY.md probe 3-5).  The library verifies that on every row and serves the plan with the ordinary builds."""
+    F = fsize // 2 + 1
+    p = lws_amd.lws(fsize, fshift, use_simplifications=False)
+    assert p.W.shape[0] == fsize
+    rng = np.random.default_rng(fsize)
+    S = rng.standard_normal((2, 37, F)) + 1j * rng.standard_normal((2, 37, F))
+    thr = [0.5, 0.0, 0.0]
+    plan = _capi.Plan(F, p.W)
+    out = plan.batch(S, thr)
+    name = plan.last_kernel()["name"]
+    assert name.startswith("systolic") and not name.endswith("_tw"), name
+    ps = lws_amd.lws(fsize, fshift)
+    assert np.array_equal(out, _capi.Plan(F, ps.W).batch(S, thr))      # the summarised tensor gives the same bits
+    for b in range(2):
+        assert rel_l2(out[b], oracle.batch_lws(S[b], p.W, thr)) < 3e-3
+
+
+def test_reference_goldens_of_the_fractional_path():
+    """tests/golden/general_weights.npz: LWSfractionalQ of the reference itself on lws(32, 12) weights (Q = 3, Qfloat = 2.67)
+    and lws(32, 8) with use_simplifications=False, through the table-twiddle / static builds in fp32."""
+    g = load_golden("general_weights.npz")
+    for tag, want_tw in (("32_12", True), ("32_8", False)):
+        fsize, fshift, T, F, Q, L, LA = [int(v) for v in g[f"meta_{tag}"]]
+        S, thr = g[f"S_{tag}"], float(g[f"thr_{tag}"][0])
+        mean = np.mean(np.abs(S))
+        plan = _capi.Plan(F, g[f"W_{tag}"])
+        out = plan.batch(S, [thr / mean, 0.0])
+        name = plan.last_kernel()["name"]
+        assert name.startswith("systolic") and name.endswith("_tw") == want_tw, name
+        ref = g[f"batch_{tag}"][Q - 1:Q - 1 + T, L:L + F]
+        assert rel_l2(out, ref) < 3e-3 and np.median(np.abs(out - ref)) < 2e-6 * mean, (tag, rel_l2(out, ref))
+        plan.close()
+
+
+@pytest.mark.parametrize("n_it", [1, 6, 7, 8, 15, 22])
+def test_sweep_counts_around_slot_groups(oracle, n_it):
+    tw_case(oracle, 400, 160, 21, np.linspace(0.8, 0.0, n_it), seed=100 + n_it)
+    tw_case(oracle, 1000, 400, 21, np.linspace(0.8, 0.0, n_it), seed=200 + n_it)
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4])
+def test_narrower_stencils(oracle, L):
+    """L < 5 runs on the L = 5 build with zero weights for the taps the caller's tensors do not have."""
+    tw_case(oracle, 400, 160, 40, THR, seed=L, L=L)
+    tw_case(oracle, 768, 256, 40, THR, seed=10 + L, L=L)
+
+
+def test_what_the_table_builds_do_not_take():
+    """Q >= 5 (the taps reach further than the 32-step ring holds), twiddle periods longer than the table, L > 5: generic engine."""
+    for fsize, fshift, L in ((1000, 200, 5), (768, 128, 5), (1024, 160, 5), (400, 160, 7)):
+        p = lws_amd.lws(fsize, fshift, L=L)
+        with pytest.warns(RuntimeWarning):
+            p.batch_lws(np.ones((4, fsize // 2 + 1)), thresholds=[0.0])
+        assert p.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32"), (fsize, fshift)
+
+
+@pytest.mark.parametrize("fsize,fshift,B,T,iters", [(400, 160, 3, 300, 30), (1000, 400, 2, 200, 30), (768, 256, 5, 260, 16)])
+def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, iters, monkeypatch):
+    rng = np.random.default_rng(B * T)
+    F = fsize // 2 + 1
+    S = np.abs(rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))).astype(np.complex128)
+    S[0] *= 30.0
+    thr = lws_amd.get_thresholds(iters, 3.0, 0.15, 1)
+    p = lws_amd.lws(fsize, fshift)
+    monkeypatch.setenv("LWS_SYSTOLIC_NWG", "1")
+    ref = p.plan().batch(S, thr)
+    assert p.plan().last_kernel()["name"].endswith("_tw")
+    for nwg in ("2", "3", "4"):
+        monkeypatch.setenv("LWS_SYSTOLIC_NWG", nwg)
+        assert np.array_equal(p.plan().batch(S, thr), ref), nwg
+    monkeypatch.delenv("LWS_SYSTOLIC_NWG")
+    assert np.array_equal(p.plan().batch(S, thr), ref)
+
+
+@pytest.mark.parametrize("fsize,fshift,T", [(400, 160, 150), (1000, 400, 150), (768, 256, 100)])
+def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
+    rng = np.random.default_rng(T)
+    F = fsize // 2 + 1
+    S = np.abs(rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))).astype(np.complex128)
+    thr = np.zeros(9)
+    p = lws_amd.lws(fsize, fshift)
+    monkeypatch.setenv("LWS_SYSTOLIC_NWG", "1")
+    ref = p.plan().batch(S, thr)
+    for role in range(8):
+        for pair in (1, 3, 5, 7):
+            monkeypatch.setenv("LWS_SYSTOLIC_STRESS", str((1 << role) | (pair << 16)))
+            assert np.array_equal(p.plan().batch(S, thr), ref), (role, pair)
+    monkeypatch.setenv("LWS_SYSTOLIC_NWG", "3")
+    for mask, pair in ((0x40, 1), (0x80, 1), (0x0f, 3), (0x30, 7)):
+        monkeypatch.setenv("LWS_SYSTOLIC_STRESS", str(mask | (pair << 16)))
+        assert np.array_equal(p.plan().batch(S, thr), ref), (mask, pair)
+
+
+def test_speech_framing_end_to_end():
+    """lws(400, 160) -- 25 ms frames every 10 ms at 16 kHz -- through the class: stft, run_lws on magnitudes, consistency up."""
+    p = lws_amd.lws(400, 160, batch_iterations=60, batch_alpha=20)
+    x = np.random.default_rng(0).standard_normal(16000)
+    X = p.stft(x)
+    Y = p.run_lws(np.abs(X))
+    assert p.plan().last_kernel()["name"] == "systolic_half_q3_l5_tw"
+    assert Y.dtype == np.complex128 and np.abs(np.abs(Y) - np.abs(X)).max() < 1e-6 * np.abs(X).max()
+    assert p.get_consistency(Y) > p.get_consistency(np.abs(X).astype(complex)) + 5.0
+    # fp16 storage and device-resident calls take the same build
+    import torch
+    ph = lws_amd.lws(400, 160, storage="fp16")
+    t = torch.from_numpy(np.abs(X)[None].astype(np.complex64)).cuda()
+    ph.plan().batch_dev(t.data_ptr(), 1, X.shape[0], np.zeros(20), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ph.plan().last_kernel()["name"] == "systolic_half_q3_l5_tw_f16"
+    assert abs(ph.get_consistency(t.cpu().numpy()[0].astype(np.complex128)) - p.get_consistency(p.batch_lws(np.abs(X), thresholds=np.zeros(20)))) < 0.3
