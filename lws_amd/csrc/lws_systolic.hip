@@ -109,14 +109,17 @@
 #ifndef LWS_TW
 #define LWS_TW 0
 #endif
-#if LWS_TW && (LWS_WIDE || LWS_Q8 || LWS_L7 || LWS_R16 || LWS_SPW == 4)
-#error "LWS_TW goes with the narrow build or with LWS_SPW=2"
+#if LWS_TW && (LWS_WIDE == 2 || LWS_Q8 || LWS_L7 || LWS_R16 || LWS_SPW == 4)
+#error "LWS_TW goes with the narrow build, with LWS_SPW=2 or with LWS_WIDE=1"
 #endif
 #if (LWS_WIDE && LWS_Q8) || ((LWS_SPW != 1 || LWS_L7) && (LWS_WIDE || LWS_Q8)) || (LWS_SPW != 1 && LWS_L7) || (LWS_R16 && (LWS_WIDE == 2 || LWS_Q8 || LWS_L7))
 #error "LWS_WIDE, LWS_Q8, LWS_SPW, LWS_L7 and LWS_R16 are separate builds (LWS_R16 goes with LWS_WIDE=1 or LWS_SPW)"
 #endif
 #if LWS_TW && LWS_SPW == 2
 #define LWS_NS_OPEN namespace lws { namespace tw_half {
+#define LWS_NS_CLOSE } }
+#elif LWS_TW && LWS_WIDE
+#define LWS_NS_OPEN namespace lws { namespace tw_wide {
 #define LWS_NS_CLOSE } }
 #elif LWS_TW
 #define LWS_NS_OPEN namespace lws { namespace tw {
@@ -2782,7 +2785,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
 #endif
-    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_TW && SPW == 2) ? "_half" : LWS_TW ? "" : (LWS_R16 && LWS_WIDE) ? "_wide_r16" : (LWS_R16 && SPW == 2) ? "_half_r16" : (LWS_R16 && SPW == 4) ? "_quarter_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
+    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_TW && SPW == 2) ? "_half" : (LWS_TW && LWS_WIDE) ? "_wide" : LWS_TW ? "" : (LWS_R16 && LWS_WIDE) ? "_wide_r16" : (LWS_R16 && SPW == 2) ? "_half_r16" : (LWS_R16 && SPW == 4) ? "_quarter_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
              h ? "_f16" : "");
     sp.name = sp.name_buf;
     return e;

@@ -31,7 +31,7 @@ def tw_case(oracle, fsize, fshift, T, thr, seed, B=2, scale=(1.0, 40.0), L=5, us
     name = plan.last_kernel()["name"]
     assert name.startswith("systolic") and name.endswith("_" + expect), name
     if expect == "tw":
-        assert ("_half_" in name) == (F <= 257), name
+        assert ("_half_" in name) == (F <= 257) and ("_wide_" in name) == (F > 513), name
     if expect == "tw" and F <= 257:
         # the build with two sweep slots per wave does the arithmetic of the one-slot build in the same order: identical bits
         os.environ["LWS_SYSTOLIC_NO_SHORT"] = "1"
@@ -75,6 +75,14 @@ def test_fractional_q_general_weights(oracle, fsize, fshift, T):
     out, name = tw_case(oracle, fsize, fshift, T, THR, seed=fsize + T)
     p = lws_amd.lws(fsize, fshift)
     assert p.W.shape[0] == fsize and not float(p.Q).is_integer()
+
+
+@pytest.mark.parametrize("fsize,fshift,T", [(2048, 768, 40), (1536, 512, 70), (2000, 800, 33), (2044, 700, 131), (1200, 480, 66), (2048, 640, 21),
+                                            (1980, 660, 37)])
+def test_wide_frames(oracle, fsize, fshift, T):
+    """Frames of 515 .. 1025 bins (a 2048-point window every 768 samples: Q = 3, Qfloat = 2.67): the table-twiddle code under the
+    build with two waves per sweep slot (lws::tw_wide)."""
+    tw_case(oracle, fsize, fshift, T, THR, seed=fsize + T)
 
 
 @pytest.mark.parametrize("fsize,fshift", [(64, 16), (1024, 256), (1024, 512), (1024, 128), (2048, 512), (512, 128)])
@@ -136,7 +144,7 @@ def test_what_the_table_builds_do_not_take():
         assert p.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32"), (fsize, fshift)
 
 
-@pytest.mark.parametrize("fsize,fshift,B,T,iters", [(400, 160, 3, 300, 30), (1000, 400, 2, 200, 30), (768, 256, 5, 260, 16)])
+@pytest.mark.parametrize("fsize,fshift,B,T,iters", [(400, 160, 3, 300, 30), (1000, 400, 2, 200, 30), (768, 256, 5, 260, 16), (2048, 768, 3, 150, 20)])
 def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, iters, monkeypatch):
     rng = np.random.default_rng(B * T)
     F = fsize // 2 + 1
@@ -154,7 +162,7 @@ def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, it
     assert np.array_equal(p.plan().batch(S, thr), ref)
 
 
-@pytest.mark.parametrize("fsize,fshift,T", [(400, 160, 150), (1000, 400, 150), (768, 256, 100)])
+@pytest.mark.parametrize("fsize,fshift,T", [(400, 160, 150), (1000, 400, 150), (768, 256, 100), (2048, 768, 100)])
 def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
     rng = np.random.default_rng(T)
     F = fsize // 2 + 1
