@@ -175,9 +175,9 @@ def summary_lines(extra):
                 out.append("# %s: total %.1f ms; " % (name, b["total_wall_ms"]) + "; ".join(
                     "%s %.2f ms (%s, %s)" % (st, b[st]["kernel_ms"], b[st]["kernel"], rf(b[st]["roofline"])) for st in ("nofuture", "online", "batch") if st in b))
             elif name == "host_api":
-                out.append("# host_api: plan.batch(numpy c128) %.1f ms vs device-resident %.1f ms (x%.2f of max(transfer, kernel)); real input %s ms; run_lws_music(numpy) %.1f ms"
-                           % (b["wall_ms"], b["device_resident_ms"], b["wall_over_max_transfer_kernel"],
-                              ("%.1f" % b["real_input"]["wall_ms"]) if b.get("real_input") else "n/a", b["run_lws_music"]["wall_ms"]))
+                out.append("# host_api: plan.batch(numpy c128 magnitudes) %.1f ms vs device-resident %.1f ms (x%.2f); complex input %s ms; run_lws_music(numpy) %.1f ms"
+                           % (b["wall_ms"], b["device_resident_ms"], b["wall_ms"] / b["device_resident_ms"],
+                              ("%.1f" % b["complex_input"]["wall_ms"]) if b.get("complex_input") else "n/a", b["run_lws_music"]["wall_ms"]))
             elif name == "1":
                 out.append("# 1: " + "; ".join("%s %.2f ms (cpu %.1f ms, rel-L2 %.1e)" % (k, v["wall_ms"], v["cpu_reference_ms"], v["checks"]["rel_l2_vs_cpu"])
                                                 for k, v in b.items() if isinstance(v, dict) and "wall_ms" in v))
@@ -651,6 +651,15 @@ def run_host_api(torch, lws_amd, dev, local_rank, B=256, T=500, iters=100):
         if len(keep) > 2:
             keep.pop(0)          # (freed outside the timed call: returning 1 GB to the OS costs 20-40 ms by itself)
     out = keep[-1]
+    # the same volume with complex input (random phases): goes up as 8 bytes per bin instead of 4
+    Mc = (M * np.exp(2j * np.pi * np.random.default_rng(1).random(M.shape))).astype(np.complex128)
+    walls_c = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        keep.append(plan.batch(Mc, thr))
+        walls_c.append(1e3 * (time.perf_counter() - t0))
+        keep.pop(0)
+    del Mc
     # pinned copy rate of this box, both directions, for the "transfer time" the wall is compared with
     h = torch.empty(1 << 28, dtype=torch.uint8).pin_memory()
     g = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
@@ -686,6 +695,8 @@ def run_host_api(torch, lws_amd, dev, local_rank, B=256, T=500, iters=100):
     out = keep3 = None
     return {"run_lws_music": music, "workload": "BASELINE config 2 through plan.batch(numpy complex128 %dx%dx%d) -> complex128, %d dense sweeps" % (B, T, F, iters),
             "wall_ms": min(walls[1:]), "wall_ms_all_calls": walls, "first_call_includes": "pinned staging buffers (hipHostMalloc) and scratch",
+            "input": "real-valued magnitudes (the documented usage run_lws(np.abs(X))): 4 B/bin over the bus on the way up, 8 on the way down",
+            "complex_input": {"wall_ms": min(walls_c[1:]), "wall_ms_all_calls": walls_c, "note": "random phases: 8 B/bin each way"},
             "value": float(B) * T * F * iters / (min(walls[1:]) * 1e-3), "device_resident_ms": dev_ms,
             "pinned_copy_GBs": {"h2d": rates[0], "d2h": rates[1]}, "bytes_over_the_bus_each_way": bytes_c64,
             "transfer_ms_each_way_at_pinned_rate": xfer_ms, "wall_over_max_transfer_kernel": min(walls[1:]) / max(xfer_ms, dev_ms),

@@ -97,6 +97,7 @@ struct HostPipe {
     void *up[2] = {nullptr, nullptr}, *down[2] = {nullptr, nullptr};
     size_t cap[2] = {0, 0};
     DevBuf io[2];
+    DevBuf io_real[2];                            // a chunk whose input is real-valued goes up as 4 B per bin and is expanded here
     hipStream_t s_up = nullptr, s_down = nullptr, s_comp = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     hipEvent_t ev_load[2] = {nullptr, nullptr};   // a chunk's light first kernels (layout, mean, thresholds) are done
@@ -127,6 +128,7 @@ struct HostPipe {
             }
             int rc = io[i].ensure(bytes);
             if (rc) return rc;
+            if ((rc = io_real[i].ensure(bytes / 2))) return rc;
         }
         return LWS_OK;
     }
@@ -136,6 +138,7 @@ struct HostPipe {
             if (down[i]) (void)hipHostFree(down[i]);
             up[i] = down[i] = nullptr;
             io[i].release();
+            io_real[i].release();
             if (ev_up[i]) (void)hipEventDestroy(ev_up[i]);
             if (ev_comp[i]) (void)hipEventDestroy(ev_comp[i]);
             if (ev_down[i]) (void)hipEventDestroy(ev_down[i]);
@@ -543,6 +546,19 @@ class HostWorkers {
 void narrow_c128(const double *in, float *out, size_t lo, size_t hi) {   // bins [lo, hi)
     for (size_t i = 2 * lo; i < 2 * hi; ++i) out[i] = (float)in[i];
 }
+// the same for an input whose imaginary parts are all zero (the documented usage: run_lws(np.abs(X)), python/README.md:98-100):
+// 4 bytes per bin.  Returns false -- with the output unfinished -- at the first non-zero imaginary part.
+bool narrow_real(const double *in, float *out, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+        if (in[2 * i + 1] != 0.0) return false;
+        out[i] = (float)in[2 * i];
+    }
+    return true;
+}
+__global__ void __launch_bounds__(256) k_expand_real(const float *__restrict__ re, float2 *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = make_float2(re[i], 0.f);
+}
 void widen_c64(const float *dev, const double *orig, double *out, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) {
         const float vr = dev[2 * i], vi = dev[2 * i + 1];
@@ -619,7 +635,13 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
         if (st[i].iters > 0 && (st[i].mode != lws::MODE_BATCH || (p->flags & LWS_FORCE_GENERIC) || !p->sysb || !p->sysb->supports(p->sys, st[i].wsel, T)))
             whole_device = true;
     const int Bc = host_chunk(per, B, cu_count(p->device), whole_device);
-    const int nch = (B + Bc - 1) / Bc;
+    // chunk c = spectrograms [cs[c], cs[c + 1]).  The first upload and the last download have nothing to overlap with: when the
+    // batch is cut at all, the first chunk is half a chunk (the device starts after half the narrowing and half the copy), and the
+    // remainder that leaves at the end is half a chunk too.
+    std::vector<int> cs{0};
+    if (Bc < B && Bc >= 2 && !whole_device && env_int("LWS_HOST_HALF_FIRST", 1)) cs.push_back(Bc / 2);
+    while (cs.back() < B) cs.push_back(std::min(B, cs.back() + Bc));
+    const int nch = (int)cs.size() - 1;
     int nthreads = env_int("LWS_HOST_THREADS", (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
     if (total < ((size_t)1 << 20)) nthreads = 1;
     nthreads = std::max(1, std::min(nthreads, 64));
@@ -640,7 +662,14 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     if (!p->host_pool) { p->host_pool = new HostWorkers(nthreads); p->host_pool_n = nthreads; }
     HostWorkers &pool = *static_cast<HostWorkers *>(p->host_pool);
     const int slices = pool.size() == 1 ? 1 : 4 * pool.size();
-    auto chunk_bins = [&](int c) { return (size_t)std::min(Bc, B - c * Bc) * per; };
+    auto chunk_bins = [&](int c) { return (size_t)(cs[c + 1] - cs[c]) * per; };
+    // Real-valued input (magnitudes: the documented usage run_lws(np.abs(X)), python/README.md:98-100) goes up as 4 bytes per bin
+    // and is expanded on the device.  Decided chunk by chunk while narrowing: the pass that reads every element anyway stops at
+    // the first non-zero imaginary part and the chunk is narrowed again as complex (an input that starts real and turns complex
+    // pays for that once; a complex input fails the probe below and never tries).
+    bool real_mode = env_int("LWS_HOST_REAL", 1) != 0;
+    for (size_t i = 0; i < std::min<size_t>(total, 256) && real_mode; ++i) real_mode = S_in[2 * i + 1] == 0.0;
+    std::vector<char> chunk_real(nch, 0);
     // LWS_HOST_TRACE=1: where the call's wall time goes, on stderr (ms since the call began)
     const bool trace = env_int("LWS_HOST_TRACE", 0) != 0;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -649,21 +678,32 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     };
     // host passes: narrow chunk cu (if any) into up[cu & 1] and widen chunk cd (if any) from down[cd & 1], together
     // ... of the bins [ulo, uhi) of chunk cu and [dlo, dhi) of chunk cd
-    auto host_ranges = [&](int cu, size_t ulo, size_t uhi, int cd, size_t dlo, size_t dhi) {
+    // (returns false if the range was to be narrowed as real values and is not real: nothing usable was written for it)
+    auto host_ranges = [&](int cu, size_t ulo, size_t uhi, bool as_real, int cd, size_t dlo, size_t dhi) -> bool {
         const int nu = uhi > ulo ? slices : 0, nd = dhi > dlo ? slices : 0;
+        std::atomic<bool> is_real{true};
         pool.run(nu + nd, [&](int i) {
             if (i < nu) {
-                const size_t nb = uhi - ulo, lo = ulo + nb * i / slices, hi = ulo + nb * (i + 1) / slices, off = (size_t)cu * Bc * per;
-                narrow_c128(S_in + 2 * off, static_cast<float *>(hp.up[cu & 1]), lo, hi);
+                const size_t nb = uhi - ulo, lo = ulo + nb * i / slices, hi = ulo + nb * (i + 1) / slices, off = (size_t)cs[cu] * per;
+                if (!as_real) narrow_c128(S_in + 2 * off, static_cast<float *>(hp.up[cu & 1]), lo, hi);
+                else if (is_real.load(std::memory_order_relaxed) && !narrow_real(S_in + 2 * off, static_cast<float *>(hp.up[cu & 1]), lo, hi))
+                    is_real.store(false, std::memory_order_relaxed);
             } else {
                 const int k = i - nu;
-                const size_t nb = dhi - dlo, lo = dlo + nb * k / slices, hi = dlo + nb * (k + 1) / slices, off = (size_t)cd * Bc * per;
+                const size_t nb = dhi - dlo, lo = dlo + nb * k / slices, hi = dlo + nb * (k + 1) / slices, off = (size_t)cs[cd] * per;
                 widen_c64(static_cast<const float *>(hp.down[cd & 1]), S_in + 2 * off, S_out + 2 * off, lo, hi);
             }
         });
+        return is_real.load();
     };
     auto host_pass = [&](int cu, int cd) {
-        host_ranges(cu, 0, (cu >= 0 && cu < nch) ? chunk_bins(cu) : 0, cd, 0, (cd >= 0 && cd < nch) ? chunk_bins(cd) : 0);
+        const size_t un = (cu >= 0 && cu < nch) ? chunk_bins(cu) : 0, dn = (cd >= 0 && cd < nch) ? chunk_bins(cd) : 0;
+        if (host_ranges(cu, 0, un, real_mode, cd, 0, dn)) {
+            if (un) chunk_real[cu] = real_mode;
+        } else {                       // chunk cu is not real-valued: again, as complex (the widening above is done)
+            real_mode = false;
+            host_ranges(cu, 0, un, false, -1, 0, 0);
+        }
     };
     constexpr int NP = HostPipe::PIECES;
     auto piece = [&](int c, int q) { return chunk_bins(c) * (size_t)q / NP; };   // first bin of piece q of chunk c
@@ -672,9 +712,16 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     // the first chunk goes up in pieces: piece q + 1 is narrowed while piece q is on the bus
     for (int q = 0; q < NP; ++q) {
         const size_t lo = piece(0, q), hi = piece(0, q + 1);
-        host_ranges(0, lo, hi, -1, 0, 0);
-        if (hi > lo) HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(hp.io[0].p) + lo, static_cast<const float2 *>(hp.up[0]) + lo, (hi - lo) * sizeof(float2), hipMemcpyHostToDevice, hp.s_up));
+        if (!host_ranges(0, lo, hi, real_mode, -1, 0, 0)) {   // not real-valued after all: the chunk again from its first piece, as complex
+            real_mode = false;
+            q = -1;
+            continue;
+        }
+        if (hi <= lo) continue;
+        if (real_mode) HIP_TRY(hipMemcpyAsync(static_cast<float *>(hp.io_real[0].p) + lo, static_cast<const float *>(hp.up[0]) + lo, (hi - lo) * sizeof(float), hipMemcpyHostToDevice, hp.s_up));
+        else HIP_TRY(hipMemcpyAsync(static_cast<float2 *>(hp.io[0].p) + lo, static_cast<const float2 *>(hp.up[0]) + lo, (hi - lo) * sizeof(float2), hipMemcpyHostToDevice, hp.s_up));
     }
+    chunk_real[0] = real_mode;
     mark("narrowed and on its way", 0);
     // D2H of chunk c: a blit kernel of the runtime that fills the device.  Started when chunk c is done it would run against
     // the light first kernels of chunk c+1 (memsets, layout pass, mean: 0.2 ms alone, 2.5 ms beside it); so it waits for
@@ -688,13 +735,19 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
         return LWS_OK;
     };
     for (int c = 0; c < nch; ++c) {
-        const int slot = c & 1, bc = std::min(Bc, B - c * Bc);
+        const int slot = c & 1, bc = cs[c + 1] - cs[c];
         const size_t bytes = chunk_bins(c) * sizeof(float2);
         float2 *io = static_cast<float2 *>(hp.io[slot].p);
         if (c >= 2) HIP_TRY(hipStreamWaitEvent(hp.s_up, hp.ev_down[slot], 0));        // chunk c-2 has left this device buffer
-        if (c >= 1) HIP_TRY(hipMemcpyAsync(io, hp.up[slot], bytes, hipMemcpyHostToDevice, hp.s_up));   // (chunk 0: above)
+        if (c >= 1) HIP_TRY(hipMemcpyAsync(chunk_real[c] ? hp.io_real[slot].p : static_cast<void *>(io), hp.up[slot], chunk_real[c] ? bytes / 2 : bytes,
+                                           hipMemcpyHostToDevice, hp.s_up));   // (chunk 0: above)
         HIP_TRY(hipEventRecord(hp.ev_up[slot], hp.s_up));
         HIP_TRY(hipStreamWaitEvent(hp.s_comp, hp.ev_up[slot], 0));
+        if (chunk_real[c]) {   // (ordered behind chunk c-2's download through ev_up: the copy stream waited for it)
+            const size_t nb = chunk_bins(c);
+            hipLaunchKernelGGL(k_expand_real, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, hp.s_comp, static_cast<const float *>(hp.io_real[slot].p), io, nb);
+            HIP_TRY(hipGetLastError());
+        }
         if (trace && c < 16) { HIP_TRY(hipEventCreate(&tr0[c])); HIP_TRY(hipEventCreate(&tr1[c])); HIP_TRY(hipEventRecord(tr0[c], hp.s_comp)); }
         p->ev_after_load = hp.ev_load[slot];
         rc = run_pipeline<float, float2>(p, io, io, io, bc, T, st, n, hp.s_comp);
@@ -744,7 +797,7 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     }
     for (int q = 0; q < NP; ++q) {
         HIP_TRY(hipEventSynchronize(hp.ev_piece[q]));
-        host_ranges(-1, 0, 0, nch - 1, piece(nch - 1, q), piece(nch - 1, q + 1));
+        host_ranges(-1, 0, 0, false, nch - 1, piece(nch - 1, q), piece(nch - 1, q + 1));
     }
     mark("arrived and widened", nch - 1);
     if (trace) {

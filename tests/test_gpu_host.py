@@ -87,3 +87,36 @@ def test_in_place_and_small_calls():
     assert np.array_equal(buf, ref)
     one = plan.batch(S[:1, :1], thr)
     assert one.shape == (1, 1, 33) and np.abs(np.abs(one) - np.abs(S[:1, :1])).max() < 1e-6 * np.abs(S).max()
+
+
+@pytest.mark.parametrize("where", ["never", "first", "chunk2", "last"])
+def test_real_valued_input_goes_up_as_four_bytes_per_bin(where, monkeypatch):
+    """Magnitudes -- the documented usage run_lws(np.abs(X)), python/README.md:98-100 -- are uploaded as 4 bytes per bin and expanded
+    on the device.  The decision is made chunk by chunk while narrowing: same bits as the complex upload (LWS_HOST_REAL=0) for
+    real input, for complex input, and for input that turns complex in its first element / in a later chunk / in its last
+    element; and a stream-ordering check rides along: a *_dev call on the same plan enqueued just before must not be overtaken."""
+    import torch
+    B, T, fsize, fshift = 9, 60, 512, 128
+    F = fsize // 2 + 1
+    S = _data(B, T, F, 77, True)
+    if where == "first": S[0, 0, 0] += 0.25j
+    if where == "chunk2": S[5, 7, 11] += 0.25j
+    if where == "last": S[-1, -1, -1] += 0.25j
+    thr = lws_amd.get_thresholds(25, 1, 0.1, 1)
+    plan = lws_amd.lws(fsize, fshift).plan()
+    monkeypatch.setenv("LWS_HOST_CHUNK_BINS", str(2 * T * F))
+    monkeypatch.setenv("LWS_HOST_CHUNK_EXACT", "1")
+    monkeypatch.setenv("LWS_HOST_REAL", "0")
+    ref = plan.batch(S, thr)
+    monkeypatch.delenv("LWS_HOST_REAL")
+    # a device-resident call on a side stream right before the host call: both use the plan's scratch
+    d = torch.from_numpy(S.astype(np.complex64)).cuda()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    plan.batch_dev(d.data_ptr(), B, T, thr, stream=side.cuda_stream)
+    out = plan.batch(S, thr)
+    side.synchronize()
+    assert np.array_equal(out, ref), where
+    assert np.abs(d.cpu().numpy() - ref).max() < 1e-6 * np.abs(S).max()      # ... and was not disturbed by it
+    monkeypatch.setenv("LWS_HOST_HALF_FIRST", "0")                           # the half-size first chunk changes nothing either
+    assert np.array_equal(plan.batch(S, thr), ref)
