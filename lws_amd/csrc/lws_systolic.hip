@@ -2756,7 +2756,11 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     const char *kind = "allmask";
 #if LWS_TW
     kind = "tw";
-    e = Q == 4 ? launch_k<4, 5, mask_all(4, 5)>(a, grid, h, stream) : launch_k<3, 5, mask_all(3, 5)>(a, grid, h, stream);
+    // hop = a third of the frame with the default sqrt-Hann window: of the centre frame's weights only k = 1 is non-zero (as for Q = 2, 4)
+    constexpr uint64_t MASK_Q3_L5_DEFAULT = 0b111111'111111'000011u;
+    if (Q == 4) e = launch_k<4, 5, mask_all(4, 5)>(a, grid, h, stream);
+    else if (tb->mask == MASK_Q3_L5_DEFAULT) { e = launch_k<3, 5, MASK_Q3_L5_DEFAULT>(a, grid, h, stream); kind = "hannmask_tw"; }
+    else e = launch_k<3, 5, mask_all(3, 5)>(a, grid, h, stream);
 #elif LWS_Q8
     // default sqrt-Hann weights at hop = window / 8: r = 0: {0,1}, r = 4: {0,1,2,4}, every other row all six taps
     constexpr uint64_t MASK_Q8_L5_DEFAULT = 0b111111'111111'111111'010111'111111'111111'111111'000011ull;
