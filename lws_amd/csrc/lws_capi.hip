@@ -163,6 +163,7 @@ struct lws_plan {
     unsigned flags = 0;
     bool fp64 = false;
     bool have[3] = {false, false, false};
+    int wperiod[3] = {0, 0, 0};    // period of the weight rows of each tensor (Q for a summarised one; 0: rows do not repeat)
     bool twiddle_all = false;      // W, W_ai and W_af all have create_weights' twiddle structure (the online LDS engine relies on it)
     std::vector<double> hostW[3];  // complex128 interleaved copies (eligibility analysis, systolic tables)
     DevBuf w[3], wflag[3];
@@ -313,9 +314,9 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     if constexpr (std::is_same<real, float>::value) {
         // no-future sweeps: the last Q + 1 frames live in LDS (same results as the generic engine, bit for bit)
         if ((mode == lws::MODE_NOFUTURE || mode == lws::MODE_NOFUTURE_Q4_COMPAT) && !(p->flags & LWS_FORCE_GENERIC) &&
-            lws::nofuture_lds_supports(a.F, a.T, a.L, a.Q, a.Qp)) {
+            lws::nofuture_lds_supports(a.F, a.T, a.L, a.Q, a.Qp, p->wperiod[a.wsel])) {
             begin_timing(p, s);
-            hipError_t e = lws::launch_nofuture_lds(a, B, s);
+            hipError_t e = lws::launch_nofuture_lds(a, B, p->wperiod[a.wsel], s);
             end_timing(p, s);
             if (e != hipSuccess) return fail(LWS_ERR_HIP, "no-future launch failed: %s", hipGetErrorString(e));
             p->last_launches = 1;
@@ -953,6 +954,8 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
         if (hipEventCreate(&p->ev0) != hipSuccess || hipEventCreate(&p->ev1) != hipSuccess)
             rc = fail(LWS_ERR_HIP, "hipEventCreate failed");
     }
+    for (int i = 0; i < 3; ++i)
+        p->wperiod[i] = !p->have[i] ? 0 : (Qp == Q ? Q : lws::weights_row_period(p->hostW[i].data(), Qp, Q, L, 256));
     p->twiddle_all = rc == LWS_OK && p->have[0] && p->have[1] && p->have[2];
     for (int i = 0; i < 3 && p->twiddle_all; ++i)
         p->twiddle_all = lws::weights_have_twiddle_structure(p->hostW[i].data(), Q, Qp, L);

@@ -15,6 +15,7 @@
 #include "lws_common.h"
 #include "lws_nofuture.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -25,9 +26,11 @@ struct NfArgs {
     float2 *state;       // [B][Tp][Np]
     const float *amp;    // [B][Tp][Np]
     const float *thr;    // [B][n_thr]
-    const float2 *w;     // [Q][Q][L+1], zero where flagged off
+    const float2 *w;     // [Q or Q'][Q][L+1], zero where flagged off
     const uint8_t *flag; // [Q][Q][L+1]
     int F, T, L, Q, n_thr, NR, compat;
+    int rows;            // weight rows kept in LDS: Q (summarised tensors: row = bin mod Q) or the period P of a general tensor's rows
+                         // (Q' = N rows, one per bin -- lws.pyx:164-181 -- that repeat with period P = frame / gcd(frame, hop): row = bin mod P)
 };
 
 template <typename C> __device__ __forceinline__ void pair(C &a, const C w, const C b, const C c) {
@@ -55,14 +58,15 @@ __device__ __forceinline__ float2 load_state(const float2 *p) {
 template <int QT, int LT, bool COMPAT, bool UNI>
 __device__ __forceinline__ void nf_update(int n, int me, float th, const float2 *S, const float2 *W, const unsigned long long *Mk,
                                           unsigned long long m_uni, const float *amp_cur, float2 *cur, int Q_, int L_, int F,
-                                          int Np, int NR) {
+                                          int Np, int NR, int RW_) {
     const int Q = QT ? QT : Q_, L = LT ? LT : L_, K1 = L + 1, RQ = Q * K1, nyq = F + L - 1;
+    const int RW = QT ? QT : RW_;                       // weight rows: a compile-time Q implies a summarised tensor
     const int c = n - L;
     const float target = amp_cur[n];
     if (!(target > th)) return;
-    const int row = c % Q;
+    const int row = c % RW;
     const float2 *wa = W + row * RQ;
-    const int rowneg = (Q - row) % Q;
+    const int rowneg = (RW - row) % RW;
     const unsigned long long ma = UNI ? m_uni : Mk[row];
     float2 acc = make_float2(0.f, 0.f);
     if constexpr (COMPAT) {                            // update_bin_nfq4 of lws_generic.hip (lwslib.cpp:550-613)
@@ -124,14 +128,15 @@ __device__ __forceinline__ float group_sum8(float v) {
 template <int QT, int LT, bool COMPAT, bool UNI>
 __device__ __forceinline__ void nf_update_split(int n, int j, int me, float th, const float2 *S, const float2 *W,
                                                 const unsigned long long *Mk, unsigned long long m_uni, const float *amp_cur,
-                                                float2 *cur, int Q_, int L_, int F, int Np, int NR) {
+                                                float2 *cur, int Q_, int L_, int F, int Np, int NR, int RW_) {
     const int Q = QT ? QT : Q_, L = LT ? LT : L_, K1 = L + 1, RQ = Q * K1, nyq = F + L - 1;
+    const int RW = QT ? QT : RW_;
     const int c = n - L;
     const float target = amp_cur[n];
     if (!(target > th)) return;                         // (the same for the 8 lanes of a bin)
-    const int row = c % Q;
+    const int row = c % RW;
     const float2 *wa = W + row * RQ;
-    const int rowneg = (Q - row) % Q;
+    const int rowneg = (RW - row) % RW;
     const unsigned long long ma = UNI ? m_uni : Mk[row], mb = UNI ? m_uni : Mk[rowneg];
     const float2 *wb = W + rowneg * RQ;
     const int nterms = (Q - 1) * K1, wrap_at = Np - 2 * n;
@@ -191,33 +196,34 @@ template <int QT, int LT, bool COMPAT, bool SPLIT>
 __global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Q = QT ? QT : a.Q, L = LT ? LT : a.L;
+    const int RW = QT ? QT : a.rows;
     const int F = a.F, T = a.T, NR = a.NR, K1 = L + 1, RQ = Q * K1;
     const int Np = F + 2 * L, Tp = T + 2 * (Q - 1);
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     float2 *S = reinterpret_cast<float2 *>(smem);                 // [NR][Np] ring of extended frames
-    float2 *W = S + (size_t)NR * Np;                              // [Q][Q][K1]
-    unsigned long long *Mk = reinterpret_cast<unsigned long long *>(W + Q * RQ);   // [Q] + 1: which weights of a row take part
-    float *A = reinterpret_cast<float *>(Mk + Q + 1);             // [2][Np] target magnitudes of the current and the next frame
+    float2 *W = S + (size_t)NR * Np;                              // [RW][Q][K1]
+    unsigned long long *Mk = reinterpret_cast<unsigned long long *>(W + RW * RQ);   // [RW] + 1: which weights of a row take part
+    float *A = reinterpret_cast<float *>(Mk + RW + 1);            // [2][Np] target magnitudes of the current and the next frame
     float2 *gS = a.state + (size_t)b * Tp * Np;
     const float *gA = a.amp + (size_t)b * Tp * Np;
-    for (int i = tid; i < Q * RQ; i += nthr) W[i] = a.w[i];
+    for (int i = tid; i < RW * RQ; i += nthr) W[i] = a.w[i];
     // The reference tests a flag per weight (lwslib.cpp:302,321,...).  Here the flags of a row are one bit mask (bit r*K1+k),
     // and when every row has the same mask -- always the case for create_weights' tensors, whose rows differ by unit-modulus
     // twiddles -- it is wave-uniform: the tests become scalar branches instead of 33 dependent byte loads per bin.
-    if (tid <= Q) {
+    for (int rw = tid; rw <= RW; rw += nthr) {
         unsigned long long mk = 0;
-        if (tid < Q) {
-            for (int x = 0; x < RQ; ++x) mk |= (unsigned long long)(a.flag[tid * RQ + x] != 0) << x;
+        if (rw < RW) {
+            for (int x = 0; x < RQ; ++x) mk |= (unsigned long long)(a.flag[rw * RQ + x] != 0) << x;
         } else {
             bool same = true;
-            for (int rw = 1; rw < Q; ++rw)
-                for (int x = 0; x < RQ; ++x) same = same && ((a.flag[rw * RQ + x] != 0) == (a.flag[x] != 0));
+            for (int r2 = 1; r2 < RW; ++r2)
+                for (int x = 0; x < RQ; ++x) same = same && ((a.flag[r2 * RQ + x] != 0) == (a.flag[x] != 0));
             mk = same ? 1ull : 0ull;
         }
-        Mk[tid] = mk;
+        Mk[rw] = mk;
     }
     __syncthreads();
-    const bool uni = Mk[Q] != 0;
+    const bool uni = Mk[RW] != 0;
     const unsigned long long m_uni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(Mk[0] >> 32)) << 32) |
                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(Mk[0] & 0xffffffffull));
     // bins whose farthest read (m-1)*Np + 2n + L stays inside frame m-1 are independent of frame m (compat rounds)
@@ -251,11 +257,11 @@ __global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
             const int slot = tid / LPB, nslots = nthr / LPB, jl = tid % LPB;
             auto update = [&](int n) __attribute__((always_inline)) {
                 if constexpr (SPLIT) {
-                    if (uni) nf_update_split<QT, LT, COMPAT, true>(n, jl, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
-                    else nf_update_split<QT, LT, COMPAT, false>(n, jl, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
+                    if (uni) nf_update_split<QT, LT, COMPAT, true>(n, jl, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
+                    else nf_update_split<QT, LT, COMPAT, false>(n, jl, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
                 } else {
-                    if (uni) nf_update<QT, LT, COMPAT, true>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
-                    else nf_update<QT, LT, COMPAT, false>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR);
+                    if (uni) nf_update<QT, LT, COMPAT, true>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
+                    else nf_update<QT, LT, COMPAT, false>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
                 }
             };
             if constexpr (COMPAT) {
@@ -315,9 +321,10 @@ hipError_t launch_t(const NfArgs &a, int B, int threads, size_t lds, hipStream_t
 
 struct NfShape { int NR, threads; size_t lds; bool ok; };
 
-NfShape shape_of(int F, int T, int L, int Q, int Qp) {
+// rows: weight rows the kernel keeps in LDS (Q for a summarised tensor, the row period of a general one; 0: not periodic)
+NfShape shape_of(int F, int T, int L, int Q, int Qp, int rows) {
     NfShape sh{0, 0, 0, false};
-    if (Qp != Q || Q < 2 || L < 1 || T < 1) return sh;
+    if (rows < 1 || (Qp == Q && rows != Q) || (Qp != Q && (Qp != 2 * (F - 1) || Qp % rows != 0)) || Q < 2 || L < 1 || T < 1) return sh;
     const int Np = F + 2 * L;
     int NR = 2;
     while (NR < Q + 1) NR *= 2;          // frames me - Q + 1 .. me and the prefetched me + 1
@@ -331,7 +338,7 @@ NfShape shape_of(int F, int T, int L, int Q, int Qp) {
         if (3 * launched < Np) return sh;
     }
     if (Q * (L + 1) > 64) return sh;     // one 64-bit participation mask per weight row
-    sh.lds = (size_t)NR * Np * 8 + (size_t)Q * Q * (L + 1) * 8 + (size_t)(Q + 1) * 8 + (size_t)2 * Np * 4 + 16;
+    sh.lds = (size_t)NR * Np * 8 + (size_t)rows * Q * (L + 1) * 8 + (size_t)(rows + 1) * 8 + (size_t)2 * Np * 4 + 16;
     if (sh.lds > 160 * 1024) return sh;
     sh.ok = true;
     return sh;
@@ -339,16 +346,39 @@ NfShape shape_of(int F, int T, int L, int Q, int Qp) {
 
 }  // namespace
 
-bool nofuture_lds_supports(int F, int T, int L, int Q, int Qp) { return shape_of(F, T, L, Q, Qp).ok; }
+bool nofuture_lds_supports(int F, int T, int L, int Q, int Qp, int rows) { return shape_of(F, T, L, Q, Qp, rows).ok; }
 
-hipError_t launch_nofuture_lds(const GenericArgs<float> &g, int B, hipStream_t stream) {
-    const NfShape sh = shape_of(g.F, g.T, g.L, g.Q, g.Qp);
+// Smallest P <= pmax dividing Qp such that the rows of W[Qp][Q][L+1] (complex128 interleaved) repeat with period P -- Q for a
+// summarised tensor (trivially), frame / gcd(frame, hop) for create_weights' general ones (lws.pyx:164-181) -- or 0.  The kernels
+// above then index row (bin mod P) where the reference indexes row bin (LWSfractionalQ, lwslib.cpp:393,408: mod = bin,
+// modneg = N - bin): the same weights to 1e-9 of the largest one (rounded to fp32 afterwards).
+int weights_row_period(const double *W, int Qp, int Q, int L, int pmax) {
+    if (!W || Qp < 1) return 0;
+    const size_t RQ = (size_t)Q * (L + 1);
+    double scale = 0;
+    for (size_t x = 0; x < (size_t)Qp * RQ; ++x) scale = std::fmax(scale, std::hypot(W[2 * x], W[2 * x + 1]));
+    for (int P = 1; P <= pmax && P <= Qp; ++P) {
+        if (Qp % P != 0) continue;
+        bool ok = true;
+        for (int p = P; p < Qp && ok; ++p)
+            for (size_t x = 0; x < RQ; ++x) {
+                const size_t i = (size_t)p * RQ + x, j = (size_t)(p % P) * RQ + x;
+                if (std::hypot(W[2 * i] - W[2 * j], W[2 * i + 1] - W[2 * j + 1]) > 1e-9 * scale) { ok = false; break; }
+            }
+        if (ok) return P;
+    }
+    return 0;
+}
+
+hipError_t launch_nofuture_lds(const GenericArgs<float> &g, int B, int rows, hipStream_t stream) {
+    const NfShape sh = shape_of(g.F, g.T, g.L, g.Q, g.Qp, rows);
     if (!sh.ok) return hipErrorInvalidValue;
     NfArgs a;
     a.state = g.state; a.amp = g.amp; a.thr = g.thr;
     a.w = g.w[g.wsel].w; a.flag = g.w[g.wsel].flag;
-    a.F = g.F; a.T = g.T; a.L = g.L; a.Q = g.Q; a.n_thr = g.n_thr; a.NR = sh.NR;
+    a.F = g.F; a.T = g.T; a.L = g.L; a.Q = g.Q; a.n_thr = g.n_thr; a.NR = sh.NR; a.rows = rows;
     a.compat = (g.mode == MODE_NOFUTURE_Q4_COMPAT);
+    if (rows != g.Q) return a.compat ? hipErrorInvalidValue : launch_t<0, 0, false>(a, B, sh.threads, sh.lds, stream);   // general weights
     if (a.compat) {
         if (g.Q != 4) return hipErrorInvalidValue;
         return g.L == 5 ? launch_t<4, 5, true>(a, B, sh.threads, sh.lds, stream) : launch_t<4, 0, true>(a, B, sh.threads, sh.lds, stream);

@@ -198,3 +198,34 @@ def test_speech_framing_end_to_end():
     torch.cuda.synchronize()
     assert ph.plan().last_kernel()["name"] == "systolic_half_q3_l5_tw_f16"
     assert abs(ph.get_consistency(t.cpu().numpy()[0].astype(np.complex128)) - p.get_consistency(p.batch_lws(np.abs(X), thresholds=np.zeros(20)))) < 0.3
+
+
+@pytest.mark.parametrize("fsize,fshift,T,n_it", [(400, 160, 40, 2), (1000, 400, 25, 1), (512, 160, 33, 3), (2048, 768, 12, 2), (32, 12, 14, 2)])
+def test_nofuture_sweeps_with_general_weights_run_on_the_lds_engine(oracle, fsize, fshift, T, n_it):
+    """NoFuture_LWSfractionalQ (lwslib.cpp:693-764): weight row = bin.  The rows of create_weights' general tensors repeat with
+    period frame / gcd(frame, hop); the LDS engine keeps one period of them and indexes row (bin mod period).  Against the oracle
+    (fp32 bars) and against the order-exact generic engine."""
+    p = lws_amd.lws(fsize, fshift)
+    F = fsize // 2 + 1
+    rng = np.random.default_rng(fsize + T)
+    S = rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))
+    S[1] *= 30.0
+    thr = np.linspace(0.5, 0.0, n_it)
+    plan = _capi.Plan(F, p.W, p.W_ai, p.W_af)
+    out = plan.nofuture(S, thr, wsel=_capi.LWS_W_AI)
+    assert plan.last_kernel()["name"] == "nofuture_lds_fp32", plan.last_kernel()
+    gen = _capi.Plan(F, p.W, p.W_ai, p.W_af, force_generic=True)
+    outg = gen.nofuture(S, thr, wsel=_capi.LWS_W_AI)
+    assert gen.last_kernel()["name"] == "generic_fp32"
+    p64 = _capi.Plan(F, p.W, p.W_ai, p.W_af, precision="fp64")
+    for b in range(2):
+        ref = oracle.nofuture_lws(S[b], p.W_ai, thr, compat=False)
+        assert rel_l2(p64.nofuture(S[b], thr, wsel=_capi.LWS_W_AI), ref) < 1e-8       # the schedule, in fp64 (1e-10: the recursion amplifies fp64 rounding too)
+        # A no-future sweep is a recursion along the frames (frame m from frames m-1 .. m-Q+1) that amplifies rounding about
+        # threefold every five frames at these sizes -- the oracle itself moves by 1e-2 over 40 frames when its weights are rounded
+        # to fp32 (tools/nf_diag.py) -- so: value-level on the first frames, and overall no worse than the order-exact engine
+        e_lds, e_gen = rel_l2(out[b], ref), rel_l2(outg[b], ref)
+        assert rel_l2(out[b][:8], ref[:8]) < 1e-4 and rel_l2(outg[b][:8], ref[:8]) < 1e-4, (fsize, b)
+        assert e_lds < 4 * e_gen + 1e-3 and e_lds < 0.2, (fsize, b, e_lds, e_gen)
+        assert np.abs(np.abs(out[b]) - np.abs(S[b])).max() < 2e-6 * np.abs(S[b]).max()
+    plan.close(); gen.close(); p64.close()
