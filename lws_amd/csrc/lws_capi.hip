@@ -165,6 +165,8 @@ struct lws_plan {
     bool have[3] = {false, false, false};
     int wperiod[3] = {0, 0, 0};    // period of the weight rows of each tensor (Q for a summarised one; 0: rows do not repeat)
     bool twiddle_all = false;      // W, W_ai and W_af all have create_weights' twiddle structure (the online LDS engine relies on it)
+    int tw_P = 0, tw_s = 0;        // ... W[p][r][k] = W[0][r][k] exp(2 pi j p r tw_s / tw_P), the same for the three of them
+    DevBuf online_tw;              // the online engine's twiddle table when those are not the static eighth turns of Q in {2,4,8}
     std::vector<double> hostW[3];  // complex128 interleaved copies (eligibility analysis, systolic tables)
     DevBuf w[3], wflag[3];
     DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out;
@@ -301,9 +303,9 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     if constexpr (std::is_same<real, float>::value) {
         // online driver: frames of the moving window live in LDS when the shape allows it
         if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) &&
-            lws::online_lds_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update, p->twiddle_all)) {
+            lws::online_lds_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update, p->twiddle_all ? p->tw_P : 0, p->tw_s)) {
             begin_timing(p, s);
-            hipError_t e = lws::launch_online_lds(a, B, s);
+            hipError_t e = lws::launch_online_lds(a, B, p->tw_P, p->tw_s, static_cast<const float *>(p->online_tw.p), s);
             end_timing(p, s);
             if (e != hipSuccess) return fail(LWS_ERR_HIP, "online launch failed: %s", hipGetErrorString(e));
             p->last_launches = 1;
@@ -957,8 +959,20 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
     for (int i = 0; i < 3; ++i)
         p->wperiod[i] = !p->have[i] ? 0 : (Qp == Q ? Q : lws::weights_row_period(p->hostW[i].data(), Qp, Q, L, 256));
     p->twiddle_all = rc == LWS_OK && p->have[0] && p->have[1] && p->have[2];
-    for (int i = 0; i < 3 && p->twiddle_all; ++i)
-        p->twiddle_all = lws::weights_have_twiddle_structure(p->hostW[i].data(), Q, Qp, L);
+    p->tw_P = 0;
+    for (int i = 0; i < 3 && p->twiddle_all; ++i) {
+        int P = 0, sg = 0;      // (P = 0: a tensor without neighbour-frame weights fits any twiddle)
+        p->twiddle_all = lws::weights_twiddle(p->hostW[i].data(), Q, Qp, L, 512, &P, &sg) && (P == 0 || p->tw_P == 0 || (P == p->tw_P && sg == p->tw_s));
+        if (P > 0) { p->tw_P = P; p->tw_s = sg; }
+    }
+    if (p->twiddle_all && p->tw_P == 0) { p->tw_P = Q; p->tw_s = 1; }
+    if (rc == LWS_OK && p->twiddle_all && !p->fp64 && !(p->tw_P == Q && p->tw_s == 1 && (Q == 2 || Q == 4 || Q == 8)) && Q <= 4) {
+        std::vector<float> tab((size_t)(p->tw_P + 3) * 8);
+        lws::online_twiddle_table(p->tw_P, p->tw_s, tab.data());
+        if ((rc = p->online_tw.ensure(tab.size() * sizeof(float))) == LWS_OK &&
+            hipMemcpy(p->online_tw.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(LWS_ERR_HIP, "twiddle table upload failed");
+    }
     if (rc == LWS_OK && !p->fp64 && !(flags & LWS_FORCE_GENERIC)) {
         const double *hw[3] = {p->have[0] ? p->hostW[0].data() : nullptr,
                                p->have[1] ? p->hostW[1].data() : nullptr,
@@ -999,7 +1013,7 @@ void lws_plan_destroy(lws_plan *p) {
     for (int i = 0; i < 3; ++i) { p->w[i].release(); p->wflag[i].release(); }
     p->state.release(); p->amp.release(); p->row_sums.release(); p->mean_amp.release();
     p->thr_host_copy.release(); p->thr_scaled.release(); p->stage.release();
-    p->resid_rows.release(); p->resid_out.release(); p->gsk_state.release(); p->gsk_amp.release();
+    p->resid_rows.release(); p->resid_out.release(); p->gsk_state.release(); p->gsk_amp.release(); p->online_tw.release();
     p->pipe.release();
     delete static_cast<HostWorkers *>(p->host_pool);
     p->host_pool = nullptr;

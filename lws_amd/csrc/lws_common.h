@@ -97,4 +97,9 @@ hipError_t launch_residual(const typename cx<real>::type *state, WeightSet<real>
                            double *out, int B, int T, int F, int L, int Q, int Qp,
                            hipStream_t stream);
 
+// Twiddle structure of a weight tensor W[Qp][Q][L+1] (host, complex128 interleaved): W[p][r][k] == W[0][r][k] exp(2 pi j p r s / P)
+// for every row p, with the smallest such P <= pmax (lws_online.hip).  create_weights (lws.pyx:160-181) builds exactly that:
+// s / P = hop / frame in lowest terms -- P = Q, s = 1 when the hop divides the frame, for summarised (Qp = Q) and general (Qp = N) tensors.
+bool weights_twiddle(const double *W, int Q, int Qp, int L, int pmax, int *P_out, int *s_out);
+
 }  // namespace lws

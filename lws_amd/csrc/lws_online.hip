@@ -79,6 +79,10 @@ struct OnlineArgs {
     int NWR, NPS;        // k_online4: frames in its LDS ring, row stride (elements, even)
     int Lu;              // k_online4: the caller's stencil half-width (<= the kernel's L): its buffers have 2 Lu pad columns and
                          // its weight tensors Lu + 1 columns; the taps it does not have carry weight zero in the kernel's table
+    // k_online4<..., TWT>: twiddles exp(2 pi j bin r s / PT) that are not the eighth turns of Q in {2,4,8} -- Q = 3, and the general
+    // weights of a hop that does not divide the frame (Asym_UpdatePhasefractionalQ, lwslib.cpp:1276-1421) -- from a table
+    const float2 *twt;   // device: [PT + 3][4]: row p = tau_0 .. tau_3 of bin p (periodic: rows PT .. PT + 2 repeat rows 0 .. 2)
+    int PT;              // period of the twiddles in bins
 };
 
 __device__ __forceinline__ void pair(float2 &a, float2 w, float2 b, float2 c) {   // the generic engine's grouped form
@@ -812,7 +816,7 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
 template <int Q> struct Online4Waves {
 #ifndef LWS_ONLINE4_IDLE_WAVE   // (tried: an idle wave on the projection wave's SIMD and the centre wave elsewhere: 57.8 vs 50.9 ms)
     static constexpr int N = 2 * Q;
-    static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : 7, IDLE = -1;
+    static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : (Q == 3 ? 5 : 7), IDLE = -1;
 #else
     static constexpr int N = (Q == 4) ? 9 : 2 * Q;
     static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : (Q == 4 ? 8 : 7), IDLE = (Q == 4) ? 7 : -1;
@@ -870,9 +874,11 @@ __device__ __forceinline__ float pow2_to_unit(float amax) {
 // 2060-column frames is 132 KB of values).  The magnitudes are then read from the caller's buffer, one step ahead (a global load on
 // the projection wave's chain: slower steps, 10x faster than the generic engine such frames used to get), and the step table's
 // entries are computed instead of fetched.  Production variant only.
-template <int Q, int L, bool SERIAL, bool BIG = false>
+// TWT: the twiddle of a bin comes from a table in LDS (per lane: row = bin mod PT) instead of being static in the two-step loop
+template <int Q, int L, bool SERIAL, bool BIG = false, bool TWT = false>
 __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs a) {
     static_assert(!(BIG && SERIAL), "the verification variant keeps everything in LDS");
+    static_assert(!(TWT && (SERIAL || BIG)) && (TWT || Q == 2 || Q == 4 || Q == 8) && Q <= 4 + 4 * !TWT, "table twiddles: production variant, Q <= 4");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int K1 = L + 1, WN = 2 * L + 2, NTW = 2 * Q - 1;
     constexpr int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2;
@@ -887,7 +893,8 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     constexpr int NLO = (L + 2) / 4, NHI = (L + 1) / 2 + 1, NST = 1 + NLO + NHI;
     // LDS layout (byte offsets; lds_of in shape4_of is the same sum)
     const unsigned oET = 2u * NTW * 64 * 16, oS = oET + (224 + 64) * 8, oA = oS + ((unsigned)NWR * NPS + 8) * 8, oW = oA + (BIG ? 0u : (unsigned)NWR * NPS * 4),
-                   oTW = oW + 3u * Q * Q * K1 * 8, oThr = oTW + Q * 8, oTAB = (oThr + (unsigned)a.n_thr * 4 + 15u) & ~15u;
+                   oTW = oW + 3u * Q * Q * K1 * 8, oThr = oTW + Q * 8, oTAB = (oThr + (unsigned)a.n_thr * 4 + 15u) & ~15u,
+                   oTT = oTAB + (BIG ? 0u : (unsigned)((F + 1) / 2) * 16u);
     float4 *P = reinterpret_cast<float4 *>(smem);                               // [2][NTW][64]: (sum of bin c, of bin c+1)
     float4 *MT = reinterpret_cast<float4 *>(smem + oET);                        // [3][NST][6]: own-history matrices of the projection wave (below)
     static_assert(3 * NST * 6 * 16 <= 224 * 8, "matrix table");
@@ -897,6 +904,8 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     float2 *TW = reinterpret_cast<float2 *>(smem + oTW);                        // [Q]
     float *thr_s = reinterpret_cast<float *>(smem + oThr);                      // [n_thr]
     int4 *TAB = reinterpret_cast<int4 *>(smem + oTAB);                          // [NU] step table of the projection wave, by bin pair
+    const float2 *TT = reinterpret_cast<const float2 *>(smem + oTT);            // TWT: [PT + 3][4] twiddles by bin mod PT and frame offset
+    const int PT = TWT ? a.PT : 1;
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool is_proj = hw_wave == Online4Waves<Q>::PROJ;
@@ -934,6 +943,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         W[i] = (x % (Q * K1) == 0) ? make_float2(0.f, 0.f) : make_float2(w.x * wscale, w.y * wscale);
     }
     if (tid < Q) TW[tid] = a.tw[tid];
+    if constexpr (TWT) for (int i = tid; i < (PT + 3) * 4; i += nthr) reinterpret_cast<float2 *>(smem + oTT)[i] = a.twt[i];
     for (int i = tid; i < NWR * NPS + 8; i += nthr) S[i] = make_float2(0.f, 0.f);
     if constexpr (!BIG) for (int i = tid; i < NWR * NPS; i += nthr) A[i] = 0.f;
     for (int i = tid; i < 2 * NTW * 64; i += nthr) P[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1001,6 +1011,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     float thr = 0.f;
     v2f w0[K1];                         // tap waves: W[wset][0][r][k] (side 0) or its conjugate (side 1)
     v2f twg[Q];                         // tap waves: gain * exp(2 pi j row r / Q) (conjugated on side 1), row = bin % Q
+    v2f gvec = {0.f, 0.f};              // TWT, tap waves: (gain, +-gain): what turns a table twiddle into this wave's (conjugated on side 1)
     v2f wc[K1];                         // projection wave: centre weights W[wset][0][0][k] (zero if the centre frame takes no part)
     v2f wlate = {0.f, 0.f};             // ... and conj W[wset][0][1][L]
     auto setup = [&]() {
@@ -1035,10 +1046,13 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 const float2 w = wb[r * K1 + k];
                 w0[k] = (v2f){w.x, h ? -w.y : w.y};
             }
+            gvec = (v2f){gain, h ? -gain : gain};
+            if constexpr (!TWT) {
 #pragma unroll
-            for (int row = 0; row < Q; ++row) {
-                const float2 tw = TW[(row * r) & (Q - 1)];
-                twg[row] = (v2f){gain * tw.x, gain * (h ? -tw.y : tw.y)};
+                for (int row = 0; row < Q; ++row) {
+                    const float2 tw = TW[(row * r) & (Q - 1)];
+                    twg[row] = (v2f){gain * tw.x, gain * (h ? -tw.y : tw.y)};
+                }
             }
         }
     };
@@ -1084,6 +1098,14 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         v2f wl[2 * NCELL];
         float4 *pw0 = P + (0 * NTW + wave) * 64 + lane, *pw1 = P + (1 * NTW + wave) * 64 + lane;
         int ue = 0 - tstart;                                        // bin pair of this lane at the even step of the pair
+        // TWT: cp = (first bin of the pair of steps) mod PT = (2 ue) mod PT; the four bins 2 ue .. 2 ue + 3 are table rows cp .. cp + 3
+        auto cp_of = [&](int u_) __attribute__((always_inline)) { const int v = (2 * u_) % PT; return v < 0 ? v + PT : v; };
+        int cp = TWT ? cp_of(ue) : 0;
+        const int step4 = 4 % PT;
+        auto tw_tab = [&](int row, v2f &twa, v2f &twb) __attribute__((always_inline)) {
+            const float2 ta = TT[(cp + row) * 4 + r], tb = TT[(cp + row + 1) * 4 + r];
+            twa = as_v2f(ta) * gvec; twb = as_v2f(tb) * gvec;
+        };
         auto cells = [&](int u_even) __attribute__((always_inline)) {
             const int uc = u_even > -8 ? u_even : -8;               // (a lane far from its start reads in range)
             return reinterpret_cast<const float4 *>(S + fb + 2 * uc);
@@ -1123,10 +1145,11 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 // window) are stored only SKB - 3 bins before this lane starts: final now, not yet when the early cells were read
                 if constexpr (KIND == 1) ld(w, std::integral_constant<int, 0>{});
                 v2f twa, twb;
-                tw_of(std::integral_constant<int, 0>{}, ue, twa, twb);
+                if constexpr (TWT) tw_tab(0, twa, twb);
+                else tw_of(std::integral_constant<int, 0>{}, ue, twa, twb);
                 if (!SERIAL) sums(std::integral_constant<int, 0>{}, twa, twb, pw0);
             }
-            if (it >= t_done) { s += NSW; setup(); ue = it - tstart; }
+            if (it >= t_done) { s += NSW; setup(); ue = it - tstart; if constexpr (TWT) cp = cp_of(ue); }
             load_frames(it - 1);
             __syncthreads();
             // ---- odd step tt = it + 1
@@ -1135,10 +1158,12 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 if constexpr (KIND == 1) ld(w, std::integral_constant<int, NCELL - 2>{});   // its last column is final now
                 ld(w, std::integral_constant<int, NCELL - 1>{});
                 v2f twa, twb;
-                tw_of(std::integral_constant<int, 1>{}, ue, twa, twb);
+                if constexpr (TWT) tw_tab(2, twa, twb);
+                else tw_of(std::integral_constant<int, 1>{}, ue, twa, twb);
                 if (!SERIAL) sums(std::integral_constant<int, 2>{}, twa, twb, pw1);
             }
             ue += 2;
+            if constexpr (TWT) { cp += step4; cp -= cp >= PT ? PT : 0; }
             {   // the next pair's early cells: columns this wave has used already, under their new names
                 const float4 *w = cells(ue);
                 static_for<NPRE>([&](auto ic) { ld(w, ic); });
@@ -1199,7 +1224,8 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 cmacc_pk(bp, w0[k], wl[L + 1 + k]);
             }
             v2f twa, twb;
-            tw_of(ph_c, u & ~1, twa, twb);
+            if constexpr (TWT) twa = twb = (v2f){gvec.x, 0.f};      // (frame offset 0: no twiddle, just "does the centre frame take part")
+            else tw_of(ph_c, u & ~1, twa, twb);
             const v2f pa = cmul_pk(twa, am + ap), pb = cmul_pk(twb, bm + bp);
             if (!SERIAL) *pw = make_float4(pa.x, pa.y, pb.x, pb.y);
         };
@@ -1301,6 +1327,10 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             int u = -1 - tstart;                       // bin pair of the step about to run
             const float *ga0 = gA;      // BIG: magnitudes of the lane's frame, bin 0
             float tq_a = 0.f, tq_b = 0.f;   // ... and those of the pair after the one being fetched, in flight
+            v2f twl_t = {0.f, 0.f};         // TWT: twiddle tau_1 of the step's second bin (frame rho-1's late column), fetched with the operands
+            auto cpp_of = [&](int u_) __attribute__((always_inline)) { const int v = (2 * u_ + 1) % PT; return v < 0 ? v + PT : v; };
+            int cpp = 0;                    // ... its table row: (2 u + 1) mod PT of the bin pair u about to be fetched
+            const int step2 = 2 % PT;
             auto derive = [&]() __attribute__((always_inline)) {
                 li0 = oS + 8u * (unsigned)(ctb + L);
                 ai0 = oA + 4u * (unsigned)(ctb + L);
@@ -1346,6 +1376,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 ia_b = li_b + (unsigned)tab.y;
                 ib_b = li_b + 8u + (unsigned)tab.z;
                 xlate = as_v2f(*reinterpret_cast<const float2 *>(lds(xl0 + 16u * uc)));
+                if constexpr (TWT) twl_t = as_v2f(TT[cpp * 4 + 1]);      // (row (2 un + 1) mod PT, kept incrementally: no division on the chain)
             };
             auto step = [&](auto ph_c, int t) __attribute__((always_inline)) {   // PH: parity of t (and of u)
                 constexpr int PH = decltype(ph_c)::value;
@@ -1355,7 +1386,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 for (int w = 0; w < NTW; ++w) part[w] = pp[w * 64];
                 __builtin_amdgcn_sched_barrier(0);   // (the reads first: the own terms below cover part of their latency)
                 // the unit's own history (columns c-1, c-2, their images, the image of bin c) and frame rho-1's late column
-                v2f twl = as_v2f(a.tw[(2 * PH + 1) & (Q - 1)]);
+                v2f twl = TWT ? twl_t : as_v2f(a.tw[(2 * PH + 1) & (Q - 1)]);
                 if constexpr (Q == 8) twl = (u & 2) ? as_v2f(a.tw[(2 * PH + 5) & (Q - 1)]) : twl;
                 v2f ownA = mat_mul_pk(mA1, p1), ownB = mat_mul_pk(mB1, p1);
                 mat_mac_pk(ownA, mA2, p2);
@@ -1406,8 +1437,9 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 load_frames(t);
                 // (a lane that changes sweeps has at least two steps without work ahead of it -- NSW DS >= SKS LA + NU + 2 in
                 // shape4_of -- : the table entries in flight, which still belong to the old sweep, are used for those two only)
-                if (t >= t_done) { s += NSW; setup(); derive(); u = t - tstart; }
+                if (t >= t_done) { s += NSW; setup(); derive(); u = t - tstart; if constexpr (TWT) cpp = cpp_of(u); }
                 ++u;
+                if constexpr (TWT) { cpp += step2; cpp -= cpp >= PT ? PT : 0; }
                 // The stores above must have landed when the other waves pass the barrier; the reads below need not have.  A
                 // wave's LDS operations complete in order, so "all but the youngest 7" covers the stores as long as at least 7
                 // LDS reads follow them (tests/test_online_isa.py checks the compiled order).  Never more than 15 LDS / scalar
@@ -1424,6 +1456,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 else asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
             };
             derive();
+            if constexpr (TWT) cpp = cpp_of(u);
             fetch(u, fetch_tab(u));
             tab1 = fetch_tab(u + 1);
             tab2 = fetch_tab(u + 2);
@@ -1518,12 +1551,14 @@ Shape shape3_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
 // k_online4: 2Q waves, one lane per (sweep slot, frame position), even lag, ring of NWR frames with an even row stride
 struct Shape4 { Shape sh; int NWR, NPS; bool big; };
 // big: the kernel's BIG variant (target magnitudes and step table not in LDS)
-Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool big) {
+// PT > 0: the table-twiddle variant (Q in {3, 4}, twiddle period PT bins: (PT + 3) x 32 bytes of LDS more)
+Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool big, int PT = 0) {
     Shape4 r{{0, 0, 0, 0, false}, 0, 0, big};
     Shape &sh = r.sh;
     // any stencil half-width up to the kernel's: narrower ones run as L = 5 with zero weights for the taps they do not have
     // (OnlineArgs::Lu) -- the same sums, on a schedule that is order-exact for the wider stencil
-    if (Qp != Q || Lu < 1 || Lu > 5 || !(Q == 2 || Q == 4 || Q == 8) || LA < 0 || LA > 63 || n_thr < 1 || T < 1) return r;
+    if (Qp != Q || Lu < 1 || Lu > 5 || LA < 0 || LA > 63 || n_thr < 1 || T < 1) return r;
+    if (PT > 0 ? (big || !(Q == 3 || Q == 4) || PT > 512) : !(Q == 2 || Q == 4 || Q == 8)) return r;
     const int L = 5;
     const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS_MIN = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
     const int NU = (F + 1) / 2;
@@ -1541,7 +1576,7 @@ Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool b
     r.NPS = Np + (Np & 1);
     auto lds_of = [&](int nwr) {
         return (size_t)2 * (2 * Q - 1) * 64 * 16 + (224 + 64) * 8 + ((size_t)nwr * r.NPS + 8) * 8 + (big ? 0 : (size_t)nwr * r.NPS * 4) +
-               (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4 + 16 + (big ? 0 : (size_t)NU * 16);
+               (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4 + 16 + (big ? 0 : (size_t)NU * 16) + (PT > 0 ? (size_t)(PT + 3) * 32 : 0);
     };
     int nwr_max = 16;
     while (nwr_max > 0 && lds_of(nwr_max) > 160 * 1024) --nwr_max;
@@ -1564,7 +1599,11 @@ Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool b
     sh.ok = true;
     return r;
 }
-Shape4 shape4_of(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
+Shape4 shape4_of(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, int PT = 0) {
+    if (PT > 0) {
+        const char *ev = getenv("LWS_ONLINE_SERIAL_TAPS");   // (no verification variant with table twiddles: generic engine)
+        return (ev && ev[0] == '1') ? Shape4{{0, 0, 0, 0, false}, 0, 0, false} : shape4_try(F, T, Lu, Q, Qp, LA, n_thr, false, PT);
+    }
     Shape4 r = shape4_try(F, T, Lu, Q, Qp, LA, n_thr, false);
     const char *ev = getenv("LWS_ONLINE_SERIAL_TAPS");   // (the verification variant has no BIG build)
     if (!r.sh.ok && !(ev && ev[0] == '1')) r = shape4_try(F, T, Lu, Q, Qp, LA, n_thr, true);
@@ -1583,11 +1622,11 @@ int pick_layout(const Shape &s2, const Shape &s3, const Shape &s4) {
     return s2.ok ? 2 : 0;
 }
 
-template <int Q, int L, bool SERIAL, bool BIG = false> hipError_t launch_4(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online4<Q, L, SERIAL, BIG>),
+template <int Q, int L, bool SERIAL, bool BIG = false, bool TWT = false> hipError_t launch_4(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online4<Q, L, SERIAL, BIG, TWT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // (per device: not cached)
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_online4<Q, L, SERIAL, BIG>), dim3(B), dim3(Online4Waves<Q>::N * 64), lds, s, a);
+    hipLaunchKernelGGL((k_online4<Q, L, SERIAL, BIG, TWT>), dim3(B), dim3(Online4Waves<Q>::N * 64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1606,39 +1645,95 @@ template <int Q, int L, bool SERIAL> hipError_t launch_3(const OnlineArgs &a, in
 
 }  // namespace
 
-bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update, bool twiddle_structure) {
-    return update == 2 && twiddle_structure && (shape_of(F, T, L, Q, Qp, LA, n_thr).ok || shape3_of(F, T, L, Q, Qp, LA, n_thr).ok ||
-                                                shape4_of(F, T, L, Q, Qp, LA, n_thr).sh.ok);
+// tw_P, tw_s: the common twiddle structure of the three tensors (online_twiddle), 0 if they have none.  Tensors of Qp = N rows
+// (general weights) are served through their first Q rows' base weights like summarised ones.
+static bool static_twiddles(int Q, int tw_P, int tw_s) { return tw_P == Q && tw_s == 1 && (Q == 2 || Q == 4 || Q == 8); }
+bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update, int tw_P, int tw_s) {
+    if (update != 2 || tw_P < 1) return false;
+    if (static_twiddles(Q, tw_P, tw_s))
+        return shape_of(F, T, L, Q, Q, LA, n_thr).ok || shape3_of(F, T, L, Q, Q, LA, n_thr).ok || shape4_of(F, T, L, Q, Q, LA, n_thr).sh.ok;
+    return shape4_of(F, T, L, Q, Q, LA, n_thr, tw_P).sh.ok;
 }
 
-// W[p][r][k] == W[0][r][k] exp(2 pi j p r / Q) for every p, r, k (what create_weights produces, lws.pyx:160-181)
-bool weights_have_twiddle_structure(const double *W, int Q, int Qp, int L) {
-    if (!W || Qp != Q) return false;
+// Common twiddle structure of a weight tensor W[Qp][Q][L+1] (complex128 interleaved): W[p][r][k] == W[0][r][k] exp(2 pi j p r s / P)
+// for every row p (create_weights, lws.pyx:160-181: s / P = hop / frame in lowest terms; P = Q, s = 1 when the hop divides the frame).
+bool weights_twiddle(const double *W, int Q, int Qp, int L, int pmax, int *P_out, int *s_out) {
+    // (*P_out = 0: every weight with r >= 1 is zero -- a tensor that fits any twiddle, e.g. W_ai of hop = frame / 2)
+    if (!W || Q < 2 || Qp < 1) return false;
     const int K1 = L + 1;
     double scale = 0;
-    for (int x = 0; x < Q * Q * K1; ++x) scale = std::fmax(scale, std::hypot(W[2 * x], W[2 * x + 1]));
-    for (int p = 0; p < Q; ++p)
-        for (int r = 0; r < Q; ++r)
-            for (int k = 0; k <= L; ++k) {
-                if (r == 0 && k == 0) continue;  // never read
-                const double ang = 2.0 * M_PI * p * r / Q;
-                const double br = W[2 * (r * K1 + k)], bi = W[2 * (r * K1 + k) + 1];
-                const double er = br * std::cos(ang) - bi * std::sin(ang), ei = br * std::sin(ang) + bi * std::cos(ang);
-                const double wr = W[2 * ((p * Q + r) * K1 + k)], wi = W[2 * ((p * Q + r) * K1 + k) + 1];
-                if (std::hypot(wr - er, wi - ei) > 1e-9 * scale) return false;
+    for (size_t x = 0; x < (size_t)Qp * Q * K1; ++x) scale = std::fmax(scale, std::hypot(W[2 * x], W[2 * x + 1]));
+    if (!(scale > 0)) return false;
+    auto at = [&](int p, int r, int k, int c) { return W[2 * (((size_t)p * Q + r) * K1 + k) + c]; };
+    auto verify = [&](int P, int sg) {
+        if (((long long)Qp * sg) % P != 0) return false;   // the rows a kernel reads besides p = bin: p = Qp - bin (modneg, lwslib.cpp:300,408)
+        for (int p = 0; p < Qp; ++p)
+            for (int r = 0; r < Q; ++r) {
+                const double ang = 2.0 * M_PI * (double)(((long long)p * r * sg) % P) / P;
+                const double cs = std::cos(ang), sn = std::sin(ang);
+                for (int k = 0; k < K1; ++k) {
+                    if (r == 0 && k == 0) continue;   // never read by the kernels
+                    const double br = at(0, r, k, 0), bi = at(0, r, k, 1);
+                    if (std::hypot(at(p, r, k, 0) - (br * cs - bi * sn), at(p, r, k, 1) - (br * sn + bi * cs)) > 1e-9 * scale) return false;
+                }
             }
-    return true;
+        return true;
+    };
+    if (Qp == 1) { *P_out = 1; *s_out = 0; return true; }
+    // the turn per bin, theta = s / P, from row 1 against row 0 on the largest weight of the first frame offset r that has one:
+    // that gives r theta mod 1, i.e. r candidates for theta
+    int rb = 0, kb = 0;
+    for (int r = 1; r < Q && rb == 0; ++r)
+        for (int k = 0; k < K1; ++k)
+            if (std::hypot(at(0, r, k, 0), at(0, r, k, 1)) > std::fmax(1e-6 * scale, rb ? std::hypot(at(0, rb, kb, 0), at(0, rb, kb, 1)) : 0.0)) { rb = r; kb = k; }
+    if (rb == 0) {   // nothing but the centre frame: the rows must simply repeat row 0
+        if (!verify(1, 0)) return false;
+        *P_out = 0; *s_out = 0;
+        return true;
+    }
+    const double br = at(0, rb, kb, 0), bi = at(0, rb, kb, 1), wr = at(1, rb, kb, 0), wi = at(1, rb, kb, 1);
+    double tr = std::atan2(wi * br - wr * bi, wr * br + wi * bi) / (2.0 * M_PI);   // arg(w / b) in turns = rb theta mod 1
+    tr -= std::floor(tr);
+    for (int j = 0; j < rb; ++j) {
+        const double theta = (tr + j) / rb;
+        for (int P = 1; P <= pmax; ++P) {
+            const double sp = theta * P, sr = std::round(sp);
+            if (std::fabs(sp - sr) > 1e-7) continue;
+            const int sg = (int)sr % P;
+            if (verify(P, sg)) { *P_out = P; *s_out = sg; return true; }
+            break;                                        // (the smallest P of this candidate failed: multiples of it fail too)
+        }
+    }
+    return false;
+}
+// the table of k_online4<..., TWT>: [P + 3][4] float2, row p: exp(2 pi j p r s / P), r = 0..3 (host side; the plan uploads it)
+void online_twiddle_table(int P, int s, float *out) {
+    for (int p = 0; p < P + 3; ++p)
+        for (int r = 0; r < 4; ++r) {
+            const double ang = 2.0 * M_PI * (double)(((long long)p * r * s) % P) / P;
+            out[(p * 4 + r) * 2] = (float)std::cos(ang);
+            out[(p * 4 + r) * 2 + 1] = (float)std::sin(ang);
+        }
 }
 
-hipError_t launch_online_lds(const GenericArgs<float> &g, int B, hipStream_t stream) {
-    const Shape sh2 = shape_of(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr), sh3 = shape3_of(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr);
-    const Shape4 sh4 = shape4_of(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr);
-    const int layout = pick_layout(sh2, sh3, sh4.sh);
-    if (layout == 0) return hipErrorInvalidValue;
-    const Shape sh = layout == 4 ? sh4.sh : (layout == 3 ? sh3 : sh2);
+hipError_t launch_online_lds(const GenericArgs<float> &g, int B, int tw_P, int tw_s, const float *tw_table_dev, hipStream_t stream) {
     OnlineArgs a;
     a.state = g.state; a.amp = g.amp; a.thr = g.thr;
     for (int i = 0; i < 3; ++i) a.w[i] = g.w[i].w;
+    a.twt = reinterpret_cast<const float2 *>(tw_table_dev); a.PT = tw_P;
+    if (!static_twiddles(g.Q, tw_P, tw_s)) {       // table twiddles: the fourth layout only
+        const Shape4 t4 = shape4_of(g.F, g.T, g.L, g.Q, g.Q, g.LA, g.n_thr, tw_P);
+        if (!t4.sh.ok || !tw_table_dev) return hipErrorInvalidValue;
+        for (int q = 0; q < 8; ++q) a.tw[q] = make_float2(1.f, 0.f);   // (unused)
+        a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = t4.sh.NSW; a.DS = t4.sh.DS;
+        a.NWR = t4.NWR; a.NPS = t4.NPS; a.Lu = g.L;
+        return g.Q == 3 ? launch_4<3, 5, false, false, true>(a, B, t4.sh.lds, stream) : launch_4<4, 5, false, false, true>(a, B, t4.sh.lds, stream);
+    }
+    const Shape sh2 = shape_of(g.F, g.T, g.L, g.Q, g.Q, g.LA, g.n_thr), sh3 = shape3_of(g.F, g.T, g.L, g.Q, g.Q, g.LA, g.n_thr);
+    const Shape4 sh4 = shape4_of(g.F, g.T, g.L, g.Q, g.Q, g.LA, g.n_thr);
+    const int layout = pick_layout(sh2, sh3, sh4.sh);
+    if (layout == 0) return hipErrorInvalidValue;
+    const Shape sh = layout == 4 ? sh4.sh : (layout == 3 ? sh3 : sh2);
     for (int q = 0; q < 8; ++q) {
         const double ang = 2.0 * M_PI * q / g.Q;
         // (exact zeros and ones at the quarter turns: the products with them must not pick up rounding)

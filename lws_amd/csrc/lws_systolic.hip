@@ -2438,48 +2438,6 @@ struct Tables {
     float w[2 * NW];   // (re, im) in the order of SysArgs::w
 };
 
-// Twiddle structure of a weight tensor W[Qp][Q][K1u] (complex128 interleaved): is there a turn theta = s / P per bin and frame
-// offset such that W[p][r][k] = W[0][r][k] exp(2 pi j p r s / P) for every row p?  create_weights (lws.pyx:160-181) builds
-// exactly that, with s / P = hop / frame size in lowest terms -- P = Q, s = 1 for the summarised tensors (Qp = Q rows, row =
-// bin mod Q), anything for the general ones (Qp = N rows, row = bin).  P <= pmax.  Checked in fp64 on every element.
-bool twiddle_structure(const double *W, int Qp, int Q, int K1u, int pmax, int *P_out, int *s_out) {
-    double scale = 0;
-    for (size_t x = 0; x < (size_t)Qp * Q * K1u; ++x) scale = std::fmax(scale, std::hypot(W[2 * x], W[2 * x + 1]));
-    if (!(scale > 0) || Q < 2 || Qp < 1) return false;
-    auto at = [&](int p, int r, int k, int c) { return W[2 * (((size_t)p * Q + r) * K1u + k) + c]; };
-    int P = 1, sgn = 0;
-    if (Qp > 1) {
-        // theta from row 1 against row 0, on the largest weight of frame offset 1
-        int kb = 0;
-        for (int k = 1; k < K1u; ++k)
-            if (std::hypot(at(0, 1, k, 0), at(0, 1, k, 1)) > std::hypot(at(0, 1, kb, 0), at(0, 1, kb, 1))) kb = k;
-        const double br = at(0, 1, kb, 0), bi = at(0, 1, kb, 1), wr = at(1, 1, kb, 0), wi = at(1, 1, kb, 1);
-        if (std::hypot(br, bi) < 1e-6 * scale) return false;
-        double theta = std::atan2(wi * br - wr * bi, wr * br + wi * bi) / (2.0 * M_PI);   // arg(w / b) in turns
-        theta -= std::floor(theta);
-        bool found = false;
-        for (P = 1; P <= pmax; ++P) {
-            const double sp = theta * P, sr = std::round(sp);
-            if (std::fabs(sp - sr) < 1e-7) { sgn = (int)sr % P; found = true; break; }
-        }
-        if (!found) return false;
-    }
-    // the rows a kernel reads besides p = bin: p = Qp - bin (modneg, lwslib.cpp:300,408) must carry the conjugate twiddle
-    if (((long long)Qp * sgn) % P != 0) return false;
-    for (int p = 0; p < Qp; ++p)
-        for (int r = 0; r < Q; ++r) {
-            const double ang = 2.0 * M_PI * (double)(((long long)p * r * sgn) % P) / P;
-            const double cs = std::cos(ang), sn = std::sin(ang);
-            for (int k = 0; k < K1u; ++k) {
-                if (r == 0 && k == 0) continue;   // never read by the kernels
-                const double br = at(0, r, k, 0), bi = at(0, r, k, 1);
-                if (std::hypot(at(p, r, k, 0) - (br * cs - bi * sn), at(p, r, k, 1) - (br * sn + bi * cs)) > 1e-9 * scale) return false;
-            }
-        }
-    *P_out = P; *s_out = sgn;
-    return true;
-}
-
 }  // namespace
 
 // =============================================================================================
@@ -2525,7 +2483,8 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
         auto wre = [&](int p, int r, int k) { return k <= Lu ? W[i][2 * ((p * Q + r) * K1u + k)] : 0.0; };
         auto wim = [&](int p, int r, int k) { return k <= Lu ? W[i][2 * ((p * Q + r) * K1u + k) + 1] : 0.0; };
         int twP = 0, twS = 0;
-        if (!twiddle_structure(W[i], Qp, Q, K1u, TW ? TW_PMAX : Q, &twP, &twS)) continue;
+        if (!lws::weights_twiddle(W[i], Q, Qp, Lu, TW ? TW_PMAX : Q, &twP, &twS)) continue;   // (lws_online.hip: every row p of the tensor, in fp64)
+        if (twP == 0) { twP = Q; twS = 1; }   // (no neighbour-frame weights at all: any twiddle will do)
 #if LWS_TW
         // (tensors whose twiddles are the eighth turns of the static builds are theirs: tried before this one, lws_capi.hip)
 #else

@@ -169,11 +169,12 @@ def test_frames_of_4096_points(fsize, fshift, T, iters, LA, oracle, monkeypatch)
 
 
 def test_fallbacks_to_generic():
-    """Shapes the LDS ring cannot hold, and fp64 plans, stay on the generic engine."""
+    """Q >= 5, and fp64 plans, stay on the generic engine.  (Q = 3 and fractional Q: the table-twiddle variant of the fourth layout,
+    tests/test_gpu_tw.py.)"""
     rng = np.random.default_rng(0)
-    p = lws_amd.lws(48, 16, mode="music")            # Q = 3
-    S = rng.standard_normal((9, 25)) + 1j * rng.standard_normal((9, 25))
-    out, name = _online(25, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 3.0)
+    p = lws_amd.lws(80, 16, mode="music")            # Q = 5
+    S = rng.standard_normal((9, 41)) + 1j * rng.standard_normal((9, 41))
+    out, name = _online(41, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 5.0)
     assert name == "generic_fp32"
     p = lws_amd.lws(64, 16, mode="music")
     S = rng.standard_normal((9, 33)) + 1j * rng.standard_normal((9, 33))

@@ -229,3 +229,65 @@ def test_nofuture_sweeps_with_general_weights_run_on_the_lds_engine(oracle, fsiz
         assert e_lds < 4 * e_gen + 1e-3 and e_lds < 0.2, (fsize, b, e_lds, e_gen)
         assert np.abs(np.abs(out[b]) - np.abs(S[b])).max() < 2e-6 * np.abs(S[b]).max()
     plan.close(); gen.close(); p64.close()
+
+
+def _online(F, W, S, thr, LA, qdiv, **kw):
+    plan = _capi.Plan(F, *W, **kw)
+    out = plan.online(S, thr, LA, qdiv)
+    name = plan.last_kernel()["name"]
+    plan.close()
+    return out, name
+
+
+@pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(48, 16, 24, 3, 3), (48, 16, 7, 0, 2), (96, 32, 16, 1, 3), (768, 256, 12, 3, 3), (400, 160, 14, 3, 3),
+                                                    (400, 160, 30, 5, 2), (512, 160, 12, 3, 3), (1024, 384, 10, 3, 2), (1000, 400, 12, 2, 3),
+                                                    (80, 32, 20, 3, 3), (60, 20, 9, 3, 2)])
+def test_online_sweeps_on_the_lds_engine(fsize, fshift, T, LA, iters, oracle):
+    """TF_RTISI_LA with Q = 3 and with the general weights of a fractional Q (Asym_UpdatePhaseanyQ / Asym_UpdatePhasefractionalQ,
+    lwslib.cpp:1129-1421): the fourth layout of the online LDS engine with its twiddles from a table (k_online4<..., TWT>).  Short
+    runs -- values against the fp64 oracle, as for the static builds (tests/test_gpu_online.py) -- and the same magnitudes as the
+    order-exact generic engine on every bin."""
+    rng = np.random.default_rng(fsize + T)
+    p = lws_amd.lws(fsize, fshift, mode="music")
+    F = fsize // 2 + 1
+    S = rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.1, 1)
+    W = (p.W, p.W_ai, p.W_af)
+    ref = oracle.online_lws(S, *W, thr, LA, fshift)
+    out, name = _online(F, W, S, thr, LA, fsize / fshift)
+    assert name == "online_lds_fp32", name
+    gen, gname = _online(F, W, S, thr, LA, fsize / fshift, force_generic=True)
+    assert gname == "generic_fp32"
+    err, gerr, scale = np.abs(out - ref), np.abs(gen - ref), np.mean(np.abs(S))
+    # (the longer runs already show the stage's own amplification of rounding -- the order-exact fp32 engine is the yardstick there)
+    assert rel_l2(out[:8], ref[:8]) < 1e-4 and np.median(err[:8]) < 2e-6 * scale, (rel_l2(out[:8], ref[:8]), np.median(err[:8]) / scale)
+    assert np.median(err) < max(2e-6 * scale, 10 * np.median(gerr)), (np.median(err) / scale, np.median(gerr) / scale)
+    assert rel_l2(out, ref) < max(1e-3, 5 * rel_l2(gen, ref)), (rel_l2(out, ref), rel_l2(gen, ref))
+    assert np.abs(np.abs(out) - np.abs(gen)).max() < 2e-6 * np.abs(S).max()
+
+
+def test_music_mode_with_speech_framing(oracle):
+    """lws(400, 160, mode='music').run_lws: no-future -> online -> batch, all three on their fast engines.  From zero-phase magnitudes
+    rounding decides many phases in the very first sweep (tests/test_gpu_parity.py), so the pipeline is compared with the oracle's
+    by the consistency it reaches; the stages' values are pinned above on well-conditioned input."""
+    p = lws_amd.lws(400, 160, mode="music", online_iterations=4, batch_iterations=30, batch_alpha=5.0, nofuture_q4_compat=False)
+    rng = np.random.default_rng(4)
+    M = np.abs(rng.standard_normal((80, 201)) + 1j * rng.standard_normal((80, 201)))
+    names = []
+    s0 = p.nofuture_lws(M); names.append(p.plan().last_kernel()["name"])
+    s1 = p.online_lws(s0); names.append(p.plan().last_kernel()["name"])
+    s2 = p.batch_lws(s1); names.append(p.plan().last_kernel()["name"])
+    assert names == ["nofuture_lds_fp32", "online_lds_fp32", "systolic_half_q3_l5_tw"], names
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # nothing lands on the generic engine any more
+        out = p.run_lws(M)
+    r0 = oracle.nofuture_lws(M, p.W_ai, lws_amd.get_thresholds(1, 1, 0.1, 1), compat=False)
+    r1 = oracle.online_lws(r0, p.W, p.W_ai, p.W_af, lws_amd.get_thresholds(4, 1, 0.1, 1), 3, 160)
+    r2 = oracle.batch_lws(r1, p.W, lws_amd.get_thresholds(30, 5.0, 0.1, 1))
+    assert np.abs(np.abs(out) - M).max() < 2e-6 * M.max() and np.abs(np.abs(s2) - M).max() < 2e-6 * M.max()
+    # (80 x 201 bins from a zero-phase start: the trajectories of fp32 and fp64 part in the first frames and the consistency of so
+    # small a spectrogram moves by a dB or two with them; what must hold is that every stage reaches the oracle's level)
+    cons = [(p.get_consistency(mine), p.get_consistency(ref)) for mine, ref in ((s0, r0), (s1, r1), (out, r2))]
+    assert all(a > b - 1.0 and a < b + 3.0 for a, b in cons), cons
+    assert p.get_consistency(out) > p.get_consistency(M.astype(complex)) + 4.0
