@@ -212,10 +212,10 @@ class Plan:
             import warnings
             warnings.warn(
                 "lws_amd: this plan (F=%d bins, Q=%d, L=%d%s) runs on the order-exact generic engine (%s), 20-40x slower than "
-                "the systolic / LDS kernels; those serve fp32 plans with create_weights() tensors: batch sweeps for Q in {2,4,8} "
-                "(F-1 from 16 -- 24 unless a multiple of 8 -- to 2048, Q = 8 to 512; L in 1..5, up to 7 for frames of up to 513 bins) and for "
-                "Q = 3 or a hop that does not divide the frame with ceil(frame/hop) <= 4 (F-1 up to 1024, L <= 5); no-future sweeps whenever "
-                "the frame ring fits the LDS; online sweeps for summarised tensors with Q in {2,4,8}, L <= 5"
+                "the systolic / LDS kernels; those serve fp32 plans with create_weights() tensors (summarised, or general with rows that "
+                "repeat): Q in {2,4,8}, or Q = 3 / a hop that does not divide the frame with ceil(frame/hop) <= 4; batch sweeps for "
+                "F-1 from 16 (24 unless a multiple of 8) to 2048 (Q = 8: to 512, table twiddles: to 1024) and L <= 5 (Q in {2,4}, F <= 513: "
+                "L <= 7); online sweeps for L <= 5; no-future sweeps whenever the frame ring fits the LDS"
                 % (self.F, self.Q, self.L, "" if self.Qp == self.Q else ", general weights", name), RuntimeWarning, stacklevel=3)
 
     def close(self):

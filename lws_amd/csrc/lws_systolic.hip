@@ -32,10 +32,15 @@
 // edge reads its image taps there.  The Nyquist bin (bin F-1) does not fit the 512-step frame period and is
 // computed by the service wave (one lane per sweep in flight), which also runs the loader.
 //
-// Scope of this kernel: summarised weights with the twiddle structure create_weights produces
-// (lws.pyx:160-181: W[p][r][k] = W[0][r][k]*exp(2j*pi*p*r/Q)), Q in {2,4} with L in {1,3,5}, or Q = 8 with L = 5 (its own
-// build: 64-step ring, a main and two helper waves per sweep slot), F-1 even -- a multiple of 8, or a frame end inside a block of 8 steps, one more build per phase (th0) -- and <= 512 (<= 1024: the wide build),
-// fp32 arithmetic, fp32 or fp16 storage.  Anything else is served by the generic engine.
+// Scope of this file (one source, fourteen builds: the -D switches below): weights with the twiddle structure create_weights produces
+// (lws.pyx:160-181: W[p][r][k] = W[0][r][k] exp(2j pi p r s / P), summarised or general tensors), fp32 arithmetic, fp32 or fp16
+// storage, F-1 even (a multiple of 8, or a frame end inside a block of 8 steps: one instantiation per phase, th0) and >= 16:
+//   static twiddles (P = Q, s = 1): Q in {2,4}, L <= 5, F-1 <= 512 (narrow; half / quarter: <= 256 / 128 with 2 / 4 sweep slots
+//     per wave; wide / xwide: <= 1024 / 2048 with 2 / 4 waves per slot; l7: L in {6,7}; r16 variants: Q = 2 on a 16-step ring);
+//     Q = 8, L <= 5, F-1 <= 512 (q8: 64-step ring, a main and two helper waves per sweep slot);
+//   table twiddles (tw, tw_half, tw_wide): Q in {3,4} with any P <= 128 -- Q = 3, and the general weights of a hop that does not
+//     divide the frame -- L <= 5, F-1 <= 1024.
+// Anything else (Q in {5,6,7}, L >= 8, F-1 > 2048, weights without the structure, fp64) is served by the generic engine.
 #include "lws_common.h"
 #include "lws_systolic.h"
 
