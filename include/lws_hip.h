@@ -132,6 +132,16 @@ int lws_residual_dev(lws_plan *plan, const void *S_dev, int B, int T, double *ou
 /* The same for HOST spectrograms S[B][T][F] complex128. */
 int lws_residual(lws_plan *plan, const double *S, int B, int T, double *out);
 
+/* The JOB's residual pair for a caller that runs ONE PROCESS PER GPU (the layout bench.py uses; BASELINE.json north_star: "RCCL
+ * over xGMI used only for the optional final consistency-residual reduction"): this rank's spectrograms are summed on the device
+ *   local[0] = sum_b sum over bins |acc + w00*S|^2,   local[1] = sum_b sum over bins |S|^2      (fp64, fixed order)
+ * and the pair is all-reduced (ncclSum over 2 doubles, in place on the device, on `stream`) over the ranks of `rccl_comm` -- an
+ * ncclComm_t the caller created (ncclCommInitRank) for its ranks; NULL: no collective, out = this rank's sums.  out: 2 HOST doubles,
+ * the same on every rank (synchronises).  RCCL is loaded at the first call (dlopen librccl.so.1): the library does not link
+ * against it, and callers that never pass a communicator never need it (LWS_ERR_UNSUPPORTED if it cannot be loaded).  The reference
+ * has no counterpart (single process, no residual); the single-process multi-GPU form is lws_multi_residual below. */
+int lws_residual_allreduce_dev(lws_plan *plan, const void *S_dev, int B, int T, void *rccl_comm, double *out, void *stream);
+
 /* Timing of the most recent *_dev / host call on this plan, measured with HIP events on the
  * stream the kernels ran on: total milliseconds spent in the update kernels and the number of
  * update-kernel launches (prep / extract kernels are not counted). */

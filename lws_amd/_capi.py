@@ -32,7 +32,7 @@ EXPORTS = (
     "lws_last_kernel_name", "lws_generic_stage", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev",
     "lws_consistency_dev", "lws_hann", "lws_synthwin", "lws_weights_shape", "lws_create_weights",
     "lws_build_asymmetric_windows", "lws_get_thresholds", "lws_plan_create_from_windows", "lws_stream_copy",
-    "lws_run_lws_dev", "lws_plan_reserve", "lws_residual", "lws_multi_plan_create", "lws_multi_plan_destroy",
+    "lws_run_lws_dev", "lws_plan_reserve", "lws_residual", "lws_residual_allreduce_dev", "lws_multi_plan_create", "lws_multi_plan_destroy",
     "lws_multi_plan_shards", "lws_multi_batch_lws", "lws_multi_run_lws", "lws_multi_residual",
 )
 
@@ -111,6 +111,7 @@ def load():
     lib.lws_run_lws_dev.argtypes = [vp, vp, ip, ip, vp, ip, vp, ip, ip, C.c_double, vp, ip, vp]
     lib.lws_plan_reserve.argtypes = [vp, ip, ip, ip]
     lib.lws_residual.argtypes = [vp, vp, ip, ip, vp]
+    lib.lws_residual_allreduce_dev.argtypes = [vp, vp, ip, ip, vp, vp, vp]
     lib.lws_multi_plan_create.argtypes = [C.POINTER(vp), ip, vp, ip, ip, ip, ip, vp, vp, vp, C.c_uint]
     lib.lws_multi_plan_destroy.argtypes = [vp]
     lib.lws_multi_plan_destroy.restype = None
@@ -313,6 +314,13 @@ class Plan:
         S, S3, _ = self._io(S)
         out = np.empty((S3.shape[0], 2), dtype=np.float64)
         check(self._lib.lws_residual(self._h, S3.ctypes.data, S3.shape[0], S3.shape[1], out.ctypes.data))
+        return out
+
+    def residual_allreduce_dev(self, ptr, B, T, comm=None, stream=None):
+        """[sum |acc + w00 S|^2, sum |S|^2] over this rank's B device spectrograms, all-reduced over the ranks of the RCCL
+        communicator `comm` (an ncclComm_t as an integer; None: this rank's sums)."""
+        out = np.empty(2, dtype=np.float64)
+        check(self._lib.lws_residual_allreduce_dev(self._h, ptr, B, T, comm, out.ctypes.data, stream))
         return out
 
     def residual_dev(self, ptr, B, T, stream=None):

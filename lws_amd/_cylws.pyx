@@ -172,6 +172,14 @@ def lws_residual_dev(plan, S_dev, int B, int T, out, stream):
     return rc
 
 
+def lws_residual_allreduce_dev(plan, S_dev, int B, int T, comm, out, stream):
+    cdef uintptr_t p = _addr(plan), s = _addr(S_dev), cm = _addr(comm), o = _addr(out), st = _addr(stream)
+    cdef int rc
+    with nogil:
+        rc = c.lws_residual_allreduce_dev(<c.lws_plan *>p, <const void *>s, B, T, <void *>cm, <double *>o, <void *>st)
+    return rc
+
+
 def lws_residual(plan, S, int B, int T, out):
     cdef uintptr_t p = _addr(plan), s = _addr(S), o = _addr(out)
     cdef int rc

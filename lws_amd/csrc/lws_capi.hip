@@ -23,6 +23,7 @@
 #include <mutex>
 #include <thread>
 #include <sys/mman.h>
+#include <dlfcn.h>
 #ifdef MADV_POPULATE_WRITE
 #define LWS_MADV_POPULATE_WRITE MADV_POPULATE_WRITE
 #else
@@ -169,7 +170,7 @@ struct lws_plan {
     DevBuf online_tw;              // the online engine's twiddle table when those are not the static eighth turns of Q in {2,4,8}
     std::vector<double> hostW[3];  // complex128 interleaved copies (eligibility analysis, systolic tables)
     DevBuf w[3], wflag[3];
-    DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out;
+    DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out, resid_sum;
     DevBuf gsk_state, gsk_amp;     // time-skewed copy of the state for the generic engine's batch sweeps
     HostPipe pipe;                 // host-array entry points: pinned staging, chunk buffers, streams
     lws::SystolicPlan sys;         // device tables of the systolic kernel (empty if not eligible)
@@ -1013,7 +1014,7 @@ void lws_plan_destroy(lws_plan *p) {
     for (int i = 0; i < 3; ++i) { p->w[i].release(); p->wflag[i].release(); }
     p->state.release(); p->amp.release(); p->row_sums.release(); p->mean_amp.release();
     p->thr_host_copy.release(); p->thr_scaled.release(); p->stage.release();
-    p->resid_rows.release(); p->resid_out.release(); p->gsk_state.release(); p->gsk_amp.release(); p->online_tw.release();
+    p->resid_rows.release(); p->resid_out.release(); p->resid_sum.release(); p->gsk_state.release(); p->gsk_amp.release(); p->online_tw.release();
     p->pipe.release();
     delete static_cast<HostWorkers *>(p->host_pool);
     p->host_pool = nullptr;
@@ -1165,6 +1166,58 @@ int lws_residual_dev(lws_plan *p, const void *S_dev, int B, int T, double *out, 
                                             p->Q, p->Qp, s));
     }
     HIP_TRY(hipMemcpyAsync(out, p->resid_out.p, (size_t)B * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LWS_OK;
+}
+
+namespace {
+// sum of the [B][2] per-spectrogram pairs, in a fixed order (one block, tree over 256 partial sums)
+__global__ void __launch_bounds__(256) k_sum_pairs(const double *pairs, double *out, int B) {
+    __shared__ double red[2][256];
+    double a = 0.0, c = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) { a += pairs[2 * b]; c += pairs[2 * b + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) { red[0][threadIdx.x] += red[0][threadIdx.x + s2]; red[1][threadIdx.x] += red[1][threadIdx.x + s2]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
+}
+// ncclAllReduce of librccl, resolved at first use (the library does not link against RCCL)
+using nccl_allreduce_fn = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
+nccl_allreduce_fn rccl_allreduce() {
+    static std::atomic<nccl_allreduce_fn> fn{nullptr};
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                if (void *sym = dlsym(h, "ncclAllReduce")) { fn.store(reinterpret_cast<nccl_allreduce_fn>(sym)); return; }
+            }
+        }
+    });
+    return fn.load();
+}
+}  // namespace
+
+int lws_residual_allreduce_dev(lws_plan *p, const void *S_dev, int B, int T, void *rccl_comm, double *out, void *stream) {
+    if (!p || !S_dev || !out) return fail(LWS_ERR_INVALID, "null argument");
+    if (B <= 0 || T < 1) return fail(LWS_ERR_INVALID, "need B >= 1 and T >= 1");
+    nccl_allreduce_fn allreduce = nullptr;
+    if (rccl_comm && !(allreduce = rccl_allreduce())) return fail(LWS_ERR_UNSUPPORTED, "librccl.so.1 (ncclAllReduce) could not be loaded");
+    std::vector<double> per((size_t)2 * B);
+    int rc = lws_residual_dev(p, S_dev, B, T, per.data(), stream);   // (leaves the [B][2] pairs in p->resid_out on the device)
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = p->resid_sum.ensure(2 * sizeof(double)))) return rc;
+    double *sum = static_cast<double *>(p->resid_sum.p);
+    hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(256), 0, s, static_cast<const double *>(p->resid_out.p), sum, B);
+    HIP_TRY(hipGetLastError());
+    if (rccl_comm) {
+        const int nrc = allreduce(sum, sum, 2, /* ncclFloat64 */ 8, /* ncclSum */ 0, rccl_comm, s);
+        if (nrc != 0) return fail(LWS_ERR_HIP, "ncclAllReduce failed (ncclResult_t %d)", nrc);
+    }
+    HIP_TRY(hipMemcpyAsync(out, sum, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return LWS_OK;
 }

@@ -126,3 +126,45 @@ def test_bench_py_runs_its_multi_rank_branch():
     assert "4shard" in ex["configs"] and ex["configs"]["4shard"]["batch_per_gpu"] == 1024
     assert np.isfinite(ex["residual_db_after"]) and np.isfinite(ex["consistency_db_after"])
     assert ex["headline_checks"]["max_rel_magnitude_error"] < 1e-6
+
+
+def test_c_abi_residual_all_reduce_over_rccl():
+    """lws_residual_allreduce_dev -- the job's residual pair for C / mex callers that run one process per GPU: this rank's sums,
+    all-reduced in place on the device by RCCL (ncclAllReduce, resolved with dlopen: the library does not link against librccl).
+    One GPU here, so the communicator has one rank (ncclCommInitRank through ctypes): the collective really is RCCL's, its result
+    must equal the sums of lws_residual_dev; without a communicator the call is the local sum."""
+    import ctypes as C
+    import torch
+    import lws_amd
+    rng = np.random.default_rng(3)
+    p = lws_amd.lws(64, 16)
+    plan = p.plan()
+    B, T, F = 5, 30, 33
+    S = (rng.standard_normal((B, T, F)) + 1j * rng.standard_normal((B, T, F))).astype(np.complex64)
+    d = torch.from_numpy(S).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    pairs = plan.residual_dev(d.data_ptr(), B, T, stream=stream)
+    local = plan.residual_allreduce_dev(d.data_ptr(), B, T, comm=None, stream=stream)
+    assert np.allclose(local, pairs.sum(axis=0), rtol=1e-12)
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("librccl not loadable")
+    class UniqueId(C.Structure):                      # ncclUniqueId: 128 bytes, passed BY VALUE to ncclCommInitRank
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        red = plan.residual_allreduce_dev(d.data_ptr(), B, T, comm=comm.value, stream=stream)
+        assert np.array_equal(red, local)            # one rank: the sum over ranks is this rank's
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
