@@ -987,10 +987,10 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
                                             &lws::q2::systolic_entry(), &lws::systolic_entry(),
                                             &lws::q8::systolic_entry(), &lws::wide_q2::systolic_entry(), &lws::wide::systolic_entry(), &lws::xwide::systolic_entry(), &lws::l7::systolic_entry(),
                                             // ... then the table-twiddle builds: Q = 3, and general weights of a hop that does not divide the frame
-                                            &lws::tw_half::systolic_entry(), &lws::tw::systolic_entry(), &lws::tw_wide::systolic_entry()}) {
+                                            &lws::tw_half::systolic_entry(), &lws::tw::systolic_entry(), &lws::tw_wide::systolic_entry(), &lws::tw_q8::systolic_entry()}) {
             const bool is_short = b == &lws::quarter::systolic_entry() || b == &lws::half::systolic_entry() || b == &lws::quarter_q2::systolic_entry() ||
                                   b == &lws::half_q2::systolic_entry() || b == &lws::tw_half::systolic_entry();
-            const bool is_tw = b == &lws::tw_half::systolic_entry() || b == &lws::tw::systolic_entry() || b == &lws::tw_wide::systolic_entry();
+            const bool is_tw = b == &lws::tw_half::systolic_entry() || b == &lws::tw::systolic_entry() || b == &lws::tw_wide::systolic_entry() || b == &lws::tw_q8::systolic_entry();
             if (is_tw && env_int("LWS_SYSTOLIC_NO_TW", 0)) continue;                                 // (comparison runs)
             const bool is_r16 = b == &lws::q2::systolic_entry() || b == &lws::wide_q2::systolic_entry() || b == &lws::quarter_q2::systolic_entry() ||
                                 b == &lws::half_q2::systolic_entry();

@@ -74,6 +74,7 @@ namespace half { const SystolicBuild &systolic_entry(); }         // -DLWS_SPW=2
 namespace quarter { const SystolicBuild &systolic_entry(); }      // -DLWS_SPW=4: frames of up to 129 bins, four sweep slots per wave (24)
 namespace tw { const SystolicBuild &systolic_entry(); }           // -DLWS_TW=1: twiddles from a table -- Q = 3, general weights of a fractional Q (Q <= 4), <= 513 bins
 namespace tw_wide { const SystolicBuild &systolic_entry(); }      // -DLWS_TW=1 -DLWS_WIDE=1: the same for frames of up to 1025 bins (two waves per sweep slot)
+namespace tw_q8 { const SystolicBuild &systolic_entry(); }        // -DLWS_TW=1 -DLWS_Q8=1: table twiddles on the 64-step ring with helper waves: ceil(frame/hop) in 5..8
 namespace tw_half { const SystolicBuild &systolic_entry(); }      // -DLWS_TW=1 -DLWS_SPW=2: the same for frames of up to 257 bins (25 ms / 10 ms speech framing)
 
 }  // namespace lws

@@ -32,15 +32,16 @@
 // edge reads its image taps there.  The Nyquist bin (bin F-1) does not fit the 512-step frame period and is
 // computed by the service wave (one lane per sweep in flight), which also runs the loader.
 //
-// Scope of this file (one source, fourteen builds: the -D switches below): weights with the twiddle structure create_weights produces
+// Scope of this file (one source, fifteen builds: the -D switches below): weights with the twiddle structure create_weights produces
 // (lws.pyx:160-181: W[p][r][k] = W[0][r][k] exp(2j pi p r s / P), summarised or general tensors), fp32 arithmetic, fp32 or fp16
 // storage, F-1 even (a multiple of 8, or a frame end inside a block of 8 steps: one instantiation per phase, th0) and >= 16:
 //   static twiddles (P = Q, s = 1): Q in {2,4}, L <= 5, F-1 <= 512 (narrow; half / quarter: <= 256 / 128 with 2 / 4 sweep slots
 //     per wave; wide / xwide: <= 1024 / 2048 with 2 / 4 waves per slot; l7: L in {6,7}; r16 variants: Q = 2 on a 16-step ring);
 //     Q = 8, L <= 5, F-1 <= 512 (q8: 64-step ring, a main and two helper waves per sweep slot);
-//   table twiddles (tw, tw_half, tw_wide): Q in {3,4} with any P <= 128 -- Q = 3, and the general weights of a hop that does not
-//     divide the frame -- L <= 5, F-1 <= 1024.
-// Anything else (Q in {5,6,7}, L >= 8, F-1 > 2048, weights without the structure, fp64) is served by the generic engine.
+//   table twiddles: tw, tw_half, tw_wide -- Q in {3,4} with any P <= 128: Q = 3, and the general weights of a hop that does not
+//     divide the frame -- L <= 5, F-1 <= 1024; tw_q8 -- 5 to 8 frames per stencil row (Q in {5,6,7}, fractional Q above 4) on the
+//     Q = 8 build's geometry, L <= 5, F-1 <= 512.
+// Anything else (hop < frame / 8, L >= 8, F-1 > 2048, weights without the structure, fp64) is served by the generic engine.
 #include "lws_common.h"
 #include "lws_systolic.h"
 
@@ -114,13 +115,19 @@
 #ifndef LWS_TW
 #define LWS_TW 0
 #endif
-#if LWS_TW && (LWS_WIDE == 2 || LWS_Q8 || LWS_L7 || LWS_R16 || LWS_SPW == 4)
-#error "LWS_TW goes with the narrow build, with LWS_SPW=2 or with LWS_WIDE=1"
+// (... and with LWS_Q8 -- namespace lws::tw_q8: the 64-step ring, halo of 7 and helper waves of the Q = 8 build with table twiddles, for
+//  ceil(frame/hop) in 5..8 with any twiddle: Q in {5,6,7}, and fractional Q above 4.  The kernel is the Q = 8 instantiation; the frame
+//  pairs the plan does not have are masked out at compile time, its pad frames and "real frame" tests follow the plan's Q, SysArgs::Qa)
+#if LWS_TW && (LWS_WIDE == 2 || LWS_L7 || LWS_R16 || LWS_SPW == 4 || (LWS_Q8 && (LWS_WIDE || LWS_SPW != 1)))
+#error "LWS_TW goes with the narrow build, with LWS_SPW=2, with LWS_WIDE=1 or with LWS_Q8"
 #endif
 #if (LWS_WIDE && LWS_Q8) || ((LWS_SPW != 1 || LWS_L7) && (LWS_WIDE || LWS_Q8)) || (LWS_SPW != 1 && LWS_L7) || (LWS_R16 && (LWS_WIDE == 2 || LWS_Q8 || LWS_L7))
 #error "LWS_WIDE, LWS_Q8, LWS_SPW, LWS_L7 and LWS_R16 are separate builds (LWS_R16 goes with LWS_WIDE=1 or LWS_SPW)"
 #endif
-#if LWS_TW && LWS_SPW == 2
+#if LWS_TW && LWS_Q8
+#define LWS_NS_OPEN namespace lws { namespace tw_q8 {
+#define LWS_NS_CLOSE } }
+#elif LWS_TW && LWS_SPW == 2
 #define LWS_NS_OPEN namespace lws { namespace tw_half {
 #define LWS_NS_CLOSE } }
 #elif LWS_TW && LWS_WIDE
@@ -222,11 +229,13 @@ __host__ __device__ constexpr int help_ahead(int h) { return h >= 1 ? 4 : 4; }
 constexpr int MBOX_OFF = SCRATCH_OFF + SCRATCH_BYTES;    // [slot][helper][pair & 3][lane]: (sum of the first bin, of the second)
 constexpr int MBOX_BYTES = NSLOTS * NHELP * 4 * LANES * 16;
 constexpr int WNYQ_OFF = MBOX_OFF + MBOX_BYTES;          // Q = 8: the Nyquist lanes' weights (the waves keep only their own in registers)
-constexpr int LDS_BASE_BYTES = WNYQ_OFF + (LWS_Q8 ? QMAX * 6 * 8 : 0);
+constexpr int TWNYQ_OFF = WNYQ_OFF + (LWS_Q8 ? QMAX * 6 * 8 : 0);   // Q = 8 with table twiddles: tau_r(F-1), r = 0..7, for the Nyquist lanes
+                                                                     // (a per-lane index: from LDS, like their weights)
+constexpr int LDS_BASE_BYTES = TWNYQ_OFF + ((LWS_Q8 && LWS_TW) ? 8 * 8 : 0);
 // LWS_TW: the twiddle table, [row][r - 1] float2 with row = bin mod P, rows 0 .. P + 7 (a lane holds the row of its block's first
 // bin; the other seven bins of the block are compile-time offsets from it); a row is TW_ROW bytes: tau_1, tau_2, tau_3, unused
 constexpr bool TW = LWS_TW != 0;
-constexpr int TW_ROW = 32;
+constexpr int TW_ROW = LWS_Q8 ? 64 : 32;              // (the 64-step-ring build: tau_1 .. tau_7, unused)
 constexpr int TW_OFF = (LDS_BASE_BYTES + 15) & ~15;
 constexpr int TW_PMAX = TW ? ((160 * 1024 - TW_OFF) / TW_ROW - 8 < 128 ? (160 * 1024 - TW_OFF) / TW_ROW - 8 : 128) : 0;   // longest twiddle period served
 constexpr int LDS_BYTES = TW ? TW_OFF + (TW_PMAX + 8) * TW_ROW : LDS_BASE_BYTES;
@@ -334,7 +343,9 @@ struct SysArgs {
     const float *tw_table;   // device: [(P + 8)][4] float2, row p: tau_1(p), tau_2(p), tau_3(p), 0
     int tw_P;                // period of the twiddles in bins
     float tw_invP;
-    unsigned long long tw_nyq[4];  // tau_r(F-1), r = 0..3, for the Nyquist lanes: bit patterns of (re, im)
+    unsigned long long tw_nyq[8];  // tau_r(F-1), r = 0..7, for the Nyquist lanes: bit patterns of (re, im)
+    int Qa;                  // the plan's Q (frames of a stencil row): the template Q, except in the build lws::tw_q8, whose kernel is the
+                             // Q = 8 instantiation for every Q in 5..8
     unsigned long long w[NW];      // W[0][r][k], r < Q, k <= L (at most 4 x 8): bit patterns of (re, im) as one 64-bit scalar;
                                    // Q = 8: [set][r][k] with set 1 = W[0][r][k] exp(j pi / 4), see widx()
 };
@@ -483,6 +494,7 @@ struct LaneCtx {
     int whi1[NDR];                  // RE != 0: the same as whi for the lane in the block before its end block (cells from th1 on)
     int mbox;                       // Q = 8: mailbox of the slot's first helper, pair 0 (own lane)
     int tw;                         // LWS_TW: LDS address of the twiddle-table row of this block's first bin
+    int tw_nxt;                     // ... and of the next block's (helper waves work ahead)
     int img_lo, img_hi, img_both;   // image_base(): row origin for the image stores of this block (phases with an image below DC / above
                                     // Nyquist / both)
 };
@@ -1004,7 +1016,7 @@ __device__ __forceinline__ void quad_finish(const SysArgs &a, const QuadCarry<L>
 // (lwslib.cpp:321-352 with W[mod] = W0 tau, W[modneg] = W0 conj(tau)).  The one group whose last operand is not in the ring yet
 // (fourth bin, k = L, frames m-1 / m+LATE_DN) is left to the second pair as in the other builds (QuadCarry::g, tw_finish).
 template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int N>
-__device__ __forceinline__ void tw_rows(const SysArgs &a, const LaneCtx &cx, const float2 (&tu)[N], const float2 (&td)[N],
+__device__ __forceinline__ void tw_rows(const SysArgs &a, int twbase, const float2 (&tu)[N], const float2 (&td)[N],
                                         float2 &accr, QuadCarry<L> &qc) {
     constexpr int K1 = L + 1, c = L + 1 + OFFS;
     static_assert(c + L < N && PH >= 0 && PH < 8, "tap window too short");
@@ -1027,7 +1039,7 @@ __device__ __forceinline__ void tw_rows(const SysArgs &a, const LaneCtx &cx, con
             }
         }
     });
-    pair_v(accr, lds_read(cx.tw + PH * TW_ROW + (R - 1) * 8), U, D);
+    pair_v(accr, lds_read(twbase + PH * TW_ROW + (R - 1) * 8), U, D);
 }
 // ... and the deferred group, by the second pair: `late` is the tap that was not there yet (frame m-R's or m+R's, at +L)
 template <int Q, int L, uint64_t MASK, int PH, int R>
@@ -1148,19 +1160,21 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
     constexpr bool r13 = (MASK & FLAG_R13) != 0 && Q == 4;
     if constexpr (TW && quad_first) {
         // (LWS_TW: the same windows; per frame pair the sums U, D of each of the quad's four bins, turned by the bin's twiddle)
-        static_assert(LATE_DN != 1 && NHELP == 0 && !r13, "narrow geometry");
+        static_assert(LATE_DN != 1 && !r13, "32- or 64-step ring");
         qc.accA = make_float2(0.f, 0.f);
         qc.accB = make_float2(0.f, 0.f);
         static_for<Q - 1>([&](auto ir) {
             constexpr int R = decltype(ir)::value + 1;
-            float2 tu[2 * L + 6], td[2 * L + 6];
             constexpr uint32_t kmask = (uint32_t)((MASK >> (R * K1)) & ((1ull << K1) - 1ull));
-            load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, tu);
-            load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, td);
-            tw_rows<Q, L, MASK, PA, R, 0>(a, cx, tu, td, accA, qc);
-            tw_rows<Q, L, MASK, PA + 1, R, 1>(a, cx, tu, td, accB, qc);
-            tw_rows<Q, L, MASK, PA + 2, R, 2>(a, cx, tu, td, qc.accA, qc);
-            tw_rows<Q, L, MASK, PA + 3, R, 3>(a, cx, tu, td, qc.accB, qc);
+            if constexpr (row_owner(R) == 0 && kmask != 0) {   // (else: a helper wave's frames, or frames this plan's Q does not have)
+                float2 tu[2 * L + 6], td[2 * L + 6];
+                load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, tu);
+                load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, td);
+                tw_rows<Q, L, MASK, PA, R, 0>(a, cx.tw, tu, td, accA, qc);
+                tw_rows<Q, L, MASK, PA + 1, R, 1>(a, cx.tw, tu, td, accB, qc);
+                tw_rows<Q, L, MASK, PA + 2, R, 2>(a, cx.tw, tu, td, qc.accA, qc);
+                tw_rows<Q, L, MASK, PA + 3, R, 3>(a, cx.tw, tu, td, qc.accB, qc);
+            }
             if constexpr (R == 1) LWS_SETPRIO(0);
             if constexpr (R == Q - 1) LWS_SETPRIO(2);
         });
@@ -1171,7 +1185,7 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
             float2 u1[2 * L + 6], d3[2 * L + 6];
             load_cells<PA0, -1, L, L + 2, 1, (uint32_t)((MASK >> K1) & ((1ull << K1) - 1ull)), 0, RE>(cx, u1);
             tw_finish<Q, L, MASK, PHB, 1>(a, cx, qc, u1[2 * L + 4], accB);
-            if constexpr (Q > LATE_DN) {
+            if constexpr (Q > LATE_DN && ((MASK >> ((Q > LATE_DN ? LATE_DN : 0) * K1)) & ((1ull << K1) - 1ull)) != 0) {
                 load_cells<PA0, LATE_DN, L, L + 2, 1, (uint32_t)((MASK >> ((Q > LATE_DN ? LATE_DN : 0) * K1)) & ((1ull << K1) - 1ull)), 0, RE>(cx, d3);
                 tw_finish<Q, L, MASK, PHB, (Q > LATE_DN ? LATE_DN : 1)>(a, cx, qc, d3[2 * L + 4], accB);
             }
@@ -1265,14 +1279,24 @@ __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx,
                 // two steps ahead of the second pair (rows_sum_ahead) and AHEAD ahead of the main wave: the newest tap
                 // fetched (fourth bin, +L) must have been produced before this pair started
                 static_assert(SKEW * R - L - 3 - AHEAD >= 1 && LAG - SKEW * R - L - 3 - AHEAD >= 1, "helper runs too far ahead");
-                float2 tu[2 * L + 6], td[2 * L + 6];
                 constexpr uint32_t kmask = (uint32_t)((MASK >> (R * (L + 1))) & ((1ull << (L + 1)) - 1ull));
+                if constexpr (kmask != 0) {
+                float2 tu[2 * L + 6], td[2 * L + 6];
                 load_cells<PH0, -R, L, 0, L + 3, kmask, CO, RE>(cx, tu);
                 load_cells<PH0, R, L, 0, L + 3, kmask, CO, RE>(cx, td);
+                if constexpr (TW) {          // (the bins belong to this block or -- CO = 8 -- to the lane's next one)
+                    const int twb = CO ? cx.tw_nxt : cx.tw;
+                    tw_rows<Q, L, MASK, PH, R, 0>(a, twb, tu, td, accA, qc);
+                    tw_rows<Q, L, MASK, PH + 1, R, 1>(a, twb, tu, td, accB, qc);
+                    tw_rows<Q, L, MASK, PH + 2, R, 2>(a, twb, tu, td, qc.accA, qc);
+                    tw_rows<Q, L, MASK, PH + 3, R, 3>(a, twb, tu, td, qc.accB, qc);
+                } else {
                 rows_sum<Q, L, MASK, PH, R, 0>(a, tu, td, p3, accA);
                 rows_sum<Q, L, MASK, PH + 1, R, 1>(a, tu, td, p3, accB);
                 rows_sum_ahead<Q, L, MASK, PH + 2, R, 2>(a, tu, td, p3, qc.accA, qc);
                 rows_sum_ahead<Q, L, MASK, PH + 3, R, 3>(a, tu, td, p3, qc.accB, qc);
+                }
+                }
             }
         });
     } else {
@@ -1339,7 +1363,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     }
     if (is_nyq_lane) {
         const float target = raw_real<H16>(sv.nyq_amp_next);
-        const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
+        const bool real_row = valid && (me >= a.Qa - 1) && (me < a.T + a.Qa - 1);
         const float thr = thr_eff[valid ? j : 0];
         const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
         int nb[Q][NBLK], ob[Q][NBLK], nn[Q], no[Q];
@@ -1453,7 +1477,7 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
     }
     if (is_nyq_lane) {
         const float target = raw_real<H16>(sv.nyq_amp_next);
-        const bool real_row = valid && (me >= Q - 1) && (me < a.T + Q - 1);
+        const bool real_row = valid && (me >= a.Qa - 1) && (me < a.T + a.Qa - 1);
         const float thr = thr_eff[valid ? j : 0];
         const int set_new = (slot + 1) * SET_BYTES, set_old = slot * SET_BYTES;
         const int ln = (rho - r) & (ROWL - 1), lo = (rho + r) & (ROWL - 1);
@@ -1464,10 +1488,12 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
         // (RE != 0: the taps k <= RE lie in the block of the frame end itself, one ring block later)
         const int bn1 = set_new + ((ablk - r) & (NBLK - 1)) * BLK_BYTES + (ln + HALO) * LANE_B;
         const int bo1 = set_old + ((ablk + r) & (NBLK - 1)) * BLK_BYTES + (lo + HALO) * LANE_B;
-        const int rot = RE ? ((RE * r) >> 1) & 3 : 0;        // quarter turns of this lane's weights
+        // (LWS_TW: the lane's twiddle tau_r(C) is any complex number: taps turned as in service_nyquist, weights as they are)
+        const float2 tau = TW ? lds_read(TWNYQ_OFF + (r & 7) * 8) : make_float2(1.f, 0.f);
+        const int rot = (RE && !TW) ? ((RE * r) >> 1) & 3 : 0;        // quarter turns of this lane's weights
         const float sg = (rot & 1) ? -1.f : 1.f;             // b = um +- dp, c = dm +- up: minus for an odd quarter turn
         auto turned = [&](wp_t w) -> wp_t {
-            if constexpr (RE == 0) return w;
+            if constexpr (RE == 0 || TW) return w;
             float wr = __uint_as_float((unsigned)(w & 0xffffffffull)), wi = __uint_as_float((unsigned)(w >> 32));
             const float t = wr;
             wr = (rot & 1) ? -wi : wr; wi = (rot & 1) ? t : wi;
@@ -1476,21 +1502,29 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
         };
         const int nn = NYQ_OFF + (slot + 1) * SLOT_BYTES + ln * 8, no = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
         const bool centre = r == 0;                 // its "frame m+r" terms are the images: dn = 0 below gives b = up, c = conj(up)
+        // (lws::tw_q8: a plan with Q < 8 has no frames m-+r for r >= Q.  Their weights are zero, but what sits at those ring
+        //  positions near the ends of the spectrogram was never written -- and zero times a stale NaN is not zero)
+        const bool dead = TW && r >= a.Qa;
         const float2 zero = make_float2(0.f, 0.f);
         float2 acc = zero;
         {
-            const float2 un = lds_read(nn), dn = lds_read(no);
-            pair_rot<0>(acc, turned(nyq_weight(a, r * K1)), centre ? zero : un, centre ? zero : dn);
+            float2 un = lds_read(nn), dn = lds_read(no);
+            if constexpr (TW) { un = cmulf(tau, un); dn = cmulf(cj(tau), dn); }
+            pair_rot<0>(acc, turned(nyq_weight(a, r * K1)), (centre || dead) ? zero : un, (centre || dead) ? zero : dn);
         }
         static_for<L>([&](auto ik) {
             constexpr int k = decltype(ik)::value + 1, within = (RE - k) & 7;   // time RE - k of the block, or of the one before
             constexpr bool same_block = RE - k >= 0;
             constexpr int off = (within >> 1) * PAIR_BYTES + (within & 1) * 8;
-            const float2 up = lds_read((same_block ? bn1 : bn) + off);
+            float2 up = lds_read((same_block ? bn1 : bn) + off);
             float2 dn = lds_read((same_block ? bo1 : bo) + off);
-            dn = centre ? zero : dn;
+            dn = (centre || dead) ? zero : dn;
+            up = dead ? zero : up;
             float2 bsum, csum;
-            if constexpr (RE == 0) {
+            if constexpr (TW) {                                 // W0 X + conj(W0) conj(X), X = tau up + conj(tau dn)  (service_nyquist)
+                bsum = cadd(cmulf(tau, up), cj(cmulf(tau, dn)));
+                csum = cj(bsum);
+            } else if constexpr (RE == 0) {
                 bsum = make_float2(up.x + dn.x, up.y - dn.y);   // up + conj(dn)
                 csum = make_float2(dn.x + up.x, dn.y - up.y);   // dn + conj(up)
             } else {
@@ -1553,6 +1587,12 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             const float re = __uint_as_float((unsigned)(u & 0xffffffffull)) * sc;
             const float im = __uint_as_float((unsigned)(u >> 32)) * sc;
             a.w[x] = ((unsigned long long)__float_as_uint(im) << 32) | __float_as_uint(re);
+        }
+        if constexpr (TW) {             // ... and their twiddles (static indices: a run-time index would put the arguments in scratch)
+            static_for<8>([&](auto ir) {
+                constexpr int r = decltype(ir)::value;
+                if (threadIdx.x == 64 + r) reinterpret_cast<float2 *>(smem + TWNYQ_OFF)[r] = wp_value(a_in.tw_nyq[r]);
+            });
         }
         if (threadIdx.x < QMAX * 6) {   // the Nyquist lanes' table (the __syncthreads() below publishes it)
             const unsigned long long u = a_in.w[WNYQ + threadIdx.x];
@@ -1782,7 +1822,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
         const int me = (here ? meb_c : meb_p) + rl;
         const bool valid = (here ? ok_c : ok_p) && (me < a.Tp);
         BlockInfo bi;
-        bi.live = valid && (me >= Q - 1) && (me < a.T + Q - 1) && (cbase < C);
+        bi.live = valid && (me >= a.Qa - 1) && (me < a.T + a.Qa - 1) && (cbase < C);
         bi.start = (cbase == 0);
         bi.end = (cbase == C - th0(RE));
         bi.end1 = (RE != 0) && (cbase == C - th1(RE));
@@ -1822,7 +1862,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                 const BlockInfo cur = nxt_bi;
                 nxt_bi = block_info(v0 + 8);
                 cx.live = cur.live; cx.is_start = cur.start; cx.is_end = cur.end; cx.is_end1 = cur.end1; cx.thr = cur.thr;
-                cx.tw = cur.tw;
+                cx.tw = cur.tw; cx.tw_nxt = nxt_bi.tw;
                 cx.nxt_live = nxt_bi.live; cx.nxt_start = nxt_bi.start; cx.nxt_end = nxt_bi.end; cx.nxt_end1 = nxt_bi.end1;
                 cx.nxt_thr = nxt_bi.thr;
             }
@@ -2405,12 +2445,16 @@ template <int Q, int L, uint64_t MASK, bool MULTI, bool H16, int RE> hipError_t 
     return hipGetLastError();
 }
 template <int Q, int L, uint64_t MASK, int RE> hipError_t launch_kr(const SysArgs &a, int grid, bool h16, hipStream_t s) {
+#if LWS_TW && LWS_Q8
+    if (h16) return hipErrorInvalidValue;   // (not instantiated: systolic_build refuses fp16 storage for this build)
+#else
     if (h16) return a.nwg > 1 ? launch_km<Q, L, MASK, true, true, RE>(a, grid, s) : launch_km<Q, L, MASK, false, true, RE>(a, grid, s);
+#endif
     return a.nwg > 1 ? launch_km<Q, L, MASK, true, false, RE>(a, grid, s) : launch_km<Q, L, MASK, false, false, RE>(a, grid, s);
 }
 // one build of the kernel per phase of the block at which the frames end, (F-1) mod 8 (see th0)
 template <int Q, int L, uint64_t MASK> hipError_t launch_k(const SysArgs &a, int grid, bool h16, hipStream_t s) {
-#if LWS_Q8
+#if LWS_Q8 && !LWS_TW
     // (the hop is an eighth of the frame size: F-1 is a multiple of 4, the frames end at phase 0 or 4)
     if ((a.C & 7) == 4) return launch_kr<Q, L, MASK, 4>(a, grid, h16, s);
     if ((a.C & 7) != 0) return hipErrorInvalidValue;
@@ -2439,7 +2483,7 @@ struct Tables {
     // (these fields sit at the same offsets in every build of this file -- w[] below does not have the same length in all)
     int tw_P = 0, tw_s = 0;
     float *tw_dev = nullptr;
-    float tw_nyq[8] = {0};   // tau_r(F-1), r = 0..3
+    float tw_nyq[16] = {0};  // tau_r(F-1), r = 0..7
     float w[2 * NW];   // (re, im) in the order of SysArgs::w
 };
 
@@ -2463,7 +2507,9 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
     // Qp: rows of the weight tensors -- Q (summarised: row = bin mod Q) or N = 2 (F-1) (general: row = bin; use_simplifications =
     // False or a hop that does not divide the frame, lws.pyx:164-168).  Either way the kernels want the twiddle structure, below.
     if (Qp != Q && Qp != 2 * (F - 1)) return hipSuccess;
-#if LWS_TW
+#if LWS_TW && LWS_Q8
+    if (Q < 5 || Q > 8 || Lu > 5 || fp16_storage) return hipSuccess;   // (fp32 storage only: half the instantiations of the other builds)
+#elif LWS_TW
     if (Q < 3 || Q > 4 || Lu > 5) return hipSuccess;     // (stencils narrower than L = 5 run with zero weights)
 #elif LWS_Q8
     if (Q != 8 || L != 5) return hipSuccess;
@@ -2476,7 +2522,7 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
 #endif
     // F-1 even (a pair of bins never straddles bin C); not a multiple of 8: the frames end inside a block (th0), and the block
     // before that one must not be the frame's first
-    if ((C & 1) != 0 || C > ROWP || C < 16 || (C % 8 != 0 && (C < 24 || (LWS_Q8 && C % 8 != 4))) || (LWS_L7 && C > 512)) return hipSuccess;
+    if ((C & 1) != 0 || C > ROWP || C < 16 || (C % 8 != 0 && (C < 24 || (LWS_Q8 && !LWS_TW && C % 8 != 4))) || (LWS_L7 && C > 512)) return hipSuccess;
     if ((Q - 1) * SKEW + L + 1 > LAG) return hipSuccess;
     const int K1 = L + 1;
     for (int i = 0; i < 3; ++i) {
@@ -2502,14 +2548,15 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
 #if LWS_TW
         {
             // the kernel's table: row p (p = 0 .. P + 7, periodic) = tau_1(p), tau_2(p), tau_3(p), 0; formed in fp64, rounded once
-            std::vector<float> tab((size_t)(twP + 8) * 8, 0.f);
+            constexpr int RF = TW_ROW / 4;     // floats per table row
+            std::vector<float> tab((size_t)(twP + 8) * RF, 0.f);
             for (int pp = 0; pp < twP + 8; ++pp)
                 for (int r = 1; r < Q; ++r) {
                     const double ang = 2.0 * M_PI * (double)(((long long)pp * r * twS) % twP) / twP;
-                    tab[(size_t)pp * 8 + 2 * (r - 1)] = (float)std::cos(ang);
-                    tab[(size_t)pp * 8 + 2 * (r - 1) + 1] = (float)std::sin(ang);
+                    tab[(size_t)pp * RF + 2 * (r - 1)] = (float)std::cos(ang);
+                    tab[(size_t)pp * RF + 2 * (r - 1) + 1] = (float)std::sin(ang);
                 }
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 8; ++r) {
                 const double ang = 2.0 * M_PI * (double)(((long long)C * r * twS) % twP) / twP;
                 tb->tw_nyq[2 * r] = (float)std::cos(ang);
                 tb->tw_nyq[2 * r + 1] = (float)std::sin(ang);
@@ -2702,11 +2749,12 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         a.rolemap = er ? atoi(er) : 0;
     }
     a.tw_table = tb->tw_dev; a.tw_P = tb->tw_P > 0 ? tb->tw_P : 1; a.tw_invP = 1.0f / (float)a.tw_P;
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 8; ++r) {
         unsigned ur, ui;
         memcpy(&ur, &tb->tw_nyq[2 * r], 4); memcpy(&ui, &tb->tw_nyq[2 * r + 1], 4);
         a.tw_nyq[r] = ((unsigned long long)ui << 32) | ur;
     }
+    a.Qa = Q;
     for (int x = 0; x < NW; ++x) {
         const bool used = LWS_Q8 || x < Q * (L + 1);
         const float re = used ? tb->w[2 * x] : 0.f, im = used ? tb->w[2 * x + 1] : 0.f;
@@ -2718,7 +2766,14 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     const bool h = sp.h16;
     hipError_t e;
     const char *kind = "allmask";
-#if LWS_TW
+#if LWS_TW && LWS_Q8
+    // the Q = 8 kernel with the frame pairs r >= Q of the plan masked out (never fetched, never summed)
+    kind = "tw";
+    if (Q == 5) e = launch_k<8, 5, mask_all(5, 5)>(a, grid, h, stream);
+    else if (Q == 6) e = launch_k<8, 5, mask_all(6, 5)>(a, grid, h, stream);
+    else if (Q == 7) e = launch_k<8, 5, mask_all(7, 5)>(a, grid, h, stream);
+    else e = launch_k<8, 5, mask_all(8, 5)>(a, grid, h, stream);
+#elif LWS_TW
     kind = "tw";
     // hop = a third of the frame with the default sqrt-Hann window: of the centre frame's weights only k = 1 is non-zero (as for Q = 2, 4)
     constexpr uint64_t MASK_Q3_L5_DEFAULT = 0b111111'111111'000011u;
@@ -2753,7 +2808,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
 #endif
-    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_TW && SPW == 2) ? "_half" : (LWS_TW && LWS_WIDE) ? "_wide" : LWS_TW ? "" : (LWS_R16 && LWS_WIDE) ? "_wide_r16" : (LWS_R16 && SPW == 2) ? "_half_r16" : (LWS_R16 && SPW == 4) ? "_quarter_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
+    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_TW && SPW == 2) ? "_half" : (LWS_TW && LWS_WIDE) ? "_wide" : (LWS_TW && LWS_Q8) ? "_r64" : LWS_TW ? "" : (LWS_R16 && LWS_WIDE) ? "_wide_r16" : (LWS_R16 && SPW == 2) ? "_half_r16" : (LWS_R16 && SPW == 4) ? "_quarter_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
              h ? "_f16" : "");
     sp.name = sp.name_buf;
     return e;

@@ -130,3 +130,32 @@ def test_generic_batch_on_the_skewed_copy_is_bit_identical(fsize, fshift, L, T, 
         for i in range(2):
             assert np.abs(a[i] - oracle.batch_lws(S[i], p.W, thr)).max() < 1e-8
     skew.close(); plain.close()
+
+
+@pytest.mark.parametrize("fsize,fshift,T,mode", [(1024, 256, 70, "batch"), (512, 128, 131, "batch"), (2048, 512, 40, "batch"), (1024, 128, 37, "batch"),
+                                                 (1024, 512, 66, "batch"), (4096, 1024, 20, "batch"), (1000, 250, 37, "batch"), (1024, 256, 33, "music"),
+                                                 (400, 160, 40, "music"), (1000, 200, 37, "batch")])
+def test_stale_device_memory_never_reaches_a_result(fsize, fshift, T, mode):
+    """A plan's scratch comes from hipMalloc as it is; LDS is what the previous kernel left.  Whatever sits in the entries of a
+    kernel's layout that no (frame, bin) owns must not reach a result, not even through a zero weight (0 x NaN): the same call on a
+    fresh plan gives the same bits after the device's free memory was filled with NaN, Inf and 1e30 and given back."""
+    import torch
+    rng = np.random.default_rng(fsize + T)
+    F = fsize // 2 + 1
+    S = np.abs(rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))).astype(np.complex128)
+    S[1] *= 25.0
+
+    def run():
+        if mode == "music":
+            p = lws_amd.lws(fsize, fshift, mode="music", online_iterations=3, batch_iterations=8, batch_alpha=2.0)
+            return p.run_lws(S)
+        p = lws_amd.lws(fsize, fshift)
+        return p.plan().batch(S, lws_amd.get_thresholds(9, 2.0, 0.3, 1))
+    ref = run()
+    assert np.isfinite(ref).all()
+    for fill in (float("nan"), float("inf"), 1e30):
+        x = torch.full((1 << 28,), fill, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        del x
+        torch.cuda.empty_cache()
+        assert np.array_equal(run(), ref), fill

@@ -30,9 +30,10 @@ def tw_case(oracle, fsize, fshift, T, thr, seed, B=2, scale=(1.0, 40.0), L=5, us
     out = plan.batch(S, thr)
     name = plan.last_kernel()["name"]
     assert name.startswith("systolic") and name.endswith("_" + expect), name
-    if expect == "tw":
+    r64 = -(-fsize // fshift) >= 5          # five or more frames per stencil row: the 64-step ring (frames of up to 513 bins)
+    if expect == "tw" and not r64:
         assert ("_half_" in name) == (F <= 257) and ("_wide_" in name) == (F > 513), name
-    if expect == "tw" and F <= 257:
+    if expect == "tw" and F <= 257 and not r64:
         # the build with two sweep slots per wave does the arithmetic of the one-slot build in the same order: identical bits
         os.environ["LWS_SYSTOLIC_NO_SHORT"] = "1"
         try:
@@ -136,15 +137,16 @@ def test_narrower_stencils(oracle, L):
 
 
 def test_what_the_table_builds_do_not_take():
-    """Q >= 5 (the taps reach further than the 32-step ring holds), twiddle periods longer than the table, L > 5: generic engine."""
-    for fsize, fshift, L in ((1000, 200, 5), (768, 128, 5), (1024, 160, 5), (400, 160, 7)):
+    """More than 8 frames per stencil row, Q >= 5 above 513 bins, L > 5: generic engine."""
+    for fsize, fshift, L in ((1008, 112, 5), (2000, 400, 5), (400, 160, 7), (1000, 200, 6)):
         p = lws_amd.lws(fsize, fshift, L=L)
         with pytest.warns(RuntimeWarning):
             p.batch_lws(np.ones((4, fsize // 2 + 1)), thresholds=[0.0])
         assert p.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32"), (fsize, fshift)
 
 
-@pytest.mark.parametrize("fsize,fshift,B,T,iters", [(400, 160, 3, 300, 30), (1000, 400, 2, 200, 30), (768, 256, 5, 260, 16), (2048, 768, 3, 150, 20)])
+@pytest.mark.parametrize("fsize,fshift,B,T,iters", [(400, 160, 3, 300, 30), (1000, 400, 2, 200, 30), (768, 256, 5, 260, 16), (2048, 768, 3, 150, 20),
+                                                    (1000, 200, 2, 300, 9), (1024, 160, 3, 200, 7)])
 def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, iters, monkeypatch):
     rng = np.random.default_rng(B * T)
     F = fsize // 2 + 1
@@ -162,7 +164,7 @@ def test_workgroups_sharing_a_spectrogram_change_nothing(fsize, fshift, B, T, it
     assert np.array_equal(p.plan().batch(S, thr), ref)
 
 
-@pytest.mark.parametrize("fsize,fshift,T", [(400, 160, 150), (1000, 400, 150), (768, 256, 100), (2048, 768, 100)])
+@pytest.mark.parametrize("fsize,fshift,T", [(400, 160, 150), (1000, 400, 150), (768, 256, 100), (2048, 768, 100), (1000, 200, 150), (1024, 160, 100)])
 def test_stalled_waves_change_nothing(fsize, fshift, T, monkeypatch):
     rng = np.random.default_rng(T)
     F = fsize // 2 + 1
@@ -291,3 +293,30 @@ def test_music_mode_with_speech_framing(oracle):
     cons = [(p.get_consistency(mine), p.get_consistency(ref)) for mine, ref in ((s0, r0), (s1, r1), (out, r2))]
     assert all(a > b - 1.0 and a < b + 3.0 for a, b in cons), cons
     assert p.get_consistency(out) > p.get_consistency(M.astype(complex)) + 4.0
+
+
+@pytest.mark.parametrize("fsize,fshift,T", [(80, 16, 70), (1000, 200, 37), (960, 192, 66), (96, 16, 131), (768, 128, 40), (1020, 170, 33),
+                                            (112, 16, 70), (896, 128, 37), (1008, 144, 65), (1024, 160, 40), (1024, 176, 21), (1000, 150, 37),
+                                            (1024, 192, 33), (100, 20, 64), (1012, 184, 30), (1024, 128, 37)])
+def test_five_to_eight_frames_per_stencil_row(oracle, fsize, fshift, T):
+    """ceil(frame / hop) in 5..8 -- Q = 5, 6, 7 (the reference's LWSanyQ) and fractional Q above 4 (LWSfractionalQ; lws(1024, 160):
+    Qfloat = 6.4) -- on the 64-step ring of the Q = 8 build with table twiddles (lws::tw_q8: the Q = 8 kernel, the frame pairs the plan
+    does not have masked out).  lws(1024, 128) itself stays on the static Q = 8 build."""
+    q = -(-fsize // fshift)
+    static = fsize % fshift == 0 and q == 8
+    out, name = tw_case(oracle, fsize, fshift, T, THR, seed=fsize + T, expect="hann" if static else "tw")
+    assert ("_r64_q%d_" % q in name) == (not static), name
+
+
+@pytest.mark.parametrize("fsize,fshift,T", [(1000, 200, 37), (112, 16, 70), (100, 20, 64), (400, 160, 70), (768, 256, 40)])
+def test_results_do_not_depend_on_stale_device_memory(oracle, fsize, fshift, T):
+    """The scratch of a plan comes from hipMalloc as it is.  Entries of the kernel's layout that no frame owns (frames beyond the padded
+    spectrogram, as the Nyquist lanes of lws::tw_q8 see them for the frame offsets a plan with Q < 8 does not have) must never reach a
+    result, not even multiplied by a zero weight: fill the device's free memory with NaNs, give it back, and run."""
+    import torch
+    for fill in (float("nan"), float("inf"), 1e30):
+        x = torch.full((1 << 28,), fill, dtype=torch.float32, device="cuda")      # 1 GiB
+        torch.cuda.synchronize()
+        del x
+        torch.cuda.empty_cache()
+        tw_case(oracle, fsize, fshift, T, THR, seed=fsize + T, expect="tw")

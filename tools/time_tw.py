@@ -16,5 +16,6 @@ def t(fsize, fshift, B, T, iters, **kw):
 t(1024, 256, 256, 500, 100); t(768, 256, 256, 500, 100); t(1000, 400, 256, 500, 100); t(1024, 384, 256, 500, 100)
 t(400, 160, 512, 500, 100); t(512, 160, 512, 500, 100); t(384, 128, 512, 500, 100); t(512, 128, 512, 500, 100)
 t(2048, 768, 64, 2000, 30); t(2048, 512, 64, 2000, 30)
+t(1024, 128, 256, 500, 40); t(1000, 200, 256, 500, 40); t(768, 128, 256, 500, 40); t(896, 128, 256, 500, 40); t(1024, 160, 256, 500, 40)
 os.environ["LWS_SYSTOLIC_NO_TW"] = "1"
-t(768, 256, 64, 500, 20); t(400, 160, 128, 500, 20); t(2048, 768, 16, 500, 10)
+t(768, 256, 64, 500, 20); t(400, 160, 128, 500, 20); t(2048, 768, 16, 500, 10); t(1000, 200, 64, 500, 10); t(1024, 160, 64, 500, 10)
