@@ -215,8 +215,8 @@ class Plan:
                 "lws_amd: this plan (F=%d bins, Q=%d, L=%d%s) runs on the order-exact generic engine (%s), 20-40x slower than "
                 "the systolic / LDS kernels; those serve fp32 plans with create_weights() tensors (summarised, or general with rows that "
                 "repeat) of up to 8 frames per stencil row: batch sweeps for F-1 from 16 (24 unless a multiple of 8) to 2048 (hop = frame/3 or not "
-                "dividing it: to 1024; 5..8 frames per row: to 512) and L <= 5 (Q in {2,4}, F <= 513: L <= 7); online sweeps for up to 4 "
-                "frames per row or Q = 8, L <= 5; no-future sweeps whenever the frame ring fits the LDS"
+                "dividing it: to 1024; 5..8 frames per row: to 512) and L <= 5 (Q in {2,4}, F <= 513: L <= 7); online sweeps for "
+                "L <= 5; no-future sweeps whenever the frame ring fits the LDS"
                 % (self.F, self.Q, self.L, "" if self.Qp == self.Q else ", general weights", name), RuntimeWarning, stacklevel=3)
 
     def close(self):

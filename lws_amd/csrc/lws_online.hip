@@ -81,7 +81,7 @@ struct OnlineArgs {
                          // its weight tensors Lu + 1 columns; the taps it does not have carry weight zero in the kernel's table
     // k_online4<..., TWT>: twiddles exp(2 pi j bin r s / PT) that are not the eighth turns of Q in {2,4,8} -- Q = 3, and the general
     // weights of a hop that does not divide the frame (Asym_UpdatePhasefractionalQ, lwslib.cpp:1276-1421) -- from a table
-    const float2 *twt;   // device: [PT + 3][4]: row p = tau_0 .. tau_3 of bin p (periodic: rows PT .. PT + 2 repeat rows 0 .. 2)
+    const float2 *twt;   // device: [PT + 3][TQ], TQ = 4 (Q <= 4) or 8: row p = tau_0 .. tau_{TQ-1} of bin p (periodic: rows PT .. PT + 2 repeat rows 0 .. 2)
     int PT;              // period of the twiddles in bins
 };
 
@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
 template <int Q> struct Online4Waves {
 #ifndef LWS_ONLINE4_IDLE_WAVE   // (tried: an idle wave on the projection wave's SIMD and the centre wave elsewhere: 57.8 vs 50.9 ms)
     static constexpr int N = 2 * Q;
-    static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : (Q == 3 ? 5 : 7), IDLE = -1;
+    static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : (Q == 3 ? 5 : 7), IDLE = -1;   // (hardware waves; N >= 8 from Q = 4 on)
 #else
     static constexpr int N = (Q == 4) ? 9 : 2 * Q;
     static constexpr int PROJ = 3, CENTRE = (Q == 2) ? 2 : (Q == 4 ? 8 : 7), IDLE = (Q == 4) ? 7 : -1;
@@ -878,7 +878,8 @@ __device__ __forceinline__ float pow2_to_unit(float amax) {
 template <int Q, int L, bool SERIAL, bool BIG = false, bool TWT = false>
 __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs a) {
     static_assert(!(BIG && SERIAL), "the verification variant keeps everything in LDS");
-    static_assert(!(TWT && (SERIAL || BIG)) && (TWT || Q == 2 || Q == 4 || Q == 8) && Q <= 4 + 4 * !TWT, "table twiddles: production variant, Q <= 4");
+    static_assert(!(TWT && (SERIAL || BIG)) && (TWT || Q == 2 || Q == 4 || Q == 8) && Q >= 2 && Q <= 8, "table twiddles: production variant");
+    constexpr int TQ = Q <= 4 ? 4 : 8;                  // twiddles per row of the table (frame offsets 0 .. TQ - 1)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int K1 = L + 1, WN = 2 * L + 2, NTW = 2 * Q - 1;
     constexpr int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2;
@@ -904,7 +905,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     float2 *TW = reinterpret_cast<float2 *>(smem + oTW);                        // [Q]
     float *thr_s = reinterpret_cast<float *>(smem + oThr);                      // [n_thr]
     int4 *TAB = reinterpret_cast<int4 *>(smem + oTAB);                          // [NU] step table of the projection wave, by bin pair
-    const float2 *TT = reinterpret_cast<const float2 *>(smem + oTT);            // TWT: [PT + 3][4] twiddles by bin mod PT and frame offset
+    const float2 *TT = reinterpret_cast<const float2 *>(smem + oTT);            // TWT: [PT + 3][TQ] twiddles by bin mod PT and frame offset
     const int PT = TWT ? a.PT : 1;
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -943,7 +944,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         W[i] = (x % (Q * K1) == 0) ? make_float2(0.f, 0.f) : make_float2(w.x * wscale, w.y * wscale);
     }
     if (tid < Q) TW[tid] = a.tw[tid];
-    if constexpr (TWT) for (int i = tid; i < (PT + 3) * 4; i += nthr) reinterpret_cast<float2 *>(smem + oTT)[i] = a.twt[i];
+    if constexpr (TWT) for (int i = tid; i < (PT + 3) * TQ; i += nthr) reinterpret_cast<float2 *>(smem + oTT)[i] = a.twt[i];
     for (int i = tid; i < NWR * NPS + 8; i += nthr) S[i] = make_float2(0.f, 0.f);
     if constexpr (!BIG) for (int i = tid; i < NWR * NPS; i += nthr) A[i] = 0.f;
     for (int i = tid; i < 2 * NTW * 64; i += nthr) P[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1103,7 +1104,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         int cp = TWT ? cp_of(ue) : 0;
         const int step4 = 4 % PT;
         auto tw_tab = [&](int row, v2f &twa, v2f &twb) __attribute__((always_inline)) {
-            const float2 ta = TT[(cp + row) * 4 + r], tb = TT[(cp + row + 1) * 4 + r];
+            const float2 ta = TT[(cp + row) * TQ + r], tb = TT[(cp + row + 1) * TQ + r];
             twa = as_v2f(ta) * gvec; twb = as_v2f(tb) * gvec;
         };
         auto cells = [&](int u_even) __attribute__((always_inline)) {
@@ -1376,7 +1377,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 ia_b = li_b + (unsigned)tab.y;
                 ib_b = li_b + 8u + (unsigned)tab.z;
                 xlate = as_v2f(*reinterpret_cast<const float2 *>(lds(xl0 + 16u * uc)));
-                if constexpr (TWT) twl_t = as_v2f(TT[cpp * 4 + 1]);      // (row (2 un + 1) mod PT, kept incrementally: no division on the chain)
+                if constexpr (TWT) twl_t = as_v2f(TT[cpp * TQ + 1]);      // (row (2 un + 1) mod PT, kept incrementally: no division on the chain)
             };
             auto step = [&](auto ph_c, int t) __attribute__((always_inline)) {   // PH: parity of t (and of u)
                 constexpr int PH = decltype(ph_c)::value;
@@ -1551,14 +1552,14 @@ Shape shape3_of(int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
 // k_online4: 2Q waves, one lane per (sweep slot, frame position), even lag, ring of NWR frames with an even row stride
 struct Shape4 { Shape sh; int NWR, NPS; bool big; };
 // big: the kernel's BIG variant (target magnitudes and step table not in LDS)
-// PT > 0: the table-twiddle variant (Q in {3, 4}, twiddle period PT bins: (PT + 3) x 32 bytes of LDS more)
+// PT > 0: the table-twiddle variant (Q in 3..8, twiddle period PT bins: (PT + 3) x 32 (Q > 4: 64) bytes of LDS more)
 Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool big, int PT = 0) {
     Shape4 r{{0, 0, 0, 0, false}, 0, 0, big};
     Shape &sh = r.sh;
     // any stencil half-width up to the kernel's: narrower ones run as L = 5 with zero weights for the taps they do not have
     // (OnlineArgs::Lu) -- the same sums, on a schedule that is order-exact for the wider stencil
     if (Qp != Q || Lu < 1 || Lu > 5 || LA < 0 || LA > 63 || n_thr < 1 || T < 1) return r;
-    if (PT > 0 ? (big || !(Q == 3 || Q == 4) || PT > 512) : !(Q == 2 || Q == 4 || Q == 8)) return r;
+    if (PT > 0 ? (big || Q < 3 || Q > 8 || PT > 512) : !(Q == 2 || Q == 4 || Q == 8)) return r;
     const int L = 5;
     const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS_MIN = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
     const int NU = (F + 1) / 2;
@@ -1576,7 +1577,7 @@ Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool b
     r.NPS = Np + (Np & 1);
     auto lds_of = [&](int nwr) {
         return (size_t)2 * (2 * Q - 1) * 64 * 16 + (224 + 64) * 8 + ((size_t)nwr * r.NPS + 8) * 8 + (big ? 0 : (size_t)nwr * r.NPS * 4) +
-               (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4 + 16 + (big ? 0 : (size_t)NU * 16) + (PT > 0 ? (size_t)(PT + 3) * 32 : 0);
+               (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4 + 16 + (big ? 0 : (size_t)NU * 16) + (PT > 0 ? (size_t)(PT + 3) * (Q <= 4 ? 32 : 64) : 0);
     };
     int nwr_max = 16;
     while (nwr_max > 0 && lds_of(nwr_max) > 160 * 1024) --nwr_max;
@@ -1706,13 +1707,15 @@ bool weights_twiddle(const double *W, int Q, int Qp, int L, int pmax, int *P_out
     }
     return false;
 }
-// the table of k_online4<..., TWT>: [P + 3][4] float2, row p: exp(2 pi j p r s / P), r = 0..3 (host side; the plan uploads it)
-void online_twiddle_table(int P, int s, float *out) {
+// the table of k_online4<..., TWT>: [P + 3][TQ] float2, TQ = 4 for Q <= 4 else 8, row p: exp(2 pi j p r s / P), r = 0..TQ-1 (host side;
+// the plan uploads it)
+void online_twiddle_table(int P, int s, int Q, float *out) {
+    const int TQ = Q <= 4 ? 4 : 8;
     for (int p = 0; p < P + 3; ++p)
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < TQ; ++r) {
             const double ang = 2.0 * M_PI * (double)(((long long)p * r * s) % P) / P;
-            out[(p * 4 + r) * 2] = (float)std::cos(ang);
-            out[(p * 4 + r) * 2 + 1] = (float)std::sin(ang);
+            out[(p * TQ + r) * 2] = (float)std::cos(ang);
+            out[(p * TQ + r) * 2 + 1] = (float)std::sin(ang);
         }
 }
 
@@ -1727,7 +1730,14 @@ hipError_t launch_online_lds(const GenericArgs<float> &g, int B, int tw_P, int t
         for (int q = 0; q < 8; ++q) a.tw[q] = make_float2(1.f, 0.f);   // (unused)
         a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = t4.sh.NSW; a.DS = t4.sh.DS;
         a.NWR = t4.NWR; a.NPS = t4.NPS; a.Lu = g.L;
-        return g.Q == 3 ? launch_4<3, 5, false, false, true>(a, B, t4.sh.lds, stream) : launch_4<4, 5, false, false, true>(a, B, t4.sh.lds, stream);
+        switch (g.Q) {
+        case 3: return launch_4<3, 5, false, false, true>(a, B, t4.sh.lds, stream);
+        case 4: return launch_4<4, 5, false, false, true>(a, B, t4.sh.lds, stream);
+        case 5: return launch_4<5, 5, false, false, true>(a, B, t4.sh.lds, stream);
+        case 6: return launch_4<6, 5, false, false, true>(a, B, t4.sh.lds, stream);
+        case 7: return launch_4<7, 5, false, false, true>(a, B, t4.sh.lds, stream);
+        default: return launch_4<8, 5, false, false, true>(a, B, t4.sh.lds, stream);
+        }
     }
     const Shape sh2 = shape_of(g.F, g.T, g.L, g.Q, g.Q, g.LA, g.n_thr), sh3 = shape3_of(g.F, g.T, g.L, g.Q, g.Q, g.LA, g.n_thr);
     const Shape4 sh4 = shape4_of(g.F, g.T, g.L, g.Q, g.Q, g.LA, g.n_thr);

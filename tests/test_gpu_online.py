@@ -169,12 +169,12 @@ def test_frames_of_4096_points(fsize, fshift, T, iters, LA, oracle, monkeypatch)
 
 
 def test_fallbacks_to_generic():
-    """Q >= 5, and fp64 plans, stay on the generic engine.  (Q = 3 and fractional Q: the table-twiddle variant of the fourth layout,
-    tests/test_gpu_tw.py.)"""
+    """More than 8 frames per stencil row, and fp64 plans, stay on the generic engine.  (Q = 3, 5, 6, 7 and fractional Q: the
+    table-twiddle variant of the fourth layout, tests/test_gpu_tw.py.)"""
     rng = np.random.default_rng(0)
-    p = lws_amd.lws(80, 16, mode="music")            # Q = 5
-    S = rng.standard_normal((9, 41)) + 1j * rng.standard_normal((9, 41))
-    out, name = _online(41, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 5.0)
+    p = lws_amd.lws(144, 16, mode="music")           # Q = 9
+    S = rng.standard_normal((9, 73)) + 1j * rng.standard_normal((9, 73))
+    out, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0)
     assert name == "generic_fp32"
     p = lws_amd.lws(64, 16, mode="music")
     S = rng.standard_normal((9, 33)) + 1j * rng.standard_normal((9, 33))

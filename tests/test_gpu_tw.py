@@ -243,7 +243,10 @@ def _online(F, W, S, thr, LA, qdiv, **kw):
 
 @pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(48, 16, 24, 3, 3), (48, 16, 7, 0, 2), (96, 32, 16, 1, 3), (768, 256, 12, 3, 3), (400, 160, 14, 3, 3),
                                                     (400, 160, 30, 5, 2), (512, 160, 12, 3, 3), (1024, 384, 10, 3, 2), (1000, 400, 12, 2, 3),
-                                                    (80, 32, 20, 3, 3), (60, 20, 9, 3, 2)])
+                                                    (80, 32, 20, 3, 3), (60, 20, 9, 3, 2),
+                                                    # five to eight frames per stencil row: ten to sixteen waves
+                                                    (80, 16, 16, 3, 3), (1000, 200, 10, 3, 2), (768, 128, 12, 2, 3), (896, 128, 9, 3, 2), (1024, 160, 10, 3, 2),
+                                                    (1024, 176, 12, 1, 3), (96, 16, 20, 0, 2)])
 def test_online_sweeps_on_the_lds_engine(fsize, fshift, T, LA, iters, oracle):
     """TF_RTISI_LA with Q = 3 and with the general weights of a fractional Q (Asym_UpdatePhaseanyQ / Asym_UpdatePhasefractionalQ,
     lwslib.cpp:1129-1421): the fourth layout of the online LDS engine with its twiddles from a table (k_online4<..., TWT>).  Short

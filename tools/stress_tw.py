@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
 cfgs = [(48, 16), (96, 32), (384, 128), (768, 256), (1008, 336), (60, 20), (1020, 340), (996, 332), (984, 328), (1536, 512), (1980, 660),
         (400, 160), (512, 160), (1000, 400), (1024, 384), (600, 250), (80, 32), (1024, 320), (644, 230), (1012, 368), (2048, 768),
         (2000, 800), (2044, 700), (1200, 480), (2048, 640), (160, 64), (320, 128), (800, 320), (240, 96), (1600, 640),
-        # five to eight frames per stencil row: the 64-step ring with table twiddles (batch; their online stage is the generic engine's)
+        # five to eight frames per stencil row: the 64-step ring with table twiddles 
         (80, 16), (1000, 200), (960, 192), (96, 16), (768, 128), (1020, 170), (112, 16), (896, 128), (1008, 144), (1024, 160), (1024, 176),
         (1000, 150), (1024, 192), (100, 20), (1012, 184)]
 bad = 0
@@ -22,8 +22,6 @@ for it in range(cases):
     F = fs // 2 + 1
     L = int(rng.choice([5, 5, 5, 1, 2, 3, 4]))
     kind = str(rng.choice(["batch", "batch", "nofuture", "online"]))
-    if -(-fs // sh) >= 5 and kind == "online":
-        kind = "batch"
     B = int(rng.integers(1, 4))
     p = lws_amd.lws(fs, sh, L=L, mode="music")
     W = (p.W, p.W_ai, p.W_af)
