@@ -835,6 +835,20 @@ template <int CONJ> __device__ __forceinline__ void cmul_w(float2 &a, wp_t w, fl
             : [a] "+v"(acc) : [w] LWS_WREG(w), [v] "v"(x));
     a = ff(acc);
 }
+// w v (CONJ = 0) or conj(w) v (CONJ = 1) without an accumulator to zero first: one multiply, one multiply-add
+template <int CONJ> __device__ __forceinline__ float2 cmul_w_init(wp_t w, float2 v) {
+    v2f r;
+    const v2f x = vv(v);
+    if constexpr (CONJ == 0)
+        asm("v_pk_mul_f32 %[r], %[w], %[v] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %[r], %[w], %[v], %[r] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+            : [r] "=&v"(r) : [w] LWS_WREG(w), [v] "v"(x));
+    else
+        asm("v_pk_mul_f32 %[r], %[w], %[v] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %[r], %[w], %[v], %[r] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
+            : [r] "=&v"(r) : [w] LWS_WREG(w), [v] "v"(x));
+    return ff(r);
+}
 __device__ __forceinline__ float2 cmulf(float2 p, float2 q) { return make_float2(p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x); }
 __device__ __forceinline__ float2 wp_value(wp_t w) { return make_float2(__uint_as_float((unsigned)(w & 0xffffffffull)), __uint_as_float((unsigned)(w >> 32))); }
 __device__ __forceinline__ float2 cadd(float2 p, float2 q) { return ff(vv(p) + vv(q)); }
@@ -1020,15 +1034,22 @@ __device__ __forceinline__ void tw_rows(const SysArgs &a, int twbase, const floa
                                         float2 &accr, QuadCarry<L> &qc) {
     constexpr int K1 = L + 1, c = L + 1 + OFFS;
     static_assert(c + L < N && PH >= 0 && PH < 8, "tap window too short");
-    float2 U = make_float2(0.f, 0.f), D = make_float2(0.f, 0.f);
-    static_for<L + 1>([&](auto ik) {
-        constexpr int k = decltype(ik)::value;
+    // (the tap k = 0 starts the two sums: nothing to zero)
+    constexpr bool k0 = ((MASK >> (R * K1)) & 1ull) != 0;
+    float2 U, D;
+    if constexpr (k0) {
+        const wp_t w0 = a.w[widx<Q, L>(0, R, 0)];
+        U = cmul_w_init<0>(w0, tu[c]);
+        D = cmul_w_init<1>(w0, td[c]);
+    } else {
+        U = make_float2(0.f, 0.f);
+        D = make_float2(0.f, 0.f);
+    }
+    static_for<L>([&](auto ik) {
+        constexpr int k = decltype(ik)::value + 1;
         if constexpr (((MASK >> (R * K1 + k)) & 1ull) != 0) {
             const wp_t w = a.w[widx<Q, L>(0, R, k)];
-            if constexpr (k == 0) {
-                cmul_w<0>(U, w, tu[c]);
-                cmul_w<1>(D, w, td[c]);
-            } else if constexpr (quad_deferred<OFFS, k, L>() && (quad_late_frame<-R, L>() || quad_late_frame<R, L>())) {
+            if constexpr (quad_deferred<OFFS, k, L>() && (quad_late_frame<-R, L>() || quad_late_frame<R, L>())) {
                 qc.g[R][0] = tu[c - k];
                 if constexpr (!quad_late_frame<-R, L>()) qc.g[R][1] = tu[c + k];
                 qc.g[R][2] = td[c - k];
