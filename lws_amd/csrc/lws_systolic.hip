@@ -1025,12 +1025,25 @@ __device__ __forceinline__ void quad_finish(const SysArgs &a, const QuadCarry<L>
     }
 }
 
+// the twiddles of the four bins of a quad for frame pair R, fetched together with the tap windows (not when the sums are done)
+// (64-step-ring build, whose waves have registers to spare and a SIMD nearly to themselves: -5 %; the other builds read each twiddle where
+// it is used: +1 % otherwise)
+template <int PH0, int R> __device__ __forceinline__ void tw_fetch(int twbase, float2 (&tau)[4]) {
+    if constexpr (LWS_Q8) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) tau[o] = lds_read(twbase + (PH0 + o) * TW_ROW + (R - 1) * 8);
+    } else {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) tau[o] = make_float2(__int_as_float(twbase + (PH0 + o) * TW_ROW + (R - 1) * 8), 0.f);   // the address, for tw_value
+    }
+}
+__device__ __forceinline__ float2 tw_value(float2 tau) { return LWS_Q8 ? tau : lds_read(__float_as_int(tau.x)); }
 // LWS_TW: contribution of frames m-R and m+R to the bin at phase PH (bin OFFS of the quad), twiddle from the table:
 //   tau U + conj(tau) D,   U = sum_k W0[R][k] S[m-R,c-k] + conj(W0[R][k]) S[m-R,c+k],   D = sum_k W0[R][k] S[m+R,c+k] + conj(W0[R][k]) S[m+R,c-k]
 // (lwslib.cpp:321-352 with W[mod] = W0 tau, W[modneg] = W0 conj(tau)).  The one group whose last operand is not in the ring yet
 // (fourth bin, k = L, frames m-1 / m+LATE_DN) is left to the second pair as in the other builds (QuadCarry::g, tw_finish).
 template <int Q, int L, uint64_t MASK, int PH, int R, int OFFS, int N>
-__device__ __forceinline__ void tw_rows(const SysArgs &a, int twbase, const float2 (&tu)[N], const float2 (&td)[N],
+__device__ __forceinline__ void tw_rows(const SysArgs &a, float2 tau, const float2 (&tu)[N], const float2 (&td)[N],
                                         float2 &accr, QuadCarry<L> &qc) {
     constexpr int K1 = L + 1, c = L + 1 + OFFS;
     static_assert(c + L < N && PH >= 0 && PH < 8, "tap window too short");
@@ -1060,7 +1073,7 @@ __device__ __forceinline__ void tw_rows(const SysArgs &a, int twbase, const floa
             }
         }
     });
-    pair_v(accr, lds_read(twbase + PH * TW_ROW + (R - 1) * 8), U, D);
+    pair_v(accr, tw_value(tau), U, D);
 }
 // ... and the deferred group, by the second pair: `late` is the tap that was not there yet (frame m-R's or m+R's, at +L)
 template <int Q, int L, uint64_t MASK, int PH, int R>
@@ -1191,10 +1204,12 @@ __device__ __forceinline__ void compute_pair(const SysArgs &a, const LaneCtx &cx
                 float2 tu[2 * L + 6], td[2 * L + 6];
                 load_cells<PA0, -R, L, 0, (quad_late_frame<-R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, tu);
                 load_cells<PA0, R, L, 0, (quad_late_frame<R, L>() ? L + 2 : L + 3), kmask, 0, RE>(cx, td);
-                tw_rows<Q, L, MASK, PA, R, 0>(a, cx.tw, tu, td, accA, qc);
-                tw_rows<Q, L, MASK, PA + 1, R, 1>(a, cx.tw, tu, td, accB, qc);
-                tw_rows<Q, L, MASK, PA + 2, R, 2>(a, cx.tw, tu, td, qc.accA, qc);
-                tw_rows<Q, L, MASK, PA + 3, R, 3>(a, cx.tw, tu, td, qc.accB, qc);
+                float2 tau[4];
+                tw_fetch<PA, R>(cx.tw, tau);
+                tw_rows<Q, L, MASK, PA, R, 0>(a, tau[0], tu, td, accA, qc);
+                tw_rows<Q, L, MASK, PA + 1, R, 1>(a, tau[1], tu, td, accB, qc);
+                tw_rows<Q, L, MASK, PA + 2, R, 2>(a, tau[2], tu, td, qc.accA, qc);
+                tw_rows<Q, L, MASK, PA + 3, R, 3>(a, tau[3], tu, td, qc.accB, qc);
             }
             if constexpr (R == 1) LWS_SETPRIO(0);
             if constexpr (R == Q - 1) LWS_SETPRIO(2);
@@ -1306,11 +1321,12 @@ __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx,
                 load_cells<PH0, -R, L, 0, L + 3, kmask, CO, RE>(cx, tu);
                 load_cells<PH0, R, L, 0, L + 3, kmask, CO, RE>(cx, td);
                 if constexpr (TW) {          // (the bins belong to this block or -- CO = 8 -- to the lane's next one)
-                    const int twb = CO ? cx.tw_nxt : cx.tw;
-                    tw_rows<Q, L, MASK, PH, R, 0>(a, twb, tu, td, accA, qc);
-                    tw_rows<Q, L, MASK, PH + 1, R, 1>(a, twb, tu, td, accB, qc);
-                    tw_rows<Q, L, MASK, PH + 2, R, 2>(a, twb, tu, td, qc.accA, qc);
-                    tw_rows<Q, L, MASK, PH + 3, R, 3>(a, twb, tu, td, qc.accB, qc);
+                    float2 tau[4];
+                    tw_fetch<PH, R>(CO ? cx.tw_nxt : cx.tw, tau);
+                    tw_rows<Q, L, MASK, PH, R, 0>(a, tau[0], tu, td, accA, qc);
+                    tw_rows<Q, L, MASK, PH + 1, R, 1>(a, tau[1], tu, td, accB, qc);
+                    tw_rows<Q, L, MASK, PH + 2, R, 2>(a, tau[2], tu, td, qc.accA, qc);
+                    tw_rows<Q, L, MASK, PH + 3, R, 3>(a, tau[3], tu, td, qc.accB, qc);
                 } else {
                 rows_sum<Q, L, MASK, PH, R, 0>(a, tu, td, p3, accA);
                 rows_sum<Q, L, MASK, PH + 1, R, 1>(a, tu, td, p3, accB);
