@@ -19,7 +19,7 @@ the launch stream, algorithmic bytes, fraction of 8 TB/s) and the property check
     2-q2 / 2-q8   config 2's volume at hop 512 (Q = 2, the reference's LWSQ2) and hop 128 (Q = 8, LWSanyQ)
     2-f501   config 2's volume with a 1000-point window (F = 501: F-1 not a multiple of 8)
     2-f257   config 2's volume at config 1's frame size, lws(512,128): 512 spectrograms of 500 x 257
-    2-q3 / 2-frac / 2-speech   hop = frame/3, lws(1024,384) and lws(400,160): the table-twiddle builds (LWSanyQ Q = 3, LWSfractionalQ)
+    2-q3 / 2-frac / 2-speech / 2-q5   hop = frame/3, lws(1024,384), lws(400,160), hop = frame/5: the table-twiddle builds (LWSanyQ, LWSfractionalQ)
     host_api config 2 through the host-array entry point plan.batch(numpy complex128): what a caller of the drop-in pays
     1        BASELINE config 1: one 5 s clip (628 x 257) through lws.lws(512,128).run_lws, wall time incl. plan creation,
              beside the reference CPU path on the same clip
@@ -77,6 +77,9 @@ BATCH_CONFIGS = {
     "2-speech": dict(B=512, T=500, fsize=400, fshift=160, iters=100, storage="fp32",
                     what="25 ms frames every 10 ms at 16 kHz (Qfloat = 2.5: LWSfractionalQ): %(B)d x %(T)d x %(F)d, lws(400,160) L=5 "
                          "(table twiddles under the two-slots-per-wave build)"),
+    "2-q5":    dict(B=256, T=500, fsize=1000, fshift=200, iters=40, storage="fp32",
+                    what="hop = a fifth of the frame (Q = 5, LWSanyQ): %(B)d x %(T)d x %(F)d, lws(1000,200) L=5 "
+                         "(the Q = 8 build's geometry with table twiddles: lws::tw_q8)"),
     "4shard":  dict(B=1024, T=500, fsize=1024, fshift=256, iters=100, storage="fp32",
                     what="BASELINE config 4, one GPU's shard: %(B)d spectrograms x %(T)d x %(F)d, lws(1024,256)"),
     "5":       dict(B=64, T=56250, fsize=2048, fshift=512, iters=200, storage="fp32",
@@ -500,7 +503,7 @@ def main():
     elif args.extras is not None:
         wanted = [x for x in args.extras.split(",") if x]
     elif world == 1 and args.config == "2":
-        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-f501", "2-f257", "4shard", "3", "3-b1024", "host_api", "1", "5", "5-f16"]
+        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-q5", "2-f501", "2-f257", "4shard", "3", "3-b1024", "host_api", "1", "5", "5-f16"]
     else:
         wanted = ["4shard"] if args.config == "2" else []
     if args.no_default_schedule and "2-default" in wanted:

@@ -38,7 +38,7 @@ for sub, suffix, what in (("trace", "", "python bench.py --steps 3 --warmup 1 --
         for n, c, s_, a, mn, mx in rows:
             w.writerow([n[:200], c, round(s_ / 1e3, 3), round(a / 1e3, 3), round(mn / 1e3, 3), round(mx / 1e3, 3), round(100 * s_ / tot, 3)])
 
-SHAPES = {"2": (256, 500, 513, 100, 20.0), "2-T1024": (256, 1024, 513, 100, 20.0), "2-q2": (256, 500, 513, 100, 20.0), "2-q8": (256, 500, 513, 100, 20.0), "2-f501": (256, 500, 501, 100, 20.0), "2-f257": (512, 500, 257, 100, 20.0), "2-q3": (256, 500, 385, 100, 20.0), "2-frac": (256, 500, 513, 100, 20.0), "2-speech": (512, 500, 201, 100, 20.0), "4shard": (1024, 500, 513, 100, 20.0),
+SHAPES = {"2": (256, 500, 513, 100, 20.0), "2-T1024": (256, 1024, 513, 100, 20.0), "2-q2": (256, 500, 513, 100, 20.0), "2-q8": (256, 500, 513, 100, 20.0), "2-f501": (256, 500, 501, 100, 20.0), "2-f257": (512, 500, 257, 100, 20.0), "2-q3": (256, 500, 385, 100, 20.0), "2-frac": (256, 500, 513, 100, 20.0), "2-speech": (512, 500, 201, 100, 20.0), "2-q5": (256, 500, 501, 40, 20.0), "4shard": (1024, 500, 513, 100, 20.0),
           "5": (64, 56250, 1025, 200, 20.0), "5-f16": (64, 56250, 1025, 200, 10.0)}
 res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE -- python bench.py --config <cfg> "
                "--no-extras --steps 1 --warmup 1 --no-cpu-baseline (config 3: --extras 3); counters are KiB per dispatch. "
