@@ -996,7 +996,12 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
                                 b == &lws::half_q2::systolic_entry();
             if ((no_short && is_short) || (is_r16 && env_int("LWS_SYSTOLIC_NO_R16", 0))) continue;   // (comparison runs)
             if ((e = b->build(p->sys, F, L, Q, Qp, hw, h16)) != hipSuccess) break;
-            if (p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2]) { p->sysb = b; break; }
+            // the build must take the tensor batch sweeps normally run on -- W, the first one present -- : a build that only takes
+            // another of the plan's tensors (W_ai of a hop above half the frame has no neighbour-frame weights and fits any
+            // twiddle) would leave the batch stage on the generic engine
+            const int first = p->have[0] ? 0 : (p->have[1] ? 1 : 2);
+            if (p->sys.ok[first]) { p->sysb = b; break; }
+            if (p->sys.ok[0] || p->sys.ok[1] || p->sys.ok[2]) b->release(p->sys);
         }
         if (e != hipSuccess) rc = fail(LWS_ERR_HIP, "systolic table upload failed: %s", hipGetErrorString(e));
     }

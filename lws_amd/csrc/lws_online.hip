@@ -1559,7 +1559,7 @@ Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool b
     // any stencil half-width up to the kernel's: narrower ones run as L = 5 with zero weights for the taps they do not have
     // (OnlineArgs::Lu) -- the same sums, on a schedule that is order-exact for the wider stencil
     if (Qp != Q || Lu < 1 || Lu > 5 || LA < 0 || LA > 63 || n_thr < 1 || T < 1) return r;
-    if (PT > 0 ? (big || Q < 3 || Q > 8 || PT > 512) : !(Q == 2 || Q == 4 || Q == 8)) return r;
+    if (PT > 0 ? (big || Q < 2 || Q > 8 || PT > 512) : !(Q == 2 || Q == 4 || Q == 8)) return r;
     const int L = 5;
     const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS_MIN = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
     const int NU = (F + 1) / 2;
@@ -1731,6 +1731,7 @@ hipError_t launch_online_lds(const GenericArgs<float> &g, int B, int tw_P, int t
         a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = t4.sh.NSW; a.DS = t4.sh.DS;
         a.NWR = t4.NWR; a.NPS = t4.NPS; a.Lu = g.L;
         switch (g.Q) {
+        case 2: return launch_4<2, 5, false, false, true>(a, B, t4.sh.lds, stream);
         case 3: return launch_4<3, 5, false, false, true>(a, B, t4.sh.lds, stream);
         case 4: return launch_4<4, 5, false, false, true>(a, B, t4.sh.lds, stream);
         case 5: return launch_4<5, 5, false, false, true>(a, B, t4.sh.lds, stream);

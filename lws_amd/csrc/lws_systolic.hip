@@ -2547,7 +2547,7 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
 #if LWS_TW && LWS_Q8
     if (Q < 5 || Q > 8 || Lu > 5 || fp16_storage) return hipSuccess;   // (fp32 storage only: half the instantiations of the other builds)
 #elif LWS_TW
-    if (Q < 3 || Q > 4 || Lu > 5) return hipSuccess;     // (stencils narrower than L = 5 run with zero weights)
+    if (Q < 2 || Q > 4 || Lu > 5) return hipSuccess;     // (stencils narrower than L = 5 run with zero weights; Q = 2: a hop above half the frame)
 #elif LWS_Q8
     if (Q != 8 || L != 5) return hipSuccess;
 #elif LWS_R16
@@ -2815,6 +2815,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
     // hop = a third of the frame with the default sqrt-Hann window: of the centre frame's weights only k = 1 is non-zero (as for Q = 2, 4)
     constexpr uint64_t MASK_Q3_L5_DEFAULT = 0b111111'111111'000011u;
     if (Q == 4) e = launch_k<4, 5, mask_all(4, 5)>(a, grid, h, stream);
+    else if (Q == 2) e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     else if (tb->mask == MASK_Q3_L5_DEFAULT) { e = launch_k<3, 5, MASK_Q3_L5_DEFAULT>(a, grid, h, stream); kind = "hannmask_tw"; }
     else e = launch_k<3, 5, mask_all(3, 5)>(a, grid, h, stream);
 #elif LWS_Q8

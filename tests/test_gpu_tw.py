@@ -31,9 +31,11 @@ def tw_case(oracle, fsize, fshift, T, thr, seed, B=2, scale=(1.0, 40.0), L=5, us
     name = plan.last_kernel()["name"]
     assert name.startswith("systolic") and name.endswith("_" + expect), name
     r64 = -(-fsize // fshift) >= 5          # five or more frames per stencil row: the 64-step ring (frames of up to 513 bins)
+    period = fsize // np.gcd(fsize, fshift)  # of the twiddles, in bins: the table of the two-slots-per-wave build holds 22 rows + 8
+    half = F <= 257 and period <= 22
     if expect == "tw" and not r64:
-        assert ("_half_" in name) == (F <= 257) and ("_wide_" in name) == (F > 513), name
-    if expect == "tw" and F <= 257 and not r64:
+        assert ("_half_" in name) == half and ("_wide_" in name) == (F > 513), name
+    if expect == "tw" and half and not r64:
         # the build with two sweep slots per wave does the arithmetic of the one-slot build in the same order: identical bits
         os.environ["LWS_SYSTOLIC_NO_SHORT"] = "1"
         try:
@@ -69,7 +71,9 @@ def test_q3_summarised_weights(oracle, fsize, fshift, T):
 
 
 @pytest.mark.parametrize("fsize,fshift,T", [(400, 160, 70), (400, 160, 131), (512, 160, 66), (1000, 400, 37), (1024, 384, 40), (600, 250, 65),
-                                            (80, 32, 70), (1024, 320, 21), (644, 230, 50), (1012, 368, 33)])
+                                            (80, 32, 70), (1024, 320, 21), (644, 230, 50), (1012, 368, 33),
+                                            # a hop above half the frame: two frames per stencil row, general weights
+                                            (512, 300, 66), (1024, 640, 37), (400, 240, 70), (64, 40, 131), (2048, 1280, 40)])
 def test_fractional_q_general_weights(oracle, fsize, fshift, T):
     """A hop that does not divide the frame: create_weights returns one weight row per bin (Q' = N) and batch_lws dispatches to
     LWSfractionalQ (lws.pyx:246-247).  25 ms / 10 ms speech framing is lws(400, 160): Q = 3 frames, twiddle period 5 bins."""
@@ -244,6 +248,7 @@ def _online(F, W, S, thr, LA, qdiv, **kw):
 @pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(48, 16, 24, 3, 3), (48, 16, 7, 0, 2), (96, 32, 16, 1, 3), (768, 256, 12, 3, 3), (400, 160, 14, 3, 3),
                                                     (400, 160, 30, 5, 2), (512, 160, 12, 3, 3), (1024, 384, 10, 3, 2), (1000, 400, 12, 2, 3),
                                                     (80, 32, 20, 3, 3), (60, 20, 9, 3, 2),
+                                                    (512, 300, 12, 3, 3), (64, 40, 20, 2, 2),
                                                     # five to eight frames per stencil row: ten to sixteen waves
                                                     (80, 16, 16, 3, 3), (1000, 200, 10, 3, 2), (768, 128, 12, 2, 3), (896, 128, 9, 3, 2), (1024, 160, 10, 3, 2),
                                                     (1024, 176, 12, 1, 3), (96, 16, 20, 0, 2)])

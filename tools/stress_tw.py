@@ -15,7 +15,9 @@ cfgs = [(48, 16), (96, 32), (384, 128), (768, 256), (1008, 336), (60, 20), (1020
         (2000, 800), (2044, 700), (1200, 480), (2048, 640), (160, 64), (320, 128), (800, 320), (240, 96), (1600, 640),
         # five to eight frames per stencil row: the 64-step ring with table twiddles 
         (80, 16), (1000, 200), (960, 192), (96, 16), (768, 128), (1020, 170), (112, 16), (896, 128), (1008, 144), (1024, 160), (1024, 176),
-        (1000, 150), (1024, 192), (100, 20), (1012, 184)]
+        (1000, 150), (1024, 192), (100, 20), (1012, 184),
+        # a hop above half the frame (Q = 2, general weights)
+        (512, 300), (1024, 640), (400, 240), (64, 40), (2048, 1280)]
 bad = 0
 for it in range(cases):
     fs, sh = cfgs[rng.integers(len(cfgs))]
