@@ -1143,6 +1143,7 @@ int lws_residual_dev(lws_plan *p, const void *S_dev, int B, int T, double *out, 
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
+    if ((rc = order_after_plan_work(p, s))) return rc;      // (the plan's scratch: behind whatever an earlier *_dev call enqueued)
     if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
     if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
     if (p->fp64) {
@@ -1234,6 +1235,7 @@ int lws_residual(lws_plan *p, const double *S, int B, int T, double *out) {
     hipStream_t s = nullptr;
     const size_t count = (size_t)B * T * p->F;
     int rc;
+    if ((rc = order_after_plan_work(p, s))) return rc;
     if ((rc = p->stage.ensure(count * sizeof(double2)))) return rc;
     if ((rc = p->resid_rows.ensure((size_t)B * T * 2 * sizeof(double)))) return rc;
     if ((rc = p->resid_out.ensure((size_t)B * 2 * sizeof(double)))) return rc;
