@@ -118,6 +118,13 @@ int lws_run_lws_dev(lws_plan *plan, void *S_dev, int B, int T,
                     const double *thr_online, int it_online, int LA, double qdiv,
                     const double *thr_batch, int it_batch, void *stream);
 
+/* Host-only query (no device needed): does the weight tensor W[Qp][Q][L+1] (complex128 interleaved, as create_weights returns it,
+ * lws.pyx:160-181) have the structure the fast kernels rely on -- W[p][r][k] == W[0][r][k] exp(2 pi j p r step / period) for every row
+ * p?  Returns 1 and sets *period, *step (period 0: the tensor has no neighbour-frame weights and fits any twiddle), else 0.  For
+ * create_weights' tensors period / step = frame / hop in lowest terms; plans whose tensors have it run on the systolic / LDS engines
+ * when their shape is served, the others on the generic engine. */
+int lws_weights_structure(const double *W, int Q, int Qp, int L, int *period, int *step);
+
 /* Pre-size every scratch buffer of the plan for calls of up to B spectrograms of T frames and `max_iters` thresholds
  * per stage.  The *_dev entry points only enqueue work and return -- unless a scratch buffer has to grow, which is a
  * (synchronising) hipMalloc: reserve once and they never allocate.  The reference allocates per call (lws.pyx:227-240;

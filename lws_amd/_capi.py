@@ -32,7 +32,7 @@ EXPORTS = (
     "lws_last_kernel_name", "lws_generic_stage", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev",
     "lws_consistency_dev", "lws_hann", "lws_synthwin", "lws_weights_shape", "lws_create_weights",
     "lws_build_asymmetric_windows", "lws_get_thresholds", "lws_plan_create_from_windows", "lws_stream_copy",
-    "lws_run_lws_dev", "lws_plan_reserve", "lws_residual", "lws_residual_allreduce_dev", "lws_multi_plan_create", "lws_multi_plan_destroy",
+    "lws_run_lws_dev", "lws_plan_reserve", "lws_residual", "lws_residual_allreduce_dev", "lws_weights_structure", "lws_multi_plan_create", "lws_multi_plan_destroy",
     "lws_multi_plan_shards", "lws_multi_batch_lws", "lws_multi_run_lws", "lws_multi_residual",
 )
 
@@ -112,6 +112,7 @@ def load():
     lib.lws_plan_reserve.argtypes = [vp, ip, ip, ip]
     lib.lws_residual.argtypes = [vp, vp, ip, ip, vp]
     lib.lws_residual_allreduce_dev.argtypes = [vp, vp, ip, ip, vp, vp, vp]
+    lib.lws_weights_structure.argtypes = [vp, ip, ip, ip, vp, vp]
     lib.lws_multi_plan_create.argtypes = [C.POINTER(vp), ip, vp, ip, ip, ip, ip, vp, vp, vp, C.c_uint]
     lib.lws_multi_plan_destroy.argtypes = [vp]
     lib.lws_multi_plan_destroy.restype = None
@@ -428,6 +429,16 @@ def istft_dev(S_ptr, B, frames, fsize, fshift, swin, perfectrec, x_ptr, device=0
     w = _win(swin)
     check(load().lws_istft_dev(int(device), S_ptr, int(B), int(frames), int(fsize), int(fshift), w.ctypes.data,
                                int(bool(perfectrec)), x_ptr, stream))
+
+
+def weights_structure(W):
+    """(period, step) of the twiddle structure of a weight tensor W[Qp][Q][L+1] -- W[p][r][k] == W[0][r][k] exp(2j pi p r step / period)
+    for every row p; create_weights gives period / step = frame / hop in lowest terms -- or None if it has none (such plans run on the
+    generic engine).  Host-only: no device needed."""
+    W = np.ascontiguousarray(W, dtype=np.complex128)
+    per, stp = np.zeros(1, dtype=np.intc), np.zeros(1, dtype=np.intc)
+    ok = load().lws_weights_structure(W.ctypes.data, int(W.shape[1]), int(W.shape[0]), int(W.shape[2]) - 1, per.ctypes.data, stp.ctypes.data)
+    return (int(per[0]), int(stp[0])) if ok else None
 
 
 def consistency_dev(S_ptr, B, frames, fsize, fshift, awin, swin, perfectrec, device=0, stream=None):

@@ -172,6 +172,11 @@ def lws_residual_dev(plan, S_dev, int B, int T, out, stream):
     return rc
 
 
+def lws_weights_structure(W, int Q, int Qp, int L, period, step):
+    cdef uintptr_t w = _addr(W), pp = _addr(period), ss = _addr(step)
+    return c.lws_weights_structure(<const double *>w, Q, Qp, L, <int *>pp, <int *>ss)
+
+
 def lws_residual_allreduce_dev(plan, S_dev, int B, int T, comm, out, stream):
     cdef uintptr_t p = _addr(plan), s = _addr(S_dev), cm = _addr(comm), o = _addr(out), st = _addr(stream)
     cdef int rc

@@ -1206,6 +1206,14 @@ nccl_allreduce_fn rccl_allreduce() {
 }
 }  // namespace
 
+int lws_weights_structure(const double *W, int Q, int Qp, int L, int *period, int *step) {
+    int P = 0, sg = 0;
+    if (!W || !period || !step || Q < 2 || Qp < 1 || L < 0) return 0;
+    if (!lws::weights_twiddle(W, Q, Qp, L, 4096, &P, &sg)) return 0;
+    *period = P; *step = sg;
+    return 1;
+}
+
 int lws_residual_allreduce_dev(lws_plan *p, const void *S_dev, int B, int T, void *rccl_comm, double *out, void *stream) {
     if (!p || !S_dev || !out) return fail(LWS_ERR_INVALID, "null argument");
     if (B <= 0 || T < 1) return fail(LWS_ERR_INVALID, "need B >= 1 and T >= 1");

@@ -35,6 +35,7 @@ cdef extern from "lws_hip.h" nogil:
     int lws_plan_reserve(lws_plan *plan, int B, int T, int max_iters)
     int lws_residual_dev(lws_plan *plan, const void *S_dev, int B, int T, double *out, void *stream)
     int lws_residual(lws_plan *plan, const double *S, int B, int T, double *out)
+    int lws_weights_structure(const double *W, int Q, int Qp, int L, int *period, int *step)
     int lws_residual_allreduce_dev(lws_plan *plan, const void *S_dev, int B, int T, void *rccl_comm, double *out, void *stream)
     int lws_last_kernel_time(lws_plan *plan, float *ms, int *launches)
     const char *lws_last_kernel_name(lws_plan *plan)
