@@ -802,13 +802,19 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
 // its seven tap waves (profiles/r03_pmc_sq_online*.json: 863 vector instructions per step and workgroup, of which 7 x 32 are
 // the register moves of the sliding windows and ~7 x 26 index / predicate arithmetic).  Same roles -- one wave per tap group,
 // one projection wave, tap waves one step ahead -- with the per-step overhead removed:
-//   * EVEN lag between sweeps (DS even; SKS is even already), so that every lane of the workgroup is at an even bin pair
-//     u = t - tstart in even steps and at an odd one in odd steps.  The step loop is unrolled by two: the twiddle of a bin
-//     (bin mod Q) is static, and a neighbour-frame tap wave works on a TWO-step window of 2L + 4 columns whose register names
-//     are fixed: no window slides.  Rows of the LDS ring have an even stride, windows start at even columns: every window
-//     read is an aligned 16-byte cell.  At the end of a pair the next pair's first cells -- values the wave already holds --
-//     are simply read again under their new names (LDS has the bandwidth to spare, the vector ALU has not); that read is
-//     issued before the barrier.  A lane that starts a frame needs no special case (it starts at an even step).
+//   * The step loop is unrolled by two and a neighbour-frame tap wave works on a TWO-step window of 2L + 4 columns whose
+//     register names are fixed: no window slides.  Rows of the LDS ring have an even stride, windows start at even columns:
+//     every window read is an aligned 16-byte cell.  At the end of a pair the next pair's first cells -- values the wave
+//     already holds -- are simply read again under their new names (LDS has the bandwidth to spare, the vector ALU has not);
+//     that read is issued before the barrier.
+//   * With an EVEN lag between sweeps (DS even; SKS is even already) every lane of the workgroup is at an even bin pair
+//     u = t - tstart in even steps and at an odd one in odd steps: the twiddle of a bin (bin mod Q) is static and a lane that
+//     starts a frame needs no special case.  The smallest order-exact lag is odd, though (SKS Q + 1), and the lag is the
+//     length of the chain: Q = 2, Q = 4 and the table-twiddle variant take an ODD lag when that is the smallest.  Every other
+//     sweep then starts at an odd step; its lanes pick their twiddles two rows further on and re-read the few window cells
+//     that hold Hermitian images stored too late for the early read (tap_loop; tools/online_schedule_check.py is the model
+//     of who stores what when, tests/test_online_schedule.py runs it, the GPU tests compare the two lags bit for bit).
+//     LWS_ONLINE_EVEN_LAG=1 rounds the lag up to even again (comparison runs).
 //   * tap waves carry no validity predicate: a lane without work computes on clamped addresses and nobody reads its sums.
 //   * 2Q waves, two per SIMD for Q = 4: the centre-frame wave shares the projection wave's SIMD (no idle wave).
 //   * the ring holds NWR frames (run-time, not a power of two), as many as the look-ahead needs: 2048-point frames fit.
@@ -875,8 +881,10 @@ __device__ __forceinline__ float pow2_to_unit(float amax) {
 // the projection wave's chain: slower steps, 10x faster than the generic engine such frames used to get), and the step table's
 // entries are computed instead of fetched.  Production variant only.
 // TWT: the twiddle of a bin comes from a table in LDS (per lane: row = bin mod PT) instead of being static in the two-step loop
-template <int Q, int L, bool SERIAL, bool BIG = false, bool TWT = false>
+// ODD: the build for an odd lag between sweeps (the even-lag build carries none of its tests)
+template <int Q, int L, bool SERIAL, bool BIG = false, bool TWT = false, bool ODD = false>
 __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs a) {
+    static_assert(!ODD || (!SERIAL && (TWT || Q == 2 || Q == 4)), "odd lags: the production variants of Q = 2, 4 and the table-twiddle one");
     static_assert(!(BIG && SERIAL), "the verification variant keeps everything in LDS");
     static_assert(!(TWT && (SERIAL || BIG)) && (TWT || Q == 2 || Q == 4 || Q == 8) && Q >= 2 && Q <= 8, "table twiddles: production variant");
     constexpr int TQ = Q <= 4 ? 4 : 8;                  // twiddles per row of the table (frame offsets 0 .. TQ - 1)
@@ -885,7 +893,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     constexpr int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2;
     constexpr int NCELL = WN / 2 + 1;                   // 16-byte cells (two columns) of a two-step window
     static_assert(SKB >= L + 3 && (SKS & 1) == 0 && (WN & 3) == 0, "two-step windows of aligned cells");
-    const int DS = a.DS;                                // even
+    const int DS = a.DS;                                // (even, or odd: see above)
     const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, Tp = T + 2 * (Q - 1), N = F - 1;
     const int NWR = a.NWR, NPS = a.NPS;                 // (a row of the ring: F + 2 L columns, rounded up to even)
     const int NU = (F + 1) / 2;
@@ -1026,7 +1034,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
         }
         valid = valid && lane_used && s < nsweeps;
         tstart = DS * s + SKS * rho;
-        t_done = DS * s + SKS * m + NU - 1;     // even: DS and SKS are, NU is odd
+        t_done = DS * s + SKS * m + NU - 1;     // (even when DS is: SKS is, NU is odd)
         const int e = rho + Q - 1;
         e_own = e;
         fb = ((h ? e + r : e - r) % NWR) * NPS;
@@ -1049,9 +1057,11 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             }
             gvec = (v2f){gain, h ? -gain : gain};
             if constexpr (!TWT) {
+                // (ODD: a lane that starts at an odd step is at an odd bin pair in even steps: its bins are two rows further on)
+                const int shift = ODD ? 2 * (tstart & 1) : 0;
 #pragma unroll
                 for (int row = 0; row < Q; ++row) {
-                    const float2 tw = TW[(row * r) & (Q - 1)];
+                    const float2 tw = TW[((row + shift) * r) & (Q - 1)];
                     twg[row] = (v2f){gain * tw.x, gain * (h ? -tw.y : tw.y)};
                 }
             }
@@ -1138,6 +1148,17 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             static_for<NPRE>([&](auto ic) { ld(w, ic); });
         }
         for (int it = 0; it < n_it; it += 2) {
+            // (ODD: a sweep may end at either step of a pair -- the lane moves on at the top of the next pair.  Its new sweep
+            // starts three steps after the old one ended at the earliest: in this pair's odd step or later; the early cells,
+            // read a step later than usual here, are the new window's)
+            if constexpr (ODD) {
+                if (it > t_done) {
+                    s += NSW; setup(); ue = it - tstart;
+                    if constexpr (TWT) cp = cp_of(ue);
+                    const float4 *w = cells(ue);
+                    static_for<NPRE>([&](auto ic) { ld(w, ic); });
+                }
+            }
             // ---- even step tt = it (interval t = it - 1)
             {
                 const float4 *w = cells(ue);
@@ -1145,18 +1166,27 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 // frame rho-1 is SKB bins ahead, but the Hermitian images of its bins 4 and 5 (columns 1, 0: this lane's first
                 // window) are stored only SKB - 3 bins before this lane starts: final now, not yet when the early cells were read
                 if constexpr (KIND == 1) ld(w, std::integral_constant<int, 0>{});
+                // A lane that starts at an odd step has its first window one cell further on.  At the smallest odd lag
+                // (DS = SKS Q + 1) the frame Q-1 ahead, previous sweep, stores the images of its bins 4 and 5 (cell 1 of that
+                // window) in the step the early cells were read in: final now.  (tools/online_schedule_check.py derives
+                // which columns of which wave need this, for every Q and lag; tests/test_online_schedule.py runs it.)
+                // (only the pair in which such a lane starts: ue = -1)
+                if constexpr (ODD && KIND == 0) { if (ue == -1) ld(w, std::integral_constant<int, 1>{}); }
                 v2f twa, twb;
                 if constexpr (TWT) tw_tab(0, twa, twb);
                 else tw_of(std::integral_constant<int, 0>{}, ue, twa, twb);
                 if (!SERIAL) sums(std::integral_constant<int, 0>{}, twa, twb, pw0);
             }
-            if (it >= t_done) { s += NSW; setup(); ue = it - tstart; if constexpr (TWT) cp = cp_of(ue); }
+            if constexpr (!ODD) { if (it >= t_done) { s += NSW; setup(); ue = it - tstart; if constexpr (TWT) cp = cp_of(ue); } }
             load_frames(it - 1);
             __syncthreads();
             // ---- odd step tt = it + 1
             {
                 const float4 *w = cells(ue);
                 if constexpr (KIND == 1) ld(w, std::integral_constant<int, NCELL - 2>{});   // its last column is final now
+                // ... and for frame rho-1 (SKS steps ahead) an odd start means: the images of its bins 2 .. 5 (cells 2 and 1 of
+                // the window) were stored one and two steps after the early cells were read: final only now
+                if constexpr (ODD && KIND == 1) { if (ue == -1) { ld(w, std::integral_constant<int, 1>{}); ld(w, std::integral_constant<int, 2>{}); } }
                 ld(w, std::integral_constant<int, NCELL - 1>{});
                 v2f twa, twb;
                 if constexpr (TWT) tw_tab(2, twa, twb);
@@ -1231,8 +1261,9 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             if (!SERIAL) *pw = make_float4(pa.x, pa.y, pb.x, pb.y);
         };
         for (int it = 0; it < n_it; it += 2) {
+            if constexpr (ODD) { if (it > t_done) { s += NSW; setup(); u = it - tstart; } }
             half(std::integral_constant<int, 0>{}, pw0);
-            if (it >= t_done) { s += NSW; setup(); u = it - tstart; }
+            if constexpr (!ODD) { if (it >= t_done) { s += NSW; setup(); u = it - tstart; } }
             load_frames(it - 1);
             __syncthreads();
             ++u;
@@ -1388,6 +1419,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 __builtin_amdgcn_sched_barrier(0);   // (the reads first: the own terms below cover part of their latency)
                 // the unit's own history (columns c-1, c-2, their images, the image of bin c) and frame rho-1's late column
                 v2f twl = TWT ? twl_t : as_v2f(a.tw[(2 * PH + 1) & (Q - 1)]);
+                if constexpr (ODD && Q == 4 && !TWT) twl = ((u ^ PH) & 1) ? as_v2f(a.tw[(2 * PH + 3) & 3]) : twl;   // (odd start: u and t differ in parity)
                 if constexpr (Q == 8) twl = (u & 2) ? as_v2f(a.tw[(2 * PH + 5) & (Q - 1)]) : twl;
                 v2f ownA = mat_mul_pk(mA1, p1), ownB = mat_mul_pk(mB1, p1);
                 mat_mac_pk(ownA, mA2, p2);
@@ -1565,12 +1597,16 @@ Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool b
     const int NU = (F + 1) / 2;
     sh.NSW = 64 / (LA + 1);
     // order-exact lag with the tap waves a step ahead (2 DS >= SKB Q + 2); a slot is free again, with two steps to spare,
-    // when its sweep is over (NSW DS >= SKS LA + NU + 2); even
+    // when its sweep is over (NSW DS >= SKS LA + NU + 2).  Q = 8 with static twiddles wants it even; so does LWS_ONLINE_EVEN_LAG=1
     int DS = DS_MIN;
     if (2 * DS < SKB * Q + 2) DS = (SKB * Q + 3) / 2;
     const int need = (SKS * LA + NU + 2 + sh.NSW - 1) / sh.NSW;
     if (DS < need) DS = need;
-    DS += DS & 1;
+    {
+        const char *ev = getenv("LWS_ONLINE_EVEN_LAG"), *es = getenv("LWS_ONLINE_SERIAL_TAPS");   // (the verification variant has no odd build)
+        const bool odd_ok = (PT > 0 || Q == 4 || Q == 2) && !(ev && ev[0] == '1') && !(es && es[0] == '1');
+        if (!odd_ok) DS += DS & 1;
+    }
     sh.DS = DS;
     sh.threads = Online4Waves<4>::N == 9 && Q == 4 ? 9 * 64 : 2 * Q * 64;
     if (F - 1 < 2 * (L + 3)) return r;
@@ -1623,12 +1659,19 @@ int pick_layout(const Shape &s2, const Shape &s3, const Shape &s4) {
     return s2.ok ? 2 : 0;
 }
 
-template <int Q, int L, bool SERIAL, bool BIG = false, bool TWT = false> hipError_t launch_4(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online4<Q, L, SERIAL, BIG, TWT>),
+template <int Q, int L, bool SERIAL, bool BIG, bool TWT, bool ODD> hipError_t launch_4p(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online4<Q, L, SERIAL, BIG, TWT, ODD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // (per device: not cached)
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_online4<Q, L, SERIAL, BIG, TWT>), dim3(B), dim3(Online4Waves<Q>::N * 64), lds, s, a);
+    hipLaunchKernelGGL((k_online4<Q, L, SERIAL, BIG, TWT, ODD>), dim3(B), dim3(Online4Waves<Q>::N * 64), lds, s, a);
     return hipGetLastError();
+}
+template <int Q, int L, bool SERIAL, bool BIG = false, bool TWT = false> hipError_t launch_4(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
+    if constexpr (!SERIAL && (TWT || Q == 2 || Q == 4)) {
+        if (a.DS & 1) return launch_4p<Q, L, SERIAL, BIG, TWT, true>(a, B, lds, s);
+    }
+    if (a.DS & 1) return hipErrorInvalidValue;      // (shape4_try gives these builds an even lag)
+    return launch_4p<Q, L, SERIAL, BIG, TWT, false>(a, B, lds, s);
 }
 
 template <int Q, int L, bool SERIAL> hipError_t launch_3(const OnlineArgs &a, int B, size_t lds, hipStream_t s) {
