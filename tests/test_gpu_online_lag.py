@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [  # (fsize, fshift): Q = 4 and Q = 2 with static twiddles, then the table-twiddle variant (Q = 3, 5, 6, fractional Q)
     (512, 128), (1024, 256), (2048, 512), (64, 16), (256, 128), (1024, 512),
-    (768, 256), (1000, 200), (960, 160), (1024, 384), (400, 160),
+    (768, 256), (1000, 200), (960, 160), (1024, 384), (400, 160), (896, 128), (960, 128),
+    (4096, 1024),       # the BIG variant (magnitudes and step table not in LDS)
 ]
 
 
@@ -25,7 +26,7 @@ def _online(fsize, fshift, S, LA, nit):
 def test_odd_lag_equals_even_lag_bit_for_bit(fsize, fshift):
     rng = np.random.default_rng(fsize * 7 + fshift)
     F = fsize // 2 + 1
-    for case in range(6):
+    for case in range(3 if fsize > 2048 else 6):
         T = int(rng.integers(1, 48)); B = int(rng.integers(1, 4)); LA = int(rng.integers(0, 6)); nit = int(rng.integers(1, 10))
         S = rng.rayleigh(1.0, (B, T, F)).astype(np.complex128)
         os.environ.pop("LWS_ONLINE_EVEN_LAG", None)
