@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(Online3Waves<Q>::N * 64) k_online3(OnlineArgs 
 //     sweep then starts at an odd step; its lanes pick their twiddles two rows further on and re-read the few window cells
 //     that hold Hermitian images stored too late for the early read (tap_loop; tools/online_schedule_check.py is the model
 //     of who stores what when, tests/test_online_schedule.py runs it, the GPU tests compare the two lags bit for bit).
-//     LWS_ONLINE_EVEN_LAG=1 rounds the lag up to even again (comparison runs).
+//     LWS_ONLINE_LAG_PLUS=k adds k steps to the lag (comparison runs).
 //   * tap waves carry no validity predicate: a lane without work computes on clamped addresses and nobody reads its sums.
 //   * 2Q waves, two per SIMD for Q = 4: the centre-frame wave shares the projection wave's SIMD (no idle wave).
 //   * the ring holds NWR frames (run-time, not a power of two), as many as the look-ahead needs: 2048-point frames fit.
@@ -1420,7 +1420,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 // the unit's own history (columns c-1, c-2, their images, the image of bin c) and frame rho-1's late column
                 v2f twl = TWT ? twl_t : as_v2f(a.tw[(2 * PH + 1) & (Q - 1)]);
                 if constexpr (ODD && Q == 4 && !TWT) twl = ((u ^ PH) & 1) ? as_v2f(a.tw[(2 * PH + 3) & 3]) : twl;   // (odd start: u and t differ in parity)
-                if constexpr (Q == 8) twl = (u & 2) ? as_v2f(a.tw[(2 * PH + 5) & (Q - 1)]) : twl;
+                if constexpr (Q == 8 && !TWT) twl = (u & 2) ? as_v2f(a.tw[(2 * PH + 5) & (Q - 1)]) : twl;
                 v2f ownA = mat_mul_pk(mA1, p1), ownB = mat_mul_pk(mB1, p1);
                 mat_mac_pk(ownA, mA2, p2);
                 mat_mac_pk(ownB, mB2, p2);
@@ -1596,15 +1596,20 @@ Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool b
     const int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2, DS_MIN = ((SKB * (Q - 1) + L + 3) / 2), Np = F + 2 * L, per = n_thr + 1;
     const int NU = (F + 1) / 2;
     sh.NSW = 64 / (LA + 1);
-    // order-exact lag with the tap waves a step ahead (2 DS >= SKB Q + 2); a slot is free again, with two steps to spare,
-    // when its sweep is over (NSW DS >= SKS LA + NU + 2).  Q = 8 with static twiddles wants it even; so does LWS_ONLINE_EVEN_LAG=1
+    // order-exact lag with the tap waves a step ahead (2 DS >= SKB Q + 2: SKS Q + 1 steps.  One step less is order-exact too, but
+    // frame rho+Q-1 of the previous sweep is then SKS steps ahead of a lane, as frame rho-1 is: its tap wave must read two cells
+    // after the barrier instead of one and leave its last column to the projection wave -- built and measured in round 4: +12 %
+    // per step for 6 % fewer steps); a slot is free again, with two steps to spare, when its sweep is over (NSW DS >= SKS LA + NU
+    // + 2).  Q = 8 with static twiddles and the verification variant want the lag even.  LWS_ONLINE_LAG_PLUS=k adds k steps
+    // (comparison runs: schedules of different lags agree bit for bit).
     int DS = DS_MIN;
     if (2 * DS < SKB * Q + 2) DS = (SKB * Q + 3) / 2;
     const int need = (SKS * LA + NU + 2 + sh.NSW - 1) / sh.NSW;
     if (DS < need) DS = need;
     {
-        const char *ev = getenv("LWS_ONLINE_EVEN_LAG"), *es = getenv("LWS_ONLINE_SERIAL_TAPS");   // (the verification variant has no odd build)
-        const bool odd_ok = (PT > 0 || Q == 4 || Q == 2) && !(ev && ev[0] == '1') && !(es && es[0] == '1');
+        const char *ep = getenv("LWS_ONLINE_LAG_PLUS"), *es = getenv("LWS_ONLINE_SERIAL_TAPS");   // (the verification variant has no odd build)
+        if (ep && atoi(ep) > 0 && atoi(ep) <= 64) DS += atoi(ep);
+        const bool odd_ok = (PT > 0 || Q == 4 || Q == 2) && !(es && es[0] == '1');
         if (!odd_ok) DS += DS & 1;
     }
     sh.DS = DS;

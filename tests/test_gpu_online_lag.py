@@ -1,6 +1,7 @@
-"""The online engine (k_online4) with the smallest order-exact lag between sweeps, which is odd, against the same engine with
-the lag rounded up to even (LWS_ONLINE_EVEN_LAG=1): the two schedules compute the same sums in the same order
-(TF_RTISI_LA, lwslib.cpp:1424-1492), so the results must agree bit for bit -- any stale or too-new window column shows here."""
+"""The online engine (k_online4) with the smallest order-exact lag between sweeps against the same engine with one, two and
+three steps more (LWS_ONLINE_LAG_PLUS: even and odd lags, and lags at which no frame is "just ahead"): the schedules compute the
+same sums in the same order (TF_RTISI_LA, lwslib.cpp:1424-1492), so the results must agree bit for bit -- any stale or too-new
+window column shows here."""
 import os
 
 import numpy as np
@@ -17,8 +18,12 @@ SHAPES = [  # (fsize, fshift): Q = 4 and Q = 2 with static twiddles, then the ta
 
 def _online(fsize, fshift, S, LA, nit):
     import lws_amd
+    os.environ["LWS_ONLINE_LAYOUT"] = "4"       # (the launcher weighs the layouts by their lags: keep it from changing engines)
     p = lws_amd.lws(fsize, fshift, mode="music", online_iterations=nit, look_ahead=LA)
-    out = np.asarray(p.online_lws(S))
+    try:
+        out = np.asarray(p.online_lws(S))
+    finally:
+        os.environ.pop("LWS_ONLINE_LAYOUT", None)
     return out, p.plan().last_kernel()["name"]
 
 
@@ -29,13 +34,14 @@ def test_odd_lag_equals_even_lag_bit_for_bit(fsize, fshift):
     for case in range(3 if fsize > 2048 else 6):
         T = int(rng.integers(1, 48)); B = int(rng.integers(1, 4)); LA = int(rng.integers(0, 6)); nit = int(rng.integers(1, 10))
         S = rng.rayleigh(1.0, (B, T, F)).astype(np.complex128)
-        os.environ.pop("LWS_ONLINE_EVEN_LAG", None)
+        os.environ.pop("LWS_ONLINE_LAG_PLUS", None)
         a, name = _online(fsize, fshift, S, LA, nit)
         assert name.startswith("online_lds"), name
-        os.environ["LWS_ONLINE_EVEN_LAG"] = "1"
-        try:
-            b, _ = _online(fsize, fshift, S, LA, nit)
-        finally:
-            os.environ.pop("LWS_ONLINE_EVEN_LAG", None)
         assert np.isfinite(a).all()
-        assert np.array_equal(a, b), (fsize, fshift, T, B, LA, nit, float(np.abs(a - b).max()))
+        for plus in (1, 2, 3):
+            os.environ["LWS_ONLINE_LAG_PLUS"] = str(plus)
+            try:
+                b, _ = _online(fsize, fshift, S, LA, nit)
+            finally:
+                os.environ.pop("LWS_ONLINE_LAG_PLUS", None)
+            assert np.array_equal(a, b), (fsize, fshift, T, B, LA, nit, plus, float(np.abs(a - b).max()))

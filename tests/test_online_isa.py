@@ -23,16 +23,20 @@ def test_counted_wait_before_the_barrier_covers_the_stores():
                "--cuda-device-only", "-S", SRC, "-o", os.path.join(td, "online.s")]
         subprocess.run(cmd, check=True, cwd=td, capture_output=True)
         lines = open(os.path.join(td, "online.s")).read().split("\n")
-    found, margin = check_online_isa.check(lines)
+    found, margin, worst = check_online_isa.check(lines)
     assert found >= 8, found      # two half-steps per instantiation: Q in {2, 4, 8} and the BIG variants
     assert margin >= 1, margin    # (the BIG variant keeps a margin of three reads by construction: lgkmcnt(5))
+    assert worst <= 15, worst     # operations in flight at a counted wait: the counter has four bits
 
 
 def test_checker_catches_a_store_behind_the_wait():
-    good = ["_ZN3lws9k_online4ILi4ELi5ELb0ELb0EEEvNS_10OnlineArgsE:", " ds_write_b64 v1, v[2:3]"] + [" ds_read_b128 v[4:7], v1"] * 7 + \
-           [" s_waitcnt lgkmcnt(7)", " s_barrier"]
-    assert check_online_isa.check(good) == (1, 0)
+    good = ["_ZN3lws9k_online4ILi4ELi5ELb0ELb0EEEvNS_10OnlineArgsE:", " s_waitcnt lgkmcnt(0)", " ds_write_b64 v1, v[2:3]"] + \
+           [" ds_read_b128 v[4:7], v1"] * 7 + [" s_waitcnt lgkmcnt(7)", " s_barrier"]
+    assert check_online_isa.check(good) == (1, 0, 8)
     bad = list(good)
-    bad.insert(5, " ds_write_b64 v1, v[2:3]")      # a store among the seven youngest operations
+    bad.insert(6, " ds_write_b64 v1, v[2:3]")      # a store among the seven youngest operations
     with pytest.raises(AssertionError):
         check_online_isa.check(bad)
+    crowded = good[:3] + [" ds_read_b128 v[4:7], v1"] * 9 + good[3:]      # 17 operations since the last full wait
+    with pytest.raises(AssertionError):
+        check_online_isa.check(crowded)

@@ -35,13 +35,20 @@ def test_even_lags_need_no_re_reads_and_odd_lags_do(Q):
         if DS % 2 == 0:
             assert misses == []
         else:
-            # frame rho-1's images of bins 2..5 (window columns 2..5 of a lane that starts at an odd step) -- always;
-            # the images of bins 4, 5 of frame rho+Q-1, previous sweep -- at the smallest odd lag only
+            # the images of bins 2..5 (window columns 2..5 of a lane that starts at an odd step) of the two frames that are close
+            # ahead: frame rho-1 at every odd lag, frame rho+Q-1 of the previous sweep at the smallest odd lag
             waves = {w for (w, _par, _u, _col, _what) in misses}
-            assert (1, 0) in waves
-            assert all(par == 1 and u == 0 for (_w, par, u, _col, _what) in misses)
-            if DS != 4 * Q + 1:
+            assert (1, 0) in waves and waves <= {(1, 0), (Q - 1, 1)}
+            assert all(par == 1 and u == 0 and 2 <= col <= 5 for (_w, par, u, col, _what) in misses)
+            if DS > 4 * Q + 1:
                 assert waves == {(1, 0)}
+
+
+def test_a_lag_below_the_launchers_minimum_is_caught():
+    """SKS Q steps are order-exact, but only if frame rho+Q-1's wave is treated as frame rho-1's is (built in round 4: slower)."""
+    m = _model()
+    for Q in range(2, 9):
+        assert {w for (w, *_rest) in m.check(Q, 4 * Q, fixes=True)} == {(Q - 1, 1)}, Q
 
 
 def test_the_model_reads_what_the_kernel_reads():

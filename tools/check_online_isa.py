@@ -15,7 +15,7 @@ LGKM = re.compile(r"^\s*(ds_\w+|s_load_\w+|s_buffer_load_\w+|s_memtime|s_memreal
 
 def check(lines):
     """Returns (number of counted waits found, smallest margin = reads that follow the last store beyond the count)."""
-    found, margin = 0, None
+    found, margin, worst = 0, None, 0
     kernel = None
     for i, ln in enumerate(lines):
         m = re.match(r"^(_ZN3lws\S*k_online\S*):", ln)
@@ -44,15 +44,28 @@ def check(lines):
             j -= 1
         assert len(young) >= K, "%s: only %d LDS reads between the last store / join and `s_waitcnt lgkmcnt(%d); s_barrier` (line %d)" % (kernel, len(young), K, i + 1)
         assert K + 1 <= 15, "more than 15 operations in flight would wrap the 4-bit counter"
+        # ... and everything issued since the last wait that bounded the counter is still countable: at most 15 in flight
+        n, j, left = 0, i - 1, None
+        while j >= 0:
+            t = lines[j]
+            mm = re.search(r"lgkmcnt\((\d+)\)", t)
+            if "s_waitcnt" in t and mm:
+                left = int(mm.group(1))
+                break
+            if LGKM.match(t):
+                n += 1
+            j -= 1
+        assert left is not None and n + left <= 15, "%s: %d LDS / scalar-memory operations may be in flight at line %d (4-bit counter)" % (kernel, n + (left or 0), i + 1)
+        worst = max(worst, n + left)
         margin = len(young) - K if margin is None else min(margin, len(young) - K)
-    return found, margin
+    return found, margin, worst
 
 
 def main():
     lines = open(sys.argv[1]).read().split("\n")
-    found, margin = check(lines)
+    found, margin, worst = check(lines)
     assert found >= 6, "expected the counted waits of k_online4 (two half-steps per instantiation), found %d" % found
-    print("check_online_isa: %d counted waits, each followed by its stores' completion; smallest margin %d reads" % (found, margin))
+    print("check_online_isa: %d counted waits, each followed by its stores' completion; smallest margin %d reads; at most %d operations in flight" % (found, margin, worst))
 
 
 if __name__ == "__main__":

@@ -59,7 +59,7 @@ def check(Q, DS, NU=40, fixes=True, verbose=False):
 
     for r in range(1, Q):
         for h in (0, 1):
-            kind = 1 if (r == 1 and h == 0) else 0
+            kind = 1 if (r == 1 and h == 0) else 0      # frame rho-1: SKS steps ahead of the lane
             reads = reads_of(kind, fixes and (DS & 1))
             for s in (4, 5):                          # an even and (DS odd) an odd start
                 rho = 10
@@ -82,7 +82,8 @@ def check(Q, DS, NU=40, fixes=True, verbose=False):
                             continue
                         cols = list(range(c0, c0 + 2 * L + 2))
                         if kind == 1:
-                            cols = cols[:-1]          # tap +L of the second bin: the projection wave adds it
+                            cols = cols[:-1]          # tap +L of the second bin: the projection wave adds it (it reads the column
+                                                      # after its own stores of the step before: stored at step t-1 at the latest)
                         if u == NU - 1:
                             cols = cols[:2 * L + 1]   # (no second bin)
                         for col in cols:
@@ -101,10 +102,7 @@ def check(Q, DS, NU=40, fixes=True, verbose=False):
 
 
 def lags(Q):
-    SKB = 2 * SKS
-    ds_min = (SKB * (Q - 1) + L + 3) // 2
-    ds = max(ds_min, (SKB * Q + 3) // 2)
-    return range(ds, ds + 8)
+    return range(SKS * Q + 1, SKS * Q + 18)   # from the launcher's minimum on (max(SKS Q + 1, what the sweep slots need))
 
 
 def main():

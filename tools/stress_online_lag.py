@@ -1,4 +1,4 @@
-"""Random shapes of the online stage: the default (smallest, often odd) lag between sweeps against LWS_ONLINE_EVEN_LAG=1, bit for bit.
+"""Random shapes of the online stage: the default (smallest) lag between sweeps against LWS_ONLINE_LAG_PLUS=1, 2, 3, bit for bit.
     python tools/stress_online_lag.py [cases]     (GPU; tests/test_gpu_online_lag.py is the short version)"""
 import os, sys, subprocess, numpy as np
 sys.path.insert(0, "/root/repo")
@@ -19,9 +19,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "run":
 else:
     n = sys.argv[1] if len(sys.argv) > 1 else "200"
     env = dict(os.environ)
-    subprocess.check_call([sys.executable, __file__, "run", "odd", n], env=env)
-    env["LWS_ONLINE_EVEN_LAG"] = "1"
-    subprocess.check_call([sys.executable, __file__, "run", "even", n], env=env)
-    a, b = np.load("/tmp/lws_lag_odd.npz"), np.load("/tmp/lws_lag_even.npz")
-    bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
-    print("cases", len(a.files), "differing", len(bad), bad[:10])
+    env["LWS_ONLINE_LAYOUT"] = "4"      # (the launcher weighs the layouts by their lags: keep it from changing engines)
+    env.pop("LWS_ONLINE_LAG_PLUS", None)
+    subprocess.check_call([sys.executable, __file__, "run", "plus0", n], env=env)
+    a = np.load("/tmp/lws_lag_plus0.npz")
+    for plus in (1, 2, 3):
+        env["LWS_ONLINE_LAG_PLUS"] = str(plus)
+        subprocess.check_call([sys.executable, __file__, "run", "plus%d" % plus, n], env=env)
+        b = np.load("/tmp/lws_lag_plus%d.npz" % plus)
+        bad = [k for k in a.files if not np.array_equal(a[k], b[k])]
+        print("lag +%d: cases" % plus, len(a.files), "differing", len(bad), bad[:10])
