@@ -18,6 +18,9 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
 
+MARGINS = []     # (fsize, fshift, T, sweeps, rel-L2, median |d| / mean |S|, max magnitude error / max |S|, kernel) of every case run
+
+
 def run_case(oracle, fsize, fshift, T, thr, seed, B=1, scale=None, L=5):
     p = lws_amd.lws(fsize, fshift, L=L)
     F = fsize // 2 + 1
@@ -59,9 +62,12 @@ def run_case(oracle, fsize, fshift, T, thr, seed, B=1, scale=None, L=5):
         assert np.abs(p64.batch(S[b], thr) - ref).max() < 1e-8
         mean = np.mean(np.abs(S[b]))
         d = np.abs(out[b] - ref)
-        assert rel_l2(out[b], ref) < 3e-3, (fsize, fshift, T, b, rel_l2(out[b], ref))
-        assert np.median(d) < 2e-6 * mean
-        assert np.abs(np.abs(out[b]) - np.abs(S[b])).max() < 2e-6 * np.abs(S[b]).max()
+        MARGINS.append((fsize, fshift, T, len(thr), rel_l2(out[b], ref), float(np.median(d) / mean),
+                        float(np.abs(np.abs(out[b]) - np.abs(S[b])).max() / np.abs(S[b]).max()), name))
+        # SURVEY 8c's bars, per case
+        assert rel_l2(out[b], ref) < 1e-3, (fsize, fshift, T, b, rel_l2(out[b], ref))
+        assert np.median(d) < 1e-6 * mean
+        assert np.abs(np.abs(out[b]) - np.abs(S[b])).max() < 1e-6 * np.abs(S[b]).max()
     p64.close()
     return out
 
@@ -461,3 +467,23 @@ def test_any_fp32_data_scale():
     assert np.isfinite(out).all()
     for b in range(3):
         assert rel_l2(out[b] / scales[b], ref[b]) < 1e-4, (b, rel_l2(out[b] / scales[b], ref[b]))
+
+
+def test_zz_margins_actually_achieved():
+    """SURVEY 8c states rel-L2 <= 1e-3, median |d| <= 1e-6 mean |S|, magnitudes <= 1e-6 relative for the order-exact fp32 engine at
+    500 x 513 after 100 sweeps; run_case holds every small random-phase case of this file to the same bars.  What the cases
+    actually reached is written out (gpurun_out/systolic_margins.json when that directory exists; profiles/r04_systolic_margins.json
+    is a copy): round 4, 213 cases: rel-L2 <= 6.1e-4 (the 4092-point build; <= 6.5e-5 elsewhere), medians <= 2.0e-7, magnitudes <= 2.0e-7."""
+    import json
+    if not MARGINS:
+        pytest.skip("run with the rest of the file")
+    rel = max(m[4] for m in MARGINS); med = max(m[5] for m in MARGINS); mag = max(m[6] for m in MARGINS)
+    rel_long = max((m[4] for m in MARGINS if m[2] >= 8), default=0.0)
+    worst = sorted(MARGINS, key=lambda m: -m[4])[:5]
+    report = {"cases": len(MARGINS), "max_rel_l2": rel, "max_rel_l2_T_ge_8": rel_long, "max_median_over_mean": med,
+              "max_magnitude_error": mag, "worst_rel_l2": [list(m) for m in worst]}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(report, open(os.path.join(out, "systolic_margins.json"), "w"), indent=1)
+    print(report)
+    assert med < 5e-7 and mag < 5e-7 and rel < 1e-3, report
