@@ -109,16 +109,21 @@ def test_multi_plan_shards_equal_one_plan():
 
 
 @pytest.mark.parametrize("fsize,fshift,L,T,precision", [(64, 8, 5, 40, "fp32"), (1024, 128, 5, 50, "fp32"), (48, 16, 4, 30, "fp32"),
-                                                      (1040, 260, 5, 40, "fp32"), (64, 16, 7, 33, "fp64"), (1024, 128, 5, 20, "fp64")])
+                                                      (1040, 260, 5, 40, "fp32"), (64, 16, 7, 33, "fp64"), (1024, 128, 5, 20, "fp64"),
+                                                      (1024, 256, 5, 60, "fp64"), (1024, 256, 5, 60, "fp32"), (512, 256, 5, 1, "fp64"),
+                                                      (512, 256, 3, 2, "fp32"), (400, 160, 5, 45, "fp64"), (400, 160, 5, 45, "fp32"),
+                                                      (2048, 512, 5, 12, "fp64"), (64, 16, 5, 200, "fp64"), (96, 32, 9, 25, "fp32"),
+                                                      (4096, 1024, 5, 9, "fp32")])
 def test_generic_batch_on_the_skewed_copy_is_bit_identical(fsize, fshift, L, T, precision, oracle):
     """Shapes the systolic kernels do not serve (Q = 3, L = 7, general weights, fp64 -- or here: forced) run their batch
     sweeps on the generic engine -- on a time-skewed copy of the state so that the taps of a wavefront step are coalesced.
-    Same schedule and arithmetic as in the reference's layout: identical bits; and the oracle's values in fp64."""
+    Same schedule and arithmetic as in the reference's layout: identical bits; and the oracle's values in fp64.  Thirteen sweeps:
+    more than a group of sweeps in flight for the long frames."""
     rng = np.random.default_rng(fsize + L)
     F = fsize // 2 + 1
     p = lws_amd.lws(fsize, fshift, L=L)
     S = rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))
-    thr = np.array([0.7, 0.3, 0.0, 0.0, 0.0])
+    thr = np.array([0.7, 0.3, 0.0, 0.0, 0.0, 0.9, 0.1, 0.0, 0.0, 0.2, 0.0, 0.0, 0.0])
     skew = _capi.Plan(F, p.W, precision=precision, force_generic=True)
     plain = _capi.Plan(F, p.W, precision=precision, force_generic=True, generic_plain_layout=True)
     a = skew.batch(S, thr)
