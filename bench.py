@@ -326,8 +326,8 @@ def load_traffic(kname, config, stage=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="2", choices=sorted(BATCH_CONFIGS), help="headline workload (default: BASELINE config 2)")
     ap.add_argument("--batch", type=int, default=None, help="spectrograms per GPU (default: the config's)")
     ap.add_argument("--frames", type=int, default=None)
