@@ -19,7 +19,7 @@ import check_online_isa  # noqa: E402
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_counted_wait_before_the_barrier_covers_the_stores():
     with tempfile.TemporaryDirectory() as td:
-        cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+        cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-I", os.path.join(ROOT, "include"),
                "--cuda-device-only", "-S", SRC, "-o", os.path.join(td, "online.s")]
         subprocess.run(cmd, check=True, cwd=td, capture_output=True)
         lines = open(os.path.join(td, "online.s")).read().split("\n")
