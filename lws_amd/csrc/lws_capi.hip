@@ -967,7 +967,7 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
         if (P > 0) { p->tw_P = P; p->tw_s = sg; }
     }
     if (p->twiddle_all && p->tw_P == 0) { p->tw_P = Q; p->tw_s = 1; }
-    if (rc == LWS_OK && p->twiddle_all && !p->fp64 && !(p->tw_P == Q && p->tw_s == 1 && (Q == 2 || Q == 4 || Q == 8)) && Q <= 8) {
+    if (rc == LWS_OK && p->twiddle_all && !p->fp64 && !lws::online_static_twiddles(Q, p->tw_P, p->tw_s) && Q <= 8) {
         std::vector<float> tab((size_t)(p->tw_P + 3) * (Q <= 4 ? 8 : 16));
         lws::online_twiddle_table(p->tw_P, p->tw_s, Q, tab.data());
         if ((rc = p->online_tw.ensure(tab.size() * sizeof(float))) == LWS_OK &&

@@ -11,6 +11,8 @@ namespace lws {
 bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update, int tw_P, int tw_s);
 // [P + 3][TQ] complex twiddles for the table variant, TQ = 4 (Q <= 4) or 8 (out: 2 (P + 3) TQ floats)
 void online_twiddle_table(int P, int s, int Q, float *out);
+// do the twiddles exp(2 pi j p r s / P) need no table (eighth turns of Q in {2,4,8})?
+bool online_static_twiddles(int Q, int tw_P, int tw_s);
 
 // Same contract as launch_generic<float> with mode == MODE_ONLINE.  tw_table_dev: the uploaded online_twiddle_table (table variant)
 hipError_t launch_online_lds(const GenericArgs<float> &a, int B, int tw_P, int tw_s, const float *tw_table_dev, hipStream_t stream);

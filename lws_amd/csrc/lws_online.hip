@@ -1696,7 +1696,12 @@ template <int Q, int L, bool SERIAL> hipError_t launch_3(const OnlineArgs &a, in
 
 // tw_P, tw_s: the common twiddle structure of the three tensors (online_twiddle), 0 if they have none.  Tensors of Qp = N rows
 // (general weights) are served through their first Q rows' base weights like summarised ones.
-static bool static_twiddles(int Q, int tw_P, int tw_s) { return tw_P == Q && tw_s == 1 && (Q == 2 || Q == 4 || Q == 8); }
+// (LWS_ONLINE_TABLE_TWIDDLES=1, read when the plan is made: the table variant also where the static one would do -- comparison runs)
+bool online_static_twiddles(int Q, int tw_P, int tw_s) {
+    const char *ev = getenv("LWS_ONLINE_TABLE_TWIDDLES");
+    return tw_P == Q && tw_s == 1 && (Q == 2 || Q == 4 || Q == 8) && !(ev && ev[0] == '1');
+}
+static bool static_twiddles(int Q, int tw_P, int tw_s) { return online_static_twiddles(Q, tw_P, tw_s); }
 bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update, int tw_P, int tw_s) {
     if (update != 2 || tw_P < 1) return false;
     if (static_twiddles(Q, tw_P, tw_s))

@@ -333,3 +333,22 @@ def test_results_do_not_depend_on_stale_device_memory(oracle, fsize, fshift, T):
         del x
         torch.cuda.empty_cache()
         tw_case(oracle, fsize, fshift, T, THR, seed=fsize + T, expect="tw")
+
+
+@pytest.mark.parametrize("fsize,fshift", [(512, 128), (256, 128), (1024, 128)])
+def test_table_twiddles_where_static_ones_would_do(fsize, fshift, monkeypatch):
+    """LWS_ONLINE_TABLE_TWIDDLES=1 (read when the plan is made) runs k_online4<..., TWT> on hop = frame / 2, 4, 8 too: the same sums with
+    the twiddles from the table (cos / sin rounded to fp32: 6e-17 where the static variant has an exact zero, which rarely moves a bit)
+    -- the first frames agree to rounding, the magnitudes everywhere.  This is how the table's cost per step is measured (+7 %)."""
+    rng = np.random.default_rng(fsize)
+    F, T, LA = fsize // 2 + 1, 14, 3
+    p = lws_amd.lws(fsize, fshift, mode="music")
+    S = rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))
+    thr = lws_amd.get_thresholds(3, 1.0, 0.1, 1)
+    W = (p.W, p.W_ai, p.W_af)
+    a, name_a = _online(F, W, S, thr, LA, fsize / fshift)
+    monkeypatch.setenv("LWS_ONLINE_TABLE_TWIDDLES", "1")
+    b, name_b = _online(F, W, S, thr, LA, fsize / fshift)
+    assert name_a == name_b == "online_lds_fp32"
+    assert rel_l2(b[:3], a[:3]) < 3e-5, rel_l2(b[:3], a[:3])
+    assert np.abs(np.abs(a) - np.abs(b)).max() < 2e-6 * np.abs(S).max()
