@@ -1,0 +1,228 @@
+"""Schedule model of the fp64 systolic batch engine (lws_amd/csrc/lws_sys64.hip), lane for lane, in numpy.
+
+Development tool (runs on the CPU, uses the oracle as the checker): the kernel is a transcription of `run_pass` below,
+so a change of the schedule is tried here first.  What is modelled: one wave per sweep slot, lane = frame (64 frames in
+flight, 8 steps apart), one bin per step; the taps of the neighbour frames arrive in *scatter* form (the position a step
+consumes is added to the 2L+1 bins it reaches), the taps of the frame itself in gather form from two register windows.
+The model keeps every slot's output by frame-time row and asserts the ages the LDS rings of the kernel must hold.
+
+    python tools/sys64_model.py            # a few shapes against the oracle
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+L = 5
+NL = 64      # lanes = frames in flight per sweep slot
+SK = 8       # steps between consecutive frames
+MARG = 64
+
+
+def geometry(F, Q):
+    P = max(NL * SK, -(-(F + 3 * L) // 8) * 8)
+    gap = P - NL * SK
+    LAG = L + SK * (Q - 1) + gap + 2
+    R = LAG - L + 1
+    return P, gap, LAG, R
+
+
+def to_skew(ext, F, Q):
+    Tp = ext.shape[0]
+    P, gap, LAG, R = geometry(F, Q)
+    nblk = -(-Tp // NL)
+    U = SK * (NL - 1) + P * nblk
+    G = np.zeros((U + 2 * MARG, NL), complex)
+    for me in range(Tp):
+        j, blk = me % NL, me // NL
+        base = SK * j + P * blk + L + MARG
+        G[base:base + F + L, j] = ext[me]
+    return G, U, nblk
+
+
+def from_skew(G, Tp, F, Q):
+    P = geometry(F, Q)[0]
+    out = np.empty((Tp, F), complex)
+    for me in range(Tp):
+        j, blk = me % NL, me // NL
+        base = SK * j + P * blk + L + MARG
+        out[me] = G[base:base + F, j]
+    return out
+
+
+def extend_cols(S, Q):
+    """frames clamped at both ends (lwslib.cpp:15-40); columns: bins 0..F-1 and the L images above Nyquist"""
+    T, F = S.shape
+    rows = np.clip(np.arange(T + 2 * (Q - 1)) - (Q - 1), 0, T - 1)
+    ext = np.empty((len(rows), F + L), complex)
+    ext[:, :F] = S[rows]
+    for j in range(1, L + 1):
+        ext[:, F - 1 + j] = np.conj(ext[:, F - 1 - j])
+    return ext
+
+
+def pair_sd(ax, ay, wx, wy, sx, dy, sy, dx):
+    return ax + (wx * sx - wy * dy), ay + (wx * sy + wy * dx)
+
+
+def run_pass(G, A, Wm, thr, F, T, Q, ns, stats):
+    """ns sweeps (thr[0..ns-1]) over the skewed state G, in place."""
+    Qp = Wm.shape[0]
+    Tp = T + 2 * (Q - 1)
+    P, gap, LAG, R = geometry(F, Q)
+    nblk = -(-Tp // NL)
+    U = SK * (NL - 1) + P * nblk
+    lane = np.arange(NL)
+    X = [np.full((U + 2 * MARG, NL), np.nan + 0j) for _ in range(ns)]     # slot outputs by frame-time row
+    Xtime = [np.full(U + 2 * MARG, -10 ** 9) for _ in range(ns)]         # time a row was written (ring-age checks)
+    acc = [np.zeros((2 * L + 1, NL), complex) for _ in range(ns)]
+    cn = [np.zeros((L + 1, NL), complex) for _ in range(ns)]
+    co = [np.zeros((L + 1, NL), complex) for _ in range(ns)]
+
+    def rd(arr, rows, lanes):
+        return arr[rows + MARG, lanes]
+
+    for t in range(U + LAG * (ns - 1)):
+        for s in range(ns):
+            u = t - LAG * s
+            if u < 0 or u >= U:
+                continue
+            v = u - SK * lane
+            act = (v >= 0) & (v < P * nblk)
+            blk = np.where(act, v // P, 0)
+            w = np.where(act, v % P, 0)
+            me = NL * blk + lane
+            c = w - L
+            ph = u % 8
+            assert np.all((w[act] % 8) == ph)
+            pos_ok = act & (w <= F + L - 1)
+            prev = G if s == 0 else X[s - 1]
+
+            def age_prev(rows, sel):
+                if s == 0 or not np.any(sel):
+                    return
+                a = t - Xtime[s - 1][rows[sel] + MARG]
+                stats['prev_min'] = min(stats['prev_min'], a.min()); stats['prev_max'] = max(stats['prev_max'], a.max())
+
+            def age_own(rows, sel):
+                if not np.any(sel):
+                    return
+                a = t - Xtime[s][rows[sel] + MARG]
+                stats['own_min'] = min(stats['own_min'], a.min()); stats['own_max'] = max(stats['own_max'], a.max())
+
+            useful = pos_ok & (me >= Q - 1) & (me < T + Q - 1)
+            # (a) the frame's own old value at position w, with the images above Nyquist that this sweep already rewrote
+            rows = u + L + 0 * lane
+            O = rd(prev, rows, lane)
+            age_prev(rows, useful)
+            kk = 2 * c + L - 2 * (F - 1)          # steps since the source of the image at c + L was updated
+            newimg = (kk >= 1) & (kk <= L)
+            for k in range(1, L + 1):
+                O = np.where(newimg & (kk == k), np.conj(cn[s][k]), O)
+            co[s][L] = O
+            # (b) neighbour frames: position w of frames me -+ r, scattered to bins c .. c + 2L
+            for r in range(1, Q):
+                rowsL = u + L - SK * r - np.where(lane < r, gap, 0)
+                rowsR = u + L + SK * r + np.where(lane + r >= NL, gap, 0)
+                Lv = rd(X[s], rowsL, (lane - r) % NL)
+                Rv = rd(prev, rowsR, (lane + r) % NL)
+                age_own(rowsL, useful); age_prev(rowsR, useful)
+                sx = np.where(pos_ok, Lv.real + Rv.real, 0.0); dy = np.where(pos_ok, Lv.imag - Rv.imag, 0.0)
+                sy = np.where(pos_ok, Lv.imag + Rv.imag, 0.0); dx = np.where(pos_ok, Lv.real - Rv.real, 0.0)
+                for d in range(2 * L + 1):
+                    tgt = (ph - L + d) % Qp
+                    if d < L:
+                        wv = np.conj(Wm[(Qp - tgt) % Qp, r, L - d])
+                    else:
+                        wv = Wm[tgt, r, d - L]
+                    ax, ay = pair_sd(acc[s][d].real, acc[s][d].imag, wv.real, wv.imag, sx, dy, sy, dx)
+                    acc[s][d] = ax + 1j * ay
+                # images below DC: position -w is the conjugate of position w, reaches bins 0 .. L - w
+                if 1 <= ph <= L:
+                    z = act & (w == ph)
+                    for ct in range(0, L - ph + 1):
+                        d = ct + L - ph
+                        wv = Wm[ct % Qp, r, ct + ph]
+                        ax = acc[s][d].real + (wv.real * sx + wv.imag * dy)
+                        ay = acc[s][d].imag + (-wv.real * sy + wv.imag * dx)
+                        acc[s][d] = np.where(z, ax + 1j * ay, acc[s][d])
+            # (c) the frame itself
+            a = acc[s][0].copy()
+            rowc = (ph - L) % Qp
+            for k in range(1, L + 1):
+                b = cn[s][k].copy()
+                for cc in range(0, L):            # bins 0..L-1: images below DC
+                    if k > cc:
+                        q = k - cc
+                        src = np.conj(cn[s][cc - q]) if q < cc else np.conj(co[s][q - cc])
+                        b = np.where(c == cc, src, b)
+                wv = Wm[rowc, 0, k]
+                cv = co[s][k]
+                ax, ay = pair_sd(a.real, a.imag, wv.real, wv.imag, b.real + cv.real, b.imag - cv.imag,
+                                 b.imag + cv.imag, b.real - cv.real)
+                a = ax + 1j * ay
+            amp = rd(A, u + 0 * lane, lane)
+            mag = np.sqrt(a.real * a.real + a.imag * a.imag)
+            upd = act & (c >= 0) & (c <= F - 1) & (me >= Q - 1) & (me < T + Q - 1) & (amp > thr[s]) & (mag > 0)
+            with np.errstate(all='ignore'):
+                vnew = (a.real * amp / mag) + 1j * (a.imag * amp / mag)
+            val = np.where(upd, vnew, co[s][0])
+            # images above Nyquist are written when the lane passes them
+            jj = c - (F - 1)
+            img = act & (jj >= 1) & (jj <= L)
+            rowsI = u - 2 * np.where(img, jj, 0)
+            age_own(rowsI, img & (me >= Q - 1) & (me < T + Q - 1))
+            val = np.where(img, np.conj(rd(X[s], rowsI, lane)), val)
+            # windows
+            j2 = (F - 1) - c
+            for q in (1, 2):
+                if 2 * q <= L:
+                    co[s][2 * q] = np.where(act & (j2 == q), np.conj(val), co[s][2 * q])
+            X[s][u + MARG] = val
+            Xtime[s][u + MARG] = t
+            if s == ns - 1:
+                wr = act & (c >= 0) & (c <= F + L - 1)
+                G[u + MARG, wr] = val[wr]
+            for k in range(L, 1, -1):
+                cn[s][k] = cn[s][k - 1]
+            cn[s][1] = val
+            for k in range(0, L):
+                co[s][k] = co[s][k + 1]
+            for d in range(2 * L):
+                acc[s][d] = acc[s][d + 1]
+            acc[s][2 * L] = 0
+
+
+def batch_lws_model(S, W, thresholds, NS=3):
+    S = np.asarray(S, complex)
+    T, F = S.shape
+    Qp, Q, _ = W.shape
+    Wm = np.where(np.abs(W) > 1e-12, W, 0)
+    ext = extend_cols(S, Q)
+    G, U, nblk = to_skew(ext, F, Q)
+    A, _, _ = to_skew(np.abs(ext).astype(complex), F, Q)
+    A = A.real.copy()
+    mean = float(np.mean(np.abs(S)))
+    thr = [th * mean for th in thresholds]
+    stats = dict(prev_min=10 ** 9, prev_max=-1, own_min=10 ** 9, own_max=-1)
+    for i in range(0, len(thr), NS):
+        run_pass(G, A, Wm, thr[i:i + NS], F, T, Q, len(thr[i:i + NS]), stats)
+    out = from_skew(G, T + 2 * (Q - 1), F, Q)[Q - 1:Q - 1 + T]
+    return out, stats
+
+
+if __name__ == "__main__":
+    import lws_amd
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    rng = np.random.default_rng(1)
+    for (fs, hop, T, F, it) in [(64, 16, 9, 33, 4), (64, 16, 70, 33, 5), (64, 32, 67, 33, 4), (1024, 256, 12, 513, 4)]:
+        p = lws_amd.lws(fs, hop, batch_iterations=it, batch_alpha=1.0)
+        S = rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))
+        thr = lws_amd.get_thresholds(it, 1.0, 0.1, 1)
+        ref = orc.batch_lws(S, p.W, thr)
+        out, st = batch_lws_model(S, p.W, thr)
+        err = np.abs(out - ref).max() / np.abs(ref).max()
+        print("lws(%d,%d) T=%d F=%d iters=%d Q=%d: max rel err %.2e  ages %s  geometry(P,gap,LAG,R)=%s"
+              % (fs, hop, T, F, it, p.W.shape[1], err, st, geometry(F, p.W.shape[1])))
