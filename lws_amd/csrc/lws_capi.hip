@@ -14,6 +14,7 @@
 #include "lws_common.h"
 #include <type_traits>
 #include "lws_systolic.h"
+#include "lws_sys64.h"
 #include "lws_online.h"
 
 #include <atomic>
@@ -248,6 +249,8 @@ int ensure_scratch(lws_plan *p, int B, int T, int n_thr) {
     return LWS_OK;
 }
 
+int env_int(const char *name, int dflt);
+
 void begin_timing(lws_plan *p, hipStream_t s) {
     (void)hipEventRecord(p->ev0, s);
     p->last_launches = 0;
@@ -325,6 +328,28 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
             p->last_launches = 1;
             p->last_name = mode == lws::MODE_NOFUTURE_Q4_COMPAT ? "nofuture_lds_q4compat_fp32" : "nofuture_lds_fp32";
             return LWS_OK;
+        }
+    }
+    if constexpr (std::is_same<real, double>::value) {
+        // batch sweeps of an fp64 plan: the fp64 systolic engine (lws_sys64.hip) when the shape and the weights allow it.  Same
+        // sweeps in the reference's order; a bin's sum is taken in another order, so results agree to rounding, not bit for bit
+        // (LWS_FORCE_GENERIC keeps the order-exact engine).
+        if (mode == lws::MODE_BATCH && !(p->flags & (LWS_FORCE_GENERIC | LWS_GENERIC_PLAIN_LAYOUT)) && !env_int("LWS_NO_SYS64", 0) &&
+            lws::sys64_supports(a.F, a.T, a.L, a.Q, a.Qp, a.update, p->have[wsel] ? p->hostW[wsel].data() : nullptr)) {
+            size_t ab = 0;
+            const size_t sb = lws::sys64_bytes(B, a.F, a.T, a.Q, &ab);
+            if (p->gsk_state.ensure(sb) == LWS_OK && p->gsk_amp.ensure(ab) == LWS_OK) {
+                int launches = 0;
+                hipError_t e = lws::launch_sys64(a, p->hostW[wsel].data(), B, p->gsk_state.p, p->gsk_amp.p, s, &launches, p->ev0, p->ev1);
+                p->timing_pending = true;
+                if (e != hipSuccess) return fail(LWS_ERR_HIP, "fp64 systolic launch failed: %s", hipGetErrorString(e));
+                p->last_launches = launches;
+                p->last_name = lws::sys64_name(a.Q);
+                return LWS_OK;
+            }
+            p->gsk_state.release(); p->gsk_amp.release();   // no room for the skewed copy: the generic engine below
+            (void)hipGetLastError();
+            g_err.clear();
         }
     }
     if (mode == lws::MODE_BATCH && !(p->flags & LWS_GENERIC_PLAIN_LAYOUT)) {

@@ -1,0 +1,483 @@
+// lws_sys64.hip -- the batch sweeps of an fp64 plan (the reference's own arithmetic type, lwslib.h:6-26) as a systolic kernel.
+//
+// What it computes: LWSQ2 / LWSQ4 / LWSanyQ (lwslib.cpp:72-373) -- every bin of every frame in the reference's order,
+// overwritten in place as soon as it is computed, Hermitian images kept in step (lwslib.cpp:356-368) -- for Q in {2, 4},
+// L = 5, frames of up to ~620 bins.  The sum of a bin is taken in a different ORDER than lwslib.cpp takes it (below), so
+// results agree with the reference to rounding (1e-13 relative after 100 sweeps, tests/test_gpu_sys64.py), not bit for bit;
+// the order-exact fp64 engine remains lws_generic.hip (LWS_FORCE_GENERIC).
+//
+// Design (tools/sys64_model.py is the same schedule in numpy, lane for lane, and was written first):
+//   * one workgroup per spectrogram, one wave per sweep slot, lane = frame: 64 consecutive frames are in flight in a slot,
+//     8 steps apart (> L + 1, and a multiple of Q so that `bin mod Q` -- the weight row -- is the same in every lane);
+//     a lane updates one bin per step and takes up its next frame (64 further on) after P >= F + 3L steps.
+//   * a slot's output lives in an LDS ring of R rows x 64 lanes x 16 B, one row per step (row = time mod R): the frames
+//     m-1..m-(Q-1) of the same sweep are the lanes to the left a few rows back, the frames m+1..m+(Q-1) of the previous
+//     sweep are in the ring of the slot before, LAG steps behind.  Slot 0 reads the previous pass from a time-skewed
+//     copy of the state in HBM (coalesced rows, prefetched four steps ahead), the last slot writes it back in place.
+//   * the taps of the neighbour frames are taken in SCATTER form: the position a step receives (one value per neighbour
+//     frame) is combined once -- sum and difference of the two frames r apart, which is how lwslib.cpp:310-311 groups
+//     them -- and added to the 2L+1 bins of the lane's frame it reaches, with 2 FMAs per component.  A bin is complete
+//     when the position L bins above it has arrived; its own frame's taps come from two register windows (new values
+//     below, old values above).  Per bin: 4(Q-1)(2L+1) + 8L FMAs instead of the 8-instruction pair of the gather form.
+//   * Hermitian images: the L images above Nyquist are ordinary positions (a lane writes them as it passes); the images
+//     below DC are never stored -- the step that receives position w <= L also scatters its conjugate as position -w.
+//
+// Entry: launch_sys64 (lws_sys64.h), called by lws_capi.hip:run_stage for MODE_BATCH of an fp64 plan.
+#include "lws_sys64.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace lws {
+namespace {
+
+constexpr int SL = 5;        // stencil half-width in bins
+constexpr int NLN = 64;      // lanes = frames in flight per slot
+constexpr int SKW = 8;       // steps between consecutive frames
+constexpr int MARG = 96;     // rows before / after the skewed state that prefetches may touch
+constexpr int PFD = 4;       // steps a global load is issued ahead of its use
+constexpr int LDS_ROWS = 160;   // ring rows of 1 KB that fit the LDS
+
+struct Geom { int P, gap, LAG, R, nblk, U; long rows; };
+inline Geom geom(int F, int T, int Q) {
+    Geom g;
+    const int Tp = T + 2 * (Q - 1);
+    g.P = std::max(NLN * SKW, (F + 3 * SL + 7) / 8 * 8);
+    g.gap = g.P - NLN * SKW;
+    g.LAG = (SL + SKW * (Q - 1) + g.gap + 2 + 7) / 8 * 8;
+    g.R = g.LAG - SL + 1;
+    g.nblk = (Tp + NLN - 1) / NLN;
+    g.U = SKW * (NLN - 1) + g.P * g.nblk;
+    g.rows = (long)g.U + 2 * MARG;
+    return g;
+}
+
+struct S64Args {
+    double2 *G;            // [B][rows][64] time-skewed state: frame me, bin c at row 8 (me % 64) + P (me / 64) + c + L
+    const double *A;       // [B][rows][64] target magnitudes, same addressing
+    const double *thr;     // [B][n_thr]
+    long g_stride;         // rows * 64
+    int n_thr, thr0, ns;   // this pass: sweeps thr0 .. thr0 + ns - 1
+    int F, T, P, gap, LAG, R, nblk, U;
+};
+
+// The weights of row 0, W[0][r][k] (entries the reference skips -- |w| <= 1e-12, lws.pyx:227-232 -- are zero here).  The other
+// rows are quarter turns of it (create_weights, lws.pyx:160-181: W[p][r][k] = W[0][r][k] exp(2 pi j p r / Q)), which costs
+// nothing at compile time: the row of a step's bins is static in the eight-times unrolled loop.  They travel in the kernel
+// arguments, i.e. they are scalar loads from the kernarg segment that the compiler may keep in SGPRs.
+template <int Q> struct BaseW {
+    double2 c[SL];            // r = 0, k = 1..L
+    double2 n[Q - 1][SL + 1];   // r = 1..Q-1, k = 0..L
+};
+
+// acc += W * (s, d) with W = j^N V (CONJ: V conjugated first):  acc.x += W.x sx - W.y dy,  acc.y += W.x sy + W.y dx
+// -- the grouped form of lwslib.cpp:310-311 on the sum / difference of the two frames r apart.
+template <int N, bool CONJ> __device__ __forceinline__ void sc_add(double2 &acc, const double2 v, double sx, double dy, double sy, double dx) {
+    const double vx = v.x, vy = CONJ ? -v.y : v.y;
+    const double wx = N == 0 ? vx : (N == 1 ? -vy : (N == 2 ? -vx : vy));
+    const double wy = N == 0 ? vy : (N == 1 ? vx : (N == 2 ? -vy : -vx));
+    acc.x = __builtin_fma(wx, sx, acc.x);
+    acc.x = __builtin_fma(-wy, dy, acc.x);
+    acc.y = __builtin_fma(wx, sy, acc.y);
+    acc.y = __builtin_fma(wy, dx, acc.y);
+}
+template <int Q> __host__ __device__ constexpr int quarter_turns(int row, int r) {   // of exp(2 pi j row r / Q), Q in {2, 4}
+    return ((((row % Q) + Q) % Q) * r % Q) * (4 / Q);
+}
+
+__device__ __forceinline__ double2 cj(double2 v) { v.y = -v.y; return v; }
+__device__ __forceinline__ double2 sel(bool c, double2 a, double2 b) { double2 r; r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; return r; }
+
+// LDS writes of this step complete, then everybody meets.  (Not __syncthreads(): that waits for the global prefetches too.)
+#define S64_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int Q, bool FIRST> struct Wave {
+    static constexpr int L = SL, NR = Q - 1, NA = 2 * SL + 1;
+    // lane state
+    double2 acc[NA];          // sums of bins c .. c + 2L
+    double2 cn[L + 1];        // cn[k]: new value of bin c - k
+    double2 co[L + 1];        // co[k]: old value of bin c + k
+    double2 nxL[NR], nxR[NR], nxO, nxI;   // inputs of the next step (LDS)
+    double2 pfO[PFD], pfR[PFD][NR];       // slot 0: inputs of the next PFD steps (HBM)
+    double pfA[PFD];
+    int offL[NR], ageL[NR], offR[NR], ageR[NR], rowR[NR];
+    int w, me, tm;
+    // wave constants
+    const S64Args &a;
+    const BaseW<Q> &bw;
+    double2 *ring_own;
+    const double2 *ring_prev;
+    double2 *G;
+    const double *A;
+    int lane, s;
+    double thr;
+    bool last;
+
+    __device__ __forceinline__ Wave(const S64Args &a_, const BaseW<Q> &bw_, double2 *ring, double2 *G_, const double *A_, int s_, int lane_)
+        : a(a_), bw(bw_), G(G_), A(A_), lane(lane_), s(s_) {
+        ring_own = ring + (size_t)s * a.R * NLN;
+        ring_prev = ring + (size_t)(s > 0 ? s - 1 : 0) * a.R * NLN;
+        last = s == a.ns - 1;
+        thr = a.thr[(size_t)blockIdx.x * a.n_thr + a.thr0 + (s < a.ns ? s : 0)];
+#pragma unroll
+        for (int r = 1; r <= NR; ++r) {
+            offL[r - 1] = (lane - r) & (NLN - 1);
+            ageL[r - 1] = SKW * r - L + (lane < r ? a.gap : 0);
+            offR[r - 1] = (lane + r) & (NLN - 1);
+            const int wrap = lane + r >= NLN ? a.gap : 0;
+            ageR[r - 1] = a.LAG - L - SKW * r - wrap;
+            rowR[r - 1] = L + SKW * r + wrap;
+        }
+        double2 z; z.x = 0; z.y = 0;
+#pragma unroll
+        for (int d = 0; d < NA; ++d) acc[d] = z;
+#pragma unroll
+        for (int k = 0; k <= L; ++k) { cn[k] = z; co[k] = z; }
+        w = -SKW * lane;
+        me = lane;
+        tm = (a.LAG * s) % a.R;
+    }
+
+    __device__ __forceinline__ int slot(int t_mod, int age) const {   // ring row written `age` steps before time t_mod
+        int x = t_mod - age;
+        return x < 0 ? x + a.R : x;
+    }
+    // LDS inputs of the step at ring time tmx, frame-time ux, lane position wx
+    __device__ __forceinline__ void issue_lds(int tmx, int wx) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) nxL[r] = ring_own[slot(tmx, ageL[r]) * NLN + offL[r]];
+        if constexpr (!FIRST) {
+            nxO = ring_prev[slot(tmx, a.LAG - L) * NLN + lane];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) nxR[r] = ring_prev[slot(tmx, ageR[r]) * NLN + offR[r]];
+        }
+        const int jj = wx - L - (a.F - 1);
+        nxI = ring_own[slot(tmx, (jj >= 1 && jj <= L) ? 2 * jj : 2) * NLN + lane];
+    }
+    __device__ __forceinline__ void issue_global(int ux, int b) {
+        pfA[b] = A[(size_t)(ux + MARG) * NLN + lane];
+        if constexpr (FIRST) {
+            pfO[b] = G[(size_t)(ux + L + MARG) * NLN + lane];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) pfR[b][r] = G[(size_t)(ux + rowR[r] + MARG) * NLN + offR[r]];
+        }
+    }
+    __device__ __forceinline__ void prologue() {   // before the step of frame-time 0
+#pragma unroll
+        for (int b = 0; b < PFD; ++b) issue_global(b, b);
+        issue_lds(tm, w);
+    }
+
+    // position w of the frames RR apart -> bins c + D .. c + 2L (target bin (PH - L + D) mod Q; weight W[row][RR][|D - L|] for
+    // the taps below a bin, conj(W[-row][RR][|D - L|]) = j^(row RR) conj(W[0][RR][..]) for the taps above it)
+    template <int PH, int RR, int D> __device__ __forceinline__ void scatter(double sx, double dy, double sy, double dx) {
+        if constexpr (D < NA) {
+            constexpr int K = D < L ? L - D : D - L;
+            sc_add<quarter_turns<Q>(PH - L + D, RR), (D < L)>(acc[D], bw.n[RR - 1][K], sx, dy, sy, dx);
+            scatter<PH, RR, D + 1>(sx, dy, sy, dx);
+        }
+    }
+    // the image below DC of position PH (= w): position -PH, the conjugate, reaches bins CT = 0 .. L - PH with W[CT][RR][CT + PH]
+    template <int PH, int RR, int CT> __device__ __forceinline__ void images(double sx, double dy, double sy, double dx) {
+        if constexpr (CT <= L - PH) {
+            constexpr int D = CT + L - PH, K = CT + PH;
+            sc_add<quarter_turns<Q>(CT, RR), false>(acc[D], bw.n[RR - 1][K], sx, -dy, -sy, dx);
+            images<PH, RR, CT + 1>(sx, dy, sy, dx);
+        }
+    }
+    // (b) of a step for the frames RR, RR + 1, .. apart
+    // (rows that are no position of a frame -- before its bin 0, after its last image, before the first and after the last
+    // frame -- hold zeros: in the ring because a lane writes 0 there, in HBM because the layout is cleared first; so a step
+    // that receives no position adds nothing, and the sums of a lane are zero again when it takes up its next frame)
+    template <int PH, int RR> __device__ __forceinline__ void neighbours(const double2 (&Lv)[NR], const double2 (&Rv)[NR]) {
+        if constexpr (RR <= NR) {
+            const double2 lv = Lv[RR - 1], rv = Rv[RR - 1];
+            const double sx = lv.x + rv.x, dy = lv.y - rv.y;
+            const double sy = lv.y + rv.y, dx = lv.x - rv.x;
+            scatter<PH, RR, 0>(sx, dy, sy, dx);
+            if constexpr (PH >= 1 && PH <= L) {
+                // images below DC: position -w is the conjugate of position w and reaches bins 0 .. L - w (one lane at most)
+                if (w == PH) images<PH, RR, 0>(sx, dy, sy, dx);
+            }
+            neighbours<PH, RR + 1>(Lv, Rv);
+        }
+    }
+
+    template <int PH> __device__ __forceinline__ void step(int u) {
+        // ---- this step's inputs (loaded earlier), then the loads of later steps
+        double2 O, Rv[NR], Lv[NR];
+        const double2 img = nxI;
+        const double amp = pfA[PH % PFD];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) Lv[r] = nxL[r];
+        if constexpr (FIRST) {
+            O = pfO[PH % PFD];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) Rv[r] = pfR[PH % PFD][r];
+        } else {
+            O = nxO;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) Rv[r] = nxR[r];
+        }
+        int w1 = w + 1, me1 = me;
+        if (w1 == a.P) { w1 = 0; me1 += NLN; }
+        const int tm1 = tm + 1 == a.R ? 0 : tm + 1;
+        issue_lds(tm1, w1);
+        issue_global(u + PFD, PH % PFD);
+
+        const int c = w - L, F = a.F;
+        const bool act = w >= 0 && me < NLN * a.nblk;
+        // ---- (a) old value of the frame itself at bin c + L; an image above Nyquist whose source this sweep has already
+        //      rewritten is the conjugate of that new value
+        {
+            const int kk = 2 * c + L - 2 * (F - 1);
+            double2 o = O;
+            o = sel(kk == 1, cj(cn[1]), o);
+            o = sel(kk == 3, cj(cn[3]), o);
+            o = sel(kk == 5, cj(cn[5]), o);
+            co[L] = o;
+        }
+        // ---- (b) neighbour frames: position w of frames me -+ r reaches bins c .. c + 2L
+        neighbours<PH, 1>(Lv, Rv);
+        // ---- (c) the frame's own taps: new values below (or their images below DC), old values above; k = 1 last (it is
+        //      the value the previous step produced)
+        double2 a0 = acc[0];
+        constexpr int CC = ((PH - L) % 8 + 8) % 8;   // the bin below L a lane can be at in this phase
+#pragma unroll
+        for (int k = L; k >= 1; --k) {
+            double2 b = cn[k];
+            if constexpr (CC < L) {
+                if (k > CC) {
+                    const int q = k - CC;
+                    const double2 src = q < CC ? cn[CC - q > 0 ? CC - q : 0] : co[q - CC <= L ? q - CC : 0];
+                    b = sel(c == CC, cj(src), b);
+                }
+            }
+            const double2 wv = bw.c[k - 1];
+            const double2 cv = co[k];
+            a0.x = __builtin_fma(wv.x, b.x + cv.x, a0.x);
+            a0.x = __builtin_fma(-wv.y, b.y - cv.y, a0.x);
+            a0.y = __builtin_fma(wv.x, b.y + cv.y, a0.y);
+            a0.y = __builtin_fma(wv.y, b.x - cv.x, a0.y);
+        }
+        // ---- re-projection on the target magnitude (lwslib.cpp:356-360)
+        const double m2 = a0.x * a0.x + a0.y * a0.y;
+        const bool upd = act && c >= 0 && c <= F - 1 && me >= Q - 1 && me < a.T + Q - 1 && amp > thr && m2 > 0.0;
+        const double sc = amp * rsqrt(m2);
+        double2 val;
+        val.x = upd ? a0.x * sc : co[0].x;
+        val.y = upd ? a0.y * sc : co[0].y;
+        // ---- images above Nyquist (lwslib.cpp:365-367): written when the lane passes them, from its own ring
+        {
+            const int jj = c - (F - 1);
+            val = sel(act && jj >= 1 && jj <= L, cj(img), val);
+            const int j2 = (F - 1) - c;
+            co[2] = sel(act && j2 == 1, cj(val), co[2]);
+            co[4] = sel(act && j2 == 2, cj(val), co[4]);
+        }
+        const bool is_pos = act && c >= 0 && c <= F + L - 1;
+        {
+            double2 z; z.x = 0; z.y = 0;
+            ring_own[tm * NLN + lane] = sel(is_pos, val, z);
+        }
+        if (last && is_pos) G[(size_t)(u + MARG) * NLN + lane] = val;
+        // ---- windows move on by one bin
+#pragma unroll
+        for (int k = L; k >= 2; --k) cn[k] = cn[k - 1];
+        cn[1] = val;
+#pragma unroll
+        for (int k = 0; k < L; ++k) co[k] = co[k + 1];
+#pragma unroll
+        for (int d = 0; d < NA - 1; ++d) acc[d] = acc[d + 1];
+        acc[NA - 1].x = 0; acc[NA - 1].y = 0;
+        w = w1; me = me1; tm = tm1;
+    }
+};
+
+template <int Q, bool FIRST>
+__device__ __forceinline__ void s64_wave(const S64Args &a, const BaseW<Q> &bw, double2 *ring, double2 *G, const double *A, int s, int lane) {
+    Wave<Q, FIRST> wv(a, bw, ring, G, A, s, lane);
+    const bool live = s < a.ns;
+    const int t_end = a.U + a.LAG * (a.ns - 1);   // U and LAG are multiples of 8
+    for (int t0 = 0; t0 < t_end; t0 += 8) {
+        const int u0 = t0 - a.LAG * s;
+        if (live && u0 >= 0 && u0 < a.U) {
+            if (u0 == 0) wv.prologue();
+            wv.template step<0>(u0); S64_BARRIER();
+            wv.template step<1>(u0 + 1); S64_BARRIER();
+            wv.template step<2>(u0 + 2); S64_BARRIER();
+            wv.template step<3>(u0 + 3); S64_BARRIER();
+            wv.template step<4>(u0 + 4); S64_BARRIER();
+            wv.template step<5>(u0 + 5); S64_BARRIER();
+            wv.template step<6>(u0 + 6); S64_BARRIER();
+            wv.template step<7>(u0 + 7); S64_BARRIER();
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) S64_BARRIER();
+        }
+    }
+}
+
+template <int Q, int NS>
+__global__ void __launch_bounds__(NLN * NS) k_sys64(S64Args a, BaseW<Q> bw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s64_lds[];
+    double2 *ring = reinterpret_cast<double2 *>(s64_lds);
+    const int lane = threadIdx.x & (NLN - 1);
+    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double2 *G = a.G + (size_t)blockIdx.x * a.g_stride;
+    const double *A = a.A + (size_t)blockIdx.x * a.g_stride;
+    {
+        double2 z; z.x = 0; z.y = 0;
+        for (int i = threadIdx.x; i < NS * a.R * NLN; i += NLN * NS) ring[i] = z;
+        __syncthreads();
+    }
+    if (s == 0) s64_wave<Q, true>(a, bw, ring, G, A, s, lane);
+    else s64_wave<Q, false>(a, bw, ring, G, A, s, lane);
+}
+
+// extended buffers [B][Tp][Np] <-> the skewed layout
+__global__ void k_s64_load(const double2 *state, const double *amp, double2 *G, double *A, int F, int Tp, int P, long g_stride) {
+    const int b = blockIdx.y, me = blockIdx.x, Np = F + 2 * SL;
+    const int j = me & (NLN - 1), blk = me / NLN;
+    const long base = (long)SKW * j + (long)P * blk + SL + MARG;
+    const double2 *src = state + ((size_t)b * Tp + me) * Np + SL;
+    const double *asrc = amp + ((size_t)b * Tp + me) * Np + SL;
+    for (int c = threadIdx.x; c < F + SL; c += blockDim.x) {
+        G[(size_t)b * g_stride + (base + c) * NLN + j] = src[c];
+        A[(size_t)b * g_stride + (base + c) * NLN + j] = asrc[c];
+    }
+}
+__global__ void k_s64_store(double2 *state, const double2 *G, int F, int Tp, int P, long g_stride) {
+    const int b = blockIdx.y, me = blockIdx.x, Np = F + 2 * SL;
+    const int j = me & (NLN - 1), blk = me / NLN;
+    const long base = (long)SKW * j + (long)P * blk + SL + MARG;
+    double2 *dst = state + ((size_t)b * Tp + me) * Np + SL;
+    for (int c = threadIdx.x; c < F + SL; c += blockDim.x) {
+        const double2 v = G[(size_t)b * g_stride + (base + c) * NLN + j];
+        dst[c] = v;
+        if (c >= 1 && c <= SL) dst[-c] = cj(v);
+    }
+}
+
+template <int Q, int NS>
+hipError_t launch_pass(const S64Args &a, const BaseW<Q> &bw, int B, hipStream_t stream) {
+    static std::atomic<unsigned long long> done{0};
+    const size_t lds = (size_t)NS * a.R * NLN * sizeof(double2);
+    int dev = 0;
+    if (attr_needed(done, &dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sys64<Q, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done(done, dev);
+    }
+    k_sys64<Q, NS><<<dim3(B), dim3(NLN * NS), lds, stream>>>(a, bw);
+    return hipGetLastError();
+}
+
+int slots_for(int Q, int R) {   // sweep slots per workgroup: what the LDS holds, among the builds that exist
+    const int fit = LDS_ROWS / R;
+    if (Q == 4) return fit >= 5 ? 5 : (fit >= 3 ? 3 : (fit >= 1 ? 1 : 0));
+    if (Q == 2) return fit >= 8 ? 8 : (fit >= 5 ? 5 : (fit >= 3 ? 3 : (fit >= 1 ? 1 : 0)));
+    return 0;
+}
+
+// W (host, complex128 interleaved, [Qp][Q][L+1]): every row a quarter-turn image of row 0, to rounding?  Fills the row-0 weights.
+template <int Q> bool base_weights(const double *W, int Qp, BaseW<Q> *out) {
+    const int K1 = SL + 1;
+    if (!W || Qp < 1 || Qp % Q != 0) return false;   // (Qp - row) mod Qp must be -row mod Q
+    auto at = [&](int p, int r, int k, int c) { return W[2 * (((size_t)p * Q + r) * K1 + k) + c]; };
+    double scale = 0;
+    for (size_t x = 0; x < (size_t)Qp * Q * K1; ++x) scale = std::max(scale, std::hypot(W[2 * x], W[2 * x + 1]));
+    if (!(scale > 0)) return false;
+    for (int p = 0; p < Qp; ++p)
+        for (int r = 0; r < Q; ++r)
+            for (int k = 0; k < K1; ++k) {
+                if (r == 0 && k == 0) continue;   // never read (update == 2)
+                const double br = at(0, r, k, 0), bi = at(0, r, k, 1);
+                const int n = quarter_turns<Q>(p, r);
+                const double er = n == 0 ? br : (n == 1 ? -bi : (n == 2 ? -br : bi));
+                const double ei = n == 0 ? bi : (n == 1 ? br : (n == 2 ? -bi : -br));
+                if (std::hypot(at(p, r, k, 0) - er, at(p, r, k, 1) - ei) > 1e-13 * scale) return false;
+                // the reference skips a weight by its own magnitude (lws.pyx:232); rows that disagree about that cannot share row 0
+                if ((std::hypot(at(p, r, k, 0), at(p, r, k, 1)) > 1e-12) != (std::hypot(br, bi) > 1e-12)) return false;
+            }
+    if (out) {
+        auto put = [&](double2 &d, int r, int k) {
+            const bool on = std::hypot(at(0, r, k, 0), at(0, r, k, 1)) > 1e-12;
+            d.x = on ? at(0, r, k, 0) : 0.0;
+            d.y = on ? at(0, r, k, 1) : 0.0;
+        };
+        for (int k = 1; k <= SL; ++k) put(out->c[k - 1], 0, k);
+        for (int r = 1; r < Q; ++r)
+            for (int k = 0; k <= SL; ++k) put(out->n[r - 1][k], r, k);
+    }
+    return true;
+}
+
+}  // namespace
+
+bool sys64_supports(int F, int T, int L, int Q, int Qp, int update, const double *W) {
+    if (L != SL || update != 2 || T < 1 || F < 2 * SL + 7) return false;
+    if (Q != 2 && Q != 4) return false;
+    const Geom g = geom(F, T, Q);
+    if (slots_for(Q, g.R) < 1) return false;
+    return Q == 4 ? base_weights<4>(W, Qp, nullptr) : base_weights<2>(W, Qp, nullptr);
+}
+
+size_t sys64_bytes(int B, int F, int T, int Q, size_t *amp_bytes) {
+    const Geom g = geom(F, T, Q);
+    if (amp_bytes) *amp_bytes = (size_t)B * g.rows * NLN * sizeof(double);
+    return (size_t)B * g.rows * NLN * sizeof(double2);
+}
+
+const char *sys64_name(int Q) { return Q == 2 ? "systolic_fp64_q2" : "systolic_fp64_q4"; }
+
+namespace {
+template <int Q>
+hipError_t run_passes(S64Args a, const double *W, int Qp, int NS, int n_thr, int B, hipStream_t stream, int *n_out) {
+    BaseW<Q> bw;
+    if (!base_weights<Q>(W, Qp, &bw)) return hipErrorInvalidValue;
+    int n = 0;
+    for (int i0 = 0; i0 < n_thr; i0 += NS, ++n) {
+        a.thr0 = i0;
+        a.ns = std::min(NS, n_thr - i0);
+        hipError_t e;
+        if constexpr (Q == 4) e = NS == 5 ? launch_pass<4, 5>(a, bw, B, stream) : (NS == 3 ? launch_pass<4, 3>(a, bw, B, stream) : launch_pass<4, 1>(a, bw, B, stream));
+        else e = NS == 8 ? launch_pass<2, 8>(a, bw, B, stream) : (NS == 5 ? launch_pass<2, 5>(a, bw, B, stream) : (NS == 3 ? launch_pass<2, 3>(a, bw, B, stream) : launch_pass<2, 1>(a, bw, B, stream)));
+        if (e != hipSuccess) return e;
+    }
+    *n_out = n;
+    return hipSuccess;
+}
+}  // namespace
+
+hipError_t launch_sys64(const GenericArgs<double> &ga, const double *W_host, int B, void *gs, void *gamp, hipStream_t stream, int *launches,
+                        hipEvent_t ev0, hipEvent_t ev1) {
+    if (B <= 0 || ga.n_thr <= 0) return hipSuccess;
+    const int F = ga.F, T = ga.T, Q = ga.Q, Tp = T + 2 * (Q - 1);
+    const Geom g = geom(F, T, Q);
+    const int NS = slots_for(Q, g.R);
+    if (NS < 1 || ga.mode != MODE_BATCH || ga.L != SL) return hipErrorInvalidValue;
+    double2 *G = static_cast<double2 *>(gs);
+    double *A = static_cast<double *>(gamp);
+    const long g_stride = g.rows * NLN;
+    hipError_t e;
+    // rows no frame owns are read by lanes whose results are discarded; they must still be numbers the first time
+    if ((e = hipMemsetAsync(G, 0, (size_t)B * g_stride * sizeof(double2), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(A, 0, (size_t)B * g_stride * sizeof(double), stream)) != hipSuccess) return e;
+    k_s64_load<<<dim3(Tp, B), 256, 0, stream>>>(ga.state, ga.amp, G, A, F, Tp, g.P, g_stride);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    S64Args a;
+    a.G = G; a.A = A; a.thr = ga.thr; a.g_stride = g_stride;
+    a.n_thr = ga.n_thr; a.thr0 = 0; a.ns = 0;
+    a.F = F; a.T = T; a.P = g.P; a.gap = g.gap; a.LAG = g.LAG; a.R = g.R; a.nblk = g.nblk; a.U = g.U;
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    int n = 0;
+    e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, ga.n_thr, B, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, ga.n_thr, B, stream, &n);
+    if (e != hipSuccess) return e;
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    k_s64_store<<<dim3(Tp, B), 256, 0, stream>>>(ga.state, G, F, Tp, g.P, g_stride);
+    if (launches) *launches = n;
+    return hipGetLastError();
+}
+
+}  // namespace lws

@@ -74,7 +74,7 @@ def run_pass(G, A, Wm, thr, F, T, Q, ns, stats):
     nblk = -(-Tp // NL)
     U = SK * (NL - 1) + P * nblk
     lane = np.arange(NL)
-    X = [np.full((U + 2 * MARG, NL), np.nan + 0j) for _ in range(ns)]     # slot outputs by frame-time row
+    X = [np.zeros((U + 2 * MARG, NL), complex) for _ in range(ns)]        # slot outputs by frame-time row (LDS rings start as zeros)
     Xtime = [np.full(U + 2 * MARG, -10 ** 9) for _ in range(ns)]         # time a row was written (ring-age checks)
     acc = [np.zeros((2 * L + 1, NL), complex) for _ in range(ns)]
     cn = [np.zeros((L + 1, NL), complex) for _ in range(ns)]
@@ -128,8 +128,9 @@ def run_pass(G, A, Wm, thr, F, T, Q, ns, stats):
                 Lv = rd(X[s], rowsL, (lane - r) % NL)
                 Rv = rd(prev, rowsR, (lane + r) % NL)
                 age_own(rowsL, useful); age_prev(rowsR, useful)
-                sx = np.where(pos_ok, Lv.real + Rv.real, 0.0); dy = np.where(pos_ok, Lv.imag - Rv.imag, 0.0)
-                sy = np.where(pos_ok, Lv.imag + Rv.imag, 0.0); dx = np.where(pos_ok, Lv.real - Rv.real, 0.0)
+                # (no masking: rows that are no position of a frame hold zeros)
+                sx = Lv.real + Rv.real; dy = Lv.imag - Rv.imag
+                sy = Lv.imag + Rv.imag; dx = Lv.real - Rv.real
                 for d in range(2 * L + 1):
                     tgt = (ph - L + d) % Qp
                     if d < L:
@@ -179,10 +180,10 @@ def run_pass(G, A, Wm, thr, F, T, Q, ns, stats):
             for q in (1, 2):
                 if 2 * q <= L:
                     co[s][2 * q] = np.where(act & (j2 == q), np.conj(val), co[s][2 * q])
-            X[s][u + MARG] = val
+            wr = act & (c >= 0) & (c <= F + L - 1)
+            X[s][u + MARG] = np.where(wr, val, 0)
             Xtime[s][u + MARG] = t
             if s == ns - 1:
-                wr = act & (c >= 0) & (c <= F + L - 1)
                 G[u + MARG, wr] = val[wr]
             for k in range(L, 1, -1):
                 cn[s][k] = cn[s][k - 1]
