@@ -9,7 +9,7 @@
 // Design (tools/sys64_model.py is the same schedule in numpy, lane for lane, and was written first):
 //   * one workgroup per spectrogram, one wave per sweep slot, lane = frame: 64 consecutive frames are in flight in a slot,
 //     8 steps apart (> L + 1, and a multiple of Q so that `bin mod Q` -- the weight row -- is the same in every lane);
-//     a lane updates one bin per step and takes up its next frame (64 further on) after P >= F + 3L steps.
+//     a lane updates one bin per step and takes up its next frame (64 further on) after P >= F + L steps.
 //   * a slot's output lives in an LDS ring of R rows x 64 lanes x 16 B, one row per step (row = time mod R): the frames
 //     m-1..m-(Q-1) of the same sweep are the lanes to the left a few rows back, the frames m+1..m+(Q-1) of the previous
 //     sweep are in the ring of the slot before, LAG steps behind.  Slot 0 reads the previous pass from a time-skewed
@@ -42,12 +42,14 @@ struct Geom { int P, gap, LAG, R, nblk, U; long rows; };
 inline Geom geom(int F, int T, int Q) {
     Geom g;
     const int Tp = T + 2 * (Q - 1);
-    g.P = std::max(NLN * SKW, (F + 3 * SL + 7) / 8 * 8);
+    // steps a lane spends on a frame: its F bins, L steps before them (positions arrive L bins ahead); the L images above
+    // Nyquist are written during the first steps of the lane's NEXT frame, which have no bin of their own
+    g.P = std::max(NLN * SKW, (F + SL + 7) / 8 * 8);
     g.gap = g.P - NLN * SKW;
     g.LAG = (SL + SKW * (Q - 1) + g.gap + 2 + 7) / 8 * 8;
     g.R = g.LAG - SL + 1;
     g.nblk = (Tp + NLN - 1) / NLN;
-    g.U = SKW * (NLN - 1) + g.P * g.nblk;
+    g.U = SKW * (NLN - 1) + g.P * g.nblk + 8;   // (+ 8: the images of the last frames)
     g.rows = (long)g.U + 2 * MARG;
     return g;
 }
@@ -151,7 +153,9 @@ template <int Q, bool FIRST> struct Wave {
 #pragma unroll
             for (int r = 0; r < NR; ++r) nxR[r] = ring_prev[slot(tmx, ageR[r]) * NLN + offR[r]];
         }
-        const int jj = wx - L - (a.F - 1);
+        int cx = wx - L;
+        if (cx < 0) cx += a.P;                        // still the images of the frame the lane has just left
+        const int jj = cx - (a.F - 1);
         nxI = ring_own[slot(tmx, (jj >= 1 && jj <= L) ? 2 * jj : 2) * NLN + lane];
     }
     __device__ __forceinline__ void issue_global(int ux, int b) {
@@ -227,6 +231,12 @@ template <int Q, bool FIRST> struct Wave {
 
         const int c = w - L, F = a.F;
         const bool act = w >= 0 && me < NLN * a.nblk;
+        if constexpr (PH == 0) {   // a lane starts a frame with empty sums
+            const bool first = w == 0;
+            double2 z; z.x = 0; z.y = 0;
+#pragma unroll
+            for (int d = 0; d < NA; ++d) acc[d] = sel(first, z, acc[d]);
+        }
         // ---- (a) old value of the frame itself at bin c + L; an image above Nyquist whose source this sweep has already
         //      rewritten is the conjugate of that new value
         {
@@ -268,14 +278,16 @@ template <int Q, bool FIRST> struct Wave {
         val.x = upd ? a0.x * sc : co[0].x;
         val.y = upd ? a0.y * sc : co[0].y;
         // ---- images above Nyquist (lwslib.cpp:365-367): written when the lane passes them, from its own ring
+        bool is_img;
         {
-            const int jj = c - (F - 1);
-            val = sel(act && jj >= 1 && jj <= L, cj(img), val);
+            const int jj = (c < 0 ? c + a.P : c) - (F - 1);
+            is_img = w >= 0 && (c < 0 ? me >= NLN : me < NLN * a.nblk) && jj >= 1 && jj <= L;
+            val = sel(is_img, cj(img), val);
             const int j2 = (F - 1) - c;
             co[2] = sel(act && j2 == 1, cj(val), co[2]);
             co[4] = sel(act && j2 == 2, cj(val), co[4]);
         }
-        const bool is_pos = act && c >= 0 && c <= F + L - 1;
+        const bool is_pos = (act && c >= 0 && c <= F + L - 1) || is_img;
         {
             double2 z; z.x = 0; z.y = 0;
             ring_own[tm * NLN + lane] = sel(is_pos, val, z);
@@ -375,7 +387,7 @@ hipError_t launch_pass(const S64Args &a, const BaseW<Q> &bw, int B, hipStream_t 
 
 int slots_for(int Q, int R) {   // sweep slots per workgroup: what the LDS holds, among the builds that exist
     const int fit = LDS_ROWS / R;
-    if (Q == 4) return fit >= 5 ? 5 : (fit >= 3 ? 3 : (fit >= 1 ? 1 : 0));
+    if (Q == 4) return fit >= 4 ? 4 : (fit >= 3 ? 3 : (fit >= 1 ? 1 : 0));   // (one wave per SIMD: a sweep slot uses > 256 registers)
     if (Q == 2) return fit >= 8 ? 8 : (fit >= 5 ? 5 : (fit >= 3 ? 3 : (fit >= 1 ? 1 : 0)));
     return 0;
 }
@@ -441,7 +453,7 @@ hipError_t run_passes(S64Args a, const double *W, int Qp, int NS, int n_thr, int
         a.thr0 = i0;
         a.ns = std::min(NS, n_thr - i0);
         hipError_t e;
-        if constexpr (Q == 4) e = NS == 5 ? launch_pass<4, 5>(a, bw, B, stream) : (NS == 3 ? launch_pass<4, 3>(a, bw, B, stream) : launch_pass<4, 1>(a, bw, B, stream));
+        if constexpr (Q == 4) e = NS == 4 ? launch_pass<4, 4>(a, bw, B, stream) : (NS == 3 ? launch_pass<4, 3>(a, bw, B, stream) : launch_pass<4, 1>(a, bw, B, stream));
         else e = NS == 8 ? launch_pass<2, 8>(a, bw, B, stream) : (NS == 5 ? launch_pass<2, 5>(a, bw, B, stream) : (NS == 3 ? launch_pass<2, 3>(a, bw, B, stream) : launch_pass<2, 1>(a, bw, B, stream)));
         if (e != hipSuccess) return e;
     }

@@ -21,9 +21,9 @@ MARG = 64
 
 
 def geometry(F, Q):
-    P = max(NL * SK, -(-(F + 3 * L) // 8) * 8)
+    P = max(NL * SK, -(-(F + L) // 8) * 8)      # a frame's last images are written during the first steps of the lane's next frame
     gap = P - NL * SK
-    LAG = L + SK * (Q - 1) + gap + 2
+    LAG = -(-(L + SK * (Q - 1) + gap + 2) // 8) * 8
     R = LAG - L + 1
     return P, gap, LAG, R
 
@@ -32,7 +32,7 @@ def to_skew(ext, F, Q):
     Tp = ext.shape[0]
     P, gap, LAG, R = geometry(F, Q)
     nblk = -(-Tp // NL)
-    U = SK * (NL - 1) + P * nblk
+    U = SK * (NL - 1) + P * nblk + 8
     G = np.zeros((U + 2 * MARG, NL), complex)
     for me in range(Tp):
         j, blk = me % NL, me // NL
@@ -72,7 +72,7 @@ def run_pass(G, A, Wm, thr, F, T, Q, ns, stats):
     Tp = T + 2 * (Q - 1)
     P, gap, LAG, R = geometry(F, Q)
     nblk = -(-Tp // NL)
-    U = SK * (NL - 1) + P * nblk
+    U = SK * (NL - 1) + P * nblk + 8      # (+ 8: the last frame's images)
     lane = np.arange(NL)
     X = [np.zeros((U + 2 * MARG, NL), complex) for _ in range(ns)]        # slot outputs by frame-time row (LDS rings start as zeros)
     Xtime = [np.full(U + 2 * MARG, -10 ** 9) for _ in range(ns)]         # time a row was written (ring-age checks)
@@ -90,13 +90,15 @@ def run_pass(G, A, Wm, thr, F, T, Q, ns, stats):
                 continue
             v = u - SK * lane
             act = (v >= 0) & (v < P * nblk)
-            blk = np.where(act, v // P, 0)
-            w = np.where(act, v % P, 0)
+            blk = np.where(v >= 0, v // P, 0)
+            w = np.where(v >= 0, v % P, 0)
             me = NL * blk + lane
             c = w - L
             ph = u % 8
             assert np.all((w[act] % 8) == ph)
             pos_ok = act & (w <= F + L - 1)
+            for d in range(2 * L + 1):              # a lane starts its next frame with empty sums
+                acc[s][d] = np.where(act & (w == 0), 0, acc[s][d])
             prev = G if s == 0 else X[s - 1]
 
             def age_prev(rows, sel):
@@ -170,8 +172,8 @@ def run_pass(G, A, Wm, thr, F, T, Q, ns, stats):
                 vnew = (a.real * amp / mag) + 1j * (a.imag * amp / mag)
             val = np.where(upd, vnew, co[s][0])
             # images above Nyquist are written when the lane passes them
-            jj = c - (F - 1)
-            img = act & (jj >= 1) & (jj <= L)
+            jj = np.where(c < 0, c + P, c) - (F - 1)      # (c < 0: still the images of the frame the lane has just left)
+            img = (v >= 0) & np.where(c < 0, me >= NL, act) & (jj >= 1) & (jj <= L)
             rowsI = u - 2 * np.where(img, jj, 0)
             age_own(rowsI, img & (me >= Q - 1) & (me < T + Q - 1))
             val = np.where(img, np.conj(rd(X[s], rowsI, lane)), val)
@@ -180,7 +182,7 @@ def run_pass(G, A, Wm, thr, F, T, Q, ns, stats):
             for q in (1, 2):
                 if 2 * q <= L:
                     co[s][2 * q] = np.where(act & (j2 == q), np.conj(val), co[s][2 * q])
-            wr = act & (c >= 0) & (c <= F + L - 1)
+            wr = (act & (c >= 0) & (c <= F + L - 1)) | img
             X[s][u + MARG] = np.where(wr, val, 0)
             Xtime[s][u + MARG] = t
             if s == ns - 1:
@@ -218,7 +220,7 @@ if __name__ == "__main__":
     from oracle.oracle import Oracle
     orc = Oracle()
     rng = np.random.default_rng(1)
-    for (fs, hop, T, F, it) in [(64, 16, 9, 33, 4), (64, 16, 70, 33, 5), (64, 32, 67, 33, 4), (1024, 256, 12, 513, 4)]:
+    for (fs, hop, T, F, it) in [(64, 16, 9, 33, 4), (64, 16, 70, 33, 5), (64, 32, 67, 33, 4), (1024, 256, 12, 513, 4), (1024, 256, 70, 513, 4), (1012, 253, 66, 507, 3), (1020, 255, 66, 511, 3)]:
         p = lws_amd.lws(fs, hop, batch_iterations=it, batch_alpha=1.0)
         S = rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))
         thr = lws_amd.get_thresholds(it, 1.0, 0.1, 1)
