@@ -36,7 +36,8 @@ constexpr int NLN = 64;      // lanes = frames in flight per slot
 constexpr int SKW = 8;       // steps between consecutive frames
 constexpr int MARG = 96;     // rows before / after the skewed state that prefetches may touch
 constexpr int PFD = 4;       // steps a global load is issued ahead of its use
-constexpr int LDS_ROWS = 160;   // ring rows of 1 KB that fit the LDS
+constexpr int LDS_ROWS = 160;
+constexpr uint64_t MASK_Q4 = 0xfd7fc3, MASK_Q2 = 0x5c3, MASK_ALL = ~0ull;   // non-zero weights of the default (sqrt-Hann) windows   // ring rows of 1 KB that fit the LDS
 
 struct Geom { int P, gap, LAG, R, nblk, U; long rows; };
 inline Geom geom(int F, int T, int Q) {
@@ -93,7 +94,9 @@ __device__ __forceinline__ double2 sel(bool c, double2 a, double2 b) { double2 r
 // LDS writes of this step complete, then everybody meets.  (Not __syncthreads(): that waits for the global prefetches too.)
 #define S64_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <int Q, bool FIRST> struct Wave {
+// MASK: bit r (L + 1) + k set if W[0][r][k] may be non-zero -- the taps of the other weights are not compiled in (the reference
+// skips them at run time, lwslib.cpp:302,321).  Default windows: 0xfd7fc3 (Q = 4), 0x5c3 (Q = 2); anything else runs on MASK = ~0.
+template <int Q, bool FIRST, uint64_t MASK> struct Wave {
     static constexpr int L = SL, NR = Q - 1, NA = 2 * SL + 1;
     // lane state
     double2 acc[NA];          // sums of bins c .. c + 2L
@@ -177,7 +180,8 @@ template <int Q, bool FIRST> struct Wave {
     template <int PH, int RR, int D> __device__ __forceinline__ void scatter(double sx, double dy, double sy, double dx) {
         if constexpr (D < NA) {
             constexpr int K = D < L ? L - D : D - L;
-            sc_add<quarter_turns<Q>(PH - L + D, RR), (D < L)>(acc[D], bw.n[RR - 1][K], sx, dy, sy, dx);
+            if constexpr ((MASK >> (RR * (L + 1) + K)) & 1)
+                sc_add<quarter_turns<Q>(PH - L + D, RR), (D < L)>(acc[D], bw.n[RR - 1][K], sx, dy, sy, dx);
             scatter<PH, RR, D + 1>(sx, dy, sy, dx);
         }
     }
@@ -185,7 +189,8 @@ template <int Q, bool FIRST> struct Wave {
     template <int PH, int RR, int CT> __device__ __forceinline__ void images(double sx, double dy, double sy, double dx) {
         if constexpr (CT <= L - PH) {
             constexpr int D = CT + L - PH, K = CT + PH;
-            sc_add<quarter_turns<Q>(CT, RR), false>(acc[D], bw.n[RR - 1][K], sx, -dy, -sy, dx);
+            if constexpr ((MASK >> (RR * (L + 1) + K)) & 1)
+                sc_add<quarter_turns<Q>(CT, RR), false>(acc[D], bw.n[RR - 1][K], sx, -dy, -sy, dx);
             images<PH, RR, CT + 1>(sx, dy, sy, dx);
         }
     }
@@ -255,6 +260,7 @@ template <int Q, bool FIRST> struct Wave {
         constexpr int CC = ((PH - L) % 8 + 8) % 8;   // the bin below L a lane can be at in this phase
 #pragma unroll
         for (int k = L; k >= 1; --k) {
+            if (!((MASK >> k) & 1)) continue;
             double2 b = cn[k];
             if constexpr (CC < L) {
                 if (k > CC) {
@@ -287,12 +293,10 @@ template <int Q, bool FIRST> struct Wave {
             co[2] = sel(act && j2 == 1, cj(val), co[2]);
             co[4] = sel(act && j2 == 2, cj(val), co[4]);
         }
-        const bool is_pos = (act && c >= 0 && c <= F + L - 1) || is_img;
-        {
-            double2 z; z.x = 0; z.y = 0;
-            ring_own[tm * NLN + lane] = sel(is_pos, val, z);
-        }
-        if (last && is_pos) G[(size_t)(u + MARG) * NLN + lane] = val;
+        // (no position of a frame here -- before its bin 0, past its last image, before the first / after the last frame: val is
+        //  the old value of such a row, which is zero, so zero is what gets written and the invariant of `neighbours` holds)
+        ring_own[tm * NLN + lane] = val;
+        if (last) G[(size_t)(u + MARG) * NLN + lane] = val;
         // ---- windows move on by one bin
 #pragma unroll
         for (int k = L; k >= 2; --k) cn[k] = cn[k - 1];
@@ -306,9 +310,9 @@ template <int Q, bool FIRST> struct Wave {
     }
 };
 
-template <int Q, bool FIRST>
+template <int Q, bool FIRST, uint64_t MASK>
 __device__ __forceinline__ void s64_wave(const S64Args &a, const BaseW<Q> &bw, double2 *ring, double2 *G, const double *A, int s, int lane) {
-    Wave<Q, FIRST> wv(a, bw, ring, G, A, s, lane);
+    Wave<Q, FIRST, MASK> wv(a, bw, ring, G, A, s, lane);
     const bool live = s < a.ns;
     const int t_end = a.U + a.LAG * (a.ns - 1);   // U and LAG are multiples of 8
     for (int t0 = 0; t0 < t_end; t0 += 8) {
@@ -330,7 +334,7 @@ __device__ __forceinline__ void s64_wave(const S64Args &a, const BaseW<Q> &bw, d
     }
 }
 
-template <int Q, int NS>
+template <int Q, int NS, uint64_t MASK>
 __global__ void __launch_bounds__(NLN * NS) k_sys64(S64Args a, BaseW<Q> bw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s64_lds[];
     double2 *ring = reinterpret_cast<double2 *>(s64_lds);
@@ -343,8 +347,8 @@ __global__ void __launch_bounds__(NLN * NS) k_sys64(S64Args a, BaseW<Q> bw) {
         for (int i = threadIdx.x; i < NS * a.R * NLN; i += NLN * NS) ring[i] = z;
         __syncthreads();
     }
-    if (s == 0) s64_wave<Q, true>(a, bw, ring, G, A, s, lane);
-    else s64_wave<Q, false>(a, bw, ring, G, A, s, lane);
+    if (s == 0) s64_wave<Q, true, MASK>(a, bw, ring, G, A, s, lane);
+    else s64_wave<Q, false, MASK>(a, bw, ring, G, A, s, lane);
 }
 
 // extended buffers [B][Tp][Np] <-> the skewed layout
@@ -371,17 +375,17 @@ __global__ void k_s64_store(double2 *state, const double2 *G, int F, int Tp, int
     }
 }
 
-template <int Q, int NS>
+template <int Q, int NS, uint64_t MASK>
 hipError_t launch_pass(const S64Args &a, const BaseW<Q> &bw, int B, hipStream_t stream) {
     static std::atomic<unsigned long long> done{0};
     const size_t lds = (size_t)NS * a.R * NLN * sizeof(double2);
     int dev = 0;
     if (attr_needed(done, &dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sys64<Q, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sys64<Q, NS, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done(done, dev);
     }
-    k_sys64<Q, NS><<<dim3(B), dim3(NLN * NS), lds, stream>>>(a, bw);
+    k_sys64<Q, NS, MASK><<<dim3(B), dim3(NLN * NS), lds, stream>>>(a, bw);
     return hipGetLastError();
 }
 
@@ -448,13 +452,24 @@ template <int Q>
 hipError_t run_passes(S64Args a, const double *W, int Qp, int NS, int n_thr, int B, hipStream_t stream, int *n_out) {
     BaseW<Q> bw;
     if (!base_weights<Q>(W, Qp, &bw)) return hipErrorInvalidValue;
+    // the build without the taps that the default windows' weights do not have, if this tensor has none of them either
+    uint64_t mask = 0;
+    for (int k = 1; k <= SL; ++k) mask |= (uint64_t)(bw.c[k - 1].x != 0 || bw.c[k - 1].y != 0) << k;
+    for (int r = 1; r < Q; ++r)
+        for (int k = 0; k <= SL; ++k) mask |= (uint64_t)(bw.n[r - 1][k].x != 0 || bw.n[r - 1][k].y != 0) << (r * (SL + 1) + k);
+    const bool dflt = (mask & ~(Q == 4 ? MASK_Q4 : MASK_Q2)) == 0;
     int n = 0;
     for (int i0 = 0; i0 < n_thr; i0 += NS, ++n) {
         a.thr0 = i0;
         a.ns = std::min(NS, n_thr - i0);
         hipError_t e;
-        if constexpr (Q == 4) e = NS == 4 ? launch_pass<4, 4>(a, bw, B, stream) : (NS == 3 ? launch_pass<4, 3>(a, bw, B, stream) : launch_pass<4, 1>(a, bw, B, stream));
-        else e = NS == 8 ? launch_pass<2, 8>(a, bw, B, stream) : (NS == 5 ? launch_pass<2, 5>(a, bw, B, stream) : (NS == 3 ? launch_pass<2, 3>(a, bw, B, stream) : launch_pass<2, 1>(a, bw, B, stream)));
+        if constexpr (Q == 4) {
+            if (dflt) e = NS == 4 ? launch_pass<4, 4, MASK_Q4>(a, bw, B, stream) : (NS == 3 ? launch_pass<4, 3, MASK_Q4>(a, bw, B, stream) : launch_pass<4, 1, MASK_Q4>(a, bw, B, stream));
+            else e = NS == 4 ? launch_pass<4, 4, MASK_ALL>(a, bw, B, stream) : (NS == 3 ? launch_pass<4, 3, MASK_ALL>(a, bw, B, stream) : launch_pass<4, 1, MASK_ALL>(a, bw, B, stream));
+        } else {
+            if (dflt) e = NS == 8 ? launch_pass<2, 8, MASK_Q2>(a, bw, B, stream) : (NS == 5 ? launch_pass<2, 5, MASK_Q2>(a, bw, B, stream) : (NS == 3 ? launch_pass<2, 3, MASK_Q2>(a, bw, B, stream) : launch_pass<2, 1, MASK_Q2>(a, bw, B, stream)));
+            else e = NS == 8 ? launch_pass<2, 8, MASK_ALL>(a, bw, B, stream) : (NS == 5 ? launch_pass<2, 5, MASK_ALL>(a, bw, B, stream) : (NS == 3 ? launch_pass<2, 3, MASK_ALL>(a, bw, B, stream) : launch_pass<2, 1, MASK_ALL>(a, bw, B, stream)));
+        }
         if (e != hipSuccess) return e;
     }
     *n_out = n;
