@@ -92,6 +92,9 @@ __device__ __forceinline__ double2 cj(double2 v) { v.y = -v.y; return v; }
 __device__ __forceinline__ double2 sel(bool c, double2 a, double2 b) { double2 r; r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; return r; }
 
 // LDS writes of this step complete, then everybody meets.  (Not __syncthreads(): that waits for the global prefetches too.)
+// the order of the independent parts of a step is chosen in the source (the bin's dependent chain interleaved with the taps of
+// the bins above); this keeps the scheduler from undoing it
+#define S64_PIN() __builtin_amdgcn_sched_barrier(0)
 #define S64_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // MASK: bit r (L + 1) + k set if W[0][r][k] may be non-zero -- the taps of the other weights are not compiled in (the reference
@@ -105,7 +108,7 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
     double2 nxL[NR], nxR[NR], nxO, nxI;   // inputs of the next step (LDS)
     double2 pfO[PFD], pfR[PFD][NR];       // slot 0: inputs of the next PFD steps (HBM)
     double pfA[PFD];
-    int offL[NR], ageL[NR], offR[NR], ageR[NR], rowR[NR];
+    int offL[NR], ageL[NR], offR[NR], ageR[NR], goffR[NR];
     int w, me, tm;
     // wave constants
     const S64Args &a;
@@ -131,7 +134,7 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
             offR[r - 1] = (lane + r) & (NLN - 1);
             const int wrap = lane + r >= NLN ? a.gap : 0;
             ageR[r - 1] = a.LAG - L - SKW * r - wrap;
-            rowR[r - 1] = L + SKW * r + wrap;
+            goffR[r - 1] = (L + SKW * r + wrap) * NLN + offR[r - 1];
         }
         double2 z; z.x = 0; z.y = 0;
 #pragma unroll
@@ -162,11 +165,13 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         nxI = ring_own[slot(tmx, (jj >= 1 && jj <= L) ? 2 * jj : 2) * NLN + lane];
     }
     __device__ __forceinline__ void issue_global(int ux, int b) {
-        pfA[b] = A[(size_t)(ux + MARG) * NLN + lane];
+        const double *Au = A + (size_t)(ux + MARG) * NLN;       // wave-uniform row pointers, per-lane constant offsets
+        pfA[b] = Au[lane];
         if constexpr (FIRST) {
-            pfO[b] = G[(size_t)(ux + L + MARG) * NLN + lane];
+            const double2 *Gu = G + (size_t)(ux + MARG) * NLN;
+            pfO[b] = Gu[L * NLN + lane];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) pfR[b][r] = G[(size_t)(ux + rowR[r] + MARG) * NLN + offR[r]];
+            for (int r = 0; r < NR; ++r) pfR[b][r] = Gu[goffR[r]];
         }
     }
     __device__ __forceinline__ void prologue() {   // before the step of frame-time 0
@@ -177,12 +182,12 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
 
     // position w of the frames RR apart -> bins c + D .. c + 2L (target bin (PH - L + D) mod Q; weight W[row][RR][|D - L|] for
     // the taps below a bin, conj(W[-row][RR][|D - L|]) = j^(row RR) conj(W[0][RR][..]) for the taps above it)
-    template <int PH, int RR, int D> __device__ __forceinline__ void scatter(double sx, double dy, double sy, double dx) {
-        if constexpr (D < NA) {
+    template <int PH, int RR, int D, int DEND = 2 * SL + 1> __device__ __forceinline__ void scatter(double sx, double dy, double sy, double dx) {
+        if constexpr (D < DEND) {
             constexpr int K = D < L ? L - D : D - L;
             if constexpr ((MASK >> (RR * (L + 1) + K)) & 1)
                 sc_add<quarter_turns<Q>(PH - L + D, RR), (D < L)>(acc[D], bw.n[RR - 1][K], sx, dy, sy, dx);
-            scatter<PH, RR, D + 1>(sx, dy, sy, dx);
+            scatter<PH, RR, D + 1, DEND>(sx, dy, sy, dx);
         }
     }
     // the image below DC of position PH (= w): position -PH, the conjugate, reaches bins CT = 0 .. L - PH with W[CT][RR][CT + PH]
@@ -195,20 +200,30 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         }
     }
     // (b) of a step for the frames RR, RR + 1, .. apart
-    // (rows that are no position of a frame -- before its bin 0, after its last image, before the first and after the last
-    // frame -- hold zeros: in the ring because a lane writes 0 there, in HBM because the layout is cleared first; so a step
-    // that receives no position adds nothing, and the sums of a lane are zero again when it takes up its next frame)
-    template <int PH, int RR> __device__ __forceinline__ void neighbours(const double2 (&Lv)[NR], const double2 (&Rv)[NR]) {
+    // (b) of a step, in two parts.  sd[r] = sum / difference of the two frames r + 1 apart at position w.  (Rows that are no
+    // position of a frame -- before its bin 0, after its last image, before the first and after the last frame -- hold zeros:
+    // in the ring because that is what a lane writes there, in HBM because the layout is cleared first; so a step that
+    // receives no position adds nothing.)
+    struct SD { double sx, dy, sy, dx; };
+    // part 1: what the bin of this step still lacks (target D = 0), and the images below DC
+    template <int PH, int RR> __device__ __forceinline__ void neighbours_now(const SD (&sd)[NR]) {
         if constexpr (RR <= NR) {
-            const double2 lv = Lv[RR - 1], rv = Rv[RR - 1];
-            const double sx = lv.x + rv.x, dy = lv.y - rv.y;
-            const double sy = lv.y + rv.y, dx = lv.x - rv.x;
-            scatter<PH, RR, 0>(sx, dy, sy, dx);
+            const SD t = sd[RR - 1];
+            scatter<PH, RR, 0, 1>(t.sx, t.dy, t.sy, t.dx);
             if constexpr (PH >= 1 && PH <= L) {
-                // images below DC: position -w is the conjugate of position w and reaches bins 0 .. L - w (one lane at most)
-                if (w == PH) images<PH, RR, 0>(sx, dy, sy, dx);
+                // position -w is the conjugate of position w and reaches bins 0 .. L - w (one lane at most)
+                if (w == PH) images<PH, RR, 0>(t.sx, t.dy, t.sy, t.dx);
             }
-            neighbours<PH, RR + 1>(Lv, Rv);
+            neighbours_now<PH, RR + 1>(sd);
+        }
+    }
+    // part 2: the bins above (targets 1 .. 2L) -- independent of this step's re-projection, which is one long dependent chain;
+    // the caller places these between the links of that chain
+    template <int PH, int RR, int REND> __device__ __forceinline__ void neighbours_later(const SD (&sd)[NR]) {
+        if constexpr (RR <= REND && RR <= NR) {
+            const SD t = sd[RR - 1];
+            scatter<PH, RR, 1>(t.sx, t.dy, t.sy, t.dx);
+            neighbours_later<PH, RR + 1, REND>(sd);
         }
     }
 
@@ -253,7 +268,13 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
             co[L] = o;
         }
         // ---- (b) neighbour frames: position w of frames me -+ r reaches bins c .. c + 2L
-        neighbours<PH, 1>(Lv, Rv);
+        SD sd[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            sd[r].sx = Lv[r].x + Rv[r].x; sd[r].dy = Lv[r].y - Rv[r].y;
+            sd[r].sy = Lv[r].y + Rv[r].y; sd[r].dx = Lv[r].x - Rv[r].x;
+        }
+        neighbours_now<PH, 1>(sd);
         // ---- (c) the frame's own taps: new values below (or their images below DC), old values above; k = 1 last (it is
         //      the value the previous step produced)
         double2 a0 = acc[0];
@@ -278,6 +299,9 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         }
         // ---- re-projection on the target magnitude (lwslib.cpp:356-360)
         const double m2 = a0.x * a0.x + a0.y * a0.y;
+        S64_PIN();
+        neighbours_later<PH, 1, 1>(sd);
+        S64_PIN();
         const bool upd = act && c >= 0 && c <= F - 1 && me >= Q - 1 && me < a.T + Q - 1 && amp > thr && m2 > 0.0;
         const double sc = amp * rsqrt(m2);
         double2 val;
@@ -297,6 +321,8 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         //  the old value of such a row, which is zero, so zero is what gets written and the invariant of `neighbours` holds)
         ring_own[tm * NLN + lane] = val;
         if (last) G[(size_t)(u + MARG) * NLN + lane] = val;
+        S64_PIN();
+        neighbours_later<PH, 2, NR>(sd);
         // ---- windows move on by one bin
 #pragma unroll
         for (int k = L; k >= 2; --k) cn[k] = cn[k - 1];
