@@ -191,6 +191,10 @@ def summary_lines(extra):
                 out.append("# host_api: plan.batch(numpy c128 magnitudes) %.1f ms vs device-resident %.1f ms (x%.2f); complex input %s ms; run_lws_music(numpy) %.1f ms"
                            % (b["wall_ms"], b["device_resident_ms"], b["wall_ms"] / b["device_resident_ms"],
                               ("%.1f" % b["complex_input"]["wall_ms"]) if b.get("complex_input") else "n/a", b["run_lws_music"]["wall_ms"]))
+            elif name == "2-fp64":
+                out.append("# 2-fp64: kernel %.1f ms (%s, %d launches), wall %.1f ms; generic engine %.1f ms (x%.1f)"
+                           % (b["systolic"]["kernel_ms"], b["systolic"]["kernel"], b["systolic"]["launches"] or 0, b["systolic"]["wall_ms"],
+                              b["generic"]["kernel_ms"], b["speedup_over_generic"]))
             elif name == "1":
                 out.append("# 1: " + "; ".join("%s %.2f ms (cpu %.1f ms, rel-L2 %.1e)" % (k, v["wall_ms"], v["cpu_reference_ms"], v["checks"]["rel_l2_vs_cpu"])
                                                 for k, v in b.items() if isinstance(v, dict) and "wall_ms" in v))
@@ -503,7 +507,7 @@ def main():
     elif args.extras is not None:
         wanted = [x for x in args.extras.split(",") if x]
     elif world == 1 and args.config == "2":
-        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-q5", "2-f501", "2-f257", "4shard", "3", "3-b1024", "host_api", "1", "5", "5-f16"]
+        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-q5", "2-f501", "2-f257", "2-fp64", "4shard", "3", "3-b1024", "host_api", "1", "5", "5-f16"]
     else:
         wanted = ["4shard"] if args.config == "2" else []
     if args.no_default_schedule and "2-default" in wanted:
@@ -532,6 +536,8 @@ def main():
                 cfgs["host_api"] = run_host_api(torch, lws_amd, dev, local_rank)
             elif name == "1":
                 cfgs["1"] = run_config1(lws_amd, local_rank)
+            elif name == "2-fp64":
+                cfgs["2-fp64"] = run_fp64(torch, lws_amd, dev, local_rank)
             elif name in BATCH_CONFIGS:
                 if BATCH_CONFIGS[name]["storage"] == "fp16" and not have_f16:
                     cfgs[name] = {"skipped": "this build has no fp16 storage mode"}
@@ -714,6 +720,38 @@ def run_host_api(torch, lws_amd, dev, local_rank, B=256, T=500, iters=100):
             "pinned_copy_GBs": {"h2d": rates[0], "d2h": rates[1]}, "bytes_over_the_bus_each_way": bytes_c64,
             "transfer_ms_each_way_at_pinned_rate": xfer_ms, "wall_over_max_transfer_kernel": min(walls[1:]) / max(xfer_ms, dev_ms),
             "checks": batch_checks}
+
+
+def run_fp64(torch, lws_amd, dev, local_rank, B=256, T=500, iters=100):
+    """BASELINE config 2's volume in the reference's own arithmetic type (lwslib.h:6-26 is double throughout): an fp64 plan on
+    device-resident complex128 spectrograms.  Its batch sweeps run on the fp64 systolic engine (lws_sys64.hip); the order-exact
+    generic engine (LWS_FORCE_GENERIC) is timed beside it."""
+    from lws_amd import _capi
+    F = 513
+    p = lws_amd.lws(1024, 256, device=local_rank)
+    M = synth_magnitudes(B, T, F, 20260928).astype(np.complex128)
+    thr = np.zeros(iters)
+    n = float(B) * T * F * iters
+    out = {"workload": "%d spectrograms x %d frames x %d bins, lws(1024,256), %d dense batch-LWS sweeps, fp64, complex128 resident in HBM" % (B, T, F, iters),
+           "algorithmic_bytes_per_bin_sweep": 40}
+    for key, generic in (("systolic", False), ("generic", True)):
+        plan = _capi.Plan(F, p.W, precision="fp64", force_generic=generic, device=local_rank)
+        d = torch.from_numpy(M).to(dev)
+        ms, wall = [], []
+        for rep in range(3 if not generic else 2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            plan.batch_dev(d.data_ptr(), B, T, thr); torch.cuda.synchronize()
+            wall.append(1e3 * (time.perf_counter() - t0)); ms.append(plan.last_kernel()["ms"])
+        k = plan.last_kernel()
+        res = d.cpu().numpy() if not generic else None
+        out[key] = {"kernel": k["name"], "kernel_ms": min(ms[1:]), "wall_ms": min(wall[1:]), "launches": k.get("launches"),
+                    "value": n / (min(wall[1:]) * 1e-3), "algorithmic_GBs": 40.0 * n / (min(ms[1:]) * 1e-3) / 1e9}
+        if res is not None:
+            out[key]["checks"] = {"max_rel_magnitude_error": float(np.abs(np.abs(res) - np.abs(M)).max() / np.abs(M).max()), "finite": bool(np.isfinite(res).all())}
+        plan.close()
+        del d
+    out["speedup_over_generic"] = out["generic"]["kernel_ms"] / out["systolic"]["kernel_ms"]
+    return out
 
 
 def run_config1(lws_amd, local_rank):

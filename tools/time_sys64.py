@@ -28,6 +28,8 @@ def t(fsize, fshift, B, T, iters, generic=False):
 
 if __name__ == "__main__":
     t(1024, 256, 256, 500, 100)
+    if "--one" in sys.argv:
+        sys.exit(0)
     if "--generic" in sys.argv:
         t(1024, 256, 256, 500, 100, generic=True)
     t(512, 128, 256, 500, 100)
