@@ -35,7 +35,7 @@ constexpr int SL = 5;        // stencil half-width in bins
 constexpr int NLN = 64;      // lanes = frames in flight per slot
 constexpr int SKW = 8;       // steps between consecutive frames
 constexpr int MARG = 96;     // rows before / after the skewed state that prefetches may touch
-constexpr int PFD = 4;       // steps a global load is issued ahead of its use
+constexpr int PFD = 4;       // steps a global load is issued ahead of its use (2: no faster)
 constexpr int LDS_ROWS = 160;
 constexpr uint64_t MASK_Q4 = 0xfd7fc3, MASK_Q2 = 0x5c3, MASK_ALL = ~0ull;   // non-zero weights of the default (sqrt-Hann) windows   // ring rows of 1 KB that fit the LDS
 
@@ -310,8 +310,11 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         // ---- images above Nyquist (lwslib.cpp:365-367): written when the lane passes them, from its own ring
         bool is_img;
         {
-            const int jj = (c < 0 ? c + a.P : c) - (F - 1);
-            is_img = w >= 0 && (c < 0 ? me >= NLN : me < NLN * a.nblk) && jj >= 1 && jj <= L;
+            // (bitwise on purpose: as && / ?: this became three branches in the middle of the step)
+            const bool before = c < 0;                                     // still the frame the lane has just left
+            const int jj = (before ? c + a.P : c) - (F - 1);
+            const bool has_frame = (before & (me >= NLN)) | (!before & (me < NLN * a.nblk));
+            is_img = (w >= 0) & has_frame & ((unsigned)(jj - 1) < (unsigned)L);
             val = sel(is_img, cj(img), val);
             const int j2 = (F - 1) - c;
             co[2] = sel(act && j2 == 1, cj(val), co[2]);
