@@ -211,8 +211,10 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
             const SD t = sd[RR - 1];
             scatter<PH, RR, 0, 1>(t.sx, t.dy, t.sy, t.dx);
             if constexpr (PH >= 1 && PH <= L) {
-                // position -w is the conjugate of position w and reaches bins 0 .. L - w (one lane at most)
-                if (w == PH) images<PH, RR, 0>(t.sx, t.dy, t.sy, t.dx);
+                // position -w is the conjugate of position w and reaches bins 0 .. L - w (one lane at most; the others add
+                // zeros -- a branch around these few FMAs costs a wave that is alone on its SIMD more than they do)
+                const bool z = w == PH;
+                images<PH, RR, 0>(z ? t.sx : 0.0, z ? t.dy : 0.0, z ? t.sy : 0.0, z ? t.dx : 0.0);
             }
             neighbours_now<PH, RR + 1>(sd);
         }
@@ -323,7 +325,8 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         // (no position of a frame here -- before its bin 0, past its last image, before the first / after the last frame: val is
         //  the old value of such a row, which is zero, so zero is what gets written and the invariant of `neighbours` holds)
         ring_own[tm * NLN + lane] = val;
-        if (last) G[(size_t)(u + MARG) * NLN + lane] = val;
+        // (every slot stores: the last one the row of the state, the others a row of the margin nobody reads -- no branch)
+        G[(size_t)(last ? u + MARG : s) * NLN + lane] = val;
         S64_PIN();
         neighbours_later<PH, 2, NR>(sd);
         // ---- windows move on by one bin
