@@ -100,3 +100,13 @@ def test_unsupported_shapes_fall_back():
         p = lws_amd.lws(fsize, fshift, batch_iterations=2, precision="fp64")
         p.batch_lws(_spec(rng, 6, fsize // 2 + 1))
         assert p.plan().last_kernel()["name"].startswith("generic"), (fsize, fshift)
+
+
+def test_random_shapes_against_the_oracle():
+    """tools/stress_sys64.py: frame sizes around the period / ring-size boundaries, frame counts around multiples of 64, sweep counts
+    that are no multiple of the slots per pass, thresholds that skip bins -- 60 cases, each <= 1e-10 of the largest value."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_sys64.py"), "60", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "worst" in r.stdout
