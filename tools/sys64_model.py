@@ -197,7 +197,136 @@ def run_pass(G, A, Wm, thr, F, T, Q, ns, stats):
             acc[s][2 * L] = 0
 
 
-def batch_lws_model(S, W, thresholds, NS=3):
+def run_continuous(G, A, Wm, thr, F, T, Q, NS, stats):
+    """ALL sweeps in one go: slot s takes sweeps s, s + NS, s + 2 NS, .. one after the other without draining -- a lane starts frame
+    j of its next sweep the step after it finished its last frame, so the 8 x 63 steps in which the lanes of a pass start and stop
+    one after the other are paid once, not once per NS sweeps.  Slot 0 reads what slot NS - 1 wrote to the skewed state during
+    the sweep before (P x blocks - LAG (NS - 1) steps earlier); rings are addressed by global time as before."""
+    n = len(thr)
+    Qp = Wm.shape[0]
+    Tp = T + 2 * (Q - 1)
+    P, gap, LAG, R = geometry(F, Q)
+    nblk = -(-Tp // NL)
+    PS = P * nblk                                   # steps a lane spends on a sweep
+    lane = np.arange(NL)
+    Kmax = -(-n // NS)
+    t_end = LAG * (NS - 1) + SK * (NL - 1) + Kmax * PS + 8
+    assert PS > SK * (Q - 1) + gap + L + LAG * (NS - 1) + 8
+    X = [np.zeros((t_end + 2 * MARG, NL), complex) for _ in range(NS)]      # slot outputs by GLOBAL time
+    acc = [np.zeros((2 * L + 1, NL), complex) for _ in range(NS)]
+    cn = [np.zeros((L + 1, NL), complex) for _ in range(NS)]
+    co = [np.zeros((L + 1, NL), complex) for _ in range(NS)]
+    thr = np.asarray(thr, float)
+
+    def rdt(arr, times, lanes):                     # ring read by global time (negative times: the ring's initial zeros)
+        return arr[times + MARG, lanes]
+
+    for t in range(t_end):
+        for s in range(NS):
+            Ks = len(range(s, n, NS))               # sweeps of this slot
+            v = t - LAG * s - SK * lane             # lane time
+            started = v >= 0
+            k = np.where(started, v // PS, 0)
+            vv = np.where(started, v % PS, 0)
+            blk = vv // P
+            w = vv % P
+            act = started & (k < Ks)
+            me = NL * blk + lane
+            c = w - L
+            g = s + k * NS                          # the sweep a lane is in
+            thr_l = thr[np.minimum(g, n - 1)]
+            ph = (t - LAG * s) % 8
+            assert np.all((w[started] % 8) == ph)
+            for d in range(2 * L + 1):
+                acc[s][d] = np.where(started & (w == 0), 0, acc[s][d])
+            row = SK * lane + P * blk + w           # row of (me, c) in the skewed state, minus L
+            # (a) own old value at position w
+            if s == 0:
+                O = G[row + L + MARG, lane]
+            else:
+                O = rdt(X[s - 1], t - (LAG - L) + 0 * lane, lane)
+                stats['prev_max'] = max(stats['prev_max'], LAG - L)
+            kk = 2 * c + L - 2 * (F - 1)
+            newimg = (kk >= 1) & (kk <= L)
+            for q in range(1, L + 1):
+                O = np.where(newimg & (kk == q), np.conj(cn[s][q]), O)
+            co[s][L] = O
+            # (b) neighbours
+            for r in range(1, Q):
+                wrapL = np.where(lane < r, gap, 0)
+                wrapR = np.where(lane + r >= NL, gap, 0)
+                Lv = rdt(X[s], t - (SK * r - L) - wrapL, (lane - r) % NL)
+                if s == 0:
+                    Rv = G[row + L + SK * r + wrapR + MARG, (lane + r) % NL]
+                else:
+                    Rv = rdt(X[s - 1], t - (LAG - L - SK * r) + wrapR, (lane + r) % NL)
+                    stats['prev_min'] = min(stats['prev_min'], LAG - L - SK * r - gap)
+                sx = Lv.real + Rv.real; dy = Lv.imag - Rv.imag
+                sy = Lv.imag + Rv.imag; dx = Lv.real - Rv.real
+                for d in range(2 * L + 1):
+                    tgt = (ph - L + d) % Qp
+                    wv = np.conj(Wm[(Qp - tgt) % Qp, r, L - d]) if d < L else Wm[tgt, r, d - L]
+                    ax, ay = pair_sd(acc[s][d].real, acc[s][d].imag, wv.real, wv.imag, sx, dy, sy, dx)
+                    acc[s][d] = ax + 1j * ay
+                if 1 <= ph <= L:
+                    z = started & (w == ph)
+                    for ct in range(0, L - ph + 1):
+                        d = ct + L - ph
+                        wv = Wm[ct % Qp, r, ct + ph]
+                        ax = acc[s][d].real + (wv.real * sx + wv.imag * dy)
+                        ay = acc[s][d].imag + (-wv.real * sy + wv.imag * dx)
+                        acc[s][d] = np.where(z, ax + 1j * ay, acc[s][d])
+            # (c) the frame itself
+            a = acc[s][0].copy()
+            rowc = (ph - L) % Qp
+            for q in range(1, L + 1):
+                b = cn[s][q].copy()
+                for cc in range(0, L):
+                    if q > cc:
+                        qq = q - cc
+                        src = np.conj(cn[s][cc - qq]) if qq < cc else np.conj(co[s][qq - cc])
+                        b = np.where(c == cc, src, b)
+                wv = Wm[rowc, 0, q]
+                cv = co[s][q]
+                ax, ay = pair_sd(a.real, a.imag, wv.real, wv.imag, b.real + cv.real, b.imag - cv.imag, b.imag + cv.imag, b.real - cv.real)
+                a = ax + 1j * ay
+            amp = A[row + MARG, lane]
+            mag = np.sqrt(a.real * a.real + a.imag * a.imag)
+            upd = act & (c >= 0) & (c <= F - 1) & (me >= Q - 1) & (me < T + Q - 1) & (amp > thr_l) & (mag > 0)
+            with np.errstate(all='ignore'):
+                vnew = (a.real * amp / mag) + 1j * (a.imag * amp / mag)
+            val = np.where(upd, vnew, co[s][0])
+            # images above Nyquist: of the current frame, or -- during the first steps of a frame -- of the frame the lane has just
+            # left (the last frame of its previous sweep when this is the first block)
+            before = c < 0
+            had_prev = (blk > 0) | (k > 0)
+            jj = np.where(before, c + P, c) - (F - 1)
+            img = started & np.where(before, had_prev & (k <= Ks), act) & (jj >= 1) & (jj <= L)
+            val = np.where(img, np.conj(rdt(X[s], t - 2 * np.where(img, jj, 0), lane)), val)
+            j2 = (F - 1) - c
+            for q in (1, 2):
+                if 2 * q <= L:
+                    co[s][2 * q] = np.where(act & (j2 == q), np.conj(val), co[s][2 * q])
+            wr = (act & (c >= 0) & (c <= F + L - 1)) | img
+            X[s][t + MARG] = np.where(wr, val, 0)
+            # the state in HBM: written by the last slot of a pass, and by whoever runs the very last sweep
+            g_w = np.where(before, g - NS, g)       # an image of the previous frame belongs to the sweep before at a sweep change
+            g_w = np.where(before & (blk > 0), g, g_w)
+            last = (s == NS - 1) | (g_w == n - 1)
+            roww = np.where(before & (blk == 0), SK * lane + P * nblk + w, row)
+            sel = wr & last
+            G[roww[sel] + MARG, lane[sel]] = val[sel]
+            for q in range(L, 1, -1):
+                cn[s][q] = cn[s][q - 1]
+            cn[s][1] = val
+            for q in range(0, L):
+                co[s][q] = co[s][q + 1]
+            for d in range(2 * L):
+                acc[s][d] = acc[s][d + 1]
+            acc[s][2 * L] = 0
+
+
+def batch_lws_model(S, W, thresholds, NS=3, continuous=False):
     S = np.asarray(S, complex)
     T, F = S.shape
     Qp, Q, _ = W.shape
@@ -209,8 +338,11 @@ def batch_lws_model(S, W, thresholds, NS=3):
     mean = float(np.mean(np.abs(S)))
     thr = [th * mean for th in thresholds]
     stats = dict(prev_min=10 ** 9, prev_max=-1, own_min=10 ** 9, own_max=-1)
-    for i in range(0, len(thr), NS):
-        run_pass(G, A, Wm, thr[i:i + NS], F, T, Q, len(thr[i:i + NS]), stats)
+    if continuous:
+        run_continuous(G, A, Wm, thr, F, T, Q, NS, stats)
+    else:
+        for i in range(0, len(thr), NS):
+            run_pass(G, A, Wm, thr[i:i + NS], F, T, Q, len(thr[i:i + NS]), stats)
     out = from_skew(G, T + 2 * (Q - 1), F, Q)[Q - 1:Q - 1 + T]
     return out, stats
 
@@ -227,5 +359,7 @@ if __name__ == "__main__":
         ref = orc.batch_lws(S, p.W, thr)
         out, st = batch_lws_model(S, p.W, thr)
         err = np.abs(out - ref).max() / np.abs(ref).max()
+        outc, _ = batch_lws_model(S, p.W, thr, NS=3, continuous=True)
+        print("   continuous: max rel err %.2e" % (np.abs(outc - ref).max() / np.abs(ref).max()))
         print("lws(%d,%d) T=%d F=%d iters=%d Q=%d: max rel err %.2e  ages %s  geometry(P,gap,LAG,R)=%s"
               % (fs, hop, T, F, it, p.W.shape[1], err, st, geometry(F, p.W.shape[1])))
