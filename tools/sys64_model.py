@@ -301,7 +301,7 @@ def run_continuous(G, A, Wm, thr, F, T, Q, NS, stats):
             before = c < 0
             had_prev = (blk > 0) | (k > 0)
             jj = np.where(before, c + P, c) - (F - 1)
-            img = started & np.where(before, had_prev & (k <= Ks), act) & (jj >= 1) & (jj <= L)
+            img = started & np.where(before, had_prev & ((k < Ks) | ((k == Ks) & (blk == 0))), act) & (jj >= 1) & (jj <= L)
             val = np.where(img, np.conj(rdt(X[s], t - 2 * np.where(img, jj, 0), lane)), val)
             j2 = (F - 1) - c
             for q in (1, 2):
@@ -344,6 +344,12 @@ def batch_lws_model(S, W, thresholds, NS=3, continuous=False):
         for i in range(0, len(thr), NS):
             run_pass(G, A, Wm, thr[i:i + NS], F, T, Q, len(thr[i:i + NS]), stats)
     out = from_skew(G, T + 2 * (Q - 1), F, Q)[Q - 1:Q - 1 + T]
+    # the images above Nyquist in the skewed state are those of the final values (they go back into the extended buffers)
+    P = geometry(F, Q)[0]
+    for me in range(Q - 1, T + Q - 1):
+        j, blk = me % NL, me // NL
+        base = SK * j + P * blk + L + MARG
+        assert np.array_equal(G[base + F:base + F + L, j], np.conj(G[base + F - 2:base + F - 2 - L:-1, j])), me
     return out, stats
 
 
