@@ -39,9 +39,13 @@ constexpr int PFD = 4;       // steps a global load is issued ahead of its use (
 constexpr int LDS_ROWS = 160;
 constexpr uint64_t MASK_Q4 = 0xfd7fc3, MASK_Q2 = 0x5c3, MASK_ALL = ~0ull;   // non-zero weights of the default (sqrt-Hann) windows   // ring rows of 1 KB that fit the LDS
 
-struct Geom { int P, gap, LAG, R, nblk, U; long rows; };
-inline Geom geom(int F, int T, int Q) {
+struct Geom { int P, gap, LAG, R, nblk, U, nls; long rows; };
+// nls: lanes (= frames in flight) per spectrogram -- 64, or 32 with two spectrograms side by side in a wave (short frames: a lane
+// period of 64 x 8 steps would be half empty)
+inline Geom geom(int F, int T, int Q, int nls) {
     Geom g;
+    g.nls = nls;
+    const int NLN = nls;   // (shadows the wave width in the formulas below)
     const int Tp = T + 2 * (Q - 1);
     // steps a lane spends on a frame: its F bins, L steps before them (positions arrive L bins ahead); the L images above
     // Nyquist are written during the first steps of the lane's NEXT frame, which have no bin of their own
@@ -62,6 +66,7 @@ struct S64Args {
     long g_stride;         // rows * 64
     int n_thr, thr0, ns;   // this pass: sweeps thr0 .. thr0 + ns - 1
     int F, T, P, gap, LAG, R, nblk, U;
+    int nls, B;            // lanes per spectrogram (64 / 32: one / two spectrograms per workgroup), spectrograms of the call
 };
 
 // The weights of row 0, W[0][r][k] (entries the reference skips -- |w| <= 1e-12, lws.pyx:227-232 -- are zero here).  The other
@@ -118,21 +123,27 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
     double2 *G;
     const double *A;
     int lane, s;
-    double thr;
-    bool last;
+    double thrA, thrB;        // thresholds of the workgroup's first / second spectrogram
+    bool last, hi;            // hi: this lane works on the second one
 
     __device__ __forceinline__ Wave(const S64Args &a_, const BaseW<Q> &bw_, double2 *ring, double2 *G_, const double *A_, int s_, int lane_)
         : a(a_), bw(bw_), G(G_), A(A_), lane(lane_), s(s_) {
         ring_own = ring + (size_t)s * a.R * NLN;
         ring_prev = ring + (size_t)(s > 0 ? s - 1 : 0) * a.R * NLN;
         last = s == a.ns - 1;
-        thr = a.thr[(size_t)blockIdx.x * a.n_thr + a.thr0 + (s < a.ns ? s : 0)];
+        const int ls = lane & (a.nls - 1), hb = lane - ls, spw = NLN / a.nls;
+        hi = hb != 0;
+        {
+            const int b0 = blockIdx.x * spw, b1 = b0 + spw - 1 < a.B ? b0 + spw - 1 : a.B - 1, ts = a.thr0 + (s < a.ns ? s : 0);
+            thrA = a.thr[(size_t)b0 * a.n_thr + ts];
+            thrB = a.thr[(size_t)b1 * a.n_thr + ts];
+        }
 #pragma unroll
         for (int r = 1; r <= NR; ++r) {
-            offL[r - 1] = (lane - r) & (NLN - 1);
-            ageL[r - 1] = SKW * r - L + (lane < r ? a.gap : 0);
-            offR[r - 1] = (lane + r) & (NLN - 1);
-            const int wrap = lane + r >= NLN ? a.gap : 0;
+            offL[r - 1] = hb + ((ls - r) & (a.nls - 1));
+            ageL[r - 1] = SKW * r - L + (ls < r ? a.gap : 0);
+            offR[r - 1] = hb + ((ls + r) & (a.nls - 1));
+            const int wrap = ls + r >= a.nls ? a.gap : 0;
             ageR[r - 1] = a.LAG - L - SKW * r - wrap;
             goffR[r - 1] = (L + SKW * r + wrap) * NLN + offR[r - 1];
         }
@@ -141,8 +152,8 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         for (int d = 0; d < NA; ++d) acc[d] = z;
 #pragma unroll
         for (int k = 0; k <= L; ++k) { cn[k] = z; co[k] = z; }
-        w = -SKW * lane;
-        me = lane;
+        w = -SKW * ls;
+        me = ls;
         tm = (a.LAG * s) % a.R;
     }
 
@@ -246,13 +257,13 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
             for (int r = 0; r < NR; ++r) Rv[r] = nxR[r];
         }
         int w1 = w + 1, me1 = me;
-        if (w1 == a.P) { w1 = 0; me1 += NLN; }
+        if (w1 == a.P) { w1 = 0; me1 += a.nls; }
         const int tm1 = tm + 1 == a.R ? 0 : tm + 1;
         issue_lds(tm1, w1);
         issue_global(u + PFD, PH % PFD);
 
         const int c = w - L, F = a.F;
-        const bool act = w >= 0 && me < NLN * a.nblk;
+        const bool act = w >= 0 && me < a.nls * a.nblk;
         if constexpr (PH == 0) {   // a lane starts a frame with empty sums
             const bool first = w == 0;
             double2 z; z.x = 0; z.y = 0;
@@ -304,7 +315,7 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         S64_PIN();
         neighbours_later<PH, 1, 1>(sd);
         S64_PIN();
-        const bool upd = act && c >= 0 && c <= F - 1 && me >= Q - 1 && me < a.T + Q - 1 && amp > thr && m2 > 0.0;
+        const bool upd = act && c >= 0 && c <= F - 1 && me >= Q - 1 && me < a.T + Q - 1 && amp > (hi ? thrB : thrA) && m2 > 0.0;
         const double sc = amp * rsqrt(m2);
         double2 val;
         val.x = upd ? a0.x * sc : co[0].x;
@@ -315,7 +326,7 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
             // (bitwise on purpose: as && / ?: this became three branches in the middle of the step)
             const bool before = c < 0;                                     // still the frame the lane has just left
             const int jj = (before ? c + a.P : c) - (F - 1);
-            const bool has_frame = (before & (me >= NLN)) | (!before & (me < NLN * a.nblk));
+            const bool has_frame = (before & (me >= a.nls)) | (!before & (me < a.nls * a.nblk));
             is_img = (w >= 0) & has_frame & ((unsigned)(jj - 1) < (unsigned)L);
             val = sel(is_img, cj(img), val);
             const int j2 = (F - 1) - c;
@@ -384,22 +395,22 @@ __global__ void __launch_bounds__(NLN * NS) k_sys64(S64Args a, BaseW<Q> bw) {
 }
 
 // extended buffers [B][Tp][Np] <-> the skewed layout
-__global__ void k_s64_load(const double2 *state, const double *amp, double2 *G, double *A, int F, int Tp, int P, long g_stride) {
-    const int b = blockIdx.y, me = blockIdx.x, Np = F + 2 * SL;
-    const int j = me & (NLN - 1), blk = me / NLN;
-    const long base = (long)SKW * j + (long)P * blk + SL + MARG;
-    const double2 *src = state + ((size_t)b * Tp + me) * Np + SL;
-    const double *asrc = amp + ((size_t)b * Tp + me) * Np + SL;
+__global__ void k_s64_load(const double2 *state, const double *amp, double2 *G, double *A, int F, int Tp, int P, long g_stride, int nls) {
+    const int bb = blockIdx.y, me = blockIdx.x, Np = F + 2 * SL;
+    const int spw = NLN / nls, b = bb / spw, ls = me & (nls - 1), j = (bb % spw) * nls + ls, blk = me / nls;   // b: workgroup
+    const long base = (long)SKW * ls + (long)P * blk + SL + MARG;
+    const double2 *src = state + ((size_t)bb * Tp + me) * Np + SL;
+    const double *asrc = amp + ((size_t)bb * Tp + me) * Np + SL;
     for (int c = threadIdx.x; c < F + SL; c += blockDim.x) {
         G[(size_t)b * g_stride + (base + c) * NLN + j] = src[c];
         A[(size_t)b * g_stride + (base + c) * NLN + j] = asrc[c];
     }
 }
-__global__ void k_s64_store(double2 *state, const double2 *G, int F, int Tp, int P, long g_stride) {
-    const int b = blockIdx.y, me = blockIdx.x, Np = F + 2 * SL;
-    const int j = me & (NLN - 1), blk = me / NLN;
-    const long base = (long)SKW * j + (long)P * blk + SL + MARG;
-    double2 *dst = state + ((size_t)b * Tp + me) * Np + SL;
+__global__ void k_s64_store(double2 *state, const double2 *G, int F, int Tp, int P, long g_stride, int nls) {
+    const int bb = blockIdx.y, me = blockIdx.x, Np = F + 2 * SL;
+    const int spw = NLN / nls, b = bb / spw, ls = me & (nls - 1), j = (bb % spw) * nls + ls, blk = me / nls;
+    const long base = (long)SKW * ls + (long)P * blk + SL + MARG;
+    double2 *dst = state + ((size_t)bb * Tp + me) * Np + SL;
     for (int c = threadIdx.x; c < F + SL; c += blockDim.x) {
         const double2 v = G[(size_t)b * g_stride + (base + c) * NLN + j];
         dst[c] = v;
@@ -417,7 +428,7 @@ hipError_t launch_pass(const S64Args &a, const BaseW<Q> &bw, int B, hipStream_t 
         if (e != hipSuccess) return e;
         attr_done(done, dev);
     }
-    k_sys64<Q, NS, MASK><<<dim3(B), dim3(NLN * NS), lds, stream>>>(a, bw);
+    k_sys64<Q, NS, MASK><<<dim3((B + NLN / a.nls - 1) / (NLN / a.nls)), dim3(NLN * NS), lds, stream>>>(a, bw);
     return hipGetLastError();
 }
 
@@ -461,20 +472,39 @@ template <int Q> bool base_weights(const double *W, int Qp, BaseW<Q> *out) {
     return true;
 }
 
+// The geometry a call runs on: one spectrogram per workgroup, or two side by side when that takes fewer steps per spectrogram
+// and sweep (frames of up to ~300 bins).  NS = 0: no ring fits.
+Geom choose_geom(int F, int T, int Q, int *NS_out) {
+    Geom best = geom(F, T, Q, NLN);
+    int best_ns = slots_for(Q, best.R);
+    double best_cost = best_ns ? (double)(best.U + best.LAG * (best_ns - 1)) / best_ns : 1e300;
+    const Geom h = geom(F, T, Q, NLN / 2);
+    const int h_ns = slots_for(Q, h.R);
+    if (h_ns) {
+        const double cost = (double)(h.U + h.LAG * (h_ns - 1)) / h_ns / 2;
+        if (cost < best_cost) { best = h; best_ns = h_ns; best_cost = cost; }
+    }
+    *NS_out = best_ns;
+    return best;
+}
+
 }  // namespace
 
 bool sys64_supports(int F, int T, int L, int Q, int Qp, int update, const double *W) {
     if (L != SL || update != 2 || T < 1 || F < 2 * SL + 7) return false;
     if (Q != 2 && Q != 4) return false;
-    const Geom g = geom(F, T, Q);
-    if (slots_for(Q, g.R) < 1) return false;
+    int ns = 0;
+    (void)choose_geom(F, T, Q, &ns);
+    if (ns < 1) return false;
     return Q == 4 ? base_weights<4>(W, Qp, nullptr) : base_weights<2>(W, Qp, nullptr);
 }
 
 size_t sys64_bytes(int B, int F, int T, int Q, size_t *amp_bytes) {
-    const Geom g = geom(F, T, Q);
-    if (amp_bytes) *amp_bytes = (size_t)B * g.rows * NLN * sizeof(double);
-    return (size_t)B * g.rows * NLN * sizeof(double2);
+    int ns = 0;
+    const Geom g = choose_geom(F, T, Q, &ns);
+    const size_t wgs = (B + NLN / g.nls - 1) / (NLN / g.nls);
+    if (amp_bytes) *amp_bytes = wgs * g.rows * NLN * sizeof(double);
+    return wgs * g.rows * NLN * sizeof(double2);
 }
 
 const char *sys64_name(int Q) { return Q == 2 ? "systolic_fp64_q2" : "systolic_fp64_q4"; }
@@ -513,28 +543,30 @@ hipError_t launch_sys64(const GenericArgs<double> &ga, const double *W_host, int
                         hipEvent_t ev0, hipEvent_t ev1) {
     if (B <= 0 || ga.n_thr <= 0) return hipSuccess;
     const int F = ga.F, T = ga.T, Q = ga.Q, Tp = T + 2 * (Q - 1);
-    const Geom g = geom(F, T, Q);
-    const int NS = slots_for(Q, g.R);
+    int NS = 0;
+    const Geom g = choose_geom(F, T, Q, &NS);
     if (NS < 1 || ga.mode != MODE_BATCH || ga.L != SL) return hipErrorInvalidValue;
+    const size_t wgs = (B + NLN / g.nls - 1) / (NLN / g.nls);
     double2 *G = static_cast<double2 *>(gs);
     double *A = static_cast<double *>(gamp);
     const long g_stride = g.rows * NLN;
     hipError_t e;
     // rows no frame owns are read by lanes whose results are discarded; they must still be numbers the first time
-    if ((e = hipMemsetAsync(G, 0, (size_t)B * g_stride * sizeof(double2), stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(A, 0, (size_t)B * g_stride * sizeof(double), stream)) != hipSuccess) return e;
-    k_s64_load<<<dim3(Tp, B), 256, 0, stream>>>(ga.state, ga.amp, G, A, F, Tp, g.P, g_stride);
+    if ((e = hipMemsetAsync(G, 0, wgs * g_stride * sizeof(double2), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(A, 0, wgs * g_stride * sizeof(double), stream)) != hipSuccess) return e;
+    k_s64_load<<<dim3(Tp, B), 256, 0, stream>>>(ga.state, ga.amp, G, A, F, Tp, g.P, g_stride, g.nls);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     S64Args a;
     a.G = G; a.A = A; a.thr = ga.thr; a.g_stride = g_stride;
     a.n_thr = ga.n_thr; a.thr0 = 0; a.ns = 0;
     a.F = F; a.T = T; a.P = g.P; a.gap = g.gap; a.LAG = g.LAG; a.R = g.R; a.nblk = g.nblk; a.U = g.U;
+    a.nls = g.nls; a.B = B;
     if (ev0) (void)hipEventRecord(ev0, stream);
     int n = 0;
     e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, ga.n_thr, B, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, ga.n_thr, B, stream, &n);
     if (e != hipSuccess) return e;
     if (ev1) (void)hipEventRecord(ev1, stream);
-    k_s64_store<<<dim3(Tp, B), 256, 0, stream>>>(ga.state, G, F, Tp, g.P, g_stride);
+    k_s64_store<<<dim3(Tp, B), 256, 0, stream>>>(ga.state, G, F, Tp, g.P, g_stride, g.nls);
     if (launches) *launches = n;
     return hipGetLastError();
 }

@@ -94,6 +94,21 @@ def test_device_resident_and_repeatable():
     plan.close()
 
 
+def test_two_short_spectrograms_share_a_workgroup(oracle):
+    """frames of up to ~300 bins: two spectrograms side by side in a wave (32 lanes each); an odd batch leaves half a workgroup idle"""
+    rng = np.random.default_rng(21)
+    for fsize, fshift, T in ((512, 128, 45), (400, 100, 70), (128, 64, 33)):
+        F = fsize // 2 + 1
+        p = lws_amd.lws(fsize, fshift, batch_iterations=6, batch_alpha=1.0, precision="fp64")
+        S = np.stack([_spec(rng, T, F) * (b + 1) for b in range(3)])       # different mean |S|: each spectrogram its own thresholds
+        out = p.batch_lws(S)
+        assert p.plan().last_kernel()["name"].startswith("systolic_fp64_q")
+        thr = lws_amd.get_thresholds(6, 1.0, 0.1, 1)
+        for b in range(3):
+            ref = oracle.batch_lws(S[b], p.W, thr)
+            assert np.abs(out[b] - ref).max() < 1e-11 * np.abs(ref).max(), (fsize, b)
+
+
 def test_unsupported_shapes_fall_back():
     rng = np.random.default_rng(3)
     for fsize, fshift in ((2048, 512), (60, 20), (64, 8)):     # 1025 bins, Q = 3, Q = 8

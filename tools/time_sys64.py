@@ -33,4 +33,6 @@ if __name__ == "__main__":
     if "--generic" in sys.argv:
         t(1024, 256, 256, 500, 100, generic=True)
     t(512, 128, 256, 500, 100)
+    t(512, 128, 512, 500, 100)       # two 257-bin spectrograms per workgroup
+    t(400, 100, 512, 500, 100)
     t(1024, 512, 256, 500, 100)
