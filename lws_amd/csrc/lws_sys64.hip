@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace lws {
 namespace {
@@ -37,6 +38,12 @@ constexpr int SKW = 8;       // steps between consecutive frames
 constexpr int MARG = 96;     // rows before / after the skewed state that prefetches may touch
 constexpr int PFD = 4;       // steps a global load is issued ahead of its use (2: no faster)
 constexpr int LDS_ROWS = 160;
+// spectrograms that go through the skewed scratch at a time (config 2's frames: 7.6 GB for 1024); LWS_S64_CHUNK: for tests
+inline int chunk_size() {
+    const char *v = getenv("LWS_S64_CHUNK");
+    const int c = (v && *v) ? atoi(v) : 1024;
+    return c >= 2 ? c & ~1 : 1024;   // (even: two spectrograms may share a workgroup)
+}
 constexpr uint64_t MASK_Q4 = 0xfd7fc3, MASK_Q2 = 0x5c3, MASK_ALL = ~0ull;   // non-zero weights of the default (sqrt-Hann) windows   // ring rows of 1 KB that fit the LDS
 
 struct Geom { int P, gap, LAG, R, nblk, U, nls; long rows; };
@@ -502,7 +509,7 @@ bool sys64_supports(int F, int T, int L, int Q, int Qp, int update, const double
 size_t sys64_bytes(int B, int F, int T, int Q, size_t *amp_bytes) {
     int ns = 0;
     const Geom g = choose_geom(F, T, Q, &ns);
-    const size_t wgs = (B + NLN / g.nls - 1) / (NLN / g.nls);
+    const size_t wgs = (std::min(B, chunk_size()) + NLN / g.nls - 1) / (NLN / g.nls);
     if (amp_bytes) *amp_bytes = wgs * g.rows * NLN * sizeof(double);
     return wgs * g.rows * NLN * sizeof(double2);
 }
@@ -546,29 +553,39 @@ hipError_t launch_sys64(const GenericArgs<double> &ga, const double *W_host, int
     int NS = 0;
     const Geom g = choose_geom(F, T, Q, &NS);
     if (NS < 1 || ga.mode != MODE_BATCH || ga.L != SL) return hipErrorInvalidValue;
-    const size_t wgs = (B + NLN / g.nls - 1) / (NLN / g.nls);
     double2 *G = static_cast<double2 *>(gs);
     double *A = static_cast<double *>(gamp);
     const long g_stride = g.rows * NLN;
+    const size_t Np = F + 2 * SL;
     hipError_t e;
-    // rows no frame owns are read by lanes whose results are discarded; they must still be numbers the first time
-    if ((e = hipMemsetAsync(G, 0, wgs * g_stride * sizeof(double2), stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(A, 0, wgs * g_stride * sizeof(double), stream)) != hipSuccess) return e;
-    k_s64_load<<<dim3(Tp, B), 256, 0, stream>>>(ga.state, ga.amp, G, A, F, Tp, g.P, g_stride, g.nls);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    S64Args a;
-    a.G = G; a.A = A; a.thr = ga.thr; a.g_stride = g_stride;
-    a.n_thr = ga.n_thr; a.thr0 = 0; a.ns = 0;
-    a.F = F; a.T = T; a.P = g.P; a.gap = g.gap; a.LAG = g.LAG; a.R = g.R; a.nblk = g.nblk; a.U = g.U;
-    a.nls = g.nls; a.B = B;
     if (ev0) (void)hipEventRecord(ev0, stream);
-    int n = 0;
-    e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, ga.n_thr, B, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, ga.n_thr, B, stream, &n);
-    if (e != hipSuccess) return e;
+    int n_all = 0;
+    // a batch larger than the scratch was sized for (sys64_bytes: at most CHUNK spectrograms) goes through it chunk by chunk
+    const int CHUNK = chunk_size();
+    for (int b0 = 0; b0 < B; b0 += CHUNK) {
+        const int Bc = std::min(CHUNK, B - b0);
+        const size_t wgs = (Bc + NLN / g.nls - 1) / (NLN / g.nls);
+        // rows no frame owns are read by lanes whose results are discarded; they must still be numbers the first time
+        if ((e = hipMemsetAsync(G, 0, wgs * g_stride * sizeof(double2), stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(A, 0, wgs * g_stride * sizeof(double), stream)) != hipSuccess) return e;
+        double2 *state = ga.state + (size_t)b0 * Tp * Np;
+        k_s64_load<<<dim3(Tp, Bc), 256, 0, stream>>>(state, ga.amp + (size_t)b0 * Tp * Np, G, A, F, Tp, g.P, g_stride, g.nls);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        S64Args a;
+        a.G = G; a.A = A; a.thr = ga.thr + (size_t)b0 * ga.n_thr; a.g_stride = g_stride;
+        a.n_thr = ga.n_thr; a.thr0 = 0; a.ns = 0;
+        a.F = F; a.T = T; a.P = g.P; a.gap = g.gap; a.LAG = g.LAG; a.R = g.R; a.nblk = g.nblk; a.U = g.U;
+        a.nls = g.nls; a.B = Bc;
+        int n = 0;
+        e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, ga.n_thr, Bc, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, ga.n_thr, Bc, stream, &n);
+        if (e != hipSuccess) return e;
+        n_all += n;
+        k_s64_store<<<dim3(Tp, Bc), 256, 0, stream>>>(state, G, F, Tp, g.P, g_stride, g.nls);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (ev1) (void)hipEventRecord(ev1, stream);
-    k_s64_store<<<dim3(Tp, B), 256, 0, stream>>>(ga.state, G, F, Tp, g.P, g_stride, g.nls);
-    if (launches) *launches = n;
-    return hipGetLastError();
+    if (launches) *launches = n_all;
+    return hipSuccess;
 }
 
 }  // namespace lws

@@ -109,6 +109,24 @@ def test_two_short_spectrograms_share_a_workgroup(oracle):
             assert np.abs(out[b] - ref).max() < 1e-11 * np.abs(ref).max(), (fsize, b)
 
 
+def test_large_batches_go_through_the_scratch_in_chunks(monkeypatch):
+    """LWS_S64_CHUNK=2: five spectrograms as 2 + 2 + 1, same bits as in one piece"""
+    rng = np.random.default_rng(8)
+    for fsize, fshift, T in ((1024, 256, 12), (256, 64, 20)):
+        F = fsize // 2 + 1
+        S = np.stack([_spec(rng, T, F) * (1 + b) for b in range(5)])
+        p = lws_amd.lws(fsize, fshift, batch_iterations=5, batch_alpha=1.0, precision="fp64")
+        whole = p.batch_lws(S)
+        monkeypatch.setenv("LWS_S64_CHUNK", "2")
+        lws_amd.clear_plan_cache()
+        q = lws_amd.lws(fsize, fshift, batch_iterations=5, batch_alpha=1.0, precision="fp64")
+        parts = q.batch_lws(S)
+        assert q.plan().last_kernel()["name"].startswith("systolic_fp64") and q.plan().last_kernel()["launches"] == 3 * (2 if F > 300 else 2)
+        monkeypatch.delenv("LWS_S64_CHUNK")
+        lws_amd.clear_plan_cache()
+        assert np.array_equal(whole, parts)
+
+
 def test_unsupported_shapes_fall_back():
     rng = np.random.default_rng(3)
     for fsize, fshift in ((2048, 512), (60, 20), (64, 8)):     # 1025 bins, Q = 3, Q = 8
