@@ -19,8 +19,13 @@
 //     them -- and added to the 2L+1 bins of the lane's frame it reaches, with 2 FMAs per component.  A bin is complete
 //     when the position L bins above it has arrived; its own frame's taps come from two register windows (new values
 //     below, old values above).  Per bin: 4(Q-1)(2L+1) + 8L FMAs instead of the 8-instruction pair of the gather form.
-//   * Hermitian images: the L images above Nyquist are ordinary positions (a lane writes them as it passes); the images
-//     below DC are never stored -- the step that receives position w <= L also scatters its conjugate as position -w.
+//   * Hermitian images: the L images above Nyquist are ordinary positions (a lane writes them as it passes, during the first
+//     steps of its next frame); the images below DC are never stored -- the step that receives position w <= L also
+//     scatters its conjugate as position -w.
+//   * a step contains no branch: a wave is alone on its SIMD (the rings fill the LDS), and every s_cbranch in the step cost it
+//     3-4 % (lane predicates are bitwise, one-lane work runs on zeroed inputs in the other lanes, every slot stores to HBM).
+//   * frames of up to ~300 bins: two spectrograms side by side in a wave, 32 lanes each (a.nls), chosen per call by steps per
+//     spectrogram and sweep.
 //
 // Entry: launch_sys64 (lws_sys64.h), called by lws_capi.hip:run_stage for MODE_BATCH of an fp64 plan.
 #include "lws_sys64.h"
