@@ -79,6 +79,7 @@ struct S64Args {
     int n_thr, thr0, ns;   // this pass: sweeps thr0 .. thr0 + ns - 1
     int F, T, P, gap, LAG, R, nblk, U;
     int nls, B;            // lanes per spectrogram (64 / 32: one / two spectrograms per workgroup), spectrograms of the call
+    int edge_exact;        // (F - 1) mod Q == 0: the Nyquist bin uses weight row 0 like DC (see Wave::step)
 };
 
 // The weights of row 0, W[0][r][k] (entries the reference skips -- |w| <= 1e-12, lws.pyx:227-232 -- are zero here).  The other
@@ -122,6 +123,7 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
     double2 acc[NA];          // sums of bins c .. c + 2L
     double2 cn[L + 1];        // cn[k]: new value of bin c - k
     double2 co[L + 1];        // co[k]: old value of bin c + k
+    double yE;                // DC / Nyquist: the imaginary part of the bin's sum (see step)
     double2 nxL[NR], nxR[NR], nxO, nxI;   // inputs of the next step (LDS)
     double2 pfO[PFD], pfR[PFD][NR];       // slot 0: inputs of the next PFD steps (HBM)
     double pfA[PFD];
@@ -166,6 +168,7 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         for (int k = 0; k <= L; ++k) { cn[k] = z; co[k] = z; }
         w = -SKW * ls;
         me = ls;
+        yE = 0;
         tm = (a.LAG * s) % a.R;
     }
 
@@ -299,6 +302,25 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
             sd[r].sx = Lv[r].x + Rv[r].x; sd[r].dy = Lv[r].y - Rv[r].y;
             sd[r].sy = Lv[r].y + Rv[r].y; sd[r].dx = Lv[r].x - Rv[r].x;
         }
+        // DC and Nyquist.  Their neighbourhood is Hermitian (the images are exact conjugates), so in the reference every tap pair
+        // k >= 1 adds x and then -x to the imaginary part of the sum, bit for bit (lwslib.cpp:310-311 on c = conj(b)): what is left
+        // is the k = 0 taps -- exactly zero for a spectrogram whose DC / Nyquist bins are real, which they then stay.  That line
+        // is unstable: an imaginary part of 1e-17 grows by three orders of magnitude per sweep (zero-phase input: a DC bin 4e-8
+        // off the real axis at its first update, O(1) two sweeps later, 5 % of all bins after 100 sweeps).  In scatter form the
+        // two halves of a pair arrive steps apart and cancel to rounding only, so the imaginary part of these two bins is taken
+        // from the k = 0 taps alone, captured when their position arrives.  (Nyquist needs row(F - 1) = row 0 and F - 1 a multiple of 4: a.edge_exact.)
+        // (Positions 0 and F - 1 arrive in phase 0 -- or 4, for frames whose half-length is 4 mod 8 -- and their bins are complete
+        // L steps later: the capture and its use are compiled into those phases only.)
+        if constexpr (PH == 0 || PH == 4) {
+            double y0 = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if ((MASK >> ((r + 1) * (L + 1))) & 1) {
+                    y0 = __builtin_fma(bw.n[r][0].x, sd[r].sy, y0);
+                    y0 = __builtin_fma(bw.n[r][0].y, sd[r].dx, y0);
+                }
+            yE = ((w == 0) | (w == F - 1)) ? y0 : yE;
+        }
         neighbours_now<PH, 1>(sd);
         // ---- (c) the frame's own taps: new values below (or their images below DC), old values above; k = 1 last (it is
         //      the value the previous step produced)
@@ -323,6 +345,7 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
             a0.y = __builtin_fma(wv.y, b.x - cv.x, a0.y);
         }
         // ---- re-projection on the target magnitude (lwslib.cpp:356-360)
+        if constexpr (PH == (L & 7) || PH == ((L + 4) & 7)) a0.y = ((c == 0) | (a.edge_exact & (c == F - 1))) ? yE : a0.y;
         const double m2 = a0.x * a0.x + a0.y * a0.y;
         S64_PIN();
         neighbours_later<PH, 1, 1>(sd);
@@ -581,6 +604,7 @@ hipError_t launch_sys64(const GenericArgs<double> &ga, const double *W_host, int
         a.n_thr = ga.n_thr; a.thr0 = 0; a.ns = 0;
         a.F = F; a.T = T; a.P = g.P; a.gap = g.gap; a.LAG = g.LAG; a.R = g.R; a.nblk = g.nblk; a.U = g.U;
         a.nls = g.nls; a.B = Bc;
+        a.edge_exact = (F - 1) % Q == 0 && (F - 1) % 4 == 0;   // (else the Nyquist bin is real to rounding only; DC always exactly)
         int n = 0;
         e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, ga.n_thr, Bc, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, ga.n_thr, Bc, stream, &n);
         if (e != hipSuccess) return e;

@@ -76,6 +76,24 @@ def test_same_as_generic_engine_to_rounding_and_thresholds_skip_bins():
         assert np.abs(np.abs(a) - np.abs(S)).max() < 1e-12 * np.abs(S).max()
 
 
+def test_config2_spectrogram_against_the_oracle(oracle):
+    """one spectrogram of BASELINE config 2's shape (500 x 513, lws(1024,256)), the reference's default schedule of 100 sweeps
+    (the oracle needs ~1 s): random phases to 1e-10, zero phases -- the documented usage run_lws(np.abs(X)) -- to 1e-7"""
+    rng = np.random.default_rng(2)
+    M = np.abs(rng.standard_normal((500, 513)) + 1j * rng.standard_normal((500, 513)))
+    p = lws_amd.lws(1024, 256, precision="fp64")
+    thr = lws_amd.get_thresholds(100, 100, 0.1, 1)
+    for name, S, bar in (("random phases", M * np.exp(2j * np.pi * rng.random(M.shape)), 1e-10), ("zero phases", M.astype(complex), 1e-7)):
+        out = p.batch_lws(S)
+        k = p.plan().last_kernel()
+        assert k["name"] == "systolic_fp64_q4" and k["launches"] == 25
+        ref = oracle.batch_lws(S, p.W, thr)
+        err = np.abs(out - ref).max() / np.abs(ref).max()
+        print("config-2 spectrogram, default schedule, %s: max err / max value = %.2e" % (name, err))
+        assert err < bar, (name, err)
+        assert np.abs(np.abs(out) - M).max() < 1e-12 * M.max()
+
+
 def test_device_resident_and_repeatable():
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(11)
