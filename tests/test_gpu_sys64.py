@@ -1,9 +1,11 @@
 """The fp64 systolic batch engine (lws_amd/csrc/lws_sys64.hip) against the oracle and against the order-exact generic engine.
 
 The engine takes a bin's sum in another order than lwslib.cpp:297-354 (scatter form), so the bar is rounding, not bits:
-<= 1e-11 of the largest value on random-phase input (observed: 1e-15 .. 1e-14).  From a zero-phase start (real-valued
-input, the documented usage) the weighted sums of the first sweeps nearly cancel and rounding is amplified by 1 / |sum|: there
-the bar is the 1e-8 that the order-exact generic engine is held to against the reference's goldens (tests/test_gpu_parity.py).
+<= 1e-11 of the largest value on random-phase input (observed: 1e-15 .. 1e-14), <= 1e-10 from a zero-phase start (real-valued
+input, the documented usage; observed <= 5e-13).  The zero-phase start is the delicate one: the DC and Nyquist bins of the reference
+stay EXACTLY real (its pairwise cancellation is exact), and that line is unstable -- an engine that keeps them real to rounding only
+drifts off it within three sweeps (tools/zero_phase_sensitivity.py; the oracle itself does when its input gets 1e-16 rad of phase).
+The kernel takes the imaginary part of these two sums from the k = 0 taps alone (lws_sys64.hip: Wave::step) and stays on it.
 """
 import numpy as np
 import pytest
@@ -52,20 +54,19 @@ def test_against_oracle(fsize, fshift, T, iters, oracle):
         ref = oracle.batch_lws(S[b], p.W, thr)
         err = np.abs(out[b] - ref).max() / np.abs(ref).max()
         print("lws(%d,%d) T=%d iters=%d %s input: max err / max value = %.2e" % (fsize, fshift, T, iters, "real" if b else "complex", err))
-        assert err < (1e-8 if b else 1e-11), (b, err)
+        assert err < (1e-10 if b else 1e-11), (b, err)
 
 
 def test_same_as_generic_engine_to_rounding_and_thresholds_skip_bins():
     """the default schedule (thresholds that decay: most bins are skipped in the first sweeps) on 100 sweeps, both engines.
-    Random phases: the two fp64 engines agree to 1e-10.  Zero phases (real-valued input): the first sweeps' sums nearly cancel,
-    a rounding difference is amplified by 1 / |sum| and carried through 100 sweeps -- two correct fp64 evaluations differ by
-    ~1e-8 there (observed 2.6e-8; the oracle's own sensitivity to one ulp of its input: tests/test_oracle_sensitivity.py)."""
+    The two fp64 engines agree to 1e-10 on random and on zero phases (observed 5e-14 / 3e-14; before the DC / Nyquist bins were
+    kept exactly real the zero-phase run differed by 2.6e-8 at this size and by O(1) on 5 % of the bins at 500 frames)."""
     rng = np.random.default_rng(5)
     T, F = 150, 513
     mag = np.abs(_spec(rng, T, F)) * rng.random((T, F)) ** 4      # wide dynamic range: the thresholds matter
     p = lws_amd.lws(1024, 256, precision="fp64")
     q = lws_amd.lws(1024, 256, precision="fp64", force_generic=True)
-    for name, S, bar in (("random phases", mag * np.exp(2j * np.pi * rng.random((T, F))), 1e-10), ("zero phases", mag.astype(complex), 1e-6)):
+    for name, S, bar in (("random phases", mag * np.exp(2j * np.pi * rng.random((T, F))), 1e-10), ("zero phases", mag.astype(complex), 1e-10)):
         a = p.batch_lws(S)
         assert p.plan().last_kernel()["name"] == "systolic_fp64_q4"
         b = q.batch_lws(S)
@@ -78,12 +79,12 @@ def test_same_as_generic_engine_to_rounding_and_thresholds_skip_bins():
 
 def test_config2_spectrogram_against_the_oracle(oracle):
     """one spectrogram of BASELINE config 2's shape (500 x 513, lws(1024,256)), the reference's default schedule of 100 sweeps
-    (the oracle needs ~1 s): random phases to 1e-10, zero phases -- the documented usage run_lws(np.abs(X)) -- to 1e-7"""
+    (the oracle needs ~1 s): random phases and zero phases -- the documented usage run_lws(np.abs(X)) -- to 1e-10 (observed 2e-12 / 8e-13)"""
     rng = np.random.default_rng(2)
     M = np.abs(rng.standard_normal((500, 513)) + 1j * rng.standard_normal((500, 513)))
     p = lws_amd.lws(1024, 256, precision="fp64")
     thr = lws_amd.get_thresholds(100, 100, 0.1, 1)
-    for name, S, bar in (("random phases", M * np.exp(2j * np.pi * rng.random(M.shape)), 1e-10), ("zero phases", M.astype(complex), 1e-7)):
+    for name, S, bar in (("random phases", M * np.exp(2j * np.pi * rng.random(M.shape)), 1e-10), ("zero phases", M.astype(complex), 1e-10)):
         out = p.batch_lws(S)
         k = p.plan().last_kernel()
         assert k["name"] == "systolic_fp64_q4" and k["launches"] == 25
