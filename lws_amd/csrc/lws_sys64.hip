@@ -79,7 +79,6 @@ struct S64Args {
     int n_thr, thr0, ns;   // this pass: sweeps thr0 .. thr0 + ns - 1
     int F, T, P, gap, LAG, R, nblk, U;
     int nls, B;            // lanes per spectrogram (64 / 32: one / two spectrograms per workgroup), spectrograms of the call
-    int edge_exact;        // (F - 1) mod Q == 0: the Nyquist bin uses weight row 0 like DC (see Wave::step)
 };
 
 // The weights of row 0, W[0][r][k] (entries the reference skips -- |w| <= 1e-12, lws.pyx:227-232 -- are zero here).  The other
@@ -308,18 +307,23 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         // is unstable: an imaginary part of 1e-17 grows by three orders of magnitude per sweep (zero-phase input: a DC bin 4e-8
         // off the real axis at its first update, O(1) two sweeps later, 5 % of all bins after 100 sweeps).  In scatter form the
         // two halves of a pair arrive steps apart and cancel to rounding only, so the imaginary part of these two bins is taken
-        // from the k = 0 taps alone, captured when their position arrives.  (Nyquist needs row(F - 1) = row 0 and F - 1 a multiple of 4: a.edge_exact.)
-        // (Positions 0 and F - 1 arrive in phase 0 -- or 4, for frames whose half-length is 4 mod 8 -- and their bins are complete
-        // L steps later: the capture and its use are compiled into those phases only.)
-        if constexpr (PH == 0 || PH == 4) {
+        // from the k = 0 taps alone, captured when their position arrives.  
+        // (Position 0 arrives in phase 0, position F - 1 -- F is odd -- in an even phase, and their bins are complete L steps later:
+        // the capture and its use are compiled into those phases only.  A half-length F - 1 that is 2 mod 4 puts the Nyquist bin
+        // on weight row 2 when Q = 4: W[2][r][0] = (-1)^r W[0][r][0] -- exactly, here; in the reference's tensor numpy's
+        // exp(j pi r) leaves those weights an imaginary part of 1e-16, which seeds the unstable line: for such frames the
+        // reference's own Nyquist bins leave the real axis and its trajectory from a zero-phase start is that noise, amplified.)
+        if constexpr (PH % 2 == 0) {
+            constexpr bool ALT = (PH % 4 == 2) && Q == 4;
             double y0 = 0.0;
 #pragma unroll
             for (int r = 0; r < NR; ++r)
                 if ((MASK >> ((r + 1) * (L + 1))) & 1) {
-                    y0 = __builtin_fma(bw.n[r][0].x, sd[r].sy, y0);
-                    y0 = __builtin_fma(bw.n[r][0].y, sd[r].dx, y0);
+                    const double sg = (ALT && (r % 2 == 0)) ? -1.0 : 1.0;     // frame distance r + 1 odd
+                    y0 = __builtin_fma(sg * bw.n[r][0].x, sd[r].sy, y0);
+                    y0 = __builtin_fma(sg * bw.n[r][0].y, sd[r].dx, y0);
                 }
-            yE = ((w == 0) | (w == F - 1)) ? y0 : yE;
+            yE = (((PH == 0) & (w == 0)) | (w == F - 1)) ? y0 : yE;
         }
         neighbours_now<PH, 1>(sd);
         // ---- (c) the frame's own taps: new values below (or their images below DC), old values above; k = 1 last (it is
@@ -345,7 +349,7 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
             a0.y = __builtin_fma(wv.y, b.x - cv.x, a0.y);
         }
         // ---- re-projection on the target magnitude (lwslib.cpp:356-360)
-        if constexpr (PH == (L & 7) || PH == ((L + 4) & 7)) a0.y = ((c == 0) | (a.edge_exact & (c == F - 1))) ? yE : a0.y;
+        if constexpr ((PH - L) % 2 == 0) a0.y = ((c == 0) | (c == F - 1)) ? yE : a0.y;
         const double m2 = a0.x * a0.x + a0.y * a0.y;
         S64_PIN();
         neighbours_later<PH, 1, 1>(sd);
@@ -604,7 +608,6 @@ hipError_t launch_sys64(const GenericArgs<double> &ga, const double *W_host, int
         a.n_thr = ga.n_thr; a.thr0 = 0; a.ns = 0;
         a.F = F; a.T = T; a.P = g.P; a.gap = g.gap; a.LAG = g.LAG; a.R = g.R; a.nblk = g.nblk; a.U = g.U;
         a.nls = g.nls; a.B = Bc;
-        a.edge_exact = (F - 1) % Q == 0 && (F - 1) % 4 == 0;   // (else the Nyquist bin is real to rounding only; DC always exactly)
         int n = 0;
         e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, ga.n_thr, Bc, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, ga.n_thr, Bc, stream, &n);
         if (e != hipSuccess) return e;

@@ -95,6 +95,48 @@ def test_config2_spectrogram_against_the_oracle(oracle):
         assert np.abs(np.abs(out) - M).max() < 1e-12 * M.max()
 
 
+@pytest.mark.parametrize("fsize,fshift", [(1024, 256), (1016, 254), (1020, 510), (400, 100)])
+def test_zero_phase_start_stays_on_the_reference_trajectory(fsize, fshift, oracle):
+    """real-valued input, the default schedule's 100 sweeps: the DC and Nyquist bins stay exactly real as in the reference (half-lengths
+    0 and 4 mod 8, and 2 mod 4 with Q = 2: weight row 0) -- else 5 % of the bins end up O(1) away"""
+    rng = np.random.default_rng(fsize)
+    T, F = 140, fsize // 2 + 1
+    M = np.abs(rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F)))
+    p = lws_amd.lws(fsize, fshift, precision="fp64")
+    out = p.batch_lws(M)
+    assert p.plan().last_kernel()["name"].startswith("systolic_fp64_q")
+    ref = oracle.batch_lws(M.astype(complex), p.W, lws_amd.get_thresholds(100, 100, 0.1, 1))
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    print("lws(%d,%d) zero phases, 100 sweeps: max err / max value = %.2e" % (fsize, fshift, err))
+    assert err < 1e-10, err
+    assert np.all(out[:, 0].imag == 0) and np.all(out[:, -1].imag == 0) and np.all(ref[:, -1].imag == 0)
+
+
+def test_zero_phase_start_where_the_reference_is_its_own_noise(oracle):
+    """lws(996,249): Q = 4 and a half-length that is 2 mod 4 put the Nyquist bin on weight row 2, whose k = 0 weights are
+    base x exp(j pi r) -- with an imaginary part of 1e-16 from numpy's exp.  That seeds the unstable line: the REFERENCE's Nyquist
+    bins leave the real axis (asserted), and its zero-phase trajectory is that noise amplified.  The kernel uses the exact (-1)^r and
+    keeps the Nyquist bin of a real signal's spectrogram real; the two agree on the median bin and in quality, not bin by bin."""
+    rng = np.random.default_rng(996)
+    T, F = 140, 499
+    M = np.abs(rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F)))
+    p = lws_amd.lws(996, 249, precision="fp64")
+    out = p.batch_lws(M)
+    assert p.plan().last_kernel()["name"] == "systolic_fp64_q4"
+    ref = oracle.batch_lws(M.astype(complex), p.W, lws_amd.get_thresholds(100, 100, 0.1, 1))
+    assert np.abs(ref[:, -1].imag).max() > 1e-3 * np.abs(ref).max()          # the reference's Nyquist bins are far from real
+    assert np.all(out[:, 0].imag == 0) and np.all(out[:, -1].imag == 0)
+    d = np.abs(out - ref)
+    assert np.median(d) < 1e-9 * np.abs(ref).max()
+    assert abs(p.get_consistency(out) - p.get_consistency(ref)) < 0.05
+    assert np.abs(np.abs(out) - M).max() < 1e-12 * M.max()
+    # 30 sweeps in, before the noise has grown: bin by bin
+    thr = lws_amd.get_thresholds(100, 100, 0.1, 1)[:45]
+    o45 = lws_amd.lws(996, 249, precision="fp64", batch_iterations=45).batch_lws(M, thresholds=thr)
+    r45 = oracle.batch_lws(M.astype(complex), p.W, thr)
+    assert np.abs(o45 - r45).max() < 1e-9 * np.abs(r45).max()
+
+
 def test_device_resident_and_repeatable():
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(11)
