@@ -137,6 +137,25 @@ def test_zero_phase_start_where_the_reference_is_its_own_noise(oracle):
     assert np.abs(o45 - r45).max() < 1e-9 * np.abs(r45).max()
 
 
+@pytest.mark.parametrize("wname", ["hamming", "blackman"])
+def test_other_windows_run_the_build_with_every_tap(wname, oracle):
+    """the default (sqrt-Hann) windows leave 6 of the 23 weights of a row at zero and get a build without those taps; any other
+    window -- here Hamming / Blackman analysis windows, whose tensors have all 23 -- runs the full build"""
+    rng = np.random.default_rng(13)
+    win = getattr(np, wname)(256)
+    for fshift, T in ((64, 70), (128, 40)):
+        p = lws_amd.lws(win, fshift, batch_iterations=8, batch_alpha=1.0, precision="fp64")
+        assert np.count_nonzero(np.abs(p.W[0]) > 1e-12) > (17 if p.W.shape[1] == 4 else 7)
+        S = np.stack([_spec(rng, T, 129), _spec(rng, T, 129, real=True)])
+        out = p.batch_lws(S)
+        assert p.plan().last_kernel()["name"].startswith("systolic_fp64_q"), p.plan().last_kernel()["name"]
+        thr = lws_amd.get_thresholds(8, 1.0, 0.1, 1)
+        for b in range(2):
+            ref = oracle.batch_lws(S[b], p.W, thr)
+            err = np.abs(out[b] - ref).max() / np.abs(ref).max()
+            assert err < 1e-10, (wname, fshift, b, err)
+
+
 def test_device_resident_and_repeatable():
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(11)
