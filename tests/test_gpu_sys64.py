@@ -156,6 +156,24 @@ def test_other_windows_run_the_build_with_every_tap(wname, oracle):
             assert err < 1e-10, (wname, fshift, b, err)
 
 
+def test_general_weight_tensor_with_row_per_bin(oracle):
+    """use_simplifications=False (lws.pyx:246-253: LWSfractionalQ on a tensor with one row per bin, Qp = N): the rows are still the
+    quarter turns of row 0, so the fp64 systolic engine takes it"""
+    rng = np.random.default_rng(17)
+    p = lws_amd.lws(256, 64)
+    Wg = lws_amd.create_weights(p.awin, p.swin, 64, 5, use_summarized_weights=False)
+    assert Wg.shape[0] > 4
+    S = _spec(rng, 50, 129)
+    thr = lws_amd.get_thresholds(6, 1.0, 0.1, 1)
+    out = lws_amd.batch_lws(S, Wg, thr, use_simplifications=False, precision="fp64")
+    ref = oracle.batch_lws(S, Wg, thr)
+    assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()
+    plan = _capi.Plan(129, Wg, precision="fp64")
+    plan.batch(S, thr)
+    assert plan.last_kernel()["name"] == "systolic_fp64_q4"
+    plan.close()
+
+
 def test_device_resident_and_repeatable():
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(11)
