@@ -191,7 +191,9 @@ _PLAN_DEFAULTS = {"device": 0, "precision": "fp32", "nofuture_q4_compat": True, 
 # in loops over spectrograms; a device plan (weight upload, table analysis, scratch, events) per call would dominate small
 # calls, so the last few plans are kept, keyed by the weights' bytes and the plan options.  `clear_plan_cache()` releases
 # their device memory.  Precision: the engine computes in fp32 by default (`precision="fp64"` selects the reference's
-# arithmetic on the order-exact generic engine; tolerances in DESIGN.md section 6); complex128 in, complex128 out either way.
+# arithmetic: batch sweeps of Q = 2 / 4 plans on the fp64 systolic engine, lws_sys64.hip, everything else -- and everything
+# with `force_generic=True` -- on the order-exact generic engine; tolerances in DESIGN.md section 6); complex128 in, complex128
+# out either way.
 _PLAN_CACHE_SIZE = 4
 # One cache per calling thread: the bindings release the GIL around the C call and an lws_plan (scratch, events, stage
 # buffers) serves one call at a time, so a plan shared between threads could be used -- or evicted and destroyed -- while
