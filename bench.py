@@ -132,7 +132,7 @@ def compact_roofline(roof):
     return out
 
 
-def final_line(head, world, steps, warmup, fsize, roof, cpu, extra_file=None, notes=None):
+def final_line(head, world, steps, warmup, fsize, roof, cpu, extra_file=None, notes=None, also=None):
     """The ONE JSON line the driver parses: compact (< MAX_LINE bytes), strict JSON.  Everything else bench.py measures goes
     to `extra_file` and to short '# ...' lines printed before it."""
     line = {
@@ -148,13 +148,15 @@ def final_line(head, world, steps, warmup, fsize, roof, cpu, extra_file=None, no
         "roofline": compact_roofline(roof),
         "cpu_baseline": ({k: _sig(v) for k, v in cpu.items()} if cpu else None),
     }
+    if also:                                      # a few numbers of the extra blocks (each block in full: extra_file)
+        line["also"] = {k: (_sig(v) if isinstance(v, float) else v) for k, v in also.items()}
     if notes:
         line["notes"] = notes
     if extra_file:
         line["extra_file"] = extra_file
     line = _clean(line)
     txt = json.dumps(line, allow_nan=False, separators=(",", ":"))
-    for drop in ("notes", "extra_file"):          # never let an optional field push the line over the limit
+    for drop in ("notes", "also", "extra_file"):  # never let an optional field push the line over the limit
         if len(txt) >= MAX_LINE and drop in line:
             del line[drop]
             txt = json.dumps(line, allow_nan=False, separators=(",", ":"))
@@ -583,7 +585,20 @@ def main():
         for l in summary_lines(extra):
             print(l)
         notes = "dense schedule: parity at quality level (DESIGN 6); default schedule value-level vs oracle in tests"
-        print(final_line(head, world, args.steps, args.warmup, p.fsize, roof, cpu, extra_file, notes))
+        also = {}
+        try:
+            c = extra.get("configs") or {}
+            if "systolic" in (c.get("2-fp64") or {}):
+                also["fp64_ms"] = float(c["2-fp64"]["systolic"]["kernel_ms"])
+                also["fp64_kernel"] = c["2-fp64"]["systolic"]["kernel"]
+                also["fp64_generic_ms"] = float(c["2-fp64"]["generic"]["kernel_ms"])
+            if "total_wall_ms" in (c.get("3") or {}):
+                also["config3_ms"] = float(c["3"]["total_wall_ms"])
+            if "wall_ms" in (c.get("host_api") or {}):
+                also["host_api_ms"] = float(c["host_api"]["wall_ms"])
+        except Exception:
+            also = {}
+        print(final_line(head, world, args.steps, args.warmup, p.fsize, roof, cpu, extra_file, notes, also))
         sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()

@@ -29,7 +29,8 @@ def _canned(world):
 def test_final_line_is_compact_strict_json():
     for world in (1, 2, 4, 8):
         head, roof, cpu = _canned(world)
-        txt = bench.final_line(head, world, 20, 5, 1024, roof, cpu, "gpurun_out/bench_extra.json", "n" * 500)
+        txt = bench.final_line(head, world, 20, 5, 1024, roof, cpu, "gpurun_out/bench_extra.json", "n" * 500,
+                               {"fp64_ms": 97.123456, "fp64_kernel": "systolic_fp64_q4", "fp64_generic_ms": 836.2, "config3_ms": 73.1, "host_api_ms": 49.1})
         assert len(txt) < 2048 and "\n" not in txt
         d = json.loads(txt, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))     # NaN / Infinity would raise
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
