@@ -244,7 +244,7 @@ def cpu_baseline(W, T, F, iters, budget_s=12.0):
     use_ref = RefLib.available()
     rl = RefLib() if use_ref else None
     L, Q = W.shape[2] - 1, W.shape[1]
-    ncores = os.cpu_count() or 1
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the cores this rank may use
     wr, wi, wf = split_weights(W)
 
     def one(seed, sweeps):
@@ -329,6 +329,137 @@ def load_traffic(kname, config, stage=None):
     return None, None
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _device_count():
+    """GPUs this process could open, without initialising a HIP context in the launcher (the ranks are fresh processes)."""
+    try:
+        import lws_amd
+        return int(lws_amd._capi.load().lws_device_count())
+    except Exception:
+        import torch
+        return int(torch.cuda.device_count())
+
+
+def self_launch(n, argv, script=None, have=None):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this file (one process per GPU) with the
+    environment torch.distributed.run would give them -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free
+    MASTER_PORT -- and wait for them.  Rank 0 inherits stdout, so its ONE JSON line is this process's last line.  Under RCCL a
+    rank needs its own GPU: with fewer GPUs than N the job runs on the GPUs there are (said on stderr; the line's n_gpus is the
+    number of ranks that ran).  LWS_BENCH_BACKEND=gloo lets ranks share a GPU (the tests' two ranks on a one-GPU box).
+    Returns the exit code."""
+    import subprocess
+    backend = os.environ.get("LWS_BENCH_BACKEND", "nccl")
+    script = script or os.path.abspath(__file__)
+    have = _device_count() if have is None else have
+    if have < 1:
+        print("bench.py: no GPU visible to liblws_hip (hipGetDeviceCount = %d): nothing to measure" % have, file=sys.stderr)
+        return 2
+    world = n
+    if backend == "nccl" and have < n:
+        print("# bench.py: --gpus %d asked, %d GPU(s) visible: running %d rank(s) (RCCL needs one GPU per rank)" % (n, have, have), file=sys.stderr)
+        world = have
+    # the children's --gpus is the world that actually runs
+    child_argv, skip = [], False
+    for i, a in enumerate(argv):
+        if skip:
+            skip = False
+            continue
+        if a == "--gpus":
+            skip = True
+            continue
+        if a.startswith("--gpus="):
+            continue
+        child_argv.append(a)
+    child_argv = ["--gpus", str(world)] + child_argv
+    env = dict(os.environ, WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between the processes of this host
+    if world == 1:
+        for k in ("WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+            env.pop(k)
+        return subprocess.call([sys.executable, script] + child_argv, env=env)
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script] + child_argv, env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))   # same process group as this launcher
+    rc = 0
+    try:
+        live = set(range(world))
+        while live:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                live.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, c), file=sys.stderr)
+                    for q in sorted(live):        # our own children, by PID
+                        procs[q].terminate()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        rc = 130
+    return rc
+
+
+def pin_rank_to_numa(torch, local_rank, local_world):
+    """Best effort: bind this rank's host threads (the host-array path runs up to 32 workers per plan) to the cores of its GPU's
+    NUMA node -- /sys/bus/pci/devices/<bus id>/numa_node -- or, when the node is unknown (-1), to an even 1/local_world slice of
+    the cores this process may use.  Only for N > 1; LWS_BENCH_NO_PIN=1 switches it off.  Returns a description or None."""
+    if local_world <= 1 or os.environ.get("LWS_BENCH_NO_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        cpus, how = None, None
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id"), getattr(pr, "pci_bus_id"), getattr(pr, "pci_device_id"))
+            node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+            if node >= 0:
+                txt = open("/sys/devices/system/node/node%d/cpulist" % node).read().strip()
+                got = set()
+                for part in txt.split(","):
+                    a, _, b = part.partition("-")
+                    got.update(range(int(a), int(b or a) + 1))
+                got &= set(allowed)
+                # ranks whose GPUs share the node split its cores between them
+                same = [i for i in range(local_world) if _numa_of(torch, i) == node]
+                if got and local_rank in same:
+                    got = sorted(got)
+                    k, j = len(same), same.index(local_rank)
+                    per = max(1, len(got) // k)
+                    cpus, how = got[j * per:(j + 1) * per] or got, "numa node %d (%s)" % (node, bus)
+        except Exception:
+            cpus = None
+        if not cpus:
+            per = max(1, len(allowed) // local_world)
+            cpus, how = allowed[local_rank * per:(local_rank + 1) * per] or allowed, "even slice"
+        os.sched_setaffinity(0, cpus)
+        return "%d cores, %s" % (len(cpus), how)
+    except Exception:
+        return None
+
+
+def _numa_of(torch, i):
+    try:
+        pr = torch.cuda.get_device_properties(i)
+        bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        return int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+    except Exception:
+        return -1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +479,10 @@ def main():
                                                        "that directory exists, else ./bench_extra.json)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (how the driver starts N = 1): start the N ranks here, one process per GPU
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
     import lws_amd
@@ -356,8 +491,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        print("# bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs (n_gpus = %d)" % (args.gpus, world, world),
+              file=sys.stderr)
     # RCCL ("nccl") between the GPUs of a node.  LWS_BENCH_BACKEND=gloo runs the same N > 1 code path with the (two)
     # all-reduces on CPU tensors, and lets ranks share a GPU when there are fewer GPUs than ranks: tests/test_gpu_dist.py
     # drives this file with 2 ranks on the single GPU of the test box.
@@ -366,6 +501,7 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    pinned = pin_rank_to_numa(torch, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -471,6 +607,8 @@ def main():
     B, T, F, iters = head["batch_per_gpu"], head["frames"], head["bins"], head["iters"]
     roof = dict(head["roofline"])
     extra = {"headline_checks": head.get("checks")}
+    if pinned:
+        extra["host_affinity_rank0"] = pinned
 
     # measured HBM copy rate of this GPU with the library's own stream-copy kernel (quote the fraction
     # against the measured copy peak as well as the spec peak); read + write bytes both counted

@@ -72,3 +72,61 @@ def test_config4_split_is_eight_contiguous_shards_of_1024():
         assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in rs]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _launch(tmp_path, n, argv, have, body, backend=None):
+    """bench.self_launch around a stand-in rank script (no GPU here): returns (rc, what the ranks wrote)."""
+    import subprocess
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, json\nout = os.environ['OUT_DIR']\n"
+                      "json.dump({k: os.environ.get(k) for k in ('RANK','LOCAL_RANK','WORLD_SIZE','LOCAL_WORLD_SIZE','MASTER_ADDR','MASTER_PORT')} | {'argv': sys.argv[1:]},"
+                      " open(os.path.join(out, 'r%s.json' % os.environ.get('RANK', 'solo')), 'w'))\n" + body)
+    code = ("import sys, os; sys.path.insert(0, %r); import bench; os.environ['OUT_DIR'] = %r; %s"
+            "raise SystemExit(bench.self_launch(%d, %r, script=%r, have=%d))"
+            % (ROOT, str(tmp_path), ("os.environ['LWS_BENCH_BACKEND'] = %r; " % backend) if backend else "", n, argv, str(script), have))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LWS_BENCH_BACKEND")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    got = {f: json.load(open(tmp_path / f)) for f in sorted(os.listdir(tmp_path)) if f.endswith(".json")}
+    return out, got
+
+
+def test_self_launch_starts_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus N` without a launcher (the way the driver starts N = 1) starts its own N ranks with the launcher's
+    environment; rank 0's stdout is the launcher's."""
+    out, got = _launch(tmp_path, 4, ["--gpus", "4", "--steps", "3", "--warmup=1"], 8, "if os.environ['RANK'] == '0': print('{\"line\": 1}')\nelse: print('noise')\n")
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == '{"line": 1}'                       # only rank 0 reaches stdout
+    assert sorted(got) == ["r0.json", "r1.json", "r2.json", "r3.json"]
+    ports = set()
+    for r in range(4):
+        g = got["r%d.json" % r]
+        assert g["RANK"] == str(r) and g["LOCAL_RANK"] == str(r) and g["WORLD_SIZE"] == "4" and g["LOCAL_WORLD_SIZE"] == "4"
+        assert g["MASTER_ADDR"] == "127.0.0.1"
+        assert g["argv"] == ["--gpus", "4", "--steps", "3", "--warmup=1"]
+        ports.add(g["MASTER_PORT"])
+    assert len(ports) == 1 and 1024 < int(ports.pop()) < 65536
+
+
+def test_self_launch_runs_on_the_gpus_there_are(tmp_path):
+    """RCCL needs a GPU per rank: --gpus 8 on a 2-GPU box runs 2 ranks (and says so); with one GPU the single rank runs without a
+    process group; the gloo test backend lets ranks share a GPU."""
+    out, got = _launch(tmp_path, 8, ["--steps", "2", "--gpus=8"], 2, "")
+    assert out.returncode == 0 and "2 GPU(s) visible" in out.stderr
+    assert sorted(got) == ["r0.json", "r1.json"] and got["r1.json"]["WORLD_SIZE"] == "2" and got["r0.json"]["argv"] == ["--gpus", "2", "--steps", "2"]
+    for f in got:
+        os.remove(tmp_path / f)
+    out, got = _launch(tmp_path, 2, ["--gpus", "2"], 1, "")
+    assert out.returncode == 0 and list(got) == ["rsolo.json"] and got["rsolo.json"]["WORLD_SIZE"] is None and got["rsolo.json"]["argv"] == ["--gpus", "1"]
+    os.remove(tmp_path / "rsolo.json")
+    out, got = _launch(tmp_path, 2, ["--gpus", "2"], 1, "", backend="gloo")
+    assert out.returncode == 0 and sorted(got) == ["r0.json", "r1.json"]
+    out, got = _launch(tmp_path, 2, ["--gpus", "2"], 0, "")
+    assert out.returncode == 2 and "no GPU" in out.stderr
+
+
+def test_self_launch_stops_the_job_when_a_rank_fails(tmp_path):
+    import time as _t
+    t0 = _t.time()
+    out, got = _launch(tmp_path, 3, ["--gpus", "3"], 3, "import time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(60)\n")
+    assert out.returncode == 7 and "rank 1 exited with code 7" in out.stderr
+    assert _t.time() - t0 < 30                                          # the other ranks were stopped, not waited for

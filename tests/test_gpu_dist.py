@@ -128,6 +128,30 @@ def test_bench_py_runs_its_multi_rank_branch():
     assert ex["headline_checks"]["max_rel_magnitude_error"] < 1e-6
 
 
+def test_bench_py_starts_its_own_ranks():
+    """`python bench.py --gpus 2` exactly as the driver starts N = 1 -- no launcher, no MASTER_* / RANK / WORLD_SIZE in the
+    environment: bench.py starts its two ranks itself (bench.self_launch) and the launcher's last stdout line is rank 0's JSON
+    line.  One GPU here, so LWS_BENCH_BACKEND=gloo lets the ranks share it."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT", "RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env["LWS_BENCH_BACKEND"] = "gloo"
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+           "--extra-file", os.path.join(ROOT, "gpurun_out", "bench_extra_selflaunch.json")]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    last = out.stdout.rstrip().splitlines()[-1]
+    assert len([ln for ln in out.stdout.splitlines() if ln.startswith("{")]) == 1 and last.startswith("{") and len(last) < 2048
+    d = json.loads(last)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["parallelism"] == "shard2"
+    B, T, F, it = d["config"]["batch_per_gpu"], d["config"]["frames"], d["config"]["bins"], d["config"]["iters"]
+    assert (B, T, F, it) == (256, 500, 513, 100)
+    assert np.isclose(d["value"], 2.0 * B * T * F * it / (d["ms_per_step"] * 1e-3), rtol=1e-5)
+    full = json.load(open(os.path.join(ROOT, d["extra_file"])))
+    assert np.isfinite(full["extra"]["residual_db_after"]) and full["extra"]["headline_checks"]["max_rel_magnitude_error"] < 1e-6
+
+
 def test_c_abi_residual_all_reduce_over_rccl():
     """lws_residual_allreduce_dev -- the job's residual pair for C / mex callers that run one process per GPU: this rank's sums,
     all-reduced in place on the device by RCCL (ncclAllReduce, resolved with dlopen: the library does not link against librccl).
