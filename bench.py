@@ -708,9 +708,12 @@ def main():
     if rank == 0:
         head["fshift"] = p.fshift
         full = {"headline": {k: v for k, v in head.items() if k != "roofline"}, "roofline": roof, "cpu_baseline": cpu, "extra": extra,
-                "parity_of_timed_workload": ("quality-level: the dense schedule from a zero-phase start is ill-conditioned (DESIGN 6); fp32 is "
-                                             "checked by magnitudes + consistency, the schedule by the fp64 plan; the default schedule "
-                                             "(extra.default_schedule) is checked value by value against the oracle (tests/test_gpu_parity.py)")}
+                "parity_of_timed_workload": ("100 dense sweeps on the fp32 systolic engine are checked value by value against the oracle from a "
+                                             "random-phase start at SURVEY 8(c)'s bars (tests/test_gpu_parity.py::test_dense_sweeps_from_random_phases_"
+                                             "value_level: rel-L2 1.4e-5, median 2e-7, p99.9 2e-4 x mean|S|).  The timed start (zero phases, "
+                                             "run_lws(np.abs(X))) is ill-conditioned (DESIGN 6): fp32 is held to magnitudes 1e-6 + consistency "
+                                             "0.05 dB there, the schedule by the fp64 plan; the default schedule (extra.default_schedule) is "
+                                             "checked value by value against the oracle")}
         extra_file = None
         try:   # everything that is not the contract's line: a file next to the run (gpurun_out/ travels back from the GPU box)
             d = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
@@ -722,7 +725,10 @@ def main():
             extra_file = None
         for l in summary_lines(extra):
             print(l)
-        notes = "dense schedule: parity at quality level (DESIGN 6); default schedule value-level vs oracle in tests"
+        # (numbers of tests/test_gpu_parity.py on an MI355X, round 5: the bench may not call the oracle on its product path)
+        notes = ("parity of this arithmetic path vs the fp64 oracle, 100 dense sweeps 500x513 from random phases: rel-L2 1.4e-5, median 2e-7, "
+                 "p99.9 2e-4, max 2e-3 (x mean|S|); from the timed zero-phase start (ill-conditioned) consistency within 0.05 dB, magnitudes 1e-6, "
+                 "fp64 plan median 1e-13 / max 1e-5 vs the reference fingerprint")
         also = {}
         try:
             c = extra.get("configs") or {}

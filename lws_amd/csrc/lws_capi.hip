@@ -1316,4 +1316,9 @@ const char *lws_last_kernel_name(lws_plan *p) { return p ? p->last_name : "none"
 
 const char *lws_generic_stage(lws_plan *p) { return p ? p->generic_stage : ""; }
 
+// Test hook, not part of include/lws_hip.h: the fp64 systolic engine's scratch layout for frames of F bins (tests/test_sys64_model.py
+// checks that no prefetch reads past the rows it allocates).  out = {rows, highest row read, highest row written, gap}; 0 if the shape
+// is not one the engine takes.
+int lws_debug_sys64_layout(int F, int T, int Q, long *out) { return out && lws::sys64_layout(F, T, Q, out) ? 1 : 0; }
+
 }  // extern "C"

@@ -12,6 +12,8 @@ bool sys64_supports(int F, int T, int L, int Q, int Qp, int update, const double
 // Scratch of a call: the time-skewed state (return value), the magnitudes in the same addressing.
 size_t sys64_bytes(int B, int F, int T, int Q, size_t *amp_bytes);
 const char *sys64_name(int Q);
+// Diagnostics (tests): out = {rows allocated per workgroup, highest row the prefetch reads, highest row written, gap}
+bool sys64_layout(int F, int T, int Q, long out[4]);
 // Runs a.n_thr batch sweeps on the extended buffers a.state / a.amp (reference layout), in place.  Same results as
 // launch_generic<double> up to the rounding of a different summation order.  ev0 / ev1 (may be null) bracket the update kernels.
 hipError_t launch_sys64(const GenericArgs<double> &a, const double *W_host, int B, void *skew_state, void *skew_amp, hipStream_t stream,

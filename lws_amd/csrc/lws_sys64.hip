@@ -67,7 +67,11 @@ inline Geom geom(int F, int T, int Q, int nls) {
     g.R = g.LAG - SL + 1;
     g.nblk = (Tp + NLN - 1) / NLN;
     g.U = SKW * (NLN - 1) + g.P * g.nblk + 8;   // (+ 8: the images of the last frames)
-    g.rows = (long)g.U + 2 * MARG;
+    // rows after the skewed state: slot 0's prefetch of step ux <= U - 1 + PFD reads row ux + MARG + L + SKW r + (gap in the lanes
+    // whose right-hand neighbour wrapped into the next block) for r <= Q - 1 -- past a fixed margin once gap > 64 (frames of more
+    // than ~570 bins).  The values are discarded; the rows must exist.
+    const int tail = std::max(MARG, PFD + SL + SKW * (Q - 1) + g.gap + 8);
+    g.rows = (long)g.U + MARG + tail;
     return g;
 }
 
@@ -532,6 +536,9 @@ Geom choose_geom(int F, int T, int Q, int *NS_out) {
 bool sys64_supports(int F, int T, int L, int Q, int Qp, int update, const double *W) {
     if (L != SL || update != 2 || T < 1 || F < 2 * SL + 7) return false;
     if (Q != 2 && Q != 4) return false;
+    // even F (a frame length that is 2 mod 4): the Nyquist bin would fall into an odd phase of the unrolled step, where its
+    // exact-real handling (yE) is not compiled in; the order-exact engine takes those plans
+    if (!(F & 1)) return false;
     int ns = 0;
     (void)choose_geom(F, T, Q, &ns);
     if (ns < 1) return false;
@@ -544,6 +551,17 @@ size_t sys64_bytes(int B, int F, int T, int Q, size_t *amp_bytes) {
     const size_t wgs = (std::min(B, chunk_size()) + NLN / g.nls - 1) / (NLN / g.nls);
     if (amp_bytes) *amp_bytes = wgs * g.rows * NLN * sizeof(double);
     return wgs * g.rows * NLN * sizeof(double2);
+}
+
+bool sys64_layout(int F, int T, int Q, long out[4]) {
+    int ns = 0;
+    const Geom g = choose_geom(F, T, Q, &ns);
+    if (ns < 1) return false;
+    out[0] = g.rows;                                                            // rows of the skewed state / magnitudes per workgroup
+    out[1] = (long)(g.U - 1 + PFD) + MARG + SL + SKW * (Q - 1) + g.gap;         // highest row slot 0's prefetch reads (issue_global)
+    out[2] = (long)(g.U - 1) + MARG;                                            // highest row a step writes
+    out[3] = g.gap;
+    return true;
 }
 
 const char *sys64_name(int Q) { return Q == 2 ? "systolic_fp64_q2" : "systolic_fp64_q4"; }

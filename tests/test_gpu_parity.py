@@ -279,6 +279,37 @@ def test_config_scale_against_oracle_and_fingerprint(oracle):
         assert np.median(np.abs(out_d.ravel()[::97] - fp["sample_dense20"])) < 1e-3 * mean
 
 
+def _bars_8c(out, ref, mean, label):
+    d = np.abs(out - ref)
+    m = {"rel_l2": rel_l2(out, ref), "median": np.median(d) / mean, "p999": np.quantile(d, 0.999) / mean, "max": d.max() / mean}
+    print("%s: rel-L2 %.2e, median %.1e, 99.9 %% %.1e, max %.1e (x mean |S|)" % (label, m["rel_l2"], m["median"], m["p999"], m["max"]))
+    return m
+
+
+@pytest.mark.parametrize("fshift,iters,kernel", [(256, 100, "systolic_q4"), (512, 20, "systolic"), (128, 20, "systolic")])
+def test_dense_sweeps_from_random_phases_value_level(oracle, fshift, iters, kernel):
+    """The arithmetic path bench.py times -- 500 x 513, lws(1024,256), 100 DENSE sweeps (all thresholds 0: every bin updated in
+    every sweep) on the fp32 systolic engine -- compared value by value with the oracle at SURVEY.md 8(c)'s bars.  The start has
+    random phases: well conditioned, unlike the zero-phase start of the bench (whose weighted sums nearly cancel, so that there
+    rounding decides individual bins: test_config_scale_against_oracle_and_fingerprint).  Same for the Q = 2 and Q = 8 builds
+    (LWSQ2 / LWSanyQ: lwslib.cpp:72-150, 283-373) at 20 sweeps.  Reference of the headline case: lwslib.cpp:153-280 (LWSQ4)."""
+    rng = np.random.default_rng(20260928)
+    T, F = 500, 513
+    M = np.abs(rng.standard_normal((T, F)) + 1j * rng.standard_normal((T, F))).astype(np.float32).astype(np.float64)
+    S = (M * np.exp(2j * np.pi * rng.random((T, F)))).astype(np.complex64).astype(np.complex128)
+    p = lws_amd.lws(1024, fshift)
+    thr = np.zeros(iters)
+    out = p.batch_lws(S, thresholds=thr)
+    name = p.plan().last_kernel()["name"]
+    assert name.startswith(kernel) and "generic" not in name, name
+    ref = oracle.batch_lws(S, p.W, thr)
+    mean = np.abs(S).mean()
+    m = _bars_8c(out, ref, mean, "dense %d sweeps, random phases, lws(1024,%d), %s" % (iters, fshift, name))
+    assert m["rel_l2"] < 1e-3 and m["median"] < 1e-6 and m["p999"] < 1e-3
+    assert np.abs(np.abs(out) - np.abs(S)).max() < 1e-6 * np.abs(S).max()
+    assert abs(p.get_consistency(out) - p.get_consistency(ref)) < 0.05
+
+
 def test_config1_shape_noop_and_ten_iterations(oracle):
     fp = load_golden("config1_fingerprint.npz")
     x = np.random.default_rng(0).standard_normal(80000)

@@ -43,3 +43,29 @@ def test_geometry_matches_the_kernel_for_the_headline_shape():
     assert model.geometry(513, 4) == (520, 8, 40, 36)
     assert model.geometry(257, 4) == (512, 0, 32, 28)
     assert model.geometry(513, 2) == (520, 8, 24, 20)
+
+
+def test_prefetch_stays_inside_the_scratch_rows():
+    """lws_sys64.hip's slot 0 prefetches the neighbour frames of the next steps unconditionally; in lanes whose right-hand neighbour
+    wrapped into the next block of frames the row is `gap` further on.  The rows after the skewed state are sized from the geometry
+    (round 4 had a fixed margin of 96 rows: frames of more than ~570 bins read up to 57 KB past a spectrogram's scratch -- past the
+    allocation for the last one).  Host-side check over every frame length the engine takes (no GPU needed)."""
+    import ctypes as C
+    from lws_amd import _capi
+    lib = _capi.load_raw()
+    lib.lws_debug_sys64_layout.argtypes = [C.c_int] * 3 + [C.c_void_p]
+    seen, worst = 0, None
+    for Q in (2, 4):
+        for F in range(17, 1100, 2):
+            for T in (1, 63, 500, 3000):
+                out = (C.c_long * 4)()
+                if not lib.lws_debug_sys64_layout(F, T, Q, out):
+                    continue
+                rows, hi_read, hi_write, gap = out
+                seen += 1
+                assert hi_read < rows and hi_write < rows, (Q, F, T, list(out))
+                if worst is None or rows - 1 - hi_read < worst[0]:
+                    worst = (rows - 1 - hi_read, Q, F, T, gap)
+    assert seen > 1000 and worst[0] >= 0
+    out = (C.c_long * 4)()
+    assert lib.lws_debug_sys64_layout(601, 90, 4, out) and out[3] > 64       # lws(1200,300): a gap the fixed margin did not cover
