@@ -125,6 +125,9 @@ def compact_roofline(roof):
     # counters say actually limits the kernel (vector-ALU issue or a dependent chain: profiles/*pmc_sq*.json)
     out["limiter"] = out.get("bound")
     out["bound"] = "hbm"
+    # frac is NOT a bound for the LDS-fused kernels: several sweeps run per pass over HBM, so algorithmic bytes / time can exceed
+    # what HBM moves (2-q2: 1.3); the physical limit of those kernels is `limiter`, priced in `valu`
+    out["frac_basis"] = "algorithmic_hbm_bytes"
     v = roof.get("valu") or {}
     out["valu"] = {"peak_tflops": v.get("peak_tflops"), "frac_naive": _sig(v.get("frac_naive"), 4), "frac_factored": _sig(v.get("frac_factored"), 4)}
     if isinstance(out.get("traffic_source"), str):

@@ -307,7 +307,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     if constexpr (std::is_same<real, float>::value) {
         // online driver: frames of the moving window live in LDS when the shape allows it
         if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) &&
-            lws::online_lds_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update, p->twiddle_all ? p->tw_P : 0, p->tw_s)) {
+            lws::online_lds_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update, p->twiddle_all ? p->tw_P : 0, p->tw_s, p->online_tw.p != nullptr)) {
             begin_timing(p, s);
             hipError_t e = lws::launch_online_lds(a, B, p->tw_P, p->tw_s, static_cast<const float *>(p->online_tw.p), s);
             end_timing(p, s);

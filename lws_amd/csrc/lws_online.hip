@@ -1701,10 +1701,12 @@ bool online_static_twiddles(int Q, int tw_P, int tw_s) {
     const char *ev = getenv("LWS_ONLINE_TABLE_TWIDDLES");
     return tw_P == Q && tw_s == 1 && (Q == 2 || Q == 4 || Q == 8) && !(ev && ev[0] == '1');
 }
-static bool static_twiddles(int Q, int tw_P, int tw_s) { return online_static_twiddles(Q, tw_P, tw_s); }
-bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update, int tw_P, int tw_s) {
+// `table`: the plan's decision (latched when it was made: it uploaded the table or it did not), never re-read from the environment
+bool online_lds_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update, int tw_P, int tw_s, bool table) {
     if (update != 2 || tw_P < 1) return false;
-    if (static_twiddles(Q, tw_P, tw_s))
+    const bool eighth_turns = tw_P == Q && tw_s == 1 && (Q == 2 || Q == 4 || Q == 8);
+    if (!table && !eighth_turns) return false;     // (a structure that needs a table the plan does not have, e.g. Q > 8)
+    if (!table)
         return shape_of(F, T, L, Q, Q, LA, n_thr).ok || shape3_of(F, T, L, Q, Q, LA, n_thr).ok || shape4_of(F, T, L, Q, Q, LA, n_thr).sh.ok;
     return shape4_of(F, T, L, Q, Q, LA, n_thr, tw_P).sh.ok;
 }
@@ -1777,9 +1779,9 @@ hipError_t launch_online_lds(const GenericArgs<float> &g, int B, int tw_P, int t
     a.state = g.state; a.amp = g.amp; a.thr = g.thr;
     for (int i = 0; i < 3; ++i) a.w[i] = g.w[i].w;
     a.twt = reinterpret_cast<const float2 *>(tw_table_dev); a.PT = tw_P;
-    if (!static_twiddles(g.Q, tw_P, tw_s)) {       // table twiddles: the fourth layout only
+    if (tw_table_dev) {                            // table twiddles (the plan uploaded one): the fourth layout only
         const Shape4 t4 = shape4_of(g.F, g.T, g.L, g.Q, g.Q, g.LA, g.n_thr, tw_P);
-        if (!t4.sh.ok || !tw_table_dev) return hipErrorInvalidValue;
+        if (!t4.sh.ok) return hipErrorInvalidValue;
         for (int q = 0; q < 8; ++q) a.tw[q] = make_float2(1.f, 0.f);   // (unused)
         a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = t4.sh.NSW; a.DS = t4.sh.DS;
         a.NWR = t4.NWR; a.NPS = t4.NPS; a.Lu = g.L;
