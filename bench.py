@@ -313,10 +313,41 @@ def roofline_block(alg_bytes, k_ms, active_bins, W, traffic, tsrc, kernel, launc
     return blk
 
 
+def _source_hashes():
+    """sha1 of the kernel sources next to the running library (they travel with it): a committed PMC profile names the ones it was
+    taken on (tools/collect_profiles.py), so that a kernel change without tools/profile.sh does not report stale bytes silently."""
+    import hashlib
+    out = {}
+    d = os.path.join(ROOT, "lws_amd", "csrc")
+    for fn in ("lws_systolic.hip", "lws_online.hip", "lws_nofuture.hip", "lws_common.h"):
+        try:
+            out[fn] = hashlib.sha1(open(os.path.join(d, fn), "rb").read()).hexdigest()
+        except OSError:
+            pass
+    return out
+
+
+_PROFILE_KERNEL_OF = {"systolic": "k_systolic", "online": "k_online", "nofuture": "k_nofuture"}
+
+
+def traffic_entry_matches(ent, kname):
+    """Is the profile entry `ent` a measurement of the kernel the plan just ran (`kname` = lws_last_kernel_name)?  Entries written
+    since round 5 carry that name (engine_kernel); older ones only the profiler's C++ name, checked by kernel family."""
+    if not ent or not kname:
+        return False
+    if ent.get("engine_kernel"):
+        return ent["engine_kernel"] == kname
+    fam = next((v for k, v in _PROFILE_KERNEL_OF.items() if str(kname).startswith(k)), None)
+    return bool(fam) and fam in str(ent.get("kernel", ""))
+
+
 def load_traffic(kname, config, stage=None):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*.json): NOT measured in
-    this run -- PMC collection needs the profiler around the process (tools/profile.sh regenerates the files)."""
-    for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    this run -- PMC collection needs the profiler around the process (tools/profile.sh regenerates the files).  An entry
+    recorded for another kernel than the one that just ran is refused (traffic = null, the reason in traffic_source); one whose
+    kernel source has changed since is returned marked STALE."""
+    refused = None
+    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
             continue
@@ -328,8 +359,17 @@ def load_traffic(kname, config, stage=None):
         if ent and stage:
             ent = ent.get(stage)
         if ent and ent.get("hbm_bytes_per_launch"):
-            return ent["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; not this run)" % fn
-    return None, None
+            if "kernel" in ent and not traffic_entry_matches(ent, kname):
+                refused = refused or "refused profiles/%s: taken on %s, this run's kernel is %s" % (fn, ent.get("engine_kernel") or str(ent.get("kernel"))[:60], kname)
+                continue
+            src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; not this run)" % fn
+            rec = d.get("_sources") or {}
+            now = _source_hashes()
+            changed = sorted(k for k in rec if k in now and rec[k] != now[k])
+            if changed:
+                src = "STALE (%s changed since) " % ",".join(changed) + src
+            return ent["hbm_bytes_per_launch"], src
+    return None, refused
 
 
 def _free_port():

@@ -22,6 +22,13 @@ double *mxGetPr(const mxArray *a);
 double *mxGetPi(const mxArray *a);
 double mxGetScalar(const mxArray *a);
 mxArray *mxCreateNumericArray(mwSize ndim, const mwSize *dims, mxClassID cls, mxComplexity cplx);
+mxArray *mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity cplx);
+void mxSetM(mxArray *a, mwSize m);
+void mxSetN(mxArray *a, mwSize n);
+void *mxMalloc(size_t n);
+void mxFree(void *p);
+void mxSetData(mxArray *a, void *p);
+void mxSetImagData(mxArray *a, void *p);
 int mexPrintf(const char *fmt, ...);
 int mexAtExit(void (*fn)(void));
 

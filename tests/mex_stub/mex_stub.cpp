@@ -2,6 +2,7 @@
 // uses to invoke a gateway's mexFunction with numpy buffers.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -10,8 +11,10 @@
 
 struct mxArray_tag {
     std::vector<mwSize> dims;
-    std::vector<double> re, im;
+    std::vector<double> re, im;      // storage the stub allocated ...
+    double *xre = nullptr, *xim = nullptr;   // ... or storage handed over with mxSetData / mxSetImagData (mxMalloc'd: freed with the array)
     bool cplx = false;
+    ~mxArray_tag() { free(xre); free(xim); }
 };
 
 static std::string g_log;
@@ -29,9 +32,21 @@ size_t mxGetN(const mxArray *a) {
     return n;
 }
 size_t mxGetNumberOfElements(const mxArray *a) { return a->dims[0] * mxGetN(a); }
-double *mxGetPr(const mxArray *a) { return const_cast<double *>(a->re.data()); }
-double *mxGetPi(const mxArray *a) { return a->cplx ? const_cast<double *>(a->im.data()) : nullptr; }
-double mxGetScalar(const mxArray *a) { return a->re.empty() ? 0.0 : a->re[0]; }
+double *mxGetPr(const mxArray *a) { return a->xre ? a->xre : const_cast<double *>(a->re.data()); }
+double *mxGetPi(const mxArray *a) { return !a->cplx ? nullptr : (a->xim ? a->xim : const_cast<double *>(a->im.data())); }
+double mxGetScalar(const mxArray *a) { return mxGetNumberOfElements(a) ? mxGetPr(a)[0] : 0.0; }
+
+// the pre-2018 way of building an output (what the reference's gateways do: an empty matrix, then dimensions and mxMalloc'd planes)
+mxArray *mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity c) {
+    const mwSize dims[2] = {m, n};
+    return mxCreateNumericArray(2, dims, mxDOUBLE_CLASS, c);
+}
+void mxSetM(mxArray *a, mwSize m) { a->dims[0] = m; }
+void mxSetN(mxArray *a, mwSize n) { a->dims.resize(2); a->dims[1] = n; }
+void *mxMalloc(size_t n) { return malloc(n ? n : 1); }
+void mxFree(void *p) { free(p); }
+void mxSetData(mxArray *a, void *p) { free(a->xre); a->xre = static_cast<double *>(p); }
+void mxSetImagData(mxArray *a, void *p) { free(a->xim); a->xim = static_cast<double *>(p); a->cplx = true; }
 
 mxArray *mxCreateNumericArray(mwSize ndim, const mwSize *dims, mxClassID, mxComplexity c) {
     mxArray *a = new mxArray_tag;
@@ -84,8 +99,8 @@ int mexstub_call(int nrhs, const double **re, const double **im, const int *ndim
     if (plhs[0]) {
         const long n = (long)mxGetNumberOfElements(plhs[0]);
         if (n <= out_cap) {
-            memcpy(out_re, plhs[0]->re.data(), n * sizeof(double));
-            if (plhs[0]->cplx) memcpy(out_im, plhs[0]->im.data(), n * sizeof(double));
+            memcpy(out_re, mxGetPr(plhs[0]), n * sizeof(double));
+            if (plhs[0]->cplx) memcpy(out_im, mxGetPi(plhs[0]), n * sizeof(double));
             for (int d = 0; d < 3; ++d) out_dims[d] = d < (int)plhs[0]->dims.size() ? (long)plhs[0]->dims[d] : 1;
             produced = 1;
         }

@@ -91,6 +91,58 @@ def test_gateways_check_arguments_like_the_reference(gateways):
         assert out is None and log.startswith("lws:")
 
 
+REFERENCE = os.environ.get("LWS_REFERENCE", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REFERENCE, "matlab", "batch_lws.cpp")),
+                    reason="the reference tree is only mounted in the build container")
+def test_reference_gateways_compile_and_link_against_the_compat_header(tmp_path):
+    """the reference's OWN mex gateways (matlab/{batch,nofuture,online}_lws.cpp, compiled where they lie -- nothing is
+    copied into the repository and the objects stay in pytest's tmp dir, they do not travel) build unchanged against the product's
+    replacement for lwslib.h (include/lwslib_compat.h, reached through a one-line lwslib.h on the include path) and the test-only mx
+    stub, and every lwslib symbol they need is resolved by liblws_hip.so under the reference's C++ mangling."""
+    import lws_amd._capi as capi
+    capi.load()
+    inc = tmp_path / "inc"
+    inc.mkdir()
+    (inc / "lwslib.h").write_text('#include "lwslib_compat.h"\n')
+    want = {"batch_lws": ["_Z5LWSQ4PdS_S_S_PiS_iiid", "_Z5LWSQ2PdS_S_S_PiS_iiid", "_Z7LWSanyQPdS_S_S_PiS_iiiid", "_Z10ExtendSpecPdS_S_S_iiii"],
+            "nofuture_lws": ["_Z14NoFuture_LWSQ4PdS_S_S_PiS_iiid", "_Z16NoFuture_LWSanyQPdS_S_S_PiS_iiiid"],
+            "online_lws": ["_Z11TF_RTISI_LAPdS_S_S_S_S_S_S_PiS0_S0_S_iiiiiidiS_i", "_Z8CopySpecPdS_S_S_iiii"]}
+    exported = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "lws_amd", "liblws_hip.so")], capture_output=True, text=True).stdout
+    for g in GATEWAYS:
+        so = str(tmp_path / f"ref_{g}.so")
+        out = subprocess.run(
+            ["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-w", "-Wl,--no-undefined", "-I", str(inc), "-I", os.path.join(ROOT, "tests", "mex_stub"),
+             "-I", os.path.join(ROOT, "include"), os.path.join(REFERENCE, "matlab", g + ".cpp"),
+             os.path.join(ROOT, "tests", "mex_stub", "mex_stub.cpp"), "-L", os.path.join(ROOT, "lws_amd"), "-llws_hip",
+             "-Wl,-rpath," + os.path.join(ROOT, "lws_amd"), "-o", so], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-3000:]
+        undef = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+        for sym in want[g]:
+            assert sym in undef, (g, sym)          # the gateway calls it ...
+            assert sym in exported, sym            # ... and the MI355X library provides it
+        lib = C.CDLL(so)                            # (RTLD_NOW: every symbol resolves)
+        lib.mexstub_call.restype = C.c_int
+        out_, log = call(lib, np.ones((33, 6)))     # the reference's own argument check, through the stub
+        assert out_ is None and "not enought inputs" in log
+        if not have_gpu():
+            continue
+        # on a box with a GPU and the reference tree (none today): the reference's gateway code on the MI355X engine
+        g_, h = load_golden("wrappers.npz"), load_golden("helpers.npz")
+        W, W_ai, W_af = (matlab_weights(h[f"{k}_64_16"]) for k in ("W", "W_ai", "W_af"))
+        S, thr = g_["S_64_16"], g_["thr_64_16"]
+        if g == "batch_lws":
+            o, log = call(lib, S.T, W, thr)
+            assert np.abs(o.T - g_["batch_64_16"]).max() < 1e-8
+        elif g == "nofuture_lws":
+            o, log = call(lib, S.T, W_ai, thr[:2])
+            assert np.abs(o.T - g_["nofuture_64_16"]).max() < 1e-8
+        else:
+            o, log = call(lib, S.T, W, W_ai, W_af, thr[:3], np.array(3.0))
+            assert np.abs(o.T - g_["online_64_16"]).max() < 1e-8
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["64_16", "64_32", "64_8"])
 def test_gateways_reproduce_wrapper_goldens(gateways, tag, monkeypatch):

@@ -46,6 +46,28 @@ res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pas
                "bytes -> doubled here; WRITE_SIZE is exact.  hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) * 1024 of the LAST "
                "launch of the update kernel (the timed step; the warm-up launch of the big shapes runs 3 sweeps only).",
        "configs": {}}
+import hashlib
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+res["_sources"] = {}
+for fn in ("lws_systolic.hip", "lws_online.hip", "lws_nofuture.hip", "lws_common.h"):   # what bench.py's load_traffic compares with
+    try:
+        res["_sources"][fn] = hashlib.sha1(open(os.path.join(root, "lws_amd", "csrc", fn), "rb").read()).hexdigest()
+    except OSError:
+        pass
+
+
+def engine_names(cfg):
+    """lws_last_kernel_name of the profiled run (the bench line / extra file tools/profile.sh kept): {stage: name}"""
+    try:
+        if cfg == "3":
+            c3 = json.load(open(os.path.join(prof, "extra_3.json")))["extra"]["configs"]["3"]
+            return {st: c3[st]["kernel"] for st in ("nofuture", "online", "batch") if st in c3}
+        last = [l for l in open(os.path.join(prof, "pmc_line_%s.json" % cfg)).read().splitlines() if l.startswith("{")][-1]
+        return {"batch": json.loads(last)["roofline"]["kernel"]}
+    except Exception:
+        return {}
+
+
 for cfg in list(SHAPES) + ["3"]:
     per = {}
     for cn in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -68,7 +90,7 @@ for cfg in list(SHAPES) + ["3"]:
         if key is None or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
             continue
         f, w = d["FETCH_SIZE"][-1], d["WRITE_SIZE"][-1]
-        ent[key] = {"kernel": n[:160], "launches_seen": len(d["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
+        ent[key] = {"engine_kernel": engine_names(cfg).get(key), "kernel": n[:160], "launches_seen": len(d["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                     "hbm_bytes_per_launch": (2 * f + w) * 1024}
     if cfg in SHAPES and "batch" in ent:
         B, T, F, it, bpb = SHAPES[cfg]
