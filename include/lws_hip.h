@@ -167,7 +167,7 @@ const char *lws_last_kernel_name(lws_plan *plan);
 const char *lws_generic_stage(lws_plan *plan);
 
 /* ---- the steps either side of the path, on the device (lws.pyx:43-144; float32, any even frame size N in [32, 4096]
- *      -- an odd factor times a power of two: radix-2 stages and one stage of odd-point DFTs --, fftsize == fsize).  Windows are host arrays of N doubles, already normalised the way the caller
+ *      -- an odd factor times a power of two: radix-2 stages and one stage of odd-point DFTs; fftsize == fsize unless said otherwise).  Windows are host arrays of N doubles, already normalised the way the caller
  *      wants them (class lws: awin and synthwin(awin, fshift)).  perfectrec as in lws.pyx:55-67,130-137. ---- */
 
 /* Frames stft() produces for a signal of `len` samples (lws.pyx:55-76); < 1 if the signal is too short. */
@@ -180,6 +180,12 @@ int lws_stft_dev(int device, const float *x_dev, int B, int len, int N, int fshi
 /* istft (lws.pyx:93-137) of S_dev[B][M][N/2+1] (complex64) into x_dev[B][lws_istft_length()] (float32). */
 int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *swin,
                   int perfectrec, float *x_dev, void *stream);
+/* stft with a transform longer than the frame (lws.pyx:49-50,85: np.fft.fft(frame, n = fftsize) of the fsize windowed samples,
+ * zeros behind them): fsize even, fsize <= fftsize, fftsize an even size in [32, 4096]; frame count and padding follow fsize
+ * (M = lws_stft_frames(len, fsize, ...)); awin has fsize entries; S_dev[B][M][fftsize/2+1].  (There is no inverse counterpart: the
+ * reference's istft raises for every fftsize != 2 (bins - 1), lws.pyx:107-126; class lws pads its windows instead, 396-411.) */
+int lws_stft_zp_dev(int device, const float *x_dev, int B, int len, int fsize, int fftsize, int fshift, const double *awin,
+                    int perfectrec, void *S_dev, void *stream);
 /* get_consistency (lws.pyx:140-144) per spectrogram: out[2b] = sum |S|^2, out[2b+1] = sum |stft(istft(S)) - S|^2
  * (fp64 sums of the fp32 transform); consistency in dB = 10 log10(out[2b] / out[2b+1]).  out: HOST, 2*B doubles
  * (synchronises).  Sums of several spectrograms / ranks add up to the batch consistency. */

@@ -7,6 +7,7 @@ loops run as HIP kernels on gfx950 through the C ABI of include/lws_hip.h.
 from .lws import (  # noqa: F401
     __version__, hann, synthwin, stft, istft, get_consistency, extspec, create_weights,
     build_asymmetric_windows, get_thresholds, batch_lws, nofuture_lws, online_lws, lws, clear_plan_cache,
+    stft_dev, istft_dev,
 )
 from . import _capi  # noqa: F401
 from ._capi import Plan, MultiPlan, LwsHipError  # noqa: F401

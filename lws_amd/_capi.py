@@ -29,7 +29,7 @@ EXPORTS = (
     "lws_hip_version", "lws_last_error", "lws_device_count", "lws_plan_create", "lws_plan_destroy",
     "lws_batch_lws", "lws_nofuture_lws", "lws_online_lws", "lws_run_lws", "lws_batch_lws_dev",
     "lws_nofuture_lws_dev", "lws_online_lws_dev", "lws_residual_dev", "lws_last_kernel_time",
-    "lws_last_kernel_name", "lws_generic_stage", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev",
+    "lws_last_kernel_name", "lws_generic_stage", "lws_stft_frames", "lws_istft_length", "lws_stft_dev", "lws_istft_dev", "lws_stft_zp_dev",
     "lws_consistency_dev", "lws_hann", "lws_synthwin", "lws_weights_shape", "lws_create_weights",
     "lws_build_asymmetric_windows", "lws_get_thresholds", "lws_plan_create_from_windows", "lws_stream_copy",
     "lws_run_lws_dev", "lws_plan_reserve", "lws_residual", "lws_residual_allreduce_dev", "lws_weights_structure", "lws_multi_plan_create", "lws_multi_plan_destroy",
@@ -99,6 +99,7 @@ def load():
     lib.lws_istft_length.argtypes = [ip, ip, ip, ip]
     lib.lws_stft_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp]
     lib.lws_istft_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp]
+    lib.lws_stft_zp_dev.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, vp, vp]
     lib.lws_consistency_dev.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp]
     dp = C.c_double
     lib.lws_hann.argtypes = [ip, ip, ip, vp]
@@ -417,11 +418,15 @@ def istft_length(frames, fsize, fshift, perfectrec):
     return load().lws_istft_length(int(frames), int(fsize), int(fshift), int(bool(perfectrec)))
 
 
-def stft_dev(x_ptr, B, length, fsize, fshift, awin, perfectrec, S_ptr, device=0, stream=None):
-    """x_ptr: device float32 [B][length]; S_ptr: device complex64 [B][stft_frames(...)][fsize//2+1]."""
+def stft_dev(x_ptr, B, length, fsize, fshift, awin, perfectrec, S_ptr, device=0, stream=None, fftsize=None):
+    """x_ptr: device float32 [B][length]; S_ptr: device complex64 [B][stft_frames(...)][fftsize//2+1] (fftsize: fsize unless given)."""
     a = _win(awin)
-    check(load().lws_stft_dev(int(device), x_ptr, int(B), int(length), int(fsize), int(fshift), a.ctypes.data,
-                              int(bool(perfectrec)), S_ptr, stream))
+    if fftsize is None or int(fftsize) == int(fsize):
+        check(load().lws_stft_dev(int(device), x_ptr, int(B), int(length), int(fsize), int(fshift), a.ctypes.data,
+                                  int(bool(perfectrec)), S_ptr, stream))
+    else:
+        check(load().lws_stft_zp_dev(int(device), x_ptr, int(B), int(length), int(fsize), int(fftsize), int(fshift), a.ctypes.data,
+                                     int(bool(perfectrec)), S_ptr, stream))
 
 
 def istft_dev(S_ptr, B, frames, fsize, fshift, swin, perfectrec, x_ptr, device=0, stream=None):

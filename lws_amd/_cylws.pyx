@@ -245,6 +245,14 @@ def lws_istft_dev(int device, S_dev, int B, int M, int N, int fshift, swin, int 
     return rc
 
 
+def lws_stft_zp_dev(int device, x_dev, int B, int length, int fsize, int fftsize, int fshift, awin, int perfectrec, S_dev, stream):
+    cdef uintptr_t x = _addr(x_dev), a = _addr(awin), s = _addr(S_dev), st = _addr(stream)
+    cdef int rc
+    with nogil:
+        rc = c.lws_stft_zp_dev(device, <const float *>x, B, length, fsize, fftsize, fshift, <const double *>a, perfectrec, <void *>s, <void *>st)
+    return rc
+
+
 def lws_consistency_dev(int device, S_dev, int B, int M, int N, int fshift, awin, swin, int perfectrec, out, stream):
     cdef uintptr_t a = _addr(awin), w = _addr(swin), s = _addr(S_dev), o = _addr(out), st = _addr(stream)
     cdef int rc

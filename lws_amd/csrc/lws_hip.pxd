@@ -47,6 +47,8 @@ cdef extern from "lws_hip.h" nogil:
                      int perfectrec, void *S_dev, void *stream)
     int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *swin, int perfectrec,
                       float *x_dev, void *stream)
+    int lws_stft_zp_dev(int device, const float *x_dev, int B, int length, int fsize, int fftsize, int fshift, const double *awin,
+                        int perfectrec, void *S_dev, void *stream)
     int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *awin,
                             const double *swin, int perfectrec, double *out, void *stream)
     int lws_hann(int n, int symmetric, int use_offset, double *out)

@@ -127,11 +127,12 @@ __global__ void k_overlap_add(const float *frames, float *signal, int M, int N, 
     signal[(size_t)b * Tfull + t] = acc;
 }
 
-// lws.pyx:82-88: frame m = x[m*hop + n - pre] * awin[n] (zero outside the signal), FFT, bins 0..N/2.
+// lws.pyx:82-88: frame m = x[m*hop + n - pre] * awin[n] (zero outside the signal; zero for n >= fs when the transform is longer
+// than the frame: np.fft.fft(frame, n = fftsize) pads at the end), FFT, bins 0..N/2.
 // S_out != null: write the spectrogram.  rows != null: accumulate |X - S_ref|^2 and |S_ref|^2 of the frame in fp64.
 __global__ void __launch_bounds__(FFT_THREADS) k_stft_frames(const float *x, int len, int pitch, int pre, const float *awin,
                                                               float2 *S_out, const float2 *S_ref, double *rows, int M,
-                                                              int N, int odd, int log2e, int hop) {
+                                                              int fs, int N, int odd, int log2e, int hop) {
     extern __shared__ float2 lds[];
     __shared__ double red[2][FFT_THREADS];
     const int m = blockIdx.x, b = blockIdx.y, F = N / 2 + 1;
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_stft_frames(const float *x, int
     const float *sig = x + (size_t)b * pitch;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int i = m * hop + n - pre;
-        xa[n] = make_float2((i >= 0 && i < len) ? sig[i] * awin[n] : 0.f, 0.f);
+        xa[n] = make_float2((n < fs && i >= 0 && i < len) ? sig[i] * awin[n] : 0.f, 0.f);
     }
     __syncthreads();
     const float2 *r = fft_lds(xa, ya, N, odd, log2e, -1.0f);
@@ -274,11 +275,13 @@ int lws_istft_length(int M, int N, int fshift, int perfectrec) {
     return perfectrec ? Tfull - prepad(N, fshift) - (N - fshift) : Tfull;
 }
 
-int lws_stft_dev(int device, const float *x_dev, int B, int len, int N, int fshift, const double *awin, int perfectrec,
-                 void *S_dev, void *stream) {
-    const int M = lws_stft_frames(len, N, fshift, perfectrec);
+// fs: samples per frame (the window's length), N >= fs: points of the transform (fs..N-1 are zeros)
+static int stft_impl(int device, const float *x_dev, int B, int len, int fs, int N, int fshift, const double *awin, int perfectrec,
+                     void *S_dev, void *stream) {
+    const int M = lws_stft_frames(len, fs, fshift, perfectrec);
     int rc = check_shape(device, B, M, N, fshift);
     if (rc) return rc;
+    if (fs < 2 || fs > N || (fs & 1) || fshift > fs) return lws::set_error(LWS_ERR_INVALID, "frame of %d samples, transform of %d points, shift %d", fs, N, fshift);
     if (!x_dev || !S_dev) return lws::set_error(LWS_ERR_INVALID, "null device pointer");
     if (B == 0) return LWS_OK;
     STFT_TRY(hipSetDevice(device));
@@ -287,17 +290,17 @@ int lws_stft_dev(int device, const float *x_dev, int B, int len, int N, int fshi
     DeviceCtx &c = g_ctx[device];
     if ((rc = ctx_enter(c, s))) return rc;
     if ((rc = allow_lds_all())) return rc;
-    if ((rc = upload_window(c.win_a, awin, N, s))) return rc;
+    if ((rc = upload_window(c.win_a, awin, fs, s))) return rc;
     hipLaunchKernelGGL(k_stft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s, x_dev, len, len,
-                       perfectrec ? prepad(N, fshift) : 0, static_cast<const float *>(c.win_a.p),
-                       static_cast<float2 *>(S_dev), nullptr, nullptr, M, N, factor(N).odd, factor(N).log2e, fshift);
+                       perfectrec ? prepad(fs, fshift) : 0, static_cast<const float *>(c.win_a.p),
+                       static_cast<float2 *>(S_dev), nullptr, nullptr, M, fs, N, factor(N).odd, factor(N).log2e, fshift);
     STFT_TRY(hipGetLastError());
     return ctx_leave(c, s);
 }
 
-int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *swin, int perfectrec,
+int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int Nhift, const double *swin, int perfectrec,
                   float *x_dev, void *stream) {
-    int rc = check_shape(device, B, M, N, fshift);
+    int rc = check_shape(device, B, M, N, Nhift);
     if (rc) return rc;
     if (!x_dev || !S_dev) return lws::set_error(LWS_ERR_INVALID, "null device pointer");
     if (B == 0) return LWS_OK;
@@ -308,20 +311,30 @@ int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift
     if ((rc = ctx_enter(c, s))) return rc;
     if ((rc = allow_lds_all())) return rc;
     if ((rc = upload_window(c.win_s, swin, N, s))) return rc;
-    const int Tfull = fshift * (M - 1) + N, out_len = lws_istft_length(M, N, fshift, perfectrec);
+    const int Tfull = Nhift * (M - 1) + N, out_len = lws_istft_length(M, N, Nhift, perfectrec);
     if ((rc = c.frames.ensure((size_t)B * M * N * sizeof(float)))) return rc;
     if ((rc = c.signal.ensure((size_t)B * Tfull * sizeof(float)))) return rc;
     hipLaunchKernelGGL(k_istft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s,
                        static_cast<const float2 *>(S_dev), static_cast<float *>(c.frames.p),
                        static_cast<const float *>(c.win_s.p), M, N, factor(N).odd, factor(N).log2e);
     hipLaunchKernelGGL(k_overlap_add, dim3((Tfull + 255) / 256, B), dim3(256), 0, s, static_cast<const float *>(c.frames.p),
-                       static_cast<float *>(c.signal.p), M, N, fshift, Tfull, 0, 0);
+                       static_cast<float *>(c.signal.p), M, N, Nhift, Tfull, 0, 0);
     STFT_TRY(hipGetLastError());
     // lws.pyx:130-137: cut the leading pad and the last N - hop samples
-    const int off = perfectrec ? prepad(N, fshift) : 0;
+    const int off = perfectrec ? prepad(N, Nhift) : 0;
     STFT_TRY(hipMemcpy2DAsync(x_dev, (size_t)out_len * sizeof(float), static_cast<const float *>(c.signal.p) + off,
                               (size_t)Tfull * sizeof(float), (size_t)out_len * sizeof(float), B, hipMemcpyDeviceToDevice, s));
     return ctx_leave(c, s);
+}
+
+int lws_stft_dev(int device, const float *x_dev, int B, int len, int N, int fshift, const double *awin, int perfectrec,
+                 void *S_dev, void *stream) {
+    return stft_impl(device, x_dev, B, len, N, N, fshift, awin, perfectrec, S_dev, stream);
+}
+
+int lws_stft_zp_dev(int device, const float *x_dev, int B, int len, int fsize, int fftsize, int fshift, const double *awin,
+                    int perfectrec, void *S_dev, void *stream) {
+    return stft_impl(device, x_dev, B, len, fsize, fftsize, fshift, awin, perfectrec, S_dev, stream);
 }
 
 int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *awin,
@@ -353,7 +366,7 @@ int lws_consistency_dev(int device, const void *S_dev, int B, int M, int N, int 
                        perfectrec ? N - fshift : 0);
     hipLaunchKernelGGL(k_stft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s,
                        static_cast<const float *>(c.signal.p), Tfull, Tfull, 0, static_cast<const float *>(c.win_a.p),
-                       static_cast<float2 *>(nullptr), S, static_cast<double *>(c.rows.p), M, N, factor(N).odd, factor(N).log2e, fshift);
+                       static_cast<float2 *>(nullptr), S, static_cast<double *>(c.rows.p), M, N, N, factor(N).odd, factor(N).log2e, fshift);
     hipLaunchKernelGGL(k_sum_rows, dim3((B + 63) / 64), dim3(64), 0, s, static_cast<const double *>(c.rows.p),
                        static_cast<double *>(c.out.p), M, B);
     STFT_TRY(hipGetLastError());

@@ -103,7 +103,11 @@ def istft(spec, fshift, swin, awin=None, fftsize=None, perfectrec=False):
     if fftsize > len(swin):
         swin = np.concatenate([swin, np.zeros(fftsize - len(swin))])
     full = np.concatenate([spec, np.conjugate(spec[:, -2:0:-1])], axis=1)  # Hermitian completion
-    frames = np.real(np.fft.ifft(full, n=fftsize, axis=1))[:, :fsize] * np.squeeze(swin)[None, :fsize]
+    # (as in the reference, lws.pyx:107-126: the frame is 2 (bins - 1) samples, so a window of any other length -- which is what
+    # every fftsize > fsize makes of it, and an fftsize < fsize of the frame -- fails to broadcast: ValueError)
+    frames = np.real(np.fft.ifft(full, n=fftsize, axis=1))[:, :fsize] * np.squeeze(swin)[None, :]
+    if frames.shape[1] != fsize:
+        raise ValueError('operands could not be broadcast together with shapes (%d,) (%d,)' % (fsize, frames.shape[1]))
     signal = np.zeros(fshift * (M - 1) + fsize)
     for s in range(M):
         signal[fshift * s: fshift * s + fsize] += frames[s]
@@ -116,6 +120,62 @@ def get_consistency(S, fsize, fshift, awin, swin, perfectrec=False):
     """20 log10(|S| / |stft(istft(S)) - S|) in dB (lws.pyx:140-144)."""
     back = stft(istft(S, fshift, swin, perfectrec=perfectrec), fsize, fshift, awin, perfectrec=perfectrec)
     return 20 * np.log10(np.linalg.norm(S) / np.linalg.norm(back - S))
+
+
+def _dev_tensor(a, dtype, device):
+    import torch
+    dev = torch.device("cuda", int(device))
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(device=dev, dtype=dtype).contiguous()
+
+
+def stft_dev(x, fsize, fshift, awin, fftsize=None, perfectrec=False, device=0):
+    """stft() above on the device (lws_stft.hip, float32): x a signal (len,) or a stack (B, len), numpy or torch; returns a complex64
+    torch tensor (T, fftsize//2+1) / (B, T, ...).  fftsize > fsize: the fsize windowed samples followed by zeros, as
+    np.fft.fft(frame, n=fftsize) does (lws.pyx:49-50,85); any even fftsize in [32, 4096]."""
+    import torch
+    if fftsize is None:
+        fftsize = fsize
+    if fftsize % 2 == 1:
+        raise ValueError('Odd ffts not supported.')
+    t = _dev_tensor(x, torch.float32, device)
+    if t.dim() not in (1, 2):
+        raise ValueError('We only deal with single channel signals here')
+    single = t.dim() == 1
+    if single:
+        t = t[None]
+    B, n = t.shape
+    T = _capi.stft_frames(n, fsize, fshift, perfectrec)
+    out = torch.empty((B, T, fftsize // 2 + 1), dtype=torch.complex64, device=t.device)
+    _capi.stft_dev(t.data_ptr(), B, n, fsize, fshift, np.asarray(awin, dtype=np.float64), perfectrec, out.data_ptr(), device=int(device),
+                   stream=torch.cuda.current_stream(t.device).cuda_stream, fftsize=fftsize)
+    return out[0] if single else out
+
+
+def istft_dev(spec, fshift, swin, awin=None, fftsize=None, perfectrec=False, device=0):
+    """istft() above on the device: spec (T, F) or (B, T, F), numpy or torch; returns a float32 torch tensor (len,) / (B, len).
+    As in the reference (lws.pyx:107-126) the frame is 2 (F - 1) samples and any other fftsize / window length is a ValueError."""
+    import torch
+    t = _dev_tensor(spec, torch.complex64, device)
+    if t.dim() not in (2, 3):
+        raise ValueError('We only deal with single channel signals here')
+    single = t.dim() == 2
+    if single:
+        t = t[None]
+    B, T, N = t.shape
+    if N % 2 != 1:
+        raise ValueError('We expect the spectrogram to only have non-negative frequencies')
+    fsize = 2 * (N - 1)
+    if awin is not None:
+        swin = synthwin(awin, fshift, swin=swin)
+    swin = np.squeeze(np.asarray(swin, dtype=np.float64))
+    if (fftsize is not None and fftsize != fsize) or swin.shape != (fsize,):
+        raise ValueError('operands could not be broadcast together with shapes (%d,) (%d,)' % (fsize, max(swin.size, fftsize or 0)))
+    n = _capi.istft_length(T, fsize, fshift, perfectrec)
+    out = torch.empty((B, n), dtype=torch.float32, device=t.device)
+    _capi.istft_dev(t.data_ptr(), B, T, fsize, fshift, swin, perfectrec, out.data_ptr(), device=int(device),
+                    stream=torch.cuda.current_stream(t.device).cuda_stream)
+    return out[0] if single else out
 
 
 def extspec(S, L, Q):

@@ -271,8 +271,39 @@ def extra():
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
 
+def fftsize():
+    """stft / istft with a transform longer than the frame (lws.pyx:49-50,85,100-121) and class lws(fftsize=...), which pads its
+    windows instead (lws.pyx:396-411) (added in round 5; `python make_golden.py fftsize` writes only this file)."""
+    ref = build_reference_module()
+    rng = np.random.default_rng(20260928 + 9)
+    out = {"x": rng.standard_normal(330)}
+    for fsize, nfft, hop in ((64, 128, 16), (48, 96, 16), (100, 128, 40)):
+        k = f"{fsize}_{nfft}_{hop}"
+        awin = np.sqrt(ref.hann(fsize, symmetric=True, use_offset=False))
+        swin = ref.synthwin(awin, hop)
+        out[f"awin_{k}"], out[f"swin_{k}"] = awin, swin
+        for pr in (False, True):
+            out[f"stft_{k}_{int(pr)}"] = ref.stft(out["x"], fsize, hop, awin, fftsize=nfft, perfectrec=pr)
+        spec = rng.standard_normal((9, fsize // 2 + 1)) + 1j * rng.standard_normal((9, fsize // 2 + 1))
+        try:      # the reference's istft cannot take fftsize != 2 (bins - 1): the window no longer broadcasts (lws.pyx:107-126)
+            ref.istft(spec, hop, swin, fftsize=nfft)
+            out[f"istft_raises_{k}"] = np.array(0)
+        except ValueError:
+            out[f"istft_raises_{k}"] = np.array(1)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = ref.lws(64, 16, fftsize=96)
+    out["cls_awin_64_96_16"], out["cls_swin_64_96_16"], out["cls_W_64_96_16"] = p.awin, p.swin, p.W
+    out["cls_stft_64_96_16"] = p.stft(out["x"])
+    out["cls_istft_64_96_16"] = p.istft(out["cls_stft_64_96_16"])
+    np.savez_compressed(os.path.join(HERE, "fftsize.npz"), **out)
+    print("fftsize.npz", os.path.getsize(os.path.join(HERE, "fftsize.npz")))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fftsize":
+        fftsize()
     else:
         main()

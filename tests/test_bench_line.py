@@ -130,3 +130,32 @@ def test_self_launch_stops_the_job_when_a_rank_fails(tmp_path):
     out, got = _launch(tmp_path, 3, ["--gpus", "3"], 3, "import time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(60)\n")
     assert out.returncode == 7 and "rank 1 exited with code 7" in out.stderr
     assert _t.time() - t0 < 30                                          # the other ranks were stopped, not waited for
+
+
+def test_traffic_profile_of_another_kernel_is_refused(tmp_path, monkeypatch):
+    """roofline.traffic comes from committed rocprofv3 --pmc passes, not from the timed run: an entry taken on another kernel than
+    the one the plan just ran is refused (traffic null, the reason in traffic_source), a changed kernel source marks it STALE."""
+    assert bench.traffic_entry_matches({"kernel": "void lws::(anonymous namespace)::k_systolic<4, 5, 1ul, false, false, 0>(...)"}, "systolic_q4_l5_hann")
+    assert not bench.traffic_entry_matches({"kernel": "void lws::(anonymous namespace)::k_systolic<4, 5, 1ul>(...)"}, "generic_skew_fp32")
+    assert not bench.traffic_entry_matches({"kernel": "k_online4<...>"}, "systolic_q4_l5_hann")
+    assert bench.traffic_entry_matches({"engine_kernel": "online_lds_fp32", "kernel": "k_online4"}, "online_lds_fp32")
+    assert not bench.traffic_entry_matches({"engine_kernel": "systolic_q4_l5_hann", "kernel": "k_systolic"}, "systolic_q4_l3_hann")
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    (root / "lws_amd" / "csrc").mkdir(parents=True)
+    (root / "lws_amd" / "csrc" / "lws_systolic.hip").write_text("v1")
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    prof = {"_sources": bench._source_hashes(),
+            "configs": {"2": {"engine_kernel": "systolic_q4_l5_hann", "kernel": "k_systolic<4>", "hbm_bytes_per_launch": 2.0e10}}}
+    (root / "profiles" / "r05_pmc_traffic.json").write_text(json.dumps(prof))
+    t, src = bench.load_traffic("systolic_q4_l5_hann", "2")
+    assert t == 2.0e10 and "STALE" not in src
+    t, src = bench.load_traffic("generic_skew_fp32", "2")
+    assert t is None and "refused" in src and "generic_skew_fp32" in src
+    (root / "lws_amd" / "csrc" / "lws_systolic.hip").write_text("v2")
+    t, src = bench.load_traffic("systolic_q4_l5_hann", "2")
+    assert t == 2.0e10 and src.startswith("STALE (lws_systolic.hip")
+    # the committed profile still matches what the headline plan runs
+    monkeypatch.undo()
+    t, src = bench.load_traffic("systolic_q4_l5_hann", "2")
+    assert t and t > 1e10

@@ -7,7 +7,71 @@ import torch
 
 import lws_amd
 
+from conftest import load_golden
+
 pytestmark = pytest.mark.gpu
+
+
+def test_device_transforms_against_the_reference_goldens():
+    """Directly against tests/golden/helpers.npz (made by importing the reference, tests/golden/make_golden.py:70-81): stft /
+    istft of lws.lws(64,16) with and without perfectrec, and get_consistency -- not through the host restatement."""
+    g = load_golden("helpers.npz")
+    p = lws_amd.lws(64, 16)
+    x = g["x"]
+    X = p.stft_dev(x).cpu().numpy()
+    assert X.shape == g["stft_64_16"].shape
+    assert np.abs(X - g["stft_64_16"]).max() < 3e-6 * np.abs(g["stft_64_16"]).max()
+    y = p.istft_dev(g["stft_64_16"]).cpu().numpy()
+    assert y.shape == g["istft_64_16"].shape and np.abs(y - g["istft_64_16"]).max() < 3e-6 * np.abs(g["istft_64_16"]).max()
+    Xn = lws_amd.stft_dev(x, 64, 16, p.awin, perfectrec=False).cpu().numpy()                      # lws.pyx:43-90, module level
+    assert Xn.shape == g["stft_np_64_16"].shape and np.abs(Xn - g["stft_np_64_16"]).max() < 3e-6 * np.abs(g["stft_np_64_16"]).max()
+    yn = lws_amd.istft_dev(g["stft_np_64_16"], 16, p.swin, perfectrec=False).cpu().numpy()        # lws.pyx:93-137
+    assert yn.shape == g["istft_np_64_16"].shape and np.abs(yn - g["istft_np_64_16"]).max() < 3e-6 * np.abs(g["istft_np_64_16"]).max()
+    c = p.get_consistency_dev(np.abs(g["stft_64_16"]).astype(complex))
+    assert abs(c - float(g["consistency_64_16"])) < 0.01
+
+
+@pytest.mark.parametrize("fsize,fftsize,fshift", [(64, 128, 16), (48, 96, 16), (100, 128, 40), (400, 512, 160), (1000, 1024, 250), (1024, 4096, 256), (250, 1000, 100)])
+@pytest.mark.parametrize("perfectrec", [True, False])
+def test_transform_longer_than_the_frame(fsize, fftsize, fshift, perfectrec):
+    """fftsize > fsize (lws.pyx:49-50,85: np.fft.fft(frame, n=fftsize) of the fsize windowed samples; the frame count and padding
+    follow fsize): against the reference goldens of tests/golden/fftsize.npz where there is one, else against the host restatement
+    (which tests/test_host_helpers.py pins to those goldens).  The inverse with fftsize != frame is a ValueError, as in the reference."""
+    g = load_golden("fftsize.npz")
+    k = "%d_%d_%d" % (fsize, fftsize, fshift)
+    if f"awin_{k}" in g.files:
+        X = lws_amd.stft_dev(g["x"], fsize, fshift, g[f"awin_{k}"], fftsize=fftsize, perfectrec=perfectrec).cpu().numpy()
+        ref = g[f"stft_{k}_{int(perfectrec)}"]
+        assert X.shape == ref.shape and np.abs(X - ref).max() < 3e-6 * np.abs(ref).max()
+    rng = np.random.default_rng(fsize + fftsize)
+    awin = np.sqrt(lws_amd.hann(fsize, symmetric=True, use_offset=False))
+    n = 9 * fsize + 13
+    x = rng.standard_normal((2, n))
+    S = lws_amd.stft_dev(x, fsize, fshift, awin, fftsize=fftsize, perfectrec=perfectrec).cpu().numpy()
+    ref = np.stack([lws_amd.stft(x[b], fsize, fshift, awin, fftsize=fftsize, perfectrec=perfectrec) for b in range(2)])
+    assert S.shape == ref.shape == (2, ref.shape[1], fftsize // 2 + 1)
+    assert np.abs(S - ref).max() < 3e-6 * np.abs(ref).max()
+    swin = lws_amd.synthwin(awin, fshift)
+    spec = rng.standard_normal((2, 11, fsize // 2 + 1)) + 1j * rng.standard_normal((2, 11, fsize // 2 + 1))
+    with pytest.raises(ValueError):
+        lws_amd.istft_dev(spec, fshift, swin, fftsize=fftsize)
+    with pytest.raises(ValueError):
+        lws_amd.stft_dev(x, fsize, fshift, awin, fftsize=fftsize + 1)
+    with pytest.raises((ValueError, lws_amd.LwsHipError)):
+        lws_amd.stft_dev(x, fsize, fshift, awin, fftsize=fsize - 2)           # a transform shorter than the frame
+
+
+def test_class_with_fftsize_pads_its_windows():
+    """class lws(fsize, fshift, fftsize=...) zero-pads its windows symmetrically (lws.pyx:396-411) and works on fftsize-point frames
+    from there on: the device transforms against the reference golden."""
+    import contextlib, io
+    g = load_golden("fftsize.npz")
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = lws_amd.lws(64, 16, fftsize=96)
+    X = p.stft_dev(g["x"]).cpu().numpy()
+    assert np.abs(X - g["cls_stft_64_96_16"]).max() < 3e-6 * np.abs(g["cls_stft_64_96_16"]).max()
+    y = p.istft_dev(g["cls_stft_64_96_16"]).cpu().numpy()
+    assert np.abs(y - g["cls_istft_64_96_16"]).max() < 3e-6 * np.abs(g["cls_istft_64_96_16"]).max()
 
 
 @pytest.mark.parametrize("fsize,fshift", [(64, 16), (128, 64), (512, 128), (1024, 256), (2048, 512), (256, 96), (4096, 1024),

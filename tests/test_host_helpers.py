@@ -89,3 +89,33 @@ def test_mode_presets_and_kwargs():
     assert (p.nofuture_iterations, p.online_iterations) == (0, 0)
     assert p.Q == 4 and p.L == 5 and p.look_ahead == 3 and p.fsize == 64
     assert lws_amd.__version__ == "1.2.8"
+
+
+def test_transform_longer_than_the_frame_goldens():
+    """stft(..., fftsize > fsize) (lws.pyx:49-50,85), istft's ValueError for every fftsize != 2 (bins - 1) (lws.pyx:107-126), and
+    class lws(fftsize=...), which pads its windows symmetrically instead (lws.pyx:396-411): tests/golden/fftsize.npz, made by
+    importing the reference (make_golden.py fftsize)."""
+    import contextlib, io
+    g = load_golden("fftsize.npz")
+    for k in ("64_128_16", "48_96_16", "100_128_40"):
+        fsize, nfft, hop = (int(v) for v in k.split("_"))
+        awin, swin = g[f"awin_{k}"], g[f"swin_{k}"]
+        assert np.abs(lws_amd.synthwin(awin, hop) - swin).max() < 1e-14
+        for pr in (False, True):
+            X = lws_amd.stft(g["x"], fsize, hop, awin, fftsize=nfft, perfectrec=pr)
+            ref = g[f"stft_{k}_{int(pr)}"]
+            assert X.shape == ref.shape and np.abs(X - ref).max() < 1e-12
+        assert int(g[f"istft_raises_{k}"]) == 1
+        spec = np.ones((5, fsize // 2 + 1), complex)
+        with pytest.raises(ValueError):
+            lws_amd.istft(spec, hop, swin, fftsize=nfft)
+        with pytest.raises(ValueError):
+            lws_amd.istft(spec, hop, np.concatenate([swin, [0.0, 0.0]]))       # a window that is not the frame's length
+        assert lws_amd.istft(spec, hop, swin).shape == (hop * 4 + fsize,)
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        p = lws_amd.lws(64, 16, fftsize=96)
+    assert "Zero-padding symmetrically" in out.getvalue()
+    assert p.fsize == 96 and np.abs(p.awin - g["cls_awin_64_96_16"]).max() < 1e-14 and np.abs(p.swin - g["cls_swin_64_96_16"]).max() < 1e-13
+    assert np.abs(p.W - g["cls_W_64_96_16"]).max() < 1e-12
+    X = p.stft(g["x"])
+    assert np.abs(X - g["cls_stft_64_96_16"]).max() < 1e-12 and np.abs(p.istft(X) - g["cls_istft_64_96_16"]).max() < 1e-12
