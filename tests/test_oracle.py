@@ -186,3 +186,25 @@ def test_config3_and_config5_fingerprints(oracle):
     p5 = lws_amd.lws(2048, 512)
     Y = oracle.batch_lws(M, p5.W, fp["thr"])
     assert np.abs(Y.ravel()[::97] - fp["sample_out"]).max() < 1e-8
+
+
+def test_fp16_storage_model_reduces_to_the_oracle_without_rounding():
+    """tests/fp16_model.py (the checker of the fp16 storage mode): with the half rounding switched off it is batch_lws on the
+    complex64 input up to the float32 rounding of thresholds and returned magnitudes; with it, it differs at the 2^-11 level."""
+    from fp16_model import fp16_storage_batch, store_scale, half
+    from oracle.oracle import Oracle
+    o = Oracle()
+    rng = np.random.default_rng(1)
+    W = load_golden("helpers.npz")["W_64_16"]
+    S = (rng.standard_normal((30, 33)) + 1j * rng.standard_normal((30, 33))) * 37.0
+    thr = np.array([50.0, 1.2, 0.6, 0.3, 0.0, 0.0, 0.0, 0.0, 0.0])
+    ref = o.batch_lws(S.astype(np.complex64).astype(np.complex128), W, thr)
+    plain = fp16_storage_batch(o, S, W, thr, 7, round_state=False)
+    assert np.abs(plain - ref).max() < 2e-6 * np.abs(S).max()
+    h = fp16_storage_batch(o, S, W, thr, 7)
+    d = np.abs(h - ref)
+    assert 1e-5 < np.median(d) / np.abs(S).mean() < 2e-3
+    assert np.abs(np.abs(h) - np.abs(S.astype(np.complex64))).max() < 1e-6 * np.abs(S).max()     # magnitudes are the fp32 ones
+    assert (store_scale(111.0), store_scale(1.5), store_scale(0.3), store_scale(2.0)) == (2.0 ** -6, 1.0, 4.0, 0.5)
+    assert half(1.0 + 2.0 ** -11) == 1.0 and half(1.0 + 3 * 2.0 ** -11) == 1.0 + 2.0 ** -9      # ties to even
+    assert np.array_equal(fp16_storage_batch(o, S, W, [90.0], 7), S.astype(np.complex64).astype(np.complex128))
