@@ -44,7 +44,10 @@
 #include <utility>
 
 namespace lws {
-#ifdef LWS_LAB   // tools/online_lab.hip: per-wave phase stamps of k_online3 (block 0), clocks summed over the steps
+#ifdef LWS_LAB   // tools/online_budget.hip: per-wave phase stamps of k_online3 / k_online4 (block 0), clocks summed over the steps.
+// s_memtime returns through the scalar-memory counter, so reading a stamp drains the wave's LDS operations too: level 1 puts
+// stamps only where the wave is about to wait for everything in flight anyway; level 2 (-DLWS_LAB=2) adds one in front of every
+// barrier (turning the projection wave's counted wait into a full one: who waits for whom, at the price of a longer step).
 #define LAB_N 256
 __device__ unsigned long long g_lab[LAB_N];
 __device__ __forceinline__ unsigned long long lab_now() {
@@ -53,8 +56,14 @@ __device__ __forceinline__ unsigned long long lab_now() {
     return t;
 }
 #define LAB(...) __VA_ARGS__
+#if LWS_LAB >= 2
+#define LAB2(...) __VA_ARGS__
+#else
+#define LAB2(...)
+#endif
 #else
 #define LAB(...)
+#define LAB2(...)
 #endif
 namespace {
 
@@ -1147,6 +1156,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             const float4 *w = cells(ue);
             static_for<NPRE>([&](auto ic) { ld(w, ic); });
         }
+        LAB(unsigned long long lab_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long lb0 = lab_now();)
         for (int it = 0; it < n_it; it += 2) {
             // (ODD: a sweep may end at either step of a pair -- the lane moves on at the top of the next pair.  Its new sweep
             // starts three steps after the old one ended at the earliest: in this pair's odd step or later; the early cells,
@@ -1172,14 +1182,18 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 // which columns of which wave need this, for every Q and lag; tests/test_online_schedule.py runs it.)
                 // (only the pair in which such a lane starts: ue = -1)
                 if constexpr (ODD && KIND == 0) { if (ue == -1) ld(w, std::integral_constant<int, 1>{}); }
+                LAB(const unsigned long long lb1 = lab_now(); lab_acc[0] += lb1 - lb0;)       // late cells of the even step in registers
                 v2f twa, twb;
                 if constexpr (TWT) tw_tab(0, twa, twb);
                 else tw_of(std::integral_constant<int, 0>{}, ue, twa, twb);
                 if (!SERIAL) sums(std::integral_constant<int, 0>{}, twa, twb, pw0);
+                LAB(lb0 = lab_now(); lab_acc[1] += lb0 - lb1;)                                // sums formed, partial sums stored
             }
             if constexpr (!ODD) { if (it >= t_done) { s += NSW; setup(); ue = it - tstart; if constexpr (TWT) cp = cp_of(ue); } }
             load_frames(it - 1);
+            LAB2({ const unsigned long long lbw = lab_now(); lab_acc[2] += lbw - lb0; lb0 = lbw; })   // (level 2) ready for the barrier
             __syncthreads();
+            LAB({ const unsigned long long lbb = lab_now(); lab_acc[3] += lbb - lb0; lb0 = lbb; })     // barrier released
             // ---- odd step tt = it + 1
             {
                 const float4 *w = cells(ue);
@@ -1188,20 +1202,34 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 // the window) were stored one and two steps after the early cells were read: final only now
                 if constexpr (ODD && KIND == 1) { if (ue == -1) { ld(w, std::integral_constant<int, 1>{}); ld(w, std::integral_constant<int, 2>{}); } }
                 ld(w, std::integral_constant<int, NCELL - 1>{});
+                LAB(const unsigned long long lb1 = lab_now(); lab_acc[0] += lb1 - lb0;)
                 v2f twa, twb;
                 if constexpr (TWT) tw_tab(2, twa, twb);
                 else tw_of(std::integral_constant<int, 1>{}, ue, twa, twb);
                 if (!SERIAL) sums(std::integral_constant<int, 2>{}, twa, twb, pw1);
+                LAB(lb0 = lab_now(); lab_acc[1] += lb0 - lb1;)
             }
             ue += 2;
             if constexpr (TWT) { cp += step4; cp -= cp >= PT ? PT : 0; }
-            {   // the next pair's early cells: columns this wave has used already, under their new names
-                const float4 *w = cells(ue);
-                static_for<NPRE>([&](auto ic) { ld(w, ic); });
-            }
             load_frames(it);
-            __syncthreads();
+            asm volatile("" ::: "memory");   // (the partial sums' store stays in front of the reads below)
+            {   // the next pair's early cells: columns this wave has used already, under their new names
+                // (KIND 1 reads its cell 0 after the barrier anyway -- the compiler would drop an early read of it, and the
+                //  count below must be the number of reads that really are issued)
+                const float4 *w = cells(ue);
+                static_for<NPRE - (KIND == 1 ? 1 : 0)>([&](auto ic) { ld(w, std::integral_constant<int, decltype(ic)::value + (KIND == 1 ? 1 : 0)>{}); });
+            }
+            LAB2({ const unsigned long long lbw = lab_now(); lab_acc[2] += lbw - lb0; lb0 = lbw; })   // (level 2: the early cells have arrived too)
+            // the partial sums must have landed when the projection wave passes the barrier; the early cells need not have (a wave's
+            // LDS operations complete in order, and the NPRE youngest are those reads: tools/check_online_isa.py checks the compiled
+            // order; a frame load before them drains everything itself, global loads included)
+            static_assert(L != 5 || (NPRE == (KIND == 1 ? 4 : 5)), "the counts below are those of L = 5");
+            if constexpr (!SERIAL && L == 5 && KIND == 0) asm volatile("s_waitcnt lgkmcnt(5)\n\ts_barrier" ::: "memory");
+            else if constexpr (!SERIAL && L == 5 && KIND == 1) asm volatile("s_waitcnt lgkmcnt(3)\n\ts_barrier" ::: "memory");
+            else __syncthreads();
+            LAB({ const unsigned long long lbb = lab_now(); lab_acc[3] += lbb - lb0; lb0 = lbb; })
         }
+        LAB(if (b == 0 && lane == 0) { for (int i = 0; i < 8; ++i) g_lab[8 + hw_wave * 8 + i] = lab_acc[i]; })
     };
 
     // ---- centre-frame tap wave: its unit's own outputs of this step and the last (columns c-2 .. c, and their Hermitian
@@ -1209,6 +1237,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
     auto centre_loop = [&]() __attribute__((always_inline)) {
         float4 *pw0 = P + (0 * NTW + wave) * 64 + lane, *pw1 = P + (1 * NTW + wave) * 64 + lane;
         int u = 0 - tstart;
+        LAB(unsigned long long lab_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long lb0 = 0;)
         auto half = [&](auto ph_c, float4 *pw) __attribute__((always_inline)) {
             const int uc = u > -8 ? u : -8;
             const float4 *w = reinterpret_cast<const float4 *>(S + ctb + 2 * uc);
@@ -1218,27 +1247,27 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 const float4 q = w[i];
                 wl[2 * i] = (v2f){q.x, q.y}; wl[2 * i + 1] = (v2f){q.z, q.w};
             }
+            LAB({ const unsigned long long lbr = lab_now(); lab_acc[0] += lbr - lb0; lb0 = lbr; })   // the window is in registers
+            // (selects, not branches: some lane of the 64 is near a frame edge in most steps, and a nest of lane-divergent branches
+            //  on this wave -- the longest of the step until round 5: profiles/r05_online_phase_budget.json -- cost ~400 clocks a step)
             const int c = 2 * u, g = N - c;
-            if (2 * c <= L + 2 || 2 * g <= L + 1) {
-                static_for<(L + 2) / 4>([&](auto iu) {
-                    constexpr int U = decltype(iu)::value + 1, C = 2 * U;
-                    if (u == U) {
-                        static_for<3>([&](auto id) {
-                            constexpr int D = decltype(id)::value, I = L - 2 * C + D;
-                            if constexpr (C - D >= 1 && I >= 0 && I < WN) wl[I] = (v2f){0.f, 0.f};
-                        });
-                    }
+            const v2f zero_ = {0.f, 0.f};
+            static_for<(L + 2) / 4>([&](auto iu) {
+                constexpr int U = decltype(iu)::value + 1, C = 2 * U;
+                const bool at = u == U;
+                static_for<3>([&](auto id) {
+                    constexpr int D = decltype(id)::value, I = L - 2 * C + D;
+                    if constexpr (C - D >= 1 && I >= 0 && I < WN) wl[I] = at ? zero_ : wl[I];
                 });
-                static_for<(L + 1) / 2 + 1>([&](auto ig) {
-                    constexpr int G = decltype(ig)::value;
-                    if (g == G) {
-                        static_for<3>([&](auto id) {
-                            constexpr int D = decltype(id)::value, I = L + 2 * G + D;
-                            if constexpr (G + D >= 1 && G + D <= L && I < WN) wl[I] = (v2f){0.f, 0.f};
-                        });
-                    }
+            });
+            static_for<(L + 1) / 2 + 1>([&](auto ig) {
+                constexpr int G = decltype(ig)::value;
+                const bool at = g == G;
+                static_for<3>([&](auto id) {
+                    constexpr int D = decltype(id)::value, I = L + 2 * G + D;
+                    if constexpr (G + D >= 1 && G + D <= L && I < WN) wl[I] = at ? zero_ : wl[I];
                 });
-            }
+            });
             // bin a (column L): taps -1, -2 are columns L-1, L-2 (left out); bin b (column L+1): taps -1 .. -3 are columns L .. L-2
             // (at a frame start those columns are the images of bins 1 and 2 as the previous sweep left them: taken here)
             const bool start = u == 0;
@@ -1260,18 +1289,24 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             const v2f pa = cmul_pk(twa, am + ap), pb = cmul_pk(twb, bm + bp);
             if (!SERIAL) *pw = make_float4(pa.x, pa.y, pb.x, pb.y);
         };
+        LAB(lb0 = lab_now();)
         for (int it = 0; it < n_it; it += 2) {
             if constexpr (ODD) { if (it > t_done) { s += NSW; setup(); u = it - tstart; } }
             half(std::integral_constant<int, 0>{}, pw0);
             if constexpr (!ODD) { if (it >= t_done) { s += NSW; setup(); u = it - tstart; } }
             load_frames(it - 1);
+            LAB({ const unsigned long long lbw = lab_now(); lab_acc[1] += lbw - lb0; lb0 = lbw; })   // window read, sums formed and stored
             __syncthreads();
+            LAB({ const unsigned long long lbb = lab_now(); lab_acc[3] += lbb - lb0; lb0 = lbb; })
             ++u;
             half(std::integral_constant<int, 1>{}, pw1);
             ++u;
             load_frames(it);
+            LAB({ const unsigned long long lbw = lab_now(); lab_acc[1] += lbw - lb0; lb0 = lbw; })
             __syncthreads();
+            LAB({ const unsigned long long lbb = lab_now(); lab_acc[3] += lbb - lb0; lb0 = lbb; })
         }
+        LAB(if (b == 0 && lane == 0) { for (int i = 0; i < 8; ++i) g_lab[8 + hw_wave * 8 + i] = lab_acc[i]; })
     };
 
     if (hw_wave == Online4Waves<Q>::IDLE) {
@@ -1346,6 +1381,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             // and is rarely done in time; the tap waves sleeping 64-192 clocks after a barrier to let this wave's reads go
             // first, +0.3-1.7 ms; an idle ninth wave instead of the centre wave on this SIMD, +7 ms; a row stride that spreads
             // the window cells of a ds_read_b128 group over all 16 bank slots, +0.8 ms.  Times: DESIGN 4c.)
+            LAB(unsigned long long lab_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long lp0 = 0;)
             v2f p1 = {0.f, 0.f}, p2 = {0.f, 0.f};   // current values of columns c-1, c-2 of the unit's frame; zero while the lane
                                                     // has no work and at a frame start (the centre wave reads the images there itself)
             auto lds = [&](unsigned off) __attribute__((always_inline)) { return smem + off; };
@@ -1417,6 +1453,10 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
 #pragma unroll
                 for (int w = 0; w < NTW; ++w) part[w] = pp[w * 64];
                 __builtin_amdgcn_sched_barrier(0);   // (the reads first: the own terms below cover part of their latency)
+                LAB(const unsigned long long lp1 = lab_now(); lab_acc[0] += lp1 - lp0;)   // the tap waves' sums are in registers
+                // while the sums are on their way this wave has nothing urgent to issue: the centre-frame wave, which shares its SIMD
+                // and is the last to reach the barrier, goes first (its window reads went out ~200 clocks late behind the terms below)
+                asm volatile("s_setprio 0");
                 // the unit's own history (columns c-1, c-2, their images, the image of bin c) and frame rho-1's late column
                 v2f twl = TWT ? twl_t : as_v2f(a.tw[(2 * PH + 1) & (Q - 1)]);
                 if constexpr (ODD && Q == 4 && !TWT) twl = ((u ^ PH) & 1) ? as_v2f(a.tw[(2 * PH + 3) & 3]) : twl;   // (odd start: u and t differ in parity)
@@ -1429,6 +1469,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                     const v2f x = cmul_pk(wlate, xlate);
                     cmac_pk(ownB, twl, x);
                 }
+                asm volatile("s_setprio 3");
                 // the tap waves' partial sums, as a tree
                 v2f sa[NTW], sb[NTW];
 #pragma unroll
@@ -1457,6 +1498,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 // without an image has offset 0 -- its conjugate goes to the bin's own place FIRST and is overwritten at once
                 // (one wave's LDS stores land in order).  A frame's last pair has no second bin: that place is an image column
                 // and gets its old value back (it was read after the store of the step before).
+                LAB(const unsigned long long lp2 = lab_now(); lab_acc[1] += lp2 - lp1;)    // own terms, tree, both re-projections
                 if (act) {
                     *reinterpret_cast<float2 *>(lds(ia_b)) = make_float2(newA.x, -newA.y);
                     *reinterpret_cast<float2 *>(lds(ib_b)) = make_float2(newB.x, -newB.y);
@@ -1485,18 +1527,26 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 tab2 = tab3;
                 // (BIG: the step-table entry is computed and the targets come from global memory -- two LDS reads fewer follow the
                 // stores, ~8 remain: a count of 5 keeps a margin of three instructions against a reordering by the compiler)
+                LAB2(const unsigned long long lp3 = lab_now(); lab_acc[2] += lp3 - lp2;)   // (level 2) stores landed AND the next operands fetched
                 if constexpr (BIG) asm volatile("s_waitcnt lgkmcnt(5)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
+#if defined(LWS_LAB) && LWS_LAB >= 2
+                LAB(lp0 = lab_now(); lab_acc[3] += lp0 - lp3;)                             // waiting in the barrier
+#else
+                LAB(lp0 = lab_now(); lab_acc[3] += lp0 - lp2;)                             // stores, next fetch, counted wait, barrier (and the fetched operands' arrival: the stamp drains)
+#endif
             };
             derive();
             if constexpr (TWT) cpp = cpp_of(u);
             fetch(u, fetch_tab(u));
             tab1 = fetch_tab(u + 1);
             tab2 = fetch_tab(u + 2);
+            LAB(lp0 = lab_now();)
             for (int it = 0; it < n_it; it += 2) {
                 step(std::integral_constant<int, 1>{}, it - 1);
                 step(std::integral_constant<int, 0>{}, it);
             }
+            LAB(if (b == 0 && lane == 0) { for (int i = 0; i < 8; ++i) g_lab[8 + hw_wave * 8 + i] = lab_acc[i]; g_lab[0] = (unsigned long long)n_it; })
         }
     }
     const int first_row = loaded > NWR ? loaded - NWR : 0;

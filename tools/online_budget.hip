@@ -1,9 +1,12 @@
-// online_lab.hip -- timing harness for the online LDS kernels (lws_online.hip) on BASELINE config 3's shape, without Python:
-// random state / magnitudes / weights (timing does not depend on the values), launch_online_lds directly, HIP events, and --
-// when built with -DLWS_LAB -- the per-wave phase stamps the kernel leaves in g_lab.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DLWS_LAB -I include -I lws_amd/csrc tools/online_lab.hip -o online_lab
-//   ./online_lab [B] [T] [F] [LA] [iters] [reps]
-#include "../../lws_amd/csrc/lws_online.hip"
+// online_budget.hip -- per-phase clock budget of the online LDS kernel (lws_amd/csrc/lws_online.hip: k_online4) on BASELINE config 3's
+// shape, without Python: random state / magnitudes / weights (timing does not depend on the values), launch_online_lds directly, HIP
+// events around it, and -- built with -DLWS_LAB=1 or 2 -- the s_memtime stamps every wave of workgroup 0 sums up per phase
+// (lws_online.hip: LAB / LAB2).  Prints one JSON object; tools/online_budget.sh builds the three variants (no stamps / level 1 /
+// level 2), runs them and writes profiles/r05_online_phase_budget.json.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp [-DLWS_LAB=1|2] \
+//         -I include -I lws_amd/csrc tools/online_budget.hip -o tools/online_budget_l<n>
+//   ./online_budget_l<n> [B] [T] [F] [LA] [iters] [reps]
+#include "../lws_amd/csrc/lws_online.hip"
 #include <cstdio>
 #include <vector>
 #include <random>
@@ -42,40 +45,39 @@ int main(int argc, char **argv) {
     for (int s = 0; s < 3; ++s) { g.w[s].w = dw + s * Q * Q * K1; g.w[s].flag = nullptr; }
     g.F = F; g.T = T; g.L = L; g.Q = Q; g.Qp = Q; g.n_thr = iters; g.LA = LA; g.update = 2; g.qdiv = 4.f; g.mode = lws::MODE_ONLINE;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
     for (int rep = 0; rep < reps; ++rep) {
         CK(hipMemcpy(ds, ds0, n * 8, hipMemcpyDeviceToDevice));
         CK(hipEventRecord(e0, 0));
-        CK(lws::launch_online_lds(g, B, 0));
+        CK(lws::launch_online_lds(g, B, Q, 1, nullptr, 0));
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("B=%d T=%d F=%d LA=%d it=%d: %.3f ms\n", B, T, F, LA, iters, ms);
+        if (ms < best) best = ms;
     }
     std::vector<float2> out((size_t)Tp * Np);
     CK(hipMemcpy(out.data(), ds, out.size() * 8, hipMemcpyDeviceToHost));
     double cs = 0; for (auto &v : out) cs += fabs(v.x) * 1.25 + fabs(v.y);
-    printf("checksum (spectrogram 0) %.12e\n", cs);
-#if 0
-    {
-        std::vector<unsigned long long> lab(LAB_N);
-        CK(hipMemcpyFromSymbol(lab.data(), HIP_SYMBOL(lws::g_lab), LAB_N * 8));
-        printf("mismatches %llu; first:", lab[0]);
-        for (int i = 1; i < 40 && i <= (int)lab[0]; ++i) printf(" (t=%llu lane=%llu w=%llu)", lab[i] >> 32, (lab[i] >> 8) & 0xffffff, lab[i] & 0xff);
-        printf("\n");
-    }
+    int lab_level = 0;
+#ifdef LWS_LAB
+    lab_level = LWS_LAB;
 #endif
+    printf("{\"B\": %d, \"T\": %d, \"F\": %d, \"LA\": %d, \"iters\": %d, \"lab_level\": %d, \"kernel_ms\": %.3f, \"checksum_spectrogram0\": %.9e",
+           B, T, F, LA, iters, lab_level, best, cs);
 #ifdef LWS_LAB
     std::vector<unsigned long long> lab(LAB_N);
     CK(hipMemcpyFromSymbol(lab.data(), HIP_SYMBOL(lws::g_lab), LAB_N * 8));
     const long long steps = lab[0] ? (long long)lab[0] : 1;
-    printf("steps %lld\n", steps);
+    printf(", \"steps\": %lld, \"waves\": {", steps);
+    bool first = true;
     for (int w = 0; w < 16; ++w) {
         const unsigned long long *p = lab.data() + 8 + w * 8;
         if (!p[0] && !p[1] && !p[2] && !p[3]) continue;
-        printf("wave %2d: per step clocks:", w);
-        for (int i = 0; i < 8; ++i) printf(" %8.1f", (double)p[i] / steps);
-        printf("\n");
+        printf("%s\"hw%d\": [%.1f, %.1f, %.1f, %.1f]", first ? "" : ", ", w, (double)p[0] / steps, (double)p[1] / steps, (double)p[2] / steps, (double)p[3] / steps);
+        first = false;
     }
+    printf("}");
 #endif
+    printf("}\n");
     return 0;
 }
