@@ -1063,6 +1063,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             for (int k = 0; k <= L; ++k) {
                 const float2 w = wb[r * K1 + k];
                 w0[k] = (v2f){w.x, h ? -w.y : w.y};
+                if (r == 0) w0[k] *= (v2f){gain, gain};       // the centre-frame wave multiplies by no twiddle: its gain (0 or 1) goes here
             }
             gvec = (v2f){gain, h ? -gain : gain};
             if constexpr (!TWT) {
@@ -1262,6 +1263,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             });
             static_for<(L + 1) / 2 + 1>([&](auto ig) {
                 constexpr int G = decltype(ig)::value;
+                if constexpr (G & 1) return;                // (N = F - 1 and c are even: g is)
                 const bool at = g == G;
                 static_for<3>([&](auto id) {
                     constexpr int D = decltype(id)::value, I = L + 2 * G + D;
@@ -1283,10 +1285,8 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
                 if (k >= 4) cmac_pk(bm, w0[k], wl[L + 1 - k]);
                 cmacc_pk(bp, w0[k], wl[L + 1 + k]);
             }
-            v2f twa, twb;
-            if constexpr (TWT) twa = twb = (v2f){gvec.x, 0.f};      // (frame offset 0: no twiddle, just "does the centre frame take part")
-            else tw_of(ph_c, u & ~1, twa, twb);
-            const v2f pa = cmul_pk(twa, am + ap), pb = cmul_pk(twb, bm + bp);
+            // (frame offset 0 has no twiddle; whether the centre frame takes part at all is in the weights: setup())
+            const v2f pa = am + ap, pb = bm + bp;
             if (!SERIAL) *pw = make_float4(pa.x, pa.y, pb.x, pb.y);
         };
         LAB(lb0 = lab_now();)
@@ -1666,6 +1666,8 @@ Shape4 shape4_try(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr, bool b
     sh.threads = Online4Waves<4>::N == 9 && Q == 4 ? 9 * 64 : 2 * Q * 64;
     if (F - 1 < 2 * (L + 3)) return r;
     r.NPS = Np + (Np & 1);
+    // (row strides of Np + 2 .. Np + 44 columns measured in round 5, as in round 3: 40.2-40.8 ms against 40.5 -- the window reads'
+    //  bank conflicts are not what a step waits for)
     auto lds_of = [&](int nwr) {
         return (size_t)2 * (2 * Q - 1) * 64 * 16 + (224 + 64) * 8 + ((size_t)nwr * r.NPS + 8) * 8 + (big ? 0 : (size_t)nwr * r.NPS * 4) +
                (size_t)3 * Q * Q * (L + 1) * 8 + (size_t)Q * 8 + (size_t)n_thr * 4 + 16 + (big ? 0 : (size_t)NU * 16) + (PT > 0 ? (size_t)(PT + 3) * (Q <= 4 ? 32 : 64) : 0);

@@ -25,7 +25,8 @@ def test_counted_wait_before_the_barrier_covers_the_stores():
         lines = open(os.path.join(td, "online.s")).read().split("\n")
     found, margin, worst = check_online_isa.check(lines)
     assert found >= 8, found      # two half-steps per instantiation: Q in {2, 4, 8} and the BIG variants
-    assert margin >= 1, margin    # (the BIG variant keeps a margin of three reads by construction: lgkmcnt(5))
+    assert margin >= 0, margin    # (the tap waves' waits count exactly the reads that follow their store -- pinned in the source by a
+                                  #  compiler barrier between the two; the projection wave's BIG variant keeps a margin of three: lgkmcnt(5))
     assert worst <= 15, worst     # operations in flight at a counted wait: the counter has four bits
 
 
