@@ -14,6 +14,7 @@ the launch stream, algorithmic bytes, fraction of 8 TB/s) and the property check
     4shard   config 4's per-GPU shard: 1024 spectrograms of 500 x 513
     3        run_lws(mode='music'): no-future -> online -> batch, stage by stage
     3-b1024  the same on 1024 spectrograms (the one-workgroup-per-spectrogram stages then run two per CU)
+    3-fp64   the same pipeline on an fp64 plan (the reference's own arithmetic type), complex128 resident in HBM
     5        64 clips of 56 250 frames x 1025 bins (2048-point STFT), 200 sweeps
     5-f16    the same with fp16-complex storage (fp32 arithmetic)
     2-q2 / 2-q8   config 2's volume at hop 512 (Q = 2, the reference's LWSQ2) and hop 128 (Q = 8, LWSanyQ)
@@ -189,13 +190,16 @@ def summary_lines(extra):
         try:
             if "error" in b or "skipped" in b:
                 out.append("# %s: %s" % (name, (b.get("error") or b.get("skipped"))[:200]))
-            elif name.startswith("3"):
+            elif name.startswith("3") and name != "3-fp64":
                 out.append("# %s: total %.1f ms; " % (name, b["total_wall_ms"]) + "; ".join(
                     "%s %.2f ms (%s, %s)" % (st, b[st]["kernel_ms"], b[st]["kernel"], rf(b[st]["roofline"])) for st in ("nofuture", "online", "batch") if st in b))
             elif name == "host_api":
-                out.append("# host_api: plan.batch(numpy c128 magnitudes) %.1f ms vs device-resident %.1f ms (x%.2f); complex input %s ms; run_lws_music(numpy) %.1f ms"
+                out.append("# host_api: plan.batch(numpy c128 magnitudes) %.1f ms vs device-resident %.1f ms (x%.2f); complex input %s ms; run_lws_music(numpy) %.1f ms%s"
                            % (b["wall_ms"], b["device_resident_ms"], b["wall_ms"] / b["device_resident_ms"],
-                              ("%.1f" % b["complex_input"]["wall_ms"]) if b.get("complex_input") else "n/a", b["run_lws_music"]["wall_ms"]))
+                              ("%.1f" % b["complex_input"]["wall_ms"]) if b.get("complex_input") else "n/a", b["run_lws_music"]["wall_ms"],
+                              "".join("; %s: %.1f ms (x%.2f)" % (k, v["wall_ms"], v["ratio"]) for k, v in (b.get("other_batch_sizes") or {}).items())))
+            elif name == "3-fp64":
+                out.append("# 3-fp64: total %.1f ms; " % b["total_wall_ms"] + "; ".join("%s %.2f ms (%s)" % (st, b[st]["kernel_ms"], b[st]["kernel"]) for st in ("nofuture", "online", "batch") if st in b))
             elif name == "2-fp64":
                 out.append("# 2-fp64: kernel %.1f ms (%s, %d launches), wall %.1f ms; generic engine %.1f ms (x%.1f)"
                            % (b["systolic"]["kernel_ms"], b["systolic"]["kernel"], b["systolic"]["launches"] or 0, b["systolic"]["wall_ms"],
@@ -690,7 +694,7 @@ def main():
     elif args.extras is not None:
         wanted = [x for x in args.extras.split(",") if x]
     elif world == 1 and args.config == "2":
-        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-q5", "2-f501", "2-f257", "2-fp64", "4shard", "3", "3-b1024", "host_api", "1", "5", "5-f16"]
+        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-q5", "2-f501", "2-f257", "2-fp64", "4shard", "3", "3-b1024", "3-fp64", "host_api", "1", "5", "5-f16"]
     else:
         wanted = ["4shard"] if args.config == "2" else []
     if args.no_default_schedule and "2-default" in wanted:
@@ -721,6 +725,8 @@ def main():
                 cfgs["1"] = run_config1(lws_amd, local_rank)
             elif name == "2-fp64":
                 cfgs["2-fp64"] = run_fp64(torch, lws_amd, dev, local_rank)
+            elif name == "3-fp64":
+                cfgs["3-fp64"] = run_config3_fp64(torch, lws_amd, dev, local_rank)
             elif name in BATCH_CONFIGS:
                 if BATCH_CONFIGS[name]["storage"] == "fp16" and not have_f16:
                     cfgs[name] = {"skipped": "this build has no fp16 storage mode"}
@@ -781,6 +787,8 @@ def main():
                 also["fp64_generic_ms"] = float(c["2-fp64"]["generic"]["kernel_ms"])
             if "total_wall_ms" in (c.get("3") or {}):
                 also["config3_ms"] = float(c["3"]["total_wall_ms"])
+            if "total_wall_ms" in (c.get("3-fp64") or {}):
+                also["fp64_config3_ms"] = float(c["3-fp64"]["total_wall_ms"])
             if "wall_ms" in (c.get("host_api") or {}):
                 also["host_api_ms"] = float(c["host_api"]["wall_ms"])
         except Exception:
@@ -914,7 +922,28 @@ def run_host_api(torch, lws_amd, dev, local_rank, B=256, T=500, iters=100):
              "wall_ms": min(walls3[1:]), "wall_ms_all_calls": walls3,
              "checks": {"max_rel_magnitude_error": float(np.abs(np.abs(out) - np.abs(M)).max() / np.abs(M).max()), "finite": bool(np.isfinite(out).all())}}
     out = keep3 = None
-    return {"run_lws_music": music, "workload": "BASELINE config 2 through plan.batch(numpy complex128 %dx%dx%d) -> complex128, %d dense sweeps" % (B, T, F, iters),
+    # the same entry point on a quarter and on four times the batch (what the chunking costs a small call, and whether a large one
+    # reaches the device-resident rate): wall of the call / spectrogram, against config 2's
+    other = {}
+    if B == 256:
+        for B2 in (64, 1024):
+            M2 = synth_magnitudes(B2, T, F, 20260928).astype(np.complex128)
+            w2, keep2 = [], []
+            for rep in range(3):
+                t0 = time.perf_counter()
+                keep2.append(plan.batch(M2, thr))
+                w2.append(1e3 * (time.perf_counter() - t0))
+                if len(keep2) > 1:
+                    keep2.pop(0)
+            d2 = torch.from_numpy(M2.astype(np.complex64)).to(dev)
+            for rep in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                plan.batch_dev(d2.data_ptr(), B2, T, thr); torch.cuda.synchronize()
+                dev2 = 1e3 * (time.perf_counter() - t0)
+            other["B%d" % B2] = {"wall_ms": min(w2[1:]), "device_resident_ms": dev2, "ratio": min(w2[1:]) / dev2,
+                                 "value": float(B2) * T * F * iters / (min(w2[1:]) * 1e-3)}
+            del M2, keep2, d2
+    return {"run_lws_music": music, "other_batch_sizes": other, "workload": "BASELINE config 2 through plan.batch(numpy complex128 %dx%dx%d) -> complex128, %d dense sweeps" % (B, T, F, iters),
             "wall_ms": min(walls[1:]), "wall_ms_all_calls": walls, "first_call_includes": "pinned staging buffers (hipHostMalloc) and scratch",
             "input": "real-valued magnitudes (the documented usage run_lws(np.abs(X))): 4 B/bin over the bus on the way up, 8 on the way down",
             "complex_input": {"wall_ms": min(walls_c[1:]), "wall_ms_all_calls": walls_c, "note": "random phases: 8 B/bin each way"},
@@ -922,6 +951,39 @@ def run_host_api(torch, lws_amd, dev, local_rank, B=256, T=500, iters=100):
             "pinned_copy_GBs": {"h2d": rates[0], "d2h": rates[1]}, "bytes_over_the_bus_each_way": bytes_c64,
             "transfer_ms_each_way_at_pinned_rate": xfer_ms, "wall_over_max_transfer_kernel": min(walls[1:]) / max(xfer_ms, dev_ms),
             "checks": batch_checks}
+
+
+def run_config3_fp64(torch, lws_amd, dev, local_rank, B=256, T=500):
+    """BASELINE config 3 in the reference's own arithmetic type: run_lws(mode='music') of an fp64 plan on device-resident complex128
+    spectrograms, stage by stage (kernel names say which engine served each: the LDS engines of the no-future / online stages and the
+    fp64 systolic engine, or the order-exact generic engine)."""
+    F = 513
+    pm = lws_amd.lws(1024, 256, mode="music", precision="fp64", device=local_rank)
+    plan = pm.plan()
+    M = synth_magnitudes(B, T, F, 20260928).astype(np.complex128)
+    thr = [lws_amd.get_thresholds(pm.nofuture_iterations, pm.nofuture_alpha, pm.nofuture_beta, pm.nofuture_gamma),
+           lws_amd.get_thresholds(pm.online_iterations, pm.online_alpha, pm.online_beta, pm.online_gamma),
+           lws_amd.get_thresholds(pm.batch_iterations, pm.batch_alpha, pm.batch_beta, pm.batch_gamma)]
+    d = torch.from_numpy(M).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    stages = [("nofuture", lambda: plan.nofuture_dev(d.data_ptr(), B, T, thr[0], wsel=1, stream=stream)),
+              ("online", lambda: plan.online_dev(d.data_ptr(), B, T, thr[1], pm.look_ahead, 4.0, stream=stream)),
+              ("batch", lambda: plan.batch_dev(d.data_ptr(), B, T, thr[2], stream=stream))]
+    out = {"workload": "BASELINE config 3 in fp64: run_lws(mode='music', precision='fp64') on %d spectrograms of %d x %d, complex128 resident in HBM" % (B, T, F)}
+    for rep in range(2):
+        d.copy_(torch.from_numpy(M))
+        torch.cuda.synchronize(); t_all = time.perf_counter()
+        for name, fn in stages:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            k = plan.last_kernel()
+            out[name] = {"wall_ms": 1e3 * (time.perf_counter() - t0), "kernel_ms": k["ms"], "kernel": k["name"]}
+        out["total_wall_ms"] = 1e3 * (time.perf_counter() - t_all)
+    res = d.cpu().numpy()
+    out["checks"] = {"max_rel_magnitude_error": float(np.abs(np.abs(res) - np.abs(M)).max() / np.abs(M).max()), "finite": bool(np.isfinite(res).all())}
+    plan.close()
+    return out
 
 
 def run_fp64(torch, lws_amd, dev, local_rank, B=256, T=500, iters=100):

@@ -16,6 +16,7 @@
 #include "lws_systolic.h"
 #include "lws_sys64.h"
 #include "lws_online.h"
+#include "lws_online64.h"
 
 #include <atomic>
 #include <chrono>
@@ -331,6 +332,19 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
         }
     }
     if constexpr (std::is_same<real, double>::value) {
+        // online driver of an fp64 plan: the frames of the moving window in LDS, every sum in the generic engine's order (same bits)
+        if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_ONLINE64", 0) &&
+            lws::online64_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update)) {
+            begin_timing(p, s);
+            hipError_t e = lws::launch_online64(a, B, s);
+            end_timing(p, s);
+            if (e != hipSuccess) return fail(LWS_ERR_HIP, "fp64 online launch failed: %s", hipGetErrorString(e));
+            p->last_launches = 1;
+            p->last_name = "online_lds_fp64";
+            return LWS_OK;
+        }
+    }
+    if constexpr (std::is_same<real, double>::value) {
         // batch sweeps of an fp64 plan: the fp64 systolic engine (lws_sys64.hip) when the shape and the weights allow it.  Same
         // sweeps in the reference's order; a bin's sum is taken in another order, so results agree to rounding, not bit for bit
         // (LWS_FORCE_GENERIC keeps the order-exact engine).
@@ -623,6 +637,10 @@ int host_chunk(size_t per, int B, int n_cu, bool whole_device = false) {
     // 65 spectrograms on 256 CUs keep 195 of them busy, 64 all of them -- round to a divisor / multiple of the CU count
     if (n_cu > 1 && !env_int("LWS_HOST_CHUNK_EXACT", 0)) {
         if (bc >= n_cu) bc -= bc % n_cu;
+        // a batch of several devices' worth: chunks of one device's worth, one workgroup per spectrogram -- the launches then run at
+        // the whole-batch rate (no passes shared out between workgroups) and only the first upload / last download are exposed
+        // (1024 x 500 x 513, round 5: 211 ms in chunks of 64, 154 in chunks of 256, 131 device-resident)
+        else if (B >= 2 * n_cu && (size_t)n_cu * per * sizeof(float2) <= ((size_t)std::max(1, env_int("LWS_HOST_PIN_MB", 2048)) << 20)) bc = n_cu;
         else bc = std::max(1, n_cu / ((n_cu + bc - 1) / bc));
     }
     return std::min(bc, B);

@@ -1,0 +1,225 @@
+// lws_online64.hip -- the online driver TF_RTISI_LA (lwslib.cpp:1424-1492) of an fp64 plan with the frames of the moving window in
+// LDS: the reference's own arithmetic type, every sum in the order-exact engine's order (lws_generic.hip: accumulate_v / update_bin),
+// so results are BIT-IDENTICAL to generic_fp64 -- which served this stage until round 5 at 2.55 s for config 3's 256 x 500 x 513
+// (one bin per step, 76 dependent tap loads per bin from L2).
+//
+// One workgroup = one wave = one spectrogram.  A lane is a (sweep slot, frame position) unit, exactly the units of the fp32
+// engine's fourth layout (lws_online.hip: k_online4) on the schedule of its verification variant: two bins per step, frames of a
+// sweep SKS steps apart, sweeps DS steps apart (order-exact: every writer of a neighbouring frame or sweep is at least L + 2 bins
+// from a lane's taps), 64 units in flight.  A lane sums all the taps of its two bins itself, from LDS, with the full weight tensors
+// (no twiddle structure assumed: any summarised tensor, Qp == Q).  A single wave needs no barrier: its LDS operations complete in
+// order.  fp64 FMA contraction is off for this file (Makefile), as for the generic engine.
+//
+// Entry: online64_supports / launch_online64 (lws_online64.h), called by lws_capi.hip: run_stage for MODE_ONLINE of an fp64 plan.
+#include "lws_online64.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+
+namespace lws {
+namespace {
+
+constexpr int L = 5, K1 = L + 1;
+constexpr int SKB = 2 * ((L + 3) / 2), SKS = SKB / 2;     // bins / steps between consecutive frames of a sweep
+
+struct Args64 {
+    double2 *state;        // [B][Tp][Np]
+    const double *amp;     // [B][Tp][Np]
+    const double *thr;     // [B][n_thr]
+    const double2 *w[3];   // W, W_ai, W_af: [Q][Q][L+1], zero where flagged off (lws_capi.hip: upload_weights)
+    int F, T, n_thr, LA, NSW, DS, NWR, NPS;
+};
+
+// a += w b + conj(w) c, the grouped form of lwslib.cpp:310-311 exactly as lws_generic.hip: pair() writes it
+__device__ __forceinline__ void pair(double2 &a, const double2 w, const double2 b, const double2 c) {
+    a.x += w.x * (b.x + c.x) - w.y * (b.y - c.y);
+    a.y += w.x * (b.y + c.y) + w.y * (b.x - c.x);
+}
+
+template <int Q>
+__global__ void __launch_bounds__(64) k_online64(Args64 a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, DS = a.DS, NWR = a.NWR, NPS = a.NPS;
+    const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), NU = (F + 1) / 2;
+    const int rps = LA + 1, per = a.n_thr + 1, nsweeps = T * per;
+    double2 *S = reinterpret_cast<double2 *>(smem);                       // [NWR][NPS] (+ 8)
+    double *A = reinterpret_cast<double *>(S + (size_t)NWR * NPS + 8);    // [NWR][NPS]
+    double2 *W = reinterpret_cast<double2 *>(A + (size_t)NWR * NPS);      // [3][Q][Q][K1]
+    double *thr_s = reinterpret_cast<double *>(W + 3 * Q * Q * K1);       // [n_thr]
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double2 *gS = a.state + (size_t)b * Tp * Np;
+    const double *gA = a.amp + (size_t)b * Tp * Np;
+
+    for (int i = lane; i < 3 * Q * Q * K1; i += 64) W[i] = a.w[i / (Q * Q * K1)][i % (Q * Q * K1)];
+    for (int i = lane; i < NWR * NPS + 8; i += 64) S[i] = make_double2(0.0, 0.0);   // slots no frame has reached are read with zero weight: finite
+    for (int i = lane; i < NWR * NPS; i += 64) A[i] = 0.0;
+    for (int i = lane; i < a.n_thr; i += 64) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
+    int loaded = Q < T + Q - 1 ? Q : T + Q - 1;          // rows 0 .. Q-1 (left edge pads and the first frame) are needed at step 0
+    for (int r0 = 0; r0 < loaded; ++r0)
+        for (int i = lane; i < Np; i += 64) { S[r0 * NPS + i] = gS[(size_t)r0 * Np + i]; A[r0 * NPS + i] = gA[(size_t)r0 * Np + i]; }
+
+    const int sigma = lane / rps, j = lane - sigma * rps;
+    const bool lane_used = sigma < NSW;
+    int s = sigma, rho = 0, tstart = 0, t_done = 0, ts = 1, wset = 0, ctb = 0;
+    int rowL[Q], rowR[Q];               // ring rows (element offsets) of frames rho - rr / rho + rr, per sweep (no division in the step loop)
+    bool valid = false, centre = false;
+    double thr = 0.0;
+    // sweep s: frame m = s / per, q = s % per.  q == 0: first estimate of frame m from the past (W_ai, threshold 0); q >= 1: iteration
+    // q - 1 over frames max(0, m - LA) .. m, the look-ahead frames with W, frame m with W_af (lwslib.cpp:1432-1491)
+    auto setup = [&]() {
+        const int m = s / per, q = s - m * per;
+        const int first = m - LA > 0 ? m - LA : 0;
+        if (q == 0) { valid = (j == 0); rho = m; wset = 1; centre = false; ts = 1; thr = 0.0; }
+        else {
+            rho = first + j; valid = rho <= m; wset = (rho == m) ? 2 : 0; centre = true;
+            ts = m - rho + 1; if (ts > Q) ts = Q;
+            thr = thr_s[q - 1];
+        }
+        valid = valid && lane_used && s < nsweeps;
+        tstart = DS * s + SKS * rho;
+        t_done = DS * s + SKS * m + NU - 1;
+        ctb = ((rho + Q - 1) % NWR) * NPS;
+#pragma unroll
+        for (int rr = 1; rr < Q; ++rr) { rowL[rr] = ((rho + Q - 1 - rr) % NWR) * NPS; rowR[rr] = ((rho + Q - 1 + rr) % NWR) * NPS; }
+    };
+    setup();
+
+    const int t_end = DS * (nsweeps - 1) + SKS * (T - 1) + NU;
+    const int frame_period = DS * per + SKS;
+    int next_need = (loaded - (Q - 1)) * frame_period;
+    auto load_frames = [&](int t) {      // the next frame a few steps before its first sweep starts; the oldest one goes back to memory
+        while (loaded < T + Q - 1 && next_need <= t + 4) {
+            const int slot = (loaded % NWR) * NPS;
+            const bool evict = loaded >= NWR;
+            for (int i = lane; i < Np; i += 64) {
+                if (evict) gS[(size_t)(loaded - NWR) * Np + i] = S[slot + i];
+                S[slot + i] = gS[(size_t)loaded * Np + i];
+                A[slot + i] = gA[(size_t)loaded * Np + i];
+            }
+            ++loaded;
+            next_need += frame_period;
+        }
+    };
+    for (int t = 0; t < t_end; ++t) {
+        const int u = t - tstart;
+        if (valid && u >= 0 && u < NU) {
+            const int c = 2 * u, n = c + L;
+            const double2 zero = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int cb = c + bb, nb = n + bb;
+                if (cb >= F) break;
+                const int row = cb % Q, rowneg = (Q - row) % Q;
+                const double2 *wa = W + wset * Q * Q * K1 + row * Q * K1;
+                double2 acc = zero;
+                if (centre) {
+                    const double2 *ctr = S + ctb + nb;
+#pragma unroll
+                    for (int k = 1; k <= L; ++k) pair(acc, wa[k], ctr[-k], ctr[k]);
+                }
+#pragma unroll
+                for (int rr = 1; rr < Q; ++rr) {
+                    const double2 *lf = S + rowL[rr] + nb;
+                    const double2 *rt = S + rowR[rr] + nb;
+                    const double2 *wa_r = W + wset * Q * Q * K1 + (row * Q + rr) * K1;
+                    const double2 *wb_r = W + wset * Q * Q * K1 + (rowneg * Q + rr) * K1;
+                    const bool two = rr < ts;
+                    // a frame to the right that is not usable yet contributes a zero: pair(w, b, 0) == w b, pair(w, 0, c) == conj(w) c,
+                    // the one-sided forms of lwslib.cpp:1222-1253 (lws_generic.hip: mac / macc) bit for bit
+                    pair(acc, wa_r[0], lf[0], two ? rt[0] : zero);
+#pragma unroll
+                    for (int k = 1; k <= L; ++k) {
+                        pair(acc, wa_r[k], lf[-k], two ? rt[-k] : zero);
+                        pair(acc, wb_r[k], two ? rt[k] : zero, lf[k]);
+                    }
+                }
+                const int lj = ctb + nb;
+                const double target = A[lj];
+                if (target > thr) {
+                    const double mag = sqrt(acc.x * acc.x + acc.y * acc.y);
+                    if (mag > 0.0) {
+                        const double2 v = make_double2(acc.x * target / mag, acc.y * target / mag);
+                        const double2 vc = make_double2(v.x, -v.y);
+                        S[lj] = v;
+                        const int nyq = F + L - 1;     // Hermitian images in the pad columns (lwslib.cpp:362-367)
+                        if (nb >= L + 1 && nb < 2 * L + 1) S[lj + 2 * (L - nb)] = vc;
+                        else if (nb >= F - 1 && nb < nyq) S[lj + 2 * (nyq - nb)] = vc;
+                    }
+                }
+            }
+        }
+        if (t >= t_done) { s += NSW; setup(); }
+        load_frames(t);
+        // (one wave: its LDS operations complete in order, the stores above are visible to the reads of the next step)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    const int first_row = loaded > NWR ? loaded - NWR : 0;
+    for (int e = first_row; e < loaded; ++e) {
+        const int slot = (e % NWR) * NPS;
+        for (int i = lane; i < Np; i += 64) gS[(size_t)e * Np + i] = S[slot + i];
+    }
+}
+
+struct Shape64 { int NSW, DS, NWR, NPS; size_t lds; bool ok; };
+// The schedule of lws_online.hip: shape4_try for its verification variant (even lag), sized for fp64 rows.
+Shape64 shape64(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
+    Shape64 r{0, 0, 0, 0, 0, false};
+    if (Qp != Q || Lu != L || LA < 0 || LA > 63 || n_thr < 1 || T < 1 || !(Q == 2 || Q == 3 || Q == 4 || Q == 8)) return r;
+    const int Np = F + 2 * L, per = n_thr + 1, NU = (F + 1) / 2;
+    if (F - 1 < 2 * (L + 3)) return r;
+    r.NSW = 64 / (LA + 1);
+    int DS = (SKB * (Q - 1) + L + 3) / 2;
+    if (2 * DS < SKB * Q + 2) DS = (SKB * Q + 3) / 2;
+    const int need = (SKS * LA + NU + 2 + r.NSW - 1) / r.NSW;      // a slot is free again when its sweep is over
+    if (DS < need) DS = need;
+    DS += DS & 1;
+    r.NPS = Np + (Np & 1);
+    auto lds_of = [&](int nwr) {
+        return ((size_t)nwr * r.NPS + 8) * 16 + (size_t)nwr * r.NPS * 8 + (size_t)3 * Q * Q * K1 * 16 + (size_t)n_thr * 8 + 64;
+    };
+    int nwr_max = 16;
+    while (nwr_max > 0 && lds_of(nwr_max) > 160 * 1024) --nwr_max;
+    auto window_of = [&](int ds) { return (ds * (per - 1) + NU + 3) / (ds * per + SKS) + LA + Q; };   // frames alive at once
+    const int ds0 = DS;
+    while (window_of(DS) > nwr_max && DS < 16 * ds0) DS += 2;
+    if (window_of(DS) > nwr_max) return r;
+    r.DS = DS;
+    const int window = window_of(DS);
+    r.NWR = window + 1 <= nwr_max ? window + 1 : window;
+    r.lds = lds_of(r.NWR);
+    if ((double)DS * T * per + (double)SKS * T + NU > 1.0e9) return r;
+    r.ok = true;
+    return r;
+}
+
+template <int Q> hipError_t launch_q(const Args64 &a, int B, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online64<Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_online64<Q>), dim3(B), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool online64_supports(int F, int T, int Lplan, int Q, int Qp, int LA, int n_thr, int update) {
+    return update == 2 && shape64(F, T, Lplan, Q, Qp, LA, n_thr).ok;
+}
+
+hipError_t launch_online64(const GenericArgs<double> &g, int B, hipStream_t stream) {
+    const Shape64 sh = shape64(g.F, g.T, g.L, g.Q, g.Qp, g.LA, g.n_thr);
+    if (!sh.ok || g.update != 2 || g.mode != MODE_ONLINE) return hipErrorInvalidValue;
+    if (B <= 0) return hipSuccess;
+    Args64 a;
+    a.state = g.state; a.amp = g.amp; a.thr = g.thr;
+    for (int i = 0; i < 3; ++i) a.w[i] = g.w[i].w;
+    a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = sh.NSW; a.DS = sh.DS; a.NWR = sh.NWR; a.NPS = sh.NPS;
+    switch (g.Q) {
+    case 2: return launch_q<2>(a, B, sh.lds, stream);
+    case 3: return launch_q<3>(a, B, sh.lds, stream);
+    case 4: return launch_q<4>(a, B, sh.lds, stream);
+    default: return launch_q<8>(a, B, sh.lds, stream);
+    }
+}
+
+}  // namespace lws

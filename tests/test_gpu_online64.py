@@ -1,0 +1,73 @@
+"""GPU (-m gpu): the online stage of an fp64 plan on its LDS engine (lws_online64.hip): every sum in the order-exact generic engine's
+order, so the results must equal generic_fp64's BIT FOR BIT, and the reference goldens to 1e-8 (TF_RTISI_LA, lwslib.cpp:1424-1492)."""
+import numpy as np
+import pytest
+
+import lws_amd
+from conftest import load_golden
+from lws_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def weights(tag):
+    h = load_golden("helpers.npz")
+    return h[f"W_{tag}"], h[f"W_ai_{tag}"], h[f"W_af_{tag}"]
+
+
+@pytest.mark.parametrize("tag", ["64_16", "64_32", "64_8", "48_16"])
+def test_reference_goldens_and_generic_bits(tag):
+    g = load_golden("wrappers.npz")
+    W, W_ai, W_af = weights(tag)
+    S, thr = g[f"S_{tag}"], g[f"thr_{tag}"]
+    F = S.shape[1]
+    qdiv = 2 * (F - 1) / int(tag.split("_")[1])
+    lds = _capi.Plan(F, W, W_ai, W_af, precision="fp64")
+    gen = _capi.Plan(F, W, W_ai, W_af, precision="fp64", force_generic=True)
+    for thr_n, LA, key in ((3, 3, "online"), (3, 0, "online_la0"), (2, 5, "online_la5")):
+        out = lds.online(S, thr[:thr_n], LA, qdiv)
+        assert lds.last_kernel()["name"] == "online_lds_fp64"
+        assert np.abs(out - g[f"{key}_{tag}"]).max() < 1e-8
+        ref = gen.online(S, thr[:thr_n], LA, qdiv)
+        assert gen.last_kernel()["name"] == "generic_fp64"
+        assert np.array_equal(out, ref)
+    lds.close(); gen.close()
+
+
+@pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(1024, 256, 40, 3, 10), (1024, 512, 30, 3, 4), (1024, 128, 24, 3, 3), (512, 128, 70, 5, 6),
+                                                     (768, 256, 30, 2, 5), (64, 16, 200, 3, 10), (1000, 250, 25, 0, 4), (1024, 256, 9, 7, 2), (1024, 256, 3, 3, 3)])
+def test_bit_identical_to_the_generic_engine(fsize, fshift, T, LA, iters):
+    """Config-3-like shapes (and Q = 2 / 8 / 3, short and long look-aheads, fewer frames than the look-ahead): complex input and
+    magnitudes-only input, stacks of spectrograms of different scale."""
+    rng = np.random.default_rng(fsize + T)
+    F = fsize // 2 + 1
+    p = lws_amd.lws(fsize, fshift, mode="music", precision="fp64", look_ahead=LA, online_iterations=iters)
+    pg = lws_amd.lws(fsize, fshift, mode="music", precision="fp64", look_ahead=LA, online_iterations=iters, force_generic=True)
+    S = rng.standard_normal((3, T, F)) + 1j * rng.standard_normal((3, T, F))
+    S[1] = np.abs(S[1])
+    S[2] *= 1e-3
+    out = p.online_lws(S)
+    assert p.plan().last_kernel()["name"] == "online_lds_fp64"
+    ref = pg.online_lws(S)
+    assert pg.plan().last_kernel()["name"] == "generic_fp64"
+    assert np.array_equal(out, ref)
+    assert np.isfinite(out).all() and np.abs(np.abs(out) - np.abs(S)).max() < 1e-9 * np.abs(S).max()
+
+
+def test_frames_too_long_for_fp64_rows_stay_on_the_generic_engine():
+    p = lws_amd.lws(2048, 512, mode="music", precision="fp64", online_iterations=2)
+    S = np.abs(np.random.default_rng(0).standard_normal((6, 1025))).astype(complex)
+    p.online_lws(S)
+    assert p.plan().last_kernel()["name"] == "generic_fp64"
+
+
+def test_run_lws_music_fp64_uses_it():
+    rng = np.random.default_rng(5)
+    M = np.abs(rng.standard_normal((40, 513)) + 1j * rng.standard_normal((40, 513)))
+    p = lws_amd.lws(1024, 256, mode="music", precision="fp64", batch_iterations=20)
+    pg = lws_amd.lws(1024, 256, mode="music", precision="fp64", batch_iterations=20, force_generic=True)
+    s1 = p.online_lws(p.nofuture_lws(M))
+    assert p.plan().last_kernel()["name"] == "online_lds_fp64"
+    assert np.array_equal(s1, pg.online_lws(pg.nofuture_lws(M)))
+    out = p.run_lws(M)
+    assert np.abs(np.abs(out) - M).max() < 1e-12 * M.max()
