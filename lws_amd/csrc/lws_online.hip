@@ -1448,6 +1448,7 @@ __global__ void __launch_bounds__(Online4Waves<Q>::N * 64) k_online4(OnlineArgs 
             };
             auto step = [&](auto ph_c, int t) __attribute__((always_inline)) {   // PH: parity of t (and of u)
                 constexpr int PH = decltype(ph_c)::value;
+                // (this wave has no slack either: 64 / 128 / 256 clocks of s_sleep here cost 2.2 / 4.5 / 7.2 ms, round 5)
                 const float4 *pp = P + (PH * NTW) * 64 + lane;
                 float4 part[NTW];
 #pragma unroll

@@ -169,17 +169,19 @@ def test_frames_of_4096_points(fsize, fshift, T, iters, LA, oracle, monkeypatch)
 
 
 def test_fallbacks_to_generic():
-    """More than 8 frames per stencil row, and fp64 plans, stay on the generic engine.  (Q = 3, 5, 6, 7 and fractional Q: the
-    table-twiddle variant of the fourth layout, tests/test_gpu_tw.py.)"""
+    """More than 8 frames per stencil row stays on the generic engine, in fp32 and in fp64.  (Q = 3, 5, 6, 7 and fractional Q: the
+    table-twiddle variant of the fourth layout, tests/test_gpu_tw.py; fp64 plans of Q in {2,3,4,8}: lws_online64.hip, tests/test_gpu_online64.py.)"""
     rng = np.random.default_rng(0)
     p = lws_amd.lws(144, 16, mode="music")           # Q = 9
     S = rng.standard_normal((9, 73)) + 1j * rng.standard_normal((9, 73))
     out, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0)
     assert name == "generic_fp32"
+    out, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0, precision="fp64")
+    assert name == "generic_fp64"
     p = lws_amd.lws(64, 16, mode="music")
     S = rng.standard_normal((9, 33)) + 1j * rng.standard_normal((9, 33))
     out, name = _online(33, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 4.0, precision="fp64")
-    assert name == "generic_fp64"
+    assert name == "online_lds_fp64"
 
 
 @pytest.mark.parametrize("iters,T", [(1, 30), (3, 14), (10, 8)])
