@@ -1030,10 +1030,14 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
                                             &lws::q2::systolic_entry(), &lws::systolic_entry(),
                                             &lws::q8::systolic_entry(), &lws::wide_q2::systolic_entry(), &lws::wide::systolic_entry(), &lws::xwide::systolic_entry(), &lws::l7::systolic_entry(),
                                             // ... then the table-twiddle builds: Q = 3, and general weights of a hop that does not divide the frame
-                                            &lws::tw_half::systolic_entry(), &lws::tw::systolic_entry(), &lws::tw_wide::systolic_entry(), &lws::tw_q8::systolic_entry()}) {
+                                            &lws::tw_half::systolic_entry(), &lws::tw::systolic_entry(), &lws::tw_wide::systolic_entry(),
+                                            // (5 / 6 frames per stencil row: their own ring depth first; LWS_SYSTOLIC_NO_TWQ=1 skips them -- comparison runs)
+                                            &lws::tw_q5::systolic_entry(), &lws::tw_q6::systolic_entry(), &lws::tw_q8::systolic_entry()}) {
             const bool is_short = b == &lws::quarter::systolic_entry() || b == &lws::half::systolic_entry() || b == &lws::quarter_q2::systolic_entry() ||
                                   b == &lws::half_q2::systolic_entry() || b == &lws::tw_half::systolic_entry();
-            const bool is_tw = b == &lws::tw_half::systolic_entry() || b == &lws::tw::systolic_entry() || b == &lws::tw_wide::systolic_entry() || b == &lws::tw_q8::systolic_entry();
+            const bool is_twq = b == &lws::tw_q5::systolic_entry() || b == &lws::tw_q6::systolic_entry();
+            const bool is_tw = is_twq || b == &lws::tw_half::systolic_entry() || b == &lws::tw::systolic_entry() || b == &lws::tw_wide::systolic_entry() || b == &lws::tw_q8::systolic_entry();
+            if (is_twq && env_int("LWS_SYSTOLIC_NO_TWQ", 0)) continue;
             if (is_tw && env_int("LWS_SYSTOLIC_NO_TW", 0)) continue;                                 // (comparison runs)
             const bool is_r16 = b == &lws::q2::systolic_entry() || b == &lws::wide_q2::systolic_entry() || b == &lws::quarter_q2::systolic_entry() ||
                                 b == &lws::half_q2::systolic_entry();

@@ -75,6 +75,8 @@ namespace quarter { const SystolicBuild &systolic_entry(); }      // -DLWS_SPW=4
 namespace tw { const SystolicBuild &systolic_entry(); }           // -DLWS_TW=1: twiddles from a table -- Q = 3, general weights of a fractional Q (Q <= 4), <= 513 bins
 namespace tw_wide { const SystolicBuild &systolic_entry(); }      // -DLWS_TW=1 -DLWS_WIDE=1: the same for frames of up to 1025 bins (two waves per sweep slot)
 namespace tw_q8 { const SystolicBuild &systolic_entry(); }        // -DLWS_TW=1 -DLWS_Q8=1: table twiddles on the 64-step ring with helper waves: ceil(frame/hop) in 5..8
+namespace tw_q5 { const SystolicBuild &systolic_entry(); }        // ... -DLWS_TWQ=5: exactly 5 frames per stencil row on a 40-step ring: 3 sweep slots of a main and a helper wave
+namespace tw_q6 { const SystolicBuild &systolic_entry(); }        // ... -DLWS_TWQ=6: 6 frames per row, 48-step ring, 3 slots
 namespace tw_half { const SystolicBuild &systolic_entry(); }      // -DLWS_TW=1 -DLWS_SPW=2: the same for frames of up to 257 bins (25 ms / 10 ms speech framing)
 
 }  // namespace lws

@@ -118,13 +118,30 @@
 // (... and with LWS_Q8 -- namespace lws::tw_q8: the 64-step ring, halo of 7 and helper waves of the Q = 8 build with table twiddles, for
 //  ceil(frame/hop) in 5..8 with any twiddle: Q in {5,6,7}, and fractional Q above 4.  The kernel is the Q = 8 instantiation; the frame
 //  pairs the plan does not have are masked out at compile time, its pad frames and "real frame" tests follow the plan's Q, SysArgs::Qa)
+// (... and with LWS_Q8 and -DLWS_TWQ=5 / 6 -- namespaces lws::tw_q5 / lws::tw_q6 (round 5): the same kernel on the ring a plan of exactly 5 / 6
+//  frames per stencil row needs -- LAG > 8 (Q - 1) + L: 40 / 48 steps instead of 64 -- so that the LDS holds THREE sweep slots of a main
+//  and ONE helper wave (frames m-+1 and m-+(Q-1) stay with the main wave, the helper sums the two / three pairs in between) where
+//  lws::tw_q8 has two slots of a main and two helpers.  The ring is then 5 / 6 blocks of 8 steps: block indices are taken modulo NBLK
+//  (blk_mod), not masked.)
+#ifndef LWS_TWQ
+#define LWS_TWQ 0
+#endif
+#if LWS_TWQ && !(LWS_TW && LWS_Q8 && (LWS_TWQ == 5 || LWS_TWQ == 6))
+#error "LWS_TWQ = 5 or 6 goes with LWS_TW and LWS_Q8"
+#endif
 #if LWS_TW && (LWS_WIDE == 2 || LWS_L7 || LWS_R16 || LWS_SPW == 4 || (LWS_Q8 && (LWS_WIDE || LWS_SPW != 1)))
 #error "LWS_TW goes with the narrow build, with LWS_SPW=2, with LWS_WIDE=1 or with LWS_Q8"
 #endif
 #if (LWS_WIDE && LWS_Q8) || ((LWS_SPW != 1 || LWS_L7) && (LWS_WIDE || LWS_Q8)) || (LWS_SPW != 1 && LWS_L7) || (LWS_R16 && (LWS_WIDE == 2 || LWS_Q8 || LWS_L7))
 #error "LWS_WIDE, LWS_Q8, LWS_SPW, LWS_L7 and LWS_R16 are separate builds (LWS_R16 goes with LWS_WIDE=1 or LWS_SPW)"
 #endif
-#if LWS_TW && LWS_Q8
+#if LWS_TWQ == 5
+#define LWS_NS_OPEN namespace lws { namespace tw_q5 {
+#define LWS_NS_CLOSE } }
+#elif LWS_TWQ == 6
+#define LWS_NS_OPEN namespace lws { namespace tw_q6 {
+#define LWS_NS_CLOSE } }
+#elif LWS_TW && LWS_Q8
 #define LWS_NS_OPEN namespace lws { namespace tw_q8 {
 #define LWS_NS_CLOSE } }
 #elif LWS_TW && LWS_SPW == 2
@@ -183,8 +200,10 @@ constexpr int SPW = LWS_SPW;                             // sweep slots per wave
 constexpr int ROWL = LANES * WPS / SPW;                  // lanes (frames) of a ring row = frames of a round
 constexpr int ROWL_SHIFT = LWS_WIDE == 2 ? 8 : (LWS_WIDE ? 7 : (SPW == 4 ? 4 : (SPW == 2 ? 5 : 6)));
 static_assert((1 << ROWL_SHIFT) == ROWL, "row length");
-constexpr int RING = (LWS_Q8 || LWS_L7) ? 64 : (LWS_R16 ? 16 : 32);
+constexpr int RING = LWS_TWQ ? 8 * LWS_TWQ : ((LWS_Q8 || LWS_L7) ? 64 : (LWS_R16 ? 16 : 32));
 constexpr int NBLK = RING / 8;                           // ring blocks of 8 steps
+// block index of the ring: x mod NBLK (a mask when NBLK is a power of two; lws::tw_q5 / tw_q6 have 5 / 6 blocks)
+__host__ __device__ constexpr int blk_mod(int x) { return (NBLK & (NBLK - 1)) == 0 ? (x & (NBLK - 1)) : ((x % NBLK) + NBLK) % NBLK; }
 // ring entry of production time nu, lane l:  set + ((nu >> 1) & 15) * PAIR_BYTES + (l + HALO) * 16 + (nu & 1) * 8
 // -- two consecutive times of one lane share a 16-byte cell, so a reader fetches two adjacent taps with one
 // ds_read_b128; every row of 64 lanes carries HALO copies of the opposite end on each side (lanes -3..-1 mirror
@@ -204,7 +223,7 @@ constexpr int PAIR_BYTES = (ROWL + 2 * HALO + 2) * LANE_B;   // two consecutive 
 constexpr int BLK_BYTES = 4 * PAIR_BYTES;                // one block of 8 steps
 constexpr int SET_BYTES = (RING / 2) * PAIR_BYTES;       // 18 KiB (wide: 34 KiB, Q = 8: 40 KiB)
 #ifndef LWS_NSLOTS
-#define LWS_NSLOTS ((LWS_R16 && LWS_WIDE) ? 7 : (LWS_R16 && LWS_SPW == 2) ? 26 : (LWS_R16 && LWS_SPW == 4) ? 44 : LWS_R16 ? 15 : LWS_L7 ? 3 : LWS_WIDE == 2 ? 1 : LWS_WIDE ? 3 : (LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
+#define LWS_NSLOTS ((LWS_R16 && LWS_WIDE) ? 7 : (LWS_R16 && LWS_SPW == 2) ? 26 : (LWS_R16 && LWS_SPW == 4) ? 44 : LWS_R16 ? 15 : LWS_L7 ? 3 : LWS_WIDE == 2 ? 1 : LWS_WIDE ? 3 : (LWS_TWQ ? 3 : LWS_Q8 ? 2 : (LWS_SPW == 4 ? 24 : 7 * LWS_SPW)))   // (SPW = 4: 25 ring sets of 6 KB are what the LDS holds -- six compute waves)
 #endif
 constexpr int NSLOTS = LWS_NSLOTS;                       // sweeps in flight (compute waves)
 constexpr int NSETS = NSLOTS + 1;
@@ -221,7 +240,7 @@ constexpr int SCRATCH_BYTES = 4 * PAIR_BYTES + LANES * 8;
 // at least 10 steps old when its bin is due -- and leave the two sums of a pair of bins in a mailbox (4 pairs deep).  The
 // sums of a bin are the bulk of its ~310 instructions and one wave per SIMD issues one every ~4.4 clocks: spreading a slot
 // over three waves is what fills the other SIMDs (2 slots are all the LDS holds at this ring depth).
-constexpr int NHELP = LWS_Q8 ? 2 : 0;                    // helper waves per sweep slot
+constexpr int NHELP = LWS_TWQ ? 1 : (LWS_Q8 ? 2 : 0);    // helper waves per sweep slot
 // how far ahead helper h works: two pairs.  (Three -- 6 steps, so that a helper sums in the pair in which the main wave of its
 // SIMD has little to do -- is legal but slower: the waves of a slot meet at every pair, and then every pair is a heavy one
 // for somebody: 143 -> 165 ms.)
@@ -517,7 +536,7 @@ template <int P, int OFF, int DR = 0, int NEWSET = 0> __device__ __forceinline__
     static_assert(q >= -RING && q <= 15, "ring retention exceeded");
     static_assert(DR >= -HALO && DR <= HALO, "halo too small");
     constexpr int fl = floor_div8(q);
-    constexpr int m = (-fl) & (NBLK - 1);        // block a+1 shares the physical block of a-(NBLK-1)
+    constexpr int m = blk_mod(-fl);        // block a+1 shares the physical block of a-(NBLK-1)
     constexpr int within = q - 8 * fl;
     return base[m] + NEWSET * SET_BYTES + (HALO + DR) * LANE_B + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
 }
@@ -527,7 +546,7 @@ template <int P, int OFF, int LIDX, int NEWSET = 0> __device__ __forceinline__ i
     constexpr int q = P + OFF;
     static_assert(q >= -RING && q <= (NBLK > 4 ? 31 : 15), "ring retention exceeded");   // (images are written up to 2(L-1) steps ahead of their time)
     constexpr int fl = floor_div8(q);
-    constexpr int m = (-fl) & (NBLK - 1);
+    constexpr int m = blk_mod(-fl);
     constexpr int within = q - 8 * fl;
     return base[m] + NEWSET * SET_BYTES + LIDX * LANE_B + (within >> 1) * PAIR_BYTES + (within & 1) * 8;
 }
@@ -566,7 +585,7 @@ __device__ __forceinline__ void image_publish(const int (&u)[NBLK], bool st, boo
 // the low image for a lane at the start of its frame, the block of the high image (+ one lane) for a lane at its end,
 // a scratch area for everybody else.
 template <int L> struct ImageBlocks {
-    static constexpr int m_lo = (-floor_div8(-1)) & (NBLK - 1), m_hi = (-floor_div8(15)) & (NBLK - 1);
+    static constexpr int m_lo = blk_mod(-floor_div8(-1)), m_hi = blk_mod(-floor_div8(15));
     static_assert(L <= 7, "images within one block of the frame edge");
 };
 template <int PH, int NEWSET> __host__ __device__ constexpr int image_off() {   // offset of phase PH's image from its row origin
@@ -1117,7 +1136,7 @@ __device__ __forceinline__ void load_cells(const LaneCtx &cx, float2 (&t)[N]) {
         // (RE != 0, see th0: image cells start at bin C wherever it sits in the lane's block or the next one)
         constexpr bool img_lo = (b + 1 < 0), img_hi = (b >= th0(RE)) && (RE == 0 || b < th1(RE)), img_hi1 = (RE != 0) && (b >= th1(RE));
         constexpr int fl = floor_div8(q);
-        constexpr int m = (-fl) & (NBLK - 1);
+        constexpr int m = blk_mod(-fl);
         constexpr int within = q - 8 * fl;                       // even
         constexpr int setoff = (DR < 0) ? SET_BYTES : 0;
         int base = cx.ob[m];
@@ -1311,12 +1330,12 @@ __device__ __forceinline__ void helper_pair(const SysArgs &a, const LaneCtx &cx,
         static_for<Q - 1>([&](auto ir) {
             constexpr int R = decltype(ir)::value + 1;
             if constexpr (row_owner(R) == H) {
+                constexpr uint32_t kmask = (uint32_t)((MASK >> (R * (L + 1))) & ((1ull << (L + 1)) - 1ull));
+                if constexpr (kmask != 0) {   // (a frame pair the plan has)
                 static_assert(!quad_late_frame<-R, L>() && !quad_late_frame<R, L>(), "late frames stay with the main wave");
                 // two steps ahead of the second pair (rows_sum_ahead) and AHEAD ahead of the main wave: the newest tap
                 // fetched (fourth bin, +L) must have been produced before this pair started
                 static_assert(SKEW * R - L - 3 - AHEAD >= 1 && LAG - SKEW * R - L - 3 - AHEAD >= 1, "helper runs too far ahead");
-                constexpr uint32_t kmask = (uint32_t)((MASK >> (R * (L + 1))) & ((1ull << (L + 1)) - 1ull));
-                if constexpr (kmask != 0) {
                 float2 tu[2 * L + 6], td[2 * L + 6];
                 load_cells<PH0, -R, L, 0, L + 3, kmask, CO, RE>(cx, tu);
                 load_cells<PH0, R, L, 0, L + 3, kmask, CO, RE>(cx, td);
@@ -1393,7 +1412,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
     if (is_nyq_loader && PART != 1) {
         const float2 nin = raw_value<H16>(sv.nyq_in_next);   // loaded one block ago for this frame
         lds_write(NYQ_OFF + rho * 8, nin);
-        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, nin);   // and as entry "bin C" of set 0's image lane
+        lds_write(blk_mod(ablk) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, nin);   // and as entry "bin C" of set 0's image lane
         const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
         if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2<H16>(state_nyq_b, me1);
@@ -1411,7 +1430,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
             no[d] = NYQ_OFF + slot * SLOT_BYTES + lo * 8;
 #pragma unroll
             for (int m = 0; m < NBLK; ++m) {
-                const int blk = ((ablk - m) & (NBLK - 1)) * BLK_BYTES;
+                const int blk = blk_mod(ablk - m) * BLK_BYTES;
                 nb[d][m] = set_new + blk + ln * LANE_B;   // ring_addr adds the HALO offset
                 ob[d][m] = set_old + blk + lo * LANE_B;
             }
@@ -1467,7 +1486,7 @@ __device__ __forceinline__ void service_nyquist(const SysArgs &a, ServiceState &
         const bool active = real_row && (target > thr);
         const float2 out = project(acc, target, active, old);
         lds_write(nn[0], out);
-        lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, out);   // bin C of the image lane: production time = this clock
+        lds_write(set_new + blk_mod(ablk) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, out);   // bin C of the image lane: production time = this clock
         // (the last slot stores whatever reaches it: idle slots of the last group pass the final values on)
         if ((slot == NSLOTS - 1) && (v0 + RE - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2<H16>(state_nyq_b, me, out, MULTI);
         // target magnitude of the next block's Nyquist bin
@@ -1507,7 +1526,7 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
     if (is_nyq_loader) {
         const float2 nin = raw_value<H16>(sv.nyq_in_next);
         lds_write(NYQ_OFF + rho * 8, nin);
-        lds_write((ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, nin);
+        lds_write(blk_mod(ablk) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, nin);
         const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
         const int g1 = kap1 / Kr, k1 = kap1 - g1 * Kr, me1 = k1 * ROWL + rho1;
         if (vr1 >= 0 && me1 < a.Tp) sv.nyq_in_next = load_l2<H16>(state_nyq_b, me1);
@@ -1520,11 +1539,11 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
         const int ln = (rho - r) & (ROWL - 1), lo = (rho + r) & (ROWL - 1);
         // the taps at times -SKEW r - k (frame m-r, this sweep) and SKEW r - k - LAG (frame m+r, previous sweep): r whole ring
         // blocks before / after the block of time -k
-        const int bn = set_new + ((ablk - r - 1) & (NBLK - 1)) * BLK_BYTES + (ln + HALO) * LANE_B;
-        const int bo = set_old + ((ablk + r - 1) & (NBLK - 1)) * BLK_BYTES + (lo + HALO) * LANE_B;
+        const int bn = set_new + blk_mod(ablk - r - 1) * BLK_BYTES + (ln + HALO) * LANE_B;
+        const int bo = set_old + blk_mod(ablk + r - 1) * BLK_BYTES + (lo + HALO) * LANE_B;
         // (RE != 0: the taps k <= RE lie in the block of the frame end itself, one ring block later)
-        const int bn1 = set_new + ((ablk - r) & (NBLK - 1)) * BLK_BYTES + (ln + HALO) * LANE_B;
-        const int bo1 = set_old + ((ablk + r) & (NBLK - 1)) * BLK_BYTES + (lo + HALO) * LANE_B;
+        const int bn1 = set_new + blk_mod(ablk - r) * BLK_BYTES + (ln + HALO) * LANE_B;
+        const int bo1 = set_old + blk_mod(ablk + r) * BLK_BYTES + (lo + HALO) * LANE_B;
         // (LWS_TW: the lane's twiddle tau_r(C) is any complex number: taps turned as in service_nyquist, weights as they are)
         const float2 tau = TW ? lds_read(TWNYQ_OFF + (r & 7) * 8) : make_float2(1.f, 0.f);
         const int rot = (RE && !TW) ? ((RE * r) >> 1) & 3 : 0;        // quarter turns of this lane's weights
@@ -1586,7 +1605,7 @@ __device__ __forceinline__ void service_nyquist_rows(const SysArgs &a, ServiceSt
         const float2 out = project(acc, target, active, old);
         if (centre) {
             lds_write(nn, out);
-            lds_write(set_new + (ablk & (NBLK - 1)) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, out);
+            lds_write(set_new + blk_mod(ablk) * BLK_BYTES + PLR * LANE_B + (RE >> 1) * PAIR_BYTES, out);
             if ((slot == NSLOTS - 1) && (v0 + RE - C >= 0) && (me < a.Tp) && (g < n_groups)) store_l2<H16>(state_nyq_b, me, out, MULTI);
         }
         const int vr1 = vrow + 1, rho1 = vr1 & (ROWL - 1), kap1 = vr1 >> ROWL_SHIFT;
@@ -1617,7 +1636,11 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #if LWS_Q8
         // (hardware wave -> role table below) the list of the wave's role: mains 0, helpers 1 / 2
         const int hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if LWS_TWQ
+        const int owner = hw >= 4 ? 1 : 0;            // (role = hardware wave: mains 0..2, service 3, the helper of slot s 4 + s)
+#else
         const int owner = (hw == 2 || hw == 3) ? 1 : ((hw == 4 || hw == 5) ? 2 : 0);
+#endif
 #pragma unroll
         for (int x = 0; x < WLIST; ++x) {
             const unsigned long long u = owner == 0 ? a_in.w[x] : (owner == 1 ? a_in.w[WLIST + x] : a_in.w[2 * WLIST + x]);
@@ -1662,8 +1685,14 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
 #if LWS_Q8
     // hardware waves w and w + 4 share a SIMD: main 0 | main 1 | helper 1 of slot 0 | helper 1 of slot 1 on SIMDs 0..3, then the
     // (lighter) second helpers beside the mains and the service wave beside a first helper
+#if LWS_TWQ
+    // three slots of a main and one helper wave: main s on SIMD s with its helper beside it, the service wave alone on the fourth
+    static_assert(NSLOTS == 3 && NHELP == 1 && WPS == 1 && NWAVES == 7, "role table");
+    const int wave = hw_wave;
+#else
     static_assert(NSLOTS == 2 && NHELP == 2 && WPS == 1, "role table");   // (the weight lists above follow the same table)
     const int wave = hw_wave < 2 ? hw_wave : (hw_wave == 2 ? 3 : (hw_wave == 3 ? 5 : (hw_wave == 4 ? 4 : (hw_wave == 5 ? 6 : 2))));
+#endif
 #else
 #ifndef LWS_WIDE_ROLEMAP
 #define LWS_WIDE_ROLEMAP LWS_WIDE
@@ -1916,7 +1945,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
             }
     #pragma unroll
             for (int m = 0; m < NBLK; ++m) {
-                const int blk = ((ablk - m) & (NBLK - 1)) * BLK_BYTES;
+                const int blk = blk_mod(ablk - m) * BLK_BYTES;
                 cx.uo[m] = set_old + blk;
                 cx.ob[m] = set_old + blk + rl * LANE_B;
                 cx.obh[m] = cx.ob[m] + cx.halo_shift;
@@ -2013,7 +2042,7 @@ __global__ void __launch_bounds__(NTHREADS, (NTHREADS + 255) / 256) k_systolic(S
                     int ldb[NBLK], ldu[NBLK], ldh[NBLK];
     #pragma unroll
                     for (int m = 0; m < NBLK; ++m) {
-                        ldu[m] = (((t0 >> 3) - m) & (NBLK - 1)) * BLK_BYTES;
+                        ldu[m] = blk_mod((t0 >> 3) - m) * BLK_BYTES;
                         ldb[m] = ldu[m] + rl * LANE_B;
                         ldh[m] = ldb[m] + cx.halo_shift;
                     }
@@ -2546,6 +2575,7 @@ hipError_t systolic_build(SystolicPlan &sp, int F, int Lu, int Q, int Qp, const 
     if (Qp != Q && Qp != 2 * (F - 1)) return hipSuccess;
 #if LWS_TW && LWS_Q8
     if (Q < 5 || Q > 8 || Lu > 5 || fp16_storage) return hipSuccess;   // (fp32 storage only: half the instantiations of the other builds)
+    if (LWS_TWQ && Q != LWS_TWQ) return hipSuccess;                     // (the shallower rings: exactly that many frames per stencil row)
 #elif LWS_TW
     if (Q < 2 || Q > 4 || Lu > 5) return hipSuccess;     // (stencils narrower than L = 5 run with zero weights; Q = 2: a hop above half the frame)
 #elif LWS_Q8
@@ -2806,10 +2836,15 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
 #if LWS_TW && LWS_Q8
     // the Q = 8 kernel with the frame pairs r >= Q of the plan masked out (never fetched, never summed)
     kind = "tw";
+#if LWS_TWQ
+    if (Q != LWS_TWQ) return hipErrorInvalidValue;       // (systolic_build refuses every other Q)
+    e = launch_k<8, 5, mask_all(LWS_TWQ, 5)>(a, grid, h, stream);
+#else
     if (Q == 5) e = launch_k<8, 5, mask_all(5, 5)>(a, grid, h, stream);
     else if (Q == 6) e = launch_k<8, 5, mask_all(6, 5)>(a, grid, h, stream);
     else if (Q == 7) e = launch_k<8, 5, mask_all(7, 5)>(a, grid, h, stream);
     else e = launch_k<8, 5, mask_all(8, 5)>(a, grid, h, stream);
+#endif
 #elif LWS_TW
     kind = "tw";
     // hop = a third of the frame with the default sqrt-Hann window: of the centre frame's weights only k = 1 is non-zero (as for Q = 2, 4)
@@ -2846,7 +2881,7 @@ hipError_t launch_update(SystolicPlan &sp, const Geom &g, int wsel, const float 
         else e = launch_k<2, 5, mask_all(2, 5)>(a, grid, h, stream);
     }
 #endif
-    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_TW && SPW == 2) ? "_half" : (LWS_TW && LWS_WIDE) ? "_wide" : (LWS_TW && LWS_Q8) ? "_r64" : LWS_TW ? "" : (LWS_R16 && LWS_WIDE) ? "_wide_r16" : (LWS_R16 && SPW == 2) ? "_half_r16" : (LWS_R16 && SPW == 4) ? "_quarter_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
+    snprintf(sp.name_buf, sizeof sp.name_buf, "systolic%s_q%d_l%d_%s%s", (LWS_TW && SPW == 2) ? "_half" : (LWS_TW && LWS_WIDE) ? "_wide" : (LWS_TWQ == 5) ? "_r40" : (LWS_TWQ == 6) ? "_r48" : (LWS_TW && LWS_Q8) ? "_r64" : LWS_TW ? "" : (LWS_R16 && LWS_WIDE) ? "_wide_r16" : (LWS_R16 && SPW == 2) ? "_half_r16" : (LWS_R16 && SPW == 4) ? "_quarter_r16" : LWS_R16 ? "_r16" : LWS_WIDE == 2 ? "_xwide" : LWS_WIDE ? "_wide" : (SPW == 2 ? "_half" : (SPW == 4 ? "_quarter" : "")), Q, L, kind,
              h ? "_f16" : "");
     sp.name = sp.name_buf;
     return e;

@@ -314,11 +314,13 @@ def test_music_mode_with_speech_framing(oracle):
 def test_five_to_eight_frames_per_stencil_row(oracle, fsize, fshift, T):
     """ceil(frame / hop) in 5..8 -- Q = 5, 6, 7 (the reference's LWSanyQ) and fractional Q above 4 (LWSfractionalQ; lws(1024, 160):
     Qfloat = 6.4) -- on the 64-step ring of the Q = 8 build with table twiddles (lws::tw_q8: the Q = 8 kernel, the frame pairs the plan
-    does not have masked out).  lws(1024, 128) itself stays on the static Q = 8 build."""
+    does not have masked out; Q = 5 and 6 on the same kernel with a 40- / 48-step ring and three sweep slots, lws::tw_q5 / tw_q6).
+    lws(1024, 128) itself stays on the static Q = 8 build."""
     q = -(-fsize // fshift)
     static = fsize % fshift == 0 and q == 8
     out, name = tw_case(oracle, fsize, fshift, T, THR, seed=fsize + T, expect="hann" if static else "tw")
-    assert ("_r64_q%d_" % q in name) == (not static), name
+    ring = {5: 40, 6: 48}.get(q, 64)            # (round 5: exactly 5 / 6 frames per row run on a ring of their own depth, lws::tw_q5 / tw_q6)
+    assert ("_r%d_q%d_" % (ring, q) in name) == (not static), name
 
 
 @pytest.mark.parametrize("fsize,fshift,T", [(1000, 200, 37), (112, 16, 70), (100, 20, 64), (400, 160, 70), (768, 256, 40)])
