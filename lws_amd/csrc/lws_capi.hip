@@ -1031,7 +1031,7 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
                                             &lws::q8::systolic_entry(), &lws::wide_q2::systolic_entry(), &lws::wide::systolic_entry(), &lws::xwide::systolic_entry(), &lws::l7::systolic_entry(),
                                             // ... then the table-twiddle builds: Q = 3, and general weights of a hop that does not divide the frame
                                             &lws::tw_half::systolic_entry(), &lws::tw::systolic_entry(), &lws::tw_wide::systolic_entry(),
-                                            // (5 / 6 frames per stencil row: their own ring depth first; LWS_SYSTOLIC_NO_TWQ=1 skips them -- comparison runs)
+                                            // (exactly 5 / 6 frames per stencil row: the builds with their own ring depth first; LWS_SYSTOLIC_NO_TWQ=1 skips them -- comparison runs)
                                             &lws::tw_q5::systolic_entry(), &lws::tw_q6::systolic_entry(), &lws::tw_q8::systolic_entry()}) {
             const bool is_short = b == &lws::quarter::systolic_entry() || b == &lws::half::systolic_entry() || b == &lws::quarter_q2::systolic_entry() ||
                                   b == &lws::half_q2::systolic_entry() || b == &lws::tw_half::systolic_entry();

@@ -129,6 +129,9 @@
 #if LWS_TWQ && !(LWS_TW && LWS_Q8 && (LWS_TWQ == 5 || LWS_TWQ == 6))
 #error "LWS_TWQ = 5 or 6 goes with LWS_TW and LWS_Q8"
 #endif
+// (Measured and not kept, round 5: the same for exactly THREE frames per row -- a 24-step ring holds nine sweep slots where lws::tw has
+//  seven, ten waves of <= 151 VGPRs -- lws(768,256): 8.9 ps per bin-sweep against 7.9.  A pass of nine slots takes 1.37x a pass of seven:
+//  three waves on a SIMD that two already keep busy.  The shallower ring pays where sweep slots were missing, not where issue slots are.)
 #if LWS_TW && (LWS_WIDE == 2 || LWS_L7 || LWS_R16 || LWS_SPW == 4 || (LWS_Q8 && (LWS_WIDE || LWS_SPW != 1)))
 #error "LWS_TW goes with the narrow build, with LWS_SPW=2, with LWS_WIDE=1 or with LWS_Q8"
 #endif

@@ -1,6 +1,6 @@
 import sys, time; sys.path.insert(0,'.')
 import numpy as np, torch, lws_amd
-for fs,hop in ((1020,170),(1000,200),(1024,224)):
+for fs,hop in ((768,256),(1024,384),(1020,170),(1000,200),(1024,224)):
     p=lws_amd.lws(fs,hop); F=fs//2+1
     x=torch.rand((256,500,F),device='cuda').to(torch.complex64)
     thr=np.zeros(40)
