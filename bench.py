@@ -775,9 +775,8 @@ def main():
         for l in summary_lines(extra):
             print(l)
         # (numbers of tests/test_gpu_parity.py on an MI355X, round 5: the bench may not call the oracle on its product path)
-        notes = ("parity of this arithmetic path vs the fp64 oracle, 100 dense sweeps 500x513 from random phases: rel-L2 1.4e-5, median 2e-7, "
-                 "p99.9 2e-4, max 2e-3 (x mean|S|); from the timed zero-phase start (ill-conditioned) consistency within 0.05 dB, magnitudes 1e-6, "
-                 "fp64 plan median 1e-13 / max 1e-5 vs the reference fingerprint")
+        notes = ("parity of this arithmetic path vs the fp64 oracle (tests/test_gpu_parity.py): 100 dense sweeps 500x513 from random phases rel-L2 1.4e-5, "
+                 "median 2e-7, p99.9 2e-4 of mean|S|; timed zero-phase start (ill-conditioned): consistency within 0.05 dB, magnitudes 1e-6")
         also = {}
         try:
             c = extra.get("configs") or {}
