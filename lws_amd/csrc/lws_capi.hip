@@ -332,6 +332,19 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
         }
     }
     if constexpr (std::is_same<real, double>::value) {
+        // no-future sweeps of an fp64 plan: the LDS engine's one-lane-per-bin variant in double (the generic engine's bits)
+        if ((mode == lws::MODE_NOFUTURE || mode == lws::MODE_NOFUTURE_Q4_COMPAT) && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_ONLINE64", 0) &&
+            lws::nofuture_lds64_supports(a.F, a.T, a.L, a.Q, a.Qp, p->wperiod[a.wsel])) {
+            begin_timing(p, s);
+            hipError_t e = lws::launch_nofuture_lds64(a, B, p->wperiod[a.wsel], s);
+            end_timing(p, s);
+            if (e != hipSuccess) return fail(LWS_ERR_HIP, "fp64 no-future launch failed: %s", hipGetErrorString(e));
+            p->last_launches = 1;
+            p->last_name = mode == lws::MODE_NOFUTURE_Q4_COMPAT ? "nofuture_lds_q4compat_fp64" : "nofuture_lds_fp64";
+            return LWS_OK;
+        }
+    }
+    if constexpr (std::is_same<real, double>::value) {
         // online driver of an fp64 plan: the frames of the moving window in LDS, every sum in the generic engine's order (same bits)
         if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_ONLINE64", 0) &&
             lws::online64_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update)) {

@@ -22,16 +22,18 @@
 namespace lws {
 namespace {
 
-struct NfArgs {
-    float2 *state;       // [B][Tp][Np]
-    const float *amp;    // [B][Tp][Np]
-    const float *thr;    // [B][n_thr]
-    const float2 *w;     // [Q or Q'][Q][L+1], zero where flagged off
+// R: float, or double (round 5: the one-lane-per-bin variant only -- an fp64 plan's no-future sweeps in the generic engine's order, bit for bit)
+template <typename R> struct NfArgsT {
+    typename cx<R>::type *state;       // [B][Tp][Np]
+    const R *amp;    // [B][Tp][Np]
+    const R *thr;    // [B][n_thr]
+    const typename cx<R>::type *w;     // [Q or Q'][Q][L+1], zero where flagged off
     const uint8_t *flag; // [Q][Q][L+1]
     int F, T, L, Q, n_thr, NR, compat;
     int rows;            // weight rows kept in LDS: Q (summarised tensors: row = bin mod Q) or the period P of a general tensor's rows
                          // (Q' = N rows, one per bin -- lws.pyx:164-181 -- that repeat with period P = frame / gcd(frame, hop): row = bin mod P)
 };
+using NfArgs = NfArgsT<float>;
 
 template <typename C> __device__ __forceinline__ void pair(C &a, const C w, const C b, const C c) {
     a.x += w.x * (b.x + c.x) - w.y * (b.y - c.y);
@@ -53,22 +55,31 @@ __device__ __forceinline__ float2 load_state(const float2 *p) {
     return make_float2(__uint_as_float((unsigned)(u & 0xffffffffull)), __uint_as_float((unsigned)(u >> 32)));
 }
 
+__device__ __forceinline__ double2 load_state(const double2 *p) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_double2(__longlong_as_double((long long)a), __longlong_as_double((long long)b));
+}
+
 // One bin of frame `me`: weighted sum over the past frames, re-projection, Hermitian image upkeep -- update_bin /
 // update_bin_nfq4 of lws_generic.hip on the LDS ring.  UNI: every weight row has the same participation mask (m_uni).
-template <int QT, int LT, bool COMPAT, bool UNI>
-__device__ __forceinline__ void nf_update(int n, int me, float th, const float2 *S, const float2 *W, const unsigned long long *Mk,
-                                          unsigned long long m_uni, const float *amp_cur, float2 *cur, int Q_, int L_, int F,
+template <int QT, int LT, bool COMPAT, bool UNI, typename R, typename C2>
+__device__ __forceinline__ void nf_update(int n, int me, R th, const C2 *S, const C2 *W, const unsigned long long *Mk,
+                                          unsigned long long m_uni, const R *amp_cur, C2 *cur, int Q_, int L_, int F,
                                           int Np, int NR, int RW_) {
+    using float2 = C2;                                  // (the body below is written once for both precisions)
+    auto make_float2 = [](R x, R y) { C2 v; v.x = x; v.y = y; return v; };
     const int Q = QT ? QT : Q_, L = LT ? LT : L_, K1 = L + 1, RQ = Q * K1, nyq = F + L - 1;
     const int RW = QT ? QT : RW_;                       // weight rows: a compile-time Q implies a summarised tensor
     const int c = n - L;
-    const float target = amp_cur[n];
+    const R target = amp_cur[n];
     if (!(target > th)) return;
     const int row = c % RW;
     const float2 *wa = W + row * RQ;
     const int rowneg = (RW - row) % RW;
     const unsigned long long ma = UNI ? m_uni : Mk[row];
-    float2 acc = make_float2(0.f, 0.f);
+    float2 acc = make_float2((R)0, (R)0);
     if constexpr (COMPAT) {                            // update_bin_nfq4 of lws_generic.hip (lwslib.cpp:550-613)
         const int wrap_at = Np - 2 * n;                 // offsets j >= wrap_at run past the end of the frame
 #pragma unroll
@@ -76,7 +87,7 @@ __device__ __forceinline__ void nf_update(int n, int me, float th, const float2 
             // flat offset (me - r) * Np + 2n + j: column 2n + j of frame me - r, or past its end in the next frame
             const int i0 = ((me - r) & (NR - 1)) * Np + 2 * n, i1 = ((me - r + 1) & (NR - 1)) * Np + 2 * n - Np;
             const int u = r * K1;
-            const float sgn = ((c & 1) && (r & 1)) ? -1.f : 1.f;
+            const R sgn = ((c & 1) && (r & 1)) ? (R)-1 : (R)1;
 #pragma unroll
             for (int k = 1; k <= L; ++k)
                 if ((ma >> (u + k)) & 1ull) {
@@ -101,8 +112,8 @@ __device__ __forceinline__ void nf_update(int n, int me, float th, const float2 
             }
         }
     }
-    const float mag = sqrtf(acc.x * acc.x + acc.y * acc.y);
-    if (!(mag > 0.f)) return;
+    const R mag = sqrt(acc.x * acc.x + acc.y * acc.y);
+    if (!(mag > (R)0)) return;
     const float2 v = make_float2(acc.x * target / mag, acc.y * target / mag);
     cur[n] = v;
     const float2 vc = make_float2(v.x, -v.y);            // Hermitian images in the pad columns (lwslib.cpp:362-367)
@@ -192,8 +203,11 @@ __device__ __forceinline__ void nf_update_split(int n, int j, int me, float th, 
 
 // QT / LT: compile-time Q and L (0: use the run-time values); COMPAT: NoFuture_LWSQ4's flat addressing (Q = 4 only);
 // SPLIT: eight lanes per bin (production) or one (the verification variant, bit-identical to the generic engine)
-template <int QT, int LT, bool COMPAT, bool SPLIT>
-__global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
+template <int QT, int LT, bool COMPAT, bool SPLIT, typename R = float>
+__global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgsT<R> a) {
+    static_assert(!SPLIT || std::is_same<R, float>::value, "the eight-lanes-per-bin variant is fp32");
+    using float2 = typename cx<R>::type;          // (the body below is written once for both precisions)
+    auto make_float2 = [](R x, R y) { typename cx<R>::type v; v.x = x; v.y = y; return v; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Q = QT ? QT : a.Q, L = LT ? LT : a.L;
     const int RW = QT ? QT : a.rows;
@@ -203,9 +217,9 @@ __global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
     float2 *S = reinterpret_cast<float2 *>(smem);                 // [NR][Np] ring of extended frames
     float2 *W = S + (size_t)NR * Np;                              // [RW][Q][K1]
     unsigned long long *Mk = reinterpret_cast<unsigned long long *>(W + RW * RQ);   // [RW] + 1: which weights of a row take part
-    float *A = reinterpret_cast<float *>(Mk + RW + 1);            // [2][Np] target magnitudes of the current and the next frame
+    R *A = reinterpret_cast<R *>(Mk + RW + 1);            // [2][Np] target magnitudes of the current and the next frame
     float2 *gS = a.state + (size_t)b * Tp * Np;
-    const float *gA = a.amp + (size_t)b * Tp * Np;
+    const R *gA = a.amp + (size_t)b * Tp * Np;
     for (int i = tid; i < RW * RQ; i += nthr) W[i] = a.w[i];
     // The reference tests a flag per weight (lwslib.cpp:302,321,...).  Here the flags of a row are one bit mask (bit r*K1+k),
     // and when every row has the same mask -- always the case for create_weights' tensors, whose rows differ by unit-modulus
@@ -232,7 +246,7 @@ __global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
     if (n_split > F + L) n_split = F + L;
 
     for (int s = 0; s < a.n_thr; ++s) {
-        const float th = a.thr[(size_t)b * a.n_thr + s];
+        const R th = a.thr[(size_t)b * a.n_thr + s];
         // frames 0 .. Q-1 of the extended spectrogram: the left edge pads and the first frame to update
         __syncthreads();
         for (int i = tid; i < Q * Np; i += nthr) S[(size_t)((i / Np) & (NR - 1)) * Np + (i % Np)] = load_state(gS + i);
@@ -243,14 +257,14 @@ __global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
             float2 *cur = S + (size_t)(me & (NR - 1)) * Np;
             // the next frame, fetched now, stored after this frame's rounds (its slot held frame me + 1 - NR, long final)
             const bool have_next = me + 1 < Tp && m + 1 < T;
-            const float *amp_cur = A + (me & 1) * Np;
+            const R *amp_cur = A + (me & 1) * Np;
             float2 nxt[3];
-            float anxt[3];
+            R anxt[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int i = tid + j * nthr;
-                nxt[j] = (have_next && i < Np) ? load_state(gS + (size_t)(me + 1) * Np + i) : make_float2(0.f, 0.f);
-                anxt[j] = (have_next && i < Np) ? gA[(size_t)(me + 1) * Np + i] : 0.f;
+                nxt[j] = (have_next && i < Np) ? load_state(gS + (size_t)(me + 1) * Np + i) : make_float2((R)0, (R)0);
+                anxt[j] = (have_next && i < Np) ? gA[(size_t)(me + 1) * Np + i] : (R)0;
             }
             // bins are dealt to lanes (SPLIT: to groups of 8 lanes)
             constexpr int LPB = SPLIT ? 8 : 1;
@@ -260,8 +274,8 @@ __global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
                     if (uni) nf_update_split<QT, LT, COMPAT, true>(n, jl, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
                     else nf_update_split<QT, LT, COMPAT, false>(n, jl, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
                 } else {
-                    if (uni) nf_update<QT, LT, COMPAT, true>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
-                    else nf_update<QT, LT, COMPAT, false>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
+                    if (uni) nf_update<QT, LT, COMPAT, true, R, float2>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
+                    else nf_update<QT, LT, COMPAT, false, R, float2>(n, me, th, S, W, Mk, m_uni, amp_cur, cur, Q, L, F, Np, NR, RW);
                 }
             };
             if constexpr (COMPAT) {
@@ -296,17 +310,17 @@ __global__ void __launch_bounds__(SPLIT ? 1024 : 512) k_nofuture(NfArgs a) {
     }
 }
 
-template <int QT, int LT, bool COMPAT, bool SPLIT>
-hipError_t launch_ts(const NfArgs &a, int B, int threads, size_t lds, hipStream_t s) {
+template <int QT, int LT, bool COMPAT, bool SPLIT, typename R = float>
+hipError_t launch_ts(const NfArgsT<R> &a, int B, int threads, size_t lds, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};   // one bit per device
     int attr_dev;
     if (lws::attr_needed(attr_set, &attr_dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nofuture<QT, LT, COMPAT, SPLIT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nofuture<QT, LT, COMPAT, SPLIT, R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         lws::attr_done(attr_set, attr_dev);
     }
-    hipLaunchKernelGGL((k_nofuture<QT, LT, COMPAT, SPLIT>), dim3(B), dim3(threads), lds, s, a);
+    hipLaunchKernelGGL((k_nofuture<QT, LT, COMPAT, SPLIT, R>), dim3(B), dim3(threads), lds, s, a);
     return hipGetLastError();
 }
 // threads: of the one-lane-per-bin variant; the eight-lane one takes up to 1024
@@ -322,7 +336,7 @@ hipError_t launch_t(const NfArgs &a, int B, int threads, size_t lds, hipStream_t
 struct NfShape { int NR, threads; size_t lds; bool ok; };
 
 // rows: weight rows the kernel keeps in LDS (Q for a summarised tensor, the row period of a general one; 0: not periodic)
-NfShape shape_of(int F, int T, int L, int Q, int Qp, int rows) {
+NfShape shape_of(int F, int T, int L, int Q, int Qp, int rows, bool fp64 = false) {
     NfShape sh{0, 0, 0, false};
     if (rows < 1 || (Qp == Q && rows != Q) || (Qp != Q && (Qp != 2 * (F - 1) || Qp % rows != 0)) || Q < 2 || L < 1 || T < 1) return sh;
     const int Np = F + 2 * L;
@@ -334,11 +348,12 @@ NfShape shape_of(int F, int T, int L, int Q, int Qp, int rows) {
     // 1024 threads (frames of up to 3072 columns: 4096-point STFTs), the one-lane verification variant `threads`
     {
         const char *ev = getenv("LWS_NOFUTURE_SERIAL_TAPS");
-        const int launched = (ev && ev[0] == '1') ? sh.threads : (4 * sh.threads > 1024 ? 1024 : 4 * sh.threads);
+        const int launched = (fp64 || (ev && ev[0] == '1')) ? sh.threads : (4 * sh.threads > 1024 ? 1024 : 4 * sh.threads);
         if (3 * launched < Np) return sh;
     }
     if (Q * (L + 1) > 64) return sh;     // one 64-bit participation mask per weight row
-    sh.lds = (size_t)NR * Np * 8 + (size_t)rows * Q * (L + 1) * 8 + (size_t)(rows + 1) * 8 + (size_t)2 * Np * 4 + 16;
+    const size_t es = fp64 ? 2 : 1;      // fp64: twice the bytes per value
+    sh.lds = (size_t)NR * Np * 8 * es + (size_t)rows * Q * (L + 1) * 8 * es + (size_t)(rows + 1) * 8 + (size_t)2 * Np * 4 * es + 16;
     if (sh.lds > 160 * 1024) return sh;
     sh.ok = true;
     return sh;
@@ -347,6 +362,8 @@ NfShape shape_of(int F, int T, int L, int Q, int Qp, int rows) {
 }  // namespace
 
 bool nofuture_lds_supports(int F, int T, int L, int Q, int Qp, int rows) { return shape_of(F, T, L, Q, Qp, rows).ok; }
+// (summarised tensors only: the rows of a general tensor repeat to 1e-9, not to the bit)
+bool nofuture_lds64_supports(int F, int T, int L, int Q, int Qp, int rows) { return Qp == Q && shape_of(F, T, L, Q, Qp, rows, true).ok; }
 
 // Smallest P <= pmax dividing Qp such that the rows of W[Qp][Q][L+1] (complex128 interleaved) repeat with period P -- Q for a
 // summarised tensor (trivially), frame / gcd(frame, hop) for create_weights' general ones (lws.pyx:164-181) -- or 0.  The kernels
@@ -387,6 +404,26 @@ hipError_t launch_nofuture_lds(const GenericArgs<float> &g, int B, int rows, hip
     if (g.Q == 2 && g.L == 5) return launch_t<2, 5, false>(a, B, sh.threads, sh.lds, stream);
     if (g.Q == 8 && g.L == 5) return launch_t<8, 5, false>(a, B, sh.threads, sh.lds, stream);
     return launch_t<0, 0, false>(a, B, sh.threads, sh.lds, stream);
+}
+
+// The no-future sweeps of an fp64 plan: the one-lane-per-bin variant above in double -- update_bin / update_bin_nfq4 of lws_generic.hip on
+// the LDS ring, same arithmetic, same order, no contraction: generic_fp64's results bit for bit (tests/test_gpu_online64.py).
+hipError_t launch_nofuture_lds64(const GenericArgs<double> &g, int B, int rows, hipStream_t stream) {
+    const NfShape sh = shape_of(g.F, g.T, g.L, g.Q, g.Qp, rows, true);
+    if (!sh.ok) return hipErrorInvalidValue;
+    NfArgsT<double> a;
+    a.state = g.state; a.amp = g.amp; a.thr = g.thr;
+    a.w = g.w[g.wsel].w; a.flag = g.w[g.wsel].flag;
+    a.F = g.F; a.T = g.T; a.L = g.L; a.Q = g.Q; a.n_thr = g.n_thr; a.NR = sh.NR; a.rows = rows;
+    a.compat = (g.mode == MODE_NOFUTURE_Q4_COMPAT);
+    if (rows != g.Q || g.Qp != g.Q) return hipErrorInvalidValue;
+    if (a.compat) {
+        if (g.Q != 4) return hipErrorInvalidValue;
+        return g.L == 5 ? launch_ts<4, 5, true, false, double>(a, B, sh.threads, sh.lds, stream) : launch_ts<4, 0, true, false, double>(a, B, sh.threads, sh.lds, stream);
+    }
+    if (g.Q == 4 && g.L == 5) return launch_ts<4, 5, false, false, double>(a, B, sh.threads, sh.lds, stream);
+    if (g.Q == 2 && g.L == 5) return launch_ts<2, 5, false, false, double>(a, B, sh.threads, sh.lds, stream);
+    return launch_ts<0, 0, false, false, double>(a, B, sh.threads, sh.lds, stream);
 }
 
 }  // namespace lws

@@ -71,3 +71,45 @@ def test_run_lws_music_fp64_uses_it():
     assert np.array_equal(s1, pg.online_lws(pg.nofuture_lws(M)))
     out = p.run_lws(M)
     assert np.abs(np.abs(out) - M).max() < 1e-12 * M.max()
+
+
+# ---------------------------------------------------------------------------------------------- no-future sweeps of an fp64 plan
+@pytest.mark.parametrize("tag", ["64_16", "64_32", "64_8", "48_16"])
+def test_nofuture_goldens_and_generic_bits(tag):
+    """lws_nofuture.hip's one-lane-per-bin variant in double (round 5): NoFuture_LWSQ2 / anyQ and the shipped NoFuture_LWSQ4 addressing
+    (lwslib.cpp:473-690) -- the reference goldens to 1e-8 and generic_fp64's results bit for bit."""
+    g = load_golden("wrappers.npz")
+    W, W_ai, W_af = weights(tag)
+    S, thr = g[f"S_{tag}"], g[f"thr_{tag}"]
+    F = S.shape[1]
+    lds = _capi.Plan(F, W, W_ai, W_af, precision="fp64")
+    gen = _capi.Plan(F, W, W_ai, W_af, precision="fp64", force_generic=True)
+    out = lds.nofuture(S, thr[:2], wsel=_capi.LWS_W_AI)
+    assert lds.last_kernel()["name"] in ("nofuture_lds_fp64", "nofuture_lds_q4compat_fp64")
+    assert np.abs(out - g[f"nofuture_{tag}"]).max() < 1e-8
+    assert np.array_equal(out, gen.nofuture(S, thr[:2], wsel=_capi.LWS_W_AI)) and gen.last_kernel()["name"] == "generic_fp64"
+    out = lds.nofuture(np.abs(S), thr, wsel=_capi.LWS_W)
+    assert np.array_equal(out, gen.nofuture(np.abs(S), thr, wsel=_capi.LWS_W))
+    lds.close(); gen.close()
+
+
+@pytest.mark.parametrize("fsize,fshift,T", [(1024, 256, 60), (1024, 512, 40), (1024, 128, 30), (512, 128, 90), (768, 256, 40), (2048, 512, 12), (1000, 250, 30)])
+def test_nofuture_bit_identical_to_the_generic_engine(fsize, fshift, T):
+    rng = np.random.default_rng(fsize + T)
+    F = fsize // 2 + 1
+    p = lws_amd.lws(fsize, fshift, mode="music", precision="fp64", nofuture_iterations=2)
+    pg = lws_amd.lws(fsize, fshift, mode="music", precision="fp64", nofuture_iterations=2, force_generic=True)
+    S = rng.standard_normal((3, T, F)) + 1j * rng.standard_normal((3, T, F))
+    S[1] = np.abs(S[1])
+    S[2] *= 1e3
+    out = p.nofuture_lws(S)
+    assert p.plan().last_kernel()["name"].startswith("nofuture_lds") and p.plan().last_kernel()["name"].endswith("_fp64")
+    assert np.array_equal(out, pg.nofuture_lws(S)) and pg.plan().last_kernel()["name"] == "generic_fp64"
+
+
+def test_general_weights_of_an_fp64_plan_stay_on_the_generic_engine():
+    """The rows of a general tensor (use_simplifications=False) repeat to 1e-9, not to the bit: an fp64 plan keeps the order-exact engine."""
+    p = lws_amd.lws(64, 16, mode="music", precision="fp64", use_simplifications=False, nofuture_iterations=1)
+    S = np.abs(np.random.default_rng(0).standard_normal((9, 33))).astype(complex)
+    p.nofuture_lws(S)
+    assert p.plan().last_kernel()["name"] == "generic_fp64"
