@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace lws {
 namespace {
@@ -37,6 +39,11 @@ __device__ __forceinline__ void pair(double2 &a, const double2 w, const double2 
     a.y += w.x * (b.y + c.y) + w.y * (b.x - c.x);
 }
 
+__device__ __forceinline__ double2 sel(bool c, double2 a, double2 b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
+
+// (Measured and not kept, round 5: four waves sharing out the PRODUCTS of a bin's tap pairs through LDS, wave 0 adding them up in order --
+//  the same bits, the same 440 ms: the counters say one wave issues 1 380 vector instructions a step, 68 % of its time, but spreading the
+//  1 000 fp64 operations among them over four SIMDs bought nothing and cost 39 KB of LDS; profiles/r05_pmc_sq_online64.json.)
 template <int Q>
 __global__ void __launch_bounds__(64) k_online64(Args64 a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -45,19 +52,20 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
     const int rps = LA + 1, per = a.n_thr + 1, nsweeps = T * per;
     double2 *S = reinterpret_cast<double2 *>(smem);                       // [NWR][NPS] (+ 8)
     double *A = reinterpret_cast<double *>(S + (size_t)NWR * NPS + 8);    // [NWR][NPS]
-    double2 *W = reinterpret_cast<double2 *>(A + (size_t)NWR * NPS);      // [3][Q][Q][K1]
+    double2 *W = reinterpret_cast<double2 *>(A + (((size_t)NWR * NPS + 1) & ~(size_t)1));      // [3][Q][Q][K1] (16-byte aligned: the stride may be odd)
     double *thr_s = reinterpret_cast<double *>(W + 3 * Q * Q * K1);       // [n_thr]
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x, tid = threadIdx.x;
+    constexpr int NTH = 64;
     double2 *gS = a.state + (size_t)b * Tp * Np;
     const double *gA = a.amp + (size_t)b * Tp * Np;
 
-    for (int i = lane; i < 3 * Q * Q * K1; i += 64) W[i] = a.w[i / (Q * Q * K1)][i % (Q * Q * K1)];
-    for (int i = lane; i < NWR * NPS + 8; i += 64) S[i] = make_double2(0.0, 0.0);   // slots no frame has reached are read with zero weight: finite
-    for (int i = lane; i < NWR * NPS; i += 64) A[i] = 0.0;
-    for (int i = lane; i < a.n_thr; i += 64) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
+    for (int i = tid; i < 3 * Q * Q * K1; i += NTH) W[i] = a.w[i / (Q * Q * K1)][i % (Q * Q * K1)];
+    for (int i = tid; i < NWR * NPS + 8; i += NTH) S[i] = make_double2(0.0, 0.0);   // slots no frame has reached are read with zero weight: finite
+    for (int i = tid; i < NWR * NPS; i += NTH) A[i] = 0.0;
+    for (int i = tid; i < a.n_thr; i += NTH) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
     int loaded = Q < T + Q - 1 ? Q : T + Q - 1;          // rows 0 .. Q-1 (left edge pads and the first frame) are needed at step 0
     for (int r0 = 0; r0 < loaded; ++r0)
-        for (int i = lane; i < Np; i += 64) { S[r0 * NPS + i] = gS[(size_t)r0 * Np + i]; A[r0 * NPS + i] = gA[(size_t)r0 * Np + i]; }
+        for (int i = tid; i < Np; i += NTH) { S[r0 * NPS + i] = gS[(size_t)r0 * Np + i]; A[r0 * NPS + i] = gA[(size_t)r0 * Np + i]; }
 
     const int sigma = lane / rps, j = lane - sigma * rps;
     const bool lane_used = sigma < NSW;
@@ -92,7 +100,7 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
         while (loaded < T + Q - 1 && next_need <= t + 4) {
             const int slot = (loaded % NWR) * NPS;
             const bool evict = loaded >= NWR;
-            for (int i = lane; i < Np; i += 64) {
+            for (int i = tid; i < Np; i += NTH) {
                 if (evict) gS[(size_t)(loaded - NWR) * Np + i] = S[slot + i];
                 S[slot + i] = gS[(size_t)loaded * Np + i];
                 A[slot + i] = gA[(size_t)loaded * Np + i];
@@ -127,11 +135,13 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
                     const bool two = rr < ts;
                     // a frame to the right that is not usable yet contributes a zero: pair(w, b, 0) == w b, pair(w, 0, c) == conj(w) c,
                     // the one-sided forms of lwslib.cpp:1222-1253 (lws_generic.hip: mac / macc) bit for bit
-                    pair(acc, wa_r[0], lf[0], two ? rt[0] : zero);
+                    // (fetched whether usable or not, dropped by a select: `two ? rt[..] : zero` makes the compiler branch around every load)
+                    { const double2 rv = rt[0]; pair(acc, wa_r[0], lf[0], sel(two, rv, zero)); }
 #pragma unroll
                     for (int k = 1; k <= L; ++k) {
-                        pair(acc, wa_r[k], lf[-k], two ? rt[-k] : zero);
-                        pair(acc, wb_r[k], two ? rt[k] : zero, lf[k]);
+                        const double2 rm = rt[-k], rp = rt[k];
+                        pair(acc, wa_r[k], lf[-k], sel(two, rm, zero));
+                        pair(acc, wb_r[k], sel(two, rp, zero), lf[k]);
                     }
                 }
                 const int lj = ctb + nb;
@@ -157,7 +167,7 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
     const int first_row = loaded > NWR ? loaded - NWR : 0;
     for (int e = first_row; e < loaded; ++e) {
         const int slot = (e % NWR) * NPS;
-        for (int i = lane; i < Np; i += 64) gS[(size_t)e * Np + i] = S[slot + i];
+        for (int i = tid; i < Np; i += NTH) gS[(size_t)e * Np + i] = S[slot + i];
     }
 }
 
@@ -174,9 +184,32 @@ Shape64 shape64(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
     const int need = (SKS * LA + NU + 2 + r.NSW - 1) / r.NSW;      // a slot is free again when its sweep is over
     if (DS < need) DS = need;
     DS += DS & 1;
-    r.NPS = Np + (Np & 1);
+    // Row stride.  A lane's tap (frame j' rows from its unit's, 2 DS sigma columns from its neighbour sweep's) is a 16-byte double2: a
+    // wave's ds_read_b128 is served in four groups of 16 lanes, conflict-free when the 16 addresses of a group fall into 16 different
+    // 16-byte slots of a 256-byte line (MI355X_MICROARCH, LDS).  With the rows Np (+1) columns apart the sweeps' 64-byte steps and the
+    // frames' 192-byte steps left four slots for sixteen lanes -- every read took four times its cycles, and a step is 2 x 228 of them: the stride is chosen, among Np .. Np + 15, for the fewest cycles per read (439 -> 419 ms for config 3's stage).
+    {
+        static const int GRP[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                       {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+        const int rps = LA + 1;
+        int best = 0, best_cost = 1 << 30;
+        for (int pad = 0; pad < 16; ++pad) {
+            int cost = 0;
+            for (int g = 0; g < 4; ++g) {
+                int cnt[16] = {0}, mx = 0;
+                for (int i = 0; i < 16; ++i) {
+                    const int lane = GRP[g][i], sg = lane / rps, jj = lane % rps;
+                    const long addr = ((long)jj * (Np + pad) + 2L * DS * sg) * 16;
+                    mx = std::max(mx, ++cnt[(addr >> 4) & 15]);
+                }
+                cost += mx;
+            }
+            if (cost < best_cost) { best_cost = cost; best = pad; }
+        }
+        r.NPS = Np + best;
+    }
     auto lds_of = [&](int nwr) {
-        return ((size_t)nwr * r.NPS + 8) * 16 + (size_t)nwr * r.NPS * 8 + (size_t)3 * Q * Q * K1 * 16 + (size_t)n_thr * 8 + 64;
+        return ((size_t)nwr * r.NPS + 8) * 16 + (size_t)nwr * r.NPS * 8 + (size_t)3 * Q * Q * K1 * 16 + (size_t)(n_thr + 2) * 8 + 64;
     };
     int nwr_max = 16;
     while (nwr_max > 0 && lds_of(nwr_max) > 160 * 1024) --nwr_max;

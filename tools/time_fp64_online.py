@@ -1,0 +1,12 @@
+"""The online stage of an fp64 plan on config 3's shape (profiling target: tools/pmc_sq_kernel.sh r05_online64 k_online64 1 python tools/time_fp64_online.py)."""
+import sys, time; sys.path.insert(0, '.')
+import numpy as np, torch, lws_amd
+B, T, F = 256, 500, 513
+pm = lws_amd.lws(1024, 256, mode="music", precision="fp64")
+thr = lws_amd.get_thresholds(pm.online_iterations, pm.online_alpha, pm.online_beta, pm.online_gamma)
+M = np.abs(np.random.default_rng(0).standard_normal((B, T, F)) + 1j * np.random.default_rng(1).standard_normal((B, T, F))).astype(np.complex128)
+d = torch.from_numpy(M).cuda()
+for rep in range(2):
+    d.copy_(torch.from_numpy(M)); torch.cuda.synchronize(); t0 = time.perf_counter()
+    pm.plan().online_dev(d.data_ptr(), B, T, thr, pm.look_ahead, 4.0); torch.cuda.synchronize()
+    print("online fp64: %.1f ms (%s)" % (1e3 * (time.perf_counter() - t0), pm.plan().last_kernel()["name"]))
