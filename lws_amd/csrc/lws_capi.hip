@@ -371,7 +371,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
                 p->timing_pending = true;
                 if (e != hipSuccess) return fail(LWS_ERR_HIP, "fp64 systolic launch failed: %s", hipGetErrorString(e));
                 p->last_launches = launches;
-                p->last_name = lws::sys64_name(a.Q);
+                p->last_name = lws::sys64_name(a.F, a.T, a.Q);
                 return LWS_OK;
             }
             p->gsk_state.release(); p->gsk_amp.release();   // no room for the skewed copy: the generic engine below

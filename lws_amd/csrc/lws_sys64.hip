@@ -2,7 +2,7 @@
 //
 // What it computes: LWSQ2 / LWSQ4 / LWSanyQ (lwslib.cpp:72-373) -- every bin of every frame in the reference's order,
 // overwritten in place as soon as it is computed, Hermitian images kept in step (lwslib.cpp:356-368) -- for Q in {2, 4},
-// L = 5, frames of up to ~620 bins.  The sum of a bin is taken in a different ORDER than lwslib.cpp takes it (below), so
+// L = 5, frames of up to ~1070 bins.  The sum of a bin is taken in a different ORDER than lwslib.cpp takes it (below), so
 // results agree with the reference to rounding (1e-13 relative after 100 sweeps, tests/test_gpu_sys64.py), not bit for bit;
 // the order-exact fp64 engine remains lws_generic.hip (LWS_FORCE_GENERIC).
 //
@@ -26,6 +26,9 @@
 //     3-4 % (lane predicates are bitwise, one-lane work runs on zeroed inputs in the other lanes, every slot stores to HBM).
 //   * frames of up to ~300 bins: two spectrograms side by side in a wave, 32 lanes each (a.nls), chosen per call by steps per
 //     spectrogram and sweep.
+//   * frames of more than ~525 bins (round 5, WPS = 2): 128 frames in flight, a sweep slot is two waves side by side on a ring row of 128
+//     lanes (a lane period of 1024 steps; on 64 lanes such a frame needs a ring as deep as its surplus over 512 steps, one slot at best).
+//     Same step, same flow control, same layout with rows of 128; chosen per call like the 32-lane geometry.
 //
 // Entry: launch_sys64 (lws_sys64.h), called by lws_capi.hip:run_stage for MODE_BATCH of an fp64 plan.
 #include "lws_sys64.h"
@@ -51,12 +54,13 @@ inline int chunk_size() {
 }
 constexpr uint64_t MASK_Q4 = 0xfd7fc3, MASK_Q2 = 0x5c3, MASK_ALL = ~0ull;   // non-zero weights of the default (sqrt-Hann) windows   // ring rows of 1 KB that fit the LDS
 
-struct Geom { int P, gap, LAG, R, nblk, U, nls; long rows; };
+struct Geom { int P, gap, LAG, R, nblk, U, nls, rw; long rows; };   // rw: lanes of a ring row = 64 x waves per sweep slot
 // nls: lanes (= frames in flight) per spectrogram -- 64, or 32 with two spectrograms side by side in a wave (short frames: a lane
 // period of 64 x 8 steps would be half empty)
 inline Geom geom(int F, int T, int Q, int nls) {
     Geom g;
     g.nls = nls;
+    g.rw = nls > 64 ? nls : 64;
     const int NLN = nls;   // (shadows the wave width in the formulas below)
     const int Tp = T + 2 * (Q - 1);
     // steps a lane spends on a frame: its F bins, L steps before them (positions arrive L bins ahead); the L images above
@@ -79,7 +83,7 @@ struct S64Args {
     double2 *G;            // [B][rows][64] time-skewed state: frame me, bin c at row 8 (me % 64) + P (me / 64) + c + L
     const double *A;       // [B][rows][64] target magnitudes, same addressing
     const double *thr;     // [B][n_thr]
-    long g_stride;         // rows * 64
+    long g_stride;         // rows * row width (64, or 128 with two waves per sweep slot)
     int n_thr, thr0, ns;   // this pass: sweeps thr0 .. thr0 + ns - 1
     int F, T, P, gap, LAG, R, nblk, U;
     int nls, B;            // lanes per spectrogram (64 / 32: one / two spectrograms per workgroup), spectrograms of the call
@@ -120,8 +124,9 @@ __device__ __forceinline__ double2 sel(bool c, double2 a, double2 b) { double2 r
 
 // MASK: bit r (L + 1) + k set if W[0][r][k] may be non-zero -- the taps of the other weights are not compiled in (the reference
 // skips them at run time, lwslib.cpp:302,321).  Default windows: 0xfd7fc3 (Q = 4), 0x5c3 (Q = 2); anything else runs on MASK = ~0.
-template <int Q, bool FIRST, uint64_t MASK> struct Wave {
+template <int Q, bool FIRST, uint64_t MASK, int WPS> struct Wave {
     static constexpr int L = SL, NR = Q - 1, NA = 2 * SL + 1;
+    static constexpr int RW = NLN * WPS;   // lanes of a ring row: a sweep slot is WPS waves side by side (lane = place in the row)
     // lane state
     double2 acc[NA];          // sums of bins c .. c + 2L
     double2 cn[L + 1];        // cn[k]: new value of bin c - k
@@ -145,10 +150,10 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
 
     __device__ __forceinline__ Wave(const S64Args &a_, const BaseW<Q> &bw_, double2 *ring, double2 *G_, const double *A_, int s_, int lane_)
         : a(a_), bw(bw_), G(G_), A(A_), lane(lane_), s(s_) {
-        ring_own = ring + (size_t)s * a.R * NLN;
-        ring_prev = ring + (size_t)(s > 0 ? s - 1 : 0) * a.R * NLN;
+        ring_own = ring + (size_t)s * a.R * RW;
+        ring_prev = ring + (size_t)(s > 0 ? s - 1 : 0) * a.R * RW;
         last = s == a.ns - 1;
-        const int ls = lane & (a.nls - 1), hb = lane - ls, spw = NLN / a.nls;
+        const int ls = lane & (a.nls - 1), hb = lane - ls, spw = RW / a.nls;
         hi = hb != 0;
         {
             const int b0 = blockIdx.x * spw, b1 = b0 + spw - 1 < a.B ? b0 + spw - 1 : a.B - 1, ts = a.thr0 + (s < a.ns ? s : 0);
@@ -162,7 +167,7 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
             offR[r - 1] = hb + ((ls + r) & (a.nls - 1));
             const int wrap = ls + r >= a.nls ? a.gap : 0;
             ageR[r - 1] = a.LAG - L - SKW * r - wrap;
-            goffR[r - 1] = (L + SKW * r + wrap) * NLN + offR[r - 1];
+            goffR[r - 1] = (L + SKW * r + wrap) * RW + offR[r - 1];
         }
         double2 z; z.x = 0; z.y = 0;
 #pragma unroll
@@ -182,23 +187,23 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
     // LDS inputs of the step at ring time tmx, frame-time ux, lane position wx
     __device__ __forceinline__ void issue_lds(int tmx, int wx) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) nxL[r] = ring_own[slot(tmx, ageL[r]) * NLN + offL[r]];
+        for (int r = 0; r < NR; ++r) nxL[r] = ring_own[slot(tmx, ageL[r]) * RW + offL[r]];
         if constexpr (!FIRST) {
-            nxO = ring_prev[slot(tmx, a.LAG - L) * NLN + lane];
+            nxO = ring_prev[slot(tmx, a.LAG - L) * RW + lane];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) nxR[r] = ring_prev[slot(tmx, ageR[r]) * NLN + offR[r]];
+            for (int r = 0; r < NR; ++r) nxR[r] = ring_prev[slot(tmx, ageR[r]) * RW + offR[r]];
         }
         int cx = wx - L;
         if (cx < 0) cx += a.P;                        // still the images of the frame the lane has just left
         const int jj = cx - (a.F - 1);
-        nxI = ring_own[slot(tmx, (jj >= 1 && jj <= L) ? 2 * jj : 2) * NLN + lane];
+        nxI = ring_own[slot(tmx, (jj >= 1 && jj <= L) ? 2 * jj : 2) * RW + lane];
     }
     __device__ __forceinline__ void issue_global(int ux, int b) {
-        const double *Au = A + (size_t)(ux + MARG) * NLN;       // wave-uniform row pointers, per-lane constant offsets
+        const double *Au = A + (size_t)(ux + MARG) * RW;       // wave-uniform row pointers, per-lane constant offsets
         pfA[b] = Au[lane];
         if constexpr (FIRST) {
-            const double2 *Gu = G + (size_t)(ux + MARG) * NLN;
-            pfO[b] = Gu[L * NLN + lane];
+            const double2 *Gu = G + (size_t)(ux + MARG) * RW;
+            pfO[b] = Gu[L * RW + lane];
 #pragma unroll
             for (int r = 0; r < NR; ++r) pfR[b][r] = Gu[goffR[r]];
         }
@@ -378,9 +383,9 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
         }
         // (no position of a frame here -- before its bin 0, past its last image, before the first / after the last frame: val is
         //  the old value of such a row, which is zero, so zero is what gets written and the invariant of `neighbours` holds)
-        ring_own[tm * NLN + lane] = val;
+        ring_own[tm * RW + lane] = val;
         // (every slot stores: the last one the row of the state, the others a row of the margin nobody reads -- no branch)
-        G[(size_t)(last ? u + MARG : s) * NLN + lane] = val;
+        G[(size_t)(last ? u + MARG : s) * RW + lane] = val;
         S64_PIN();
         neighbours_later<PH, 2, NR>(sd);
         // ---- windows move on by one bin
@@ -396,9 +401,9 @@ template <int Q, bool FIRST, uint64_t MASK> struct Wave {
     }
 };
 
-template <int Q, bool FIRST, uint64_t MASK>
+template <int Q, bool FIRST, uint64_t MASK, int WPS>
 __device__ __forceinline__ void s64_wave(const S64Args &a, const BaseW<Q> &bw, double2 *ring, double2 *G, const double *A, int s, int lane) {
-    Wave<Q, FIRST, MASK> wv(a, bw, ring, G, A, s, lane);
+    Wave<Q, FIRST, MASK, WPS> wv(a, bw, ring, G, A, s, lane);
     const bool live = s < a.ns;
     const int t_end = a.U + a.LAG * (a.ns - 1);   // U and LAG are multiples of 8
     for (int t0 = 0; t0 < t_end; t0 += 8) {
@@ -420,63 +425,71 @@ __device__ __forceinline__ void s64_wave(const S64Args &a, const BaseW<Q> &bw, d
     }
 }
 
-template <int Q, int NS, uint64_t MASK>
-__global__ void __launch_bounds__(NLN * NS) k_sys64(S64Args a, BaseW<Q> bw) {
+template <int Q, int NS, uint64_t MASK, int WPS>
+__global__ void __launch_bounds__(NLN * NS * WPS) k_sys64(S64Args a, BaseW<Q> bw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s64_lds[];
     double2 *ring = reinterpret_cast<double2 *>(s64_lds);
-    const int lane = threadIdx.x & (NLN - 1);
-    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int RW = NLN * WPS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = wave / WPS;                                      // sweep slot
+    const int lane = (wave % WPS) * NLN + (threadIdx.x & (NLN - 1));   // place in the slot's ring row (WPS = 2: hardware waves 2s and 2s + 1 hold its two halves)
     double2 *G = a.G + (size_t)blockIdx.x * a.g_stride;
     const double *A = a.A + (size_t)blockIdx.x * a.g_stride;
     {
         double2 z; z.x = 0; z.y = 0;
-        for (int i = threadIdx.x; i < NS * a.R * NLN; i += NLN * NS) ring[i] = z;
+        for (int i = threadIdx.x; i < NS * a.R * RW; i += NLN * NS * WPS) ring[i] = z;
         __syncthreads();
     }
-    if (s == 0) s64_wave<Q, true, MASK>(a, bw, ring, G, A, s, lane);
-    else s64_wave<Q, false, MASK>(a, bw, ring, G, A, s, lane);
+    if (s == 0) s64_wave<Q, true, MASK, WPS>(a, bw, ring, G, A, s, lane);
+    else s64_wave<Q, false, MASK, WPS>(a, bw, ring, G, A, s, lane);
 }
 
 // extended buffers [B][Tp][Np] <-> the skewed layout
-__global__ void k_s64_load(const double2 *state, const double *amp, double2 *G, double *A, int F, int Tp, int P, long g_stride, int nls) {
+__global__ void k_s64_load(const double2 *state, const double *amp, double2 *G, double *A, int F, int Tp, int P, long g_stride, int nls, int rw) {
     const int bb = blockIdx.y, me = blockIdx.x, Np = F + 2 * SL;
-    const int spw = NLN / nls, b = bb / spw, ls = me & (nls - 1), j = (bb % spw) * nls + ls, blk = me / nls;   // b: workgroup
+    const int spw = rw / nls, b = bb / spw, ls = me & (nls - 1), j = (bb % spw) * nls + ls, blk = me / nls;   // b: workgroup
     const long base = (long)SKW * ls + (long)P * blk + SL + MARG;
     const double2 *src = state + ((size_t)bb * Tp + me) * Np + SL;
     const double *asrc = amp + ((size_t)bb * Tp + me) * Np + SL;
     for (int c = threadIdx.x; c < F + SL; c += blockDim.x) {
-        G[(size_t)b * g_stride + (base + c) * NLN + j] = src[c];
-        A[(size_t)b * g_stride + (base + c) * NLN + j] = asrc[c];
+        G[(size_t)b * g_stride + (base + c) * rw + j] = src[c];
+        A[(size_t)b * g_stride + (base + c) * rw + j] = asrc[c];
     }
 }
-__global__ void k_s64_store(double2 *state, const double2 *G, int F, int Tp, int P, long g_stride, int nls) {
+__global__ void k_s64_store(double2 *state, const double2 *G, int F, int Tp, int P, long g_stride, int nls, int rw) {
     const int bb = blockIdx.y, me = blockIdx.x, Np = F + 2 * SL;
-    const int spw = NLN / nls, b = bb / spw, ls = me & (nls - 1), j = (bb % spw) * nls + ls, blk = me / nls;
+    const int spw = rw / nls, b = bb / spw, ls = me & (nls - 1), j = (bb % spw) * nls + ls, blk = me / nls;
     const long base = (long)SKW * ls + (long)P * blk + SL + MARG;
     double2 *dst = state + ((size_t)bb * Tp + me) * Np + SL;
     for (int c = threadIdx.x; c < F + SL; c += blockDim.x) {
-        const double2 v = G[(size_t)b * g_stride + (base + c) * NLN + j];
+        const double2 v = G[(size_t)b * g_stride + (base + c) * rw + j];
         dst[c] = v;
         if (c >= 1 && c <= SL) dst[-c] = cj(v);
     }
 }
 
-template <int Q, int NS, uint64_t MASK>
+template <int Q, int NS, uint64_t MASK, int WPS = 1>
 hipError_t launch_pass(const S64Args &a, const BaseW<Q> &bw, int B, hipStream_t stream) {
     static std::atomic<unsigned long long> done{0};
-    const size_t lds = (size_t)NS * a.R * NLN * sizeof(double2);
+    constexpr int RW = NLN * WPS;
+    const size_t lds = (size_t)NS * a.R * RW * sizeof(double2);
     int dev = 0;
     if (attr_needed(done, &dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sys64<Q, NS, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sys64<Q, NS, MASK, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done(done, dev);
     }
-    k_sys64<Q, NS, MASK><<<dim3((B + NLN / a.nls - 1) / (NLN / a.nls)), dim3(NLN * NS), lds, stream>>>(a, bw);
+    k_sys64<Q, NS, MASK, WPS><<<dim3((B + RW / a.nls - 1) / (RW / a.nls)), dim3(NLN * NS * WPS), lds, stream>>>(a, bw);
     return hipGetLastError();
 }
 
-int slots_for(int Q, int R) {   // sweep slots per workgroup: what the LDS holds, among the builds that exist
-    const int fit = LDS_ROWS / R;
+int slots_for(int Q, int R, int rw) {   // sweep slots per workgroup: what the LDS holds, among the builds that exist
+    const int fit = (LDS_ROWS * NLN / rw) / R;
+    if (rw > NLN) {   // two waves per slot (frames of ~620 to ~1070 bins)
+        if (Q == 4) return fit >= 2 ? 2 : (fit >= 1 ? 1 : 0);
+        if (Q == 2) return fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0));
+        return 0;
+    }
     if (Q == 4) return fit >= 4 ? 4 : (fit >= 3 ? 3 : (fit >= 1 ? 1 : 0));   // (one wave per SIMD: a sweep slot uses > 256 registers)
     if (Q == 2) return fit >= 8 ? 8 : (fit >= 5 ? 5 : (fit >= 3 ? 3 : (fit >= 1 ? 1 : 0)));
     return 0;
@@ -519,13 +532,20 @@ template <int Q> bool base_weights(const double *W, int Qp, BaseW<Q> *out) {
 // and sweep (frames of up to ~300 bins).  NS = 0: no ring fits.
 Geom choose_geom(int F, int T, int Q, int *NS_out) {
     Geom best = geom(F, T, Q, NLN);
-    int best_ns = slots_for(Q, best.R);
+    int best_ns = slots_for(Q, best.R, best.rw);
     double best_cost = best_ns ? (double)(best.U + best.LAG * (best_ns - 1)) / best_ns : 1e300;
     const Geom h = geom(F, T, Q, NLN / 2);
-    const int h_ns = slots_for(Q, h.R);
+    const int h_ns = slots_for(Q, h.R, h.rw);
     if (h_ns) {
         const double cost = (double)(h.U + h.LAG * (h_ns - 1)) / h_ns / 2;
         if (cost < best_cost) { best = h; best_ns = h_ns; best_cost = cost; }
+    }
+    // frames too long for a 64-lane period (a ring as deep as the surplus): 128 frames in flight, two waves per sweep slot
+    const Geom w = geom(F, T, Q, 2 * NLN);
+    const int w_ns = slots_for(Q, w.R, w.rw);
+    if (w_ns) {
+        const double cost = (double)(w.U + w.LAG * (w_ns - 1)) / w_ns;
+        if (cost < best_cost) { best = w; best_ns = w_ns; best_cost = cost; }
     }
     *NS_out = best_ns;
     return best;
@@ -548,9 +568,9 @@ bool sys64_supports(int F, int T, int L, int Q, int Qp, int update, const double
 size_t sys64_bytes(int B, int F, int T, int Q, size_t *amp_bytes) {
     int ns = 0;
     const Geom g = choose_geom(F, T, Q, &ns);
-    const size_t wgs = (std::min(B, chunk_size()) + NLN / g.nls - 1) / (NLN / g.nls);
-    if (amp_bytes) *amp_bytes = wgs * g.rows * NLN * sizeof(double);
-    return wgs * g.rows * NLN * sizeof(double2);
+    const size_t wgs = (std::min(B, chunk_size()) + g.rw / g.nls - 1) / (g.rw / g.nls);
+    if (amp_bytes) *amp_bytes = wgs * g.rows * g.rw * sizeof(double);
+    return wgs * g.rows * g.rw * sizeof(double2);
 }
 
 bool sys64_layout(int F, int T, int Q, long out[4]) {
@@ -564,11 +584,15 @@ bool sys64_layout(int F, int T, int Q, long out[4]) {
     return true;
 }
 
-const char *sys64_name(int Q) { return Q == 2 ? "systolic_fp64_q2" : "systolic_fp64_q4"; }
+const char *sys64_name(int F, int T, int Q) {
+    int ns = 0;
+    const bool wide = choose_geom(F, T, Q, &ns).rw > NLN;
+    return Q == 2 ? (wide ? "systolic_fp64_q2_wide" : "systolic_fp64_q2") : (wide ? "systolic_fp64_q4_wide" : "systolic_fp64_q4");
+}
 
 namespace {
 template <int Q>
-hipError_t run_passes(S64Args a, const double *W, int Qp, int NS, int n_thr, int B, hipStream_t stream, int *n_out) {
+hipError_t run_passes(S64Args a, const double *W, int Qp, int NS, bool wide, int n_thr, int B, hipStream_t stream, int *n_out) {
     BaseW<Q> bw;
     if (!base_weights<Q>(W, Qp, &bw)) return hipErrorInvalidValue;
     // the build without the taps that the default windows' weights do not have, if this tensor has none of them either
@@ -582,7 +606,15 @@ hipError_t run_passes(S64Args a, const double *W, int Qp, int NS, int n_thr, int
         a.thr0 = i0;
         a.ns = std::min(NS, n_thr - i0);
         hipError_t e;
-        if constexpr (Q == 4) {
+        if (wide) {
+            if constexpr (Q == 4) {
+                if (dflt) e = NS == 2 ? launch_pass<4, 2, MASK_Q4, 2>(a, bw, B, stream) : launch_pass<4, 1, MASK_Q4, 2>(a, bw, B, stream);
+                else e = NS == 2 ? launch_pass<4, 2, MASK_ALL, 2>(a, bw, B, stream) : launch_pass<4, 1, MASK_ALL, 2>(a, bw, B, stream);
+            } else {
+                if (dflt) e = NS == 4 ? launch_pass<2, 4, MASK_Q2, 2>(a, bw, B, stream) : (NS == 2 ? launch_pass<2, 2, MASK_Q2, 2>(a, bw, B, stream) : launch_pass<2, 1, MASK_Q2, 2>(a, bw, B, stream));
+                else e = NS == 4 ? launch_pass<2, 4, MASK_ALL, 2>(a, bw, B, stream) : (NS == 2 ? launch_pass<2, 2, MASK_ALL, 2>(a, bw, B, stream) : launch_pass<2, 1, MASK_ALL, 2>(a, bw, B, stream));
+            }
+        } else if constexpr (Q == 4) {
             if (dflt) e = NS == 4 ? launch_pass<4, 4, MASK_Q4>(a, bw, B, stream) : (NS == 3 ? launch_pass<4, 3, MASK_Q4>(a, bw, B, stream) : launch_pass<4, 1, MASK_Q4>(a, bw, B, stream));
             else e = NS == 4 ? launch_pass<4, 4, MASK_ALL>(a, bw, B, stream) : (NS == 3 ? launch_pass<4, 3, MASK_ALL>(a, bw, B, stream) : launch_pass<4, 1, MASK_ALL>(a, bw, B, stream));
         } else {
@@ -605,7 +637,7 @@ hipError_t launch_sys64(const GenericArgs<double> &ga, const double *W_host, int
     if (NS < 1 || ga.mode != MODE_BATCH || ga.L != SL) return hipErrorInvalidValue;
     double2 *G = static_cast<double2 *>(gs);
     double *A = static_cast<double *>(gamp);
-    const long g_stride = g.rows * NLN;
+    const long g_stride = g.rows * g.rw;
     const size_t Np = F + 2 * SL;
     hipError_t e;
     if (ev0) (void)hipEventRecord(ev0, stream);
@@ -614,12 +646,12 @@ hipError_t launch_sys64(const GenericArgs<double> &ga, const double *W_host, int
     const int CHUNK = chunk_size();
     for (int b0 = 0; b0 < B; b0 += CHUNK) {
         const int Bc = std::min(CHUNK, B - b0);
-        const size_t wgs = (Bc + NLN / g.nls - 1) / (NLN / g.nls);
+        const size_t wgs = (Bc + g.rw / g.nls - 1) / (g.rw / g.nls);
         // rows no frame owns are read by lanes whose results are discarded; they must still be numbers the first time
         if ((e = hipMemsetAsync(G, 0, wgs * g_stride * sizeof(double2), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(A, 0, wgs * g_stride * sizeof(double), stream)) != hipSuccess) return e;
         double2 *state = ga.state + (size_t)b0 * Tp * Np;
-        k_s64_load<<<dim3(Tp, Bc), 256, 0, stream>>>(state, ga.amp + (size_t)b0 * Tp * Np, G, A, F, Tp, g.P, g_stride, g.nls);
+        k_s64_load<<<dim3(Tp, Bc), 256, 0, stream>>>(state, ga.amp + (size_t)b0 * Tp * Np, G, A, F, Tp, g.P, g_stride, g.nls, g.rw);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         S64Args a;
         a.G = G; a.A = A; a.thr = ga.thr + (size_t)b0 * ga.n_thr; a.g_stride = g_stride;
@@ -627,10 +659,10 @@ hipError_t launch_sys64(const GenericArgs<double> &ga, const double *W_host, int
         a.F = F; a.T = T; a.P = g.P; a.gap = g.gap; a.LAG = g.LAG; a.R = g.R; a.nblk = g.nblk; a.U = g.U;
         a.nls = g.nls; a.B = Bc;
         int n = 0;
-        e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, ga.n_thr, Bc, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, ga.n_thr, Bc, stream, &n);
+        e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, g.rw > NLN, ga.n_thr, Bc, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, g.rw > NLN, ga.n_thr, Bc, stream, &n);
         if (e != hipSuccess) return e;
         n_all += n;
-        k_s64_store<<<dim3(Tp, Bc), 256, 0, stream>>>(state, G, F, Tp, g.P, g_stride, g.nls);
+        k_s64_store<<<dim3(Tp, Bc), 256, 0, stream>>>(state, G, F, Tp, g.P, g_stride, g.nls, g.rw);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (ev1) (void)hipEventRecord(ev1, stream);

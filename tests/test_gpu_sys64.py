@@ -36,7 +36,13 @@ CASES = [
     (1024, 256, 20, 4),                # 513 bins: frame period 528 (16 steps more than 64 lanes x 8)
     (1024, 512, 75, 9),                # Q = 2 at 513 bins
     (996, 249, 66, 4),                 # 499 bins, not a multiple of anything
-    (1200, 300, 10, 4),                # 601 bins: one sweep slot only
+    (1200, 300, 10, 4),                # 601 bins: one sweep slot on 64 lanes -> the 128-lane geometry (round 5)
+    # 128 frames in flight, two waves per sweep slot (round 5: frames of ~620 to ~1070 bins)
+    (2048, 512, 20, 5),                # 1025 bins, Q = 4: two slots per pass, fewer frames than lanes
+    (2048, 512, 140, 3),               # lanes wrap to the next block of 128 frames
+    (2048, 1024, 131, 6),              # Q = 2 at 1025 bins: four slots per pass, 6 sweeps = two passes
+    (1536, 384, 30, 4),                # 769 bins: the period is the 128 lanes' own (no surplus steps)
+    (2100, 525, 12, 2),                # 1051 bins: one sweep slot only
 ]
 
 
@@ -49,6 +55,7 @@ def test_against_oracle(fsize, fshift, T, iters, oracle):
     out = p.batch_lws(S)
     name = p.plan().last_kernel()["name"]
     assert name.startswith("systolic_fp64_q"), name
+    assert name.endswith("_wide") == (fsize >= 1200), name       # 128 frames in flight from ~525 bins on (where 64 lanes hold one slot only)
     thr = lws_amd.get_thresholds(iters, 1.0, 0.1, 1)
     for b in range(2):
         ref = oracle.batch_lws(S[b], p.W, thr)
@@ -227,7 +234,7 @@ def test_large_batches_go_through_the_scratch_in_chunks(monkeypatch):
 
 def test_unsupported_shapes_fall_back():
     rng = np.random.default_rng(3)
-    for fsize, fshift in ((2048, 512), (60, 20), (64, 8)):     # 1025 bins, Q = 3, Q = 8
+    for fsize, fshift in ((4096, 1024), (2200, 550), (60, 20), (64, 8)):     # 2049 / 1101 bins, Q = 3, Q = 8
         p = lws_amd.lws(fsize, fshift, batch_iterations=2, precision="fp64")
         p.batch_lws(_spec(rng, 6, fsize // 2 + 1))
         assert p.plan().last_kernel()["name"].startswith("generic"), (fsize, fshift)

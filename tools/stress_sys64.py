@@ -12,8 +12,10 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 orc = Oracle()
 worst, names = 0.0, {}
-F_EDGE = [17, 19, 33, 65, 129, 251, 257, 499, 501, 503, 505, 507, 509, 511, 513, 515, 517, 519, 521, 523, 577, 601, 617]
-T_EDGE = [1, 2, 3, 5, 57, 58, 59, 61, 63, 64, 65, 66, 67, 121, 122, 127, 128, 129, 130, 200]
+F_EDGE = [17, 19, 33, 65, 129, 251, 257, 499, 501, 503, 505, 507, 509, 511, 513, 515, 517, 519, 521, 523, 577, 601, 617,
+          # 128 frames in flight, two waves per sweep slot (round 5): around its period of 1024 steps and its ring-size boundaries
+          619, 621, 641, 769, 1001, 1013, 1015, 1017, 1019, 1021, 1023, 1025, 1027, 1029, 1031, 1033, 1041, 1051, 1061, 1067]
+T_EDGE = [1, 2, 3, 5, 57, 58, 59, 61, 63, 64, 65, 66, 67, 121, 122, 123, 125, 127, 128, 129, 130, 131, 200, 257]
 for case in range(n_cases):
     Q = int(rng.choice([2, 4]))
     F = int(rng.choice(F_EDGE)) if rng.random() < 0.7 else int(rng.integers(9, 310)) * 2 + 1
@@ -25,8 +27,10 @@ for case in range(n_cases):
         continue
     fshift = fsize // Q
     T = int(rng.choice(T_EDGE)) if rng.random() < 0.6 else int(rng.integers(1, 150))
-    if F > 400:
+    if 400 < F < 619:
         T = min(T, 70)
+    if F >= 619 and T > 140 and rng.random() < 0.7:
+        T = min(T, 140)
     iters = int(rng.integers(1, 11))
     alpha = float(rng.choice([1.0, 3.0, 100.0]))
     p = lws_amd.lws(fsize, fshift, batch_iterations=iters, batch_alpha=alpha, precision="fp64")

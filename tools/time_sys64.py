@@ -27,6 +27,14 @@ def t(fsize, fshift, B, T, iters, generic=False):
 
 
 if __name__ == "__main__":
+    if "--wide" in sys.argv:   # 128 frames in flight (round 5): 2048-point frames, and the shapes the 64-lane geometry held one slot of
+        t(2048, 512, 256, 250, 40)
+        t(2048, 512, 256, 250, 40, generic=True)
+        t(2048, 1024, 256, 250, 40)
+        t(1536, 384, 256, 250, 40)
+        t(1200, 300, 256, 500, 40)
+        t(1100, 275, 256, 500, 40)
+        sys.exit(0)
     t(1024, 256, 256, 500, 100)
     if "--one" in sys.argv:
         sys.exit(0)
