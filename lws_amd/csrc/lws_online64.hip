@@ -44,7 +44,9 @@ __device__ __forceinline__ double2 sel(bool c, double2 a, double2 b) { return ma
 // (Measured and not kept, round 5: four waves sharing out the PRODUCTS of a bin's tap pairs through LDS, wave 0 adding them up in order --
 //  the same bits, the same 440 ms: the counters say one wave issues 1 380 vector instructions a step, 68 % of its time, but spreading the
 //  1 000 fp64 operations among them over four SIMDs bought nothing and cost 39 KB of LDS; profiles/r05_pmc_sq_online64.json.)
-template <int Q>
+// AMP_LDS: the target magnitudes of the window's frames in LDS beside the state (frames of up to ~700 bins); false: read from memory, one
+// value per bin update, requested before the bin's taps are summed (2048-point frames: the LDS holds the state rows only).
+template <int Q, bool AMP_LDS>
 __global__ void __launch_bounds__(64) k_online64(Args64 a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, DS = a.DS, NWR = a.NWR, NPS = a.NPS;
@@ -52,7 +54,7 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
     const int rps = LA + 1, per = a.n_thr + 1, nsweeps = T * per;
     double2 *S = reinterpret_cast<double2 *>(smem);                       // [NWR][NPS] (+ 8)
     double *A = reinterpret_cast<double *>(S + (size_t)NWR * NPS + 8);    // [NWR][NPS]
-    double2 *W = reinterpret_cast<double2 *>(A + (((size_t)NWR * NPS + 1) & ~(size_t)1));      // [3][Q][Q][K1] (16-byte aligned: the stride may be odd)
+    double2 *W = reinterpret_cast<double2 *>(A + (AMP_LDS ? (((size_t)NWR * NPS + 1) & ~(size_t)1) : 0));      // [3][Q][Q][K1] (16-byte aligned: the stride may be odd)
     double *thr_s = reinterpret_cast<double *>(W + 3 * Q * Q * K1);       // [n_thr]
     const int b = blockIdx.x, lane = threadIdx.x, tid = threadIdx.x;
     constexpr int NTH = 64;
@@ -61,11 +63,12 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
 
     for (int i = tid; i < 3 * Q * Q * K1; i += NTH) W[i] = a.w[i / (Q * Q * K1)][i % (Q * Q * K1)];
     for (int i = tid; i < NWR * NPS + 8; i += NTH) S[i] = make_double2(0.0, 0.0);   // slots no frame has reached are read with zero weight: finite
-    for (int i = tid; i < NWR * NPS; i += NTH) A[i] = 0.0;
+    if constexpr (AMP_LDS)
+        for (int i = tid; i < NWR * NPS; i += NTH) A[i] = 0.0;
     for (int i = tid; i < a.n_thr; i += NTH) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
     int loaded = Q < T + Q - 1 ? Q : T + Q - 1;          // rows 0 .. Q-1 (left edge pads and the first frame) are needed at step 0
     for (int r0 = 0; r0 < loaded; ++r0)
-        for (int i = tid; i < Np; i += NTH) { S[r0 * NPS + i] = gS[(size_t)r0 * Np + i]; A[r0 * NPS + i] = gA[(size_t)r0 * Np + i]; }
+        for (int i = tid; i < Np; i += NTH) { S[r0 * NPS + i] = gS[(size_t)r0 * Np + i]; if constexpr (AMP_LDS) A[r0 * NPS + i] = gA[(size_t)r0 * Np + i]; }
 
     const int sigma = lane / rps, j = lane - sigma * rps;
     const bool lane_used = sigma < NSW;
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
             for (int i = tid; i < Np; i += NTH) {
                 if (evict) gS[(size_t)(loaded - NWR) * Np + i] = S[slot + i];
                 S[slot + i] = gS[(size_t)loaded * Np + i];
-                A[slot + i] = gA[(size_t)loaded * Np + i];
+                if constexpr (AMP_LDS) A[slot + i] = gA[(size_t)loaded * Np + i];
             }
             ++loaded;
             next_need += frame_period;
@@ -120,6 +123,8 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
                 if (cb >= F) break;
                 const int row = cb % Q, rowneg = (Q - row) % Q;
                 const double2 *wa = W + wset * Q * Q * K1 + row * Q * K1;
+                double target_mem = 0.0;
+                if constexpr (!AMP_LDS) target_mem = gA[(size_t)(rho + Q - 1) * Np + nb];   // (in flight while the taps are summed)
                 double2 acc = zero;
                 if (centre) {
                     const double2 *ctr = S + ctb + nb;
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
                     }
                 }
                 const int lj = ctb + nb;
-                const double target = A[lj];
+                const double target = AMP_LDS ? A[lj] : target_mem;
                 if (target > thr) {
                     const double mag = sqrt(acc.x * acc.x + acc.y * acc.y);
                     if (mag > 0.0) {
@@ -171,10 +176,10 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
     }
 }
 
-struct Shape64 { int NSW, DS, NWR, NPS; size_t lds; bool ok; };
+struct Shape64 { int NSW, DS, NWR, NPS; size_t lds; bool ok, amp_lds; };
 // The schedule of lws_online.hip: shape4_try for its verification variant (even lag), sized for fp64 rows.
 Shape64 shape64(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
-    Shape64 r{0, 0, 0, 0, 0, false};
+    Shape64 r{0, 0, 0, 0, 0, false, true};
     if (Qp != Q || Lu != L || LA < 0 || LA > 63 || n_thr < 1 || T < 1 || !(Q == 2 || Q == 3 || Q == 4 || Q == 8)) return r;
     const int Np = F + 2 * L, per = n_thr + 1, NU = (F + 1) / 2;
     if (F - 1 < 2 * (L + 3)) return r;
@@ -208,15 +213,27 @@ Shape64 shape64(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
         }
         r.NPS = Np + best;
     }
-    auto lds_of = [&](int nwr) {
-        return ((size_t)nwr * r.NPS + 8) * 16 + (size_t)nwr * r.NPS * 8 + (size_t)3 * Q * Q * K1 * 16 + (size_t)(n_thr + 2) * 8 + 64;
-    };
-    int nwr_max = 16;
-    while (nwr_max > 0 && lds_of(nwr_max) > 160 * 1024) --nwr_max;
     auto window_of = [&](int ds) { return (ds * (per - 1) + NU + 3) / (ds * per + SKS) + LA + Q; };   // frames alive at once
+    // the window's state rows and magnitudes in LDS; if that does not fit at the schedule's own pace, the state rows alone (the
+    // magnitudes then come from memory, k_online64<.., false>); only then a slower schedule (fewer frames alive at once)
     const int ds0 = DS;
-    while (window_of(DS) > nwr_max && DS < 16 * ds0) DS += 2;
+    int nwr_max = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+        r.amp_lds = pass == 0;
+        auto lds_try = [&](int nwr) {
+            return ((size_t)nwr * r.NPS + 8) * 16 + (r.amp_lds ? (size_t)nwr * r.NPS * 8 + 8 : 0) + (size_t)3 * Q * Q * K1 * 16 + (size_t)(n_thr + 2) * 8 + 64;
+        };
+        nwr_max = 16;
+        while (nwr_max > 0 && lds_try(nwr_max) > 160 * 1024) --nwr_max;
+        DS = ds0;
+        if (pass == 2)
+            while (window_of(DS) > nwr_max && DS < 16 * ds0) DS += 2;
+        if (window_of(DS) <= nwr_max) break;
+    }
     if (window_of(DS) > nwr_max) return r;
+    auto lds_of = [&](int nwr) {
+        return ((size_t)nwr * r.NPS + 8) * 16 + (r.amp_lds ? (size_t)nwr * r.NPS * 8 + 8 : 0) + (size_t)3 * Q * Q * K1 * 16 + (size_t)(n_thr + 2) * 8 + 64;
+    };
     r.DS = DS;
     const int window = window_of(DS);
     r.NWR = window + 1 <= nwr_max ? window + 1 : window;
@@ -226,11 +243,14 @@ Shape64 shape64(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
     return r;
 }
 
-template <int Q> hipError_t launch_q(const Args64 &a, int B, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online64<Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <int Q, bool AMP_LDS> hipError_t launch_qa(const Args64 &a, int B, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online64<Q, AMP_LDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_online64<Q>), dim3(B), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((k_online64<Q, AMP_LDS>), dim3(B), dim3(64), lds, s, a);
     return hipGetLastError();
+}
+template <int Q> hipError_t launch_q(const Args64 &a, int B, size_t lds, bool amp_lds, hipStream_t s) {
+    return amp_lds ? launch_qa<Q, true>(a, B, lds, s) : launch_qa<Q, false>(a, B, lds, s);
 }
 
 }  // namespace
@@ -248,10 +268,10 @@ hipError_t launch_online64(const GenericArgs<double> &g, int B, hipStream_t stre
     for (int i = 0; i < 3; ++i) a.w[i] = g.w[i].w;
     a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = sh.NSW; a.DS = sh.DS; a.NWR = sh.NWR; a.NPS = sh.NPS;
     switch (g.Q) {
-    case 2: return launch_q<2>(a, B, sh.lds, stream);
-    case 3: return launch_q<3>(a, B, sh.lds, stream);
-    case 4: return launch_q<4>(a, B, sh.lds, stream);
-    default: return launch_q<8>(a, B, sh.lds, stream);
+    case 2: return launch_q<2>(a, B, sh.lds, sh.amp_lds, stream);
+    case 3: return launch_q<3>(a, B, sh.lds, sh.amp_lds, stream);
+    case 4: return launch_q<4>(a, B, sh.lds, sh.amp_lds, stream);
+    default: return launch_q<8>(a, B, sh.lds, sh.amp_lds, stream);
     }
 }
 

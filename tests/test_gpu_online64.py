@@ -55,10 +55,27 @@ def test_bit_identical_to_the_generic_engine(fsize, fshift, T, LA, iters):
 
 
 def test_frames_too_long_for_fp64_rows_stay_on_the_generic_engine():
-    p = lws_amd.lws(2048, 512, mode="music", precision="fp64", online_iterations=2)
-    S = np.abs(np.random.default_rng(0).standard_normal((6, 1025))).astype(complex)
+    p = lws_amd.lws(4096, 1024, mode="music", precision="fp64", online_iterations=2)
+    S = np.abs(np.random.default_rng(0).standard_normal((6, 2049))).astype(complex)
     p.online_lws(S)
     assert p.plan().last_kernel()["name"] == "generic_fp64"
+
+
+@pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(2048, 512, 14, 3, 3), (2048, 1024, 9, 3, 10), (2048, 512, 30, 0, 2), (1536, 384, 20, 5, 4), (2048, 512, 5, 4, 2)])
+def test_2048_point_frames_keep_their_magnitudes_in_memory(fsize, fshift, T, LA, iters):
+    """Frames whose window of state rows AND magnitudes does not fit the LDS (from ~700 bins): k_online64<Q, false> keeps the state rows
+    only and reads a bin's target magnitude from memory while its taps are summed -- the same sums, the same bits."""
+    rng = np.random.default_rng(fsize + T)
+    F = fsize // 2 + 1
+    p = lws_amd.lws(fsize, fshift, mode="music", precision="fp64", look_ahead=LA, online_iterations=iters)
+    pg = lws_amd.lws(fsize, fshift, mode="music", precision="fp64", look_ahead=LA, online_iterations=iters, force_generic=True)
+    S = rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))
+    S[1] = np.abs(S[1]) * 1e2
+    out = p.online_lws(S)
+    assert p.plan().last_kernel()["name"] == "online_lds_fp64"
+    assert np.array_equal(out, pg.online_lws(S))
+    assert pg.plan().last_kernel()["name"] == "generic_fp64"
+    assert np.isfinite(out).all() and np.abs(np.abs(out) - np.abs(S)).max() < 1e-9 * np.abs(S).max()
 
 
 def test_run_lws_music_fp64_uses_it():
