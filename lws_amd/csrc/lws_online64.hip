@@ -10,6 +10,9 @@
 // (no twiddle structure assumed: any summarised tensor, Qp == Q).  A single wave needs no barrier: its LDS operations complete in
 // order.  fp64 FMA contraction is off for this file (Makefile), as for the generic engine.
 //
+// Frames whose window does not fit the LDS with its magnitudes (2048-point frames) keep the state rows there and read the magnitudes from
+// memory (AMP_LDS = false).
+//
 // Entry: online64_supports / launch_online64 (lws_online64.h), called by lws_capi.hip: run_stage for MODE_ONLINE of an fp64 plan.
 #include "lws_online64.h"
 
