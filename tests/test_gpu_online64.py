@@ -90,6 +90,25 @@ def test_run_lws_music_fp64_uses_it():
     assert np.abs(np.abs(out) - M).max() < 1e-12 * M.max()
 
 
+def test_run_lws_music_fp64_of_a_2048_point_plan_has_no_generic_stage():
+    rng = np.random.default_rng(6)
+    M = np.abs(rng.standard_normal((2, 30, 1025)) + 1j * rng.standard_normal((2, 30, 1025)))
+    p = lws_amd.lws(2048, 512, mode="music", precision="fp64", batch_iterations=12)
+    pg = lws_amd.lws(2048, 512, mode="music", precision="fp64", batch_iterations=12, force_generic=True)
+    s0 = p.nofuture_lws(M)
+    assert p.plan().last_kernel()["name"].startswith("nofuture_lds") and p.plan().last_kernel()["name"].endswith("_fp64")
+    assert np.array_equal(s0, pg.nofuture_lws(M))
+    s1 = p.online_lws(s0)
+    assert p.plan().last_kernel()["name"] == "online_lds_fp64"
+    assert np.array_equal(s1, pg.online_lws(s0))
+    s2 = p.batch_lws(s1)
+    assert p.plan().last_kernel()["name"] == "systolic_fp64_q4_wide"
+    ref = pg.batch_lws(s1)
+    assert np.abs(s2 - ref).max() < 1e-10 * np.abs(ref).max()
+    out = p.run_lws(M)
+    assert np.abs(np.abs(out) - M).max() < 1e-12 * M.max()
+
+
 # ---------------------------------------------------------------------------------------------- no-future sweeps of an fp64 plan
 @pytest.mark.parametrize("tag", ["64_16", "64_32", "64_8", "48_16"])
 def test_nofuture_goldens_and_generic_bits(tag):
