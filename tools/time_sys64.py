@@ -27,6 +27,9 @@ def t(fsize, fshift, B, T, iters, generic=False):
 
 
 if __name__ == "__main__":
+    if "--wide-one" in sys.argv:   # profiling target of tools/profile_sys64.sh <tag> --wide-one
+        t(2048, 512, 256, 250, 40)
+        sys.exit(0)
     if "--wide" in sys.argv:   # 128 frames in flight (round 5): 2048-point frames, and the shapes the 64-lane geometry held one slot of
         t(2048, 512, 256, 250, 40)
         t(2048, 512, 256, 250, 40, generic=True)
