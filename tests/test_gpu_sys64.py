@@ -232,6 +232,22 @@ def test_large_batches_go_through_the_scratch_in_chunks(monkeypatch):
         assert np.array_equal(whole, parts)
 
 
+@pytest.mark.parametrize("fsize,fshift,T,iters", [(2048, 512, 700, 3), (2048, 1024, 530, 5), (1536, 384, 400, 4)])
+def test_wide_geometry_over_many_blocks_of_frames(fsize, fshift, T, iters):
+    """128 frames in flight: four to six blocks of 128 frames, complex and magnitudes-only input, against the order-exact engine
+    (to rounding: the sums are taken in another order)."""
+    rng = np.random.default_rng(T)
+    F = fsize // 2 + 1
+    p = lws_amd.lws(fsize, fshift, batch_iterations=iters, batch_alpha=1.0, precision="fp64")
+    pg = lws_amd.lws(fsize, fshift, batch_iterations=iters, batch_alpha=1.0, precision="fp64", force_generic=True)
+    S = np.stack([_spec(rng, T, F), _spec(rng, T, F, real=True)])
+    out = p.batch_lws(S)
+    assert p.plan().last_kernel()["name"].endswith("_wide")
+    ref = pg.batch_lws(S)
+    assert pg.plan().last_kernel()["name"] == "generic_skew_fp64"
+    assert np.abs(out - ref).max() < 1e-10 * np.abs(ref).max()
+
+
 def test_unsupported_shapes_fall_back():
     rng = np.random.default_rng(3)
     for fsize, fshift in ((4096, 1024), (2200, 550), (60, 20), (64, 8)):     # 2049 / 1101 bins, Q = 3, Q = 8
