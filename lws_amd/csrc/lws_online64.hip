@@ -34,6 +34,7 @@ struct Args64 {
     const double *thr;     // [B][n_thr]
     const double2 *w[3];   // W, W_ai, W_af: [Q][Q][L+1], zero where flagged off (lws_capi.hip: upload_weights)
     int F, T, n_thr, LA, NSW, DS, NWR, NPS;
+    int stress;            // test hook (LWS_ONLINE64_STRESS): the two-wave kernel's waves idle for pseudo-random times inside their half-steps
 };
 
 // a += w b + conj(w) c, the grouped form of lwslib.cpp:310-311 exactly as lws_generic.hip: pair() writes it
@@ -179,6 +180,201 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Two waves per spectrogram (round 5): the wave above issues 1 380 vector instructions a step and that is its time.  The two bins of a
+// step depend on each other through the centre frame only (bin c + 1 starts from the new bin c: its k = 1 tap, and near DC / Nyquist the
+// Hermitian image of it), so wave 0 takes the even bin of every step, wave 1 the odd one, and each splits its bin in two:
+//   P  the PRODUCTS of the neighbour frames' tap pairs, w (b + c) ... of lwslib.cpp:310-311, one (re, im) per pair, kept in registers
+//      -- they involve other (sweep, frame) units' frames only, which are final steps before (below);
+//   C  the chain: the centre frame's five tap pairs, then the products added IN THE ORDER the one-wave kernel adds them, the
+//      re-projection and the stores.
+// acc += (m1 - m2) is two roundings whether the difference is formed now or a step earlier: the sums -- and the results -- are the
+// one-wave kernel's and the generic engine's, bit for bit.  A step is two half-steps, each closed by a barrier of the two waves:
+//      wave 0:  C(bin 2u) . P1(bin 2u+2) | P2(bin 2u+2)
+//      wave 1:  P2(bin 2u+1)             | C(bin 2u+1) . P1(bin 2u+3)
+// with P1 / P2 the first SPLIT / the other pairs, cut so that the halves take the same time.  Reading ahead is legal: a product of bin c + 3
+// is formed one and a half steps before the one-wave schedule reads its taps (up to bin c + 8 of the frame one to the left, which that
+// frame's even-bin wave wrote in the first half of this step; up to c + 8 of the previous sweep's frames, 2 DS - 8 r >= 8 bins ahead:
+// shape64 keeps 2 DS >= 8 Q + 2), and reading later-to-be-overwritten values earlier is always safe.
+template <class Fn, int... I> __device__ __forceinline__ void static_for64_impl(Fn &f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class Fn> __device__ __forceinline__ void static_for64(Fn &&f) { static_for64_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int Q, bool AMP_LDS, int SPLIT, bool STRESS>
+__global__ void __launch_bounds__(128) k_online64p(Args64 a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, DS = a.DS, NWR = a.NWR, NPS = a.NPS;
+    const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), NU = (F + 1) / 2;
+    const int rps = LA + 1, per = a.n_thr + 1, nsweeps = T * per;
+    double2 *S = reinterpret_cast<double2 *>(smem);                       // [NWR][NPS] (+ 8)
+    double *A = reinterpret_cast<double *>(S + (size_t)NWR * NPS + 8);    // [NWR][NPS] (AMP_LDS)
+    double2 *W = reinterpret_cast<double2 *>(A + (AMP_LDS ? (((size_t)NWR * NPS + 1) & ~(size_t)1) : 0));
+    double *thr_s = reinterpret_cast<double *>(W + 3 * Q * Q * K1);
+    const int b = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int par = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // 0: the even bin of a step, 1: the odd one
+    constexpr int NTH = 128;
+    constexpr int NP = (Q - 1) * (2 * L + 1);                             // neighbour tap pairs of a bin, in the order they are added
+    static_assert(SPLIT >= 0 && SPLIT <= NP, "cut of the pair list");
+    double2 *gS = a.state + (size_t)b * Tp * Np;
+    const double *gA = a.amp + (size_t)b * Tp * Np;
+
+    for (int i = tid; i < 3 * Q * Q * K1; i += NTH) W[i] = a.w[i / (Q * Q * K1)][i % (Q * Q * K1)];
+    for (int i = tid; i < NWR * NPS + 8; i += NTH) S[i] = make_double2(0.0, 0.0);
+    if constexpr (AMP_LDS)
+        for (int i = tid; i < NWR * NPS; i += NTH) A[i] = 0.0;
+    for (int i = tid; i < a.n_thr; i += NTH) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
+    __syncthreads();
+    int loaded = Q < T + Q - 1 ? Q : T + Q - 1;
+    for (int r0 = 0; r0 < loaded; ++r0)
+        for (int i = tid; i < Np; i += NTH) { S[r0 * NPS + i] = gS[(size_t)r0 * Np + i]; if constexpr (AMP_LDS) A[r0 * NPS + i] = gA[(size_t)r0 * Np + i]; }
+    __syncthreads();
+
+    const int sigma = lane / rps, j = lane - sigma * rps;
+    const bool lane_used = sigma < NSW;
+    int s = sigma, rho = 0, tstart = 0, t_done = 0, ts = 1, wset = 0, ctb = 0;
+    int rowL[Q], rowR[Q];
+    bool valid = false, centre = false;
+    double thr = 0.0;
+    auto setup = [&]() {      // as in k_online64
+        const int m = s / per, q = s - m * per;
+        const int first = m - LA > 0 ? m - LA : 0;
+        if (q == 0) { valid = (j == 0); rho = m; wset = 1; centre = false; ts = 1; thr = 0.0; }
+        else {
+            rho = first + j; valid = rho <= m; wset = (rho == m) ? 2 : 0; centre = true;
+            ts = m - rho + 1; if (ts > Q) ts = Q;
+            thr = thr_s[q - 1];
+        }
+        valid = valid && lane_used && s < nsweeps;
+        tstart = DS * s + SKS * rho;
+        t_done = DS * s + SKS * m + NU - 1;
+        ctb = ((rho + Q - 1) % NWR) * NPS;
+#pragma unroll
+        for (int rr = 1; rr < Q; ++rr) { rowL[rr] = ((rho + Q - 1 - rr) % NWR) * NPS; rowR[rr] = ((rho + Q - 1 + rr) % NWR) * NPS; }
+    };
+    setup();
+
+    const int t_end = DS * (nsweeps - 1) + SKS * (T - 1) + NU;
+    const int frame_period = DS * per + SKS;
+    int next_need = (loaded - (Q - 1)) * frame_period;
+    auto load_frames = [&](int t) {      // wave 0 moves the rows, in its second half-step (the slot it overwrites is a frame no unit reads any more); wave 1 keeps count
+        while (loaded < T + Q - 1 && next_need <= t + 4) {
+            if (par == 0) {
+                const int slot = (loaded % NWR) * NPS;
+                const bool evict = loaded >= NWR;
+                for (int i = lane; i < Np; i += 64) {
+                    if (evict) gS[(size_t)(loaded - NWR) * Np + i] = S[slot + i];
+                    S[slot + i] = gS[(size_t)loaded * Np + i];
+                    if constexpr (AMP_LDS) A[slot + i] = gA[(size_t)loaded * Np + i];
+                }
+            }
+            ++loaded;
+            next_need += frame_period;
+        }
+    };
+    // the bin of this wave in step t of the unit's current sweep: its index, or -1
+    auto my_bin = [&](int t) {
+        const int u = t - tstart, cb = 2 * u + par;
+        return (valid && u >= 0 && u < NU && cb < F) ? cb : -1;
+    };
+    double px[NP > 0 ? NP : 1], py[NP > 0 ? NP : 1];      // products of the bin whose chain comes next
+    double target = 0.0;
+    const double2 zero = make_double2(0.0, 0.0);
+    auto products = [&](auto lo_c, auto hi_c, int t) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        const int cb = my_bin(t);
+        if (cb < 0) return;
+        const int nb = cb + L, row = cb % Q, rowneg = (Q - row) % Q;
+        if constexpr (LO == 0) target = AMP_LDS ? A[ctb + nb] : gA[(size_t)(rho + Q - 1) * Np + nb];
+        static_for64<HI - LO>([&](auto ic) {
+            constexpr int I = LO + decltype(ic)::value, rr = 1 + I / (2 * L + 1), jj = I % (2 * L + 1), k = (jj + 1) / 2;
+            const double2 *lf = S + rowL[rr] + nb;
+            const double2 *rt = S + rowR[rr] + nb;
+            const double2 *wa_r = W + wset * Q * Q * K1 + (row * Q + rr) * K1;
+            const double2 *wb_r = W + wset * Q * Q * K1 + (rowneg * Q + rr) * K1;
+            const bool two = rr < ts;
+            double2 w, bb, cc;
+            if constexpr (jj == 0) { w = wa_r[0]; bb = lf[0]; const double2 rv = rt[0]; cc = sel(two, rv, zero); }
+            else if constexpr (jj & 1) { w = wa_r[k]; bb = lf[-k]; const double2 rm = rt[-k]; cc = sel(two, rm, zero); }
+            else { w = wb_r[k]; const double2 rp = rt[k]; bb = sel(two, rp, zero); cc = lf[k]; }
+            px[I] = w.x * (bb.x + cc.x) - w.y * (bb.y - cc.y);
+            py[I] = w.x * (bb.y + cc.y) + w.y * (bb.x - cc.x);
+        });
+    };
+    auto chain = [&](int t) {
+        const int cb = my_bin(t);
+        if (cb < 0) return;
+        const int nb = cb + L, row = cb % Q;
+        double2 acc = zero;
+        if (centre) {
+            const double2 *wa = W + wset * Q * Q * K1 + row * Q * K1;
+            const double2 *ctr = S + ctb + nb;
+#pragma unroll
+            for (int k = 1; k <= L; ++k) pair(acc, wa[k], ctr[-k], ctr[k]);
+        }
+        static_for64<NP>([&](auto ic) { constexpr int I = decltype(ic)::value; acc.x += px[I]; acc.y += py[I]; });
+        const int lj = ctb + nb;
+        if (target > thr) {
+            const double mag = sqrt(acc.x * acc.x + acc.y * acc.y);
+            if (mag > 0.0) {
+                const double2 v = make_double2(acc.x * target / mag, acc.y * target / mag);
+                const double2 vc = make_double2(v.x, -v.y);
+                S[lj] = v;
+                const int nyq = F + L - 1;
+                if (nb >= L + 1 && nb < 2 * L + 1) S[lj + 2 * (L - nb)] = vc;
+                else if (nb >= F - 1 && nb < nyq) S[lj + 2 * (nyq - nb)] = vc;
+            }
+        }
+    };
+    auto advance = [&](int t) { if (t >= t_done) { s += NSW; setup(); } };     // the unit's state becomes that of step t + 1
+#define O64_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    using c0 = std::integral_constant<int, 0>;
+    using cs = std::integral_constant<int, SPLIT>;
+    using cn = std::integral_constant<int, NP>;
+    if (par == 0) { products(c0{}, cn{}, 0); }
+    else { products(c0{}, cs{}, 0); }
+    // (test hook: what a half-step reads must not depend on how far the other wave has got inside it -- the waves idle for
+    //  pseudo-random times before and between their parts, and the results must stay the same bits)
+    auto jitter = [&](int t, int where) {
+        if constexpr (STRESS) {
+            const unsigned h = ((unsigned)(t * 4 + where) * 2654435761u + (unsigned)a.stress * 40503u + (unsigned)par * 0x9e3779b9u) >> 24;
+            if (h & 1) for (unsigned q = 0; q < ((h >> 1) & 15u); ++q) __builtin_amdgcn_s_sleep(16);
+        }
+    };
+    for (int t = 0; t < t_end; ++t) {
+        if (par == 0) {
+            jitter(t, 0);
+            chain(t);
+            advance(t);
+            jitter(t, 1);
+            products(c0{}, cs{}, t + 1);
+            O64_BARRIER();
+            jitter(t, 2);
+            products(cs{}, cn{}, t + 1);
+            load_frames(t);
+            O64_BARRIER();
+        } else {
+            jitter(t, 0);
+            products(cs{}, cn{}, t);
+            O64_BARRIER();
+            jitter(t, 2);
+            chain(t);
+            advance(t);
+            jitter(t, 3);
+            products(c0{}, cs{}, t + 1);
+            load_frames(t);
+            O64_BARRIER();
+        }
+    }
+#undef O64_BARRIER
+    __syncthreads();
+    const int first_row = loaded > NWR ? loaded - NWR : 0;
+    for (int e = first_row; e < loaded; ++e) {
+        const int slot = (e % NWR) * NPS;
+        for (int i = tid; i < Np; i += NTH) gS[(size_t)e * Np + i] = S[slot + i];
+    }
+}
+
 struct Shape64 { int NSW, DS, NWR, NPS; size_t lds; bool ok, amp_lds; };
 // The schedule of lws_online.hip: shape4_try for its verification variant (even lag), sized for fp64 rows.
 Shape64 shape64(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
@@ -252,7 +448,23 @@ template <int Q, bool AMP_LDS> hipError_t launch_qa(const Args64 &a, int B, size
     hipLaunchKernelGGL((k_online64<Q, AMP_LDS>), dim3(B), dim3(64), lds, s, a);
     return hipGetLastError();
 }
+template <int Q, bool AMP_LDS, int SPLIT, bool STRESS> hipError_t launch_qps(const Args64 &a, int B, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online64p<Q, AMP_LDS, SPLIT, STRESS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_online64p<Q, AMP_LDS, SPLIT, STRESS>), dim3(B), dim3(128), lds, s, a);
+    return hipGetLastError();
+}
+template <int Q, bool AMP_LDS, int SPLIT> hipError_t launch_qp(const Args64 &a, int B, size_t lds, hipStream_t s) {
+    return a.stress ? launch_qps<Q, AMP_LDS, SPLIT, true>(a, B, lds, s) : launch_qps<Q, AMP_LDS, SPLIT, false>(a, B, lds, s);
+}
+// the cut of a bin's (Q - 1)(2L + 1) neighbour pairs between the two half-steps: the chain (the centre frame's pairs, the additions,
+// the re-projection) costs about sixteen pairs' products
+template <int Q> constexpr int split_of() { return (Q - 1) * (2 * L + 1) > 16 ? ((Q - 1) * (2 * L + 1) - 16) / 2 : 0; }
 template <int Q> hipError_t launch_q(const Args64 &a, int B, size_t lds, bool amp_lds, hipStream_t s) {
+    static const bool one_wave = getenv("LWS_ONLINE64_ONE_WAVE") != nullptr;      // the one-wave kernel, for comparison
+    if constexpr (Q <= 4) {
+        if (!one_wave) return amp_lds ? launch_qp<Q, true, split_of<Q>()>(a, B, lds, s) : launch_qp<Q, false, split_of<Q>()>(a, B, lds, s);
+    }
     return amp_lds ? launch_qa<Q, true>(a, B, lds, s) : launch_qa<Q, false>(a, B, lds, s);
 }
 
@@ -270,6 +482,7 @@ hipError_t launch_online64(const GenericArgs<double> &g, int B, hipStream_t stre
     a.state = g.state; a.amp = g.amp; a.thr = g.thr;
     for (int i = 0; i < 3; ++i) a.w[i] = g.w[i].w;
     a.F = g.F; a.T = g.T; a.n_thr = g.n_thr; a.LA = g.LA; a.NSW = sh.NSW; a.DS = sh.DS; a.NWR = sh.NWR; a.NPS = sh.NPS;
+    { const char *es = getenv("LWS_ONLINE64_STRESS"); a.stress = es ? atoi(es) : 0; }
     switch (g.Q) {
     case 2: return launch_q<2>(a, B, sh.lds, sh.amp_lds, stream);
     case 3: return launch_q<3>(a, B, sh.lds, sh.amp_lds, stream);

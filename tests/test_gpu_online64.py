@@ -54,6 +54,29 @@ def test_bit_identical_to_the_generic_engine(fsize, fshift, T, LA, iters):
     assert np.isfinite(out).all() and np.abs(np.abs(out) - np.abs(S)).max() < 1e-9 * np.abs(S).max()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(1024, 256, 24, 3, 10), (1024, 512, 20, 3, 4), (768, 256, 18, 2, 5), (64, 16, 90, 5, 6), (2048, 512, 10, 3, 10)])
+def test_two_waves_per_spectrogram_do_not_race(fsize, fshift, T, LA, iters, seed, monkeypatch):
+    """k_online64p: the even bin of a step on one wave, the odd bin on the other, the neighbour frames' products formed up to one and a half
+    steps ahead.  What a half-step reads must not depend on how far the other wave has got inside it: with the waves idling for
+    pseudo-random times inside their half-steps (LWS_ONLINE64_STRESS) the results are the same bits -- the one-wave kernel's and the
+    generic engine's."""
+    rng = np.random.default_rng(fsize + T + seed)
+    F = fsize // 2 + 1
+    kw = dict(mode="music", precision="fp64", look_ahead=LA, online_iterations=iters)
+    S = rng.standard_normal((2, T, F)) + 1j * rng.standard_normal((2, T, F))
+    S[1] = np.abs(S[1])
+    ref = lws_amd.lws(fsize, fshift, force_generic=True, **kw).online_lws(S)
+    monkeypatch.setenv("LWS_ONLINE64_STRESS", str(seed))
+    p = lws_amd.lws(fsize, fshift, **kw)
+    out = p.online_lws(S)
+    assert p.plan().last_kernel()["name"] == "online_lds_fp64"
+    assert np.array_equal(out, ref)
+    monkeypatch.delenv("LWS_ONLINE64_STRESS")
+    monkeypatch.setenv("LWS_ONLINE64_ONE_WAVE", "1")      # (read once per process: effective only if this is the first fp64 online call)
+    assert np.array_equal(lws_amd.lws(fsize, fshift, **kw).online_lws(S), ref)
+
+
 def test_frames_too_long_for_fp64_rows_stay_on_the_generic_engine():
     p = lws_amd.lws(4096, 1024, mode="music", precision="fp64", online_iterations=2)
     S = np.abs(np.random.default_rng(0).standard_normal((6, 2049))).astype(complex)
