@@ -2,7 +2,7 @@
 //
 // What it computes: LWSQ2 / LWSQ4 / LWSanyQ (lwslib.cpp:72-373) -- every bin of every frame in the reference's order,
 // overwritten in place as soon as it is computed, Hermitian images kept in step (lwslib.cpp:356-368) -- for Q in {2, 4},
-// L = 5, frames of up to ~1070 bins.  The sum of a bin is taken in a different ORDER than lwslib.cpp takes it (below), so
+// L = 5, frames of up to ~2090 bins.  The sum of a bin is taken in a different ORDER than lwslib.cpp takes it (below), so
 // results agree with the reference to rounding (1e-13 relative after 100 sweeps, tests/test_gpu_sys64.py), not bit for bit;
 // the order-exact fp64 engine remains lws_generic.hip (LWS_FORCE_GENERIC).
 //
@@ -28,7 +28,8 @@
 //     spectrogram and sweep.
 //   * frames of more than ~525 bins (round 5, WPS = 2): 128 frames in flight, a sweep slot is two waves side by side on a ring row of 128
 //     lanes (a lane period of 1024 steps; on 64 lanes such a frame needs a ring as deep as its surplus over 512 steps, one slot at best).
-//     Same step, same flow control, same layout with rows of 128; chosen per call like the 32-lane geometry.
+//     Same step, same flow control, same layout with rows of 128; chosen per call like the 32-lane geometry.  From ~1070 bins: 256 frames in
+//     flight, four waves per slot (WPS = 4: 4096-point frames; one slot for Q = 4).
 //
 // Entry: launch_sys64 (lws_sys64.h), called by lws_capi.hip:run_stage for MODE_BATCH of an fp64 plan.
 #include "lws_sys64.h"
@@ -485,7 +486,12 @@ hipError_t launch_pass(const S64Args &a, const BaseW<Q> &bw, int B, hipStream_t 
 
 int slots_for(int Q, int R, int rw) {   // sweep slots per workgroup: what the LDS holds, among the builds that exist
     const int fit = (LDS_ROWS * NLN / rw) / R;
-    if (rw > NLN) {   // two waves per slot (frames of ~620 to ~1070 bins)
+    if (rw > 2 * NLN) {   // four waves per slot (frames of ~1070 to ~2090 bins)
+        if (Q == 4) return fit >= 1 ? 1 : 0;
+        if (Q == 2) return fit >= 2 ? 2 : (fit >= 1 ? 1 : 0);
+        return 0;
+    }
+    if (rw > NLN) {   // two waves per slot (frames of ~525 to ~1070 bins)
         if (Q == 4) return fit >= 2 ? 2 : (fit >= 1 ? 1 : 0);
         if (Q == 2) return fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0));
         return 0;
@@ -547,6 +553,13 @@ Geom choose_geom(int F, int T, int Q, int *NS_out) {
         const double cost = (double)(w.U + w.LAG * (w_ns - 1)) / w_ns;
         if (cost < best_cost) { best = w; best_ns = w_ns; best_cost = cost; }
     }
+    // and 256 (four waves per slot: 4096-point frames)
+    const Geom x = geom(F, T, Q, 4 * NLN);
+    const int x_ns = slots_for(Q, x.R, x.rw);
+    if (x_ns) {
+        const double cost = (double)(x.U + x.LAG * (x_ns - 1)) / x_ns;
+        if (cost < best_cost) { best = x; best_ns = x_ns; best_cost = cost; }
+    }
     *NS_out = best_ns;
     return best;
 }
@@ -586,13 +599,14 @@ bool sys64_layout(int F, int T, int Q, long out[4]) {
 
 const char *sys64_name(int F, int T, int Q) {
     int ns = 0;
-    const bool wide = choose_geom(F, T, Q, &ns).rw > NLN;
-    return Q == 2 ? (wide ? "systolic_fp64_q2_wide" : "systolic_fp64_q2") : (wide ? "systolic_fp64_q4_wide" : "systolic_fp64_q4");
+    const int rw = choose_geom(F, T, Q, &ns).rw;
+    if (rw > 2 * NLN) return Q == 2 ? "systolic_fp64_q2_xwide" : "systolic_fp64_q4_xwide";
+    return Q == 2 ? (rw > NLN ? "systolic_fp64_q2_wide" : "systolic_fp64_q2") : (rw > NLN ? "systolic_fp64_q4_wide" : "systolic_fp64_q4");
 }
 
 namespace {
 template <int Q>
-hipError_t run_passes(S64Args a, const double *W, int Qp, int NS, bool wide, int n_thr, int B, hipStream_t stream, int *n_out) {
+hipError_t run_passes(S64Args a, const double *W, int Qp, int NS, int wps, int n_thr, int B, hipStream_t stream, int *n_out) {
     BaseW<Q> bw;
     if (!base_weights<Q>(W, Qp, &bw)) return hipErrorInvalidValue;
     // the build without the taps that the default windows' weights do not have, if this tensor has none of them either
@@ -606,7 +620,13 @@ hipError_t run_passes(S64Args a, const double *W, int Qp, int NS, bool wide, int
         a.thr0 = i0;
         a.ns = std::min(NS, n_thr - i0);
         hipError_t e;
-        if (wide) {
+        if (wps == 4) {
+            if constexpr (Q == 4) e = dflt ? launch_pass<4, 1, MASK_Q4, 4>(a, bw, B, stream) : launch_pass<4, 1, MASK_ALL, 4>(a, bw, B, stream);
+            else {
+                if (dflt) e = NS == 2 ? launch_pass<2, 2, MASK_Q2, 4>(a, bw, B, stream) : launch_pass<2, 1, MASK_Q2, 4>(a, bw, B, stream);
+                else e = NS == 2 ? launch_pass<2, 2, MASK_ALL, 4>(a, bw, B, stream) : launch_pass<2, 1, MASK_ALL, 4>(a, bw, B, stream);
+            }
+        } else if (wps == 2) {
             if constexpr (Q == 4) {
                 if (dflt) e = NS == 2 ? launch_pass<4, 2, MASK_Q4, 2>(a, bw, B, stream) : launch_pass<4, 1, MASK_Q4, 2>(a, bw, B, stream);
                 else e = NS == 2 ? launch_pass<4, 2, MASK_ALL, 2>(a, bw, B, stream) : launch_pass<4, 1, MASK_ALL, 2>(a, bw, B, stream);
@@ -659,7 +679,7 @@ hipError_t launch_sys64(const GenericArgs<double> &ga, const double *W_host, int
         a.F = F; a.T = T; a.P = g.P; a.gap = g.gap; a.LAG = g.LAG; a.R = g.R; a.nblk = g.nblk; a.U = g.U;
         a.nls = g.nls; a.B = Bc;
         int n = 0;
-        e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, g.rw > NLN, ga.n_thr, Bc, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, g.rw > NLN, ga.n_thr, Bc, stream, &n);
+        e = Q == 4 ? run_passes<4>(a, W_host, ga.Qp, NS, g.rw / NLN, ga.n_thr, Bc, stream, &n) : run_passes<2>(a, W_host, ga.Qp, NS, g.rw / NLN, ga.n_thr, Bc, stream, &n);
         if (e != hipSuccess) return e;
         n_all += n;
         k_s64_store<<<dim3(Tp, Bc), 256, 0, stream>>>(state, G, F, Tp, g.P, g_stride, g.nls, g.rw);

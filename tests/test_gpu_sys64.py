@@ -43,6 +43,11 @@ CASES = [
     (2048, 1024, 131, 6),              # Q = 2 at 1025 bins: four slots per pass, 6 sweeps = two passes
     (1536, 384, 30, 4),                # 769 bins: the period is the 128 lanes' own (no surplus steps)
     (2100, 525, 12, 2),                # 1051 bins: one sweep slot only
+    # 256 frames in flight, four waves per sweep slot (frames of ~1070 to ~2090 bins)
+    (4096, 1024, 20, 3),               # 2049 bins, Q = 4: one slot per pass
+    (4096, 2048, 270, 4),              # Q = 2: two slots per pass, lanes wrap to the next block of 256 frames
+    (3000, 750, 40, 2),                # 1501 bins
+    (2200, 550, 30, 2),                # 1101 bins: the first frames past the 128-lane geometry
 ]
 
 
@@ -55,7 +60,8 @@ def test_against_oracle(fsize, fshift, T, iters, oracle):
     out = p.batch_lws(S)
     name = p.plan().last_kernel()["name"]
     assert name.startswith("systolic_fp64_q"), name
-    assert name.endswith("_wide") == (fsize >= 1200), name       # 128 frames in flight from ~525 bins on (where 64 lanes hold one slot only)
+    assert name.endswith("_wide") == (1200 <= fsize <= 2100), name       # 128 frames in flight from ~525 bins on (where 64 lanes hold one slot only)
+    assert name.endswith("_xwide") == (fsize > 2100), name
     thr = lws_amd.get_thresholds(iters, 1.0, 0.1, 1)
     for b in range(2):
         ref = oracle.batch_lws(S[b], p.W, thr)
@@ -250,7 +256,7 @@ def test_wide_geometry_over_many_blocks_of_frames(fsize, fshift, T, iters):
 
 def test_unsupported_shapes_fall_back():
     rng = np.random.default_rng(3)
-    for fsize, fshift in ((4096, 1024), (2200, 550), (60, 20), (64, 8)):     # 2049 / 1101 bins, Q = 3, Q = 8
+    for fsize, fshift in ((8192, 2048), (4200, 1050), (60, 20), (64, 8)):     # 4097 / 2101 bins, Q = 3, Q = 8
         p = lws_amd.lws(fsize, fshift, batch_iterations=2, precision="fp64")
         p.batch_lws(_spec(rng, 6, fsize // 2 + 1))
         assert p.plan().last_kernel()["name"].startswith("generic"), (fsize, fshift)

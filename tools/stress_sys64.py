@@ -14,8 +14,10 @@ orc = Oracle()
 worst, names = 0.0, {}
 F_EDGE = [17, 19, 33, 65, 129, 251, 257, 499, 501, 503, 505, 507, 509, 511, 513, 515, 517, 519, 521, 523, 577, 601, 617,
           # 128 frames in flight, two waves per sweep slot (round 5): around its period of 1024 steps and its ring-size boundaries
-          619, 621, 641, 769, 1001, 1013, 1015, 1017, 1019, 1021, 1023, 1025, 1027, 1029, 1031, 1033, 1041, 1051, 1061, 1067]
-T_EDGE = [1, 2, 3, 5, 57, 58, 59, 61, 63, 64, 65, 66, 67, 121, 122, 123, 125, 127, 128, 129, 130, 131, 200, 257]
+          619, 621, 641, 769, 1001, 1013, 1015, 1017, 1019, 1021, 1023, 1025, 1027, 1029, 1031, 1033, 1041, 1051, 1061, 1067,
+          # 256 frames in flight, four waves per slot
+          1069, 1071, 1101, 1501, 2041, 2043, 2045, 2047, 2049, 2051, 2053, 2061, 2081, 2089]
+T_EDGE = [1, 2, 3, 5, 57, 58, 59, 61, 63, 64, 65, 66, 67, 121, 122, 123, 125, 127, 128, 129, 130, 131, 200, 255, 256, 257, 258]
 for case in range(n_cases):
     Q = int(rng.choice([2, 4]))
     F = int(rng.choice(F_EDGE)) if rng.random() < 0.7 else int(rng.integers(9, 310)) * 2 + 1

@@ -37,6 +37,9 @@ if __name__ == "__main__":
         t(1536, 384, 256, 250, 40)
         t(1200, 300, 256, 500, 40)
         t(1100, 275, 256, 500, 40)
+        t(4096, 1024, 256, 250, 20)      # 256 frames in flight
+        t(4096, 1024, 256, 250, 20, generic=True)
+        t(4096, 2048, 256, 250, 20)
         sys.exit(0)
     t(1024, 256, 256, 500, 100)
     if "--one" in sys.argv:
