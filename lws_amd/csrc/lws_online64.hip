@@ -192,7 +192,8 @@ __global__ void __launch_bounds__(64) k_online64(Args64 a) {
 // one-wave kernel's and the generic engine's, bit for bit.  A step is two half-steps, each closed by a barrier of the two waves:
 //      wave 0:  C(bin 2u) . P1(bin 2u+2) | P2(bin 2u+2)
 //      wave 1:  P2(bin 2u+1)             | C(bin 2u+1) . P1(bin 2u+3)
-// with P1 / P2 the first SPLIT / the other pairs, cut so that the halves take the same time.  Reading ahead is legal: a product of bin c + 3
+// with P1 / P2 the first SPLIT / the other pairs, cut so that the halves take the same time (Q = 4: the nearest frame's eleven pairs are formed
+// on the chain instead -- ONCH -- and P1 is empty: fewer products to hold, launch_q).  Reading ahead is legal: a product of bin c + 3
 // is formed one and a half steps before the one-wave schedule reads its taps (up to bin c + 8 of the frame one to the left, which that
 // frame's even-bin wave wrote in the first half of this step; up to c + 8 of the previous sweep's frames, 2 DS - 8 r >= 8 bins ahead:
 // shape64 keeps 2 DS >= 8 Q + 2), and reading later-to-be-overwritten values earlier is always safe.
@@ -201,7 +202,7 @@ template <class Fn, int... I> __device__ __forceinline__ void static_for64_impl(
 }
 template <int N, class Fn> __device__ __forceinline__ void static_for64(Fn &&f) { static_for64_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <int Q, bool AMP_LDS, int SPLIT, bool STRESS>
+template <int Q, bool AMP_LDS, int SPLIT, bool STRESS, int ONCH = 0>
 __global__ void __launch_bounds__(128) k_online64p(Args64 a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int F = a.F, T = a.T, LA = a.LA, NSW = a.NSW, DS = a.DS, NWR = a.NWR, NPS = a.NPS;
@@ -211,11 +212,13 @@ __global__ void __launch_bounds__(128) k_online64p(Args64 a) {
     double *A = reinterpret_cast<double *>(S + (size_t)NWR * NPS + 8);    // [NWR][NPS] (AMP_LDS)
     double2 *W = reinterpret_cast<double2 *>(A + (AMP_LDS ? (((size_t)NWR * NPS + 1) & ~(size_t)1) : 0));
     double *thr_s = reinterpret_cast<double *>(W + 3 * Q * Q * K1);
+    double2 *Z = reinterpret_cast<double2 *>(thr_s + ((a.n_thr + 2) & ~1)) + L;     // eleven zeros, Z[-L .. L]: what a frame to the right that is not usable yet contributes
     const int b = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int par = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // 0: the even bin of a step, 1: the odd one
     constexpr int NTH = 128;
     constexpr int NP = (Q - 1) * (2 * L + 1);                             // neighbour tap pairs of a bin, in the order they are added
-    static_assert(SPLIT >= 0 && SPLIT <= NP, "cut of the pair list");
+    constexpr int NPC = ONCH * (2 * L + 1);                               // the pairs of the first ONCH neighbour frames stay on the chain (fewer products to hold)
+    static_assert(SPLIT >= NPC && SPLIT <= NP, "cut of the pair list");
     double2 *gS = a.state + (size_t)b * Tp * Np;
     const double *gA = a.amp + (size_t)b * Tp * Np;
 
@@ -224,6 +227,7 @@ __global__ void __launch_bounds__(128) k_online64p(Args64 a) {
     if constexpr (AMP_LDS)
         for (int i = tid; i < NWR * NPS; i += NTH) A[i] = 0.0;
     for (int i = tid; i < a.n_thr; i += NTH) thr_s[i] = a.thr[(size_t)b * a.n_thr + i];
+    if (tid < 2 * L + 1) Z[tid - L] = make_double2(0.0, 0.0);
     __syncthreads();
     int loaded = Q < T + Q - 1 ? Q : T + Q - 1;
     for (int r0 = 0; r0 < loaded; ++r0)
@@ -280,25 +284,31 @@ __global__ void __launch_bounds__(128) k_online64p(Args64 a) {
     double px[NP > 0 ? NP : 1], py[NP > 0 ? NP : 1];      // products of the bin whose chain comes next
     double target = 0.0;
     const double2 zero = make_double2(0.0, 0.0);
+    // product I of the bin at column nb (weight rows row / rowneg): (re, im) of w (b + c) ... as pair() forms it
+    auto product = [&](auto ic, int nb, int row, int rowneg, double &ox, double &oy) {
+        constexpr int I = decltype(ic)::value, rr = 1 + I / (2 * L + 1), jj = I % (2 * L + 1), k = (jj + 1) / 2;
+        const double2 *lf = S + rowL[rr] + nb;
+        // (a frame to the right that is not usable yet contributes zeros: read from the zero block -- one select on the address per frame
+        //  instead of four on every value; pair(w, b, 0) == w b, pair(w, 0, c) == conj(w) c, the one-sided forms of lwslib.cpp:1222-1253)
+        const double2 *rt = rr < ts ? S + rowR[rr] + nb : Z;
+        const double2 *wa_r = W + wset * Q * Q * K1 + (row * Q + rr) * K1;
+        const double2 *wb_r = W + wset * Q * Q * K1 + (rowneg * Q + rr) * K1;
+        double2 w, bb, cc;
+        if constexpr (jj == 0) { w = wa_r[0]; bb = lf[0]; cc = rt[0]; }
+        else if constexpr (jj & 1) { w = wa_r[k]; bb = lf[-k]; cc = rt[-k]; }
+        else { w = wb_r[k]; bb = rt[k]; cc = lf[k]; }
+        ox = w.x * (bb.x + cc.x) - w.y * (bb.y - cc.y);
+        oy = w.x * (bb.y + cc.y) + w.y * (bb.x - cc.x);
+    };
     auto products = [&](auto lo_c, auto hi_c, int t) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         const int cb = my_bin(t);
         if (cb < 0) return;
         const int nb = cb + L, row = cb % Q, rowneg = (Q - row) % Q;
-        if constexpr (LO == 0) target = AMP_LDS ? A[ctb + nb] : gA[(size_t)(rho + Q - 1) * Np + nb];
+        if constexpr (LO == NPC) target = AMP_LDS ? A[ctb + nb] : gA[(size_t)(rho + Q - 1) * Np + nb];
         static_for64<HI - LO>([&](auto ic) {
-            constexpr int I = LO + decltype(ic)::value, rr = 1 + I / (2 * L + 1), jj = I % (2 * L + 1), k = (jj + 1) / 2;
-            const double2 *lf = S + rowL[rr] + nb;
-            const double2 *rt = S + rowR[rr] + nb;
-            const double2 *wa_r = W + wset * Q * Q * K1 + (row * Q + rr) * K1;
-            const double2 *wb_r = W + wset * Q * Q * K1 + (rowneg * Q + rr) * K1;
-            const bool two = rr < ts;
-            double2 w, bb, cc;
-            if constexpr (jj == 0) { w = wa_r[0]; bb = lf[0]; const double2 rv = rt[0]; cc = sel(two, rv, zero); }
-            else if constexpr (jj & 1) { w = wa_r[k]; bb = lf[-k]; const double2 rm = rt[-k]; cc = sel(two, rm, zero); }
-            else { w = wb_r[k]; const double2 rp = rt[k]; bb = sel(two, rp, zero); cc = lf[k]; }
-            px[I] = w.x * (bb.x + cc.x) - w.y * (bb.y - cc.y);
-            py[I] = w.x * (bb.y + cc.y) + w.y * (bb.x - cc.x);
+            constexpr int I = LO + decltype(ic)::value;
+            product(std::integral_constant<int, I>{}, nb, row, rowneg, px[I], py[I]);
         });
     };
     auto chain = [&](int t) {
@@ -312,7 +322,12 @@ __global__ void __launch_bounds__(128) k_online64p(Args64 a) {
 #pragma unroll
             for (int k = 1; k <= L; ++k) pair(acc, wa[k], ctr[-k], ctr[k]);
         }
-        static_for64<NP>([&](auto ic) { constexpr int I = decltype(ic)::value; acc.x += px[I]; acc.y += py[I]; });
+        static_for64<NPC>([&](auto ic) {      // the nearest frames' pairs, formed here
+            double tx, ty;
+            product(ic, nb, row, (Q - row) % Q, tx, ty);
+            acc.x += tx; acc.y += ty;
+        });
+        static_for64<NP - NPC>([&](auto ic) { constexpr int I = NPC + decltype(ic)::value; acc.x += px[I]; acc.y += py[I]; });
         const int lj = ctb + nb;
         if (target > thr) {
             const double mag = sqrt(acc.x * acc.x + acc.y * acc.y);
@@ -328,7 +343,7 @@ __global__ void __launch_bounds__(128) k_online64p(Args64 a) {
     };
     auto advance = [&](int t) { if (t >= t_done) { s += NSW; setup(); } };     // the unit's state becomes that of step t + 1
 #define O64_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    using c0 = std::integral_constant<int, 0>;
+    using c0 = std::integral_constant<int, NPC>;
     using cs = std::integral_constant<int, SPLIT>;
     using cn = std::integral_constant<int, NP>;
     if (par == 0) { products(c0{}, cn{}, 0); }
@@ -420,7 +435,7 @@ Shape64 shape64(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
     for (int pass = 0; pass < 3; ++pass) {
         r.amp_lds = pass == 0;
         auto lds_try = [&](int nwr) {
-            return ((size_t)nwr * r.NPS + 8) * 16 + (r.amp_lds ? (size_t)nwr * r.NPS * 8 + 8 : 0) + (size_t)3 * Q * Q * K1 * 16 + (size_t)(n_thr + 2) * 8 + 64;
+            return ((size_t)nwr * r.NPS + 8) * 16 + (r.amp_lds ? (size_t)nwr * r.NPS * 8 + 8 : 0) + (size_t)3 * Q * Q * K1 * 16 + (size_t)(n_thr + 2) * 8 + 64 + 256;
         };
         nwr_max = 16;
         while (nwr_max > 0 && lds_try(nwr_max) > 160 * 1024) --nwr_max;
@@ -431,7 +446,7 @@ Shape64 shape64(int F, int T, int Lu, int Q, int Qp, int LA, int n_thr) {
     }
     if (window_of(DS) > nwr_max) return r;
     auto lds_of = [&](int nwr) {
-        return ((size_t)nwr * r.NPS + 8) * 16 + (r.amp_lds ? (size_t)nwr * r.NPS * 8 + 8 : 0) + (size_t)3 * Q * Q * K1 * 16 + (size_t)(n_thr + 2) * 8 + 64;
+        return ((size_t)nwr * r.NPS + 8) * 16 + (r.amp_lds ? (size_t)nwr * r.NPS * 8 + 8 : 0) + (size_t)3 * Q * Q * K1 * 16 + (size_t)(n_thr + 2) * 8 + 64 + 256;
     };
     r.DS = DS;
     const int window = window_of(DS);
@@ -448,22 +463,26 @@ template <int Q, bool AMP_LDS> hipError_t launch_qa(const Args64 &a, int B, size
     hipLaunchKernelGGL((k_online64<Q, AMP_LDS>), dim3(B), dim3(64), lds, s, a);
     return hipGetLastError();
 }
-template <int Q, bool AMP_LDS, int SPLIT, bool STRESS> hipError_t launch_qps(const Args64 &a, int B, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online64p<Q, AMP_LDS, SPLIT, STRESS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <int Q, bool AMP_LDS, int SPLIT, bool STRESS, int ONCH = 0> hipError_t launch_qps(const Args64 &a, int B, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_online64p<Q, AMP_LDS, SPLIT, STRESS, ONCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_online64p<Q, AMP_LDS, SPLIT, STRESS>), dim3(B), dim3(128), lds, s, a);
+    hipLaunchKernelGGL((k_online64p<Q, AMP_LDS, SPLIT, STRESS, ONCH>), dim3(B), dim3(128), lds, s, a);
     return hipGetLastError();
 }
-template <int Q, bool AMP_LDS, int SPLIT> hipError_t launch_qp(const Args64 &a, int B, size_t lds, hipStream_t s) {
-    return a.stress ? launch_qps<Q, AMP_LDS, SPLIT, true>(a, B, lds, s) : launch_qps<Q, AMP_LDS, SPLIT, false>(a, B, lds, s);
+template <int Q, bool AMP_LDS, int SPLIT, int ONCH> hipError_t launch_qp(const Args64 &a, int B, size_t lds, hipStream_t s) {
+    return a.stress ? launch_qps<Q, AMP_LDS, SPLIT, true, ONCH>(a, B, lds, s) : launch_qps<Q, AMP_LDS, SPLIT, false, ONCH>(a, B, lds, s);
 }
-// the cut of a bin's (Q - 1)(2L + 1) neighbour pairs between the two half-steps: the chain (the centre frame's pairs, the additions,
-// the re-projection) costs about sixteen pairs' products
-template <int Q> constexpr int split_of() { return (Q - 1) * (2 * L + 1) > 16 ? ((Q - 1) * (2 * L + 1) - 16) / 2 : 0; }
+// How a bin's (Q - 1)(2L + 1) neighbour pairs are shared out.  The chain (the centre frame's pairs, the additions, the re-projection) costs
+// about twelve pairs' products, and every product held across a barrier is two registers: with all 33 pairs of Q = 4 held (cut after 8)
+// the kernel needs 256 + 92 registers and a tenth of its instructions are moves to and from the AGPRs -- 373 ms; with the nearest frame's
+// eleven pairs formed on the chain and the other 22 in the opposite half-step (no cut) the halves balance and nothing spills: 331 ms
+// (cuts after 13 / 15 / 17: 343 / 357 / 366).
+template <int Q> constexpr int onch_of() { return Q == 4 ? 1 : 0; }
+template <int Q> constexpr int split_of() { return Q == 4 ? 11 : ((Q - 1) * (2 * L + 1) > 16 ? ((Q - 1) * (2 * L + 1) - 16) / 2 : 0); }
 template <int Q> hipError_t launch_q(const Args64 &a, int B, size_t lds, bool amp_lds, hipStream_t s) {
     static const bool one_wave = getenv("LWS_ONLINE64_ONE_WAVE") != nullptr;      // the one-wave kernel, for comparison
     if constexpr (Q <= 4) {
-        if (!one_wave) return amp_lds ? launch_qp<Q, true, split_of<Q>()>(a, B, lds, s) : launch_qp<Q, false, split_of<Q>()>(a, B, lds, s);
+        if (!one_wave) return amp_lds ? launch_qp<Q, true, split_of<Q>(), onch_of<Q>()>(a, B, lds, s) : launch_qp<Q, false, split_of<Q>(), onch_of<Q>()>(a, B, lds, s);
     }
     return amp_lds ? launch_qa<Q, true>(a, B, lds, s) : launch_qa<Q, false>(a, B, lds, s);
 }
