@@ -477,11 +477,12 @@ template <int Q, bool AMP_LDS, int SPLIT, int ONCH> hipError_t launch_qp(const A
 // the kernel needs 256 + 92 registers and a tenth of its instructions are moves to and from the AGPRs -- 373 ms; with the nearest frame's
 // eleven pairs formed on the chain and the other 22 in the opposite half-step (no cut) the halves balance and nothing spills: 331 ms
 // (cuts after 13 / 15 / 17: 343 / 357 / 366).
-template <int Q> constexpr int onch_of() { return Q == 4 ? 1 : 0; }
-template <int Q> constexpr int split_of() { return Q == 4 ? 11 : ((Q - 1) * (2 * L + 1) > 16 ? ((Q - 1) * (2 * L + 1) - 16) / 2 : 0); }
+// Q = 8 (77 pairs): three frames' pairs on the chain, 44 products held (256 + 200 registers): 980 -> 597 ms for 256 x 250 x 513; four / 33: 650.
+template <int Q> constexpr int onch_of() { return Q == 4 ? 1 : (Q == 8 ? 3 : 0); }
+template <int Q> constexpr int split_of() { return Q == 4 ? 11 : (Q == 8 ? 33 : ((Q - 1) * (2 * L + 1) > 16 ? ((Q - 1) * (2 * L + 1) - 16) / 2 : 0)); }
 template <int Q> hipError_t launch_q(const Args64 &a, int B, size_t lds, bool amp_lds, hipStream_t s) {
     static const bool one_wave = getenv("LWS_ONLINE64_ONE_WAVE") != nullptr;      // the one-wave kernel, for comparison
-    if constexpr (Q <= 4) {
+    {
         if (!one_wave) return amp_lds ? launch_qp<Q, true, split_of<Q>(), onch_of<Q>()>(a, B, lds, s) : launch_qp<Q, false, split_of<Q>(), onch_of<Q>()>(a, B, lds, s);
     }
     return amp_lds ? launch_qa<Q, true>(a, B, lds, s) : launch_qa<Q, false>(a, B, lds, s);

@@ -55,7 +55,8 @@ def test_bit_identical_to_the_generic_engine(fsize, fshift, T, LA, iters):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-@pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(1024, 256, 24, 3, 10), (1024, 512, 20, 3, 4), (768, 256, 18, 2, 5), (64, 16, 90, 5, 6), (2048, 512, 10, 3, 10)])
+@pytest.mark.parametrize("fsize,fshift,T,LA,iters", [(1024, 256, 24, 3, 10), (1024, 512, 20, 3, 4), (768, 256, 18, 2, 5), (64, 16, 90, 5, 6), (2048, 512, 10, 3, 10),
+                                                     (1024, 128, 14, 3, 4), (64, 8, 60, 2, 5)])
 def test_two_waves_per_spectrogram_do_not_race(fsize, fshift, T, LA, iters, seed, monkeypatch):
     """k_online64p: the even bin of a step on one wave, the odd bin on the other, the neighbour frames' products formed up to one and a half
     steps ahead.  What a half-step reads must not depend on how far the other wave has got inside it: with the waves idling for
