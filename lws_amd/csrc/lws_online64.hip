@@ -3,7 +3,8 @@
 // so results are BIT-IDENTICAL to generic_fp64 -- which served this stage until round 5 at 2.55 s for config 3's 256 x 500 x 513
 // (one bin per step, 76 dependent tap loads per bin from L2).
 //
-// One workgroup = one wave = one spectrogram.  A lane is a (sweep slot, frame position) unit, exactly the units of the fp32
+// One workgroup = one spectrogram, on one wave (k_online64, described here) or on two (k_online64p below: the kernel that runs; the
+// one-wave kernel stays for comparison, LWS_ONLINE64_ONE_WAVE).  A lane is a (sweep slot, frame position) unit, exactly the units of the fp32
 // engine's fourth layout (lws_online.hip: k_online4) on the schedule of its verification variant: two bins per step, frames of a
 // sweep SKS steps apart, sweeps DS steps apart (order-exact: every writer of a neighbouring frame or sweep is at least L + 2 bins
 // from a lane's taps), 64 units in flight.  A lane sums all the taps of its two bins itself, from LDS, with the full weight tensors
