@@ -1,0 +1,328 @@
+// lws_band_core.h -- the per-lane step of the band engine (lws_band.hip).
+//
+// The same text compiles for the GPU (hipcc: every function __device__) and for a host-side emulation (g++:
+// tests/band_emul.cpp steps through the schedule lane by lane on the CPU and is compared with the oracle by
+// tests/test_band_model.py), so the schedule -- ring ages, Hermitian images, frame wrap-around -- is debugged without a GPU.
+//
+// What a step computes is one bin of LWSanyQ / LWSfractionalQ (lwslib.cpp:283-467) per lane; the schedule is the fp64 systolic
+// engine's (lws_sys64.hip: lane = frame, frames SKW steps apart, one bin per step, a slot's output in an LDS ring addressed by
+// time, neighbour frames in scatter form), with everything that engine fixes at compile time -- Q, the quarter-turn twiddles of
+// the weight rows, the phase of a step in an eight-times unrolled loop -- taken at run time:
+//   * any Q up to QT (the frame offsets r = 1..Q-1 are blocks of straight-line code behind a wave-uniform test);
+//   * any stencil half-width up to LT (a narrower stencil runs with zero weights in the outer columns);
+//   * any weight tensor with create_weights' twiddle structure W[p][r][k] = W[0][r][k] tau_r^p, tau_r = exp(2 pi j r s / Pt)
+//     (lws.pyx:160-181): the value a step receives from the frames r apart -- position w of frame m - r and of frame m + r --
+//     is turned by tau_r^w once, after which the weight of target bin w -+ k is V[r][k] = W[0][r][k] tau_r^k whatever the bin:
+//         W[(w+k) mod][r][k] A + conj(.) B  =  V (tau^w A) + conj(V) (conj(tau^w) B)
+//         W[-(w-k) mod][r][k] B + conj(.) A =  V (conj(tau^w) B) + conj(V) (tau^w A)
+//     (the two groupings of lwslib.cpp:333-352), so the table of twiddles is indexed by the lane's position, the weights by
+//     nothing but (r, k), and both are the same for every lane.
+#pragma once
+
+#if defined(__HIPCC__)
+#define BAND_FN __device__ __forceinline__
+#else
+#include <cassert>
+#include <cmath>
+#define BAND_FN inline
+#endif
+
+namespace lws {
+namespace band {
+
+constexpr int PFD = 2;   // steps a load from the skewed state is issued ahead of its use (the step loop is unrolled by this)
+
+// The geometry of a call (host: band_geometry() in lws_band.hip; tests/band_emul.cpp uses the same function).
+struct Geom {
+    int F, T, Q;          // bins, frames, frame offsets of the stencil (0 .. Q-1)
+    int SKW, nls;         // steps between consecutive frames; frames in flight per sweep slot = lanes of a ring row
+    int P, gap;           // steps a lane spends on a frame (a multiple of SKW, >= F + LT and >= nls SKW); P - nls SKW
+    int LAG, R;           // steps between consecutive sweep slots; rows of a slot's ring
+    int nblk, U;          // blocks of nls frames; steps of one sweep
+    int Pt;               // period of the weights' twiddle, in bins
+    long rows;            // rows of the skewed state of one spectrogram
+};
+
+template <typename real> BAND_FN real fma_(real a, real b, real c);
+template <> BAND_FN float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> BAND_FN double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#if defined(__HIPCC__)
+BAND_FN float rsqrt_(float x) { return __frsqrt_rn(x); }
+BAND_FN double rsqrt_(double x) { return rsqrt(x); }
+#else
+inline float rsqrt_(float x) { return 1.0f / std::sqrt(x); }
+inline double rsqrt_(double x) { return 1.0 / std::sqrt(x); }
+#endif
+
+template <typename C> BAND_FN C cj(C v) { v.y = -v.y; return v; }
+template <typename C> BAND_FN C sel(bool c, C a, C b) { C r; r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; return r; }
+
+// What a wave (a sweep slot, or one of the waves a slot is spread over) needs besides its lanes' state.
+template <typename real, typename C> struct Env {
+    Geom g;
+    C *ring_own;            // LDS: this slot's output, R rows of nls lanes, row = time mod R
+    const C *ring_prev;     // LDS: the output of the slot before (unused by the first slot of a pass)
+    const C *tw;            // LDS: [Pt][Q-1] twiddles tau_r^p
+    const C *wt;            // [Q][LT+1]: row 0 the frame's own taps W[0][0][k], row r the neighbour weights V[r][k] (uniform: scalar loads)
+    C *G;                   // the skewed state of this spectrogram: frame me, bin b at row SKW (me % nls) + P (me / nls) + b + LT
+    const real *A;          // target magnitudes, same addressing (row u holds the bin a lane completes at frame-time u, row u + LT the one it receives)
+    real thr;
+    bool last;              // this slot's output is what the pass leaves in the skewed state
+};
+
+// acc += W (s, d),  W = v or conj(v):  the grouped form of lwslib.cpp:310-311 on the sum / difference of the two frames r apart
+template <typename real, typename C, bool CONJ> BAND_FN void sc_add(C &acc, const C v, real sx, real dy, real sy, real dx) {
+    const real wy = CONJ ? -v.y : v.y;
+    acc.x = fma_<real>(v.x, sx, acc.x);
+    acc.x = fma_<real>(-wy, dy, acc.x);
+    acc.y = fma_<real>(v.x, sy, acc.y);
+    acc.y = fma_<real>(wy, dx, acc.y);
+}
+
+template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
+    static constexpr int NA = 2 * LT + 1, NRT = QT - 1, K1 = LT + 1;
+    struct SD { real sx, dy, sy, dx; };
+    // lane state
+    C acc[NA];               // sums of bins c .. c + 2 LT
+    C cn[LT + 1];            // cn[k]: new value of bin c - k (below DC: the image, lwslib.cpp:362-364, as it stands at that moment)
+    C co[LT + 1];            // co[k]: old value of bin c + k
+    real yE;                 // DC / Nyquist: the imaginary part of the bin's sum (see step)
+    C nxL[NRT], nxT[NRT], nxI;                        // inputs of the next step from the LDS
+    C nxR[FIRST ? 1 : NRT], nxO;
+    C pfO[FIRST ? PFD : 1], pfR[FIRST ? PFD : 1][FIRST ? NRT : 1];   // first slot: inputs of the next PFD steps from the skewed state
+    real pfA[PFD];
+    int w, me, tm, pm;       // position in the frame period, frame, ring time, w mod Pt
+    int lane;
+    const Env<real, C> &e;
+
+    BAND_FN Lane(const Env<real, C> &e_, int lane_, int slot_index) : e(e_) {
+        lane = lane_;
+        C z; z.x = 0; z.y = 0;
+#pragma unroll
+        for (int d = 0; d < NA; ++d) acc[d] = z;
+#pragma unroll
+        for (int k = 0; k <= LT; ++k) { cn[k] = z; co[k] = z; }
+        yE = 0;
+        // a lane that has not started yet (its frame-time is negative) counts up to position 0 of its first frame
+        w = -e.g.SKW * lane;
+        me = lane;
+        pm = 0;
+        tm = (int)(((long)e.g.LAG * slot_index) % e.g.R);
+    }
+    BAND_FN int row_at(int t_mod, int age) const {   // ring row written `age` steps before time t_mod
+        int x = t_mod - age;
+#if !defined(__HIPCC__)
+        assert(age >= 2 && age <= e.g.R);            // (what the prefetch of the NEXT step may read while this step is being written)
+#endif
+        return x < 0 ? x + e.g.R : x;
+    }
+    BAND_FN void issue_lds(int tmx, int wx, int pmx) {
+        const Geom &g = e.g;
+        const int NR = g.Q - 1;
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) {
+            if (r >= NR) break;
+            const int offL = (lane - (r + 1)) & (g.nls - 1);
+            const int ageL = g.SKW * (r + 1) - LT + (lane < r + 1 ? g.gap : 0);
+            nxL[r] = e.ring_own[row_at(tmx, ageL) * g.nls + offL];
+            nxT[r] = e.tw[pmx * NR + r];
+            if constexpr (!FIRST) {
+                const int offR = (lane + r + 1) & (g.nls - 1);
+                const int ageR = g.LAG - LT - g.SKW * (r + 1) - (lane + r + 1 >= g.nls ? g.gap : 0);
+                nxR[r] = e.ring_prev[row_at(tmx, ageR) * g.nls + offR];
+            }
+        }
+        if constexpr (!FIRST) nxO = e.ring_prev[row_at(tmx, g.LAG - LT) * g.nls + lane];
+        int cx = wx - LT;
+        if (cx < 0) cx += g.P;                        // still the images of the frame the lane has just left
+        const int jj = cx - (g.F - 1);
+        nxI = e.ring_own[row_at(tmx, (jj >= 1 && jj <= LT) ? 2 * jj : 2) * g.nls + lane];
+    }
+    BAND_FN void issue_global(int ux, int b) {
+        const Geom &g = e.g;
+        pfA[b] = e.A[(long)ux * g.nls + lane];
+        if constexpr (FIRST) {
+            const int NR = g.Q - 1;
+            const C *Gu = e.G + (long)(ux + LT) * g.nls;
+            pfO[b] = Gu[lane];
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                if (r >= NR) break;
+                const int offR = (lane + r + 1) & (g.nls - 1);
+                const int wrap = lane + r + 1 >= g.nls ? g.gap : 0;
+                pfR[b][r] = Gu[(long)(g.SKW * (r + 1) + wrap) * g.nls + offR];
+            }
+        }
+    }
+    BAND_FN void prologue() {   // before the step of frame-time 0
+#pragma unroll
+        for (int b = 0; b < PFD; ++b) issue_global(b, b);
+        issue_lds(tm, w, pm);
+    }
+
+    // the image below DC of position PH (= w): position -PH holds the conjugate and reaches bins ct = 0 .. LT - PH with V[r][ct + PH]
+    template <int PH> BAND_FN void images(const SD (&sd)[NRT], bool z) {
+        if constexpr (PH >= 1 && PH <= LT) {
+            const int NR = e.g.Q - 1;
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                if (r >= NR) break;
+                // (one lane at most; the others add zeros)
+                const real sx = z ? sd[r].sx : (real)0, dy = z ? sd[r].dy : (real)0, sy = z ? sd[r].sy : (real)0, dx = z ? sd[r].dx : (real)0;
+#pragma unroll
+                for (int ct = 0; ct <= LT - PH; ++ct)
+                    sc_add<real, C, false>(acc[ct + LT - PH], e.wt[(r + 1) * K1 + ct + PH], sx, -dy, -sy, dx);
+            }
+        }
+    }
+
+    // One step: the lane completes bin c = w - LT of its frame (if that is a bin) from the position w it receives.
+    //   PB: which of the PFD prefetch buffers holds this step's loads (u mod PFD);  ph = u mod SKW = w mod SKW in every lane
+    template <int PB> BAND_FN void step(int u, int ph) {
+        const Geom &g = e.g;
+        const int NR = g.Q - 1, F = g.F;
+        // ---- this step's inputs (loaded earlier), then the loads of later steps
+        C O, Rv[NRT], Lv[NRT], Tv[NRT];
+        const C img = nxI;
+        const real amp = pfA[PB];
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) {
+            if (r >= NR) break;
+            Lv[r] = nxL[r];
+            Tv[r] = nxT[r];
+            if constexpr (FIRST) Rv[r] = pfR[PB][r]; else Rv[r] = nxR[r];
+        }
+        if constexpr (FIRST) O = pfO[PB]; else O = nxO;
+        int w1 = w + 1, me1 = me, pm1 = pm + 1 == g.Pt ? 0 : pm + 1;
+        if (w1 == g.P) { w1 = 0; me1 += g.nls; }
+        if (w1 == 0) pm1 = 0;
+        const int tm1 = tm + 1 == g.R ? 0 : tm + 1;
+        issue_lds(tm1, w1, pm1);
+        issue_global(u + PFD, PB);
+
+        const int c = w - LT;
+        const bool act = w >= 0 && me < g.nls * g.nblk;
+        if (ph == 0) {   // (wave-uniform) a lane starts a frame with empty sums
+            const bool first = w == 0;
+            C z; z.x = 0; z.y = 0;
+#pragma unroll
+            for (int d = 0; d < NA; ++d) acc[d] = sel(first, z, acc[d]);
+        }
+        // ---- (a) old value of the frame itself at bin c + LT; an image above Nyquist whose source this sweep has already
+        //      rewritten is the conjugate of that new value
+        {
+            const int kk = 2 * c + LT - 2 * (F - 1);
+            C o = O;
+#pragma unroll
+            for (int k = 1; k <= LT; ++k) o = sel(kk == k, cj(cn[k]), o);
+            co[LT] = o;
+        }
+        // ---- (b) neighbour frames: position w of frames me -+ r, turned by tau_r^w, reaches bins c .. c + 2 LT
+        SD sd[NRT];
+        real y0 = 0;
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) {
+            if (r >= NR) break;
+            const real ux = Lv[r].x + Rv[r].x, uy = Lv[r].y + Rv[r].y, vx = Lv[r].x - Rv[r].x, vy = Lv[r].y - Rv[r].y;
+            const real tx = Tv[r].x, ty = Tv[r].y;
+            // A' = tau A, B' = conj(tau) B:  A' + B' = tau.x (A + B) + j tau.y (A - B),  A' - B' = tau.x (A - B) + j tau.y (A + B)
+            SD t;
+            t.sx = fma_<real>(-ty, vy, tx * ux);
+            t.sy = fma_<real>(ty, vx, tx * uy);
+            t.dx = fma_<real>(-ty, uy, tx * vx);
+            t.dy = fma_<real>(ty, ux, tx * vy);
+            sd[r] = t;
+            const C *wr = e.wt + (r + 1) * K1;
+            // DC and Nyquist: see below
+            y0 = fma_<real>(wr[0].x, t.sy, y0);
+            y0 = fma_<real>(wr[0].y, t.dx, y0);
+            sc_add<real, C, false>(acc[LT], wr[0], t.sx, t.dy, t.sy, t.dx);
+#pragma unroll
+            for (int k = 1; k <= LT; ++k) {
+                sc_add<real, C, false>(acc[LT + k], wr[k], t.sx, t.dy, t.sy, t.dx);   // the taps below bin w + k
+                sc_add<real, C, true>(acc[LT - k], wr[k], t.sx, t.dy, t.sy, t.dx);    // the taps above bin w - k
+            }
+        }
+        // DC and Nyquist.  Their neighbourhood is Hermitian (the images are exact conjugates), so in the reference every tap pair
+        // k >= 1 adds x and then -x to the imaginary part of the sum, bit for bit (lwslib.cpp:310-311 on c = conj(b)): what is left
+        // is the k = 0 taps -- exactly zero for a spectrogram whose DC / Nyquist bins are real, which they then stay.  That line
+        // is unstable (lws_sys64.hip), and in scatter form the two halves of a pair arrive steps apart and cancel to
+        // rounding only: so the imaginary part of these two bins is taken from the k = 0 taps alone, captured when their position
+        // arrives (LT steps before the bin is complete).
+        yE = (w == 0 || w == F - 1) ? y0 : yE;
+        // images below DC: position -w is the conjugate of position w and reaches bins 0 .. LT - w (w = ph in the one lane that has
+        // w <= LT; every lane has w = ph modulo SKW)
+        if (ph >= 1 && ph <= LT) {
+            const bool z = w == ph;
+            switch (ph) {
+                case 1: images<1>(sd, z); break;
+                case 2: images<2>(sd, z); break;
+                case 3: images<3>(sd, z); break;
+                case 4: images<4>(sd, z); break;
+                case 5: images<5>(sd, z); break;
+                case 6: images<6>(sd, z); break;
+                case 7: images<7>(sd, z); break;
+                case 8: images<8>(sd, z); break;
+                case 9: images<9>(sd, z); break;
+                default: images<10>(sd, z); break;
+            }
+        }
+        // ---- (c) the frame's own taps: new values below (the images below DC among them), old values above; k = 1 last (it is
+        //      the value the previous step produced)
+        if (ph == LT % g.SKW) {   // bin 0: nothing of this frame is new yet, the images below DC are those of the old values
+            const bool b0 = c == 0;
+#pragma unroll
+            for (int k = 1; k <= LT; ++k) cn[k] = sel(b0, cj(co[k]), cn[k]);
+        }
+        C a0 = acc[0];
+#pragma unroll
+        for (int k = LT; k >= 1; --k) {
+            const C wv = e.wt[k], b = cn[k], cv = co[k];
+            a0.x = fma_<real>(wv.x, b.x + cv.x, a0.x);
+            a0.x = fma_<real>(-wv.y, b.y - cv.y, a0.x);
+            a0.y = fma_<real>(wv.x, b.y + cv.y, a0.y);
+            a0.y = fma_<real>(wv.y, b.x - cv.x, a0.y);
+        }
+        // ---- re-projection on the target magnitude (lwslib.cpp:356-360)
+        a0.y = (c == 0 || c == F - 1) ? yE : a0.y;
+        const real m2 = a0.x * a0.x + a0.y * a0.y;
+        const bool upd = act && c >= 0 && c <= F - 1 && me >= g.Q - 1 && me < g.T + g.Q - 1 && amp > e.thr && m2 > (real)0;
+        const real sc = amp * rsqrt_(m2);
+        C val;
+        val.x = upd ? a0.x * sc : co[0].x;
+        val.y = upd ? a0.y * sc : co[0].y;
+        // ---- images above Nyquist (lwslib.cpp:365-367): written when the lane passes them, from its own ring
+        {
+            const bool before = c < 0;                                     // still the frame the lane has just left
+            const int jj = (before ? c + g.P : c) - (F - 1);
+            const bool has_frame = (before & (me >= g.nls)) | (!before & (me < g.nls * g.nblk));
+            const bool is_img = (w >= 0) & has_frame & ((unsigned)(jj - 1) < (unsigned)LT);
+            val = sel(is_img, cj(img), val);
+            // an image above Nyquist that sits in the window of old values and whose source is the bin just written
+            const int j2 = (F - 1) - c;
+#pragma unroll
+            for (int j = 1; 2 * j <= LT; ++j) co[2 * j] = sel(act && j2 == j, cj(val), co[2 * j]);
+        }
+        // (no position of a frame here -- before its bin 0, past its last image, before the first / after the last frame: val is
+        //  the old value of such a row, which is zero, so zero is what gets written and the rows that are nobody's stay zero)
+        e.ring_own[tm * g.nls + lane] = val;
+        if (e.last) e.G[(long)u * g.nls + lane] = val;
+        // ---- windows move on by one bin
+#pragma unroll
+        for (int k = LT; k >= 2; --k) cn[k] = cn[k - 1];
+        cn[1] = val;
+        // ... and the image below DC of the bin just written, where the window of new values holds it: bin c = j is bin -j for
+        // the step of bin c + 1, k = 2 j + 1 below it
+#pragma unroll
+        for (int j = 1; 2 * j + 1 <= LT; ++j) cn[2 * j + 1] = sel(c == j, cj(val), cn[2 * j + 1]);
+#pragma unroll
+        for (int k = 0; k < LT; ++k) co[k] = co[k + 1];
+#pragma unroll
+        for (int d = 0; d < NA - 1; ++d) acc[d] = acc[d + 1];
+        acc[NA - 1].x = 0; acc[NA - 1].y = 0;
+        w = w1; me = me1; tm = tm1; pm = pm1;
+    }
+};
+
+}  // namespace band
+}  // namespace lws
