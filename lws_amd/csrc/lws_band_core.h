@@ -20,6 +20,7 @@
 #pragma once
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define BAND_FN __device__ __forceinline__
 #else
 #include <cassert>
@@ -40,6 +41,7 @@ struct Geom {
     int LAG, R;           // steps between consecutive sweep slots; rows of a slot's ring
     int nblk, U;          // blocks of nls frames; steps of one sweep
     int Pt;               // period of the weights' twiddle, in bins
+    int lg;               // log2(nls)
     long rows;            // rows of the skewed state of one spectrogram
 };
 
@@ -49,10 +51,27 @@ template <> BAND_FN double fma_<double>(double a, double b, double c) { return _
 #if defined(__HIPCC__)
 BAND_FN float rsqrt_(float x) { return __frsqrt_rn(x); }
 BAND_FN double rsqrt_(double x) { return rsqrt(x); }
+// a pair of reals that the fp32 build keeps in an aligned register pair: its arithmetic is one packed instruction per pair
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32; a scalar broadcast into both halves and a negation are operand modifiers)
+template <typename real> struct pair_of { typedef real type __attribute__((ext_vector_type(2))); };
+template <typename real> using V2 = typename pair_of<real>::type;
+template <typename real> BAND_FN V2<real> vfma(V2<real> a, V2<real> b, V2<real> c) { return __builtin_elementwise_fma(a, b, c); }
 #else
 inline float rsqrt_(float x) { return 1.0f / std::sqrt(x); }
 inline double rsqrt_(double x) { return 1.0 / std::sqrt(x); }
+template <typename real> struct V2 {
+    real x, y;
+    V2 operator+(V2 o) const { return V2{x + o.x, y + o.y}; }
+    V2 operator-(V2 o) const { return V2{x - o.x, y - o.y}; }
+    V2 operator*(V2 o) const { return V2{x * o.x, y * o.y}; }
+    V2 operator-() const { return V2{-x, -y}; }
+};
+template <typename real> inline V2<real> vfma(V2<real> a, V2<real> b, V2<real> c) { return V2<real>{fma_<real>(a.x, b.x, c.x), fma_<real>(a.y, b.y, c.y)}; }
 #endif
+template <typename real> BAND_FN V2<real> splat(real v) { return V2<real>{v, v}; }
+template <typename real> BAND_FN V2<real> turn(V2<real> v) { return V2<real>{-v.y, v.x}; }   // j v
+template <typename real, typename C> BAND_FN V2<real> pr(C v) { return V2<real>{v.x, v.y}; }
+template <typename real> BAND_FN V2<real> vsel(bool c, V2<real> a, V2<real> b) { return V2<real>{c ? a.x : b.x, c ? a.y : b.y}; }
 
 template <typename C> BAND_FN C cj(C v) { v.y = -v.y; return v; }
 template <typename C> BAND_FN C sel(bool c, C a, C b) { C r; r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; return r; }
@@ -63,35 +82,31 @@ template <typename real, typename C> struct Env {
     C *ring_own;            // LDS: this slot's output, R rows of nls lanes, row = time mod R
     const C *ring_prev;     // LDS: the output of the slot before (unused by the first slot of a pass)
     const C *tw;            // LDS: [Pt][Q-1] twiddles tau_r^p
-    const C *wt;            // [Q][LT+1]: row 0 the frame's own taps W[0][0][k], row r the neighbour weights V[r][k] (uniform: scalar loads)
+    const C *wt;            // LDS: [Q][LT+1]: row 0 the frame's own taps W[0][0][k], row r the neighbour weights V[r][k] (the same address in every lane)
     C *G;                   // the skewed state of this spectrogram: frame me, bin b at row SKW (me % nls) + P (me / nls) + b + LT
     const real *A;          // target magnitudes, same addressing (row u holds the bin a lane completes at frame-time u, row u + LT the one it receives)
     real thr;
     bool last;              // this slot's output is what the pass leaves in the skewed state
 };
 
-// acc += W (s, d),  W = v or conj(v):  the grouped form of lwslib.cpp:310-311 on the sum / difference of the two frames r apart
-template <typename real, typename C, bool CONJ> BAND_FN void sc_add(C &acc, const C v, real sx, real dy, real sy, real dx) {
-    const real wy = CONJ ? -v.y : v.y;
-    acc.x = fma_<real>(v.x, sx, acc.x);
-    acc.x = fma_<real>(-wy, dy, acc.x);
-    acc.y = fma_<real>(v.x, sy, acc.y);
-    acc.y = fma_<real>(wy, dx, acc.y);
-}
-
 template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
     static constexpr int NA = 2 * LT + 1, NRT = QT - 1, K1 = LT + 1;
-    struct SD { real sx, dy, sy, dx; };
+    using P = V2<real>;
+    // what a step receives from the frames r apart -- position w of frame me - r (L) and of frame me + r (R), tau_r^w (T) -- and what
+    // it makes of it: with A' = tau A, B' = conj(tau) B the sum S = A' + B' and D = j (A' - B'), so that a weight v adds
+    // v.x S +- v.y D to a bin (the grouped form of lwslib.cpp:310-311; + for the taps below a bin, - above)
+    struct In { C L, R, T; };
+    struct SD { P S, D; };
     // lane state
-    C acc[NA];               // sums of bins c .. c + 2 LT
+    P acc[NA];               // sums of bins c .. c + 2 LT
     C cn[LT + 1];            // cn[k]: new value of bin c - k (below DC: the image, lwslib.cpp:362-364, as it stands at that moment)
     C co[LT + 1];            // co[k]: old value of bin c + k
     real yE;                 // DC / Nyquist: the imaginary part of the bin's sum (see step)
-    C nxL[NRT], nxT[NRT], nxI;                        // inputs of the next step from the LDS
-    C nxR[FIRST ? 1 : NRT], nxO;
+    In nx;                   // inputs of the next step's first frame offset (r = 1), requested from the LDS one step early
+    C nxO, nxI;              // ... its old value of the frame itself and the image above Nyquist it may have to write
     C pfO[FIRST ? PFD : 1], pfR[FIRST ? PFD : 1][FIRST ? NRT : 1];   // first slot: inputs of the next PFD steps from the skewed state
     real pfA[PFD];
-    int w, me, tm, pm;       // position in the frame period, frame, ring time, w mod Pt
+    int w, me, tm, pmo;      // position in the frame period, frame, ring time, (w mod Pt) (Q - 1)
     int lane;
     const Env<real, C> &e;
 
@@ -99,79 +114,93 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
         lane = lane_;
         C z; z.x = 0; z.y = 0;
 #pragma unroll
-        for (int d = 0; d < NA; ++d) acc[d] = z;
+        for (int d = 0; d < NA; ++d) acc[d] = P{0, 0};
 #pragma unroll
         for (int k = 0; k <= LT; ++k) { cn[k] = z; co[k] = z; }
         yE = 0;
         // a lane that has not started yet (its frame-time is negative) counts up to position 0 of its first frame
         w = -e.g.SKW * lane;
         me = lane;
-        pm = 0;
+        pmo = 0;
         tm = (int)(((long)e.g.LAG * slot_index) % e.g.R);
     }
-    BAND_FN int row_at(int t_mod, int age) const {   // ring row written `age` steps before time t_mod
+    // ring row written `age` steps before time t_mod.  A read issued for the NEXT step (t_mod = its time) sees rows of age >= 2: the
+    // row of age 1 is being written while it is issued; a read of THIS step sees ages >= 1.
+    BAND_FN int row_at(int t_mod, int age, int min_age) const {
         int x = t_mod - age;
 #if !defined(__HIPCC__)
-        assert(age >= 2 && age <= e.g.R);            // (what the prefetch of the NEXT step may read while this step is being written)
+        assert(age >= min_age && age <= e.g.R - 2 + min_age);
 #endif
+        (void)min_age;
         return x < 0 ? x + e.g.R : x;
+    }
+    // the inputs of frame offset r + 1 at ring time tmx (pmx: the position's row of the twiddle table)
+    BAND_FN In fetch(int r, int tmx, int pmx, int min_age) const {
+        const Geom &g = e.g;
+        In v;
+        const int offL = (lane - (r + 1)) & (g.nls - 1);
+        const int ageL = g.SKW * (r + 1) - LT + (lane < r + 1 ? g.gap : 0);
+        v.L = e.ring_own[(row_at(tmx, ageL, min_age) << g.lg) + offL];
+        v.T = e.tw[pmx + r];
+        if constexpr (!FIRST) {
+            const int offR = (lane + r + 1) & (g.nls - 1);
+            const int ageR = g.LAG - LT - g.SKW * (r + 1) - (lane + r + 1 >= g.nls ? g.gap : 0);
+            v.R = e.ring_prev[(row_at(tmx, ageR, min_age) << g.lg) + offR];
+        } else {
+            v.R = v.L;   // (replaced by the value from the skewed state)
+        }
+        return v;
     }
     BAND_FN void issue_lds(int tmx, int wx, int pmx) {
         const Geom &g = e.g;
-        const int NR = g.Q - 1;
-#pragma unroll
-        for (int r = 0; r < NRT; ++r) {
-            if (r >= NR) break;
-            const int offL = (lane - (r + 1)) & (g.nls - 1);
-            const int ageL = g.SKW * (r + 1) - LT + (lane < r + 1 ? g.gap : 0);
-            nxL[r] = e.ring_own[row_at(tmx, ageL) * g.nls + offL];
-            nxT[r] = e.tw[pmx * NR + r];
-            if constexpr (!FIRST) {
-                const int offR = (lane + r + 1) & (g.nls - 1);
-                const int ageR = g.LAG - LT - g.SKW * (r + 1) - (lane + r + 1 >= g.nls ? g.gap : 0);
-                nxR[r] = e.ring_prev[row_at(tmx, ageR) * g.nls + offR];
-            }
-        }
-        if constexpr (!FIRST) nxO = e.ring_prev[row_at(tmx, g.LAG - LT) * g.nls + lane];
+        nx = fetch(0, tmx, pmx, 2);
+        if constexpr (!FIRST) nxO = e.ring_prev[(row_at(tmx, g.LAG - LT, 2) << g.lg) + lane];
         int cx = wx - LT;
         if (cx < 0) cx += g.P;                        // still the images of the frame the lane has just left
         const int jj = cx - (g.F - 1);
-        nxI = e.ring_own[row_at(tmx, (jj >= 1 && jj <= LT) ? 2 * jj : 2) * g.nls + lane];
+        nxI = e.ring_own[(row_at(tmx, (jj >= 1 && jj <= LT) ? 2 * jj : 2, 2) << g.lg) + lane];
     }
     BAND_FN void issue_global(int ux, int b) {
         const Geom &g = e.g;
-        pfA[b] = e.A[(long)ux * g.nls + lane];
+        pfA[b] = e.A[((long)ux << g.lg) + lane];
         if constexpr (FIRST) {
             const int NR = g.Q - 1;
-            const C *Gu = e.G + (long)(ux + LT) * g.nls;
+            const C *Gu = e.G + ((long)(ux + LT) << g.lg);
             pfO[b] = Gu[lane];
 #pragma unroll
             for (int r = 0; r < NRT; ++r) {
-                if (r >= NR) break;
+                if (r >= NR) continue;
                 const int offR = (lane + r + 1) & (g.nls - 1);
                 const int wrap = lane + r + 1 >= g.nls ? g.gap : 0;
-                pfR[b][r] = Gu[(long)(g.SKW * (r + 1) + wrap) * g.nls + offR];
+                pfR[b][r] = Gu[((long)(g.SKW * (r + 1) + wrap) << g.lg) + offR];
             }
         }
     }
     BAND_FN void prologue() {   // before the step of frame-time 0
 #pragma unroll
         for (int b = 0; b < PFD; ++b) issue_global(b, b);
-        issue_lds(tm, w, pm);
+        issue_lds(tm, w, pmo);
     }
 
-    // the image below DC of position PH (= w): position -PH holds the conjugate and reaches bins ct = 0 .. LT - PH with V[r][ct + PH]
+    // the image below DC of position PH (= w): position -PH holds the conjugate -- of A' and B' too -- and reaches bins
+    // ct = 0 .. LT - PH with V[r][ct + PH]; one lane at most (z), the others add zeros
     template <int PH> BAND_FN void images(const SD (&sd)[NRT], bool z) {
         if constexpr (PH >= 1 && PH <= LT) {
             const int NR = e.g.Q - 1;
 #pragma unroll
             for (int r = 0; r < NRT; ++r) {
-                if (r >= NR) break;
-                // (one lane at most; the others add zeros)
-                const real sx = z ? sd[r].sx : (real)0, dy = z ? sd[r].dy : (real)0, sy = z ? sd[r].sy : (real)0, dx = z ? sd[r].dx : (real)0;
+                if (r >= NR) continue;
+                const C *wr = e.wt + (r + 1) * K1;
+                // conj(A') + conj(B') = conj(S);  j (conj(A') - conj(B')) = (-D.x, D.y)
+                const P Sc = vsel<real>(z, P{sd[r].S.x, -sd[r].S.y}, P{0, 0}), Dc = vsel<real>(z, P{-sd[r].D.x, sd[r].D.y}, P{0, 0});
 #pragma unroll
-                for (int ct = 0; ct <= LT - PH; ++ct)
-                    sc_add<real, C, false>(acc[ct + LT - PH], e.wt[(r + 1) * K1 + ct + PH], sx, -dy, -sy, dx);
+                for (int ct = 0; ct <= LT - PH; ++ct) {
+                    const C v = wr[ct + PH];
+                    P a = acc[ct + LT - PH];
+                    a = vfma<real>(splat<real>(v.x), Sc, a);
+                    a = vfma<real>(splat<real>(v.y), Dc, a);
+                    acc[ct + LT - PH] = a;
+                }
             }
         }
     }
@@ -181,32 +210,23 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
     template <int PB> BAND_FN void step(int u, int ph) {
         const Geom &g = e.g;
         const int NR = g.Q - 1, F = g.F;
-        // ---- this step's inputs (loaded earlier), then the loads of later steps
-        C O, Rv[NRT], Lv[NRT], Tv[NRT];
+        // ---- this step's inputs were requested earlier (LDS: the first frame offset's one step early, the others' while the
+        //      offset before them is worked on; skewed state: PFD steps early)
         const C img = nxI;
         const real amp = pfA[PB];
-#pragma unroll
-        for (int r = 0; r < NRT; ++r) {
-            if (r >= NR) break;
-            Lv[r] = nxL[r];
-            Tv[r] = nxT[r];
-            if constexpr (FIRST) Rv[r] = pfR[PB][r]; else Rv[r] = nxR[r];
-        }
+        C O;
         if constexpr (FIRST) O = pfO[PB]; else O = nxO;
-        int w1 = w + 1, me1 = me, pm1 = pm + 1 == g.Pt ? 0 : pm + 1;
+        int w1 = w + 1, me1 = me, pmo1 = pmo + NR == g.Pt * NR ? 0 : pmo + NR;
         if (w1 == g.P) { w1 = 0; me1 += g.nls; }
-        if (w1 == 0) pm1 = 0;
+        if (w1 == 0) pmo1 = 0;
         const int tm1 = tm + 1 == g.R ? 0 : tm + 1;
-        issue_lds(tm1, w1, pm1);
-        issue_global(u + PFD, PB);
 
         const int c = w - LT;
         const bool act = w >= 0 && me < g.nls * g.nblk;
         if (ph == 0) {   // (wave-uniform) a lane starts a frame with empty sums
             const bool first = w == 0;
-            C z; z.x = 0; z.y = 0;
 #pragma unroll
-            for (int d = 0; d < NA; ++d) acc[d] = sel(first, z, acc[d]);
+            for (int d = 0; d < NA; ++d) acc[d] = vsel<real>(first, P{0, 0}, acc[d]);
         }
         // ---- (a) old value of the frame itself at bin c + LT; an image above Nyquist whose source this sweep has already
         //      rewritten is the conjugate of that new value
@@ -218,29 +238,40 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
             co[LT] = o;
         }
         // ---- (b) neighbour frames: position w of frames me -+ r, turned by tau_r^w, reaches bins c .. c + 2 LT
-        SD sd[NRT];
         real y0 = 0;
+        SD sd[NRT];
+        In cur = nx;
 #pragma unroll
         for (int r = 0; r < NRT; ++r) {
-            if (r >= NR) break;
-            const real ux = Lv[r].x + Rv[r].x, uy = Lv[r].y + Rv[r].y, vx = Lv[r].x - Rv[r].x, vy = Lv[r].y - Rv[r].y;
-            const real tx = Tv[r].x, ty = Tv[r].y;
-            // A' = tau A, B' = conj(tau) B:  A' + B' = tau.x (A + B) + j tau.y (A - B),  A' - B' = tau.x (A - B) + j tau.y (A + B)
-            SD t;
-            t.sx = fma_<real>(-ty, vy, tx * ux);
-            t.sy = fma_<real>(ty, vx, tx * uy);
-            t.dx = fma_<real>(-ty, uy, tx * vx);
-            t.dy = fma_<real>(ty, ux, tx * vy);
-            sd[r] = t;
+            if (r >= NR) continue;
+            const In in = cur;
+            if (r + 1 < NR) cur = fetch(r + 1, tm, pmo, 1);
             const C *wr = e.wt + (r + 1) * K1;
-            // DC and Nyquist: see below
-            y0 = fma_<real>(wr[0].x, t.sy, y0);
-            y0 = fma_<real>(wr[0].y, t.dx, y0);
-            sc_add<real, C, false>(acc[LT], wr[0], t.sx, t.dy, t.sy, t.dx);
+            C Rv;
+            if constexpr (FIRST) Rv = pfR[PB][r]; else Rv = in.R;
+            const P uu = pr<real>(in.L) + pr<real>(Rv), jv = turn<real>(pr<real>(in.L) - pr<real>(Rv));
+            const P tx = splat<real>(in.T.x), ty = splat<real>(in.T.y);
+            // A' = tau A, B' = conj(tau) B:  A' + B' = tau.x (A + B) + tau.y j (A - B),  j (A' - B') = tau.x j (A - B) - tau.y (A + B)
+            SD t;
+            t.S = vfma<real>(ty, jv, tx * uu);
+            t.D = vfma<real>(-ty, uu, tx * jv);
+            sd[r] = t;
+            // DC and Nyquist (below): the imaginary part of the k = 0 taps
+            y0 = fma_<real>(wr[0].x, t.S.y, y0);
+            y0 = fma_<real>(wr[0].y, t.D.y, y0);
+            {
+                P a = acc[LT];
+                a = vfma<real>(splat<real>(wr[0].x), t.S, a);
+                acc[LT] = vfma<real>(splat<real>(wr[0].y), t.D, a);
+            }
 #pragma unroll
             for (int k = 1; k <= LT; ++k) {
-                sc_add<real, C, false>(acc[LT + k], wr[k], t.sx, t.dy, t.sy, t.dx);   // the taps below bin w + k
-                sc_add<real, C, true>(acc[LT - k], wr[k], t.sx, t.dy, t.sy, t.dx);    // the taps above bin w - k
+                const C v = wr[k];
+                P a = acc[LT + k], b = acc[LT - k];
+                a = vfma<real>(splat<real>(v.x), t.S, a);        // the taps below bin w + k:  V A' + conj(V) B'
+                b = vfma<real>(splat<real>(v.x), t.S, b);        // the taps above bin w - k:  V B' + conj(V) A'
+                acc[LT + k] = vfma<real>(splat<real>(v.y), t.D, a);
+                acc[LT - k] = vfma<real>(-splat<real>(v.y), t.D, b);
             }
         }
         // DC and Nyquist.  Their neighbourhood is Hermitian (the images are exact conjugates), so in the reference every tap pair
@@ -267,6 +298,8 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
                 default: images<10>(sd, z); break;
             }
         }
+        issue_lds(tm1, w1, pmo1);
+        issue_global(u + PFD, PB);
         // ---- (c) the frame's own taps: new values below (the images below DC among them), old values above; k = 1 last (it is
         //      the value the previous step produced)
         if (ph == LT % g.SKW) {   // bin 0: nothing of this frame is new yet, the images below DC are those of the old values
@@ -274,14 +307,13 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
 #pragma unroll
             for (int k = 1; k <= LT; ++k) cn[k] = sel(b0, cj(co[k]), cn[k]);
         }
-        C a0 = acc[0];
+        P a0 = acc[0];
 #pragma unroll
         for (int k = LT; k >= 1; --k) {
-            const C wv = e.wt[k], b = cn[k], cv = co[k];
-            a0.x = fma_<real>(wv.x, b.x + cv.x, a0.x);
-            a0.x = fma_<real>(-wv.y, b.y - cv.y, a0.x);
-            a0.y = fma_<real>(wv.x, b.y + cv.y, a0.y);
-            a0.y = fma_<real>(wv.y, b.x - cv.x, a0.y);
+            const C wv = e.wt[k];
+            const P b = pr<real>(cn[k]), cv = pr<real>(co[k]);
+            a0 = vfma<real>(splat<real>(wv.x), b + cv, a0);
+            a0 = vfma<real>(splat<real>(wv.y), turn<real>(b - cv), a0);
         }
         // ---- re-projection on the target magnitude (lwslib.cpp:356-360)
         a0.y = (c == 0 || c == F - 1) ? yE : a0.y;
@@ -305,8 +337,8 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
         }
         // (no position of a frame here -- before its bin 0, past its last image, before the first / after the last frame: val is
         //  the old value of such a row, which is zero, so zero is what gets written and the rows that are nobody's stay zero)
-        e.ring_own[tm * g.nls + lane] = val;
-        if (e.last) e.G[(long)u * g.nls + lane] = val;
+        e.ring_own[(tm << g.lg) + lane] = val;
+        if (e.last) e.G[((long)u << g.lg) + lane] = val;
         // ---- windows move on by one bin
 #pragma unroll
         for (int k = LT; k >= 2; --k) cn[k] = cn[k - 1];
@@ -319,8 +351,8 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
         for (int k = 0; k < LT; ++k) co[k] = co[k + 1];
 #pragma unroll
         for (int d = 0; d < NA - 1; ++d) acc[d] = acc[d + 1];
-        acc[NA - 1].x = 0; acc[NA - 1].y = 0;
-        w = w1; me = me1; tm = tm1; pm = pm1;
+        acc[NA - 1] = P{0, 0};
+        w = w1; me = me1; tm = tm1; pmo = pmo1;
     }
 };
 

@@ -15,6 +15,7 @@ namespace band {
 inline Geom geometry(int F, int T, int Q, int LT, int SKW, int nls, int Pt) {
     Geom g{};
     g.F = F; g.T = T; g.Q = Q; g.SKW = SKW; g.nls = nls; g.Pt = Pt < 1 ? 1 : Pt;
+    for (g.lg = 0; (1 << g.lg) < nls; ++g.lg) {}
     const int Tp = T + 2 * (Q - 1);
     // steps a lane spends on a frame: its F bins, LT steps before them (positions arrive LT bins ahead); the LT images above
     // Nyquist are written during the first steps of the lane's NEXT frame, which have no bin of their own
@@ -32,7 +33,7 @@ inline Geom geometry(int F, int T, int Q, int LT, int SKW, int nls, int Pt) {
     return g;
 }
 inline size_t ring_bytes(const Geom &g, size_t csize) { return (size_t)g.R * g.nls * csize; }
-inline size_t table_bytes(const Geom &g, size_t csize) { return (size_t)g.Pt * (g.Q - 1) * csize; }
+inline size_t table_bytes(const Geom &g, int LT, size_t csize) { return ((size_t)g.Q * (LT + 1) + (size_t)g.Pt * (g.Q - 1)) * csize; }   // weights + twiddles
 
 // exp(2 pi j num / den), exact on the axes
 inline void unit(long long num, long long den, double *re, double *im) {

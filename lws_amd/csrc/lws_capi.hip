@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "lws_systolic.h"
 #include "lws_sys64.h"
+#include "lws_band.h"
 #include "lws_online.h"
 #include "lws_online64.h"
 
@@ -372,6 +373,26 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
                 if (e != hipSuccess) return fail(LWS_ERR_HIP, "fp64 systolic launch failed: %s", hipGetErrorString(e));
                 p->last_launches = launches;
                 p->last_name = lws::sys64_name(a.F, a.T, a.Q);
+                return LWS_OK;
+            }
+            p->gsk_state.release(); p->gsk_amp.release();   // no room for the skewed copy: the generic engine below
+            (void)hipGetLastError();
+            g_err.clear();
+        }
+    }
+    // batch sweeps no systolic build takes (5-8 frames per stencil row above 513 bins, more than 8 frames per row, stencils of
+    // half-width 6-10, fp64 plans beyond Q in {2, 4}): the band engine (lws_band.hip) when the weights have create_weights'
+    // twiddle structure and a sweep slot's ring fits the LDS.  Same sweeps in the reference's order; a bin's sum in another order.
+    if (mode == lws::MODE_BATCH && !(p->flags & (LWS_FORCE_GENERIC | LWS_GENERIC_PLAIN_LAYOUT)) && !env_int("LWS_NO_BAND", 0) && p->have[wsel]) {
+        lws::BandPlan bp;
+        if (lws::band_plan(p->fp64, B, a.F, a.T, a.L, a.Q, a.Qp, a.update, a.n_thr, p->hostW[wsel].data(), &bp)) {
+            if (p->gsk_state.ensure(bp.state_bytes) == LWS_OK && p->gsk_amp.ensure(bp.amp_bytes) == LWS_OK) {
+                int launches = 0;
+                hipError_t e = lws::launch_band<real>(bp, a, p->hostW[wsel].data(), B, p->gsk_state.p, p->gsk_amp.p, s, &launches, p->ev0, p->ev1);
+                p->timing_pending = true;
+                if (e != hipSuccess) return fail(LWS_ERR_HIP, "band engine launch failed: %s", hipGetErrorString(e));
+                p->last_launches = launches;
+                p->last_name = lws::band_name(bp);
                 return LWS_OK;
             }
             p->gsk_state.release(); p->gsk_amp.release();   // no room for the skewed copy: the generic engine below
@@ -1030,7 +1051,8 @@ int lws_plan_create(lws_plan **plan, int device, int F, int L, int Q, int Qp, co
             hipMemcpy(p->online_tw.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(LWS_ERR_HIP, "twiddle table upload failed");
     }
-    if (rc == LWS_OK && !p->fp64 && !(flags & LWS_FORCE_GENERIC)) {
+    // (LWS_NO_SYSTOLIC=1, read here: no systolic build -- comparison runs of the engines behind them)
+    if (rc == LWS_OK && !p->fp64 && !(flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_SYSTOLIC", 0)) {
         const double *hw[3] = {p->have[0] ? p->hostW[0].data() : nullptr,
                                p->have[1] ? p->hostW[1].data() : nullptr,
                                p->have[2] ? p->hostW[2].data() : nullptr};
