@@ -21,6 +21,7 @@ the launch stream, algorithmic bytes, fraction of 8 TB/s) and the property check
     2-f501   config 2's volume with a 1000-point window (F = 501: F-1 not a multiple of 8)
     2-f257   config 2's volume at config 1's frame size, lws(512,128): 512 spectrograms of 500 x 257
     2-q3 / 2-frac / 2-speech / 2-q5   hop = frame/3, lws(1024,384), lws(400,160), hop = frame/5: the table-twiddle builds (LWSanyQ, LWSfractionalQ)
+    2-q8w / 2-q16 / 2-l8   lws(2048,256), lws(1024,64), lws(1024,256,L=8): the band engine (shapes no systolic build takes)
     host_api config 2 through the host-array entry point plan.batch(numpy complex128): what a caller of the drop-in pays
     1        BASELINE config 1: one 5 s clip (628 x 257) through lws.lws(512,128).run_lws, wall time incl. plan creation,
              beside the reference CPU path on the same clip
@@ -81,6 +82,14 @@ BATCH_CONFIGS = {
     "2-q5":    dict(B=256, T=500, fsize=1000, fshift=200, iters=40, storage="fp32",
                     what="hop = a fifth of the frame (Q = 5, LWSanyQ): %(B)d x %(T)d x %(F)d, lws(1000,200) L=5 "
                          "(the Q = 8 build's geometry with table twiddles: lws::tw_q8)"),
+    # the band engine (lws_band.hip): shapes no systolic build takes
+    "2-q8w":   dict(B=256, T=500, fsize=2048, fshift=256, iters=20, storage="fp32",
+                    what="87.5 %% overlap at config 5's frame size (Q = 8 above 513 bins, LWSanyQ): %(B)d x %(T)d x %(F)d, lws(2048,256) L=5 "
+                         "(band engine; the generic engine takes 235 ps per bin and sweep)"),
+    "2-q16":   dict(B=256, T=500, fsize=1024, fshift=64, iters=10, storage="fp32",
+                    what="hop = a sixteenth of the frame (Q = 16, LWSanyQ): %(B)d x %(T)d x %(F)d, lws(1024,64) L=5 (band engine)"),
+    "2-l8":    dict(B=256, T=500, fsize=1024, fshift=256, iters=40, storage="fp32", L=8,
+                    what="a stencil of half-width 8 (LWSQ4 with L = 8): %(B)d x %(T)d x %(F)d, lws(1024,256,L=8) (band engine)"),
     "4shard":  dict(B=1024, T=500, fsize=1024, fshift=256, iters=100, storage="fp32",
                     what="BASELINE config 4, one GPU's shard: %(B)d spectrograms x %(T)d x %(F)d, lws(1024,256)"),
     "5":       dict(B=64, T=56250, fsize=2048, fshift=512, iters=200, storage="fp32",
@@ -122,10 +131,12 @@ def compact_roofline(roof):
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm_measured_frac",
             "frac_of_measured_copy", "kernel", "kernel_ms_per_step", "launches_per_step", "algorithmic_bytes_per_launch")
     out = {k: _sig(roof.get(k)) for k in keep if k in roof}
-    # `bound` names the roofline achieved / peak / frac are expressed against (the metric's: HBM bytes); `limiter` what the
-    # counters say actually limits the kernel (vector-ALU issue or a dependent chain: profiles/*pmc_sq*.json)
+    # `bound` is the contract's field: the roofline achieved / peak / frac are expressed against (the metric's axis: HBM bytes,
+    # repeated as `roofline_axis`); `limiter` is what the SQ counters say actually limits the kernel (vector-ALU issue or a
+    # dependent chain: profiles/*pmc_sq*.json) -- the two are different questions, and for the LDS-fused kernels different answers
     out["limiter"] = out.get("bound")
     out["bound"] = "hbm"
+    out["roofline_axis"] = "hbm"
     # frac is NOT a bound for the LDS-fused kernels: several sweeps run per pass over HBM, so algorithmic bytes / time can exceed
     # what HBM moves (2-q2: 1.3); the physical limit of those kernels is `limiter`, priced in `valu`
     out["frac_basis"] = "algorithmic_hbm_bytes"
@@ -209,8 +220,9 @@ def summary_lines(extra):
                                                 for k, v in b.items() if isinstance(v, dict) and "wall_ms" in v))
             elif "roofline" in b:
                 r = b["roofline"]
-                out.append("# %s: %.2f ms/step, kernel %.2f ms (%s), %s%s" % (name, b["ms_per_step"], r["kernel_ms_per_step"], r["kernel"], rf(r),
-                                                                            (", default schedule %.1f ms" % b["default_schedule"]["ms_per_step"]) if "default_schedule" in b else ""))
+                out.append("# %s: %.2f ms/step, kernel %.2f ms (%s), %s%s%s" % (name, b["ms_per_step"], r["kernel_ms_per_step"], r["kernel"], rf(r),
+                                                                              (", %.1f ps per bin-sweep" % b["kernel_ps_per_bin_sweep"]) if "kernel_ps_per_bin_sweep" in b else "",
+                                                                              (", default schedule %.1f ms" % b["default_schedule"]["ms_per_step"]) if "default_schedule" in b else ""))
         except Exception as e:       # a summary must never cost the final line
             out.append("# %s: (summary failed: %s)" % (name, e))
     return [l[:300] for l in out]
@@ -239,50 +251,99 @@ def device_magnitudes(torch, dev, B, T, F, first_seed):
     return out, "torch.randn on the device (Philox, seed 20260928)"
 
 
-def cpu_baseline(W, T, F, iters, budget_s=12.0):
+def physical_cores():
+    """Physical cores among the ones this process may run on (hyper-threads share a core's FPU: one spectrogram per core)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                seen.add(f.read().strip())
+        except OSError:
+            seen.add(str(c))
+    return len(allowed), max(1, len(seen))
+
+
+def cpu_baseline(W, T, F, iters, budget_s=12.0, plan=None):
     """The reference CPU path timed on this box's host cores, on a bounded sample of the same workload
     (dense thresholds).  Uses oracle/_ref (the reference's own lwslib.cpp, LWSQ4) when the prebuilt
     library travelled with the repo, else the fp64 C restatement.  Single thread = the reference's
     execution model (it never releases the GIL); an all-cores figure (one spectrogram per thread) is
-    reported beside it."""
+    reported beside it: every thread's inputs are built before the clock starts, the threads leave a barrier
+    together and only their sweeps (ctypes calls, GIL released) are timed.
+    With `plan` (the plan that was just timed): the parity of the timed arithmetic path, measured now -- one T x F
+    spectrogram from a random-phase start, `iters` dense sweeps on the GPU against the same CPU sweeps."""
     from oracle.oracle import Oracle, RefLib, split_weights
     import ctypes as C
     orc = Oracle()
     use_ref = RefLib.available()
     rl = RefLib() if use_ref else None
     L, Q = W.shape[2] - 1, W.shape[1]
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the cores this rank may use
+    nthreads, ncores = physical_cores()
     wr, wi, wf = split_weights(W)
 
+    def prepare(S):
+        er, ei = orc.extend(np.asarray(S, dtype=np.complex128), L, Q)
+        return er, ei, np.ascontiguousarray(np.abs(er + 1j * ei))
+
+    wfi = np.ascontiguousarray(wf, dtype=np.intc)
+    ref_fn = C.cast(rl.fn["LWSQ4" if Q == 4 else "LWSanyQ"], C.c_void_p) if use_ref else None
+
+    def sweep(er, ei, amp, sweeps):
+        """`sweeps` dense sweeps in ONE C call (oracle/lws_oracle.c: lwso_repeat_*): the timed region never enters the interpreter"""
+        if use_ref:   # the reference's own LWSQ4 / LWSanyQ (lwslib.cpp:153-373)
+            orc.lib.lwso_repeat_kernel(ref_fn, 0 if Q == 4 else 1, er.ctypes.data, ei.ctypes.data, wr.ctypes.data, wi.ctypes.data, wfi.ctypes.data,
+                                       amp.ctypes.data, F, T, L, Q, 0.0, sweeps)
+        else:
+            orc.lib.lwso_repeat_sweep(er.ctypes.data, ei.ctypes.data, wr.ctypes.data, wi.ctypes.data, wfi.ctypes.data, amp.ctypes.data,
+                                      F, T, L, Q, W.shape[0], 0.0, sweeps)
+
     def one(seed, sweeps):
-        M = synth_magnitudes(1, T, F, seed)[0].astype(np.float64)
-        er, ei = orc.extend(M.astype(np.complex128), L, Q)
-        amp = np.ascontiguousarray(np.abs(er + 1j * ei))
+        bufs = prepare(synth_magnitudes(1, T, F, seed)[0].astype(np.float64))
         t0 = time.perf_counter()
-        for _ in range(sweeps):
-            if use_ref:
-                rl.fn["LWSQ4" if Q == 4 else "LWSanyQ"](
-                    *( [C.c_void_p(er.ctypes.data), C.c_void_p(ei.ctypes.data), C.c_void_p(wr.ctypes.data),
-                        C.c_void_p(wi.ctypes.data), C.c_void_p(wf.ctypes.data), C.c_void_p(amp.ctypes.data),
-                        F, T, L] + ([] if Q == 4 else [Q]) + [0.0]))
-            else:
-                orc.sweep(er, ei, W, amp, F, T, L, Q, 0.0)
+        sweep(*bufs, sweeps)
         return time.perf_counter() - t0
 
     t1 = one(1, 2)  # calibrate: two sweeps
     sweeps = int(max(4, min(iters, budget_s / 2 / (t1 / 2))))
     dt = one(2, sweeps)
     single = T * F * sweeps / dt
-    # all cores: one spectrogram per thread (ctypes releases the GIL)
-    times = [0.0] * ncores
-    th = [threading.Thread(target=lambda i=i: times.__setitem__(i, one(10 + i, sweeps))) for i in range(ncores)]
-    t0 = time.perf_counter()
-    [t.start() for t in th]
-    [t.join() for t in th]
-    wall = time.perf_counter() - t0
-    return {"value": single, "unit": "bin*iter/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": "1 spectrogram %dx%d, %d dense sweeps, fp64, single thread" % (T, F, sweeps),
-            "all_cores_value": ncores * T * F * sweeps / wall, "all_cores": ncores}
+    # all cores: one spectrogram per physical core; inputs first, then everybody leaves the barrier and only the sweeps are timed
+    bufs = [prepare(synth_magnitudes(1, T, F, 10 + i)[0].astype(np.float64)) for i in range(ncores)]
+    wall = None
+    for _attempt in range(2):   # the better of two rounds: the first one also pays for waking the cores and starting the threads
+        gate = threading.Barrier(ncores + 1)
+        ends = [0.0] * ncores
+
+        def work(i):
+            sweep(*bufs[i], 1)      # (untimed: the thread's core awake, its buffers in its caches)
+            gate.wait()
+            sweep(*bufs[i], sweeps)
+            ends[i] = time.perf_counter()
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(ncores)]
+        [t.start() for t in th]
+        gate.wait()
+        t0 = time.perf_counter()
+        [t.join() for t in th]
+        wall = max(ends) - t0 if wall is None else min(wall, max(ends) - t0)
+    out = {"value": single, "unit": "bin*iter/s", "cores": 1, "kind": "reference" if use_ref else "port",
+           "sample": "1 spectrogram %dx%d, %d dense sweeps, fp64, single thread" % (T, F, sweeps),
+           "all_cores_value": ncores * T * F * sweeps / wall, "all_cores": ncores, "hw_threads": nthreads}
+    if plan is not None:
+        rng = np.random.default_rng(20260929)
+        S = (synth_magnitudes(1, T, F, 3)[0] * np.exp(2j * np.pi * rng.random((T, F)))).astype(np.complex64).astype(np.complex128)
+        got = plan.batch(S, np.zeros(iters))
+        er, ei, amp = prepare(S)
+        sweep(er, ei, amp, iters)
+        ref = (er + 1j * ei)[Q - 1:Q - 1 + T, L:L + F]
+        d = np.abs(got - ref)
+        mean = float(np.mean(np.abs(S)))
+        out["parity"] = {"what": "%dx%d, %d dense sweeps from random phases: timed plan (%s) vs %s, measured in this run"
+                                 % (T, F, iters, plan.last_kernel()["name"], "oracle/_ref LWSQ4" if use_ref and Q == 4 else ("oracle/_ref" if use_ref else "oracle")),
+                         "rel_l2": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "median_over_mean": float(np.median(d) / mean),
+                         "p999_over_mean": float(np.quantile(d, 0.999) / mean), "max_over_mean": float(d.max() / mean)}
+    return out
 
 
 def flops_per_active_bin(W):
@@ -568,10 +629,10 @@ def main():
 
     plans = {}
 
-    def engine(fsize, fshift, storage="fp32", mode=None):
-        key = (fsize, fshift, storage, mode)
+    def engine(fsize, fshift, storage="fp32", mode=None, L=5):
+        key = (fsize, fshift, storage, mode, L)
         if key not in plans:
-            kw = dict(device=local_rank, force_generic=args.force_generic)
+            kw = dict(device=local_rank, force_generic=args.force_generic, L=L)
             if storage == "fp16":
                 kw["storage"] = "fp16"
             if mode:
@@ -585,7 +646,7 @@ def main():
         B = B or cfg["B"]; T = T or cfg["T"]; iters = iters or cfg["iters"]
         F = cfg["fsize"] // 2 + 1
         storage = cfg["storage"]
-        p = engine(cfg["fsize"], cfg["fshift"], storage)
+        p = engine(cfg["fsize"], cfg["fshift"], storage, L=cfg.get("L", 5))
         plan = p.plan()
         lo, _hi = shard_range(B * world, rank, world)      # this rank's contiguous block of the job's B * world spectrograms
         mags, gen = device_magnitudes(torch, dev, B, T, F, 20260928 + lo)
@@ -625,11 +686,11 @@ def main():
             "workload": (cfg["what"] % dict(B=B, T=T, F=F)) + ", %d %s batch-LWS sweeps" % (iters, "dense (all thresholds 0)" if schedule == "dense" else "default-schedule (100 exp(-0.1 i))"),
             "batch_per_gpu": B, "frames": T, "bins": F, "iters": iters, "schedule": schedule, "storage": storage,
             "data": "synthetic Rayleigh magnitudes, %s, zero phase" % gen,
-            "steps": steps, "ms_per_step": 1e3 * dt / steps, "value": units * world / (dt / steps),
+            "steps": steps, "ms_per_step": 1e3 * dt / steps, "value": units * world / (dt / steps), "kernel_ps_per_bin_sweep": 1e9 * k_ms / units,
             "active_value": active * world / (dt / steps), "effective_sweeps": active / (float(B) * T * F),
             # bound: the vector ALU (66 % busy, HBM at 0.16x the algorithmic bytes: profiles/r02_pmc_sq_counters.json)
             "roofline": roofline_block(alg, k_ms, active, p.W, traffic, tsrc, info["name"], launches / steps,
-                                       "valu" if str(info["name"]).startswith("systolic") else "latency"),
+                                       "valu" if str(info["name"]).startswith(("systolic", "band")) else "latency"),
         }
         if checks:
             # size-independent properties of the result (the -m gpu tests assert the same ones at these sizes)
@@ -694,7 +755,7 @@ def main():
     elif args.extras is not None:
         wanted = [x for x in args.extras.split(",") if x]
     elif world == 1 and args.config == "2":
-        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-q5", "2-f501", "2-f257", "2-fp64", "4shard", "3", "3-b1024", "3-fp64", "host_api", "1", "5", "5-f16"]
+        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-q5", "2-q8w", "2-q16", "2-l8", "2-f501", "2-f257", "2-fp64", "4shard", "3", "3-b1024", "3-fp64", "host_api", "1", "5", "5-f16"]
     else:
         wanted = ["4shard"] if args.config == "2" else []
     if args.no_default_schedule and "2-default" in wanted:
@@ -750,19 +811,18 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:   # rank 0's host cores, outside every timed region
-        cpu = cpu_baseline(p.W, min(T, 500), F, iters)
+        cpu = cpu_baseline(p.W, min(T, 500), F, iters, plan=None if args.force_generic else p.plan())
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         head["fshift"] = p.fshift
         full = {"headline": {k: v for k, v in head.items() if k != "roofline"}, "roofline": roof, "cpu_baseline": cpu, "extra": extra,
-                "parity_of_timed_workload": ("100 dense sweeps on the fp32 systolic engine are checked value by value against the oracle from a "
-                                             "random-phase start at SURVEY 8(c)'s bars (tests/test_gpu_parity.py::test_dense_sweeps_from_random_phases_"
-                                             "value_level: rel-L2 1.4e-5, median 2e-7, p99.9 2e-4 x mean|S|).  The timed start (zero phases, "
-                                             "run_lws(np.abs(X))) is ill-conditioned (DESIGN 6): fp32 is held to magnitudes 1e-6 + consistency "
-                                             "0.05 dB there, the schedule by the fp64 plan; the default schedule (extra.default_schedule) is "
-                                             "checked value by value against the oracle")}
+                "parity_of_timed_workload": ("measured in this run (parity_measured_in_this_run: the timed plan against the CPU reference on one "
+                                             "spectrogram from a random-phase start); the timed start (zero phases, run_lws(np.abs(X))) is "
+                                             "ill-conditioned (DESIGN 6): fp32 is held to magnitudes 1e-6 + consistency 0.05 dB there, the "
+                                             "schedule by the fp64 plan; the default schedule (extra.default_schedule) is checked value by value "
+                                             "against the oracle in tests/test_gpu_parity.py")}
         extra_file = None
         try:   # everything that is not the contract's line: a file next to the run (gpurun_out/ travels back from the GPU box)
             d = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
@@ -774,9 +834,15 @@ def main():
             extra_file = None
         for l in summary_lines(extra):
             print(l)
-        # (numbers of tests/test_gpu_parity.py on an MI355X, round 5: the bench may not call the oracle on its product path)
-        notes = ("parity of this arithmetic path vs the fp64 oracle (tests/test_gpu_parity.py): 100 dense sweeps 500x513 from random phases rel-L2 1.4e-5, "
-                 "median 2e-7, p99.9 2e-4 of mean|S|; timed zero-phase start (ill-conditioned): consistency within 0.05 dB, magnitudes 1e-6")
+        # parity of the timed arithmetic path, measured in this run (cpu_baseline leg: the oracle is the checker there, outside every
+        # timed region); the timed start itself (zero phases) is ill-conditioned and is held to its properties
+        par = (cpu or {}).pop("parity", None) if cpu else None
+        if par:
+            full["parity_measured_in_this_run"] = par
+            notes = ("measured now, %s: rel-L2 %.2e, median %.1e, p99.9 %.1e, max %.1e of mean|S| (bars: 1e-3 / 1e-6 / 1e-3); timed zero-phase start "
+                     "(ill-conditioned): magnitudes 1e-6, consistency 0.05 dB (tests)" % (par["what"], par["rel_l2"], par["median_over_mean"], par["p999_over_mean"], par["max_over_mean"]))
+        else:
+            notes = "parity of this arithmetic path: tests/test_gpu_parity.py (not measured in this run: no CPU leg)"
         also = {}
         try:
             c = extra.get("configs") or {}

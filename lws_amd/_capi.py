@@ -421,6 +421,10 @@ def istft_length(frames, fsize, fshift, perfectrec):
 def stft_dev(x_ptr, B, length, fsize, fshift, awin, perfectrec, S_ptr, device=0, stream=None, fftsize=None):
     """x_ptr: device float32 [B][length]; S_ptr: device complex64 [B][stft_frames(...)][fftsize//2+1] (fftsize: fsize unless given)."""
     a = _win(awin)
+    if int(fsize) % 2:
+        # (the reference's stft only asks for an even fftsize, lws.pyx:49-50: an odd frame under an even, longer transform works on
+        #  the host path; the device kernels pair up the samples of a frame)
+        raise ValueError("stft_dev needs an even frame size (got %d): use the host stft() for an odd frame under a longer transform" % int(fsize))
     if fftsize is None or int(fftsize) == int(fsize):
         check(load().lws_stft_dev(int(device), x_ptr, int(B), int(length), int(fsize), int(fshift), a.ctypes.data,
                                   int(bool(perfectrec)), S_ptr, stream))

@@ -15,6 +15,7 @@
 #include "lws_band.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "lws_band_host.h"
@@ -24,7 +25,6 @@ namespace {
 using namespace band;
 
 constexpr size_t LDS_BYTES = 160 * 1024;
-constexpr size_t TAB_BYTES = 64 * 1024;   // room for the two tables behind the skewed state
 
 template <typename real> struct BArgs {
     typename cx<real>::type *G;           // [chunk][rows][nls] time-skewed state
@@ -39,7 +39,7 @@ template <typename real> struct BArgs {
 // LDS writes of this step complete, then everybody meets.  (Not __syncthreads(): that waits for the global prefetches too.)
 #define BAND_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <typename real, int LT, int QT, bool FIRST>
+template <typename real, int LT, int QT, bool FIRST, bool EXACT>
 __device__ __forceinline__ void band_wave(const BArgs<real> &a, typename cx<real>::type *ring, const typename cx<real>::type *wt, const typename cx<real>::type *tw,
                                           typename cx<real>::type *G, const real *A, int s, int lane) {
     using C = typename cx<real>::type;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void band_wave(const BArgs<real> &a, typename cx<real
     const bool live = s < a.ns;
     e.thr = a.thr[(size_t)blockIdx.x * a.n_thr + a.thr0 + (live ? s : 0)];
     e.last = s == a.ns - 1;
-    Lane<real, C, LT, QT, FIRST> ln(e, lane, s);
+    Lane<real, C, LT, QT, FIRST, EXACT> ln(e, lane, s);
     const int t_end = a.g.U + a.g.LAG * (a.ns - 1);   // U and LAG are even
     int ph = 0;
     for (int t0 = 0; t0 < t_end; t0 += 2) {
@@ -74,7 +74,7 @@ __device__ __forceinline__ void band_wave(const BArgs<real> &a, typename cx<real
     }
 }
 
-template <typename real, int LT, int QT, int MAXT>
+template <typename real, int LT, int QT, bool EXACT, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_band(BArgs<real> a) {
     using C = typename cx<real>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];
@@ -95,8 +95,8 @@ __global__ void __launch_bounds__(MAXT) k_band(BArgs<real> a) {
     }
     C *G = a.G + (size_t)blockIdx.x * a.g_stride;
     const real *A = a.A + (size_t)blockIdx.x * a.g_stride;
-    if (s == 0) band_wave<real, LT, QT, true>(a, ring, wt, tw, G, A, s, lane);
-    else band_wave<real, LT, QT, false>(a, ring, wt, tw, G, A, s, lane);
+    if (s == 0) band_wave<real, LT, QT, true, EXACT>(a, ring, wt, tw, G, A, s, lane);
+    else band_wave<real, LT, QT, false, EXACT>(a, ring, wt, tw, G, A, s, lane);
 }
 
 // extended buffers [B][Tp][F + 2 L] <-> the skewed layout (bins 0 .. F-1 and LT images above Nyquist per frame)
@@ -134,32 +134,38 @@ __global__ void __launch_bounds__(256) k_band_store(typename cx<real>::type *sta
     }
 }
 
-template <typename real, int LT, int QT, int MAXT>
+template <typename real, int LT, int QT, bool EXACT, int MAXT>
 hipError_t launch_pass(const BArgs<real> &a, int B, hipStream_t stream) {
     using C = typename cx<real>::type;
     static std::atomic<unsigned long long> done{0};
     const size_t lds = (size_t)a.nsl * a.g.R * a.g.nls * sizeof(C) + table_bytes(a.g, LT, sizeof(C));
     int dev = 0;
     if (attr_needed(done, &dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_band<real, LT, QT, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_band<real, LT, QT, EXACT, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done(done, dev);
     }
-    k_band<real, LT, QT, MAXT><<<dim3(B), dim3(a.g.nls * a.nsl), lds, stream>>>(a);
+    k_band<real, LT, QT, EXACT, MAXT><<<dim3(B), dim3(a.g.nls * a.nsl), lds, stream>>>(a);
     return hipGetLastError();
 }
 template <typename real>
 hipError_t launch_pass_any(const BandPlan &bp, const BArgs<real> &a, int B, hipStream_t stream) {
-    // (two waves per SIMD -- 256 vector registers each -- only where the step fits them: fp32, L <= 5, Q <= 8)
-    if constexpr (std::is_same<real, float>::value) {
-        if (bp.LT == 5 && bp.QT == 8) return launch_pass<real, 5, 8, 512>(a, B, stream);
-    } else {
-        if (bp.LT == 5 && bp.QT == 8) return launch_pass<real, 5, 8, 256>(a, B, stream);
+    // the instantiations: an exact one for the Q each family is mostly used with (no test on the frame offsets: a step is
+    // straight-line code), one with the tests for the others.  Two waves per SIMD (256 vector registers each) only where the step
+    // fits them: fp32, L <= 5, Q <= 8.
+    const int Q = a.g.Q;
+    constexpr int M8 = std::is_same<real, float>::value ? 512 : 256;
+    if (bp.LT == 5) {
+        if (Q == 8 && a.g.nls * a.nsl <= 256) return launch_pass<real, 5, 8, true, 256>(a, B, stream);   // (straight-line: one wave per SIMD's registers)
+        if (Q <= 8) return launch_pass<real, 5, 8, false, M8>(a, B, stream);
+        if constexpr (std::is_same<real, float>::value) {
+            if (Q == 16) return launch_pass<real, 5, 16, true, 256>(a, B, stream);
+        }
+        return launch_pass<real, 5, 16, false, 256>(a, B, stream);
     }
-    if (bp.LT == 5 && bp.QT == 16) return launch_pass<real, 5, 16, 256>(a, B, stream);
-    if (bp.LT == 10 && bp.QT == 8) return launch_pass<real, 10, 8, 256>(a, B, stream);
-    if (bp.LT == 10 && bp.QT == 16) return launch_pass<real, 10, 16, 256>(a, B, stream);
-    return hipErrorInvalidValue;
+    if (Q == 4) return launch_pass<real, 10, 4, true, 256>(a, B, stream);
+    if (Q <= 8) return launch_pass<real, 10, 8, false, 256>(a, B, stream);
+    return launch_pass<real, 10, 16, false, 256>(a, B, stream);
 }
 inline int max_threads(bool fp64, int LT, int QT) { return (!fp64 && LT == 5 && QT == 8) ? 512 : 256; }
 
@@ -205,8 +211,12 @@ bool band_plan(bool fp64, int B, int F, int T, int L, int Q, int Qp, int update,
     int Pt = 0, s = 0;
     if (!weights_twiddle(W, Q, Qp, L, 128, &Pt, &s)) return false;
     if (Pt < 1) { Pt = 1; s = 0; }
-    // (general tensors: numpy's exp of an angle of up to N turns leaves the rows 1e-13 of a turn off their twiddle)
-    if (!rows_are_twiddles(W, Q, Qp, L, Pt, s, fp64 ? (Qp == Q ? 1e-13 : 1e-11) : 1e-9)) return false;
+    // (fp64: the rows must be the twiddle images of row 0 to rounding, or the results would not be the reference's.  The general
+    //  tensors create_weights builds for a hop that does not divide the frame -- one row per bin, numpy's exp of an angle of up to N
+    //  turns -- are 1e-13 to 1e-16 of a turn off, which a few sweeps amplify a thousandfold: fp64 plans with such tensors stay on the
+    //  order-exact engine, whatever the check below would say)
+    if (fp64 && Qp != Q) return false;
+    if (!rows_are_twiddles(W, Q, Qp, L, Pt, s, fp64 ? 1e-13 : 1e-9)) return false;
     const size_t csize = fp64 ? 16 : 8;
     const int maxt = max_threads(fp64, LT, QT);
     BandPlan best{};
@@ -240,37 +250,37 @@ bool band_plan(bool fp64, int B, int F, int T, int L, int Q, int Qp, int update,
     const int cf = env_i("LWS_BAND_CHUNK", 0);
     if (cf > 0) chunk = std::min(chunk, cf);
     best.chunk = chunk;
-    best.state_bytes = (size_t)chunk * best.g.rows * best.g.nls * csize + TAB_BYTES;
+    best.state_bytes = (size_t)chunk * best.g.rows * best.g.nls * csize;
     best.amp_bytes = (size_t)chunk * best.g.rows * best.g.nls * (csize / 2);
-    if (table_bytes(best.g, LT, csize) > TAB_BYTES) return false;
     if (out) *out = best;
     return true;
 }
 
 const char *band_name(const BandPlan &bp) { return bp.fp64 ? "band_fp64" : "band_fp32"; }
 
+std::vector<unsigned char> band_tables(const BandPlan &bp, const double *W_host) {
+    std::vector<double> wtd, twd;
+    tables(W_host, bp.g.Q, bp.L, bp.LT, bp.Pt, bp.s, wtd, twd);
+    wtd.insert(wtd.end(), twd.begin(), twd.end());
+    std::vector<unsigned char> out(wtd.size() * (bp.fp64 ? sizeof(double) : sizeof(float)));
+    if (bp.fp64) memcpy(out.data(), wtd.data(), out.size());
+    else for (size_t i = 0; i < wtd.size(); ++i) reinterpret_cast<float *>(out.data())[i] = (float)wtd[i];
+    return out;
+}
+
 template <typename real>
-hipError_t launch_band(const BandPlan &bp, const GenericArgs<real> &ga, const double *W_host, int B, void *gs, void *gamp, hipStream_t stream,
+hipError_t launch_band(const BandPlan &bp, const GenericArgs<real> &ga, const void *tables_dev, int B, void *gs, void *gamp, hipStream_t stream,
                        int *launches, hipEvent_t ev0, hipEvent_t ev1) {
     using C = typename cx<real>::type;
     if (B <= 0 || ga.n_thr <= 0) return hipSuccess;
-    if (ga.mode != MODE_BATCH || ga.L != bp.L || ga.F != bp.g.F || ga.T != bp.g.T || ga.Q != bp.g.Q) return hipErrorInvalidValue;
+    if (ga.mode != MODE_BATCH || ga.L != bp.L || ga.F != bp.g.F || ga.T != bp.g.T || ga.Q != bp.g.Q || !tables_dev) return hipErrorInvalidValue;
     const Geom &g = bp.g;
     const int Tp = g.T + 2 * (g.Q - 1);
     const size_t Np = g.F + 2 * bp.L;
     C *G = static_cast<C *>(gs);
     real *A = static_cast<real *>(gamp);
     const long g_stride = g.rows * g.nls;
-    // the two tables, behind the skewed state
-    std::vector<double> wtd, twd;
-    tables(W_host, g.Q, bp.L, bp.LT, bp.Pt, bp.s, wtd, twd);
-    std::vector<C> tab(wtd.size() / 2 + twd.size() / 2);
-    for (size_t i = 0; i < wtd.size() / 2; ++i) { tab[i].x = (real)wtd[2 * i]; tab[i].y = (real)wtd[2 * i + 1]; }
-    for (size_t i = 0; i < twd.size() / 2; ++i) { tab[wtd.size() / 2 + i].x = (real)twd[2 * i]; tab[wtd.size() / 2 + i].y = (real)twd[2 * i + 1]; }
-    C *tab_dev = reinterpret_cast<C *>(reinterpret_cast<unsigned char *>(gs) + (bp.state_bytes - TAB_BYTES));
     hipError_t e;
-    // (pageable source: the copy is staged before the call returns, so `tab` may go out of scope)
-    if ((e = hipMemcpyAsync(tab_dev, tab.data(), tab.size() * sizeof(C), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if (ev0) (void)hipEventRecord(ev0, stream);
     int n_all = 0;
     for (int b0 = 0; b0 < B; b0 += bp.chunk) {
@@ -283,7 +293,7 @@ hipError_t launch_band(const BandPlan &bp, const GenericArgs<real> &ga, const do
         if ((e = hipGetLastError()) != hipSuccess) return e;
         BArgs<real> a;
         a.G = G; a.A = A; a.thr = ga.thr + (size_t)b0 * ga.n_thr;
-        a.tab = tab_dev;
+        a.tab = static_cast<const C *>(tables_dev);
         a.g_stride = g_stride; a.n_thr = ga.n_thr; a.nsl = bp.NS; a.g = g;
         for (int i0 = 0; i0 < ga.n_thr; i0 += bp.NS, ++n_all) {
             a.thr0 = i0;
@@ -297,7 +307,7 @@ hipError_t launch_band(const BandPlan &bp, const GenericArgs<real> &ga, const do
     if (launches) *launches = n_all;
     return hipSuccess;
 }
-template hipError_t launch_band<float>(const BandPlan &, const GenericArgs<float> &, const double *, int, void *, void *, hipStream_t, int *, hipEvent_t, hipEvent_t);
-template hipError_t launch_band<double>(const BandPlan &, const GenericArgs<double> &, const double *, int, void *, void *, hipStream_t, int *, hipEvent_t, hipEvent_t);
+template hipError_t launch_band<float>(const BandPlan &, const GenericArgs<float> &, const void *, int, void *, void *, hipStream_t, int *, hipEvent_t, hipEvent_t);
+template hipError_t launch_band<double>(const BandPlan &, const GenericArgs<double> &, const void *, int, void *, void *, hipStream_t, int *, hipEvent_t, hipEvent_t);
 
 }  // namespace lws

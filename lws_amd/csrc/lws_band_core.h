@@ -89,7 +89,8 @@ template <typename real, typename C> struct Env {
     bool last;              // this slot's output is what the pass leaves in the skewed state
 };
 
-template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
+// EXACT: Q == QT -- the tests on the frame offsets are decided at compile time and a step is straight-line code
+template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = false> struct Lane {
     static constexpr int NA = 2 * LT + 1, NRT = QT - 1, K1 = LT + 1;
     using P = V2<real>;
     // what a step receives from the frames r apart -- position w of frame me - r (L) and of frame me + r (R), tau_r^w (T) -- and what
@@ -164,7 +165,7 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
         const Geom &g = e.g;
         pfA[b] = e.A[((long)ux << g.lg) + lane];
         if constexpr (FIRST) {
-            const int NR = g.Q - 1;
+            const int NR = EXACT ? NRT : g.Q - 1;
             const C *Gu = e.G + ((long)(ux + LT) << g.lg);
             pfO[b] = Gu[lane];
 #pragma unroll
@@ -186,7 +187,7 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
     // ct = 0 .. LT - PH with V[r][ct + PH]; one lane at most (z), the others add zeros
     template <int PH> BAND_FN void images(const SD (&sd)[NRT], bool z) {
         if constexpr (PH >= 1 && PH <= LT) {
-            const int NR = e.g.Q - 1;
+            const int NR = EXACT ? NRT : e.g.Q - 1;
 #pragma unroll
             for (int r = 0; r < NRT; ++r) {
                 if (r >= NR) continue;
@@ -209,7 +210,7 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
     //   PB: which of the PFD prefetch buffers holds this step's loads (u mod PFD);  ph = u mod SKW = w mod SKW in every lane
     template <int PB> BAND_FN void step(int u, int ph) {
         const Geom &g = e.g;
-        const int NR = g.Q - 1, F = g.F;
+        const int NR = EXACT ? NRT : g.Q - 1, F = g.F;
         // ---- this step's inputs were requested earlier (LDS: the first frame offset's one step early, the others' while the
         //      offset before them is worked on; skewed state: PFD steps early)
         const C img = nxI;
@@ -241,12 +242,21 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
         real y0 = 0;
         SD sd[NRT];
         In cur = nx;
+        C wcur[K1];              // the weights of the frame offset at hand, requested like its inputs: while the one before is worked on
+#pragma unroll
+        for (int k = 0; k <= LT; ++k) wcur[k] = e.wt[K1 + k];
 #pragma unroll
         for (int r = 0; r < NRT; ++r) {
             if (r >= NR) continue;
             const In in = cur;
-            if (r + 1 < NR) cur = fetch(r + 1, tm, pmo, 1);
-            const C *wr = e.wt + (r + 1) * K1;
+            C wr[K1];
+#pragma unroll
+            for (int k = 0; k <= LT; ++k) wr[k] = wcur[k];
+            if (r + 1 < NR) {
+                cur = fetch(r + 1, tm, pmo, 1);
+#pragma unroll
+                for (int k = 0; k <= LT; ++k) wcur[k] = e.wt[(r + 2) * K1 + k];
+            }
             C Rv;
             if constexpr (FIRST) Rv = pfR[PB][r]; else Rv = in.R;
             const P uu = pr<real>(in.L) + pr<real>(Rv), jv = turn<real>(pr<real>(in.L) - pr<real>(Rv));
@@ -273,6 +283,11 @@ template <typename real, typename C, int LT, int QT, bool FIRST> struct Lane {
                 acc[LT + k] = vfma<real>(splat<real>(v.y), t.D, a);
                 acc[LT - k] = vfma<real>(-splat<real>(v.y), t.D, b);
             }
+#if defined(__HIPCC__)
+            // (the requests of the next frame offset are in flight behind this one's arithmetic; moving more across this line only
+            //  costs registers)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         // DC and Nyquist.  Their neighbourhood is Hermitian (the images are exact conjugates), so in the reference every tap pair
         // k >= 1 adds x and then -x to the imaginary part of the sum, bit for bit (lwslib.cpp:310-311 on c = conj(b)): what is left

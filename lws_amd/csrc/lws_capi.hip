@@ -175,6 +175,8 @@ struct lws_plan {
     DevBuf w[3], wflag[3];
     DevBuf state, amp, row_sums, mean_amp, thr_host_copy, thr_scaled, stage, resid_rows, resid_out, resid_sum;
     DevBuf gsk_state, gsk_amp;     // time-skewed copy of the state for the generic engine's batch sweeps
+    DevBuf band_tab[3];            // the band engine's tables of each weight tensor (lws_band.h: band_tables), uploaded at first use
+    int band_tab_lt[3] = {0, 0, 0};
     HostPipe pipe;                 // host-array entry points: pinned staging, chunk buffers, streams
     lws::SystolicPlan sys;         // device tables of the systolic kernel (empty if not eligible)
     const lws::SystolicBuild *sysb = nullptr;   // the build of it that serves this plan (narrow / Q = 8 / wide), if any
@@ -354,7 +356,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
             end_timing(p, s);
             if (e != hipSuccess) return fail(LWS_ERR_HIP, "fp64 online launch failed: %s", hipGetErrorString(e));
             p->last_launches = 1;
-            p->last_name = "online_lds_fp64";
+            p->last_name = lws::online64_name();
             return LWS_OK;
         }
     }
@@ -386,9 +388,16 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     if (mode == lws::MODE_BATCH && !(p->flags & (LWS_FORCE_GENERIC | LWS_GENERIC_PLAIN_LAYOUT)) && !env_int("LWS_NO_BAND", 0) && p->have[wsel]) {
         lws::BandPlan bp;
         if (lws::band_plan(p->fp64, B, a.F, a.T, a.L, a.Q, a.Qp, a.update, a.n_thr, p->hostW[wsel].data(), &bp)) {
+            if (p->band_tab_lt[wsel] != bp.LT) {   // (once per plan and tensor: a blocking copy of a few KB)
+                const std::vector<unsigned char> tab = lws::band_tables(bp, p->hostW[wsel].data());
+                int rc = p->band_tab[wsel].ensure(tab.size());
+                if (rc) return rc;
+                HIP_TRY(hipMemcpy(p->band_tab[wsel].p, tab.data(), tab.size(), hipMemcpyHostToDevice));
+                p->band_tab_lt[wsel] = bp.LT;
+            }
             if (p->gsk_state.ensure(bp.state_bytes) == LWS_OK && p->gsk_amp.ensure(bp.amp_bytes) == LWS_OK) {
                 int launches = 0;
-                hipError_t e = lws::launch_band<real>(bp, a, p->hostW[wsel].data(), B, p->gsk_state.p, p->gsk_amp.p, s, &launches, p->ev0, p->ev1);
+                hipError_t e = lws::launch_band<real>(bp, a, p->band_tab[wsel].p, B, p->gsk_state.p, p->gsk_amp.p, s, &launches, p->ev0, p->ev1);
                 p->timing_pending = true;
                 if (e != hipSuccess) return fail(LWS_ERR_HIP, "band engine launch failed: %s", hipGetErrorString(e));
                 p->last_launches = launches;
@@ -1102,6 +1111,7 @@ void lws_plan_destroy(lws_plan *p) {
     p->state.release(); p->amp.release(); p->row_sums.release(); p->mean_amp.release();
     p->thr_host_copy.release(); p->thr_scaled.release(); p->stage.release();
     p->resid_rows.release(); p->resid_out.release(); p->resid_sum.release(); p->gsk_state.release(); p->gsk_amp.release(); p->online_tw.release();
+    for (int i = 0; i < 3; ++i) p->band_tab[i].release();
     p->pipe.release();
     delete static_cast<HostWorkers *>(p->host_pool);
     p->host_pool = nullptr;
@@ -1377,5 +1387,35 @@ const char *lws_generic_stage(lws_plan *p) { return p ? p->generic_stage : ""; }
 // checks that no prefetch reads past the rows it allocates).  out = {rows, highest row read, highest row written, gap}; 0 if the shape
 // is not one the engine takes.
 int lws_debug_sys64_layout(int F, int T, int Q, long *out) { return out && lws::sys64_layout(F, T, Q, out) ? 1 : 0; }
+
+// Test hook, not part of include/lws_hip.h: ONE stage on extended buffers the caller supplies -- the reference's ExtSr/ExtSi and AmpSpec
+// (lws.pyx:235-240) as it would hand them to a kernel of lwslib.h, [B][T + 2(Q-1)][F + 2L] on the host, in the plan's arithmetic type
+// (complex64 + float32, or complex128 + float64) -- with the thresholds taken as they are (not scaled by mean|S|).  State and target
+// magnitudes are independent here, which no public entry point allows: a frame whose targets are zero is never updated, so a test can
+// freeze the first m0 frames at values of its choice and compare what the PRODUCTION kernel makes of the frames after them with the
+// oracle on the same buffers (tests/test_gpu_teacher.py).  stage: 0 batch, 1 no-future, 2 online.  The state is updated in place.
+int lws_debug_stage_ext(lws_plan *p, int stage, int wsel, void *state_ext, const void *amp_ext, int B, int T, const double *thresholds, int iters,
+                        int LA, double qdiv) {
+    int rc = check_common(p, B, T, thresholds, iters);
+    if (rc) return rc;
+    if (!state_ext || !amp_ext || stage < 0 || stage > 2 || B < 1 || iters < 1) return fail(LWS_ERR_INVALID, "lws_debug_stage_ext: bad arguments");
+    StageSpec st{stage == 0 ? lws::MODE_BATCH : (stage == 1 ? lws::MODE_NOFUTURE : lws::MODE_ONLINE), wsel, thresholds, iters, LA, qdiv};
+    if ((rc = need_weights(p, &st, 1))) return rc;
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = nullptr;
+    if ((rc = order_after_plan_work(p, s))) return rc;
+    rc = p->fp64 ? ensure_scratch<double>(p, B, T, iters) : ensure_scratch<float>(p, B, T, iters);
+    if (rc) return rc;
+    const size_t n = (size_t)B * (T + 2 * (p->Q - 1)) * (p->F + 2 * p->L), rs = p->fp64 ? sizeof(double) : sizeof(float);
+    HIP_TRY(hipMemcpy(p->state.p, state_ext, n * 2 * rs, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->amp.p, amp_ext, n * rs, hipMemcpyHostToDevice));
+    std::vector<double> ones((size_t)B, 1.0);
+    HIP_TRY(hipMemcpy(p->mean_amp.p, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+    rc = p->fp64 ? run_stage<double>(p, st.mode, wsel, B, T, thresholds, iters, LA, qdiv, s) : run_stage<float>(p, st.mode, wsel, B, T, thresholds, iters, LA, qdiv, s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(state_ext, p->state.p, n * 2 * rs, hipMemcpyDeviceToHost));
+    return LWS_OK;
+}
 
 }  // extern "C"

@@ -9,5 +9,7 @@ namespace lws {
 bool online64_supports(int F, int T, int L, int Q, int Qp, int LA, int n_thr, int update);
 // Same contract and the same BITS as launch_generic<double> with mode == MODE_ONLINE.
 hipError_t launch_online64(const GenericArgs<double> &a, int B, hipStream_t stream);
+// "online_lds_fp64"; "online_lds_fp64_1w" when LWS_ONLINE64_ONE_WAVE selects the one-wave kernel (comparison runs; read on every launch)
+const char *online64_name();
 
 }  // namespace lws

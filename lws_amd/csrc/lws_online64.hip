@@ -482,7 +482,7 @@ template <int Q, bool AMP_LDS, int SPLIT, int ONCH> hipError_t launch_qp(const A
 template <int Q> constexpr int onch_of() { return Q == 4 ? 1 : (Q == 8 ? 3 : 0); }
 template <int Q> constexpr int split_of() { return Q == 4 ? 11 : (Q == 8 ? 33 : ((Q - 1) * (2 * L + 1) > 16 ? ((Q - 1) * (2 * L + 1) - 16) / 2 : 0)); }
 template <int Q> hipError_t launch_q(const Args64 &a, int B, size_t lds, bool amp_lds, hipStream_t s) {
-    static const bool one_wave = getenv("LWS_ONLINE64_ONE_WAVE") != nullptr;      // the one-wave kernel, for comparison
+    const bool one_wave = getenv("LWS_ONLINE64_ONE_WAVE") != nullptr;      // the one-wave kernel, for comparison (read on every launch: a test sets it between calls)
     {
         if (!one_wave) return amp_lds ? launch_qp<Q, true, split_of<Q>(), onch_of<Q>()>(a, B, lds, s) : launch_qp<Q, false, split_of<Q>(), onch_of<Q>()>(a, B, lds, s);
     }
@@ -490,6 +490,8 @@ template <int Q> hipError_t launch_q(const Args64 &a, int B, size_t lds, bool am
 }
 
 }  // namespace
+
+const char *online64_name() { return getenv("LWS_ONLINE64_ONE_WAVE") != nullptr ? "online_lds_fp64_1w" : "online_lds_fp64"; }
 
 bool online64_supports(int F, int T, int Lplan, int Q, int Qp, int LA, int n_thr, int update) {
     return update == 2 && shape64(F, T, Lplan, Q, Qp, LA, n_thr).ok;

@@ -298,9 +298,9 @@ static int stft_impl(int device, const float *x_dev, int B, int len, int fs, int
     return ctx_leave(c, s);
 }
 
-int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int Nhift, const double *swin, int perfectrec,
+int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int fshift, const double *swin, int perfectrec,
                   float *x_dev, void *stream) {
-    int rc = check_shape(device, B, M, N, Nhift);
+    int rc = check_shape(device, B, M, N, fshift);
     if (rc) return rc;
     if (!x_dev || !S_dev) return lws::set_error(LWS_ERR_INVALID, "null device pointer");
     if (B == 0) return LWS_OK;
@@ -311,17 +311,17 @@ int lws_istft_dev(int device, const void *S_dev, int B, int M, int N, int Nhift,
     if ((rc = ctx_enter(c, s))) return rc;
     if ((rc = allow_lds_all())) return rc;
     if ((rc = upload_window(c.win_s, swin, N, s))) return rc;
-    const int Tfull = Nhift * (M - 1) + N, out_len = lws_istft_length(M, N, Nhift, perfectrec);
+    const int Tfull = fshift * (M - 1) + N, out_len = lws_istft_length(M, N, fshift, perfectrec);
     if ((rc = c.frames.ensure((size_t)B * M * N * sizeof(float)))) return rc;
     if ((rc = c.signal.ensure((size_t)B * Tfull * sizeof(float)))) return rc;
     hipLaunchKernelGGL(k_istft_frames, dim3(M, B), dim3(FFT_THREADS), fft_lds_bytes(N), s,
                        static_cast<const float2 *>(S_dev), static_cast<float *>(c.frames.p),
                        static_cast<const float *>(c.win_s.p), M, N, factor(N).odd, factor(N).log2e);
     hipLaunchKernelGGL(k_overlap_add, dim3((Tfull + 255) / 256, B), dim3(256), 0, s, static_cast<const float *>(c.frames.p),
-                       static_cast<float *>(c.signal.p), M, N, Nhift, Tfull, 0, 0);
+                       static_cast<float *>(c.signal.p), M, N, fshift, Tfull, 0, 0);
     STFT_TRY(hipGetLastError());
     // lws.pyx:130-137: cut the leading pad and the last N - hop samples
-    const int off = perfectrec ? prepad(N, Nhift) : 0;
+    const int off = perfectrec ? prepad(N, fshift) : 0;
     STFT_TRY(hipMemcpy2DAsync(x_dev, (size_t)out_len * sizeof(float), static_cast<const float *>(c.signal.p) + off,
                               (size_t)Tfull * sizeof(float), (size_t)out_len * sizeof(float), B, hipMemcpyDeviceToDevice, s));
     return ctx_leave(c, s);

@@ -188,6 +188,24 @@ void lwso_sweep(int flavour, double *sr, double *si, const double *wr, const dou
         sweep_canonical(sr, si, wr, wi, wflag, amp, F, M, M0, L, Q, Qp, threshold, update, qdiv);
 }
 
+/* ---- timing helpers (bench.py's cpu_baseline leg): `sweeps` dense sweeps in one call, so that a timed thread never
+ * touches the Python interpreter between sweeps.  `fn` is a batch kernel with the calling convention of lwslib.h:9-12
+ * (LWSQ2 / LWSQ4: has_q = 0; LWSanyQ / LWSfractionalQ: has_q = 1) -- the reference's own, out of oracle/_ref. */
+typedef void (*lwso_batch_fn)(double *, double *, double *, double *, int *, double *, int, int, int, double);
+typedef void (*lwso_batch_q_fn)(double *, double *, double *, double *, int *, double *, int, int, int, int, double);
+void lwso_repeat_kernel(void *fn, int has_q, double *sr, double *si, double *wr, double *wi, int *wflag, double *amp,
+                        int F, int M, int L, int Q, double threshold, int sweeps) {
+    for (int i = 0; i < sweeps; ++i) {
+        if (has_q) ((lwso_batch_q_fn)fn)(sr, si, wr, wi, wflag, amp, F, M, L, Q, threshold);
+        else ((lwso_batch_fn)fn)(sr, si, wr, wi, wflag, amp, F, M, L, threshold);
+    }
+}
+void lwso_repeat_sweep(double *sr, double *si, const double *wr, const double *wi, const int *wflag, const double *amp,
+                       int F, int M, int L, int Q, int Qp, double threshold, int sweeps) {
+    for (int i = 0; i < sweeps; ++i)
+        sweep_canonical(sr, si, wr, wi, wflag, amp, F, M, LWSO_M0_ALL, L, Q, Qp, threshold, 2, (double)Q);
+}
+
 /* ---- online driver (lwslib.cpp:1424-1492) ---- */
 
 void lwso_online(double *sr, double *si, const double *wr, const double *wi, const int *wflag,

@@ -54,6 +54,8 @@ class Oracle:
         lib.lwso_amplitude.argtypes = [vp, vp, vp, ci]
         lib.lwso_sweep.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, ci, cd]
         lib.lwso_online.argtypes = [vp] * 12 + [ci] * 7 + [cd, vp, ci]
+        lib.lwso_repeat_kernel.argtypes = [vp, ci] + [vp] * 6 + [ci] * 4 + [cd, ci]
+        lib.lwso_repeat_sweep.argtypes = [vp] * 6 + [ci] * 5 + [cd, ci]
         lib.lwso_batch_lws.argtypes = [vp, vp, ci, ci, vp, ci, ci, ci, vp, ci, cd]
         lib.lwso_nofuture_lws.argtypes = [vp, vp, ci, ci, vp, ci, ci, ci, vp, ci, cd, ci]
         lib.lwso_online_lws.argtypes = [vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, cd, cd]

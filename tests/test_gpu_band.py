@@ -66,8 +66,7 @@ def test_band_engine_against_the_oracle_fp32(oracle, fsize, fshift, L, T, sweeps
 
 
 @pytest.mark.parametrize("fsize,fshift,L,T,sweeps", [(1024, 128, 5, 40, 5), (2048, 256, 5, 20, 3), (1024, 64, 5, 20, 3), (1024, 256, 8, 40, 4),
-                                                      (768, 256, 5, 40, 4), (1000, 200, 5, 40, 4), (1024, 384, 5, 40, 4), (1024, 256, 3, 40, 4),
-                                                      (400, 160, 5, 40, 4)])
+                                                      (768, 256, 5, 40, 4), (1000, 200, 5, 40, 4), (1024, 256, 3, 40, 4), (4200, 1050, 5, 20, 3)])
 def test_band_engine_fp64_is_the_reference_to_rounding(oracle, fsize, fshift, L, T, sweeps):
     """What the fp64 systolic engine does not take -- Q other than 2 and 4, table twiddles, general tensors, other stencil widths --
     on an fp64 plan: the reference's arithmetic type, a bin's sum in another order."""
@@ -80,8 +79,19 @@ def test_band_engine_fp64_is_the_reference_to_rounding(oracle, fsize, fshift, L,
     assert plan.last_kernel()["name"] == "band_fp64", plan.last_kernel()
     for b in range(2):
         ref = oracle.batch_lws(S[b], p.W, thr)
-        # (general tensors: their rows are twiddle images of row 0 to 1e-13 only, and the sweeps amplify that)
-        assert np.abs(out[b] - ref).max() < (1e-10 if fsize % fshift == 0 else 1e-8) * np.abs(ref).max(), np.abs(out[b] - ref).max() / np.abs(ref).max()
+        assert np.abs(out[b] - ref).max() < 1e-10 * np.abs(ref).max(), np.abs(out[b] - ref).max() / np.abs(ref).max()
+    plan.close()
+
+
+def test_fp64_plans_with_general_tensors_stay_on_the_order_exact_engine():
+    """The rows of the tensors create_weights builds for a hop that does not divide the frame (lws.pyx:164-181) are twiddle images of
+    row 0 to 1e-13 only (numpy's exp of an angle of up to N turns); the band engine works from row 0 and exact twiddles, which in fp32
+    is below rounding and in fp64 would be 1e-9 after a few sweeps -- not the reference's values: such fp64 plans are refused."""
+    p = lws_amd.lws(1024, 384)
+    S = spectrograms(1, 20, 513, seed=2)[0]
+    plan = _capi.Plan(513, p.W, precision="fp64")
+    plan.batch(S, [0.0, 0.0])
+    assert plan.last_kernel()["name"].startswith("generic"), plan.last_kernel()
     plan.close()
 
 

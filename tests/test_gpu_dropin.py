@@ -51,12 +51,12 @@ def test_cython_and_ctypes_bindings_agree():
 
 
 def test_generic_engine_fallback_warns_once():
-    """A shape only the generic engine serves (L = 9) says so once per plan;
+    """A shape only the generic engine serves (L = 12: beyond the band engine's stencils) says so once per plan;
     plans that asked for it (force_generic, fp64) stay quiet."""
     import warnings
     import lws_amd
     rng = np.random.default_rng(0)
-    p = lws_amd.lws(1000, 250, L=9, batch_iterations=3, batch_alpha=1.0)
+    p = lws_amd.lws(1000, 250, L=12, batch_iterations=3, batch_alpha=1.0)
     S = np.abs(rng.standard_normal((6, 501)) + 1j * rng.standard_normal((6, 501)))
     with pytest.warns(RuntimeWarning, match="generic engine"):
         p.batch_lws(S)

@@ -74,8 +74,10 @@ def test_two_waves_per_spectrogram_do_not_race(fsize, fshift, T, LA, iters, seed
     assert p.plan().last_kernel()["name"] == "online_lds_fp64"
     assert np.array_equal(out, ref)
     monkeypatch.delenv("LWS_ONLINE64_STRESS")
-    monkeypatch.setenv("LWS_ONLINE64_ONE_WAVE", "1")      # (read once per process: effective only if this is the first fp64 online call)
-    assert np.array_equal(lws_amd.lws(fsize, fshift, **kw).online_lws(S), ref)
+    monkeypatch.setenv("LWS_ONLINE64_ONE_WAVE", "1")      # (read on every launch)
+    p1 = lws_amd.lws(fsize, fshift, **kw)
+    assert np.array_equal(p1.online_lws(S), ref)
+    assert p1.plan().last_kernel()["name"] == "online_lds_fp64_1w"      # the one-wave kernel did run
 
 
 def test_frames_too_long_for_fp64_rows_stay_on_the_generic_engine():

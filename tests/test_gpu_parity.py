@@ -46,7 +46,8 @@ def test_fp64_wrappers_match_reference_goldens(tag):
     F = S.shape[1]
     plan = _capi.Plan(F, W, W_ai, W_af, precision="fp64")
     assert np.abs(plan.batch(S, thr) - g[f"batch_{tag}"]).max() < 1e-8
-    assert plan.last_kernel()["name"] in ("generic_skew_fp64", "systolic_fp64_q2", "systolic_fp64_q4")   # the latter for Q = 2, 4 (lws_sys64.hip)
+    # (Q = 2, 4: lws_sys64.hip; Q = 3, 8 -- summarised tensors -- the band engine in fp64; general tensors: the order-exact engine)
+    assert plan.last_kernel()["name"] in ("generic_skew_fp64", "systolic_fp64_q2", "systolic_fp64_q4", "band_fp64"), plan.last_kernel()
     assert np.abs(plan.batch(np.abs(S), thr) - g[f"batch_mag_{tag}"]).max() < 1e-8
     assert np.abs(plan.nofuture(S, thr[:2], wsel=_capi.LWS_W_AI) - g[f"nofuture_{tag}"]).max() < 1e-8
     qdiv = 2 * (F - 1) / fshift

@@ -108,7 +108,7 @@ def test_other_stencil_widths(oracle, fsize, fshift, L, T):
     assert name.startswith("systolic") and ("_l%d_" % L) in name, name
     pg = lws_amd.lws(fsize, fshift, L=8)
     pg.batch_lws(np.ones((3, fsize // 2 + 1)), thresholds=[0.0])
-    assert pg.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
+    assert pg.plan().last_kernel()["name"] == "band_fp32"       # (round 6: the band engine, tests/test_gpu_band.py; before: generic)
 
 
 @pytest.mark.parametrize("fsize,fshift,L,T", [(64, 16, 7, 70), (1024, 256, 7, 37), (1024, 512, 7, 66), (1000, 250, 7, 33), (512, 128, 6, 131),
@@ -123,7 +123,7 @@ def test_stencils_of_half_width_6_and_7(oracle, fsize, fshift, L, T):
     assert p.plan().last_kernel()["name"].startswith("systolic_q%d_l7_" % (fsize // fshift)), p.plan().last_kernel()
     pw = lws_amd.lws(2048, 512, L=7)
     pw.batch_lws(np.ones((3, 1025)), thresholds=[0.0])
-    assert pw.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
+    assert pw.plan().last_kernel()["name"] == "band_fp32"       # (round 6: the band engine; before: generic)
 
 
 @pytest.mark.parametrize("fsize,fshift,L,T", [(64, 16, 4, 70), (1024, 256, 4, 37), (1024, 512, 2, 37), (2048, 512, 4, 40),
@@ -277,14 +277,31 @@ def test_frames_that_end_inside_a_block(oracle, fsize, fshift, T):
 
 
 def test_what_still_needs_the_generic_engine():
-    """F - 1 below 24 with a frame end inside a block.  (F - 1 is always even: the library rejects an even number of bins
-    as the reference does, lws.pyx:223-224.)"""
+    """Round 6: the shapes of rounds 1-5's list -- more than 8 frames per stencil row, 5-8 frames per row above 513 bins, stencils of
+    half-width 8 and more, F - 1 below 24 with a frame end inside a block -- run on the band engine (lws_band.hip).  What is left:
+    stencils wider than 10 bins, more than 16 frames per row, frames of fewer than 17 bins, weights without create_weights'
+    twiddle structure.  (F - 1 is always even: the library rejects an even number of bins as the reference does, lws.pyx:223-224.)"""
     with pytest.raises(ValueError):
         _capi.Plan(502, lws_amd.lws(1000, 250).W).batch(np.ones((4, 502), dtype=np.complex128), [0.0])
-    for fsize, fshift in ((44, 11), (36, 9)):
-        p = lws_amd.lws(fsize, fshift)
+    for fsize, fshift, L in ((44, 11, 5), (36, 9, 5), (2048, 256, 5), (1024, 64, 5), (1024, 256, 8)):
+        p = lws_amd.lws(fsize, fshift, L=L)
         p.batch_lws(np.ones((4, fsize // 2 + 1)), thresholds=[0.0])
-        assert p.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32"), (fsize, fshift)
+        assert p.plan().last_kernel()["name"] == "band_fp32", (fsize, fshift, L)
+    import warnings
+    for fsize, fshift, L in ((1024, 256, 11), (1088, 64, 5), (28, 7, 5)):
+        p = lws_amd.lws(fsize, fshift, L=L)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            p.batch_lws(np.ones((4, fsize // 2 + 1)), thresholds=[0.0])
+        assert p.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32"), (fsize, fshift, L)
+    rng = np.random.default_rng(0)
+    W = rng.standard_normal((4, 4, 6)) + 1j * rng.standard_normal((4, 4, 6))     # no twiddle structure
+    plan = _capi.Plan(513, W)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plan.batch(np.ones((4, 513), dtype=np.complex128), [0.0])
+    assert plan.last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32")
+    plan.close()
 
 
 # ----------------------------------------------------------------------------- several workgroups per spectrogram

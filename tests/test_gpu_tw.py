@@ -141,12 +141,14 @@ def test_narrower_stencils(oracle, L):
 
 
 def test_what_the_table_builds_do_not_take():
-    """More than 8 frames per stencil row, Q >= 5 above 513 bins, L > 5: generic engine."""
+    """More than 8 frames per stencil row, Q >= 5 above 513 bins, L > 5 with table twiddles: the band engine (round 6; generic before)."""
+    import warnings
     for fsize, fshift, L in ((1008, 112, 5), (2000, 400, 5), (400, 160, 7), (1000, 200, 6)):
         p = lws_amd.lws(fsize, fshift, L=L)
-        with pytest.warns(RuntimeWarning):
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                      # (a plan on the generic engine warns)
             p.batch_lws(np.ones((4, fsize // 2 + 1)), thresholds=[0.0])
-        assert p.plan().last_kernel()["name"] in ("generic_fp32", "generic_skew_fp32"), (fsize, fshift)
+        assert p.plan().last_kernel()["name"] == "band_fp32", (fsize, fshift)
 
 
 @pytest.mark.parametrize("fsize,fshift,B,T,iters", [(400, 160, 3, 300, 30), (1000, 400, 2, 200, 30), (768, 256, 5, 260, 16), (2048, 768, 3, 150, 20),

@@ -16,6 +16,7 @@ LGKM = re.compile(r"^\s*(ds_\w+|s_load_\w+|s_buffer_load_\w+|s_memtime|s_memreal
 def check(lines):
     """Returns (number of counted waits found, smallest margin = reads that follow the last store beyond the count)."""
     found, margin, worst = 0, None, 0
+    counts = {}
     kernel = None
     for i, ln in enumerate(lines):
         m = re.match(r"^(_ZN3lws\S*k_online\S*):", ln)
@@ -29,6 +30,10 @@ def check(lines):
             continue            # (the compiler's own partial waits)
         K = int(m.group(1))
         found += 1
+        # the counts the source asks for (lws_online.hip: tap waves 5 / 3 reads of early cells, projection wave 7, 5 in the BIG variant);
+        # any other count in front of a barrier is a wait this checker was not written for
+        assert K in (3, 5, 7), "%s: unexpected `s_waitcnt lgkmcnt(%d); s_barrier` (line %d)" % (kernel, K, i + 1)
+        counts[K] = counts.get(K, 0) + 1
         assert kernel and "k_online4" in kernel, (kernel, i)
         young = []
         j = i - 1
@@ -58,6 +63,7 @@ def check(lines):
         assert left is not None and n + left <= 15, "%s: %d LDS / scalar-memory operations may be in flight at line %d (4-bit counter)" % (kernel, n + (left or 0), i + 1)
         worst = max(worst, n + left)
         margin = len(young) - K if margin is None else min(margin, len(young) - K)
+    check.counts = counts
     return found, margin, worst
 
 
@@ -65,7 +71,9 @@ def main():
     lines = open(sys.argv[1]).read().split("\n")
     found, margin, worst = check(lines)
     assert found >= 6, "expected the counted waits of k_online4 (two half-steps per instantiation), found %d" % found
-    print("check_online_isa: %d counted waits, each followed by its stores' completion; smallest margin %d reads; at most %d operations in flight" % (found, margin, worst))
+    assert all(check.counts.get(k, 0) > 0 for k in (3, 5, 7)), "a kind of counted wait is missing from the assembly: %r" % (check.counts,)
+    print("check_online_isa: %d counted waits %r, each followed by its stores' completion; smallest margin %d reads; at most %d operations in flight"
+          % (found, check.counts, margin, worst))
 
 
 if __name__ == "__main__":
