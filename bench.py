@@ -252,7 +252,9 @@ def device_magnitudes(torch, dev, B, T, F, first_seed):
 
 
 def physical_cores():
-    """Physical cores among the ones this process may run on (hyper-threads share a core's FPU: one spectrogram per core)."""
+    """(hardware threads this process may run on, physical cores among them, CPUs the container's quota allows).
+    Hyper-threads share a core's FPU: one spectrogram per core; a cgroup CPU quota (cpu.max: the GPU boxes of this pool give a
+    container 16 CPUs of their 256 hardware threads) caps what any number of threads can use."""
     allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     seen = set()
     for c in allowed:
@@ -261,7 +263,19 @@ def physical_cores():
                 seen.add(f.read().strip())
         except OSError:
             seen.add(str(c))
-    return len(allowed), max(1, len(seen))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                    # cgroup v2: "<quota us> <period us>" or "max <period>"
+            q, per = f.read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # v1
+                q, per = float(f.read()), float(g.read())
+                quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            quota = None
+    return len(allowed), max(1, len(seen)), quota
 
 
 def cpu_baseline(W, T, F, iters, budget_s=12.0, plan=None):
@@ -279,7 +293,8 @@ def cpu_baseline(W, T, F, iters, budget_s=12.0, plan=None):
     use_ref = RefLib.available()
     rl = RefLib() if use_ref else None
     L, Q = W.shape[2] - 1, W.shape[1]
-    nthreads, ncores = physical_cores()
+    nthreads, pcores, quota = physical_cores()
+    ncores = max(1, min(pcores, int(quota) if quota else pcores))     # threads of the all-cores figure: what can actually run at once
     wr, wi, wf = split_weights(W)
 
     def prepare(S):
@@ -329,20 +344,50 @@ def cpu_baseline(W, T, F, iters, budget_s=12.0, plan=None):
         wall = max(ends) - t0 if wall is None else min(wall, max(ends) - t0)
     out = {"value": single, "unit": "bin*iter/s", "cores": 1, "kind": "reference" if use_ref else "port",
            "sample": "1 spectrogram %dx%d, %d dense sweeps, fp64, single thread" % (T, F, sweeps),
-           "all_cores_value": ncores * T * F * sweeps / wall, "all_cores": ncores, "hw_threads": nthreads}
+           "all_cores_value": ncores * T * F * sweeps / wall, "all_cores": ncores, "hw_threads": nthreads, "physical_cores": pcores,
+           "cpu_quota": quota}
     if plan is not None:
+        # three spectrograms (the tail of such a comparison -- bins whose weighted sum nearly cancels, where fp32 rounding decides the
+        # phase -- differs from input to input: 0 to ~60 bins of 256 500), aggregated
+        NP = 3
         rng = np.random.default_rng(20260929)
-        S = (synth_magnitudes(1, T, F, 3)[0] * np.exp(2j * np.pi * rng.random((T, F)))).astype(np.complex64).astype(np.complex128)
+        S = np.stack([(synth_magnitudes(1, T, F, 3 + i)[0] * np.exp(2j * np.pi * rng.random((T, F)))).astype(np.complex64).astype(np.complex128) for i in range(NP)])
         got = plan.batch(S, np.zeros(iters))
-        er, ei, amp = prepare(S)
-        sweep(er, ei, amp, iters)
-        ref = (er + 1j * ei)[Q - 1:Q - 1 + T, L:L + F]
-        d = np.abs(got - ref)
+        kname = plan.last_kernel()["name"]
+        ref = np.empty_like(S)
+        for i in range(NP):
+            er, ei, amp = prepare(S[i])
+            sweep(er, ei, amp, iters)
+            ref[i] = (er + 1j * ei)[Q - 1:Q - 1 + T, L:L + F]
         mean = float(np.mean(np.abs(S)))
-        out["parity"] = {"what": "%dx%d, %d dense sweeps from random phases: timed plan (%s) vs %s, measured in this run"
-                                 % (T, F, iters, plan.last_kernel()["name"], "oracle/_ref LWSQ4" if use_ref and Q == 4 else ("oracle/_ref" if use_ref else "oracle")),
-                         "rel_l2": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "median_over_mean": float(np.median(d) / mean),
-                         "p999_over_mean": float(np.quantile(d, 0.999) / mean), "max_over_mean": float(d.max() / mean)}
+
+        def figures(x):
+            d = np.abs(x - ref)
+            return {"rel_l2": float(np.linalg.norm(x - ref) / np.linalg.norm(ref)), "median_over_mean": float(np.median(d) / mean),
+                    "p999_over_mean": float(np.quantile(d, 0.999) / mean), "max_over_mean": float(d.max() / mean),
+                    "bins_off_by_1e-2_mean": int((d > 1e-2 * mean).sum()), "bins": int(d.size)}
+        out["parity"] = figures(got)
+        out["parity"]["what"] = ("%d x %dx%d, %d dense sweeps from random phases: timed plan (%s) vs %s, measured in this run"
+                                 % (NP, T, F, iters, kname, "oracle/_ref LWSQ4" if use_ref and Q == 4 else ("oracle/_ref" if use_ref else "oracle")))
+        try:
+            # the same input through the order-exact fp32 engine (the reference's own order of operations in fp32): what fp32 state costs
+            # whatever the kernel -- the figure the timed kernel's is to be read against
+            from lws_amd import _capi
+            gen = _capi.Plan(F, W, force_generic=True)
+            out["parity"]["order_exact_fp32"] = figures(gen.batch(S, np.zeros(iters)))
+            gen.close()
+        except Exception as e:   # (the comparison is context, not the measurement)
+            out["parity"]["order_exact_fp32"] = {"error": str(e)[:100]}
+        if use_ref:
+            # ... and how far the fp64 reference is from ITSELF on this input: the same sweeps in the oracle's canonical form (LWSanyQ's
+            # grouping instead of LWSQ4's, lwslib.cpp:153-373), a re-association of fp64 sums
+            alt = np.empty_like(S)
+            for i in range(NP):
+                er2, ei2, amp2 = prepare(S[i])
+                orc.lib.lwso_repeat_sweep(er2.ctypes.data, ei2.ctypes.data, wr.ctypes.data, wi.ctypes.data, wfi.ctypes.data, amp2.ctypes.data,
+                                          F, T, L, Q, W.shape[0], 0.0, iters)
+                alt[i] = (er2 + 1j * ei2)[Q - 1:Q - 1 + T, L:L + F]
+            out["parity"]["fp64_reassociation"] = figures(alt)
     return out
 
 
@@ -384,7 +429,7 @@ def _source_hashes():
     import hashlib
     out = {}
     d = os.path.join(ROOT, "lws_amd", "csrc")
-    for fn in ("lws_systolic.hip", "lws_online.hip", "lws_nofuture.hip", "lws_common.h"):
+    for fn in ("lws_systolic.hip", "lws_online.hip", "lws_nofuture.hip", "lws_common.h", "lws_band.hip", "lws_band_core.h"):
         try:
             out[fn] = hashlib.sha1(open(os.path.join(d, fn), "rb").read()).hexdigest()
         except OSError:
@@ -412,7 +457,7 @@ def load_traffic(kname, config, stage=None):
     recorded for another kernel than the one that just ran is refused (traffic = null, the reason in traffic_source); one whose
     kernel source has changed since is returned marked STALE."""
     refused = None
-    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
             continue
@@ -839,12 +884,20 @@ def main():
         par = (cpu or {}).pop("parity", None) if cpu else None
         if par:
             full["parity_measured_in_this_run"] = par
-            notes = ("measured now, %s: rel-L2 %.2e, median %.1e, p99.9 %.1e, max %.1e of mean|S| (bars: 1e-3 / 1e-6 / 1e-3); timed zero-phase start "
-                     "(ill-conditioned): magnitudes 1e-6, consistency 0.05 dB (tests)" % (par["what"], par["rel_l2"], par["median_over_mean"], par["p999_over_mean"], par["max_over_mean"]))
+            ra, oe = par.get("fp64_reassociation") or {}, par.get("order_exact_fp32") or {}
+            # (a compact copy for the line; `tail` = bins off by more than 1e-2 of mean|S| -- near-cancelling sums -- and, beside the timed
+            #  kernel's figures, the order-exact fp32 engine's on the same input: what fp32 state costs whatever the kernel)
+            also_parity = {"rel_l2": par["rel_l2"], "median": par["median_over_mean"], "p999": par["p999_over_mean"], "tail": par["bins_off_by_1e-2_mean"],
+                           "bins": par["bins"], "order_exact_fp32_rel_l2": oe.get("rel_l2"), "order_exact_fp32_tail": oe.get("bins_off_by_1e-2_mean"),
+                           "fp64_ref_vs_itself_rel_l2": ra.get("rel_l2")}
+            notes = ("parity measured in this run (also.parity): 3 x %dx%d, %d dense sweeps from random phases, timed plan vs %s, in units of mean|S|; "
+                     "bars 1e-3 / 1e-6 / 1e-3" % (min(T, 500), F, iters, "oracle/_ref" if cpu.get("kind") == "reference" else "oracle"))
         else:
             notes = "parity of this arithmetic path: tests/test_gpu_parity.py (not measured in this run: no CPU leg)"
         also = {}
         try:
+            if par:
+                also["parity"] = {k: (_sig(v, 3) if isinstance(v, float) else v) for k, v in also_parity.items()}
             c = extra.get("configs") or {}
             if "systolic" in (c.get("2-fp64") or {}):
                 also["fp64_ms"] = float(c["2-fp64"]["systolic"]["kernel_ms"])
@@ -856,6 +909,8 @@ def main():
                 also["fp64_config3_ms"] = float(c["3-fp64"]["total_wall_ms"])
             if "wall_ms" in (c.get("host_api") or {}):
                 also["host_api_ms"] = float(c["host_api"]["wall_ms"])
+            if "kernel_ps_per_bin_sweep" in (c.get("2-q8w") or {}):      # lws(2048,256) on the band engine (generic engine: 235)
+                also["q8w_ps_per_bin_sweep"] = float(c["2-q8w"]["kernel_ps_per_bin_sweep"])
         except Exception:
             also = {}
         print(final_line(head, world, args.steps, args.warmup, p.fsize, roof, cpu, extra_file, notes, also))

@@ -22,7 +22,7 @@ def _canned(world):
                                 "systolic_q4_l5_hann_with_a_rather_long_kernel_name", 1.0, "valu")
     roof["frac_of_measured_copy"] = 0.654321
     cpu = {"value": 3.68e7, "unit": "bin*iter/s", "cores": 1, "kind": "reference", "sample": "1 spectrogram 500x513, 23 dense sweeps, fp64, single thread",
-           "all_cores_value": 3.66e9, "all_cores": 128, "hw_threads": 256}
+           "all_cores_value": 5.5e8, "all_cores": 16, "hw_threads": 256, "physical_cores": 128, "cpu_quota": 16.0}
     return head, roof, cpu
 
 
@@ -43,6 +43,21 @@ def test_final_line_is_compact_strict_json():
         assert math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-4)
         assert math.isclose(r["achieved"], 131.328e9 / 32.4123456e-3 / 1e9, rel_tol=1e-4)
         assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "reference"
+
+
+def test_the_line_keeps_its_measured_parity():
+    """Round 6: the parity of the timed arithmetic path is measured in the run (cpu_baseline leg) and travels in `also.parity`;
+    with realistic field sizes nothing is dropped to stay under the limit."""
+    head, roof, cpu = _canned(1)
+    also = {"parity": {"rel_l2": 1.26e-3, "median": 2.0e-7, "p999": 3.6e-4, "tail": 57, "bins": 769500, "order_exact_fp32_rel_l2": 4.1e-4, "order_exact_fp32_tail": 41, "fp64_ref_vs_itself_rel_l2": 1.7e-12},
+            "fp64_ms": 97.123456, "fp64_kernel": "systolic_fp64_q4", "fp64_generic_ms": 836.2, "config3_ms": 73.1, "fp64_config3_ms": 402.3, "host_api_ms": 49.1,
+            "q8w_ps_per_bin_sweep": 43.4}
+    notes = ("parity measured in this run (also.parity): 3 x 500x513, 100 dense sweeps from random phases, timed plan vs oracle/_ref, in units of mean|S|; "
+             "bars 1e-3 / 1e-6 / 1e-3")
+    txt = bench.final_line(head, 1, 20, 5, 1024, roof, cpu, "gpurun_out/bench_extra.json", notes, also)
+    d = json.loads(txt)
+    assert len(txt) < bench.MAX_LINE and d["notes"] == notes and d["also"]["parity"]["tail"] == 57 and d["cpu_baseline"]["cpu_quota"] == 16.0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["roofline_axis"] == "hbm" and d["roofline"]["limiter"] == "valu"
 
 
 def test_cpu_baseline_times_only_the_sweeps_of_its_threads():

@@ -38,18 +38,19 @@ for sub, suffix, what in (("trace", "", "python bench.py --steps 3 --warmup 1 --
         for n, c, s_, a, mn, mx in rows:
             w.writerow([n[:200], c, round(s_ / 1e3, 3), round(a / 1e3, 3), round(mn / 1e3, 3), round(mx / 1e3, 3), round(100 * s_ / tot, 3)])
 
-SHAPES = {"2": (256, 500, 513, 100, 20.0), "2-T1024": (256, 1024, 513, 100, 20.0), "2-q2": (256, 500, 513, 100, 20.0), "2-q8": (256, 500, 513, 100, 20.0), "2-f501": (256, 500, 501, 100, 20.0), "2-f257": (512, 500, 257, 100, 20.0), "2-q3": (256, 500, 385, 100, 20.0), "2-frac": (256, 500, 513, 100, 20.0), "2-speech": (512, 500, 201, 100, 20.0), "2-q5": (256, 500, 501, 40, 20.0), "4shard": (1024, 500, 513, 100, 20.0),
+SHAPES = {"2": (256, 500, 513, 100, 20.0), "2-T1024": (256, 1024, 513, 100, 20.0), "2-q2": (256, 500, 513, 100, 20.0), "2-q8": (256, 500, 513, 100, 20.0), "2-f501": (256, 500, 501, 100, 20.0), "2-f257": (512, 500, 257, 100, 20.0), "2-q3": (256, 500, 385, 100, 20.0), "2-frac": (256, 500, 513, 100, 20.0), "2-speech": (512, 500, 201, 100, 20.0), "2-q5": (256, 500, 501, 40, 20.0), "2-q8w": (256, 500, 1025, 20, 20.0), "2-q16": (256, 500, 513, 10, 20.0), "2-l8": (256, 500, 513, 40, 20.0), "4shard": (1024, 500, 513, 100, 20.0),
           "5": (64, 56250, 1025, 200, 20.0), "5-f16": (64, 56250, 1025, 200, 10.0)}
 res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE -- python bench.py --config <cfg> "
                "--no-extras --steps 1 --warmup 1 --no-cpu-baseline (config 3: --extras 3); counters are KiB per dispatch. "
                "MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e. reports 1/2 of the "
                "bytes -> doubled here; WRITE_SIZE is exact.  hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) * 1024 of the LAST "
-               "launch of the update kernel (the timed step; the warm-up launch of the big shapes runs 3 sweeps only).",
+               "launch of the update kernel (the timed step; the warm-up launch of the big shapes runs 3 sweeps only); the band engine launches "
+               "once per pass of its sweep slots: its entry is the sum over the launches of the timed step (launches_per_step).",
        "configs": {}}
 import hashlib
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 res["_sources"] = {}
-for fn in ("lws_systolic.hip", "lws_online.hip", "lws_nofuture.hip", "lws_common.h"):   # what bench.py's load_traffic compares with
+for fn in ("lws_systolic.hip", "lws_online.hip", "lws_nofuture.hip", "lws_common.h", "lws_band.hip", "lws_band_core.h"):   # what bench.py's load_traffic compares with
     try:
         res["_sources"][fn] = hashlib.sha1(open(os.path.join(root, "lws_amd", "csrc", fn), "rb").read()).hexdigest()
     except OSError:
@@ -85,12 +86,17 @@ for cfg in list(SHAPES) + ["3"]:
     for n, d in per.items():
         key = None
         if "k_systolic" in n: key = "batch"
+        elif "k_band<" in n: key = "batch"
         elif "k_nofuture" in n: key = "nofuture"
         elif "k_online" in n: key = "online"
         if key is None or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
             continue
         f, w = d["FETCH_SIZE"][-1], d["WRITE_SIZE"][-1]
-        ent[key] = {"engine_kernel": engine_names(cfg).get(key), "kernel": n[:160], "launches_seen": len(d["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
+        per_step = 1
+        if "k_band<" in n:   # one launch per pass of NS sweeps: the step (bench: --steps 1 --warmup 1) is the second half of the launches seen
+            per_step = max(1, len(d["FETCH_SIZE"]) // 2)
+            f, w = sum(d["FETCH_SIZE"][-per_step:]), sum(d["WRITE_SIZE"][-per_step:])
+        ent[key] = {"launches_per_step": per_step, "engine_kernel": engine_names(cfg).get(key), "kernel": n[:160], "launches_seen": len(d["FETCH_SIZE"]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                     "hbm_bytes_per_launch": (2 * f + w) * 1024}
     if cfg in SHAPES and "batch" in ent:
         B, T, F, it, bpb = SHAPES[cfg]
