@@ -658,10 +658,24 @@ def main():
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # a rank that cannot join (a GPU that does not open, a peer that died before the rendezvous) must end the job with a
+        # non-zero exit code in bounded time and say who it is: the rendezvous has a deadline (LWS_BENCH_INIT_TIMEOUT seconds,
+        # default 180), a failure is reported with the rank, and the launcher -- self_launch below, or torch.distributed.run --
+        # stops the other ranks when one exits non-zero.  (LWS_BENCH_FAIL_RANK=<r>: rank r fails here on purpose -- tests.)
+        import datetime
+        try:
+            if os.environ.get("LWS_BENCH_FAIL_RANK") == str(rank):
+                raise RuntimeError("LWS_BENCH_FAIL_RANK=%d: failing before the rendezvous (test hook)" % rank)
+            deadline = datetime.timedelta(seconds=int(os.environ.get("LWS_BENCH_INIT_TIMEOUT", "180")))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=deadline)
+            else:
+                dist.init_process_group(backend, timeout=deadline)
+        except Exception as e:
+            print("bench.py: rank %d of %d (GPU %d): init_process_group(%s) failed: %s: %s" % (rank, world, local_rank, backend, type(e).__name__, str(e)[:300]),
+                  file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(3)       # (not sys.exit: a half-initialised process group must not get to run its destructors against dead peers)
     from lws_amd.dist import reduce_residual, shard_range
     stream = torch.cuda.current_stream().cuda_stream
     have_f16 = hasattr(lws_amd._capi, "LWS_STORAGE_FP16")
@@ -714,10 +728,14 @@ def main():
             launches += info["launches"]
         sync_all()
         dt = time.perf_counter() - t0
+        rank_ms = None
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            # the step time of the job is the slowest rank's; every rank's own is kept too (extra: a straggler shows in min / max)
+            mine = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            rank_ms = [1e3 * float(x.item()) / steps for x in every]
+            dt = max(float(x.item()) for x in every)
         units = float(B) * T * F * iters
         if schedule == "dense":
             active = units
@@ -732,6 +750,7 @@ def main():
             "batch_per_gpu": B, "frames": T, "bins": F, "iters": iters, "schedule": schedule, "storage": storage,
             "data": "synthetic Rayleigh magnitudes, %s, zero phase" % gen,
             "steps": steps, "ms_per_step": 1e3 * dt / steps, "value": units * world / (dt / steps), "kernel_ps_per_bin_sweep": 1e9 * k_ms / units,
+            "rank_ms_per_step": ({"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms} if rank_ms else None),
             "active_value": active * world / (dt / steps), "effective_sweeps": active / (float(B) * T * F),
             # bound: the vector ALU (66 % busy, HBM at 0.16x the algorithmic bytes: profiles/r02_pmc_sq_counters.json)
             "roofline": roofline_block(alg, k_ms, active, p.W, traffic, tsrc, info["name"], launches / steps,
@@ -760,6 +779,8 @@ def main():
     B, T, F, iters = head["batch_per_gpu"], head["frames"], head["bins"], head["iters"]
     roof = dict(head["roofline"])
     extra = {"headline_checks": head.get("checks")}
+    if head.get("rank_ms_per_step"):
+        extra["rank_ms_per_step"] = head["rank_ms_per_step"]     # every rank's own step time: a straggler shows as min / max
     if pinned:
         extra["host_affinity_rank0"] = pinned
 

@@ -15,6 +15,8 @@
 #include <type_traits>
 #include "lws_systolic.h"
 #include "lws_sys64.h"
+#include <sched.h>
+#include <cstring>
 #include "lws_band.h"
 #include "lws_online.h"
 #include "lws_online64.h"
@@ -183,6 +185,7 @@ struct lws_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *host_pool = nullptr;     // HostWorkers of the host-array entry points (kept between calls: 32 thread starts cost ~1 ms)
     int host_pool_n = 0;
+    int host_threads = 0;          // > 0: the conversion threads this plan may use (lws_multi_*: an even share of the usable CPUs per device)
     hipEvent_t ev_after_load = nullptr;   // if set: recorded by run_pipeline between its light first kernels and the update kernels
     // The plan's scratch (state, amp, thresholds, the skewed layouts, progress counters) is shared by all of its calls.  A *_dev
     // call only enqueues work; the next call of the plan -- on another stream, or a host-array call on the pipeline's private
@@ -655,6 +658,38 @@ void widen_c64(const float *dev, const double *orig, double *out, size_t lo, siz
     }
 }
 
+}  // namespace
+namespace lws {
+int usable_cpus() {
+    static const int n = [] {
+        int cpus = (int)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = std::max(1, CPU_COUNT(&set));
+        // cgroup v2: "<quota us> <period us>" or "max <period us>"; v1: cpu.cfs_quota_us / cpu.cfs_period_us
+        double quota = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            double per = 0;
+            if (fscanf(f, "%31s %lf", q, &per) == 2 && per > 0 && strcmp(q, "max") != 0) quota = atof(q) / per;
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            double q = 0, per = 0;
+            if (fscanf(g, "%lf", &q) == 1 && q > 0) {
+                if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                    if (fscanf(h, "%lf", &per) == 1 && per > 0) quota = q / per;
+                    fclose(h);
+                }
+            }
+            fclose(g);
+        }
+        if (quota >= 1.0) cpus = std::min(cpus, (int)quota);
+        return std::max(1, cpus);
+    }();
+    return n;
+}
+}  // namespace lws
+void lws_plan_set_host_threads(lws_plan *p, int n) { if (p) p->host_threads = n; }
+namespace {
 int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
@@ -732,7 +767,9 @@ int run_host_pipelined(lws_plan *p, const double *S_in, double *S_out, int B, in
     if (Bc < B && Bc >= 2 && !whole_device && env_int("LWS_HOST_HALF_FIRST", 1)) cs.push_back(Bc / 2);
     while (cs.back() < B) cs.push_back(std::min(B, cs.back() + Bc));
     const int nch = (int)cs.size() - 1;
-    int nthreads = env_int("LWS_HOST_THREADS", (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
+    // conversion threads: up to 32 (more gain nothing: the passes are memory-bound), at most the CPUs the process can use at once
+    // (lws_multi_* plans: their share of them -- eight plans of 32 threads on a 16-CPU quota only fight each other)
+    int nthreads = env_int("LWS_HOST_THREADS", std::min(32, p->host_threads > 0 ? p->host_threads : lws::usable_cpus()));
     if (total < ((size_t)1 << 20)) nthreads = 1;
     nthreads = std::max(1, std::min(nthreads, 64));
     HIP_TRY(hipSetDevice(p->device));

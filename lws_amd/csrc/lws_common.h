@@ -25,6 +25,10 @@ inline void attr_done(std::atomic<unsigned long long> &done, int dev) {
 // records the text lws_last_error() returns and passes `code` through (lws_capi.hip)
 int set_error(int code, const char *fmt, ...);
 
+// CPUs this process can actually use at once: the CPUs it may run on, capped by the container's CPU quota (cgroup cpu.max -- the GPU
+// boxes of this pool give a container 16 CPUs of their 256 hardware threads; std::thread::hardware_concurrency() does not see that).
+int usable_cpus();
+
 template <typename real> struct cx;
 template <> struct cx<float>  { using type = float2; };
 template <> struct cx<double> { using type = double2; };

@@ -20,6 +20,8 @@ struct lws_multi_plan {
     int F = 0;
 };
 
+void lws_plan_set_host_threads(lws_plan *p, int n);   // lws_capi.hip (internal)
+
 namespace {
 
 // contiguous block [lo, hi) of n items owned by shard i of k; blocks differ by at most one item (lws_amd/dist.py)
@@ -75,6 +77,9 @@ int lws_multi_plan_create(lws_multi_plan **out, int ndev, const int *devices, in
         mp->plans.push_back(p);
         mp->devices.push_back(dev);
     }
+    // the shards run side by side, each with its own conversion threads (host-array entry points): an even share of the CPUs this
+    // process can use per device, not 32 each
+    for (lws_plan *p : mp->plans) lws_plan_set_host_threads(p, std::max(2, lws::usable_cpus() / ndev));
     *out = mp;
     return LWS_OK;
 }

@@ -150,6 +150,26 @@ def test_bench_py_starts_its_own_ranks():
     assert np.isclose(d["value"], 2.0 * B * T * F * it / (d["ms_per_step"] * 1e-3), rtol=1e-5)
     full = json.load(open(os.path.join(ROOT, d["extra_file"])))
     assert np.isfinite(full["extra"]["residual_db_after"]) and full["extra"]["headline_checks"]["max_rel_magnitude_error"] < 1e-6
+    # every rank's own step time travels in the extra file (a straggler shows as min / max); the line's is the slowest rank's
+    rk = full["extra"]["rank_ms_per_step"]
+    assert len(rk["all"]) == 2 and rk["min"] <= rk["max"] and np.isclose(rk["max"], d["ms_per_step"], rtol=1e-6)
+
+
+def test_a_rank_that_cannot_join_ends_the_job_and_is_named():
+    """`python bench.py --gpus 2` with a rank that fails before the rendezvous (LWS_BENCH_FAIL_RANK, the stand-in for a GPU that does
+    not open or a peer that died): the job must end with a non-zero exit code in bounded time -- not hang in init_process_group --
+    and stderr must say which rank it was."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT", "RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env.update(LWS_BENCH_BACKEND="gloo", LWS_BENCH_FAIL_RANK="1", LWS_BENCH_INIT_TIMEOUT="60")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"]
+    t0 = time.time()
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and time.time() - t0 < 120, (out.returncode, time.time() - t0)
+    assert "rank 1 of 2" in out.stderr and "init_process_group" in out.stderr, out.stderr[-2000:]
+    assert "rank 1 exited with code" in out.stderr                      # the launcher names it too, and stops rank 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_c_abi_residual_all_reduce_over_rccl():
