@@ -1,7 +1,8 @@
 """CPU: pins the fp64 C restatement (oracle/lws_oracle.c) against the reference.
 
 Sources of truth: (a) golden vectors generated from the reference (tests/golden/make_golden.py),
-(b) oracle/_ref/liblws_ref.so = the reference's lwslib.cpp compiled in place (skipped if absent).
+(b) oracle/_ref/liblws_ref.so = the reference's lwslib.cpp compiled in place (skipped if absent).  That library is git-ignored but
+    travels to the GPU box with the snapshot -- for bench.py's cpu_baseline leg only (kind: "reference"); no -m gpu test loads it.
 Tolerance: the restatement re-associates fp64 sums (one canonical kernel instead of the reference's
 Q2/Q4 specialisations), and a bin whose weighted sum nearly cancels amplifies that by 1/|acc|; the
 reference's own Q2/Q4 kernels differ from its anyQ kernels by up to 1e-9 in the same way
