@@ -11,7 +11,7 @@
 // nls, slots -- is chosen per call (band_plan) from the frame length, Q and what the LDS holds.
 //
 // The step is checked on the CPU: tests/band_emul.cpp compiles lws_band_core.h with g++ and tests/test_band_model.py compares
-// it with the oracle (Q = 2..16, L = 3..10, fractional Q, every geometry parameter).
+// it with the fp64 CPU restatement of the reference (Q = 2..16, L = 3..10, fractional Q, every geometry parameter).
 #include "lws_band.h"
 
 #include <cstdlib>

@@ -1,7 +1,7 @@
 // lws_band_core.h -- the per-lane step of the band engine (lws_band.hip).
 //
 // The same text compiles for the GPU (hipcc: every function __device__) and for a host-side emulation (g++:
-// tests/band_emul.cpp steps through the schedule lane by lane on the CPU and is compared with the oracle by
+// tests/band_emul.cpp steps through the schedule lane by lane on the CPU and is compared with the fp64 CPU restatement of the reference by
 // tests/test_band_model.py), so the schedule -- ring ages, Hermitian images, frame wrap-around -- is debugged without a GPU.
 //
 // What a step computes is one bin of LWSanyQ / LWSfractionalQ (lwslib.cpp:283-467) per lane; the schedule is the fp64 systolic

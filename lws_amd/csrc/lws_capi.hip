@@ -1430,7 +1430,7 @@ int lws_debug_sys64_layout(int F, int T, int Q, long *out) { return out && lws::
 // (complex64 + float32, or complex128 + float64) -- with the thresholds taken as they are (not scaled by mean|S|).  State and target
 // magnitudes are independent here, which no public entry point allows: a frame whose targets are zero is never updated, so a test can
 // freeze the first m0 frames at values of its choice and compare what the PRODUCTION kernel makes of the frames after them with the
-// oracle on the same buffers (tests/test_gpu_teacher.py).  stage: 0 batch, 1 no-future, 2 online.  The state is updated in place.
+// CPU restatement of the reference on the same buffers (tests/test_gpu_teacher.py).  stage: 0 batch, 1 no-future, 2 online.  The state is updated in place.
 int lws_debug_stage_ext(lws_plan *p, int stage, int wsel, void *state_ext, const void *amp_ext, int B, int T, const double *thresholds, int iters,
                         int LA, double qdiv) {
     int rc = check_common(p, B, T, thresholds, iters);
