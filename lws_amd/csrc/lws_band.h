@@ -11,7 +11,7 @@ namespace lws {
 // sweep slots per workgroup, the instantiation (LT >= L, QT >= Q), the scratch it needs.
 struct BandPlan {
     band::Geom g;
-    int NS, LT, QT, Pt, s, L, chunk;
+    int NS, LT, QT, Pt, s, L, chunk, helpers;   // helpers: helper waves per sweep slot (exact builds: lws_band_core.h, Split)
     bool fp64;
     size_t state_bytes, amp_bytes;   // scratch: the time-skewed state of `chunk` spectrograms; the magnitudes
 };

@@ -39,9 +39,11 @@ template <typename real> struct BArgs {
 // LDS writes of this step complete, then everybody meets.  (Not __syncthreads(): that waits for the global prefetches too.)
 #define BAND_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <typename real, int LT, int QT, bool FIRST, bool EXACT>
+// One wave's share of a pass.  NH > 0: the slot's frame offsets are shared out between a main wave and NH helper waves a step ahead of it
+// (lws_band_core.h: Lane, Split); `part` = 0 main, 1 .. NH the helpers.
+template <typename real, int LT, int QT, bool FIRST, bool EXACT, bool HELP, int RLO, int RHI, int NHELP>
 __device__ __forceinline__ void band_wave(const BArgs<real> &a, typename cx<real>::type *ring, const typename cx<real>::type *wt, const typename cx<real>::type *tw,
-                                          typename cx<real>::type *G, const real *A, int s, int lane) {
+                                          typename cx<real>::type *mail, int nh, int h, typename cx<real>::type *G, const real *A, int s, int lane) {
     using C = typename cx<real>::type;
     Env<real, C> e;
     e.g = a.g;
@@ -49,54 +51,83 @@ __device__ __forceinline__ void band_wave(const BArgs<real> &a, typename cx<real
     e.ring_prev = ring + (size_t)(s > 0 ? s - 1 : 0) * a.g.R * a.g.nls;
     e.tw = tw;
     e.wt = wt;
+    e.mail = mail;
+    e.mail_nh = nh;
+    e.mail_h = h;
     e.G = G;
     e.A = A;
     const bool live = s < a.ns;
     e.thr = a.thr[(size_t)blockIdx.x * a.n_thr + a.thr0 + (live ? s : 0)];
     e.last = s == a.ns - 1;
-    Lane<real, C, LT, QT, FIRST, EXACT> ln(e, lane, s);
-    const int t_end = a.g.U + a.g.LAG * (a.ns - 1);   // U and LAG are even
+    Lane<real, C, LT, QT, FIRST, EXACT, HELP, RLO, RHI, NHELP> ln(e, lane, s);
+    // a slot's main wave starts LAG steps after the slot before it -- two steps later still when helpers run a step ahead of it
+    constexpr int SHIFT = HELP ? 1 : (NHELP ? 2 : 0);
+    const int t_end = a.g.U + a.g.LAG * (a.ns - 1) + (nh ? 2 : 0);   // U and LAG are even
     int ph = 0;
     for (int t0 = 0; t0 < t_end; t0 += 2) {
-        const int u0 = t0 - a.g.LAG * s;
+        const int u0 = t0 - a.g.LAG * s - SHIFT;      // frame-time of this pair's first step (odd for a helper)
         if (live && u0 >= 0 && u0 < a.g.U) {
             if (u0 == 0) ln.prologue();
-            ln.template step<0>(u0, ph);
+            ln.template step<(SHIFT & 1)>(u0, ph);
             ph = ph + 1 == a.g.SKW ? 0 : ph + 1;
-            BAND_BARRIER();
-            ln.template step<1>(u0 + 1, ph);
-            ph = ph + 1 == a.g.SKW ? 0 : ph + 1;
-            BAND_BARRIER();
-        } else {
-            BAND_BARRIER();
-            BAND_BARRIER();
         }
+        BAND_BARRIER();
+        const int u1 = u0 + 1;
+        if (live && u1 >= 0 && u1 < a.g.U) {
+            if (u1 == 0) ln.prologue();
+            ln.template step<((SHIFT + 1) & 1)>(u1, ph);
+            ph = ph + 1 == a.g.SKW ? 0 : ph + 1;
+        }
+        BAND_BARRIER();
+    }
+}
+template <typename real, int LT, int QT, bool FIRST, int NH, int I>
+__device__ __forceinline__ void band_helper(const BArgs<real> &a, typename cx<real>::type *ring, const typename cx<real>::type *wt, const typename cx<real>::type *tw,
+                                            typename cx<real>::type *mail, int sub, typename cx<real>::type *G, const real *A, int s, int lane) {
+    if constexpr (I <= NH) {
+        if (sub == I) band_wave<real, LT, QT, FIRST, true, true, Split<QT>::lo(I), Split<QT>::hi(I), 0>(a, ring, wt, tw, mail, NH, I - 1, G, A, s, lane);
+        else band_helper<real, LT, QT, FIRST, NH, I + 1>(a, ring, wt, tw, mail, sub, G, A, s, lane);
     }
 }
 
-template <typename real, int LT, int QT, bool EXACT, int MAXT>
+template <typename real, int LT, int QT, bool EXACT, int NH, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_band(BArgs<real> a) {
     using C = typename cx<real>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];
     C *ring = reinterpret_cast<C *>(band_lds);
     const int nls = a.g.nls, wps = nls >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = wave / wps;                                       // sweep slot
+    // waves in the order [role][slot][part of the ring row]: the hardware deals consecutive waves to the four SIMDs in turn, so a
+    // SIMD gets a main wave AND a helper wave (their instruction counts differ) rather than two of a kind
+    const int sub = wave / (a.nsl * wps);                           // 0: the slots' main waves; 1 .. NH: their helpers
+    const int s = (wave / wps) % a.nsl;                             // sweep slot
     const int lane = (wave % wps) * 64 + (threadIdx.x & 63);        // place in the slot's ring row
     const int nring = a.nsl * a.g.R * nls;
     // behind the rings: the weights (read at the same address by every lane: a broadcast; as kernel arguments or behind a global
-    // pointer the compiler keeps all of them live -- 94 scalar or vector registers for Q = 8) and the twiddles
-    C *wt = ring + nring, *tw = wt + a.g.Q * (LT + 1);
+    // pointer the compiler keeps all of them live -- 94 scalar or vector registers for Q = 8), the twiddles, the helpers' mailboxes
+    C *wt = ring + nring, *tw = wt + a.g.Q * (LT + 1), *mail = tw + a.g.Pt * (a.g.Q - 1);
     {
         C z; z.x = 0; z.y = 0;
         for (int i = threadIdx.x; i < nring; i += blockDim.x) ring[i] = z;
         for (int i = threadIdx.x; i < a.g.Q * (LT + 1) + a.g.Pt * (a.g.Q - 1); i += blockDim.x) wt[i] = a.tab[i];
+        for (int i = threadIdx.x; i < a.nsl * 2 * NH * nls * 2; i += blockDim.x) mail[i] = z;
         __syncthreads();
     }
     C *G = a.G + (size_t)blockIdx.x * a.g_stride;
     const real *A = a.A + (size_t)blockIdx.x * a.g_stride;
-    if (s == 0) band_wave<real, LT, QT, true, EXACT>(a, ring, wt, tw, G, A, s, lane);
-    else band_wave<real, LT, QT, false, EXACT>(a, ring, wt, tw, G, A, s, lane);
+    mail += (size_t)s * 2 * NH * nls * 2;
+    if constexpr (NH == 0) {
+        if (s == 0) band_wave<real, LT, QT, true, EXACT, false, 0, QT - 1, 0>(a, ring, wt, tw, mail, 0, 0, G, A, s, lane);
+        else band_wave<real, LT, QT, false, EXACT, false, 0, QT - 1, 0>(a, ring, wt, tw, mail, 0, 0, G, A, s, lane);
+    } else {
+        if (sub == 0) {
+            if (s == 0) band_wave<real, LT, QT, true, true, false, Split<QT>::lo(0), Split<QT>::hi(0), NH>(a, ring, wt, tw, mail, NH, 0, G, A, s, lane);
+            else band_wave<real, LT, QT, false, true, false, Split<QT>::lo(0), Split<QT>::hi(0), NH>(a, ring, wt, tw, mail, NH, 0, G, A, s, lane);
+        } else {
+            if (s == 0) band_helper<real, LT, QT, true, NH, 1>(a, ring, wt, tw, mail, sub, G, A, s, lane);
+            else band_helper<real, LT, QT, false, NH, 1>(a, ring, wt, tw, mail, sub, G, A, s, lane);
+        }
+    }
 }
 
 // extended buffers [B][Tp][F + 2 L] <-> the skewed layout (bins 0 .. F-1 and LT images above Nyquist per frame)
@@ -134,40 +165,53 @@ __global__ void __launch_bounds__(256) k_band_store(typename cx<real>::type *sta
     }
 }
 
-template <typename real, int LT, int QT, bool EXACT, int MAXT>
+template <typename real, int LT, int QT, bool EXACT, int NH, int MAXT>
 hipError_t launch_pass(const BArgs<real> &a, int B, hipStream_t stream) {
     using C = typename cx<real>::type;
     static std::atomic<unsigned long long> done{0};
-    const size_t lds = (size_t)a.nsl * a.g.R * a.g.nls * sizeof(C) + table_bytes(a.g, LT, sizeof(C));
+    const size_t lds = (size_t)a.nsl * (ring_bytes(a.g, sizeof(C)) + mail_bytes(a.g, NH, sizeof(C))) + table_bytes(a.g, LT, sizeof(C));
     int dev = 0;
     if (attr_needed(done, &dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_band<real, LT, QT, EXACT, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_band<real, LT, QT, EXACT, NH, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done(done, dev);
     }
-    k_band<real, LT, QT, EXACT, MAXT><<<dim3(B), dim3(a.g.nls * a.nsl), lds, stream>>>(a);
+    k_band<real, LT, QT, EXACT, NH, MAXT><<<dim3(B), dim3(a.g.nls * a.nsl * (1 + NH)), lds, stream>>>(a);
     return hipGetLastError();
 }
+// The instantiations.  For the Q each family is mostly used with an EXACT one (no test on the frame offsets: a step is straight-line
+// code) whose slots are a main wave and helper waves (bp.helpers > 0: two waves per SIMD, 256 vector registers each); one with the
+// tests, one wave per slot, for every other Q.
 template <typename real>
 hipError_t launch_pass_any(const BandPlan &bp, const BArgs<real> &a, int B, hipStream_t stream) {
-    // the instantiations: an exact one for the Q each family is mostly used with (no test on the frame offsets: a step is
-    // straight-line code), one with the tests for the others.  Two waves per SIMD (256 vector registers each) only where the step
-    // fits them: fp32, L <= 5, Q <= 8.
     const int Q = a.g.Q;
-    constexpr int M8 = std::is_same<real, float>::value ? 512 : 256;
+    constexpr bool F32 = std::is_same<real, float>::value;
+    constexpr int M8 = F32 ? 512 : 256;
     if (bp.LT == 5) {
-        if (Q == 8 && a.g.nls * a.nsl <= 256) return launch_pass<real, 5, 8, true, 256>(a, B, stream);   // (straight-line: one wave per SIMD's registers)
-        if (Q <= 8) return launch_pass<real, 5, 8, false, M8>(a, B, stream);
-        if constexpr (std::is_same<real, float>::value) {
-            if (Q == 16) return launch_pass<real, 5, 16, true, 256>(a, B, stream);
+        if (Q == 8 && bp.helpers == 1) return launch_pass<real, 5, 8, true, 1, M8>(a, B, stream);   // (fp64: 512 registers a wave, so 256 threads)
+        if (Q == 8 && a.g.nls * a.nsl <= 256) return launch_pass<real, 5, 8, true, 0, 256>(a, B, stream);   // (straight-line: one wave per SIMD's registers)
+        if (Q <= 8) return launch_pass<real, 5, 8, false, 0, M8>(a, B, stream);
+        if constexpr (F32) {
+            if (Q == 16 && bp.helpers == 3) return launch_pass<real, 5, 16, true, 3, 512>(a, B, stream);
+            if (Q == 16) return launch_pass<real, 5, 16, true, 0, 256>(a, B, stream);
         }
-        return launch_pass<real, 5, 16, false, 256>(a, B, stream);
+        return launch_pass<real, 5, 16, false, 0, 256>(a, B, stream);
     }
-    if (Q == 4) return launch_pass<real, 10, 4, true, 256>(a, B, stream);
-    if (Q <= 8) return launch_pass<real, 10, 8, false, 256>(a, B, stream);
-    return launch_pass<real, 10, 16, false, 256>(a, B, stream);
+    if constexpr (F32) {
+        if (Q == 4 && bp.helpers == 1) return launch_pass<real, 10, 4, true, 1, 512>(a, B, stream);
+    }
+    if (Q == 4) return launch_pass<real, 10, 4, true, 0, 256>(a, B, stream);
+    if (Q <= 8) return launch_pass<real, 10, 8, false, 0, 256>(a, B, stream);
+    return launch_pass<real, 10, 16, false, 0, 256>(a, B, stream);
 }
-inline int max_threads(bool fp64, int LT, int QT) { return (!fp64 && LT == 5 && QT == 8) ? 512 : 256; }
+// threads a workgroup may have (the instantiation's launch bound) and the helper waves per slot of the build a plan runs on
+inline int helpers_of(bool fp64, int LT, int Q) {
+    if (LT == 5 && Q == 8) return Split<8>::NH;            // (fp64 too: a ring of 513 bins leaves one slot -- a second wave per CU)
+    if (LT == 5 && Q == 16 && !fp64) return Split<16>::NH;
+    if (LT == 10 && Q == 4 && !fp64) return Split<4>::NH;  // (fp64: the slots the LDS holds already fill the 256 threads its registers allow)
+    return 0;
+}
+inline int max_threads(bool fp64, int LT, int QT, int helpers) { return fp64 ? 256 : ((helpers || (LT == 5 && QT == 8)) ? 512 : 256); }
 
 int env_i(const char *name, int dflt) {
     const char *v = getenv(name);
@@ -218,24 +262,26 @@ bool band_plan(bool fp64, int B, int F, int T, int L, int Q, int Qp, int update,
     if (fp64 && Qp != Q) return false;
     if (!rows_are_twiddles(W, Q, Qp, L, Pt, s, fp64 ? 1e-13 : 1e-9)) return false;
     const size_t csize = fp64 ? 16 : 8;
-    const int maxt = max_threads(fp64, LT, QT);
+    // (LWS_BAND_NO_HELPERS=1: the exact builds' one-wave-per-slot variant -- comparison runs)
+    const int helpers = env_i("LWS_BAND_NO_HELPERS", 0) ? 0 : helpers_of(fp64, LT, Q);
+    const int maxt = max_threads(fp64, LT, QT, helpers);
     BandPlan best{};
     double best_cost = 1e300;
     const int skw_force = env_i("LWS_BAND_SKW", 0), nls_force = env_i("LWS_BAND_NLS", 0), ns_force = env_i("LWS_BAND_NS", 0);   // (tests)
-    for (int nls = 64; nls <= maxt; nls *= 2) {
+    for (int nls = 64; nls * (1 + helpers) <= maxt; nls *= 2) {
         if (nls_force && nls != nls_force) continue;
         for (int SKW = LT + 2; SKW <= LT + 2 + 10; ++SKW) {
             if (skw_force && SKW != skw_force) continue;
-            const Geom g = geometry(F, T, Q, LT, SKW, nls, Pt);
+            const Geom g = geometry(F, T, Q, LT, SKW, nls, Pt, helpers);
             const size_t avail = LDS_BYTES - table_bytes(g, LT, csize);
-            int NS = (int)std::min<size_t>(avail / ring_bytes(g, csize), (size_t)(maxt / nls));
+            int NS = (int)std::min<size_t>(avail / (ring_bytes(g, csize) + mail_bytes(g, helpers, csize)), (size_t)(maxt / (nls * (1 + helpers))));
             NS = std::min(NS, n_thr);
             if (ns_force) NS = std::min(NS, ns_force);
             if (NS < 1) continue;
             // steps per sweep (the passes of a call: full ones, then the rest), by what a step costs with that many waves
             const int full = n_thr / NS, rest = n_thr % NS;
             const double steps = (double)full * (g.U + (double)g.LAG * (NS - 1)) + (rest ? g.U + (double)g.LAG * (rest - 1) : 0.0);
-            const double cost = steps * step_cost(NS * nls / 64);
+            const double cost = steps * step_cost(NS * nls / 64);      // (helper waves share their main wave's work: not counted)
             if (cost < best_cost) {
                 best_cost = cost;
                 best.g = g; best.NS = NS;
@@ -243,7 +289,7 @@ bool band_plan(bool fp64, int B, int F, int T, int L, int Q, int Qp, int update,
         }
     }
     if (best_cost >= 1e300) return false;
-    best.LT = LT; best.QT = QT; best.Pt = Pt; best.s = s; best.L = L; best.fp64 = fp64;
+    best.LT = LT; best.QT = QT; best.Pt = Pt; best.s = s; best.L = L; best.fp64 = fp64; best.helpers = helpers;
     // spectrograms that go through the skewed scratch at a time: at most 32 GiB of it (LWS_BAND_CHUNK: for tests)
     const size_t per = (size_t)best.g.rows * best.g.nls * (csize + csize / 2);
     int chunk = (int)std::min<size_t>((size_t)std::max(B, 1), std::max<size_t>(1, ((size_t)32 << 30) / per));

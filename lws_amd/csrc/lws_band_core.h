@@ -85,13 +85,33 @@ template <typename real, typename C> struct Env {
     const C *wt;            // LDS: [Q][LT+1]: row 0 the frame's own taps W[0][0][k], row r the neighbour weights V[r][k] (the same address in every lane)
     C *G;                   // the skewed state of this spectrogram: frame me, bin b at row SKW (me % nls) + P (me / nls) + b + LT
     const real *A;          // target magnitudes, same addressing (row u holds the bin a lane completes at frame-time u, row u + LT the one it receives)
+    C *mail;                // LDS: the mailbox of this slot's helper waves, [2 (parity of the step)][helpers][nls][2] (see Lane)
+    int mail_nh, mail_h;    // helpers of the slot; which of them this wave is
     real thr;
     bool last;              // this slot's output is what the pass leaves in the skewed state
 };
 
-// EXACT: Q == QT -- the tests on the frame offsets are decided at compile time and a step is straight-line code
-template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = false> struct Lane {
-    static constexpr int NA = 2 * LT + 1, NRT = QT - 1, K1 = LT + 1;
+// How the frame offsets of an exact build are shared out between the main wave and its helpers (see Lane): block r (0-based; frame
+// offset r + 1) belongs to part i if b[i] <= r < b[i + 1]; part 0 is the main wave's.
+template <int QT> struct Split { static constexpr int NH = 0; };
+template <> struct Split<4> { static constexpr int NH = 1; static constexpr int lo(int i) { return i == 0 ? 0 : 1; } static constexpr int hi(int i) { return i == 0 ? 1 : 3; } };
+template <> struct Split<8> { static constexpr int NH = 1; static constexpr int lo(int i) { return i == 0 ? 0 : 3; } static constexpr int hi(int i) { return i == 0 ? 3 : 7; } };
+template <> struct Split<16> { static constexpr int NH = 3; static constexpr int lo(int i) { return i == 0 ? 0 : 4 * i - 1; } static constexpr int hi(int i) { return 4 * i + 3; } };
+
+// EXACT: Q == QT -- the tests on the frame offsets are decided at compile time and a step is straight-line code.
+//
+// Helper waves (exact builds).  A sweep slot's ring fills most of the LDS, so a slot that is ONE wave per 64 frames leaves a wave alone
+// on its SIMD with every LDS round trip exposed.  With NHELP > 0 the frame offsets are shared out: the MAIN wave (HELP = false) takes
+// offsets RLO+1 .. RHI, the frame's own taps, the re-projection and all stores; each helper wave (HELP = true) takes a range of the far
+// offsets for the same lanes ONE STEP AHEAD of the main wave -- it reads what the main wave will receive a step later (every such value
+// is at least two steps old for offsets >= 2) -- keeps sums of its own for bins c .. c + 2 LT and leaves what the bin it completes
+// gets from its offsets, and their share of the DC / Nyquist imaginary part, in a mailbox (LDS, two cells deep by the step's parity)
+// that the main wave adds to its own a step later.  The order of a bin's sum changes (per helper a partial sum): rounding only.
+template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = false, bool HELP = false, int RLO = 0, int RHI = QT - 1, int NHELP = 0>
+struct Lane {
+    static constexpr int NA = 2 * LT + 1, NRT = QT - 1, K1 = LT + 1, NB = RHI - RLO;
+    static constexpr int LEAD = HELP ? 1 : 0;           // steps this wave runs ahead of the slot's main wave
+    static_assert(RLO >= 0 && RHI <= NRT && NB >= 1 && (!HELP || (EXACT && RLO >= 1)) && (NHELP == 0 || (EXACT && !HELP)), "roles");
     using P = V2<real>;
     // what a step receives from the frames r apart -- position w of frame me - r (L) and of frame me + r (R), tau_r^w (T) -- and what
     // it makes of it: with A' = tau A, B' = conj(tau) B the sum S = A' + B' and D = j (A' - B'), so that a weight v adds
@@ -99,14 +119,14 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
     struct In { C L, R, T; };
     struct SD { P S, D; };
     // lane state
-    P acc[NA];               // sums of bins c .. c + 2 LT
-    C cn[LT + 1];            // cn[k]: new value of bin c - k (below DC: the image, lwslib.cpp:362-364, as it stands at that moment)
-    C co[LT + 1];            // co[k]: old value of bin c + k
+    P acc[NA];               // sums of bins c .. c + 2 LT (of this wave's frame offsets)
+    C cn[HELP ? 1 : LT + 1]; // cn[k]: new value of bin c - k (below DC: the image, lwslib.cpp:362-364, as it stands at that moment)
+    C co[HELP ? 1 : LT + 1]; // co[k]: old value of bin c + k
     real yE;                 // DC / Nyquist: the imaginary part of the bin's sum (see step)
-    In nx;                   // inputs of the next step's first frame offset (r = 1), requested from the LDS one step early
+    In nx;                   // inputs of the next step's first frame offset, requested from the LDS one step early
     C nxO, nxI;              // ... its old value of the frame itself and the image above Nyquist it may have to write
-    C pfO[FIRST ? PFD : 1], pfR[FIRST ? PFD : 1][FIRST ? NRT : 1];   // first slot: inputs of the next PFD steps from the skewed state
-    real pfA[PFD];
+    C pfO[FIRST && !HELP ? PFD : 1], pfR[FIRST ? PFD : 1][FIRST ? NB : 1];   // first slot: inputs of the next PFD steps from the skewed state
+    real pfA[HELP ? 1 : PFD];
     int w, me, tm, pmo;      // position in the frame period, frame, ring time, (w mod Pt) (Q - 1)
     int lane;
     const Env<real, C> &e;
@@ -117,13 +137,15 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
 #pragma unroll
         for (int d = 0; d < NA; ++d) acc[d] = P{0, 0};
 #pragma unroll
-        for (int k = 0; k <= LT; ++k) { cn[k] = z; co[k] = z; }
+        for (int k = 0; k < (HELP ? 1 : LT + 1); ++k) { cn[k] = z; co[k] = z; }
         yE = 0;
         // a lane that has not started yet (its frame-time is negative) counts up to position 0 of its first frame
         w = -e.g.SKW * lane;
         me = lane;
         pmo = 0;
-        tm = (int)(((long)e.g.LAG * slot_index) % e.g.R);
+        // ring rows are addressed by the workgroup's time: a slot's main wave starts LAG steps after the slot before it (two steps
+        // later still when helpers run a step ahead of it)
+        tm = (int)(((long)e.g.LAG * slot_index + (HELP ? 1 : (NHELP ? 2 : 0))) % e.g.R);
     }
     // ring row written `age` steps before time t_mod.  A read issued for the NEXT step (t_mod = its time) sees rows of age >= 2: the
     // row of age 1 is being written while it is issued; a read of THIS step sees ages >= 1.
@@ -140,12 +162,12 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
         const Geom &g = e.g;
         In v;
         const int offL = (lane - (r + 1)) & (g.nls - 1);
-        const int ageL = g.SKW * (r + 1) - LT + (lane < r + 1 ? g.gap : 0);
+        const int ageL = g.SKW * (r + 1) - LT - LEAD + (lane < r + 1 ? g.gap : 0);
         v.L = e.ring_own[(row_at(tmx, ageL, min_age) << g.lg) + offL];
         v.T = e.tw[pmx + r];
         if constexpr (!FIRST) {
             const int offR = (lane + r + 1) & (g.nls - 1);
-            const int ageR = g.LAG - LT - g.SKW * (r + 1) - (lane + r + 1 >= g.nls ? g.gap : 0);
+            const int ageR = g.LAG - LT - LEAD - g.SKW * (r + 1) - (lane + r + 1 >= g.nls ? g.gap : 0);
             v.R = e.ring_prev[(row_at(tmx, ageR, min_age) << g.lg) + offR];
         } else {
             v.R = v.L;   // (replaced by the value from the skewed state)
@@ -154,26 +176,28 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
     }
     BAND_FN void issue_lds(int tmx, int wx, int pmx) {
         const Geom &g = e.g;
-        nx = fetch(0, tmx, pmx, 2);
-        if constexpr (!FIRST) nxO = e.ring_prev[(row_at(tmx, g.LAG - LT, 2) << g.lg) + lane];
-        int cx = wx - LT;
-        if (cx < 0) cx += g.P;                        // still the images of the frame the lane has just left
-        const int jj = cx - (g.F - 1);
-        nxI = e.ring_own[(row_at(tmx, (jj >= 1 && jj <= LT) ? 2 * jj : 2, 2) << g.lg) + lane];
+        nx = fetch(RLO, tmx, pmx, 2);
+        if constexpr (!HELP) {
+            if constexpr (!FIRST) nxO = e.ring_prev[(row_at(tmx, g.LAG - LT, 2) << g.lg) + lane];
+            int cx = wx - LT;
+            if (cx < 0) cx += g.P;                        // still the images of the frame the lane has just left
+            const int jj = cx - (g.F - 1);
+            nxI = e.ring_own[(row_at(tmx, (jj >= 1 && jj <= LT) ? 2 * jj : 2, 2) << g.lg) + lane];
+        }
     }
     BAND_FN void issue_global(int ux, int b) {
         const Geom &g = e.g;
-        pfA[b] = e.A[((long)ux << g.lg) + lane];
+        if constexpr (!HELP) pfA[b] = e.A[((long)ux << g.lg) + lane];
         if constexpr (FIRST) {
             const int NR = EXACT ? NRT : g.Q - 1;
             const C *Gu = e.G + ((long)(ux + LT) << g.lg);
-            pfO[b] = Gu[lane];
+            if constexpr (!HELP) pfO[b] = Gu[lane];
 #pragma unroll
-            for (int r = 0; r < NRT; ++r) {
+            for (int r = RLO; r < RHI; ++r) {
                 if (r >= NR) continue;
                 const int offR = (lane + r + 1) & (g.nls - 1);
                 const int wrap = lane + r + 1 >= g.nls ? g.gap : 0;
-                pfR[b][r] = Gu[((long)(g.SKW * (r + 1) + wrap) << g.lg) + offR];
+                pfR[b][r - RLO] = Gu[((long)(g.SKW * (r + 1) + wrap) << g.lg) + offR];
             }
         }
     }
@@ -185,15 +209,15 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
 
     // the image below DC of position PH (= w): position -PH holds the conjugate -- of A' and B' too -- and reaches bins
     // ct = 0 .. LT - PH with V[r][ct + PH]; one lane at most (z), the others add zeros
-    template <int PH> BAND_FN void images(const SD (&sd)[NRT], bool z) {
+    template <int PH> BAND_FN void images(const SD (&sd)[NB], bool z) {
         if constexpr (PH >= 1 && PH <= LT) {
             const int NR = EXACT ? NRT : e.g.Q - 1;
 #pragma unroll
-            for (int r = 0; r < NRT; ++r) {
+            for (int r = RLO; r < RHI; ++r) {
                 if (r >= NR) continue;
                 const C *wr = e.wt + (r + 1) * K1;
                 // conj(A') + conj(B') = conj(S);  j (conj(A') - conj(B')) = (-D.x, D.y)
-                const P Sc = vsel<real>(z, P{sd[r].S.x, -sd[r].S.y}, P{0, 0}), Dc = vsel<real>(z, P{-sd[r].D.x, sd[r].D.y}, P{0, 0});
+                const P Sc = vsel<real>(z, P{sd[r - RLO].S.x, -sd[r - RLO].S.y}, P{0, 0}), Dc = vsel<real>(z, P{-sd[r - RLO].D.x, sd[r - RLO].D.y}, P{0, 0});
 #pragma unroll
                 for (int ct = 0; ct <= LT - PH; ++ct) {
                     const C v = wr[ct + PH];
@@ -213,15 +237,24 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
         const int NR = EXACT ? NRT : g.Q - 1, F = g.F;
         // ---- this step's inputs were requested earlier (LDS: the first frame offset's one step early, the others' while the
         //      offset before them is worked on; skewed state: PFD steps early)
-        const C img = nxI;
-        const real amp = pfA[PB];
-        C O;
-        if constexpr (FIRST) O = pfO[PB]; else O = nxO;
         int w1 = w + 1, me1 = me, pmo1 = pmo + NR == g.Pt * NR ? 0 : pmo + NR;
         if (w1 == g.P) { w1 = 0; me1 += g.nls; }
         if (w1 == 0) pmo1 = 0;
         const int tm1 = tm + 1 == g.R ? 0 : tm + 1;
+        // what the helper waves left for this step a step ago (requested now, used when the bin is completed)
+        C mb[NHELP ? 2 * NHELP : 1];
+        if constexpr (NHELP > 0) {
+#pragma unroll
+            for (int h = 0; h < NHELP; ++h) {
+                const C *cell = e.mail + ((((PB * NHELP + h) << g.lg) + lane) << 1);
+                mb[2 * h] = cell[0];
+                mb[2 * h + 1] = cell[1];
+            }
+        }
 
+        C img; img.x = 0; img.y = 0;
+        real amp = 0;
+        if constexpr (!HELP) { img = nxI; amp = pfA[PB]; }
         const int c = w - LT;
         const bool act = w >= 0 && me < g.nls * g.nblk;
         if (ph == 0) {   // (wave-uniform) a lane starts a frame with empty sums
@@ -231,7 +264,9 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
         }
         // ---- (a) old value of the frame itself at bin c + LT; an image above Nyquist whose source this sweep has already
         //      rewritten is the conjugate of that new value
-        {
+        if constexpr (!HELP) {
+            C O;
+            if constexpr (FIRST) O = pfO[PB]; else O = nxO;
             const int kk = 2 * c + LT - 2 * (F - 1);
             C o = O;
 #pragma unroll
@@ -240,32 +275,32 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
         }
         // ---- (b) neighbour frames: position w of frames me -+ r, turned by tau_r^w, reaches bins c .. c + 2 LT
         real y0 = 0;
-        SD sd[NRT];
+        SD sd[NB];
         In cur = nx;
         C wcur[K1];              // the weights of the frame offset at hand, requested like its inputs: while the one before is worked on
 #pragma unroll
-        for (int k = 0; k <= LT; ++k) wcur[k] = e.wt[K1 + k];
+        for (int k = 0; k <= LT; ++k) wcur[k] = e.wt[(RLO + 1) * K1 + k];
 #pragma unroll
-        for (int r = 0; r < NRT; ++r) {
+        for (int r = RLO; r < RHI; ++r) {
             if (r >= NR) continue;
             const In in = cur;
             C wr[K1];
 #pragma unroll
             for (int k = 0; k <= LT; ++k) wr[k] = wcur[k];
-            if (r + 1 < NR) {
+            if (r + 1 < RHI && r + 1 < NR) {
                 cur = fetch(r + 1, tm, pmo, 1);
 #pragma unroll
                 for (int k = 0; k <= LT; ++k) wcur[k] = e.wt[(r + 2) * K1 + k];
             }
             C Rv;
-            if constexpr (FIRST) Rv = pfR[PB][r]; else Rv = in.R;
+            if constexpr (FIRST) Rv = pfR[PB][r - RLO]; else Rv = in.R;
             const P uu = pr<real>(in.L) + pr<real>(Rv), jv = turn<real>(pr<real>(in.L) - pr<real>(Rv));
             const P tx = splat<real>(in.T.x), ty = splat<real>(in.T.y);
             // A' = tau A, B' = conj(tau) B:  A' + B' = tau.x (A + B) + tau.y j (A - B),  j (A' - B') = tau.x j (A - B) - tau.y (A + B)
             SD t;
             t.S = vfma<real>(ty, jv, tx * uu);
             t.D = vfma<real>(-ty, uu, tx * jv);
-            sd[r] = t;
+            sd[r - RLO] = t;
             // DC and Nyquist (below): the imaginary part of the k = 0 taps
             y0 = fma_<real>(wr[0].x, t.S.y, y0);
             y0 = fma_<real>(wr[0].y, t.D.y, y0);
@@ -289,13 +324,6 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
             __builtin_amdgcn_sched_barrier(0);
 #endif
         }
-        // DC and Nyquist.  Their neighbourhood is Hermitian (the images are exact conjugates), so in the reference every tap pair
-        // k >= 1 adds x and then -x to the imaginary part of the sum, bit for bit (lwslib.cpp:310-311 on c = conj(b)): what is left
-        // is the k = 0 taps -- exactly zero for a spectrogram whose DC / Nyquist bins are real, which they then stay.  That line
-        // is unstable (lws_sys64.hip, DESIGN 6), and in scatter form the two halves of a pair arrive steps apart and cancel to
-        // rounding only: so the imaginary part of these two bins is taken from the k = 0 taps alone, captured when their position
-        // arrives (LT steps before the bin is complete).
-        yE = (w == 0 || w == F - 1) ? y0 : yE;
         // images below DC: position -w is the conjugate of position w and reaches bins 0 .. LT - w (w = ph in the one lane that has
         // w <= LT; every lane has w = ph modulo SKW)
         if (ph >= 1 && ph <= LT) {
@@ -315,6 +343,32 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
         }
         issue_lds(tm1, w1, pmo1);
         issue_global(u + PFD, PB);
+        if constexpr (HELP) {
+            // ---- a helper wave: what bin c gets from this wave's frame offsets, and their share of the DC / Nyquist imaginary part
+            //      (position w), for the main wave's step of the same frame-time -- the next step of the workgroup
+            C m0, m1;
+            m0.x = acc[0].x; m0.y = acc[0].y;
+            m1.x = y0; m1.y = 0;
+            C *out = e.mail + ((((PB * e.mail_nh + e.mail_h) << g.lg) + lane) << 1);
+            out[0] = m0;
+            out[1] = m1;
+#pragma unroll
+            for (int d = 0; d < NA - 1; ++d) acc[d] = acc[d + 1];
+            acc[NA - 1] = P{0, 0};
+            w = w1; me = me1; tm = tm1; pmo = pmo1;
+            return;
+        } else {
+        if constexpr (NHELP > 0) {
+#pragma unroll
+            for (int h = 0; h < NHELP; ++h) y0 += mb[2 * h + 1].x;
+        }
+        // DC and Nyquist.  Their neighbourhood is Hermitian (the images are exact conjugates), so in the reference every tap pair
+        // k >= 1 adds x and then -x to the imaginary part of the sum, bit for bit (lwslib.cpp:310-311 on c = conj(b)): what is left
+        // is the k = 0 taps -- exactly zero for a spectrogram whose DC / Nyquist bins are real, which they then stay.  That line
+        // is unstable (lws_sys64.hip, DESIGN 6), and in scatter form the two halves of a pair arrive steps apart and cancel to
+        // rounding only: so the imaginary part of these two bins is taken from the k = 0 taps alone, captured when their position
+        // arrives (LT steps before the bin is complete).
+        yE = (w == 0 || w == F - 1) ? y0 : yE;
         // ---- (c) the frame's own taps: new values below (the images below DC among them), old values above; k = 1 last (it is
         //      the value the previous step produced)
         if (ph == LT % g.SKW) {   // bin 0: nothing of this frame is new yet, the images below DC are those of the old values
@@ -323,6 +377,10 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
             for (int k = 1; k <= LT; ++k) cn[k] = sel(b0, cj(co[k]), cn[k]);
         }
         P a0 = acc[0];
+        if constexpr (NHELP > 0) {
+#pragma unroll
+            for (int h = 0; h < NHELP; ++h) a0 = a0 + pr<real>(mb[2 * h]);
+        }
 #pragma unroll
         for (int k = LT; k >= 1; --k) {
             const C wv = e.wt[k];
@@ -368,6 +426,7 @@ template <typename real, typename C, int LT, int QT, bool FIRST, bool EXACT = fa
         for (int d = 0; d < NA - 1; ++d) acc[d] = acc[d + 1];
         acc[NA - 1] = P{0, 0};
         w = w1; me = me1; tm = tm1; pmo = pmo1;
+        }
     }
 };
 

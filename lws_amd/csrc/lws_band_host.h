@@ -12,7 +12,7 @@ namespace band {
 
 // LT: the stencil half-width the kernel is compiled for (>= the plan's L).  SKW >= LT + 2: the value a lane reads from its
 // left-hand neighbour is requested one step early and must have been written two steps before that.
-inline Geom geometry(int F, int T, int Q, int LT, int SKW, int nls, int Pt) {
+inline Geom geometry(int F, int T, int Q, int LT, int SKW, int nls, int Pt, int helpers = 0) {
     Geom g{};
     g.F = F; g.T = T; g.Q = Q; g.SKW = SKW; g.nls = nls; g.Pt = Pt < 1 ? 1 : Pt;
     for (g.lg = 0; (1 << g.lg) < nls; ++g.lg) {}
@@ -22,7 +22,8 @@ inline Geom geometry(int F, int T, int Q, int LT, int SKW, int nls, int Pt) {
     g.P = (std::max(nls * SKW, F + LT) + SKW - 1) / SKW * SKW;
     g.gap = g.P - nls * SKW;
     // a sweep slot follows the one before it at the distance of the farthest old value it reads, + 2 (requested a step early)
-    g.LAG = std::max(LT + SKW * (Q - 1) + g.gap + 2, 3 * LT);   // (3 LT: an image above Nyquist is read 2 LT rows back)
+    // (helper waves run a step ahead of their slot's main wave: what they read of the slot before is a step younger)
+    g.LAG = std::max(LT + SKW * (Q - 1) + g.gap + 2 + (helpers > 0 ? 1 : 0), 3 * LT);   // (3 LT: an image above Nyquist is read 2 LT rows back)
     g.LAG += g.LAG & 1;                                         // (slots start on even steps: the step loop is unrolled by PFD = 2)
     g.R = g.LAG - LT + 1;
     g.nblk = (Tp + nls - 1) / nls;
@@ -33,6 +34,8 @@ inline Geom geometry(int F, int T, int Q, int LT, int SKW, int nls, int Pt) {
     return g;
 }
 inline size_t ring_bytes(const Geom &g, size_t csize) { return (size_t)g.R * g.nls * csize; }
+// the mailboxes of a slot's helper waves: [2][helpers][nls][2] complex values
+inline size_t mail_bytes(const Geom &g, int helpers, size_t csize) { return (size_t)2 * helpers * g.nls * 2 * csize; }
 inline size_t table_bytes(const Geom &g, int LT, size_t csize) { return ((size_t)g.Q * (LT + 1) + (size_t)g.Pt * (g.Q - 1)) * csize; }   // weights + twiddles
 
 // exp(2 pi j num / den), exact on the axes

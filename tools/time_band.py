@@ -23,8 +23,13 @@ def t(fsize, fshift, B, T, iters, precision="fp32", force_generic=False, reps=3,
 t(2048, 256, 256, 250, 20, reps=1 if one else 3)
 if one:
     sys.exit(0)
+t(2048, 256, 256, 500, 20)
 t(1024, 64, 256, 500, 10)
 t(1024, 256, 256, 500, 40, L=8)
+if quick:
+    os.environ["LWS_BAND_NO_HELPERS"] = "1"      # the exact builds with one wave per slot, for comparison
+    t(2048, 256, 256, 500, 20); t(1024, 64, 256, 500, 10); t(1024, 256, 256, 500, 40, L=8)
+    del os.environ["LWS_BAND_NO_HELPERS"]
 if not quick:
     t(1024, 256, 256, 500, 40, L=7); t(1024, 256, 256, 500, 20, L=10); t(2000, 400, 256, 250, 20); t(2048, 320, 256, 250, 20); t(8192, 2048, 64, 250, 20)
     t(2048, 256, 256, 250, 10, precision="fp64"); t(1024, 128, 256, 500, 10, precision="fp64"); t(1024, 64, 256, 500, 4, precision="fp64"); t(768, 256, 256, 500, 20, precision="fp64")
