@@ -30,6 +30,7 @@ template <typename real> struct BArgs {
     typename cx<real>::type *G;           // [chunk][rows][nls] time-skewed state
     const real *A;                        // [chunk][rows][nls] target magnitudes
     const real *thr;                      // [chunk][n_thr]
+    const real *amax;                     // [chunk] largest target magnitude of each spectrogram (k_band_load)
     const typename cx<real>::type *tab;   // the two tables of lws_band_host.h: [Q][LT+1] weights, then [Pt][Q-1] twiddles
     long g_stride;                        // rows * nls
     int n_thr, thr0, ns, nsl;             // this pass: sweeps thr0 .. thr0 + ns - 1 on the first ns of the nsl slots launched
@@ -102,6 +103,14 @@ __global__ void __launch_bounds__(MAXT) k_band(BArgs<real> a) {
     const int sub = wave / (a.nsl * wps);                           // 0: the slots' main waves; 1 .. NH: their helpers
     const int s = (wave / wps) % a.nsl;                             // sweep slot
     const int lane = (wave % wps) * 64 + (threadIdx.x & 63);        // place in the slot's ring row
+    {
+        // a pass none of whose sweeps has a bin above its threshold changes nothing (lwslib.cpp:295-296: strict '>'): the first ~38 of
+        // the reference's default 100 sweeps are such sweeps.  The same answer in every thread of the workgroup.
+        const real top = a.amax[blockIdx.x];
+        bool any = false;
+        for (int i = 0; i < a.ns; ++i) any |= top > a.thr[(size_t)blockIdx.x * a.n_thr + a.thr0 + i];
+        if (!any) return;
+    }
     const int nring = a.nsl * a.g.R * nls;
     // behind the rings: the weights (read at the same address by every lane: a broadcast; as kernel arguments or behind a global
     // pointer the compiler keeps all of them live -- 94 scalar or vector registers for Q = 8), the twiddles, the helpers' mailboxes
@@ -133,19 +142,34 @@ __global__ void __launch_bounds__(MAXT) k_band(BArgs<real> a) {
 // extended buffers [B][Tp][F + 2 L] <-> the skewed layout (bins 0 .. F-1 and LT images above Nyquist per frame)
 template <typename real>
 __global__ void __launch_bounds__(256) k_band_load(const typename cx<real>::type *state, const real *amp, typename cx<real>::type *G, real *A,
-                                                    int L, int LT, int Tp, Geom g, long g_stride) {
+                                                    real *amax, int L, int LT, int Tp, Geom g, long g_stride) {
     using C = typename cx<real>::type;
     const int bb = blockIdx.y, me = blockIdx.x, F = g.F, Np = F + 2 * L;
     const int j = me & (g.nls - 1), blk = me / g.nls;
     const long base = (long)g.SKW * j + (long)g.P * blk + LT;
     const C *src = state + ((size_t)bb * Tp + me) * Np + L;
     const real *asrc = amp + ((size_t)bb * Tp + me) * Np + L;
+    real top = 0;
     for (int b = threadIdx.x; b < F + LT; b += blockDim.x) {
         const int q = b < F ? b : 2 * (F - 1) - b;
         C v = src[q];
         if (b >= F) v.y = -v.y;
         G[(size_t)bb * g_stride + (base + b) * g.nls + j] = v;
-        A[(size_t)bb * g_stride + (base + b) * g.nls + j] = asrc[q];
+        const real am = asrc[q];
+        A[(size_t)bb * g_stride + (base + b) * g.nls + j] = am;
+        top = am > top ? am : top;
+    }
+    // the spectrogram's largest target magnitude (non-negative values order like their bit patterns)
+    __shared__ real red[256];
+    red[threadIdx.x] = top;
+    __syncthreads();
+    for (int h = blockDim.x / 2; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + h] ? red[threadIdx.x] : red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && me >= g.Q - 1 && me < g.T + g.Q - 1) {
+        if constexpr (sizeof(real) == 4) atomicMax(reinterpret_cast<unsigned int *>(amax + bb), __float_as_uint((float)red[0]));
+        else atomicMax(reinterpret_cast<unsigned long long *>(amax + bb), (unsigned long long)__double_as_longlong((double)red[0]));
     }
 }
 template <typename real>
@@ -297,7 +321,7 @@ bool band_plan(bool fp64, int B, int F, int T, int L, int Q, int Qp, int update,
     if (cf > 0) chunk = std::min(chunk, cf);
     best.chunk = chunk;
     best.state_bytes = (size_t)chunk * best.g.rows * best.g.nls * csize;
-    best.amp_bytes = (size_t)chunk * best.g.rows * best.g.nls * (csize / 2);
+    best.amp_bytes = (size_t)chunk * best.g.rows * best.g.nls * (csize / 2) + (size_t)chunk * (csize / 2);   // (+ a largest magnitude per spectrogram)
     if (out) *out = best;
     return true;
 }
@@ -334,11 +358,13 @@ hipError_t launch_band(const BandPlan &bp, const GenericArgs<real> &ga, const vo
         // rows no frame owns are read by lanes whose results are discarded, and must be zeros for the lanes that do use them
         if ((e = hipMemsetAsync(G, 0, (size_t)Bc * g_stride * sizeof(C), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(A, 0, (size_t)Bc * g_stride * sizeof(real), stream)) != hipSuccess) return e;
+        real *amax = A + (size_t)bp.chunk * g_stride;      // behind the magnitudes
+        if ((e = hipMemsetAsync(amax, 0, (size_t)Bc * sizeof(real), stream)) != hipSuccess) return e;
         C *state = ga.state + (size_t)b0 * Tp * Np;
-        k_band_load<real><<<dim3(Tp, Bc), 256, 0, stream>>>(state, ga.amp + (size_t)b0 * Tp * Np, G, A, bp.L, bp.LT, Tp, g, g_stride);
+        k_band_load<real><<<dim3(Tp, Bc), 256, 0, stream>>>(state, ga.amp + (size_t)b0 * Tp * Np, G, A, amax, bp.L, bp.LT, Tp, g, g_stride);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         BArgs<real> a;
-        a.G = G; a.A = A; a.thr = ga.thr + (size_t)b0 * ga.n_thr;
+        a.G = G; a.A = A; a.thr = ga.thr + (size_t)b0 * ga.n_thr; a.amax = amax;
         a.tab = static_cast<const C *>(tables_dev);
         a.g_stride = g_stride; a.n_thr = ga.n_thr; a.nsl = bp.NS; a.g = g;
         for (int i0 = 0; i0 < ga.n_thr; i0 += bp.NS, ++n_all) {

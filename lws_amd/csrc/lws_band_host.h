@@ -27,7 +27,14 @@ inline Geom geometry(int F, int T, int Q, int LT, int SKW, int nls, int Pt, int 
     g.LAG += g.LAG & 1;                                         // (slots start on even steps: the step loop is unrolled by PFD = 2)
     g.R = g.LAG - LT + 1;
     g.nblk = (Tp + nls - 1) / nls;
-    g.U = SKW * (nls - 1) + g.P * g.nblk + LT + 3;              // (+ LT: the images of the last frames)
+    // steps of one sweep: until the last of the Tp frames is finished -- frame me sits in lane me % nls, block me / nls, and ends at step
+    // SKW (me % nls) + P (me / nls + 1) -- + LT for its images.  (The last block is rarely full: its idle lanes are not waited for.)
+    {
+        const int rem = Tp - (g.nblk - 1) * nls;                // frames of the last block (1 .. nls)
+        const long end_last = (long)SKW * (rem - 1) + (long)g.P * g.nblk;
+        const long end_prev = g.nblk > 1 ? (long)SKW * (nls - 1) + (long)g.P * (g.nblk - 1) : 0;
+        g.U = (int)std::max(end_last, end_prev) + LT + 3;
+    }
     g.U += g.U & 1;
     // rows after the last one a step writes: the first slot's prefetch of step ux <= U - 1 + PFD reads row ux + LT + SKW r + gap
     g.rows = (long)g.U + PFD + LT + (long)SKW * (Q - 1) + g.gap + 8;

@@ -6,12 +6,12 @@ import numpy as np, torch, lws_amd
 from lws_amd import _capi
 quick = len(sys.argv) > 1 and sys.argv[1] in ("quick", "q8w")
 one = len(sys.argv) > 1 and sys.argv[1] == "q8w"
-def t(fsize, fshift, B, T, iters, precision="fp32", force_generic=False, reps=3, **kw):
+def t(fsize, fshift, B, T, iters, precision="fp32", force_generic=False, reps=3, default=False, **kw):
     F = fsize // 2 + 1
     p = lws_amd.lws(fsize, fshift, **kw)
     dt = np.complex64 if precision == "fp32" else np.complex128
     S = torch.from_numpy(np.abs(np.random.default_rng(0).standard_normal((B, T, F))).astype(dt)).cuda()
-    plan = _capi.Plan(F, p.W, precision=precision, force_generic=force_generic); thr = np.zeros(iters)
+    plan = _capi.Plan(F, p.W, precision=precision, force_generic=force_generic); thr = lws_amd.get_thresholds(iters, 100, 0.1, 1) if default else np.zeros(iters)     # default: the reference's default schedule (first ~38 of 100 sweeps are no-ops)
     plan.batch_dev(S.data_ptr(), B, T, thr); torch.cuda.synchronize()
     ms = []
     for _ in range(reps):
@@ -24,6 +24,7 @@ t(2048, 256, 256, 250, 20, reps=1 if one else 3)
 if one:
     sys.exit(0)
 t(2048, 256, 256, 500, 20)
+t(2048, 256, 256, 500, 100, default=True, reps=1)
 t(1024, 64, 256, 500, 10)
 t(1024, 256, 256, 500, 40, L=8)
 if quick:
