@@ -221,6 +221,12 @@ hipError_t launch_pass_any(const BandPlan &bp, const BArgs<real> &a, int B, hipS
         }
         return launch_pass<real, 5, 16, false, 0, 256>(a, B, stream);
     }
+    if (bp.LT == 8) {   // (Q = 4 only: band_plan)
+        if constexpr (F32) {
+            if (bp.helpers == 1) return launch_pass<real, 8, 4, true, 1, 512>(a, B, stream);
+        }
+        return launch_pass<real, 8, 4, true, 0, 256>(a, B, stream);
+    }
     if constexpr (F32) {
         if (Q == 4 && bp.helpers == 1) return launch_pass<real, 10, 4, true, 1, 512>(a, B, stream);
     }
@@ -232,7 +238,7 @@ hipError_t launch_pass_any(const BandPlan &bp, const BArgs<real> &a, int B, hipS
 inline int helpers_of(bool fp64, int LT, int Q) {
     if (LT == 5 && Q == 8) return Split<8>::NH;            // (fp64 too: a ring of 513 bins leaves one slot -- a second wave per CU)
     if (LT == 5 && Q == 16 && !fp64) return Split<16>::NH;
-    if (LT == 10 && Q == 4 && !fp64) return Split<4>::NH;  // (fp64: the slots the LDS holds already fill the 256 threads its registers allow)
+    if ((LT == 10 || LT == 8) && Q == 4 && !fp64) return Split<4>::NH;  // (fp64: the slots the LDS holds already fill the 256 threads its registers allow)
     return 0;
 }
 inline int max_threads(bool fp64, int LT, int QT, int helpers) { return fp64 ? 256 : ((helpers || (LT == 5 && QT == 8)) ? 512 : 256); }
@@ -274,7 +280,8 @@ inline double step_cost(int waves) {
 
 bool band_plan(bool fp64, int B, int F, int T, int L, int Q, int Qp, int update, int n_thr, const double *W, BandPlan *out) {
     if (!W || update != 2 || T < 1 || n_thr < 1 || Q < 2 || Q > 16 || L < 1 || L > 10 || Qp < 1) return false;
-    const int LT = L <= 5 ? 5 : 10, QT = Q <= 8 ? 8 : 16;
+    // the stencil half-width the kernel is compiled for: 5, 10, and 8 for Q = 4 (`lws(1024,256,L=8)`: frames 10 steps apart instead of 12)
+    const int LT = L <= 5 ? 5 : ((L <= 8 && Q == 4) ? 8 : 10), QT = Q <= 8 ? 8 : 16;
     if (F < 2 * LT + 7) return false;
     int Pt = 0, s = 0;
     if (!weights_twiddle(W, Q, Qp, L, 128, &Pt, &s)) return false;

@@ -212,6 +212,7 @@ extern "C" int band_emul_helpers(const double *S, double *out, int T, int F, con
     BAND_HCASE(5, 8)
     BAND_HCASE(5, 16)
     BAND_HCASE(10, 4)
+    BAND_HCASE(8, 4)
     return 1;
 }
 

@@ -29,11 +29,12 @@ def emul():
     lib = C.CDLL(SO)
     vp, ci = C.c_void_p, C.c_int
     lib.band_emul.argtypes = [vp, vp, ci, ci, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci]
+    lib.band_emul_helpers.argtypes = lib.band_emul.argtypes
     lib.band_emul_geometry.argtypes = [ci] * 7 + [vp]
     return lib
 
 
-def run(lib, oracle, fs, hop, T, iters, L=5, NS=2, SKW=8, nls=64, LT=5, QT=8, fp32=0, seed=0, alpha=1.0):
+def run(lib, oracle, fs, hop, T, iters, L=5, NS=2, SKW=8, nls=64, LT=5, QT=8, fp32=0, seed=0, alpha=1.0, helpers=False):
     p = lws_amd.lws(fs, hop, L=L)
     W = np.ascontiguousarray(p.W)
     Qp, Q, L1 = W.shape
@@ -48,7 +49,7 @@ def run(lib, oracle, fs, hop, T, iters, L=5, NS=2, SKW=8, nls=64, LT=5, QT=8, fp
     ths = np.ascontiguousarray(thr * np.mean(np.abs(S)))
     out = np.empty_like(S)
     W0 = np.ascontiguousarray(W[0])
-    rc = lib.band_emul(S.ctypes.data, out.ctypes.data, T, F, W0.ctypes.data, Q, L1 - 1, Pt, s, ths.ctypes.data, iters, NS, SKW, nls, LT, QT, fp32)
+    rc = (lib.band_emul_helpers if helpers else lib.band_emul)(S.ctypes.data, out.ctypes.data, T, F, W0.ctypes.data, Q, L1 - 1, Pt, s, ths.ctypes.data, iters, NS, SKW, nls, LT, QT, fp32)
     assert rc == 0, rc
     return np.abs(out - ref).max() / np.abs(ref).max()
 
@@ -79,6 +80,22 @@ def test_emulated_schedule_reproduces_the_oracle(emul, oracle, fs, hop, T, iters
     assert err < (2e-12 if (fs % hop) else 2e-13), err
 
 
+HELPER_CASES = [
+    (64, 8, 20, 3, {}), (64, 8, 150, 5, dict(NS=3)), (64, 8, 114, 3, {}), (64, 8, 70, 3, dict(SKW=7, NS=1)),     # Q = 8: main r = 1..3, one helper r = 4..7
+    (64, 4, 40, 3, dict(QT=16)),                                                                                  # Q = 16: three helpers
+    (64, 16, 30, 3, dict(L=8, LT=10, QT=4, SKW=12)), (64, 16, 70, 4, dict(L=10, LT=10, QT=4, SKW=13, NS=4)),      # Q = 4, wide stencils
+    (64, 16, 70, 4, dict(L=8, LT=8, QT=4, SKW=10, NS=4)), (64, 16, 70, 4, dict(L=6, LT=8, QT=4, SKW=11)),         # ... on the LT = 8 build
+    (2048, 256, 10, 2, dict(nls=128)),
+]
+
+
+@pytest.mark.parametrize("fs,hop,T,iters,kw", HELPER_CASES)
+def test_helper_waves_reproduce_the_oracle(emul, oracle, fs, hop, T, iters, kw):
+    """The exact builds' slots are a main wave and helper waves a step ahead of it (lws_band_core.h: Lane, Split): the frame offsets
+    shared out, the helpers' partial sums handed over through a mailbox two cells deep.  Same schedule on the CPU, ring ages asserted."""
+    assert run(emul, oracle, fs, hop, T, iters, helpers=True, **kw) < 2e-13
+
+
 def test_fp32_arithmetic(emul, oracle):
     assert run(emul, oracle, 64, 16, 70, 5, fp32=1) < 1e-4
     assert run(emul, oracle, 64, 8, 40, 4, fp32=1) < 1e-4
@@ -98,6 +115,9 @@ def test_geometry_of_the_shapes_the_engine_was_built_for(emul):
     # lws(1024,256, L=8) on the LT = 10 build
     g = geom(513, 500, 4, 10, 12, 64, 4)
     assert (g["P"], g["gap"], g["LAG"], g["R"]) == (768, 0, 48, 39)
+    # a sweep ends with the last real frame: 500 + 14 frames on 128 lanes = four full blocks and two frames
+    g = geom(1025, 500, 8, 5, 8, 128, 8)
+    assert g["nblk"] == 5 and g["U"] == 8 * 1 + 1032 * 5 + 5 + 3
     for F, Q, LT, SKW, nls in ((1025, 8, 5, 8, 128), (513, 16, 5, 7, 64), (513, 4, 10, 12, 64), (33, 2, 5, 7, 64), (4097, 4, 5, 9, 512)):
         g = geom(F, 100, Q, LT, SKW, nls, Q)
         assert g["P"] % SKW == 0 and g["P"] >= F + LT and g["LAG"] % 2 == 0 and g["U"] % 2 == 0

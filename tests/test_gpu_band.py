@@ -138,6 +138,41 @@ def test_the_geometry_is_scheduling_only_l8(monkeypatch):
     plan.close()
 
 
+def test_helper_waves_change_rounding_only(monkeypatch):
+    """The exact builds share a slot's frame offsets between a main wave and helper waves (LWS_BAND_NO_HELPERS=1: one wave per slot):
+    a bin's sum is then a sum of partial sums -- the same values to fp32 rounding, not the same bits."""
+    for fsize, fshift, L in ((2048, 256, 5), (1024, 64, 5), (1024, 256, 8)):
+        p = lws_amd.lws(fsize, fshift, L=L)
+        F = fsize // 2 + 1
+        S = spectrograms(2, 140, F, seed=fsize + L)
+        thr = lws_amd.get_thresholds(5, 1.0, 0.2, 1)
+        plan = _capi.Plan(F, p.W)
+        with_h = plan.batch(S, thr)
+        monkeypatch.setenv("LWS_BAND_NO_HELPERS", "1")
+        without = plan.batch(S, thr)
+        monkeypatch.delenv("LWS_BAND_NO_HELPERS")
+        assert plan.last_kernel()["name"] == "band_fp32"
+        assert not np.array_equal(with_h, without) and rel_l2(with_h, without) < 1e-4, (fsize, fshift, L, rel_l2(with_h, without))
+        plan.close()
+
+
+def test_passes_without_an_active_bin_are_dropped_per_spectrogram():
+    """The reference's default schedule starts with ~38 sweeps no bin takes part in; the band engine skips a pass of its
+    sweep slots for a spectrogram whose largest magnitude is below all of the pass's thresholds -- per spectrogram: one of another scale in
+    the same batch has another set of such passes.  Results equal the oracle's either way."""
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    p = lws_amd.lws(2048, 256)
+    S = np.abs(spectrograms(2, 30, 1025, seed=5, scale=[1.0, 300.0])).astype(np.complex128)
+    thr = np.array([50.0, 40.0, 3.9, 3.8, 1.0, 0.9, 1e9, 1e9, 0.5])      # x mean|S| of each spectrogram: the largest Rayleigh magnitude is ~3.8-4.5 x the mean
+    plan = _capi.Plan(1025, p.W)
+    out = plan.batch(S, thr)
+    assert plan.last_kernel()["name"] == "band_fp32"
+    for b in range(2):
+        check_fp32(out[b], orc.batch_lws(S[b], p.W, thr), S[b])
+    plan.close()
+
+
 def test_dropped_sweeps_and_untouched_bins():
     """Sweeps whose threshold no bin exceeds change nothing; a bin no sweep updates comes back bit for bit (complex128)."""
     p = lws_amd.lws(2048, 256)
