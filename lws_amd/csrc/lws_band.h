@@ -16,7 +16,7 @@ struct BandPlan {
     size_t state_bytes, amp_bytes;   // scratch: the time-skewed state of `chunk` spectrograms; the magnitudes
 };
 // What the band engine can run: MODE_BATCH, update == 2, 2 <= Q <= 16, L <= 10, F >= 2 LT + 7 (LT = 5 for L <= 5, else 10), a weight
-// tensor with create_weights' twiddle structure (lws.pyx:160-181; weights_twiddle(), twiddle period <= 128 bins -- for an fp64 plan
+// tensor with create_weights' twiddle structure (lws.pyx:160-181; weights_twiddle(), any twiddle period whose table leaves room for a ring in the LDS -- for an fp64 plan
 // a summarised tensor (Qp == Q) whose rows are twiddle images of row 0 to 1e-13, so that the results are the reference's to rounding) and a frame short enough for one sweep
 // slot's ring in the LDS (Q F complex values: e.g. Q = 8 at 1025 bins, Q = 16 at 513 bins in fp32; half that in fp64).
 // W: the plan's tensor on the host (complex128 interleaved, [Qp][Q][L+1]).  False: the caller uses the generic engine.

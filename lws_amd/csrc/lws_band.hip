@@ -284,7 +284,8 @@ bool band_plan(bool fp64, int B, int F, int T, int L, int Q, int Qp, int update,
     const int LT = L <= 5 ? 5 : ((L <= 8 && Q == 4) ? 8 : 10), QT = Q <= 8 ? 8 : 16;
     if (F < 2 * LT + 7) return false;
     int Pt = 0, s = 0;
-    if (!weights_twiddle(W, Q, Qp, L, 128, &Pt, &s)) return false;
+    // (any twiddle period whose table still leaves room for a ring: a hop with no common factor with the frame has Pt = the frame)
+    if (!weights_twiddle(W, Q, Qp, L, 4096, &Pt, &s)) return false;
     if (Pt < 1) { Pt = 1; s = 0; }
     // (fp64: the rows must be the twiddle images of row 0 to rounding, or the results would not be the reference's.  The general
     //  tensors create_weights builds for a hop that does not divide the frame -- one row per bin, numpy's exp of an angle of up to N
@@ -304,6 +305,7 @@ bool band_plan(bool fp64, int B, int F, int T, int L, int Q, int Qp, int update,
         for (int SKW = LT + 2; SKW <= LT + 2 + 10; ++SKW) {
             if (skw_force && SKW != skw_force) continue;
             const Geom g = geometry(F, T, Q, LT, SKW, nls, Pt, helpers);
+            if (table_bytes(g, LT, csize) + 1024 >= LDS_BYTES) continue;
             const size_t avail = LDS_BYTES - table_bytes(g, LT, csize);
             int NS = (int)std::min<size_t>(avail / (ring_bytes(g, csize) + mail_bytes(g, helpers, csize)), (size_t)(maxt / (nls * (1 + helpers))));
             NS = std::min(NS, n_thr);

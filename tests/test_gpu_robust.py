@@ -139,7 +139,9 @@ def test_generic_batch_on_the_skewed_copy_is_bit_identical(fsize, fshift, L, T, 
 
 @pytest.mark.parametrize("fsize,fshift,T,mode", [(1024, 256, 70, "batch"), (512, 128, 131, "batch"), (2048, 512, 40, "batch"), (1024, 128, 37, "batch"),
                                                  (1024, 512, 66, "batch"), (4096, 1024, 20, "batch"), (1000, 250, 37, "batch"), (1024, 256, 33, "music"),
-                                                 (400, 160, 40, "music"), (1000, 200, 37, "batch")])
+                                                 (400, 160, 40, "music"), (1000, 200, 37, "batch"),
+                                                 # the band engine (round 6): helper waves, a partly filled last block, Q = 16, table twiddles on long frames
+                                                 (2048, 256, 70, "batch"), (1024, 64, 40, "batch"), (2000, 400, 33, "batch"), (2048, 256, 20, "music")])
 def test_stale_device_memory_never_reaches_a_result(fsize, fshift, T, mode):
     """A plan's scratch comes from hipMalloc as it is; LDS is what the previous kernel left.  Whatever sits in the entries of a
     kernel's layout that no (frame, bin) owns must not reach a result, not even through a zero weight (0 x NaN): the same call on a
