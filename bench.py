@@ -437,7 +437,7 @@ def _source_hashes():
     return out
 
 
-_PROFILE_KERNEL_OF = {"systolic": "k_systolic", "online": "k_online", "nofuture": "k_nofuture"}
+_PROFILE_KERNEL_OF = {"systolic": "k_systolic", "online": "k_online", "nofuture": "k_nofuture", "band": "k_band<"}
 
 
 def traffic_entry_matches(ent, kname):
@@ -475,11 +475,67 @@ def load_traffic(kname, config, stage=None):
             src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; not this run)" % fn
             rec = d.get("_sources") or {}
             now = _source_hashes()
-            changed = sorted(k for k in rec if k in now and rec[k] != now[k])
+            # (only the sources of the kernel that ran: a change of the band engine does not age the systolic kernel's figure)
+            mine = {"systolic": ("lws_systolic.hip", "lws_common.h"), "online": ("lws_online.hip", "lws_common.h"), "nofuture": ("lws_nofuture.hip", "lws_common.h"),
+                    "band": ("lws_band.hip", "lws_band_core.h", "lws_common.h")}
+            keep = next((v for k, v in mine.items() if str(kname).startswith(k)), None)
+            changed = sorted(k for k in rec if k in now and rec[k] != now[k] and (keep is None or k in keep))
             if changed:
                 src = "STALE (%s changed since) " % ",".join(changed) + src
             return ent["hbm_bytes_per_launch"], src
     return None, refused
+
+
+def measure_traffic(config, kname, timeout_s=300):
+    """HBM bytes per step of the update kernel, MEASURED NOW: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE: separate
+    passes, with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes) around a child `bench.py --config <config>
+    --no-extras --steps 1 --warmup 1` of this very workload, read back from the rocpd database: (2 FETCH_SIZE + WRITE_SIZE) KiB of the
+    timed step's launches of the kernel the plan ran (gfx950 tallies 128-B fetches as 64 B: doubled; WRITE_SIZE is exact).  Runs after
+    the timed region, outside it.  Returns (bytes, source) or (None, why not) -- the caller then falls back to the committed profile."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    fam = next((v for k, v in _PROFILE_KERNEL_OF.items() if str(kname).startswith(k)), None)
+    if not fam:
+        return None, "no profiler kernel name known for %s" % kname
+    work = tempfile.mkdtemp(prefix="lws_traffic_", dir="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--config", config,
+                   "--no-extras", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-traffic-pass", "--extra-file", os.path.join(work, "extra.json")]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (ctr, r.returncode)
+            con = sqlite3.connect(dbs[0])
+            tabs = [t[0] for t in con.execute("select name from sqlite_master where type in ('table','view')")]
+            ct = next((t for t in tabs if t.startswith("counters_collection")), None)
+            if not ct:
+                return None, "no counters in the rocpd database"
+            cols = [c[1] for c in con.execute("pragma table_info(%s)" % ct)]
+            order = "dispatch_id" if "dispatch_id" in cols else "rowid"
+            v = [x[0] for x in con.execute("select value from %s where counter_name=? and kernel_name like ? order by %s" % (ct, order), (ctr, "%" + fam + "%"))]
+            con.close()
+            if not v:
+                return None, "no dispatch of %s in the profile" % fam
+            # the child ran a warm-up step and the timed step with the same number of launches: the step is the second half
+            per_step = max(1, len(v) // 2)
+            vals[ctr] = float(sum(v[-per_step:]))
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes around a child run of "
+                                                                            "this workload (2 x FETCH + WRITE, KiB)")
+    except Exception as e:       # (a profiler problem must never cost the line)
+        return None, "traffic pass failed: %s: %s" % (type(e).__name__, str(e)[:120])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def _free_port():
@@ -627,6 +683,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-default-schedule", action="store_true")
+    ap.add_argument("--no-traffic-pass", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs (the committed profile is quoted instead)")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--extra-file", default=None, help="where the full (non-contract) results go (default: gpurun_out/bench_extra.json if "
                                                        "that directory exists, else ./bench_extra.json)")
@@ -779,6 +836,17 @@ def main():
     B, T, F, iters = head["batch_per_gpu"], head["frames"], head["bins"], head["iters"]
     roof = dict(head["roofline"])
     extra = {"headline_checks": head.get("checks")}
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and rank == 0 and not args.no_traffic_pass and not under_profiler and not args.force_generic and args.batch is None and args.frames is None and args.iters is None \
+            and args.schedule == "dense":
+        # roofline.traffic measured in this run (two rocprofv3 --pmc passes around a child run of the headline workload: ~1 min);
+        # the committed profile's figure stays in the extra file beside it
+        got, how = measure_traffic(args.config, roof["kernel"])
+        extra["traffic_pass"] = {"bytes": got, "how": how, "committed_profile": {"bytes": roof.get("traffic"), "source": roof.get("traffic_source")}}
+        if got:
+            sec = roof["kernel_ms_per_step"] * 1e-3
+            roof["traffic"], roof["traffic_source"] = got, how
+            roof["hbm_measured_frac"] = got / sec / 1e9 / HBM_PEAK_GBS
     if head.get("rank_ms_per_step"):
         extra["rank_ms_per_step"] = head["rank_ms_per_step"]     # every rank's own step time: a straggler shows as min / max
     if pinned:

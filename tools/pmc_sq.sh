@@ -12,12 +12,12 @@ P3="GRBM_GUI_ACTIVE SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU S
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $P -d $OUT/pass$i -o $TAG -- python bench.py --no-extras --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pass$i.err
+  timeout 600 rocprofv3 --kernel-trace --pmc $P -d $OUT/pass$i -o $TAG -- python bench.py --no-extras --steps 2 --warmup 1 --no-cpu-baseline --no-traffic-pass > /dev/null 2> $OUT/pass$i.err
 done
 python3 - $OUT $TAG <<'PY'
 import glob, json, os, sqlite3, sys
 out, tag = sys.argv[1], sys.argv[2]
-res = {"_how": "tools/pmc_sq.sh: rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --no-extras --steps 2 --warmup 1 --no-cpu-baseline, "
+res = {"_how": "tools/pmc_sq.sh: rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --no-extras --steps 2 --warmup 1 --no-cpu-baseline --no-traffic-pass, "
                "three passes; k_systolic<4,5,hann> dispatches only (256 workgroups x 8 waves, 100 dense sweeps); sums over the chip, "
                "averaged over the dispatches seen.  SQ cycle counters tick once per 4 clocks.", "counters": {}}
 for d in sorted(glob.glob(os.path.join(out, "pass*"))):

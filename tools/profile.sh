@@ -7,16 +7,16 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --extra-file $OUT/extra_traced.json > $OUT/bench_traced.json 2> $OUT/trace.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traffic-pass --extra-file $OUT/extra_traced.json > $OUT/bench_traced.json 2> $OUT/trace.err
 # the headline workload alone (config 2 only): the per-kernel averages of this one are those of bench.py's roofline block
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_headline -o $TAG -- python bench.py --steps 5 --warmup 1 --no-extras --no-cpu-baseline --extra-file $OUT/extra_scratch.json > $OUT/bench_traced_headline.json 2> $OUT/trace_headline.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_headline -o $TAG -- python bench.py --steps 5 --warmup 1 --no-extras --no-cpu-baseline --no-traffic-pass --extra-file $OUT/extra_scratch.json > $OUT/bench_traced_headline.json 2> $OUT/trace_headline.err
 for cfg in 2 2-T1024 2-q2 2-q8 2-q3 2-frac 2-speech 2-q5 2-q8w 2-q16 2-l8 2-f501 2-f257 4shard 5 5-f16; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_${ctr}_$cfg -o $TAG -- python bench.py --config $cfg --no-extras --steps 1 --warmup 1 --no-cpu-baseline --extra-file $OUT/extra_scratch.json > $OUT/pmc_line_$cfg.json 2> $OUT/pmc_${ctr}_$cfg.err
+    timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_${ctr}_$cfg -o $TAG -- python bench.py --config $cfg --no-extras --steps 1 --warmup 1 --no-cpu-baseline --no-traffic-pass --extra-file $OUT/extra_scratch.json > $OUT/pmc_line_$cfg.json 2> $OUT/pmc_${ctr}_$cfg.err
   done
 done
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_${ctr}_3 -o $TAG -- python bench.py --extras 3 --steps 1 --warmup 1 --no-cpu-baseline --extra-file $OUT/extra_3.json > /dev/null 2> $OUT/pmc_${ctr}_3.err
+  timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_${ctr}_3 -o $TAG -- python bench.py --extras 3 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic-pass --extra-file $OUT/extra_3.json > /dev/null 2> $OUT/pmc_${ctr}_3.err
 done
 python3 tools/collect_profiles.py $OUT $OUT/summary $TAG
 # the rocpd databases are tens of MiB each: only the summaries (and the error logs) travel back
