@@ -101,7 +101,9 @@ __global__ void __launch_bounds__(MAXT) k_band(BArgs<real> a) {
     // waves in the order [role][slot][part of the ring row]: the hardware deals consecutive waves to the four SIMDs in turn, so a
     // SIMD gets a main wave AND a helper wave (their instruction counts differ) rather than two of a kind
     const int sub = wave / (a.nsl * wps);                           // 0: the slots' main waves; 1 .. NH: their helpers
-    const int s = (wave / wps) % a.nsl;                             // sweep slot
+    // (... and the helpers of the slots in an order rotated by half the slots against the main waves': the first slot's waves also
+    //  issue the loads from the skewed state -- a SIMD gets one of them, not both)
+    const int s = ((wave / wps) % a.nsl + (sub & 1) * (a.nsl / 2)) % a.nsl;   // sweep slot
     const int lane = (wave % wps) * 64 + (threadIdx.x & 63);        // place in the slot's ring row
     {
         // a pass none of whose sweeps has a bin above its threshold changes nothing (lwslib.cpp:295-296: strict '>'): the first ~38 of

@@ -73,6 +73,49 @@ template <typename real> BAND_FN V2<real> turn(V2<real> v) { return V2<real>{-v.
 template <typename real, typename C> BAND_FN V2<real> pr(C v) { return V2<real>{v.x, v.y}; }
 template <typename real> BAND_FN V2<real> vsel(bool c, V2<real> a, V2<real> b) { return V2<real>{c ? a.x : b.x, c ? a.y : b.y}; }
 
+// Pair arithmetic with one component of a complex weight w = (w.x, w.y) as the scalar factor.  Generic text first; on the GPU in fp32
+// each is ONE packed instruction whose operand modifiers pick the component for both halves, swap the halves of the pair (j s) and
+// negate -- written out below because the compiler does not derive them (it builds (w.x, w.x) with two moves per weight).
+template <typename real, typename C> BAND_FN V2<real> mul_x(C w, V2<real> s) { return splat<real>(w.x) * s; }                     // w.x s
+template <typename real, typename C> BAND_FN V2<real> mul_xj(C w, V2<real> s) { return splat<real>(w.x) * turn<real>(s); }          // w.x j s
+template <typename real, typename C> BAND_FN V2<real> fma_x(V2<real> a, C w, V2<real> s) { return vfma<real>(splat<real>(w.x), s, a); }    // a + w.x s
+template <typename real, typename C> BAND_FN V2<real> fma_y(V2<real> a, C w, V2<real> s) { return vfma<real>(splat<real>(w.y), s, a); }    // a + w.y s
+template <typename real, typename C> BAND_FN V2<real> fnma_y(V2<real> a, C w, V2<real> s) { return vfma<real>(-splat<real>(w.y), s, a); }  // a - w.y s
+template <typename real, typename C> BAND_FN V2<real> fma_yj(V2<real> a, C w, V2<real> s) { return vfma<real>(splat<real>(w.y), turn<real>(s), a); }   // a + w.y j s
+#if defined(__HIPCC__)
+typedef float band_v2f __attribute__((ext_vector_type(2)));
+template <> BAND_FN band_v2f mul_x<float, float2>(float2 w, band_v2f s) {
+    band_v2f r; const band_v2f wv = {w.x, w.y};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(wv), "v"(s));
+    return r;
+}
+template <> BAND_FN band_v2f mul_xj<float, float2>(float2 w, band_v2f s) {
+    band_v2f r; const band_v2f wv = {w.x, w.y};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(wv), "v"(s));
+    return r;
+}
+template <> BAND_FN band_v2f fma_x<float, float2>(band_v2f a, float2 w, band_v2f s) {
+    const band_v2f wv = {w.x, w.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a) : "v"(wv), "v"(s));
+    return a;
+}
+template <> BAND_FN band_v2f fma_y<float, float2>(band_v2f a, float2 w, band_v2f s) {
+    const band_v2f wv = {w.x, w.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(wv), "v"(s));
+    return a;
+}
+template <> BAND_FN band_v2f fnma_y<float, float2>(band_v2f a, float2 w, band_v2f s) {
+    const band_v2f wv = {w.x, w.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(a) : "v"(wv), "v"(s));
+    return a;
+}
+template <> BAND_FN band_v2f fma_yj<float, float2>(band_v2f a, float2 w, band_v2f s) {
+    const band_v2f wv = {w.x, w.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(a) : "v"(wv), "v"(s));
+    return a;
+}
+#endif
+
 template <typename C> BAND_FN C cj(C v) { v.y = -v.y; return v; }
 template <typename C> BAND_FN C sel(bool c, C a, C b) { C r; r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; return r; }
 
@@ -127,6 +170,8 @@ struct Lane {
     C nxO, nxI;              // ... its old value of the frame itself and the image above Nyquist it may have to write
     C pfO[FIRST && !HELP ? PFD : 1], pfR[FIRST ? PFD : 1][FIRST ? NB : 1];   // first slot: inputs of the next PFD steps from the skewed state
     real pfA[HELP ? 1 : PFD];
+    C wfirst[K1];            // the weights of this wave's first frame offset, and of the frame's own taps (main wave): constants of the
+    C wown[HELP ? 1 : LT + 1];   // call, kept in registers -- read at the top of a step they would be an LDS round trip in everybody's way
     int w, me, tm, pmo;      // position in the frame period, frame, ring time, (w mod Pt) (Q - 1)
     int lane;
     const Env<real, C> &e;
@@ -146,6 +191,12 @@ struct Lane {
         // ring rows are addressed by the workgroup's time: a slot's main wave starts LAG steps after the slot before it (two steps
         // later still when helpers run a step ahead of it)
         tm = (int)(((long)e.g.LAG * slot_index + (HELP ? 1 : (NHELP ? 2 : 0))) % e.g.R);
+#pragma unroll
+        for (int k = 0; k <= LT; ++k) wfirst[k] = e.wt[(RLO + 1) * K1 + k];
+        if constexpr (!HELP) {
+#pragma unroll
+            for (int k = 0; k <= LT; ++k) wown[k] = e.wt[k];
+        }
     }
     // ring row written `age` steps before time t_mod.  A read issued for the NEXT step (t_mod = its time) sees rows of age >= 2: the
     // row of age 1 is being written while it is issued; a read of THIS step sees ages >= 1.
@@ -222,8 +273,8 @@ struct Lane {
                 for (int ct = 0; ct <= LT - PH; ++ct) {
                     const C v = wr[ct + PH];
                     P a = acc[ct + LT - PH];
-                    a = vfma<real>(splat<real>(v.x), Sc, a);
-                    a = vfma<real>(splat<real>(v.y), Dc, a);
+                    a = fma_x<real, C>(a, v, Sc);
+                    a = fma_y<real, C>(a, v, Dc);
                     acc[ct + LT - PH] = a;
                 }
             }
@@ -279,7 +330,7 @@ struct Lane {
         In cur = nx;
         C wcur[K1];              // the weights of the frame offset at hand, requested like its inputs: while the one before is worked on
 #pragma unroll
-        for (int k = 0; k <= LT; ++k) wcur[k] = e.wt[(RLO + 1) * K1 + k];
+        for (int k = 0; k <= LT; ++k) wcur[k] = wfirst[k];
 #pragma unroll
         for (int r = RLO; r < RHI; ++r) {
             if (r >= NR) continue;
@@ -294,29 +345,28 @@ struct Lane {
             }
             C Rv;
             if constexpr (FIRST) Rv = pfR[PB][r - RLO]; else Rv = in.R;
-            const P uu = pr<real>(in.L) + pr<real>(Rv), jv = turn<real>(pr<real>(in.L) - pr<real>(Rv));
-            const P tx = splat<real>(in.T.x), ty = splat<real>(in.T.y);
+            const P uu = pr<real>(in.L) + pr<real>(Rv), vv = pr<real>(in.L) - pr<real>(Rv);
             // A' = tau A, B' = conj(tau) B:  A' + B' = tau.x (A + B) + tau.y j (A - B),  j (A' - B') = tau.x j (A - B) - tau.y (A + B)
             SD t;
-            t.S = vfma<real>(ty, jv, tx * uu);
-            t.D = vfma<real>(-ty, uu, tx * jv);
+            t.S = fma_yj<real, C>(mul_x<real, C>(in.T, uu), in.T, vv);
+            t.D = fnma_y<real, C>(mul_xj<real, C>(in.T, vv), in.T, uu);
             sd[r - RLO] = t;
             // DC and Nyquist (below): the imaginary part of the k = 0 taps
             y0 = fma_<real>(wr[0].x, t.S.y, y0);
             y0 = fma_<real>(wr[0].y, t.D.y, y0);
             {
                 P a = acc[LT];
-                a = vfma<real>(splat<real>(wr[0].x), t.S, a);
-                acc[LT] = vfma<real>(splat<real>(wr[0].y), t.D, a);
+                a = fma_x<real, C>(a, wr[0], t.S);
+                acc[LT] = fma_y<real, C>(a, wr[0], t.D);
             }
 #pragma unroll
             for (int k = 1; k <= LT; ++k) {
                 const C v = wr[k];
                 P a = acc[LT + k], b = acc[LT - k];
-                a = vfma<real>(splat<real>(v.x), t.S, a);        // the taps below bin w + k:  V A' + conj(V) B'
-                b = vfma<real>(splat<real>(v.x), t.S, b);        // the taps above bin w - k:  V B' + conj(V) A'
-                acc[LT + k] = vfma<real>(splat<real>(v.y), t.D, a);
-                acc[LT - k] = vfma<real>(-splat<real>(v.y), t.D, b);
+                a = fma_x<real, C>(a, v, t.S);        // the taps below bin w + k:  V A' + conj(V) B'
+                b = fma_x<real, C>(b, v, t.S);        // the taps above bin w - k:  V B' + conj(V) A'
+                acc[LT + k] = fma_y<real, C>(a, v, t.D);
+                acc[LT - k] = fnma_y<real, C>(b, v, t.D);
             }
 #if defined(__HIPCC__)
             // (the requests of the next frame offset are in flight behind this one's arithmetic; moving more across this line only
@@ -383,10 +433,10 @@ struct Lane {
         }
 #pragma unroll
         for (int k = LT; k >= 1; --k) {
-            const C wv = e.wt[k];
+            const C wv = wown[k];
             const P b = pr<real>(cn[k]), cv = pr<real>(co[k]);
-            a0 = vfma<real>(splat<real>(wv.x), b + cv, a0);
-            a0 = vfma<real>(splat<real>(wv.y), turn<real>(b - cv), a0);
+            a0 = fma_x<real, C>(a0, wv, b + cv);
+            a0 = fma_yj<real, C>(a0, wv, b - cv);
         }
         // ---- re-projection on the target magnitude (lwslib.cpp:356-360)
         a0.y = (c == 0 || c == F - 1) ? yE : a0.y;
