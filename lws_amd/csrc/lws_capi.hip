@@ -20,6 +20,7 @@
 #include "lws_band.h"
 #include "lws_online.h"
 #include "lws_online64.h"
+#include "lws_team.h"
 
 #include <atomic>
 #include <chrono>
@@ -439,6 +440,22 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
             p->generic_stage = "batch";
             return LWS_OK;
         }
+    }
+    // online and no-future sweeps no LDS engine takes (more than 8 frames per stencil row, L > 5, weights without the twiddle
+    // structure, frames beyond the rings): the team engine (lws_team.hip) -- the generic engine's schedule with a bin's taps spread
+    // over a team of lanes.  Same sweeps in the reference's order; a bin's sum in another order.
+    // (the serial-taps verification variants of the LDS engines promise the generic engine's bits: they keep falling through to it,
+    // as do fp64 plans under LWS_NO_ONLINE64)
+    if ((mode == lws::MODE_ONLINE || mode == lws::MODE_NOFUTURE) && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_TEAM", 0) &&
+        !env_int("LWS_ONLINE_SERIAL_TAPS", 0) && !env_int("LWS_NOFUTURE_SERIAL_TAPS", 0) && !(p->fp64 && env_int("LWS_NO_ONLINE64", 0)) &&
+        lws::team_supports(mode, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr)) {
+        begin_timing(p, s);
+        hipError_t e = lws::launch_team<real>(a, B, s);
+        end_timing(p, s);
+        if (e != hipSuccess) return fail(LWS_ERR_HIP, "team engine launch failed: %s", hipGetErrorString(e));
+        p->last_launches = 1;
+        p->last_name = mode == lws::MODE_ONLINE ? (p->fp64 ? "team_online_fp64" : "team_online_fp32") : (p->fp64 ? "team_nofuture_fp64" : "team_nofuture_fp32");
+        return LWS_OK;
     }
     begin_timing(p, s);
     hipError_t e = lws::launch_generic<real>(a, B, s);

@@ -1,0 +1,18 @@
+// lws_team.h -- interface of the team engine (lws_team.hip): the generic engine's wavefront schedule with the taps of a bin
+// spread over a team of lanes.
+#pragma once
+#include "lws_common.h"
+
+namespace lws {
+
+// true if launch_team can run this stage: mode MODE_ONLINE or MODE_NOFUTURE, any weights (summarised or general), any Q, L;
+// the units a wavefront step holds must fit one workgroup with at least two lanes each (else the generic engine is as good).
+bool team_supports(int mode, int F, int T, int L, int Q, int Qp, int LA, int n_thr);
+// Same contract as launch_generic (same sweeps, same order of bins, same arithmetic per tap); a bin's sum is taken as per-lane
+// partial sums in a fixed order, so results agree with the generic engine to rounding, not bit for bit.
+template <typename real>
+hipError_t launch_team(const GenericArgs<real> &a, int B, hipStream_t stream);
+// lanes per bin the launcher chooses for this stage (reported by the tests / tools)
+int team_lanes(int mode, int F, int T, int L, int Q, int LA, int n_thr);
+
+}  // namespace lws

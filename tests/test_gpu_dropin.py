@@ -68,14 +68,21 @@ def test_generic_engine_fallback_warns_once():
         lws_amd.lws(1024, 256, batch_iterations=3, batch_alpha=1.0).batch_lws(np.abs(rng.standard_normal((6, 513))))
 
 
-def test_a_generic_stage_inside_a_pipeline_warns_too():
+def test_a_generic_stage_inside_a_pipeline_warns_too(monkeypatch):
     """run_lws(mode='music') with L = 7: the batch stage has its systolic build (frames 16 steps apart), the online stage has no
-    kernel for that stencil and runs on the generic engine -- the last kernel's name does not say so, the warning does
-    (lws_generic_stage)."""
+    LDS kernel for that stencil: it runs on the team engine (no warning) -- and on the generic engine when the team engine is
+    switched off: the last kernel's name does not say so, the warning does (lws_generic_stage)."""
+    import warnings
     import lws_amd
     rng = np.random.default_rng(1)
-    p = lws_amd.lws(1024, 256, L=7, mode="music", online_iterations=2, batch_iterations=3, batch_alpha=1.0)
     S = np.abs(rng.standard_normal((9, 513)) + 1j * rng.standard_normal((9, 513)))
+    p = lws_amd.lws(1024, 256, L=7, mode="music", online_iterations=2, batch_iterations=3, batch_alpha=1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        p.run_lws(S)
+    assert "_l7_" in p.plan().last_kernel()["name"]
+    monkeypatch.setenv("LWS_NO_TEAM", "1")
+    p = lws_amd.lws(1024, 256, L=7, mode="music", online_iterations=2, batch_iterations=3, batch_alpha=1.0)
     with pytest.warns(RuntimeWarning, match="online stage"):
         p.run_lws(S)
     assert "_l7_" in p.plan().last_kernel()["name"]

@@ -168,16 +168,25 @@ def test_frames_of_4096_points(fsize, fshift, T, iters, LA, oracle, monkeypatch)
         assert name == "generic_fp32"
 
 
-def test_fallbacks_to_generic():
-    """More than 8 frames per stencil row stays on the generic engine, in fp32 and in fp64.  (Q = 3, 5, 6, 7 and fractional Q: the
-    table-twiddle variant of the fourth layout, tests/test_gpu_tw.py; fp64 plans of Q in {2,3,4,8}: lws_online64.hip, tests/test_gpu_online64.py.)"""
+def test_more_than_eight_frames_per_row_go_to_the_team_engine(monkeypatch):
+    """More than 8 frames per stencil row has no LDS engine: the team engine (lws_team.hip, tests/test_gpu_team.py) in fp32 and in fp64,
+    the generic engine with LWS_NO_TEAM=1.  (Q = 3, 5, 6, 7 and fractional Q: the table-twiddle variant of the fourth layout,
+    tests/test_gpu_tw.py; fp64 plans of Q in {2,3,4,8}: lws_online64.hip, tests/test_gpu_online64.py.)"""
     rng = np.random.default_rng(0)
     p = lws_amd.lws(144, 16, mode="music")           # Q = 9
     S = rng.standard_normal((9, 73)) + 1j * rng.standard_normal((9, 73))
     out, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0)
+    assert name == "team_online_fp32"
+    out64, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0, precision="fp64")
+    assert name == "team_online_fp64"
+    monkeypatch.setenv("LWS_NO_TEAM", "1")
+    gen, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0)
     assert name == "generic_fp32"
-    out, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0, precision="fp64")
+    gen64, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0, precision="fp64")
     assert name == "generic_fp64"
+    monkeypatch.delenv("LWS_NO_TEAM")
+    assert np.abs(out64 - gen64).max() < 1e-10 * np.abs(S).max()
+    assert np.linalg.norm(out - gen) < 1e-3 * np.linalg.norm(gen)
     p = lws_amd.lws(64, 16, mode="music")
     S = rng.standard_normal((9, 33)) + 1j * rng.standard_normal((9, 33))
     out, name = _online(33, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 4.0, precision="fp64")
