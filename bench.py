@@ -889,7 +889,7 @@ def main():
     elif args.extras is not None:
         wanted = [x for x in args.extras.split(",") if x]
     elif world == 1 and args.config == "2":
-        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-q5", "2-q8w", "2-q16", "2-l8", "2-f501", "2-f257", "2-fp64", "4shard", "3", "3-b1024", "3-fp64", "host_api", "1", "5", "5-f16"]
+        wanted = ["2-default", "2-single", "2-T1024", "2-q2", "2-q8", "2-q3", "2-frac", "2-speech", "2-q5", "2-q8w", "2-q16", "2-l8", "2-f501", "2-f257", "2-fp64", "4shard", "3", "3-b1024", "3-q16", "3-fp64", "host_api", "1", "5", "5-f16"]
     else:
         wanted = ["4shard"] if args.config == "2" else []
     if args.no_default_schedule and "2-default" in wanted:
@@ -914,6 +914,10 @@ def main():
                 # config 3's pipeline on 1024 spectrograms: the no-future and online stages run one workgroup per spectrogram, two of
                 # them per CU side by side when the batch is larger than the chip
                 cfgs["3-b1024"] = run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, args.force_generic, B=1024)
+            elif name == "3-q16":
+                # the same pipeline at hop = frame/16 (lws(1024, 64)): no LDS engine takes its no-future and online stages -- the
+                # team engine (round 6; the generic engine: 145 ms and 30.8 s for 64 spectrograms), the batch stage on the band engine
+                cfgs["3-q16"] = run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, args.force_generic, fsize=1024, fshift=64, tag="3-q16")
             elif name == "host_api":
                 cfgs["host_api"] = run_host_api(torch, lws_amd, dev, local_rank)
             elif name == "1":
@@ -996,6 +1000,8 @@ def main():
                 also["config3_ms"] = float(c["3"]["total_wall_ms"])
             if "total_wall_ms" in (c.get("3-fp64") or {}):
                 also["fp64_config3_ms"] = float(c["3-fp64"]["total_wall_ms"])
+            if "online" in (c.get("3-q16") or {}):                       # lws(1024,64) music mode: online stage on the team engine (generic: 30.8 s / 64)
+                also["q16_online_ms"] = float(c["3-q16"]["online"]["kernel_ms"])
             if "wall_ms" in (c.get("host_api") or {}):
                 also["host_api_ms"] = float(c["host_api"]["wall_ms"])
             if "kernel_ps_per_bin_sweep" in (c.get("2-q8w") or {}):      # lws(2048,256) on the band engine (generic engine: 235)
@@ -1008,13 +1014,13 @@ def main():
         dist.destroy_process_group()
 
 
-def run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, force_generic, B=256, T=500):
+def run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, force_generic, B=256, T=500, fsize=1024, fshift=256, tag=None):
     """BASELINE config 3: the run_lws pipeline of lws(1024, 256, mode='music') -- 1 no-future sweep (W_ai, alpha 1),
     10 online iterations with look-ahead 3, 100 batch sweeps of the default schedule -- stage by stage on the device,
     each stage with its own roofline block (algorithmic bytes of SURVEY 8(d): 20 B per active bin-sweep, 4 B per
     inactive one; the online stage runs 1 + iters*(LA+1) frame sweeps per frame)."""
-    F = 513
-    pm = lws_amd.lws(1024, 256, mode="music", device=local_rank, force_generic=force_generic)
+    F = fsize // 2 + 1
+    pm = lws_amd.lws(fsize, fshift, mode="music", device=local_rank, force_generic=force_generic)
     planm = pm.plan()
     mags = torch.from_numpy(synth_magnitudes(B, T, F, 20260928 + rank * B)).to(dev)
     state = torch.empty((B, T, F), dtype=torch.complex64, device=dev)
@@ -1023,11 +1029,11 @@ def run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, force_g
     thr_b = lws_amd.get_thresholds(pm.batch_iterations, pm.batch_alpha, pm.batch_beta, pm.batch_gamma)
     stages = [
         ("nofuture", thr_nf, 1, lambda: planm.nofuture_dev(state.data_ptr(), B, T, thr_nf, wsel=1, stream=stream)),
-        ("online", thr_on, pm.look_ahead + 1, lambda: planm.online_dev(state.data_ptr(), B, T, thr_on, pm.look_ahead, 4.0, stream=stream)),
+        ("online", thr_on, pm.look_ahead + 1, lambda: planm.online_dev(state.data_ptr(), B, T, thr_on, pm.look_ahead, fsize / fshift, stream=stream)),
         ("batch", thr_b, 1, lambda: planm.batch_dev(state.data_ptr(), B, T, thr_b, stream=stream)),
     ]
-    c3 = {"workload": "BASELINE config 3: run_lws(mode='music') on %d spectrograms of %d x %d, lws(1024,256): 1 no-future sweep, "
-                      "10 online iterations (look-ahead 3), 100 default-schedule batch sweeps" % (B, T, F)}
+    c3 = {"workload": "%srun_lws(mode='music') on %d spectrograms of %d x %d, lws(%d,%d): 1 no-future sweep, "
+                      "10 online iterations (look-ahead 3), 100 default-schedule batch sweeps" % ("BASELINE config 3: " if tag is None else "", B, T, F, fsize, fshift)}
     # bin-sweeps of each stage (what its thresholds let through), from the state each stage starts from: an untimed pass
     work = {}
     state.copy_(mags)
@@ -1053,7 +1059,7 @@ def run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, force_g
             wall = 1e3 * (time.perf_counter() - t0)
             act, nominal = work[name]
             alg = 16.0 * act + 4.0 * nominal
-            traffic, tsrc = load_traffic(info["name"], "3" if B == 256 else "3-b%d" % B, stage=name)
+            traffic, tsrc = load_traffic(info["name"], tag or ("3" if B == 256 else "3-b%d" % B), stage=name)
             Wst = pm.W_ai if name == "nofuture" else pm.W      # (the online stage mixes W, W_ai, W_af: priced with W)
             c3[name] = {"wall_ms": wall, "kernel_ms": info["ms"], "kernel": info["name"], "bin_sweeps": nominal, "active_bin_sweeps": act,
                         # batch: vector-ALU issue; no-future / online: the dependent chain of a step (barrier rounds, LDS round
@@ -1062,9 +1068,9 @@ def run_config3(torch, lws_amd, dev, local_rank, rank, stream, sync_all, force_g
         c3["total_wall_ms"] = 1e3 * (time.perf_counter() - t_all)
     c3["iterations"] = {"nofuture": pm.nofuture_iterations, "online": pm.online_iterations, "batch": pm.batch_iterations,
                         "look_ahead": pm.look_ahead}
-    c0 = lws_amd._capi.consistency_dev(mags[:4].to(torch.complex64).data_ptr(), 4, T, 1024, 256, pm.awin, pm.swin, pm.perfectrec,
+    c0 = lws_amd._capi.consistency_dev(mags[:4].to(torch.complex64).data_ptr(), 4, T, fsize, fshift, pm.awin, pm.swin, pm.perfectrec,
                                        device=local_rank, stream=stream).sum(axis=0)
-    c1 = lws_amd._capi.consistency_dev(state[:4].data_ptr(), 4, T, 1024, 256, pm.awin, pm.swin, pm.perfectrec,
+    c1 = lws_amd._capi.consistency_dev(state[:4].data_ptr(), 4, T, fsize, fshift, pm.awin, pm.swin, pm.perfectrec,
                                        device=local_rank, stream=stream).sum(axis=0)
     c3["checks"] = {"max_rel_magnitude_error": float(((state.abs() - mags).abs().max() / mags.max()).item()),
                     "consistency_db_before": float(10 * np.log10(c0[0] / c0[1])), "consistency_db_after": float(10 * np.log10(c1[0] / c1[1]))}

@@ -215,10 +215,10 @@ class Plan:
             import warnings
             warnings.warn(
                 "lws_amd: this plan (F=%d bins, Q=%d, L=%d%s) runs on the order-exact generic engine (%s), 20-40x slower than "
-                "the systolic / LDS kernels; those serve fp32 plans with create_weights() tensors (summarised, or general with rows that "
-                "repeat) of up to 8 frames per stencil row: batch sweeps for F-1 from 16 (24 unless a multiple of 8) to 2048 (hop = frame/3 or not "
-                "dividing it: to 1024; 5..8 frames per row: to 512) and L <= 5 (Q in {2,4}, F <= 513: L <= 7); online sweeps for "
-                "L <= 5; no-future sweeps whenever the frame ring fits the LDS"
+                "the systolic / band / LDS kernels; those serve batch sweeps of plans with create_weights() tensors (summarised, or general "
+                "with rows that repeat) of up to 16 frames per stencil row, L <= 10 and frames of 17 bins or more (band engine: as long as one "
+                "sweep slot's ring fits the LDS); online and no-future sweeps of any tensor run on their LDS engines or on the team engine "
+                "unless a wavefront step holds more than 512 bins (long frames at a small Q)"
                 % (self.F, self.Q, self.L, "" if self.Qp == self.Q else ", general weights", name), RuntimeWarning, stacklevel=3)
 
     def close(self):

@@ -19,6 +19,7 @@
 #include "lws_team.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace lws {
 namespace {
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
     }
     // ---- the ring: extended frame e lives in row e mod NWR (targets: e mod NWA); frames [0, loaded) have been brought in
     int loaded = 0;
-    auto bring = [&]() {   // the next frame in, the one it replaces out
+    auto bring = [&]() __attribute__((always_inline)) {   // the next frame in, the one it replaces out
         const int e = loaded, row = (e % NWR) * Np, rowa = (e % NWA) * Np;
         for (int i = tid; i < Np; i += nthr) {
             if (e >= NWR) gS[(size_t)(e - NWR) * Np + i] = ring[row + i];
@@ -280,9 +281,11 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
     while (loaded <= Q - 1 && loaded <= e_last) bring();       // the pad frames on the left and frame 0
     __syncthreads();
     const int G = tg.G, g = tid & (G - 1), team = tid / G;
-    int lt[CH];                                                // the lane's first chunk of terms
+    constexpr int NC = sizeof(real) == 8 ? CH : 2 * CH;        // terms of a lane whose placement is kept in registers (fp32: two chunks)
+    int lt[NC];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) { const int jj = g + i * G; lt[i] = jj < NT ? tt[jj] : (1 << 12); }
+    for (int i = 0; i < NC; ++i) { const int jj = g + i * G; lt[i] = jj < NT ? tt[jj] : (1 << 12); }
+    const bool two_chunks = g + CH * G < NT;
     const int LA = a.LA, per = a.n_thr + 1, rps = LA + 1;
     const int slot = team / rps, j = team - slot * rps;
     const long nsweeps = (long)T * per;
@@ -291,24 +294,24 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
     long t_bring = t_frame;                                    // ... and needs extended frame m + Q - 1 from then on (m = 1 next)
     long s = slot < tg.nsl ? slot : nsweeps;
     long t0 = 0, s_end = -1;
+    int c = 0, c_end = -1, row = 0;                            // the unit's bin in this step (t - t0), its last step, c mod Qp
     int em = 0, ea = 0, two_sided = 1, wsel = 0;
     // what a sweep fixes for a term: where b and c are in the ring (the zero row if the term, or that side of it, does not take
     // part: rframe / cframe, lwslib.cpp:1143-1151), the weight's index in its row, which row (c mod Qp or its negative)
-    int rb[CH], rc[CH], wi[CH], ng[CH];
+    int rb[NC], rc[NC], wn[NC];                                // (wn: index | negative row << 31)
     bool valid = false, centre = false;
     real th = 0;
-    auto row_of = [&](int dr) { int x = em + dr; x += x < 0 ? NWR : 0; x -= x >= NWR ? NWR : 0; return x * Np; };
-    auto place = [&](int meta, int &ob, int &oc, int &w_i, int &neg) {
+    auto row_of = [&](int dr) __attribute__((always_inline)) { int x = em + dr; x += x < 0 ? NWR : 0; x -= x >= NWR ? NWR : 0; return x * Np; };
+    auto place = [&](int meta, int &ob, int &oc, int &w_n) __attribute__((always_inline)) {
         const int r = meta & 0xff, cut = (meta >> 9) & 3, dk = ((meta >> 13) & 63) - 32;
         const bool is_centre = (meta >> 11) & 1, none = (meta >> 12) & 1;
         const bool both = is_centre || r < two_sided, dead = none || (is_centre && !centre);
         const int drb = cut == 1 ? -r : (cut == 2 ? r : 0);
         ob = (dead || (!both && cut == 2)) ? zrow : row_of(drb) + dk;
         oc = (dead || (!both && cut == 1)) ? zrow : row_of(-drb) + (cut == 0 ? -dk : dk);
-        w_i = r * (L + 1) + (dk < 0 ? -dk : dk);
-        neg = ((meta >> 8) & 1) ? -1 : 0;
+        w_n = (r * (L + 1) + (dk < 0 ? -dk : dk)) | (((meta >> 8) & 1) << 31);
     };
-    auto setup = [&]() {
+    auto setup = [&]() __attribute__((always_inline)) {
         valid = false;
         if (s >= nsweeps) { s_end = t_end; return; }
         const int m = (int)(s / per), q = (int)(s - (long)m * per);
@@ -329,54 +332,64 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
             centre = true; two_sided = ts; wsel = (rho == m) ? 2 : 0; th = thr[q - 1];
         }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) place(lt[i], rb[i], rc[i], wi[i], ng[i]);
+        for (int i = 0; i < NC; ++i) place(lt[i], rb[i], rc[i], wn[i]);
+    };
+    auto advance = [&](long t) __attribute__((always_inline)) {   // the sweep this team works on at step t
+        while (t > s_end) { s += tg.nsl; setup(); }
+        const long d = t - t0, de = s_end - t0;
+        c = d < -(1 << 30) ? -(1 << 30) : (int)d;             // (a sweep that starts far ahead: its own advance() comes first)
+        c_end = valid ? (int)(de < (1 << 30) ? de : (1 << 30)) : (1 << 30);
+        if (!valid) c = -(1 << 30);
+        row = c > 0 ? c % Qp : 0;
     };
     setup();
+    advance(0);
     for (long t = 0; t < t_end; ++t) {
         if (t >= t_bring && loaded <= e_last) {                // (uniform over the workgroup)
             bring();
             t_bring += t_frame;
             __syncthreads();
         }
-        while (t > s_end) { s += tg.nsl; setup(); }
-        const long cl = t - t0;
-        const bool unit = valid && cl >= 0 && cl < F;
-        const int c = (int)cl, n = c + L;
+        if (t > s_end) advance(t);                             // (s_end of a lane without a sweep left: t_end)
+        const bool unit = c >= 0 && c < F;
+        const int n = c + L;
         C acc;
         acc.x = 0; acc.y = 0;
         real target = 0;
         if (unit) {
             target = ampr[ea * Np + n];
-            const int row = c % Qp, rowneg = row == 0 ? 0 : Qp - row;
+            const int rowneg = row == 0 ? 0 : Qp - row;
             const int d0 = (WL ? wsel * Qp + row : row) * RQ, dn = (rowneg - row) * RQ;   // weight rows: d0, d0 + dn
             const C *wg = WL ? nullptr : a.w[wsel].w;
             const uint8_t *fg = WL ? nullptr : a.w[wsel].flag;
             if (g == 0 && centre && add_self) { const C s0 = ring[em * Np + n]; acc.x += s0.x / a.qdiv; acc.y += s0.y / a.qdiv; }
-            auto chunk = [&](const int (&ob)[CH], const int (&oc)[CH], const int (&w_i)[CH], const int (&neg)[CH]) {
+            auto chunk = [&](auto off_c, const auto &ob, const auto &oc, const auto &w_n) {   // (arrays by reference, constant indices: registers)
+                constexpr int O = decltype(off_c)::value;
                 C w[CH], vb[CH], vc[CH];
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
-                    const int wo = d0 + w_i[i] + (neg[i] & dn);
+                    const int wo = d0 + (w_n[O + i] & 0x7fffffff) + ((w_n[O + i] >> 31) & dn);
                     if constexpr (WL) w[i] = wl[wo];
                     else {
                         w[i] = wg[wo];
                         if (fg[wo] == 0) { w[i].x = 0; w[i].y = 0; }
                     }
-                    vb[i] = ring[ob[i] + n];
-                    vc[i] = ring[oc[i] + n];
+                    vb[i] = ring[ob[O + i] + n];
+                    vc[i] = ring[oc[O + i] + n];
                 }
 #pragma unroll
                 for (int i = 0; i < CH; ++i) pair<real>(acc, w[i], vb[i], vc[i]);
             };
-            chunk(rb, rc, wi, ng);
-            for (int j0 = g + G * CH; j0 < NT; j0 += G * CH) {   // further chunks (thin teams): their terms from the table
-                int ob[CH], oc[CH], w_i[CH], neg[CH];
+            chunk(std::integral_constant<int, 0>{}, rb, rc, wn);
+            if constexpr (NC > CH) { if (two_chunks) chunk(std::integral_constant<int, NC - CH>{}, rb, rc, wn); }
+            for (int j0 = g + G * NC; j0 < NT; j0 += G * CH) {   // further chunks (thin teams): their terms from the table
+                int ob[CH], oc[CH], w_n[CH];
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
                     const int jj = j0 + i * G;
-                    place(jj < NT ? tt[jj] : (1 << 12), ob[i], oc[i], w_i[i], neg[i]);
+                    place(jj < NT ? tt[jj] : (1 << 12), ob[i], oc[i], w_n[i]);
                 }
-                chunk(ob, oc, w_i, neg);
+                chunk(std::integral_constant<int, 0>{}, ob, oc, w_n);
             }
         }
         const bool act = unit && (target > th);
@@ -402,6 +415,8 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
             }
         }
         __syncthreads();
+        ++c;                                                   // the next step's bin
+        row = c > 0 ? (row + 1 == Qp ? 0 : row + 1) : 0;
     }
     // what is still in the ring goes back
     for (int e = loaded > NWR ? loaded - NWR : 0; e < loaded; ++e) {

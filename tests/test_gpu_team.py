@@ -146,3 +146,21 @@ def test_run_lws_of_a_sixteen_frame_row_uses_no_generic_kernel():
     plan.batch(b, thr_b); names.append(plan.last_kernel()["name"])
     assert names == ["team_nofuture_fp32", "team_online_fp32", "band_fp32"], names
     assert np.abs(np.abs(b) - X).max() < 2e-6 * X.max()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_the_ring_is_storage_only(precision, monkeypatch):
+    """The online kernel with its window in LDS and the one that leaves it in memory take the same sums in the same order: same bits
+    (a weight without a flag is a zero in one and skipped in the other; a side that does not take part reads a row of zeros in one
+    and is replaced by zero in the other).  Summarised tensors (weights in LDS too) and general ones (weights in memory)."""
+    for fsize, fshift, L, T, LA, iters in [(512, 32, 5, 40, 3, 3), (1024, 256, 8, 30, 3, 2), (512, 56, 5, 30, 2, 2)]:
+        p, F, plan = plans(fsize, fshift, L, precision=precision)
+        S = spectrograms(2, T, F, seed=fsize + 1)
+        thr = lws_amd.get_thresholds(iters, 1.0, 0.3, 1)
+        ring = plan.online(S, thr, LA, fsize / fshift)
+        assert plan.last_kernel()["name"] == "team_online_" + precision
+        monkeypatch.setenv("LWS_TEAM_NO_RING", "1")
+        mem = plan.online(S, thr, LA, fsize / fshift)
+        monkeypatch.delenv("LWS_TEAM_NO_RING")
+        assert np.array_equal(ring, mem), np.abs(ring - mem).max()
+        plan.close()
