@@ -312,6 +312,17 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     a.qdiv = (real)qdiv;
     a.mode = mode;
     a.group = 1;
+    // (LWS_TEAM_FIRST=1, comparison runs: the team engine before the LDS engines of the online / no-future stages)
+    if ((mode == lws::MODE_ONLINE || mode == lws::MODE_NOFUTURE) && !(p->flags & LWS_FORCE_GENERIC) && env_int("LWS_TEAM_FIRST", 0) &&
+        lws::team_supports(mode, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr)) {
+        begin_timing(p, s);
+        hipError_t e = lws::launch_team<real>(a, B, s);
+        end_timing(p, s);
+        if (e != hipSuccess) return fail(LWS_ERR_HIP, "team engine launch failed: %s", hipGetErrorString(e));
+        p->last_launches = 1;
+        p->last_name = mode == lws::MODE_ONLINE ? (p->fp64 ? "team_online_fp64" : "team_online_fp32") : (p->fp64 ? "team_nofuture_fp64" : "team_nofuture_fp32");
+        return LWS_OK;
+    }
     if constexpr (std::is_same<real, float>::value) {
         // online driver: frames of the moving window live in LDS when the shape allows it
         if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) &&
@@ -353,7 +364,11 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     }
     if constexpr (std::is_same<real, double>::value) {
         // online driver of an fp64 plan: the frames of the moving window in LDS, every sum in the generic engine's order (same bits)
-        if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_ONLINE64", 0) &&
+        // (Q = 8: three frames' pairs on the two waves' chain -- 1 291 ms for 256 x 500 x 257 against 488 on the team engine with its window
+        // in LDS: such plans go there unless LWS_NO_TEAM_Q8=1 asks for this engine's bits, which are the generic engine's)
+        const bool q8_team = a.Q == 8 && !env_int("LWS_NO_TEAM", 0) && !env_int("LWS_NO_TEAM_Q8", 0) && !env_int("LWS_ONLINE_SERIAL_TAPS", 0) &&
+                             lws::team_online_in_lds(true, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr);
+        if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_ONLINE64", 0) && !q8_team &&
             lws::online64_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update)) {
             begin_timing(p, s);
             hipError_t e = lws::launch_online64(a, B, s);

@@ -12,6 +12,9 @@ bool team_supports(int mode, int F, int T, int L, int Q, int Qp, int LA, int n_t
 // partial sums in a fixed order, so results agree with the generic engine to rounding, not bit for bit.
 template <typename real>
 hipError_t launch_team(const GenericArgs<real> &a, int B, hipStream_t stream);
+// true if the online stage of this shape runs with its moving window in LDS (k_team_online_ring) and with at least 8 lanes per bin: the
+// case in which the team engine is faster than the fp64 LDS engine's Q = 8 kernel (lws_capi.hip: run_stage)
+bool team_online_in_lds(bool fp64, int F, int T, int L, int Q, int Qp, int LA, int n_thr);
 // lanes per bin the launcher chooses for this stage (reported by the tests / tools)
 int team_lanes(int mode, int F, int T, int L, int Q, int LA, int n_thr);
 

@@ -547,6 +547,13 @@ bool team_supports(int mode, int F, int T, int L, int Q, int Qp, int LA, int n_t
     return geometry(mode, F, T, L, Q, LA, n_thr).G >= (getenv("LWS_TEAM_LANES") ? 1 : 2);
 }
 
+bool team_online_in_lds(bool fp64, int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
+    if (!team_supports(MODE_ONLINE, F, T, L, Q, Qp, LA, n_thr)) return false;
+    const TeamGeom tg = geometry(MODE_ONLINE, F, T, L, Q, LA, n_thr);
+    if (tg.G < 8) return false;
+    return (fp64 ? ring_geometry<double>(tg, F, L, Q, Qp, LA, n_thr) : ring_geometry<float>(tg, F, L, Q, Qp, LA, n_thr)).bytes != 0;
+}
+
 int team_lanes(int mode, int F, int T, int L, int Q, int LA, int n_thr) { return geometry(mode, F, T, L, Q, LA, n_thr).G; }
 
 template <typename real>

@@ -10,6 +10,13 @@ from lws_amd import _capi
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def q8_on_this_engine(monkeypatch):
+    """fp64 plans of Q = 8 run their online stage on the team engine by default (2.6x faster, the generic engine's values to rounding);
+    this module is about lws_online64.hip, whose Q = 8 kernel keeps the generic engine's BITS: LWS_NO_TEAM_Q8=1."""
+    monkeypatch.setenv("LWS_NO_TEAM_Q8", "1")
+
+
 def weights(tag):
     h = load_golden("helpers.npz")
     return h[f"W_{tag}"], h[f"W_ai_{tag}"], h[f"W_af_{tag}"]

@@ -164,3 +164,22 @@ def test_the_ring_is_storage_only(precision, monkeypatch):
         monkeypatch.delenv("LWS_TEAM_NO_RING")
         assert np.array_equal(ring, mem), np.abs(ring - mem).max()
         plan.close()
+
+
+def test_fp64_plans_of_eight_frames_per_row_take_the_team_engine(oracle, monkeypatch):
+    """lws(512, 64, precision='fp64'): the fp64 LDS engine has a Q = 8 kernel (the generic engine's bits, 1.29 s for 256 x 500 x 257);
+    the team engine with its window in LDS takes 0.49 s: the default.  LWS_NO_TEAM_Q8=1: the LDS engine."""
+    fsize, fshift, T, LA, iters = 512, 64, 30, 3, 3
+    p, F, plan = plans(fsize, fshift, 5, precision="fp64")
+    S = spectrograms(2, T, F, seed=5)
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.3, 1)
+    out = plan.online(S, thr, LA, fsize / fshift)
+    assert plan.last_kernel()["name"] == "team_online_fp64"
+    monkeypatch.setenv("LWS_NO_TEAM_Q8", "1")
+    ref = plan.online(S, thr, LA, fsize / fshift)
+    assert plan.last_kernel()["name"] == "online_lds_fp64"
+    assert np.abs(out - ref).max() < 1e-10 * np.abs(S).max()
+    for b in range(2):
+        o = oracle.online_lws(S[b], p.W, p.W_ai, p.W_af, thr, LA, fshift)
+        assert np.abs(out[b] - o).max() < 1e-9 * np.abs(S[b]).max()
+    plan.close()

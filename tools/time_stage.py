@@ -14,14 +14,17 @@ ap.add_argument("--T", type=int, default=500)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--LA", type=int, default=None)
 ap.add_argument("--iters", type=int, default=None)
+ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
+ap.add_argument("--L", type=int, default=5)
 a = ap.parse_args()
 F = a.fsize // 2 + 1
-pm = lws_amd.lws(a.fsize, a.fshift, mode="music")
+pm = lws_amd.lws(a.fsize, a.fshift, L=a.L, mode="music", precision=a.precision)
 plan = pm.plan()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 re = torch.randn((a.B, a.T, F), device="cuda", generator=g); im = torch.randn((a.B, a.T, F), device="cuda", generator=g)
 mags = torch.sqrt(re * re + im * im); del re, im
-state = torch.empty((a.B, a.T, F), dtype=torch.complex64, device="cuda")
+cdt = torch.complex128 if a.precision == "fp64" else torch.complex64
+state = torch.empty((a.B, a.T, F), dtype=cdt, device="cuda")
 thr_nf = lws_amd.get_thresholds(pm.nofuture_iterations, pm.nofuture_alpha, pm.nofuture_beta, pm.nofuture_gamma)
 it_on = a.iters or pm.online_iterations
 thr_on = lws_amd.get_thresholds(it_on, pm.online_alpha, pm.online_beta, pm.online_gamma)
