@@ -36,7 +36,8 @@ __device__ __forceinline__ void pair(C &a, const C w, const C b, const C c) {   
 //                    r | negrow << 8 | (what !both removes: 1 = c, 2 = b) << 9 | centre << 11}
 struct Term { int ob, oc, wi, meta; };
 
-// entries [0, L): the centre frame's k = 1..L; then per r = 1..Q-1: (r, 0), (r, k) of the row, (r, k) of the negative row
+// entries [0, L): the centre frame's k = 1..L; then per r = 1..Q-1: (r, 0) and, for k = 1..L, (r, k) of the row, (r, k) of the negative row:
+// the order of the statements in lws_generic.hip's accumulate_v, so that ONE lane per bin (LWS_TEAM_LANES=1) adds them in that engine's order
 __device__ __forceinline__ void build_terms(Term *tt, int NT, int L, int Np, int tid, int nthr) {
     const int K1 = L + 1, W21 = 2 * L + 1;
     for (int j = tid; j < NT; j += nthr) {
@@ -45,10 +46,10 @@ __device__ __forceinline__ void build_terms(Term *tt, int NT, int L, int Np, int
             const int k = j + 1;
             e.ob = -k; e.oc = k; e.wi = k; e.meta = 1 << 11;
         } else {
-            const int jj = j - L, r = 1 + jj / W21, qk = jj - (r - 1) * W21, u = r * K1;
+            const int jj = j - L, r = 1 + jj / W21, qk = jj - (r - 1) * W21, u = r * K1, k = (qk + 1) / 2;
             if (qk == 0) { e.ob = -r * Np; e.oc = r * Np; e.wi = u; e.meta = r | (1 << 9); }
-            else if (qk <= L) { const int k = qk; e.ob = -r * Np - k; e.oc = r * Np - k; e.wi = u + k; e.meta = r | (1 << 9); }
-            else { const int k = qk - L; e.ob = r * Np + k; e.oc = -r * Np + k; e.wi = u + k; e.meta = r | (1 << 8) | (2 << 9); }
+            else if (qk & 1) { e.ob = -r * Np - k; e.oc = r * Np - k; e.wi = u + k; e.meta = r | (1 << 9); }
+            else { e.ob = r * Np + k; e.oc = -r * Np + k; e.wi = u + k; e.meta = r | (1 << 8) | (2 << 9); }
         }
         tt[j] = e;
     }
@@ -227,8 +228,8 @@ __device__ __forceinline__ void build_terms_ring(int *tt, int NT, int L, int tid
         else {
             const int jj = j - L, r = 1 + jj / W21, qk = jj - (r - 1) * W21;
             if (qk == 0) { dk = 0; meta = r | (1 << 9); }
-            else if (qk <= L) { dk = -qk; meta = r | (1 << 9); }
-            else { dk = qk - L; meta = r | (1 << 8) | (2 << 9); }
+            else if (qk & 1) { dk = -((qk + 1) / 2); meta = r | (1 << 9); }
+            else { dk = qk / 2; meta = r | (1 << 8) | (2 << 9); }
         }
         tt[j] = meta | ((dk + 32) << 13);
     }

@@ -183,3 +183,30 @@ def test_fp64_plans_of_eight_frames_per_row_take_the_team_engine(oracle, monkeyp
         o = oracle.online_lws(S[b], p.W, p.W_ai, p.W_af, thr, LA, fshift)
         assert np.abs(out[b] - o).max() < 1e-9 * np.abs(S[b]).max()
     plan.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+@pytest.mark.parametrize("fsize,fshift,L,T,LA,iters", [(1024, 64, 5, 60, 3, 10), (1024, 256, 8, 80, 3, 6), (512, 56, 5, 50, 2, 4), (256, 16, 5, 70, 5, 3)])
+def test_one_lane_per_bin_gives_the_generic_engines_bits(fsize, fshift, L, T, LA, iters, precision, monkeypatch):
+    """LWS_TEAM_LANES=1: a team of one lane adds a bin's terms in the order-exact engine's order -- everything else (sweep slots, the
+    ring of the online window and what enters and leaves it when, the placement of the terms per sweep, the row of zeros, the weights'
+    LDS copy, the no-future hyperplanes) is the production code.  Results must equal the generic engine's bit for bit, in fp32 and in
+    fp64, with the window in LDS and in memory: the pin of the team engine's schedule at sizes where value comparisons are dominated by the
+    algorithm's own sensitivity (the role LWS_ONLINE_SERIAL_TAPS plays for lws_online.hip)."""
+    p, F, plan = plans(fsize, fshift, L, precision=precision)
+    S = spectrograms(2, T, F, seed=fsize + 7, zero_phase=True)
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.2, 1)
+    gen = _capi.Plan(F, p.W, p.W_ai, p.W_af, precision=precision, force_generic=True)
+    ref_on = gen.online(S, thr, LA, fsize / fshift)
+    ref_nf = gen.nofuture(S, thr[:2], wsel=1)
+    monkeypatch.setenv("LWS_TEAM_LANES", "1")
+    monkeypatch.setenv("LWS_TEAM_FIRST", "1")          # (shapes whose no-future sweeps have an LDS engine: the team engine all the same)
+    out = plan.online(S, thr, LA, fsize / fshift)
+    assert plan.last_kernel()["name"] == "team_online_" + precision
+    assert np.array_equal(out, ref_on)
+    monkeypatch.setenv("LWS_TEAM_NO_RING", "1")
+    assert np.array_equal(plan.online(S, thr, LA, fsize / fshift), ref_on)
+    nf = plan.nofuture(S, thr[:2], wsel=1)
+    if plan.last_kernel()["name"] == "team_nofuture_" + precision:      # (Q = 4 plans: the shipped NoFuture_LWSQ4 addressing is not the team engine's)
+        assert np.array_equal(nf, ref_nf)
+    plan.close(); gen.close()
