@@ -314,6 +314,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     a.group = 1;
     // (LWS_TEAM_FIRST=1, comparison runs: the team engine before the LDS engines of the online / no-future stages)
     if ((mode == lws::MODE_ONLINE || mode == lws::MODE_NOFUTURE) && !(p->flags & LWS_FORCE_GENERIC) && env_int("LWS_TEAM_FIRST", 0) &&
+        (!p->fp64 || env_int("LWS_TEAM_FP64", 0)) &&
         lws::team_supports(mode, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr)) {
         begin_timing(p, s);
         hipError_t e = lws::launch_team<real>(a, B, s);
@@ -365,8 +366,9 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     if constexpr (std::is_same<real, double>::value) {
         // online driver of an fp64 plan: the frames of the moving window in LDS, every sum in the generic engine's order (same bits)
         // (Q = 8: three frames' pairs on the two waves' chain -- 1 291 ms for 256 x 500 x 257 against 488 on the team engine with its window
-        // in LDS: such plans go there unless LWS_NO_TEAM_Q8=1 asks for this engine's bits, which are the generic engine's)
-        const bool q8_team = a.Q == 8 && !env_int("LWS_NO_TEAM", 0) && !env_int("LWS_NO_TEAM_Q8", 0) && !env_int("LWS_ONLINE_SERIAL_TAPS", 0) &&
+        // in LDS: with LWS_TEAM_FP64=1 such plans go there.  Not by default: an fp64 plan is asked for to reproduce the reference, and the
+        // online recursion amplifies the rounding of a re-associated sum to O(1) within tens of frames -- this engine keeps the order)
+        const bool q8_team = a.Q == 8 && env_int("LWS_TEAM_FP64", 0) && !env_int("LWS_NO_TEAM", 0) && !env_int("LWS_ONLINE_SERIAL_TAPS", 0) &&
                              lws::team_online_in_lds(true, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr);
         if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_ONLINE64", 0) && !q8_team &&
             lws::online64_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update)) {
@@ -459,9 +461,11 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     // online and no-future sweeps no LDS engine takes (more than 8 frames per stencil row, L > 5, weights without the twiddle
     // structure, frames beyond the rings): the team engine (lws_team.hip) -- the generic engine's schedule with a bin's taps spread
     // over a team of lanes.  Same sweeps in the reference's order; a bin's sum in another order.
-    // (the serial-taps verification variants of the LDS engines promise the generic engine's bits: they keep falling through to it,
-    // as do fp64 plans under LWS_NO_ONLINE64)
+    // (the serial-taps verification variants of the LDS engines promise the generic engine's bits: they keep falling through to it.
+    // fp64 plans too, unless LWS_TEAM_FP64=1: the online and no-future recursions amplify the rounding of a re-associated sum by 5-10 per
+    // frame -- equally valid phases, but not the reference's numbers an fp64 plan exists to reproduce; the order-exact engine keeps them)
     if ((mode == lws::MODE_ONLINE || mode == lws::MODE_NOFUTURE) && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_TEAM", 0) &&
+        (!p->fp64 || env_int("LWS_TEAM_FP64", 0)) &&
         !env_int("LWS_ONLINE_SERIAL_TAPS", 0) && !env_int("LWS_NOFUTURE_SERIAL_TAPS", 0) && !(p->fp64 && env_int("LWS_NO_ONLINE64", 0)) &&
         lws::team_supports(mode, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr)) {
         begin_timing(p, s);

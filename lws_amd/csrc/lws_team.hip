@@ -78,7 +78,7 @@ __device__ __forceinline__ LaneTerms<real> lane_terms(const Term *tt, int NT, in
 template <typename real>
 __device__ __forceinline__ void team_bin(typename cx<real>::type *S, const real *amp, const Term *tt, const LaneTerms<real> &lt, int NT, bool unit,
                                          int m_ext, int c, bool centre, int two_sided, const WeightSet<real> ws, real thr, int F, int L, int Q,
-                                         int Qp, bool add_self, real qdiv, int g, int G, int lab = 0) {
+                                         int Qp, bool add_self, real qdiv, int g, int G) {
     using C = typename cx<real>::type;
     constexpr int CH = Chunk<real>::N;
     const int Np = F + 2 * L, RQ = Q * (L + 1);
@@ -88,7 +88,7 @@ __device__ __forceinline__ void team_bin(typename cx<real>::type *S, const real 
     a.x = 0; a.y = 0;
     C *ctr = S + idx;
     real target = 0;
-    if (unit && !(lab & 4)) {
+    if (unit) {
         target = amp[idx];
         const int row = c % Qp, rowneg = (Qp - row) % Qp;
         const C *w0 = ws.w + (size_t)row * RQ, *w1 = ws.w + (size_t)rowneg * RQ;
@@ -125,14 +125,13 @@ __device__ __forceinline__ void team_bin(typename cx<real>::type *S, const real 
     }
     const bool act = unit && (target > thr);
     // butterfly over the team (teams are aligned groups of G lanes of a wave): every lane ends with the same sum
-    if (__any(act) && !(lab & 1)) {
+    if (__any(act)) {
         for (int off = 1; off < G; off <<= 1) {
             const real ox = shfl_xor<real>(a.x, off), oy = shfl_xor<real>(a.y, off);
             a.x += ox; a.y += oy;
         }
     }
-    if (lab & 4) target = unit ? (real)1 : (real)0;
-    if (act && g == 0 && !(lab & 2)) {
+    if (act && g == 0) {
         const real mag = sqrt(a.x * a.x + a.y * a.y);
         if (mag > 0) {
             C v;
@@ -149,7 +148,7 @@ __device__ __forceinline__ void team_bin(typename cx<real>::type *S, const real 
     }
 }
 
-struct TeamGeom { int G, nsl, nunits, lab; };   // lab: timing experiments (LWS_TEAM_LAB bit mask: parts of a step switched off -- wrong results)
+struct TeamGeom { int G, nsl, nunits; };
 
 // online: sweep s = (frame m = s / per, q = s % per) is owned by slot s mod nsl; a slot has LA + 1 units (frame positions)
 template <typename real>
@@ -205,8 +204,8 @@ __global__ void __launch_bounds__(1024) k_team_online(GenericArgs<real> a, TeamG
         while (t > s_end) { s += tg.nsl; setup(); }
         const long cl = t - t0;
         const bool unit = valid && cl >= 0 && cl < F;
-        team_bin<real>(S, amp, tt, lt, NT, unit, m_ext, (int)cl, centre, two_sided, a.w[wsel], th, F, L, Q, Qp, add_self, a.qdiv, g, G, tg.lab);
-        if (!(tg.lab & 8)) __syncthreads();
+        team_bin<real>(S, amp, tt, lt, NT, unit, m_ext, (int)cl, centre, two_sided, a.w[wsel], th, F, L, Q, Qp, add_self, a.qdiv, g, G);
+        __syncthreads();
     }
 }
 
@@ -486,8 +485,7 @@ int pow2_floor(int x) { int p = 1; while (2 * p <= x) p *= 2; return p; }
 
 // lanes per team, units per step and sweeps in flight for a stage; G = 0: not worth a team
 TeamGeom geometry(int mode, int F, int T, int L, int Q, int LA, int n_thr) {
-    TeamGeom tg{0, 0, 0, 0};
-    { const char *el = getenv("LWS_TEAM_LAB"); tg.lab = el ? atoi(el) : 0; }
+    TeamGeom tg{0, 0, 0};
     const int sk = L + 1, D = Q * sk;
     if (mode == MODE_ONLINE) {
         // sweeps in flight: a slot's next sweep starts D nsl steps after its current one, which lasts at most F + sk LA steps
@@ -503,7 +501,7 @@ TeamGeom geometry(int mode, int F, int T, int L, int Q, int LA, int n_thr) {
         tg.nsl = group;
         tg.nunits = group * lpi;
     }
-    if (tg.nunits <= 0 || tg.nunits > 512) return TeamGeom{0, 0, 0, 0};
+    if (tg.nunits <= 0 || tg.nunits > 512) return TeamGeom{0, 0, 0};
     int G = pow2_floor(1024 / tg.nunits);
     if (G > 64) G = 64;
     const char *ev = getenv("LWS_TEAM_LANES");   // comparison runs: at most this many lanes per bin (1: the generic engine's order of terms)

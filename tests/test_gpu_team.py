@@ -11,6 +11,14 @@ from lws_amd import _capi
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def team_engine_for_fp64_plans_too(monkeypatch):
+    """fp32 plans take the team engine by default.  fp64 plans keep the order-exact engine unless LWS_TEAM_FP64=1 (an fp64 plan is asked
+    for to reproduce the reference's numbers, and the online / no-future recursions amplify the rounding of a re-associated sum): this
+    module tests the engine in both precisions."""
+    monkeypatch.setenv("LWS_TEAM_FP64", "1")
+
+
 def rel_l2(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
@@ -168,14 +176,14 @@ def test_the_ring_is_storage_only(precision, monkeypatch):
 
 def test_fp64_plans_of_eight_frames_per_row_take_the_team_engine(oracle, monkeypatch):
     """lws(512, 64, precision='fp64'): the fp64 LDS engine has a Q = 8 kernel (the generic engine's bits, 1.29 s for 256 x 500 x 257);
-    the team engine with its window in LDS takes 0.49 s: the default.  LWS_NO_TEAM_Q8=1: the LDS engine."""
+    the team engine with its window in LDS takes 0.49 s: with LWS_TEAM_FP64=1.  Default: the LDS engine and the reference's order."""
     fsize, fshift, T, LA, iters = 512, 64, 30, 3, 3
     p, F, plan = plans(fsize, fshift, 5, precision="fp64")
     S = spectrograms(2, T, F, seed=5)
     thr = lws_amd.get_thresholds(iters, 1.0, 0.3, 1)
     out = plan.online(S, thr, LA, fsize / fshift)
     assert plan.last_kernel()["name"] == "team_online_fp64"
-    monkeypatch.setenv("LWS_NO_TEAM_Q8", "1")
+    monkeypatch.delenv("LWS_TEAM_FP64")
     ref = plan.online(S, thr, LA, fsize / fshift)
     assert plan.last_kernel()["name"] == "online_lds_fp64"
     assert np.abs(out - ref).max() < 1e-10 * np.abs(S).max()
@@ -210,3 +218,14 @@ def test_one_lane_per_bin_gives_the_generic_engines_bits(fsize, fshift, L, T, LA
     if plan.last_kernel()["name"] == "team_nofuture_" + precision:      # (Q = 4 plans: the shipped NoFuture_LWSQ4 addressing is not the team engine's)
         assert np.array_equal(nf, ref_nf)
     plan.close(); gen.close()
+
+
+def test_fp64_plans_keep_the_order_exact_engine_by_default(monkeypatch):
+    monkeypatch.delenv("LWS_TEAM_FP64")
+    p, F, plan = plans(256, 16, 5, precision="fp64")
+    S = spectrograms(1, 12, F, seed=3)
+    plan.online(S, [0.5, 0.1], 3, 16.0)
+    assert plan.last_kernel()["name"] == "generic_fp64"
+    plan.nofuture(S, [0.5], wsel=1)
+    assert plan.last_kernel()["name"] == "generic_fp64"
+    plan.close()
