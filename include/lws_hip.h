@@ -47,7 +47,7 @@ enum {
 /* plan flags */
 enum {
     LWS_PRECISION_FP32 = 0,        /* default: fp32 state, weights and accumulation */
-    LWS_PRECISION_FP64 = 1,        /* fp64 everywhere (reference arithmetic): batch sweeps of Q = 2 / 4 plans (frames up to ~2090 bins) on the fp64 systolic engine (lws_sys64.hip), no-future and online sweeps of Q = 2 / 3 / 4 / 8 plans on LDS engines that are bit-identical to the order-exact generic engine (lws_nofuture.hip, lws_online64.hip), batch sweeps of the other plans with summarised tensors -- Q = 3, 5..8, 16, L up to 10 -- on the band engine (lws_band.hip, round 6), the rest on that engine (LWS_TEAM_FP64=1: online and no-future sweeps of the other plans on the team engine, lws_team.hip -- faster, but a re-associated sum does not reproduce the reference's numbers over long recursions) */
+    LWS_PRECISION_FP64 = 1,        /* fp64 everywhere (reference arithmetic): batch sweeps of Q = 2 / 4 plans (frames up to ~2090 bins) on the fp64 systolic engine (lws_sys64.hip), no-future and online sweeps of Q = 2 / 3 / 4 / 8 plans on LDS engines that are bit-identical to the order-exact generic engine (lws_nofuture.hip, lws_online64.hip), batch sweeps of the other plans with summarised tensors -- Q = 3, 5..8, 16, L up to 10 -- on the band engine (lws_band.hip, round 6), online sweeps of the other plans (and of Q = 8 plans) on the team engine's order-exact kernel (lws_team.hip: the generic engine's bits, ~10x faster), the rest on that engine */
     LWS_NOFUTURE_Q4_COMPAT = 2,    /* reproduce NoFuture_LWSQ4's addressing (lwslib.cpp:559-594) when Q == Qp == 4 */
     LWS_FORCE_GENERIC = 4,         /* never use the specialised systolic batch kernel */
     LWS_NO_DIRECT_IO = 8,          /* always go through the extended buffers (prep / extract passes), even for a call

@@ -314,14 +314,17 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     a.group = 1;
     // (LWS_TEAM_FIRST=1, comparison runs: the team engine before the LDS engines of the online / no-future stages)
     if ((mode == lws::MODE_ONLINE || mode == lws::MODE_NOFUTURE) && !(p->flags & LWS_FORCE_GENERIC) && env_int("LWS_TEAM_FIRST", 0) &&
-        (!p->fp64 || env_int("LWS_TEAM_FP64", 0)) &&
-        lws::team_supports(mode, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr)) {
+        (!p->fp64 || env_int("LWS_TEAM_FP64", 0) || mode == lws::MODE_ONLINE) &&
+        lws::team_supports(mode, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr) &&
+        !(mode == lws::MODE_ONLINE && lws::team_online_is_ordered(p->fp64) && !lws::team_ordered_fits(a.F, a.T, a.L, a.Q, a.LA, a.n_thr, p->fp64))) {
+        const bool ordered = mode == lws::MODE_ONLINE && lws::team_online_is_ordered(p->fp64);
         begin_timing(p, s);
         hipError_t e = lws::launch_team<real>(a, B, s);
         end_timing(p, s);
         if (e != hipSuccess) return fail(LWS_ERR_HIP, "team engine launch failed: %s", hipGetErrorString(e));
         p->last_launches = 1;
-        p->last_name = mode == lws::MODE_ONLINE ? (p->fp64 ? "team_online_fp64" : "team_online_fp32") : (p->fp64 ? "team_nofuture_fp64" : "team_nofuture_fp32");
+        p->last_name = mode == lws::MODE_ONLINE ? (ordered ? (p->fp64 ? "team_online_ordered_fp64" : "team_online_ordered_fp32") : (p->fp64 ? "team_online_fp64" : "team_online_fp32"))
+                                                : (p->fp64 ? "team_nofuture_fp64" : "team_nofuture_fp32");
         return LWS_OK;
     }
     if constexpr (std::is_same<real, float>::value) {
@@ -365,11 +368,13 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     }
     if constexpr (std::is_same<real, double>::value) {
         // online driver of an fp64 plan: the frames of the moving window in LDS, every sum in the generic engine's order (same bits)
-        // (Q = 8: three frames' pairs on the two waves' chain -- 1 291 ms for 256 x 500 x 257 against 488 on the team engine with its window
-        // in LDS: with LWS_TEAM_FP64=1 such plans go there.  Not by default: an fp64 plan is asked for to reproduce the reference, and the
-        // online recursion amplifies the rounding of a re-associated sum to O(1) within tens of frames -- this engine keeps the order)
-        const bool q8_team = a.Q == 8 && env_int("LWS_TEAM_FP64", 0) && !env_int("LWS_NO_TEAM", 0) && !env_int("LWS_ONLINE_SERIAL_TAPS", 0) &&
-                             lws::team_online_in_lds(true, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr);
+        // (Q = 8: three frames' pairs on the two waves' chain -- 1 296 ms for 256 x 500 x 257 against 991 on the team engine's order-exact
+        // kernel, which gives the same bits (the generic engine's): such plans go there unless LWS_NO_TEAM_Q8=1 asks for this kernel.
+        // With LWS_TEAM_FP64=1: the team engine's re-associating kernel with its window in LDS, 483 ms)
+        const bool q8_team = a.Q == 8 && !env_int("LWS_NO_TEAM", 0) && !env_int("LWS_NO_TEAM_Q8", 0) && !env_int("LWS_ONLINE_SERIAL_TAPS", 0) &&
+                             lws::team_supports(mode, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr) &&
+                             (env_int("LWS_TEAM_FP64", 0) ? lws::team_online_in_lds(true, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr)
+                                                          : lws::team_ordered_fits(a.F, a.T, a.L, a.Q, a.LA, a.n_thr, true));
         if (mode == lws::MODE_ONLINE && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_ONLINE64", 0) && !q8_team &&
             lws::online64_supports(a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr, a.update)) {
             begin_timing(p, s);
@@ -462,19 +467,26 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     // structure, frames beyond the rings): the team engine (lws_team.hip) -- the generic engine's schedule with a bin's taps spread
     // over a team of lanes.  Same sweeps in the reference's order; a bin's sum in another order.
     // (the serial-taps verification variants of the LDS engines promise the generic engine's bits: they keep falling through to it.
-    // fp64 plans too, unless LWS_TEAM_FP64=1: the online and no-future recursions amplify the rounding of a re-associated sum by 5-10 per
-    // frame -- equally valid phases, but not the reference's numbers an fp64 plan exists to reproduce; the order-exact engine keeps them)
-    if ((mode == lws::MODE_ONLINE || mode == lws::MODE_NOFUTURE) && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_TEAM", 0) &&
-        (!p->fp64 || env_int("LWS_TEAM_FP64", 0)) &&
-        !env_int("LWS_ONLINE_SERIAL_TAPS", 0) && !env_int("LWS_NOFUTURE_SERIAL_TAPS", 0) && !(p->fp64 && env_int("LWS_NO_ONLINE64", 0)) &&
-        lws::team_supports(mode, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr)) {
-        begin_timing(p, s);
-        hipError_t e = lws::launch_team<real>(a, B, s);
-        end_timing(p, s);
-        if (e != hipSuccess) return fail(LWS_ERR_HIP, "team engine launch failed: %s", hipGetErrorString(e));
-        p->last_launches = 1;
-        p->last_name = mode == lws::MODE_ONLINE ? (p->fp64 ? "team_online_fp64" : "team_online_fp32") : (p->fp64 ? "team_nofuture_fp64" : "team_nofuture_fp32");
-        return LWS_OK;
+    // fp64 plans: the online and no-future recursions amplify the rounding of a re-associated sum by 5-10 per frame -- equally valid
+    // phases, but not the reference's numbers an fp64 plan exists to reproduce.  Their online stage runs on the team engine's
+    // ORDER-EXACT kernel (increments by many lanes, the sum by one, in the reference's order: the generic engine's bits); the
+    // re-associating kernels, and no-future sweeps, only with LWS_TEAM_FP64=1.  fp32 plans: LWS_TEAM_ORDERED=1 selects that kernel too.)
+    {
+        const bool ordered = mode == lws::MODE_ONLINE && lws::team_online_is_ordered(p->fp64);
+        const bool allowed = p->fp64 ? (ordered || env_int("LWS_TEAM_FP64", 0)) : true;
+        if ((mode == lws::MODE_ONLINE || mode == lws::MODE_NOFUTURE) && !(p->flags & LWS_FORCE_GENERIC) && !env_int("LWS_NO_TEAM", 0) && allowed &&
+            !env_int("LWS_ONLINE_SERIAL_TAPS", 0) && !env_int("LWS_NOFUTURE_SERIAL_TAPS", 0) && !(p->fp64 && env_int("LWS_NO_ONLINE64", 0)) &&
+            lws::team_supports(mode, a.F, a.T, a.L, a.Q, a.Qp, a.LA, a.n_thr) &&
+            (!ordered || lws::team_ordered_fits(a.F, a.T, a.L, a.Q, a.LA, a.n_thr, p->fp64))) {
+            begin_timing(p, s);
+            hipError_t e = lws::launch_team<real>(a, B, s);
+            end_timing(p, s);
+            if (e != hipSuccess) return fail(LWS_ERR_HIP, "team engine launch failed: %s", hipGetErrorString(e));
+            p->last_launches = 1;
+            p->last_name = mode == lws::MODE_ONLINE ? (ordered ? (p->fp64 ? "team_online_ordered_fp64" : "team_online_ordered_fp32") : (p->fp64 ? "team_online_fp64" : "team_online_fp32"))
+                                                    : (p->fp64 ? "team_nofuture_fp64" : "team_nofuture_fp32");
+            return LWS_OK;
+        }
     }
     begin_timing(p, s);
     hipError_t e = lws::launch_generic<real>(a, B, s);

@@ -209,6 +209,144 @@ __global__ void __launch_bounds__(1024) k_team_online(GenericArgs<real> a, TeamG
     }
 }
 
+// ---- the online driver, order-exact: G lanes fetch and multiply, ONE lane adds ---------------------------------------------------
+// What makes the generic engine slow is not its additions but the latency of 341 dependent loads per bin; what makes a re-associated
+// sum unfit for an fp64 plan is the recursion, which amplifies its rounding by 5-10 per frame until the phases -- equally consistent --
+// are no longer the reference's.  So the fp64 plans' variant keeps the order: a team's lanes form the INCREMENTS of a bin's terms
+// (the value each statement of the reference's tap loop adds: w b + conj(w) c, every product and difference rounded as there) and
+// leave them in LDS, [unit][term]; after a barrier one lane per bin adds them in the reference's order -- 2 NT dependent additions,
+// all bins of the step side by side in one wave -- re-projects and writes.  Same bits as lws_generic.hip (a skipped term is a +0.0:
+// a sum that starts at +0.0 never is -0.0), two barriers per step.
+template <typename real> struct OrdUnit { long long idx; real target; int act, n, m_ext, pad; };
+
+template <typename real>
+__global__ void __launch_bounds__(1024) k_team_online_ordered(GenericArgs<real> a, TeamGeom tg, unsigned off_inc, unsigned off_unit, int NTP) {
+    using C = typename cx<real>::type;
+    constexpr int CH = Chunk<real>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+    Term *tt = reinterpret_cast<Term *>(tsm);
+    C *inc = reinterpret_cast<C *>(tsm + off_inc);                        // [unit][NTP]: slot 0 the S / qdiv term, slot 1 + j term j
+    OrdUnit<real> *ui = reinterpret_cast<OrdUnit<real> *>(tsm + off_unit);
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int F = a.F, T = a.T, L = a.L, Q = a.Q, Qp = a.Qp;
+    const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), RQ = Q * (L + 1);
+    C *S = a.state + (size_t)b * Tp * Np;
+    const real *amp = a.amp + (size_t)b * Tp * Np;
+    const real *thr = a.thr + (size_t)b * a.n_thr;
+    const int sk = L + 1, D = Q * sk;
+    const int NT = L + (Q - 1) * (2 * L + 1);
+    const bool add_self = (a.update == 1);
+    build_terms(tt, NT, L, Np, tid, nthr);
+    for (int i = tid; i < tg.nunits; i += nthr) ui[i].act = 0;
+    __syncthreads();
+    const int G = tg.G, g = tid & (G - 1), team = tid / G;
+    const int LA = a.LA, per = a.n_thr + 1, rps = LA + 1;
+    const int slot = team / rps, j = team - slot * rps;
+    const long nsweeps = (long)T * per;
+    const long t_end = D * (nsweeps - 1) + (long)sk * (T - 1) + F;
+    long s = slot < tg.nsl ? slot : nsweeps;
+    long t0 = 0, s_end = -1;
+    int m_ext = 0, two_sided = 1, wsel = 0;
+    bool valid = false, centre = false;
+    real th = 0;
+    auto setup = [&]() __attribute__((always_inline)) {
+        valid = false;
+        if (s >= nsweeps) { s_end = t_end; return; }
+        const int m = (int)(s / per), q = (int)(s - (long)m * per);
+        s_end = D * s + (long)sk * m + F - 1;
+        int first = m - LA;
+        if (first < 0) first = 0;
+        int rho;
+        if (q == 0) { if (j != 0) return; rho = m; }
+        else { rho = first + j; if (rho > m) return; }
+        valid = true;
+        t0 = D * s + (long)sk * rho;
+        m_ext = rho + Q - 1;
+        if (q == 0) { centre = false; two_sided = 1; wsel = 1; th = 0; }
+        else {
+            int ts = m - rho + 1;
+            if (ts > Q) ts = Q;
+            centre = true; two_sided = ts; wsel = (rho == m) ? 2 : 0; th = thr[q - 1];
+        }
+    };
+    setup();
+    for (long t = 0; t < t_end; ++t) {
+        while (t > s_end) { s += tg.nsl; setup(); }
+        const long cl = t - t0;
+        const bool unit = valid && cl >= 0 && cl < F && team < tg.nunits;
+        // ---- the increments
+        if (unit) {
+            const int c = (int)cl, n = c + L;
+            const size_t idx = (size_t)m_ext * Np + n;
+            const C *ctr = S + idx;
+            const real target = amp[idx];
+            const int row = c % Qp, rowneg = (Qp - row) % Qp;
+            const WeightSet<real> ws = a.w[wsel];
+            const C *w0 = ws.w + (size_t)row * RQ, *w1 = ws.w + (size_t)rowneg * RQ;
+            const uint8_t *f0 = ws.flag + (size_t)row * RQ, *f1 = ws.flag + (size_t)rowneg * RQ;
+            C *mine = inc + (size_t)team * NTP;
+            if (g == 0) {
+                C pre; pre.x = 0; pre.y = 0;
+                if (centre && add_self) { const C s0 = ctr[0]; pre.x = s0.x / a.qdiv; pre.y = s0.y / a.qdiv; }
+                mine[0] = pre;
+                OrdUnit<real> u;
+                u.idx = (long long)idx; u.target = target; u.act = (target > th) ? 1 : 0; u.n = n; u.m_ext = m_ext; u.pad = 0;
+                ui[team] = u;
+            }
+            for (int j0 = g; j0 < NT; j0 += G * CH) {
+                C w[CH], vb[CH], vc[CH];
+                bool live[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int jj = j0 + i * G;
+                    const Term e = tt[jj < NT ? jj : 0];
+                    const int r = e.meta & 0xff, neg = (e.meta >> 8) & 1, cut = (e.meta >> 9) & 3;
+                    const bool is_centre = (e.meta >> 11) & 1;
+                    const bool both = is_centre || r < two_sided;
+                    live[i] = jj < NT && (is_centre ? centre : true) && ((neg ? f1 : f0)[e.wi] != 0);
+                    w[i] = (neg ? w1 : w0)[e.wi];
+                    const C xb = ctr[e.ob], xc = ctr[e.oc];
+                    C z; z.x = 0; z.y = 0;
+                    vb[i] = (!both && cut == 2) ? z : xb;
+                    vc[i] = (!both && cut == 1) ? z : xc;
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int jj = j0 + i * G;
+                    C v; v.x = 0; v.y = 0;
+                    pair<real>(v, w[i], vb[i], vc[i]);            // 0 + increment: the increment
+                    if (!live[i]) { v.x = 0; v.y = 0; }
+                    if (jj < NT) mine[1 + jj] = v;
+                }
+            }
+        } else if (g == 0 && team < tg.nunits) ui[team].act = 0;
+        __syncthreads();
+        // ---- one lane per bin: the sum in the reference's order, the re-projection, the write
+        if (tid < tg.nunits) {
+            const OrdUnit<real> u = ui[tid];
+            if (u.act) {
+                const C *mine = inc + (size_t)tid * NTP;
+                C acc;
+                acc.x = 0; acc.y = 0;
+                for (int jj = 0; jj <= NT; ++jj) { const C v = mine[jj]; acc.x += v.x; acc.y += v.y; }
+                const real mag = sqrt(acc.x * acc.x + acc.y * acc.y);
+                if (mag > 0) {
+                    C v;
+                    v.x = acc.x * u.target / mag;
+                    v.y = acc.y * u.target / mag;
+                    S[u.idx] = v;
+                    const int n = u.n, nyq = F + L - 1;   // Hermitian images in the pad columns (lwslib.cpp:362-367)
+                    C vc;
+                    vc.x = v.x; vc.y = -v.y;
+                    if (n >= L + 1 && n < 2 * L + 1) S[(size_t)u.m_ext * Np + 2 * L - n] = vc;
+                    else if (n >= F - 1 && n < nyq) S[(size_t)u.m_ext * Np + 2 * nyq - n] = vc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- the online driver with its moving window in LDS ------------------------------------------------------------------------
 // What bounds k_team_online is the texture path: 2 NT + NT + NT scattered loads (taps, weights, flags) per bin, 4 us a step.
 // TF_RTISI_LA touches a short window -- the sweeps in flight read extended frames m_lo - LA .. m_hi + Q - 1 -- so a ring of
@@ -536,7 +674,22 @@ RingGeom ring_geometry(const TeamGeom &tg, int F, int L, int Q, int Qp, int LA, 
     return rg;
 }
 
+// fp64 plans: the order-exact online kernel unless LWS_TEAM_FP64=1 asks for the re-associating ones; fp32 plans: with LWS_TEAM_ORDERED=1
+bool team_ordered(bool fp64) {
+    const char *eo = getenv("LWS_TEAM_ORDERED"), *ef = getenv("LWS_TEAM_FP64");
+    return fp64 ? !(ef && atoi(ef)) : (eo && atoi(eo));
+}
+
 }  // namespace
+
+bool team_online_is_ordered(bool fp64) { return team_ordered(fp64); }
+bool team_ordered_fits(int F, int T, int L, int Q, int LA, int n_thr, bool fp64) {
+    const TeamGeom tg = geometry(MODE_ONLINE, F, T, L, Q, LA, n_thr);
+    if (tg.G < 1) return false;
+    const int NT = L + (Q - 1) * (2 * L + 1), NTP = (NT + 1) | 1;
+    const size_t csz = fp64 ? 16 : 8;
+    return (size_t)NT * sizeof(Term) + (size_t)tg.nunits * NTP * csz + (size_t)tg.nunits * 32 + 64 <= 160 * 1024;
+}
 
 bool team_supports(int mode, int F, int T, int L, int Q, int Qp, int LA, int n_thr) {
     if (mode != MODE_ONLINE && mode != MODE_NOFUTURE) return false;
@@ -564,6 +717,23 @@ hipError_t launch_team(const GenericArgs<real> &a, int B, hipStream_t stream) {
     if (threads > 1024) threads = 1024;
     const int NT = a.L + (a.Q - 1) * (2 * a.L + 1);
     const size_t lds = (size_t)NT * sizeof(Term);
+    if (a.mode == MODE_ONLINE && team_ordered(sizeof(real) == 8)) {
+        // order-exact variant (fp64 plans by default; LWS_TEAM_ORDERED=1: fp32 plans too)
+        const int NTP = (NT + 1) | 1;                                  // (odd row length: the bins' chains read different banks)
+        auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+        const size_t off_inc = up16((size_t)NT * sizeof(Term)), off_unit = up16(off_inc + (size_t)tg.nunits * NTP * 2 * sizeof(real));
+        const size_t bytes = off_unit + (size_t)tg.nunits * sizeof(OrdUnit<real>);
+        if (bytes > 160 * 1024) return hipErrorInvalidValue;           // (team_supports said no)
+        static std::atomic<unsigned long long> done{0};
+        int dev;
+        if (attr_needed(done, &dev)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_team_online_ordered<real>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done(done, dev);
+        }
+        hipLaunchKernelGGL(k_team_online_ordered<real>, dim3(B), dim3(threads), bytes, stream, a, tg, (unsigned)off_inc, (unsigned)off_unit, NTP);
+        return hipGetLastError();
+    }
     if (a.mode == MODE_ONLINE) {
         const RingGeom rg = ring_geometry<real>(tg, a.F, a.L, a.Q, a.Qp, a.LA, a.n_thr);
         if (rg.bytes) {

@@ -177,17 +177,15 @@ def test_more_than_eight_frames_per_row_go_to_the_team_engine(monkeypatch):
     S = rng.standard_normal((9, 73)) + 1j * rng.standard_normal((9, 73))
     out, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0)
     assert name == "team_online_fp32"
-    monkeypatch.setenv("LWS_TEAM_FP64", "1")          # (fp64 plans: the order-exact engine unless asked)
     out64, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0, precision="fp64")
-    assert name == "team_online_fp64"
-    monkeypatch.delenv("LWS_TEAM_FP64")
+    assert name == "team_online_ordered_fp64"          # (fp64 plans: the order-exact kernel)
     monkeypatch.setenv("LWS_NO_TEAM", "1")
     gen, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0)
     assert name == "generic_fp32"
     gen64, name = _online(73, (p.W, p.W_ai, p.W_af), S, [0.5, 0.1], 3, 9.0, precision="fp64")
     assert name == "generic_fp64"
     monkeypatch.delenv("LWS_NO_TEAM")
-    assert np.abs(out64 - gen64).max() < 1e-10 * np.abs(S).max()
+    assert np.array_equal(out64, gen64)
     assert np.linalg.norm(out - gen) < 1e-3 * np.linalg.norm(gen)
     p = lws_amd.lws(64, 16, mode="music")
     S = rng.standard_normal((9, 33)) + 1j * rng.standard_normal((9, 33))

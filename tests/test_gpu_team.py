@@ -176,7 +176,8 @@ def test_the_ring_is_storage_only(precision, monkeypatch):
 
 def test_fp64_plans_of_eight_frames_per_row_take_the_team_engine(oracle, monkeypatch):
     """lws(512, 64, precision='fp64'): the fp64 LDS engine has a Q = 8 kernel (the generic engine's bits, 1.29 s for 256 x 500 x 257);
-    the team engine with its window in LDS takes 0.49 s: with LWS_TEAM_FP64=1.  Default: the LDS engine and the reference's order."""
+    the team engine's order-exact kernel gives the same bits in 0.99 s: the default; its re-associating kernel with the window in LDS
+    takes 0.49 s: with LWS_TEAM_FP64=1."""
     fsize, fshift, T, LA, iters = 512, 64, 30, 3, 3
     p, F, plan = plans(fsize, fshift, 5, precision="fp64")
     S = spectrograms(2, T, F, seed=5)
@@ -184,8 +185,12 @@ def test_fp64_plans_of_eight_frames_per_row_take_the_team_engine(oracle, monkeyp
     out = plan.online(S, thr, LA, fsize / fshift)
     assert plan.last_kernel()["name"] == "team_online_fp64"
     monkeypatch.delenv("LWS_TEAM_FP64")
+    monkeypatch.setenv("LWS_NO_TEAM_Q8", "1")
     ref = plan.online(S, thr, LA, fsize / fshift)
     assert plan.last_kernel()["name"] == "online_lds_fp64"
+    monkeypatch.delenv("LWS_NO_TEAM_Q8")
+    ordered = plan.online(S, thr, LA, fsize / fshift)
+    assert plan.last_kernel()["name"] == "team_online_ordered_fp64" and np.array_equal(ordered, ref)     # the default: the same bits
     assert np.abs(out - ref).max() < 1e-10 * np.abs(S).max()
     for b in range(2):
         o = oracle.online_lws(S[b], p.W, p.W_ai, p.W_af, thr, LA, fshift)
@@ -220,12 +225,55 @@ def test_one_lane_per_bin_gives_the_generic_engines_bits(fsize, fshift, L, T, LA
     plan.close(); gen.close()
 
 
-def test_fp64_plans_keep_the_order_exact_engine_by_default(monkeypatch):
+def test_fp64_plans_keep_the_reference_order_by_default(monkeypatch):
     monkeypatch.delenv("LWS_TEAM_FP64")
     p, F, plan = plans(256, 16, 5, precision="fp64")
     S = spectrograms(1, 12, F, seed=3)
     plan.online(S, [0.5, 0.1], 3, 16.0)
-    assert plan.last_kernel()["name"] == "generic_fp64"
+    assert plan.last_kernel()["name"] == "team_online_ordered_fp64"
     plan.nofuture(S, [0.5], wsel=1)
     assert plan.last_kernel()["name"] == "generic_fp64"
     plan.close()
+
+
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+@pytest.mark.parametrize("fsize,fshift,L,T,LA,iters", [(1024, 64, 5, 60, 3, 10), (1024, 256, 8, 80, 3, 6), (512, 56, 5, 50, 2, 4), (256, 16, 5, 70, 5, 3),
+                                                      (144, 16, 5, 9, 3, 2), (512, 64, 5, 60, 3, 5), (2048, 512, 5, 8, 3, 2)])
+def test_the_order_exact_kernel_gives_the_generic_engines_bits(fsize, fshift, L, T, LA, iters, precision, monkeypatch):
+    """k_team_online_ordered -- the increments of a bin's terms by a team of lanes, their sum by ONE lane in the reference's order: what an
+    fp64 plan's online stage runs on by default where no LDS engine applies (and an fp32 plan's with LWS_TEAM_ORDERED=1).  Must equal
+    the order-exact generic engine bit for bit, on zero-phase input (what run_lws feeds) at full recursion depth too."""
+    monkeypatch.delenv("LWS_TEAM_FP64")
+    if precision == "fp32":
+        monkeypatch.setenv("LWS_TEAM_ORDERED", "1")
+    monkeypatch.setenv("LWS_TEAM_FIRST", "1")          # (4096-point fp32 frames have an LDS engine: this kernel all the same)
+    p, F, plan = plans(fsize, fshift, L, precision=precision)
+    S = spectrograms(2, T, F, seed=fsize + 9, zero_phase=True)
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.2, 1)
+    out = plan.online(S, thr, LA, fsize / fshift)
+    assert plan.last_kernel()["name"] == "team_online_ordered_" + precision, plan.last_kernel()
+    gen = _capi.Plan(F, p.W, p.W_ai, p.W_af, precision=precision, force_generic=True)
+    ref = gen.online(S, thr, LA, fsize / fshift)
+    assert gen.last_kernel()["name"] == "generic_" + precision
+    assert np.array_equal(out, ref), np.abs(out - ref).max()
+    plan.close(); gen.close()
+
+
+def test_fp64_run_lws_of_a_sixteen_frame_row(monkeypatch):
+    """lws(256, 16, mode='music', precision='fp64').run_lws against the oracle's pipeline: the online stage on the order-exact team
+    kernel, the reference's values (1e-9 of the largest: the batch stage's band engine re-associates)."""
+    monkeypatch.delenv("LWS_TEAM_FP64")
+    p = lws_amd.lws(256, 16, mode="music", precision="fp64", online_iterations=3, batch_iterations=5)
+    rng = np.random.default_rng(4)
+    X = np.abs(rng.standard_normal((40, 129)) + 1j * rng.standard_normal((40, 129)))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = p.nofuture_lws(X)
+        assert p.plan().last_kernel()["name"] == "generic_fp64"
+        b = p.online_lws(a)
+    assert p.plan().last_kernel()["name"] == "team_online_ordered_fp64"
+    pg = lws_amd.lws(256, 16, mode="music", precision="fp64", online_iterations=3, batch_iterations=5, force_generic=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.array_equal(b, pg.online_lws(a))
