@@ -277,3 +277,27 @@ def test_fp64_run_lws_of_a_sixteen_frame_row(monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert np.array_equal(b, pg.online_lws(a))
+
+
+@pytest.mark.parametrize("fsize,fshift,L,T,LA,iters", [(128, 32, 5, 1, 1, 3), (200, 100, 10, 7, 1, 3), (36, 6, 2, 7, 6, 4), (1024, 64, 5, 12, 3, 3)])
+def test_nothing_is_read_before_it_is_written(fsize, fshift, L, T, LA, iters, monkeypatch):
+    """LWS_TEAM_DBG_POISON=1 starts the ring kernel's whole LDS allocation, and 16 KB behind it, as NaNs.  A term past the end of a
+    lane's list once took `its` weight from index 32 of the row -- past the end of the LDS copy of the weights for the last rows -- and
+    multiplied it by the row of zeros: harmless while the bytes there were finite, a NaN sum and a bin silently left unwritten when the
+    kernel before had left NaN patterns (fp64 data read as fp32).  tools/stress_team.py found it (the same three shapes of 800 each
+    time); with the poison it is deterministic: one lane per bin must still give the generic engine's bits, the production team size no NaN."""
+    p, F, plan = plans(fsize, fshift, L)
+    S = spectrograms(2, T, F, seed=fsize + 3)
+    thr = lws_amd.get_thresholds(iters, 1.0, 0.4, 1)
+    gen = _capi.Plan(F, p.W, p.W_ai, p.W_af, force_generic=True)
+    ref = gen.online(S, thr, LA, fsize / fshift)
+    gen.close()
+    monkeypatch.setenv("LWS_TEAM_FIRST", "1")
+    monkeypatch.setenv("LWS_TEAM_DBG_POISON", "1")
+    full = plan.online(S, thr, LA, fsize / fshift)
+    assert plan.last_kernel()["name"] == "team_online_fp32"
+    assert not np.isnan(full).any() and np.abs(np.abs(full) - np.abs(ref)).max() < 2e-6 * np.abs(S).max()
+    assert np.array_equal(full == S, ref == S)       # the same bins written as in the generic engine (a NaN sum leaves its bin unwritten)
+    monkeypatch.setenv("LWS_TEAM_LANES", "1")
+    assert np.array_equal(plan.online(S, thr, LA, fsize / fshift), ref)
+    plan.close()
