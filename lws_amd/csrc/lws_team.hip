@@ -673,13 +673,13 @@ RingGeom ring_geometry(const TeamGeom &tg, int F, int L, int Q, int Qp, int LA, 
     const size_t cap = 160 * 1024;
     if (off > cap) return rg;                                   // (bytes = 0)
     rg.wl = (off + wbytes <= cap) ? 1 : 0;
-    { const char *ep = getenv("LWS_TEAM_DBG_POISON"); rg.poison = (ep && atoi(ep) && rg.bytes + 16384 <= cap) ? 1 : 0; }
     if (rg.wl) {
         rg.off_w = (unsigned)off; off = up16(off + (size_t)3 * Qp * RQ * csz);
     }
     rg.bytes = (unsigned)off;
     const char *ev = getenv("LWS_TEAM_NO_RING");                // comparison runs: the state stays in memory
     if (ev && atoi(ev)) rg.bytes = 0;
+    { const char *ep = getenv("LWS_TEAM_DBG_POISON"); rg.poison = (ep && atoi(ep) && rg.bytes && rg.bytes + 16384 <= cap) ? 1 : 0; }
     return rg;
 }
 

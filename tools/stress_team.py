@@ -106,6 +106,10 @@ while done < n_cases:
             # (no bar on the values: a bin whose sum nearly cancels takes its phase from rounding, and the recursion amplifies that within the
             #  look-ahead's frames -- the bit-for-bit checks above are the test; the median difference is reported)
             meds.append(float(np.median(np.abs(out[:, :n] - ref_on[:, :n]) / scale)))
+            # ... and it must not depend on what the LDS held before: the same bits with the allocation and its tail poisoned
+            env(LWS_TEAM_FP64=1, LWS_TEAM_DBG_POISON=1)
+            again = plan.online(S, thr, LA, qdiv)
+            assert np.array_equal(again, out), ("production team size, poisoned LDS", tag, np.abs(again - out).max(), bool(np.isnan(again).any()))
         plan.close()
     done += 1
     if done % 20 == 0:
