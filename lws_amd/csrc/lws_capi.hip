@@ -368,7 +368,7 @@ int run_stage(lws_plan *p, int mode, int wsel, int B, int T, const double *thr, 
     }
     if constexpr (std::is_same<real, double>::value) {
         // online driver of an fp64 plan: the frames of the moving window in LDS, every sum in the generic engine's order (same bits)
-        // (Q = 8: three frames' pairs on the two waves' chain -- 1 296 ms for 256 x 500 x 257 against 991 on the team engine's order-exact
+        // (Q = 8: three frames' pairs on the two waves' chain -- 1 296 ms for 256 x 500 x 257 against 831 on the team engine's order-exact
         // kernel, which gives the same bits (the generic engine's): such plans go there unless LWS_NO_TEAM_Q8=1 asks for this kernel.
         // With LWS_TEAM_FP64=1: the team engine's re-associating kernel with its window in LDS, 483 ms)
         const bool q8_team = a.Q == 8 && !env_int("LWS_NO_TEAM", 0) && !env_int("LWS_NO_TEAM_Q8", 0) && !env_int("LWS_ONLINE_SERIAL_TAPS", 0) &&

@@ -92,7 +92,8 @@ __device__ __forceinline__ void team_bin(typename cx<real>::type *S, const real 
         target = amp[idx];
         const int row = c % Qp, rowneg = (Qp - row) % Qp;
         const C *w0 = ws.w + (size_t)row * RQ, *w1 = ws.w + (size_t)rowneg * RQ;
-        const uint8_t *f0 = ws.flag + (size_t)row * RQ, *f1 = ws.flag + (size_t)rowneg * RQ;
+        // (no flag reads: the device copy of a tensor holds exact zeros where the reference skips a weight, |w| <= 1e-12 -- lws_capi.hip:
+        //  upload_weights -- and a zero weight adds 0 (b +- c) = +-0 to a sum that is never -0: the same value as skipping)
         if (g == 0 && centre && add_self) { const C s0 = ctr[0]; a.x += s0.x / qdiv; a.y += s0.y / qdiv; }
         for (int j0 = g; j0 < NT; j0 += G * CH) {
             C w[CH], vb[CH], vc[CH];
@@ -108,7 +109,7 @@ __device__ __forceinline__ void team_bin(typename cx<real>::type *S, const real 
                 const int r = e.meta & 0xff, neg = (e.meta >> 8) & 1, cut = (e.meta >> 9) & 3;
                 const bool is_centre = (e.meta >> 11) & 1, none = (e.meta >> 12) & 1;
                 const bool both = is_centre || r < two_sided;
-                live[i] = !none && (is_centre ? centre : true) && ((neg ? f1 : f0)[e.wi] != 0);
+                live[i] = !none && (is_centre ? centre : true);
                 w[i] = (neg ? w1 : w0)[e.wi];
                 const C xb = ctr[e.ob], xc = ctr[e.oc];   // (always inside the extended buffer: Q - 1 pad frames, L pad columns)
                 C z; z.x = 0; z.y = 0;
@@ -283,7 +284,6 @@ __global__ void __launch_bounds__(1024) k_team_online_ordered(GenericArgs<real> 
             const int row = c % Qp, rowneg = (Qp - row) % Qp;
             const WeightSet<real> ws = a.w[wsel];
             const C *w0 = ws.w + (size_t)row * RQ, *w1 = ws.w + (size_t)rowneg * RQ;
-            const uint8_t *f0 = ws.flag + (size_t)row * RQ, *f1 = ws.flag + (size_t)rowneg * RQ;
             C *mine = inc + (size_t)team * NTP;
             if (g == 0) {
                 C pre; pre.x = 0; pre.y = 0;
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(1024) k_team_online_ordered(GenericArgs<real> 
                     const int r = e.meta & 0xff, neg = (e.meta >> 8) & 1, cut = (e.meta >> 9) & 3;
                     const bool is_centre = (e.meta >> 11) & 1;
                     const bool both = is_centre || r < two_sided;
-                    live[i] = jj < NT && (is_centre ? centre : true) && ((neg ? f1 : f0)[e.wi] != 0);
+                    live[i] = jj < NT && (is_centre ? centre : true);   // (a weight the reference skips is an exact zero in the device copy)
                     w[i] = (neg ? w1 : w0)[e.wi];
                     const C xb = ctr[e.ob], xc = ctr[e.oc];
                     C z; z.x = 0; z.y = 0;
@@ -400,13 +400,11 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
     build_terms_ring(tt, NT, L, tid, nthr);
     for (int i = tid; i < Np; i += nthr) { C z; z.x = 0; z.y = 0; ring[NWR * Np + i] = z; }
     if constexpr (WL) {
-        // A weight without a flag (|w| <= 1e-12, lws.pyx:227-232) is skipped by the reference; as a zero it adds w b = 0 to a finite
-        // sum: the same value.
+        // A weight without a flag (|w| <= 1e-12, lws.pyx:227-232) is skipped by the reference; the device copy holds an exact zero there
+        // (upload_weights), which adds w b = 0 to a finite sum: the same value.
         for (int set = 0; set < 3; ++set)
             for (int i = tid; i < Qp * RQ; i += nthr) {
-                C w = a.w[set].w[i];
-                if (a.w[set].flag[i] == 0) { w.x = 0; w.y = 0; }
-                wl[set * Qp * RQ + i] = w;
+                wl[set * Qp * RQ + i] = a.w[set].w[i];
             }
     }
     // ---- the ring: extended frame e lives in row e mod NWR (targets: e mod NWA); frames [0, loaded) have been brought in
@@ -507,7 +505,6 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
             const int rowneg = row == 0 ? 0 : Qp - row;
             const int d0 = (WL ? wsel * Qp + row : row) * RQ, dn = (rowneg - row) * RQ;   // weight rows: d0, d0 + dn
             const C *wg = WL ? nullptr : a.w[wsel].w;
-            const uint8_t *fg = WL ? nullptr : a.w[wsel].flag;
             if (g == 0 && centre && add_self) { const C s0 = ring[em * Np + n]; acc.x += s0.x / a.qdiv; acc.y += s0.y / a.qdiv; }
             auto chunk = [&](auto off_c, const auto &ob, const auto &oc, const auto &w_n) {   // (arrays by reference, constant indices: registers)
                 constexpr int O = decltype(off_c)::value;
@@ -518,7 +515,6 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
                     if constexpr (WL) w[i] = wl[wo];
                     else {
                         w[i] = wg[wo];
-                        if (fg[wo] == 0) { w[i].x = 0; w[i].y = 0; }
                     }
                     vb[i] = ring[ob[O + i] + n];
                     vc[i] = ring[oc[O + i] + n];
