@@ -16,6 +16,12 @@
 // LDS table: element offsets of b and c from the bin, index of the weight in its row, which of the two rows (c mod Qp or its
 // negative) it comes from, frame distance.  `mac` and `macc` of the generic engine are the same statement with c = 0 / b = 0
 // (x + 0 and x - 0 are exact), so one body serves every term.
+//
+// Three kernels for the online driver: k_team_online_ring (fp32 plans: the moving window, targets and weights in LDS; placement of a
+// lane's terms per sweep), k_team_online (the same sums with the state in memory, when the ring does not fit), and
+// k_team_online_ordered (fp64 plans: the increments by the team, the sum by ONE lane in the reference's order -- the generic
+// engine's bits).  k_team_sweeps: no-future sweeps.  Pins: LWS_TEAM_LANES=1 makes every kernel add in the generic engine's order (its
+// bits); tools/stress_team.py compares random shapes bit for bit; LWS_TEAM_DBG_POISON=1 starts the ring kernel's LDS as NaNs.
 #include "lws_team.h"
 
 #include <cstdlib>
@@ -348,12 +354,12 @@ __global__ void __launch_bounds__(1024) k_team_online_ordered(GenericArgs<real> 
 }
 
 // ---- the online driver with its moving window in LDS ------------------------------------------------------------------------
-// What bounds k_team_online is the texture path: 2 NT + NT + NT scattered loads (taps, weights, flags) per bin, 4 us a step.
+// What bounds k_team_online is the texture path: 2 NT + NT scattered loads (taps, weights) per bin, 4 us a step.
 // TF_RTISI_LA touches a short window -- the sweeps in flight read extended frames m_lo - LA .. m_hi + Q - 1 -- so a ring of
 // NWR = Q + LA + DM extended frames (DM: how far apart the online frames of the sweeps in flight can be) is kept in LDS together
-// with the target magnitudes of the frames that can still change, the three weight tensors and their flags (summarised tensors;
-// general ones stay in memory): HBM sees a frame once on its way in and once on its way out, a step's loads are LDS reads.
-struct RingGeom { int NWR, NWA, DM, wl; unsigned off_ring, off_amp, off_w, off_f, bytes; int poison; };
+// with the target magnitudes of the frames that can still change, and the three weight tensors (summarised ones;
+// general tensors stay in memory): HBM sees a frame once on its way in and once on its way out, a step's loads are LDS reads.
+struct RingGeom { int NWR, NWA, DM, wl; unsigned off_ring, off_amp, off_w, bytes; int poison; };
 
 // a term of the ring kernel in one word: r | negrow << 8 | (what !both removes) << 9 | centre << 11 | none << 12 | (dk + 32) << 13,
 // dk the column offset of b (c: the same column, the mirrored one for the centre frame); the weight index is r (L+1) + |dk|
@@ -380,7 +386,7 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
     int *tt = reinterpret_cast<int *>(tsm);
     C *ring = reinterpret_cast<C *>(tsm + rg.off_ring);        // NWR frames and one row of zeros (what a term that does not take part reads)
     real *ampr = reinterpret_cast<real *>(tsm + rg.off_amp);
-    C *wl = reinterpret_cast<C *>(tsm + rg.off_w);             // WL: the three tensors, entries without a flag as zeros
+    C *wl = reinterpret_cast<C *>(tsm + rg.off_w);             // WL: the three tensors (exact zeros where the reference skips a weight)
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int F = a.F, T = a.T, L = a.L, Q = a.Q, Qp = a.Qp;
     const int Np = F + 2 * L, Tp = T + 2 * (Q - 1), RQ = Q * (L + 1);
