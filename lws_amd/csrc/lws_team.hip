@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(1024) k_team_online_ordered(GenericArgs<real> 
 // NWR = Q + LA + DM extended frames (DM: how far apart the online frames of the sweeps in flight can be) is kept in LDS together
 // with the target magnitudes of the frames that can still change, and the three weight tensors (summarised ones;
 // general tensors stay in memory): HBM sees a frame once on its way in and once on its way out, a step's loads are LDS reads.
-struct RingGeom { int NWR, NWA, DM, wl; unsigned off_ring, off_amp, off_w, bytes; int poison; };
+struct RingGeom { int NWR, NWA, DM, wl; unsigned off_ring, off_amp, off_w, bytes; int poison, fits; };
 
 // a term of the ring kernel in one word: r | negrow << 8 | (what !both removes) << 9 | centre << 11 | none << 12 | (dk + 32) << 13,
 // dk the column offset of b (c: the same column, the mirrored one for the centre frame); the weight index is r (L+1) + |dk|
@@ -679,6 +679,7 @@ RingGeom ring_geometry(const TeamGeom &tg, int F, int L, int Q, int Qp, int LA, 
         rg.off_w = (unsigned)off; off = up16(off + (size_t)3 * Qp * RQ * csz);
     }
     rg.bytes = (unsigned)off;
+    rg.fits = 1;                                                // (... whether or not LWS_TEAM_NO_RING sends the call to the other kernel)
     const char *ev = getenv("LWS_TEAM_NO_RING");                // comparison runs: the state stays in memory
     if (ev && atoi(ev)) rg.bytes = 0;
     { const char *ep = getenv("LWS_TEAM_DBG_POISON"); rg.poison = (ep && atoi(ep) && rg.bytes && rg.bytes + 16384 <= cap) ? 1 : 0; }
@@ -722,7 +723,7 @@ int team_lanes(int mode, int F, int T, int L, int Q, int LA, int n_thr) { return
 template <typename real>
 hipError_t launch_team(const GenericArgs<real> &a, int B, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
-    const TeamGeom tg = geometry(a.mode, a.F, a.T, a.L, a.Q, a.LA, a.n_thr);
+    TeamGeom tg = geometry(a.mode, a.F, a.T, a.L, a.Q, a.LA, a.n_thr);
     if (tg.G < 1) return hipErrorInvalidValue;
     int threads = ((tg.nunits * tg.G + 63) / 64) * 64;
     if (threads > 1024) threads = 1024;
@@ -747,6 +748,19 @@ hipError_t launch_team(const GenericArgs<real> &a, int B, hipStream_t stream) {
     }
     if (a.mode == MODE_ONLINE) {
         const RingGeom rg = ring_geometry<real>(tg, a.F, a.L, a.Q, a.Qp, a.LA, a.n_thr);
+        // Fewer, fatter teams: what a step costs beside the taps -- schedule bookkeeping, the team sum, the barrier -- is per WAVE, so
+        // the ring kernel wants the smallest team whose lanes keep all their terms' placement in registers (8 terms in fp32, 4 in
+        // fp64), not the largest the workgroup has room for: lws(1024,256,L=8) 366 -> 298 ms with 8 lanes a bin instead of 16.  (The
+        // kernel that leaves the state in memory runs with the same teams when it stands in for the ring kernel: same bits.)
+        if (rg.fits && !getenv("LWS_TEAM_LANES")) {
+            const int nc = sizeof(real) == 8 ? 4 : 8;
+            int gp = 1;
+            while (gp * nc < NT) gp *= 2;
+            if (gp < tg.G) {
+                tg.G = gp;
+                threads = ((tg.nunits * tg.G + 63) / 64) * 64;
+            }
+        }
         if (rg.bytes) {
             auto launch = [&](auto kern) {
                 static std::atomic<unsigned long long> done{0};
