@@ -378,8 +378,10 @@ __device__ __forceinline__ void build_terms_ring(int *tt, int NT, int L, int tid
     }
 }
 
-template <typename real, bool WL>
-__global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, TeamGeom tg, RingGeom rg) {
+// NCH: chunks of four terms whose placement a lane keeps in registers -- two, or three in a workgroup of at most 512 threads (twice the
+// registers per lane): sixteen lanes a bin instead of thirty-two at hop = frame/16
+template <typename real, bool WL, int NCH>
+__global__ void __launch_bounds__(NCH == 3 ? 512 : 1024) k_team_online_ring(GenericArgs<real> a, TeamGeom tg, RingGeom rg) {
     using C = typename cx<real>::type;
     constexpr int CH = 4;   // terms of a lane in flight together (LDS round trips are short: small chunks, few registers)
     extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
     while (loaded <= Q - 1 && loaded <= e_last) bring();       // the pad frames on the left and frame 0
     __syncthreads();
     const int G = tg.G, g = tid & (G - 1), team = tid / G;
-    constexpr int NC = sizeof(real) == 8 ? CH : 2 * CH;        // terms of a lane whose placement is kept in registers (fp32: two chunks)
+    constexpr int NC = sizeof(real) == 8 ? CH : NCH * CH;      // terms of a lane whose placement is kept in registers (fp32: two or three chunks)
     int lt[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) { const int jj = g + i * G; lt[i] = jj < NT ? tt[jj] : (1 << 12); }
@@ -529,7 +531,8 @@ __global__ void __launch_bounds__(1024) k_team_online_ring(GenericArgs<real> a, 
                 for (int i = 0; i < CH; ++i) pair<real>(acc, w[i], vb[i], vc[i]);
             };
             chunk(std::integral_constant<int, 0>{}, rb, rc, wn);
-            if constexpr (NC > CH) { if (two_chunks) chunk(std::integral_constant<int, NC - CH>{}, rb, rc, wn); }
+            if constexpr (NC > CH) { if (two_chunks) chunk(std::integral_constant<int, CH>{}, rb, rc, wn); }
+            if constexpr (NC > 2 * CH) { if (g + 2 * CH * G < NT) chunk(std::integral_constant<int, 2 * CH>{}, rb, rc, wn); }
             for (int j0 = g + G * NC; j0 < NT; j0 += G * CH) {   // further chunks (thin teams): their terms from the table
                 int ob[CH], oc[CH], w_n[CH];
 #pragma unroll
@@ -752,15 +755,20 @@ hipError_t launch_team(const GenericArgs<real> &a, int B, hipStream_t stream) {
         // the ring kernel wants the smallest team whose lanes keep all their terms' placement in registers (8 terms in fp32, 4 in
         // fp64), not the largest the workgroup has room for: lws(1024,256,L=8) 366 -> 298 ms with 8 lanes a bin instead of 16.  (The
         // kernel that leaves the state in memory runs with the same teams when it stands in for the ring kernel: same bits.)
+        int nch = 2;
         if (rg.fits && !getenv("LWS_TEAM_LANES")) {
-            const int nc = sizeof(real) == 8 ? 4 : 8;
-            int gp = 1;
-            while (gp * nc < NT) gp *= 2;
+            auto smallest = [&](int nc) { int gp = 1; while (gp * nc < NT) gp *= 2; return gp; };
+            int gp = smallest(sizeof(real) == 8 ? 4 : 8);
+            if (sizeof(real) == 4 && !getenv("LWS_TEAM_NO_NCH3")) {            // (fp32: three chunks in registers if that halves the team
+                const int g3 = smallest(12);                                      //  and the workgroup stays within 512 threads)
+                if (g3 < gp && g3 <= tg.G && tg.nunits * g3 <= 512) { gp = g3; nch = 3; }
+            }
             if (gp < tg.G) {
                 tg.G = gp;
                 threads = ((tg.nunits * tg.G + 63) / 64) * 64;
-            }
+            } else nch = 2;
         }
+        { const char *e3 = getenv("LWS_TEAM_NCH3"); if (e3 && atoi(e3) && rg.fits && threads <= 512) nch = 3; }   // (tests: the three-chunk kernel whatever the team)
         if (rg.bytes) {
             auto launch = [&](auto kern) {
                 static std::atomic<unsigned long long> done{0};
@@ -773,7 +781,8 @@ hipError_t launch_team(const GenericArgs<real> &a, int B, hipStream_t stream) {
                 hipLaunchKernelGGL(kern, dim3(B), dim3(threads), rg.bytes + (rg.poison ? 16384 : 0), stream, a, tg, rg);
                 return hipGetLastError();
             };
-            return rg.wl ? launch(&k_team_online_ring<real, true>) : launch(&k_team_online_ring<real, false>);
+            if (nch == 3) return rg.wl ? launch(&k_team_online_ring<real, true, 3>) : launch(&k_team_online_ring<real, false, 3>);
+            return rg.wl ? launch(&k_team_online_ring<real, true, 2>) : launch(&k_team_online_ring<real, false, 2>);
         }
         hipLaunchKernelGGL(k_team_online<real>, dim3(B), dim3(threads), lds, stream, a, tg);
     } else hipLaunchKernelGGL(k_team_sweeps<real>, dim3(B), dim3(threads), lds, stream, a, tg);

@@ -18,7 +18,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 
 
 def env(**kw):
-    for k in ("LWS_TEAM_LANES", "LWS_TEAM_NO_RING", "LWS_TEAM_FP64", "LWS_TEAM_ORDERED", "LWS_TEAM_DBG_POISON"):
+    for k in ("LWS_TEAM_LANES", "LWS_TEAM_NO_RING", "LWS_TEAM_FP64", "LWS_TEAM_ORDERED", "LWS_TEAM_DBG_POISON", "LWS_TEAM_NCH3"):
         os.environ.pop(k, None)
     for k, v in kw.items():
         os.environ[k] = str(v)
@@ -73,7 +73,7 @@ while done < n_cases:
         if name.startswith("team_online_ordered"):
             assert np.array_equal(out, ref_on), ("ordered", tag, np.abs(out - ref_on).max())
         # one lane per bin on the re-associating kernels: window in LDS, in memory; no-future
-        for kw in (dict(LWS_TEAM_LANES=1, LWS_TEAM_FP64=1), dict(LWS_TEAM_LANES=1, LWS_TEAM_FP64=1, LWS_TEAM_NO_RING=1)):
+        for kw in (dict(LWS_TEAM_LANES=1, LWS_TEAM_FP64=1), dict(LWS_TEAM_LANES=1, LWS_TEAM_FP64=1, LWS_TEAM_NCH3=1), dict(LWS_TEAM_LANES=1, LWS_TEAM_FP64=1, LWS_TEAM_NO_RING=1)):
             env(**kw)
             out = plan.online(S, thr, LA, qdiv)
             name = plan.last_kernel()["name"]
